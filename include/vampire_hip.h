@@ -1,0 +1,216 @@
+/*
+ * vampire_hip.h -- C ABI of the MI355X (gfx950) lift + volume-render hot path.
+ *
+ * The reference (cskkxjk/Vampire) has no native code and no FFI: its hot path is
+ * Python calling PyTorch aten ops.  Each entry point below therefore names the
+ * reference *Python call site* it replaces (paths relative to the reference
+ * repository root; "bv2" = src/layers/backbones/base_vampire2.py).  A Python host
+ * binds these with ctypes; nothing here depends on torch.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its name ends in _host;
+ *  - tensors are dense, row-major, fp32 unless a desc field says otherwise;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
+ *    enqueued asynchronously on it, no call synchronises or allocates;
+ *  - inputs are borrowed for the duration of the enqueued work, outputs are fully
+ *    overwritten unless documented as accumulated;
+ *  - return value: 0 on success, a negative VAMP_E* code otherwise;
+ *    vamp_last_error() gives a thread-local message.
+ */
+#ifndef VAMPIRE_HIP_H_
+#define VAMPIRE_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VAMP_ABI_VERSION 1
+
+enum {
+  VAMP_OK = 0,
+  VAMP_EINVAL = -1,  /* bad descriptor / null pointer / unsupported shape */
+  VAMP_ENOSPC = -2,  /* workspace too small */
+  VAMP_EHIP = -3     /* a HIP runtime call failed (launch error) */
+};
+
+enum { VAMP_F32 = 0, VAMP_BF16 = 1 };
+enum { VAMP_DENSITY_SIGMOID = 0, VAMP_DENSITY_SDF_LAPLACE = 1 };
+
+int vamp_abi_version(void);
+const char* vamp_last_error(void);
+
+/* ------------------------------------------------------------------------- *
+ * LIFT: voxel <- mean over cameras of trilinear samples of depth (x) feat.
+ * Replaces bv2:550-553 (outer product), bv2:351-388 (get_pixel) and
+ * bv2:483-516 (get_voxel_feats); with use_depth = 0 it is the D == 1 variant of
+ * src/layers/backbones/base_bilinear.py:471-519.
+ * ------------------------------------------------------------------------- */
+typedef struct VampLiftDesc {
+  int32_t B, N;        /* samples, cameras per sample                          */
+  int32_t C;           /* feature channels (mid_channels), multiple of 4, <= 64 */
+  int32_t D, fH, fW;   /* depth planes and feature-map size                    */
+  int32_t Z, Y, X;     /* voxel grid, output is [B, C, Z, Y, X]                */
+  float u_max, v_max;  /* final_dim[1] - 0.5, final_dim[0] - 0.5  (bv2:494-495) */
+  float u_div, v_div;  /* final_dim[1] - 1,   final_dim[0] - 1    (bv2:499-500) */
+  float d_lo, d_hi;    /* d_bound[0], d_bound[1]                  (bv2:496)     */
+  float d_span;        /* (float)(d_bound[1] - d_bound[0])        (bv2:501)     */
+  int32_t use_depth;   /* 1: depth-distribution lift; 0: bilinear (z > 0) lift  */
+  int32_t in_dtype;    /* VAMP_F32 or VAMP_BF16 for `depth` and `feat`          */
+} VampLiftDesc;
+
+/* Bytes of scratch vamp_lift_forward / vamp_lift_backward need in `workspace`. */
+size_t vamp_lift_workspace_bytes(const VampLiftDesc* d);
+
+/*
+ * mats   [B, N, 3, 4, 4]  inv(bda), intrin @ inv(sensor2ego), ida   (bv2:370-387)
+ * xs,ys,zs                voxel-centre coordinates along each axis  (bv2:273-293)
+ * depth  [B, N, D, fH, fW]  depth distribution (ignored when use_depth == 0)
+ * feat   [B, N, C, fH, fW]
+ * out    [B, C, Z, Y, X]
+ * hits   [B, Z, Y, X, ceil(C/16)] u64, 4 bits per channel = number of cameras
+ *        with a non-zero sample (bv2:509-512); may be NULL when no backward follows.
+ */
+int vamp_lift_forward(const VampLiftDesc* d, const float* mats, const float* xs,
+                      const float* ys, const float* zs, const void* depth,
+                      const void* feat, float* out, uint64_t* hits,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Backward of vamp_lift_forward w.r.t. depth and feat (autograd of bv2:507-514,
+ * i.e. grid_sampler_3d_backward + the mean).  grad_depth / grad_feat are fp32 and
+ * fully overwritten.  grad_depth may be NULL when use_depth == 0.
+ */
+int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs,
+                       const float* ys, const float* zs, const void* depth,
+                       const void* feat, const float* grad_out, const uint64_t* hits,
+                       float* grad_depth, float* grad_feat, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/*
+ * Signature-compatible path for get_voxel_feats(frustum_feats, ...) (bv2:483):
+ * gathers from the materialised [B, N, C, D, fH, fW] fp32 tensor.
+ */
+int vamp_lift_forward_dense(const VampLiftDesc* d, const float* mats, const float* xs,
+                            const float* ys, const float* zs, const float* frustum_feats,
+                            float* out, uint64_t* hits, void* stream);
+/* grad_frustum_feats [B, N, C, D, fH, fW] must be zero-filled by the caller; it is
+ * accumulated into with atomics. */
+int vamp_lift_backward_dense(const VampLiftDesc* d, const float* mats, const float* xs,
+                             const float* ys, const float* zs, const float* grad_out,
+                             const uint64_t* hits, float* grad_frustum_feats, void* stream);
+
+/*
+ * Diagnostics for the "voxel indices bit-exact" contract: the validity mask
+ * (bv2:494-497) and floor-corner taps of the lift's trilinear sample, per
+ * (b, n, z, y, x).  Shares the projection code with the lift kernels.
+ */
+int vamp_lift_indices(const VampLiftDesc* d, const float* mats, const float* xs,
+                      const float* ys, const float* zs, uint8_t* valid, int16_t* ix0,
+                      int16_t* iy0, int16_t* iz0, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * RENDER: volume_rendering_from_multiple_views (bv2:391-467) with the density
+ * activation of src/utils/render_utils.py:30-46 (or nn.Sigmoid, bv2:191-194)
+ * fused in.
+ * ------------------------------------------------------------------------- */
+typedef struct VampRenderDesc {
+  int32_t B, N;          /* samples, cameras                                     */
+  int32_t D, fH, fW;     /* frustum planes (D - 1 samples per ray), map size     */
+  int32_t K;             /* semantic classes                                     */
+  int32_t C;             /* base (voxel_features) channels, BEV branch only      */
+  int32_t Z, Y, X;       /* seg volume [B, c, Z, Y, X]                           */
+  int32_t oZ, oY, oX;    /* det grid sampled by the BEV branch                   */
+  float lo[3];           /* (x, y, z)_bound_seg[0]                   (bv2:397)   */
+  float span[3];         /* (float)(bound[1] - bound[0])             (bv2:399)   */
+  float d_far;           /* d_bound[1], background depth             (bv2:436)   */
+  float z_step_det;      /* z_bound_det[2], BEV delta                (bv2:451)   */
+  int32_t density_mode;  /* VAMP_DENSITY_*                                       */
+  float sdf_bias;        /* ModifyLaplaceDensity.bias                            */
+  float beta_min;        /* ModifyLaplaceDensity.beta_min (1e-4)                 */
+  int32_t cat_seg;       /* voxel_output = cat(base, seg)            (bv2:449)   */
+  int32_t in_dtype;      /* VAMP_F32 or VAMP_BF16 for the four volumes           */
+} VampRenderDesc;
+
+size_t vamp_render_workspace_bytes(const VampRenderDesc* d);
+
+/*
+ * Camera branch, forward (bv2:396-407, 419-440 and the nan_to_num of bv2:612).
+ *   geom        [B, N, D, fH, fW, 3] ego-frame frustum points, or NULL to have the
+ *               kernel evaluate get_geometry (bv2:314-349) itself from:
+ *   mats        [B, N, 3, 4, 4]  inv(ida), sensor2ego @ inv(intrin), bda
+ *   us[fW], vs[fH], ds[D]        frustum axes (bv2:253-271)
+ *   mids        [D - 1]          camera_mids (bv2:243-246)
+ *   beta        device pointer to the raw learnable beta (ignored for sigmoid)
+ *   density_feature [B,1,Z,Y,X], semantic [B,K,Z,Y,X], rgb [B,3,Z,Y,X]
+ * outputs: rgb_out [B,N,3,fH,fW], seg_out [B,N,K,fH,fW], depth_out [B,N,1,fH,fW]
+ */
+int vamp_render_camera_forward(const VampRenderDesc* d, const float* geom, const float* mats,
+                               const float* us, const float* vs, const float* ds,
+                               const float* mids, const float* beta,
+                               const void* density_feature, const void* semantic,
+                               const void* rgb, float* rgb_out, float* seg_out,
+                               float* depth_out, void* workspace, size_t workspace_bytes,
+                               void* stream);
+
+/*
+ * Camera branch, backward.  g_* are the upstream gradients of the three outputs
+ * (any may be NULL = zero).  grad_density_feature / grad_semantic / grad_rgb are
+ * fp32 [B,c,Z,Y,X], fully overwritten.  grad_beta (1 float) is ACCUMULATED into.
+ */
+int vamp_render_camera_backward(const VampRenderDesc* d, const float* geom, const float* mats,
+                                const float* us, const float* vs, const float* ds,
+                                const float* mids, const float* beta,
+                                const void* density_feature, const void* semantic,
+                                const void* rgb, const float* g_rgb, const float* g_seg,
+                                const float* g_depth, float* grad_density_feature,
+                                float* grad_semantic, float* grad_rgb, float* grad_beta,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * BEV (top-down) branch, forward (bv2:408-418, 442-461).
+ *   oxs[oX], oys[oY], ozs[oZ]  det-grid centres (bv2:160), bev_mids [oZ] (bv2:248-251)
+ *   base [B,C,Z,Y,X]
+ * outputs: bev_rgb [B,3,oY,oX], bev_seg [B,K,oY,oX], bev_height [B,1,oY,oX],
+ *          voxel_density [B,1,oZ,oY,oX], voxel_output [B,C(+K),oZ,oY,oX]
+ */
+int vamp_render_bev_forward(const VampRenderDesc* d, const float* oxs, const float* oys,
+                            const float* ozs, const float* bev_mids, const float* beta,
+                            const void* density_feature, const void* semantic,
+                            const void* rgb, const void* base, float* bev_rgb,
+                            float* bev_seg, float* bev_height, float* voxel_density,
+                            float* voxel_output, void* stream);
+
+/*
+ * BEV branch, backward.  The four volume gradients are ACCUMULATED into (so that
+ * the camera-branch backward can run first into the same buffers); grad_base is
+ * written only by this call and must be zero-filled (or hold a running sum).
+ */
+int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const float* oys,
+                             const float* ozs, const float* bev_mids, const float* beta,
+                             const void* density_feature, const void* semantic,
+                             const void* rgb, const void* base, const float* g_bev_rgb,
+                             const float* g_bev_seg, const float* g_bev_height,
+                             const float* g_voxel_density, const float* g_voxel_output,
+                             float* grad_density_feature, float* grad_semantic,
+                             float* grad_rgb, float* grad_base, float* grad_beta,
+                             void* stream);
+
+/*
+ * Diagnostics: inside-mask (bv2:405-407) and floor taps of the camera branch's
+ * trilinear sample per (b, n, d < D-1, h, w); geometry as in the forward.
+ */
+int vamp_render_indices(const VampRenderDesc* d, const float* geom, const float* mats,
+                        const float* us, const float* vs, const float* ds, uint8_t* inside,
+                        int16_t* ix0, int16_t* iy0, int16_t* iz0, void* stream);
+
+/* get_geometry (bv2:314-349) + nan_to_num(-1e3) (bv2:612): geom [B,N,D,fH,fW,3]. */
+int vamp_frustum_geometry(const VampRenderDesc* d, const float* mats, const float* us,
+                          const float* vs, const float* ds, float* geom, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAMPIRE_HIP_H_ */

@@ -1,0 +1,34 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    """Load a committed fixture as a dict of torch tensors."""
+    with np.load(os.path.join(GOLDEN, name)) as z:
+        return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def tiny_common():
+    return load_golden("tiny_common.npz")
+
+
+RENDER_VARIANTS = [("sdf", False), ("sdf", True), ("naive", False), ("naive", True)]
+
+
+def render_fixture_name(mode, cat_seg):
+    return f"tiny_render_{mode}_{'catseg' if cat_seg else 'plain'}.npz"

@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING THE REFERENCE in the build container.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz, *.json
+
+The reference (/root/reference, pure Python on torch) is imported on CPU with
+stub modules for its absent third-party imports (mmdet, mmdet3d, cv2,
+torchvision -- none of which is touched by the hot-path methods we call).
+Only *data* leaves this script: seeded inputs and the reference's outputs.
+/root/reference does not exist on the GPU box; nothing under tests/ reads it at
+test time -- tests read the committed fixtures.
+
+Fixtures
+  tiny_common.npz      CFG_TINY inputs, geometry (get_geometry/get_pixel), lift output,
+                       tap indices + masks, lift input-gradients for a fixed upstream grad
+  tiny_render_<mode>_<plain|catseg>.npz
+                       the 8 render outputs, fixed upstream grads, input/beta gradients
+  tiny_bilinear.npz    D==1 lift variant (BaseBiLinear.get_voxel_feats)
+  full_checksums.json  per-tensor (sum, abs-sum, max, sha256 of index tensors)
+                       for cfg-A and cfg-B at B=1 with the synthetic rig
+"""
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+REF = "/root/reference"
+
+
+def import_reference():
+    """Import the reference backbones with stubs for absent packages."""
+    from torch import nn
+
+    class _Dummy(nn.Module):
+        def init_weights(self):
+            pass
+
+        def forward(self, x):
+            return x
+
+    def _mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    _mod("mmdet3d")
+    _mod("mmdet3d.models", build_neck=lambda cfg: _Dummy())
+    _mod("mmdet")
+    _mod("mmdet.models", build_backbone=lambda cfg: _Dummy())
+    _mod("cv2", COLORMAP_JET=2)
+    tv = _mod("torchvision")
+    tv.transforms = _mod("torchvision.transforms")
+    import matplotlib
+    matplotlib.use("Agg")
+    sys.path.insert(0, REF)
+    from src.layers.backbones.base_vampire2 import BaseVAMPIRE2
+    from src.layers.backbones.base_bilinear import BaseBiLinear
+    return BaseVAMPIRE2, BaseBiLinear
+
+
+def ref_module(cls, cfg, density_mode, cat_seg):
+    torch.manual_seed(0)
+    m = cls(x_bound_seg=list(cfg.x_bound_seg), y_bound_seg=list(cfg.y_bound_seg),
+            z_bound_seg=list(cfg.z_bound_seg), x_bound_det=list(cfg.x_bound_det),
+            y_bound_det=list(cfg.y_bound_det), z_bound_det=list(cfg.z_bound_det),
+            d_bound=list(cfg.d_bound), final_dim=tuple(cfg.final_dim),
+            downsample_factor=cfg.downsample_factor, upsample_factor=cfg.downsample_factor,
+            mid_channels=cfg.mid_channels, output_channels=80,
+            img_backbone_conf=dict(), img_neck_conf=dict(out_channels=[8] * 4),
+            num_classes=cfg.num_classes, density_mode=density_mode, sdf_bias=cfg.sdf_bias,
+            cat_pos=False, cat_seg=cat_seg)
+    return m.eval()
+
+
+def tiny_rig(cfg, batch):
+    """A rig sized for CFG_TINY's 32x88 image and +-6.4 m grid.
+
+    Camera 5 is pushed forward and pitched so that part of its frustum lies
+    behind/outside every bound (exercises clamp(min=1e-6), the +-2 clamp,
+    nan_to_num and both masks).
+    """
+    from vampire_amd import synthetic
+    s2e, K, ida = synthetic.camera_rig(cfg, batch, src_hw=(64, 176), focal=60.0,
+                                       centre=(88.0, 34.0), jitter=3.0, seed=7)
+    s2e[:, :, :3, 3] *= 0.3                       # pull the ring inside the small grid
+    a = np.deg2rad(35.0)
+    pitch = torch.tensor([[1, 0, 0, 0], [0, np.cos(a), -np.sin(a), 0],
+                          [0, np.sin(a), np.cos(a), 0], [0, 0, 0, 1]], dtype=torch.float32)
+    s2e[:, 5] = s2e[:, 5] @ pitch
+    s2e[:, 5, 0, 3] += 5.0
+    return s2e, K, ida
+
+
+def stat(t):
+    t = t.detach().double()
+    return dict(sum=float(t.sum()), abs_sum=float(t.abs().sum()), max=float(t.max()),
+                min=float(t.min()), shape=list(t.shape))
+
+
+def sha(t):
+    return hashlib.sha256(np.ascontiguousarray(t.detach().cpu().numpy()).tobytes()).hexdigest()
+
+
+def make_tiny(BaseVAMPIRE2, BaseBiLinear):
+    from vampire_amd.config import CFG_TINY as cfg
+    from vampire_amd import synthetic
+    from oracle import aten_oracle as O
+    B = 2
+    s2e, K, ida = tiny_rig(cfg, B)
+    bda = torch.cat([synthetic.bda_matrix(1), synthetic.bda_matrix(1, rot_deg=10.0, scale=1.05,
+                                                                     flip_dx=True)], 0)
+    depth, feat = synthetic.lift_inputs(cfg, B, seed=11)
+    # exact zeros in one feature channel exercise the per-channel hit count (Q4)
+    feat[:, :, 1, :, : cfg.fW // 2] = 0.0
+    dens, sem, base, rgb = synthetic.render_inputs(cfg, B, seed=11)
+    mats = dict(sensor2ego_mats=s2e[:, None], intrin_mats=K[:, None], ida_mats=ida[:, None],
+                bda_mat=bda)
+    g = torch.Generator().manual_seed(5)
+
+    # ---- geometry + lift (independent of density_mode / cat_seg): tiny_common.npz ----
+    m = ref_module(BaseVAMPIRE2, cfg, "sdf", False)
+    with torch.no_grad():
+        geom = m.get_geometry(s2e, K, ida, bda)
+        pix = m.get_pixel(s2e, K, ida, bda)
+    d_ = depth.clone().requires_grad_(True)
+    f_ = feat.clone().requires_grad_(True)
+    ff = d_.unsqueeze(2) * f_.unsqueeze(3)                             # bv2:553
+    vox = m.get_voxel_feats(ff, 0, mats)
+    g_vox = torch.randn(vox.shape, generator=g)
+    vox.backward(g_vox)
+    valid, ix0, iy0, iz0 = O.lift_tap_indices(pix, cfg.final_dim, cfg.d_bound,
+                                              (cfg.D, cfg.fH, cfg.fW))
+    geom_n = torch.nan_to_num(geom, -1e3)                              # bv2:612
+    inside, rx0, ry0, rz0 = O.render_tap_indices(
+        geom_n, (cfg.x_bound_seg, cfg.y_bound_seg, cfg.z_bound_seg), (cfg.vZ, cfg.vY, cfg.vX))
+    common = dict(sensor2ego=s2e, intrin=K, ida=ida, bda=bda, depth=depth, feat=feat,
+                  density_feature=dens, semantic_logits=sem, base=base, rgb=rgb,
+                  geom=geom, pix=pix, lift=vox, lift_valid=valid.to(torch.uint8),
+                  lift_ix0=ix0.to(torch.int16), lift_iy0=iy0.to(torch.int16),
+                  lift_iz0=iz0.to(torch.int16), g_lift=g_vox,
+                  grad_depth=d_.grad, grad_feat=f_.grad,
+                  render_inside=inside.to(torch.uint8), render_ix0=rx0.to(torch.int16),
+                  render_iy0=ry0.to(torch.int16), render_iz0=rz0.to(torch.int16))
+    path = os.path.join(HERE, "tiny_common.npz")
+    np.savez_compressed(path, **{k: v.detach().cpu().numpy() for k, v in common.items()})
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; lift valid frac",
+          float(valid.float().mean()), "render inside frac", float(inside.float().mean()),
+          "min cam z", float(pix[..., 2].min()), "nan in geom", int(torch.isnan(geom).sum()))
+
+    names = ["rgb_preds", "seg_logits_preds", "depth_preds", "bev_rgb_preds",
+             "bev_seg_logits_preds", "bev_height_preds", "voxel_density", "voxel_output"]
+    for density_mode in ("sdf", "naive"):
+        for cat_seg in (False, True):
+            m = ref_module(BaseVAMPIRE2, cfg, density_mode, cat_seg)
+            out = {}
+            vols = [t.clone().requires_grad_(True) for t in (dens, sem, base, rgb)]
+            r = m.volume_rendering_from_multiple_views(geom_n, *vols)
+            g_r = [torch.randn(t.shape, generator=g) for t in r]
+            torch.autograd.backward(r, g_r)
+            for n_, t, gt in zip(names, r, g_r):
+                out[n_] = t
+                out["g_" + n_] = gt
+            for n_, t in zip(["density_feature", "semantic_logits", "base", "rgb"], vols):
+                out["grad_" + n_] = t.grad
+            if density_mode == "sdf":
+                out["beta"] = m.density.beta.detach().reshape(1)
+                out["grad_beta"] = m.density.beta.grad.reshape(1)
+            path = os.path.join(HERE, f"tiny_render_{density_mode}_{'catseg' if cat_seg else 'plain'}.npz")
+            np.savez_compressed(path, **{k: v.detach().cpu().numpy() for k, v in out.items()})
+            print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+    # ---- D == 1 (BaseBiLinear) lift variant ----
+    m = ref_module(BaseBiLinear, cfg, "sdf", False)
+    f_ = feat.clone().requires_grad_(True)
+    vox = m.get_voxel_feats(f_, 0, mats)
+    g_vox = torch.randn(vox.shape, generator=g)
+    vox.backward(g_vox)
+    np.savez_compressed(os.path.join(HERE, "tiny_bilinear.npz"),
+                        sensor2ego=s2e.numpy(), intrin=K.numpy(), ida=ida.numpy(), bda=bda.numpy(),
+                        feat=feat.numpy(), lift=vox.detach().numpy(), g_lift=g_vox.numpy(),
+                        grad_feat=f_.grad.numpy())
+    print("wrote tiny_bilinear.npz")
+
+
+def make_full(BaseVAMPIRE2):
+    """cfg-A / cfg-B checksums at B=1 (seeds + statistics only)."""
+    from vampire_amd.config import CFG_A, CFG_B
+    from vampire_amd import synthetic
+    from oracle import aten_oracle as O
+    res = {}
+    for name, cfg in (("A", CFG_A), ("B", CFG_B)):
+        m = ref_module(BaseVAMPIRE2, cfg, "sdf", False)
+        s2e, K, ida = synthetic.camera_rig(cfg, 1)
+        bda = synthetic.bda_matrix(1)
+        depth, feat = synthetic.lift_inputs(cfg, 1, seed=0)
+        vols = synthetic.render_inputs(cfg, 1, seed=0)
+        mats = dict(sensor2ego_mats=s2e[:, None], intrin_mats=K[:, None], ida_mats=ida[:, None],
+                    bda_mat=bda)
+        entry = {}
+        with torch.no_grad():
+            pix = m.get_pixel(s2e, K, ida, bda)
+            valid, ix0, iy0, iz0 = O.lift_tap_indices(pix, cfg.final_dim, cfg.d_bound,
+                                                      (cfg.D, cfg.fH, cfg.fW))
+            entry["lift_valid_sha256"] = sha(valid.to(torch.uint8))
+            entry["lift_valid_count"] = int(valid.sum())
+            # indices only matter where valid; zero elsewhere so the hash is well defined
+            for nm, t in (("ix0", ix0), ("iy0", iy0), ("iz0", iz0)):
+                entry[f"lift_{nm}_sha256"] = sha(torch.where(valid, t, torch.zeros_like(t)).to(torch.int16))
+            vox = m.get_voxel_feats(depth.unsqueeze(2) * feat.unsqueeze(3), 0, mats)
+            entry["lift"] = stat(vox)
+            geom = torch.nan_to_num(m.get_geometry(s2e, K, ida, bda), -1e3)
+            inside, rx, ry, rz = O.render_tap_indices(
+                geom, (cfg.x_bound_seg, cfg.y_bound_seg, cfg.z_bound_seg), (cfg.vZ, cfg.vY, cfg.vX))
+            entry["render_inside_sha256"] = sha(inside.to(torch.uint8))
+            entry["render_inside_count"] = int(inside.sum())
+            for nm, t in (("ix0", rx), ("iy0", ry), ("iz0", rz)):
+                entry[f"render_{nm}_sha256"] = sha(torch.where(inside, t, torch.zeros_like(t)).to(torch.int16))
+            r = m.volume_rendering_from_multiple_views(geom, vols[0], vols[1], vols[2], vols[3])
+            for n_, t in zip(["rgb_preds", "seg_logits_preds", "depth_preds", "bev_rgb_preds",
+                              "bev_seg_logits_preds", "bev_height_preds", "voxel_density",
+                              "voxel_output"], r):
+                entry[n_] = stat(t)
+            # a strided sub-sample of values for tolerance checks
+            entry["lift_probe"] = vox.flatten()[::65537][:64].tolist()
+            entry["depth_preds_probe"] = r[2].flatten()[::1013][:64].tolist()
+            entry["seg_probe"] = r[1].flatten()[::10007][:64].tolist()
+        res[name] = entry
+        print("cfg", name, "done: valid", entry["lift_valid_count"], "inside", entry["render_inside_count"])
+    with open(os.path.join(HERE, "full_checksums.json"), "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    V2, BL = import_reference()
+    make_tiny(V2, BL)
+    if "--tiny-only" not in sys.argv:
+        make_full(V2)

@@ -1,0 +1,95 @@
+"""ctypes binding of include/vampire_hip.h (the C-ABI HIP library).
+
+There is deliberately no fallback: if the shared library is missing or a symbol
+does not resolve, importing the ops raises.  The product path never routes
+through oracle/ or any CPU implementation.
+"""
+import ctypes as C
+import os
+
+from .build import lib_path
+
+ABI_VERSION = 1
+
+VAMP_F32, VAMP_BF16 = 0, 1
+VAMP_DENSITY_SIGMOID, VAMP_DENSITY_SDF_LAPLACE = 0, 1
+
+
+class VampLiftDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("C", C.c_int32),
+                ("D", C.c_int32), ("fH", C.c_int32), ("fW", C.c_int32),
+                ("Z", C.c_int32), ("Y", C.c_int32), ("X", C.c_int32),
+                ("u_max", C.c_float), ("v_max", C.c_float),
+                ("u_div", C.c_float), ("v_div", C.c_float),
+                ("d_lo", C.c_float), ("d_hi", C.c_float), ("d_span", C.c_float),
+                ("use_depth", C.c_int32), ("in_dtype", C.c_int32)]
+
+
+class VampRenderDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32),
+                ("D", C.c_int32), ("fH", C.c_int32), ("fW", C.c_int32),
+                ("K", C.c_int32), ("C", C.c_int32),
+                ("Z", C.c_int32), ("Y", C.c_int32), ("X", C.c_int32),
+                ("oZ", C.c_int32), ("oY", C.c_int32), ("oX", C.c_int32),
+                ("lo", C.c_float * 3), ("span", C.c_float * 3),
+                ("d_far", C.c_float), ("z_step_det", C.c_float),
+                ("density_mode", C.c_int32), ("sdf_bias", C.c_float), ("beta_min", C.c_float),
+                ("cat_seg", C.c_int32), ("in_dtype", C.c_int32)]
+
+
+_P = C.c_void_p
+_LD = C.POINTER(VampLiftDesc)
+_RD = C.POINTER(VampRenderDesc)
+
+# name -> (restype, argtypes); must list every symbol declared in include/vampire_hip.h
+SIGNATURES = {
+    "vamp_abi_version": (C.c_int, []),
+    "vamp_last_error": (C.c_char_p, []),
+    "vamp_lift_workspace_bytes": (C.c_size_t, [_LD]),
+    "vamp_lift_forward": (C.c_int, [_LD] + [_P] * 8 + [_P, C.c_size_t, _P]),
+    "vamp_lift_backward": (C.c_int, [_LD] + [_P] * 10 + [_P, C.c_size_t, _P]),
+    "vamp_lift_forward_dense": (C.c_int, [_LD] + [_P] * 7 + [_P]),
+    "vamp_lift_backward_dense": (C.c_int, [_LD] + [_P] * 7 + [_P]),
+    "vamp_lift_indices": (C.c_int, [_LD] + [_P] * 8 + [_P]),
+    "vamp_render_workspace_bytes": (C.c_size_t, [_RD]),
+    "vamp_render_camera_forward": (C.c_int, [_RD] + [_P] * 13 + [_P, C.c_size_t, _P]),
+    "vamp_render_camera_backward": (C.c_int, [_RD] + [_P] * 17 + [_P, C.c_size_t, _P]),
+    "vamp_render_bev_forward": (C.c_int, [_RD] + [_P] * 14 + [_P]),
+    "vamp_render_bev_backward": (C.c_int, [_RD] + [_P] * 19 + [_P]),
+    "vamp_render_indices": (C.c_int, [_RD] + [_P] * 9 + [_P]),
+    "vamp_frustum_geometry": (C.c_int, [_RD] + [_P] * 5 + [_P]),
+}
+
+_lib = None
+
+
+class VampireHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library and bind every symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.environ.get("VAMPIRE_HIP_LIB", lib_path())
+    if not os.path.exists(path):
+        raise VampireHipError(
+            f"{path} not found: build it with `python -m vampire_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.vamp_abi_version()
+    if got != ABI_VERSION:
+        raise VampireHipError(f"ABI version mismatch: library {got}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().vamp_last_error().decode("utf-8", "replace")
+        raise VampireHipError(f"{what} failed with code {code}: {msg}")

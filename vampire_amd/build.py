@@ -1,0 +1,61 @@
+"""Build recipe for the C-ABI HIP library (gfx950 only).
+
+    python -m vampire_amd.build            # -> vampire_amd/_lib/libvampire_hip.so
+
+hipcc cross-compiles without a GPU.  The library is kept in-tree (git-ignored) so
+that it travels to the GPU box with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "_lib")
+LIBNAME = "libvampire_hip.so"
+SOURCES = ["lift.hip", "render_fwd.hip", "render_bwd.hip"]
+# -ffp-contract=off: the projection chains must round like the reference's fp32 ops
+FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+
+
+def lib_path() -> str:
+    return os.path.join(LIBDIR, LIBNAME)
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = True) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(LIBDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "vampire_hip.h"))
+    objs, jobs = [], []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    out = lib_path()
+    if jobs or force or _stale(out, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv))

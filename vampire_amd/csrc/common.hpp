@@ -1,0 +1,117 @@
+// Shared device/host helpers for the gfx950 lift + render kernels.
+// Compiled with -ffp-contract=off: every a*b+c below is two IEEE roundings unless
+// written as __builtin_fmaf.  The projection chains rely on that to reproduce the
+// reference's fp32 results bit for bit (DESIGN.md "Bit-exact projection").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/vampire_hip.h"
+
+namespace vamp {
+
+constexpr int kWave = 64;
+
+extern thread_local char g_err[512];
+
+inline int fail(int code, const char* fmt, const char* a = "", long b = 0, long c = 0) {
+  snprintf(g_err, sizeof(g_err), fmt, a, b, c);
+  return code;
+}
+
+#define VAMP_REQUIRE(cond, msg)                                              \
+  do {                                                                       \
+    if (!(cond)) return ::vamp::fail(VAMP_EINVAL, "%s: requirement failed: " msg, __func__); \
+  } while (0)
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return VAMP_EHIP;
+  }
+  return VAMP_OK;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------
+// 4x4 * 4x1 in the evaluation order of torch's CPU bmm for tiny matrices:
+// ((m0*x + m1*y) + m2*z) + m3*w, no fused multiply-add.
+// ---------------------------------------------------------------------------
+struct Vec4 {
+  float x, y, z, w;
+};
+
+__device__ __forceinline__ Vec4 matvec(const float* __restrict__ m, Vec4 p) {
+  Vec4 r;
+  r.x = ((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3] * p.w;
+  r.y = ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7] * p.w;
+  r.z = ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + m[11] * p.w;
+  r.w = ((m[12] * p.x + m[13] * p.y) + m[14] * p.z) + m[15] * p.w;
+  return r;
+}
+
+// element loads with fp32 promotion
+__device__ __forceinline__ float ldf(const float* p, long i) { return p[i]; }
+__device__ __forceinline__ float ldf(const __hip_bfloat16* p, long i) {
+  return __uint_as_float(((uint32_t) reinterpret_cast<const uint16_t*>(p)[i]) << 16);
+}
+
+__device__ __forceinline__ float nan_to_num(float v) {
+  // torch.nan_to_num defaults: nan -> 0, +-inf -> +-FLT_MAX
+  if (v != v) return 0.f;
+  return fminf(fmaxf(v, -3.402823466e+38f), 3.402823466e+38f);
+}
+
+// ---------------------------------------------------------------------------
+// density activations (render_utils.py:30-46 / nn.Sigmoid)
+// ---------------------------------------------------------------------------
+struct DensityParams {
+  int mode;
+  float beta;   // |beta_raw| + beta_min
+  float bias;
+};
+
+__device__ __forceinline__ float density_fwd(const DensityParams& dp, float s) {
+  if (dp.mode == VAMP_DENSITY_SIGMOID) return 1.f / (1.f + expf(-s));
+  float t = s - dp.bias;
+  float sg = (t > 0.f) ? 1.f : ((t < 0.f) ? -1.f : 0.f);
+  return (1.f / dp.beta) * (0.5f + 0.5f * sg * expm1f(-fabsf(t) / dp.beta));
+}
+
+// d sigma / d s, and d sigma / d beta_eff (beta_eff = |beta_raw| + beta_min)
+__device__ __forceinline__ void density_bwd(const DensityParams& dp, float s, float& dsig_ds,
+                                            float& dsig_dbeta) {
+  if (dp.mode == VAMP_DENSITY_SIGMOID) {
+    float y = 1.f / (1.f + expf(-s));
+    dsig_ds = y * (1.f - y);
+    dsig_dbeta = 0.f;
+    return;
+  }
+  float t = s - dp.bias;
+  float a = fabsf(t);
+  float sg = (t > 0.f) ? 1.f : ((t < 0.f) ? -1.f : 0.f);
+  float ib = 1.f / dp.beta;
+  float e = expf(-a * ib);                 // exp(-|t|/beta)
+  float em1 = expm1f(-a * ib);
+  // sigma = ib * (0.5 + 0.5*sg*em1)
+  // d/ds: ib * 0.5*sg * e * (-sg*ib) = -0.5*ib^2*e*sg^2   (sign(t)' = 0 a.e.)
+  dsig_ds = -0.5f * ib * ib * e * (sg * sg);
+  // d/dbeta: -ib^2*(0.5+0.5*sg*em1) + ib*0.5*sg*e*(a*ib^2)
+  dsig_dbeta = -ib * ib * (0.5f + 0.5f * sg * em1) + 0.5f * sg * e * a * ib * ib * ib;
+}
+
+__device__ __forceinline__ DensityParams load_density(int mode, const float* beta_raw,
+                                                      float beta_min, float bias) {
+  DensityParams dp;
+  dp.mode = mode;
+  dp.bias = bias;
+  dp.beta = (mode == VAMP_DENSITY_SDF_LAPLACE) ? (fabsf(beta_raw[0]) + beta_min) : 1.f;
+  return dp;
+}
+
+}  // namespace vamp

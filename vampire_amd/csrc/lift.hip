@@ -1,0 +1,583 @@
+// LIFT kernels for gfx950: every voxel pulls a trilinear sample of
+// depth[d,h,w] * feat[c,h,w] from each camera and averages over the cameras that
+// hit it.  Reference call sites: base_vampire2.py:550-553 (outer product),
+// :351-388 (get_pixel), :483-516 (get_voxel_feats).
+//
+// The outer product is never materialised: the trilinear sample of a rank-1
+// (depth x feat) volume separates into
+//     sum_{4 (h,w) taps} w_hw * feat[c,h,w] * ( sum_{2 d taps} w_d * depth[d,h,w] ).
+// Memory-bound gather; no MFMA.  One thread per voxel, lanes along x so the
+// [B,C,Z,Y,X] stores coalesce; features are read channel-last (one 64-byte run
+// per tap for C = 16) from a transposed copy made by a tiny pre-pass.
+#include "common.hpp"
+
+namespace vamp {
+
+thread_local char g_err[512] = "";
+
+struct LiftParams {
+  int B, N, C, D, fH, fW, Z, Y, X;
+  float u_max, v_max, u_div, v_div, d_lo, d_hi, d_span;
+  int use_depth;
+};
+
+static LiftParams to_params(const VampLiftDesc* d) {
+  LiftParams p;
+  p.B = d->B; p.N = d->N; p.C = d->C; p.D = d->D; p.fH = d->fH; p.fW = d->fW;
+  p.Z = d->Z; p.Y = d->Y; p.X = d->X;
+  p.u_max = d->u_max; p.v_max = d->v_max; p.u_div = d->u_div; p.v_div = d->v_div;
+  p.d_lo = d->d_lo; p.d_hi = d->d_hi; p.d_span = d->d_span; p.use_depth = d->use_depth;
+  return p;
+}
+
+// Result of projecting one voxel centre into one camera.
+struct LiftTap {
+  bool valid;
+  int ix0, iy0, iz0;
+  float wx0, wx1, wy0, wy1, wz0, wz1;
+};
+
+// get_pixel (bv2:365-388) + validity / normalisation (bv2:493-505) + aten's
+// grid_sampler_unnormalize for align_corners=False.  Evaluation order is part of
+// the contract (bit-exact tap indices): do not reassociate, do not fuse.
+__device__ __forceinline__ LiftTap lift_project(const LiftParams& P, const float* __restrict__ m,
+                                                float x, float y, float z) {
+  Vec4 p{x, y, z, 1.0f};
+  p = matvec(m, p);        // inv(bda)
+  p = matvec(m + 16, p);   // intrin @ inv(sensor2ego)
+  float zc = (p.z < 1e-6f) ? 1e-6f : p.z;   // clamp(min=eps); NaN stays NaN
+  p.x = p.x / zc;
+  p.y = p.y / zc;
+  p = matvec(m + 32, p);   // ida
+  const float u = p.x, v = p.y, zz = p.z;
+  LiftTap t;
+  bool ok = (u > -0.5f) && (u < P.u_max) && (v > -0.5f) && (v < P.v_max);
+  if (P.use_depth) ok = ok && (zz > P.d_lo) && (zz < P.d_hi);
+  else ok = ok && (zz > 0.0f);
+  t.valid = ok;
+  float nx = 2.0f * (u / P.u_div) - 1.0f;
+  float ny = 2.0f * (v / P.v_div) - 1.0f;
+  float nz = P.use_depth ? (2.0f * ((zz - P.d_lo) / P.d_span) - 1.0f) : 0.0f;
+  nx = fminf(fmaxf(nx, -2.0f), 2.0f);
+  ny = fminf(fmaxf(ny, -2.0f), 2.0f);
+  nz = fminf(fmaxf(nz, -2.0f), 2.0f);
+  const float fx = ((nx + 1.0f) * (float) P.fW - 1.0f) / 2.0f;
+  const float fy = ((ny + 1.0f) * (float) P.fH - 1.0f) / 2.0f;
+  const float fz = ((nz + 1.0f) * (float) P.D - 1.0f) / 2.0f;
+  const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+  t.ix0 = (int) flx; t.iy0 = (int) fly; t.iz0 = (int) flz;
+  t.wx1 = fx - flx; t.wx0 = (flx + 1.0f) - fx;
+  t.wy1 = fy - fly; t.wy0 = (fly + 1.0f) - fy;
+  t.wz1 = fz - flz; t.wz0 = (flz + 1.0f) - fz;
+  return t;
+}
+
+// ---------------------------------------------------------------------------
+// feat [BN, C, HW] (f32 or bf16) -> channel-last fp32 [BN, HW, C]
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) feat_to_channel_last(const T* __restrict__ feat,
+                                                            float* __restrict__ out, int C, int HW) {
+  __shared__ float tile[64][65];
+  const long bn = blockIdx.z;
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int j = ty; j < 64; j += 4) {
+    int c = c0 + j, p = p0 + tx;
+    tile[j][tx] = (c < C && p < HW) ? ldf(feat, (bn * C + c) * HW + p) : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 64; j += 4) {
+    int p = p0 + j, c = c0 + tx;
+    if (p < HW && c < C) out[(bn * HW + p) * C + c] = tile[tx][j];
+  }
+}
+
+// channel-last fp32 [BN, HW, C] -> [BN, C, HW]
+__global__ void __launch_bounds__(256) feat_to_channel_first(const float* __restrict__ in,
+                                                             float* __restrict__ out, int C, int HW) {
+  __shared__ float tile[64][65];
+  const long bn = blockIdx.z;
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int j = ty; j < 64; j += 4) {
+    int p = p0 + j, c = c0 + tx;
+    tile[j][tx] = (p < HW && c < C) ? in[(bn * HW + p) * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 64; j += 4) {
+    int c = c0 + j, p = p0 + tx;
+    if (c < C && p < HW) out[(bn * C + c) * HW + p] = tile[tx][j];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// depth interpolation at the four (h,w) taps:  dep[j] = sum_d w_d depth[d, iy, ix]
+// (zero padding: out-of-range taps contribute nothing)
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void depth_taps(const LiftParams& P, const T* __restrict__ dptr,
+                                           const LiftTap& t, float dep[4]) {
+  dep[0] = dep[1] = dep[2] = dep[3] = 0.f;
+  if (!P.use_depth) {
+    // D == 1: the single plane has weight wz0 (= 1) at iz0 == 0
+    const float w = (t.iz0 == 0 ? t.wz0 : 0.f) + (t.iz0 == -1 ? t.wz1 : 0.f);
+    dep[0] = dep[1] = dep[2] = dep[3] = w;
+    return;
+  }
+  const long plane = (long) P.fH * P.fW;
+#pragma unroll
+  for (int kz = 0; kz < 2; ++kz) {
+    const int iz = t.iz0 + kz;
+    if (iz < 0 || iz >= P.D) continue;
+    const float wz = kz ? t.wz1 : t.wz0;
+#pragma unroll
+    for (int ky = 0; ky < 2; ++ky) {
+      const int iy = t.iy0 + ky;
+      if (iy < 0 || iy >= P.fH) continue;
+      const long row = iz * plane + (long) iy * P.fW;
+      if (t.ix0 >= 0 && t.ix0 < P.fW) dep[ky * 2 + 0] += wz * ldf(dptr, row + t.ix0);
+      if (t.ix0 + 1 >= 0 && t.ix0 + 1 < P.fW) dep[ky * 2 + 1] += wz * ldf(dptr, row + t.ix0 + 1);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LIFT forward.  Block = TX*TY*TZ (= 256) voxels; CH channels per pass.
+// ---------------------------------------------------------------------------
+template <typename T, int CH, int TX, int TY, int TZ>
+__global__ void __launch_bounds__(TX* TY* TZ)
+lift_fwd_kernel(LiftParams P, const float* __restrict__ mats, const float* __restrict__ xs,
+                const float* __restrict__ ys, const float* __restrict__ zs,
+                const T* __restrict__ depth, const float* __restrict__ feat_cl,
+                float* __restrict__ out, uint64_t* __restrict__ hits) {
+  const int tid = threadIdx.x;
+  const int x = blockIdx.x * TX + (tid % TX);
+  const int y = blockIdx.y * TY + ((tid / TX) % TY);
+  const int zblocks = (P.Z + TZ - 1) / TZ;
+  const int b = blockIdx.z / zblocks;
+  const int z = (blockIdx.z % zblocks) * TZ + tid / (TX * TY);
+  if (x >= P.X || y >= P.Y || z >= P.Z) return;
+
+  const float vx = xs[x], vy = ys[y], vz = zs[z];
+  const long V = (long) P.Z * P.Y * P.X;
+  const long vox = ((long) z * P.Y + y) * P.X + x;
+  const long HW = (long) P.fH * P.fW;
+  const int nchunk = P.C / CH;
+
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    float sum[CH];
+    uint64_t cnt = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) sum[c] = 0.f;
+
+    for (int n = 0; n < P.N; ++n) {
+      const long bn = (long) b * P.N + n;
+      const LiftTap t = lift_project(P, mats + bn * 48, vx, vy, vz);
+      if (!t.valid) continue;
+      float dep[4];
+      depth_taps<T>(P, depth + bn * P.D * HW, t, dep);
+      const float w[4] = {t.wy0 * t.wx0, t.wy0 * t.wx1, t.wy1 * t.wx0, t.wy1 * t.wx1};
+      float acc[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) acc[c] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int iy = t.iy0 + (j >> 1), ix = t.ix0 + (j & 1);
+        if (iy < 0 || iy >= P.fH || ix < 0 || ix >= P.fW) continue;
+        const float wd = w[j] * dep[j];
+        const float4* f4 = reinterpret_cast<const float4*>(
+            feat_cl + (bn * HW + (long) iy * P.fW + ix) * P.C + chunk * CH);
+#pragma unroll
+        for (int q = 0; q < CH / 4; ++q) {
+          const float4 f = f4[q];
+          acc[q * 4 + 0] = __builtin_fmaf(wd, f.x, acc[q * 4 + 0]);
+          acc[q * 4 + 1] = __builtin_fmaf(wd, f.y, acc[q * 4 + 1]);
+          acc[q * 4 + 2] = __builtin_fmaf(wd, f.z, acc[q * 4 + 2]);
+          acc[q * 4 + 3] = __builtin_fmaf(wd, f.w, acc[q * 4 + 3]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        sum[c] += acc[c];
+        cnt += (uint64_t) (fabsf(acc[c]) > 0.f) << (4 * c);   // per-channel hit count (bv2:509)
+      }
+    }
+    float* o = out + ((long) b * P.C + chunk * CH) * V + vox;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const float denom = (float) ((cnt >> (4 * c)) & 15) + 1e-6f;
+      o[(long) c * V] = sum[c] / denom;
+    }
+    if (hits) hits[((long) b * V + vox) * nchunk + chunk] = cnt;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LIFT forward from the materialised frustum_feats [B,N,C,D,fH,fW]
+// (signature-compatible path for get_voxel_feats, bv2:483).  8-tap gather per
+// channel in aten's tap order.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+lift_fwd_dense_kernel(LiftParams P, const float* __restrict__ mats, const float* __restrict__ xs,
+                      const float* __restrict__ ys, const float* __restrict__ zs,
+                      const float* __restrict__ ff, float* __restrict__ out,
+                      uint64_t* __restrict__ hits) {
+  const long V = (long) P.Z * P.Y * P.X;
+  const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= V * P.B) return;
+  const int b = gid / V;
+  const long vox = gid % V;
+  const int x = vox % P.X, y = (vox / P.X) % P.Y, z = vox / ((long) P.X * P.Y);
+  const float vx = xs[x], vy = ys[y], vz = zs[z];
+  const long HW = (long) P.fH * P.fW, DHW = HW * P.D;
+  const int nchunk = (P.C + 15) / 16;
+
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const int c_lo = chunk * 16, c_n = min(16, P.C - c_lo);
+    float sum[16];
+    uint64_t cnt = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) sum[c] = 0.f;
+    for (int n = 0; n < P.N; ++n) {
+      const long bn = (long) b * P.N + n;
+      const LiftTap t = lift_project(P, mats + bn * 48, vx, vy, vz);
+      if (!t.valid) continue;
+      float acc[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int iz = t.iz0 + (k >> 2), iy = t.iy0 + ((k >> 1) & 1), ix = t.ix0 + (k & 1);
+        if (iz < 0 || iz >= P.D || iy < 0 || iy >= P.fH || ix < 0 || ix >= P.fW) continue;
+        const float w = ((k & 1) ? t.wx1 : t.wx0) * ((k & 2) ? t.wy1 : t.wy0) *
+                        ((k & 4) ? t.wz1 : t.wz0);
+        const float* src = ff + (bn * P.C + c_lo) * DHW + iz * HW + (long) iy * P.fW + ix;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+          if (c < c_n) acc[c] += src[c * DHW] * w;
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        sum[c] += acc[c];
+        cnt += (uint64_t) (fabsf(acc[c]) > 0.f) << (4 * c);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < c_n)
+        out[((long) b * P.C + c_lo + c) * V + vox] =
+            sum[c] / ((float) ((cnt >> (4 * c)) & 15) + 1e-6f);
+    if (hits) hits[((long) b * V + vox) * nchunk + chunk] = cnt;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LIFT backward (v1): one thread per voxel, float atomics into channel-last
+// grad_feat and into grad_depth.
+// ---------------------------------------------------------------------------
+template <typename T, int CH, int TX, int TY, int TZ>
+__global__ void __launch_bounds__(TX* TY* TZ)
+lift_bwd_kernel(LiftParams P, const float* __restrict__ mats, const float* __restrict__ xs,
+                const float* __restrict__ ys, const float* __restrict__ zs,
+                const T* __restrict__ depth, const float* __restrict__ feat_cl,
+                const float* __restrict__ gout, const uint64_t* __restrict__ hits,
+                float* __restrict__ gdepth, float* __restrict__ gfeat_cl) {
+  const int tid = threadIdx.x;
+  const int x = blockIdx.x * TX + (tid % TX);
+  const int y = blockIdx.y * TY + ((tid / TX) % TY);
+  const int zblocks = (P.Z + TZ - 1) / TZ;
+  const int b = blockIdx.z / zblocks;
+  const int z = (blockIdx.z % zblocks) * TZ + tid / (TX * TY);
+  if (x >= P.X || y >= P.Y || z >= P.Z) return;
+
+  const float vx = xs[x], vy = ys[y], vz = zs[z];
+  const long V = (long) P.Z * P.Y * P.X;
+  const long vox = ((long) z * P.Y + y) * P.X + x;
+  const long HW = (long) P.fH * P.fW;
+  const int nchunk = P.C / CH;
+
+  for (int n = 0; n < P.N; ++n) {
+    const long bn = (long) b * P.N + n;
+    const LiftTap t = lift_project(P, mats + bn * 48, vx, vy, vz);
+    if (!t.valid) continue;
+    float dep[4];
+    depth_taps<T>(P, depth + bn * P.D * HW, t, dep);
+    const float w[4] = {t.wy0 * t.wx0, t.wy0 * t.wx1, t.wy1 * t.wx0, t.wy1 * t.wx1};
+    float gdep[4] = {0.f, 0.f, 0.f, 0.f};   // d loss / d dep[j]
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+      const uint64_t cnt = hits[((long) b * V + vox) * nchunk + chunk];
+      float gs[CH];
+      const float* g = gout + ((long) b * P.C + chunk * CH) * V + vox;
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+        gs[c] = g[(long) c * V] / ((float) ((cnt >> (4 * c)) & 15) + 1e-6f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int iy = t.iy0 + (j >> 1), ix = t.ix0 + (j & 1);
+        if (iy < 0 || iy >= P.fH || ix < 0 || ix >= P.fW) continue;
+        const long pix = (bn * HW + (long) iy * P.fW + ix) * P.C + chunk * CH;
+        const float4* f4 = reinterpret_cast<const float4*>(feat_cl + pix);
+        const float wd = w[j] * dep[j];
+        float dot = 0.f;
+#pragma unroll
+        for (int q = 0; q < CH / 4; ++q) {
+          const float4 f = f4[q];
+          dot = __builtin_fmaf(f.x, gs[q * 4 + 0], dot);
+          dot = __builtin_fmaf(f.y, gs[q * 4 + 1], dot);
+          dot = __builtin_fmaf(f.z, gs[q * 4 + 2], dot);
+          dot = __builtin_fmaf(f.w, gs[q * 4 + 3], dot);
+        }
+        gdep[j] = __builtin_fmaf(w[j], dot, gdep[j]);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) atomicAdd(gfeat_cl + pix + c, wd * gs[c]);
+      }
+    }
+    if (P.use_depth && gdepth) {
+      float* gd = gdepth + bn * P.D * HW;
+#pragma unroll
+      for (int kz = 0; kz < 2; ++kz) {
+        const int iz = t.iz0 + kz;
+        if (iz < 0 || iz >= P.D) continue;
+        const float wz = kz ? t.wz1 : t.wz0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int iy = t.iy0 + (j >> 1), ix = t.ix0 + (j & 1);
+          if (iy < 0 || iy >= P.fH || ix < 0 || ix >= P.fW) continue;
+          atomicAdd(gd + iz * HW + (long) iy * P.fW + ix, wz * gdep[j]);
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+lift_bwd_dense_kernel(LiftParams P, const float* __restrict__ mats, const float* __restrict__ xs,
+                      const float* __restrict__ ys, const float* __restrict__ zs,
+                      const float* __restrict__ gout, const uint64_t* __restrict__ hits,
+                      float* __restrict__ gff) {
+  const long V = (long) P.Z * P.Y * P.X;
+  const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= V * P.B) return;
+  const int b = gid / V;
+  const long vox = gid % V;
+  const int x = vox % P.X, y = (vox / P.X) % P.Y, z = vox / ((long) P.X * P.Y);
+  const float vx = xs[x], vy = ys[y], vz = zs[z];
+  const long HW = (long) P.fH * P.fW, DHW = HW * P.D;
+  const int nchunk = (P.C + 15) / 16;
+  for (int n = 0; n < P.N; ++n) {
+    const long bn = (long) b * P.N + n;
+    const LiftTap t = lift_project(P, mats + bn * 48, vx, vy, vz);
+    if (!t.valid) continue;
+    for (int c = 0; c < P.C; ++c) {
+      const uint64_t cnt = hits[((long) b * V + vox) * nchunk + (c >> 4)];
+      const float gs = gout[((long) b * P.C + c) * V + vox] /
+                       ((float) ((cnt >> (4 * (c & 15))) & 15) + 1e-6f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int iz = t.iz0 + (k >> 2), iy = t.iy0 + ((k >> 1) & 1), ix = t.ix0 + (k & 1);
+        if (iz < 0 || iz >= P.D || iy < 0 || iy >= P.fH || ix < 0 || ix >= P.fW) continue;
+        const float w = ((k & 1) ? t.wx1 : t.wx0) * ((k & 2) ? t.wy1 : t.wy0) *
+                        ((k & 4) ? t.wz1 : t.wz0);
+        atomicAdd(gff + (bn * P.C + c) * DHW + iz * HW + (long) iy * P.fW + ix, w * gs);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+lift_indices_kernel(LiftParams P, const float* __restrict__ mats, const float* __restrict__ xs,
+                    const float* __restrict__ ys, const float* __restrict__ zs,
+                    uint8_t* __restrict__ valid, int16_t* __restrict__ ix0,
+                    int16_t* __restrict__ iy0, int16_t* __restrict__ iz0) {
+  const long V = (long) P.Z * P.Y * P.X;
+  const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= V * P.B * P.N) return;
+  const long bn = gid / V;
+  const long vox = gid % V;
+  const int x = vox % P.X, y = (vox / P.X) % P.Y, z = vox / ((long) P.X * P.Y);
+  const LiftTap t = lift_project(P, mats + bn * 48, xs[x], ys[y], zs[z]);
+  valid[gid] = t.valid ? 1 : 0;
+  ix0[gid] = (int16_t) t.ix0;
+  iy0[gid] = (int16_t) t.iy0;
+  iz0[gid] = (int16_t) t.iz0;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static int validate(const VampLiftDesc* d) {
+  VAMP_REQUIRE(d != nullptr, "desc is NULL");
+  VAMP_REQUIRE(d->B > 0 && d->N > 0 && d->C > 0, "B, N, C must be positive");
+  VAMP_REQUIRE(d->D > 0 && d->fH > 0 && d->fW > 0, "D, fH, fW must be positive");
+  VAMP_REQUIRE(d->Z > 0 && d->Y > 0 && d->X > 0, "Z, Y, X must be positive");
+  VAMP_REQUIRE(d->X < 32768 && d->Y < 32768 && d->fW < 32768 && d->fH < 32768,
+               "axis too long for int16 taps");
+  VAMP_REQUIRE(d->N <= 15, "at most 15 cameras (4-bit hit counters)");
+  VAMP_REQUIRE(d->in_dtype == VAMP_F32 || d->in_dtype == VAMP_BF16, "in_dtype");
+  VAMP_REQUIRE(d->use_depth == 1 || d->D == 1, "use_depth == 0 requires D == 1");
+  return VAMP_OK;
+}
+
+static bool fused_channels_ok(int C) { return C == 4 || C == 8 || (C % 16 == 0 && C <= 64); }
+
+template <typename T>
+static void launch_to_cl(const void* feat, float* out, int BN, int C, int HW, hipStream_t s) {
+  dim3 grid((HW + 63) / 64, (C + 63) / 64, BN);
+  feat_to_channel_last<T><<<grid, 256, 0, s>>>(static_cast<const T*>(feat), out, C, HW);
+}
+
+struct LiftWs {
+  float* feat_cl;     // [B*N, HW, C]
+  float* gfeat_cl;    // [B*N, HW, C] (backward only)
+  size_t bytes;
+};
+
+static LiftWs carve(const VampLiftDesc* d, void* ws) {
+  LiftWs w;
+  const size_t n = align_up((size_t) d->B * d->N * d->fH * d->fW * d->C * sizeof(float), 256);
+  w.feat_cl = static_cast<float*>(ws);
+  w.gfeat_cl = reinterpret_cast<float*>(static_cast<char*>(ws) + n);
+  w.bytes = 2 * n;
+  return w;
+}
+
+// tile shape: lanes along x for coalesced stores
+#define VAMP_LIFT_TILE 64, 4, 1
+
+template <typename T>
+static int lift_forward_t(const VampLiftDesc* d, const LiftParams& P, const float* mats,
+                          const float* xs, const float* ys, const float* zs, const void* depth,
+                          const float* feat_cl, float* out, uint64_t* hits, hipStream_t s) {
+  constexpr int TX = 64, TY = 4, TZ = 1;
+  dim3 grid((P.X + TX - 1) / TX, (P.Y + TY - 1) / TY, ((P.Z + TZ - 1) / TZ) * P.B);
+  const T* dp = static_cast<const T*>(depth);
+  if (P.C == 4)
+    lift_fwd_kernel<T, 4, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, out, hits);
+  else if (P.C == 8)
+    lift_fwd_kernel<T, 8, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, out, hits);
+  else
+    lift_fwd_kernel<T, 16, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, out, hits);
+  return check_launch("lift_fwd_kernel");
+}
+
+template <typename T>
+static int lift_backward_t(const VampLiftDesc* d, const LiftParams& P, const float* mats,
+                           const float* xs, const float* ys, const float* zs, const void* depth,
+                           const float* feat_cl, const float* gout, const uint64_t* hits,
+                           float* gdepth, float* gfeat_cl, hipStream_t s) {
+  constexpr int TX = 64, TY = 4, TZ = 1;
+  dim3 grid((P.X + TX - 1) / TX, (P.Y + TY - 1) / TY, ((P.Z + TZ - 1) / TZ) * P.B);
+  const T* dp = static_cast<const T*>(depth);
+  if (P.C == 4)
+    lift_bwd_kernel<T, 4, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, gout, hits, gdepth, gfeat_cl);
+  else if (P.C == 8)
+    lift_bwd_kernel<T, 8, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, gout, hits, gdepth, gfeat_cl);
+  else
+    lift_bwd_kernel<T, 16, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, gout, hits, gdepth, gfeat_cl);
+  return check_launch("lift_bwd_kernel");
+}
+
+}  // namespace vamp
+
+using namespace vamp;
+
+extern "C" {
+
+int vamp_abi_version(void) { return VAMP_ABI_VERSION; }
+const char* vamp_last_error(void) { return g_err; }
+
+size_t vamp_lift_workspace_bytes(const VampLiftDesc* d) {
+  if (!d) return 0;
+  return carve(d, nullptr).bytes;
+}
+
+int vamp_lift_forward(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
+                      const float* zs, const void* depth, const void* feat, float* out,
+                      uint64_t* hits, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  VAMP_REQUIRE(mats && xs && ys && zs && feat && out, "null pointer");
+  VAMP_REQUIRE(depth || !d->use_depth, "depth is NULL");
+  VAMP_REQUIRE(fused_channels_ok(d->C), "C must be 4, 8 or a multiple of 16 (<= 64)");
+  const LiftWs w = carve(d, workspace);
+  if (!workspace || workspace_bytes < w.bytes)
+    return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) w.bytes);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const LiftParams P = to_params(d);
+  const int BN = d->B * d->N, HW = d->fH * d->fW;
+  if (d->in_dtype == VAMP_F32) launch_to_cl<float>(feat, w.feat_cl, BN, d->C, HW, s);
+  else launch_to_cl<__hip_bfloat16>(feat, w.feat_cl, BN, d->C, HW, s);
+  if (int e = check_launch("feat_to_channel_last")) return e;
+  if (d->in_dtype == VAMP_F32)
+    return lift_forward_t<float>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, s);
+  return lift_forward_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, s);
+}
+
+int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
+                       const float* zs, const void* depth, const void* feat,
+                       const float* grad_out, const uint64_t* hits, float* grad_depth,
+                       float* grad_feat, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  VAMP_REQUIRE(mats && xs && ys && zs && feat && grad_out && hits && grad_feat, "null pointer");
+  VAMP_REQUIRE((depth && grad_depth) || !d->use_depth, "depth / grad_depth is NULL");
+  VAMP_REQUIRE(fused_channels_ok(d->C), "C must be 4, 8 or a multiple of 16 (<= 64)");
+  const LiftWs w = carve(d, workspace);
+  if (!workspace || workspace_bytes < w.bytes)
+    return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) w.bytes);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const LiftParams P = to_params(d);
+  const int BN = d->B * d->N, HW = d->fH * d->fW;
+  if (d->in_dtype == VAMP_F32) launch_to_cl<float>(feat, w.feat_cl, BN, d->C, HW, s);
+  else launch_to_cl<__hip_bfloat16>(feat, w.feat_cl, BN, d->C, HW, s);
+  if (int e = check_launch("feat_to_channel_last")) return e;
+  if (hipMemsetAsync(w.gfeat_cl, 0, (size_t) BN * HW * d->C * sizeof(float), s) != hipSuccess)
+    return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
+  if (d->use_depth &&
+      hipMemsetAsync(grad_depth, 0, (size_t) BN * d->D * HW * sizeof(float), s) != hipSuccess)
+    return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
+  int e = (d->in_dtype == VAMP_F32)
+              ? lift_backward_t<float>(d, P, mats, xs, ys, zs, depth, w.feat_cl, grad_out, hits, grad_depth, w.gfeat_cl, s)
+              : lift_backward_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, w.feat_cl, grad_out, hits, grad_depth, w.gfeat_cl, s);
+  if (e) return e;
+  dim3 grid((HW + 63) / 64, (d->C + 63) / 64, BN);
+  feat_to_channel_first<<<grid, 256, 0, s>>>(w.gfeat_cl, grad_feat, d->C, HW);
+  return check_launch("feat_to_channel_first");
+}
+
+int vamp_lift_forward_dense(const VampLiftDesc* d, const float* mats, const float* xs,
+                            const float* ys, const float* zs, const float* frustum_feats,
+                            float* out, uint64_t* hits, void* stream) {
+  if (int e = validate(d)) return e;
+  VAMP_REQUIRE(mats && xs && ys && zs && frustum_feats && out, "null pointer");
+  const LiftParams P = to_params(d);
+  const long total = (long) d->B * d->Z * d->Y * d->X;
+  lift_fwd_dense_kernel<<<(unsigned) ((total + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      P, mats, xs, ys, zs, frustum_feats, out, hits);
+  return check_launch("lift_fwd_dense_kernel");
+}
+
+int vamp_lift_backward_dense(const VampLiftDesc* d, const float* mats, const float* xs,
+                             const float* ys, const float* zs, const float* grad_out,
+                             const uint64_t* hits, float* grad_frustum_feats, void* stream) {
+  if (int e = validate(d)) return e;
+  VAMP_REQUIRE(mats && xs && ys && zs && grad_out && hits && grad_frustum_feats, "null pointer");
+  const LiftParams P = to_params(d);
+  const long total = (long) d->B * d->Z * d->Y * d->X;
+  lift_bwd_dense_kernel<<<(unsigned) ((total + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      P, mats, xs, ys, zs, grad_out, hits, grad_frustum_feats);
+  return check_launch("lift_bwd_dense_kernel");
+}
+
+int vamp_lift_indices(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
+                      const float* zs, uint8_t* valid, int16_t* ix0, int16_t* iy0, int16_t* iz0,
+                      void* stream) {
+  if (int e = validate(d)) return e;
+  VAMP_REQUIRE(mats && xs && ys && zs && valid && ix0 && iy0 && iz0, "null pointer");
+  const LiftParams P = to_params(d);
+  const long total = (long) d->B * d->N * d->Z * d->Y * d->X;
+  lift_indices_kernel<<<(unsigned) ((total + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      P, mats, xs, ys, zs, valid, ix0, iy0, iz0);
+  return check_launch("lift_indices_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// Shared pieces of the camera / BEV render kernels.
+#pragma once
+#include "common.hpp"
+
+namespace vamp {
+
+struct RenderParams {
+  int B, N, D, fH, fW, K, C, Z, Y, X, oZ, oY, oX;
+  float lo[3], span[3];
+  float d_far, z_step;
+  int density_mode;
+  float sdf_bias, beta_min;
+  int cat_seg;
+  int CP;   // packed channels per voxel for the camera branch: 1 + K + 3 rounded up to 12/24/32
+};
+
+inline RenderParams to_params(const VampRenderDesc* d) {
+  RenderParams p;
+  p.B = d->B; p.N = d->N; p.D = d->D; p.fH = d->fH; p.fW = d->fW; p.K = d->K; p.C = d->C;
+  p.Z = d->Z; p.Y = d->Y; p.X = d->X; p.oZ = d->oZ; p.oY = d->oY; p.oX = d->oX;
+  for (int i = 0; i < 3; ++i) { p.lo[i] = d->lo[i]; p.span[i] = d->span[i]; }
+  p.d_far = d->d_far; p.z_step = d->z_step_det; p.density_mode = d->density_mode;
+  p.sdf_bias = d->sdf_bias; p.beta_min = d->beta_min; p.cat_seg = d->cat_seg;
+  // CP is chosen from {12, 24, 32} so that only three kernel bodies are compiled
+  const int need = 1 + d->K + 3;
+  p.CP = need <= 12 ? 12 : (need <= 24 ? 24 : 32);
+  return p;
+}
+
+inline int validate(const VampRenderDesc* d) {
+  VAMP_REQUIRE(d != nullptr, "desc is NULL");
+  VAMP_REQUIRE(d->B > 0 && d->N > 0, "B, N must be positive");
+  VAMP_REQUIRE(d->D > 1 && d->fH > 0 && d->fW > 0, "D > 1, fH, fW > 0");
+  VAMP_REQUIRE(d->K > 0 && d->K <= 28, "1 <= K <= 28");
+  VAMP_REQUIRE(d->C >= 0 && d->C <= 64, "0 <= C <= 64");
+  VAMP_REQUIRE(d->Z > 1 && d->Y > 1 && d->X > 1, "Z, Y, X > 1");
+  VAMP_REQUIRE(d->X < 32768 && d->Y < 32768 && d->Z < 32768, "axis too long for int16 taps");
+  VAMP_REQUIRE(d->density_mode == VAMP_DENSITY_SIGMOID ||
+               d->density_mode == VAMP_DENSITY_SDF_LAPLACE, "density_mode");
+  VAMP_REQUIRE(d->in_dtype == VAMP_F32 || d->in_dtype == VAMP_BF16, "in_dtype");
+  return VAMP_OK;
+}
+
+// One frustum point in the ego frame: get_geometry (bv2:328-349) followed by
+// nan_to_num(nan=-1e3) (bv2:612).  m = [inv(ida), sensor2ego @ inv(intrin), bda].
+__device__ __forceinline__ void frustum_point(const float* __restrict__ m, float u, float v,
+                                              float dd, float& x, float& y, float& z) {
+  Vec4 p{u, v, dd, 1.0f};
+  p = matvec(m, p);
+  p.x = p.x * p.z;
+  p.y = p.y * p.z;
+  p = matvec(m + 16, p);
+  p = matvec(m + 32, p);
+  x = p.x; y = p.y; z = p.z;
+}
+
+__device__ __forceinline__ float nan_to_num_geom(float v) {
+  // torch.nan_to_num(geom, -1e3): nan -> -1e3, +-inf -> +-FLT_MAX
+  if (v != v) return -1e3f;
+  return fminf(fmaxf(v, -3.402823466e+38f), 3.402823466e+38f);
+}
+
+// Normalise an ego point by the seg bounds (bv2:397-404), test the inclusive
+// inside mask (bv2:405-407) and unnormalise with aten's align_corners=True rule.
+struct VolTap {
+  bool inside;
+  int ix0, iy0, iz0;
+  float wx0, wx1, wy0, wy1, wz0, wz1;
+};
+
+__device__ __forceinline__ VolTap volume_tap(const RenderParams& P, float x, float y, float z) {
+  const float gx = ((x - P.lo[0]) / P.span[0]) * 2.0f - 1.0f;
+  const float gy = ((y - P.lo[1]) / P.span[1]) * 2.0f - 1.0f;
+  const float gz = ((z - P.lo[2]) / P.span[2]) * 2.0f - 1.0f;
+  VolTap t;
+  t.inside = (gx >= -1.0f) && (gx <= 1.0f) && (gy >= -1.0f) && (gy <= 1.0f) &&
+             (gz >= -1.0f) && (gz <= 1.0f);
+  const float fx = ((gx + 1.0f) / 2.0f) * (float) (P.X - 1);
+  const float fy = ((gy + 1.0f) / 2.0f) * (float) (P.Y - 1);
+  const float fz = ((gz + 1.0f) / 2.0f) * (float) (P.Z - 1);
+  const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+  t.ix0 = (int) flx; t.iy0 = (int) fly; t.iz0 = (int) flz;
+  t.wx1 = fx - flx; t.wx0 = (flx + 1.0f) - fx;
+  t.wy1 = fy - fly; t.wy0 = (fly + 1.0f) - fy;
+  t.wz1 = fz - flz; t.wz0 = (flz + 1.0f) - fz;
+  return t;
+}
+
+}  // namespace vamp

@@ -1,0 +1,410 @@
+// RENDER forward kernels for gfx950.  Reference call site:
+// volume_rendering_from_multiple_views, base_vampire2.py:391-467.
+//
+//  pack_volume         [B,c,Z,Y,X] x3  ->  channel-last [B,Z,Y,X,CP] (density, sem, rgb)
+//  render_cam_fwd      LPR lanes per ray march the D-1 samples; each sample is one
+//                      8-tap gather of CP contiguous floats; per-lane partial
+//                      composites are merged with wave shuffles
+//  render_bev_fwd      one thread per det-grid column, reads the channel-first volumes
+//                      directly (lanes along x -> coalesced)
+// HBM/L2-bound gathers and a short scan: no MFMA.
+#include "render_common.hpp"
+
+namespace vamp {
+
+// ---------------------------------------------------------------------------
+// pack: thread per voxel, CP/4 float4 stores (lanes contiguous -> coalesced)
+// ---------------------------------------------------------------------------
+template <typename T, int CP4>
+__global__ void __launch_bounds__(256)
+pack_volume_kernel(RenderParams P, const T* __restrict__ dens, const T* __restrict__ sem,
+                   const T* __restrict__ rgb, float* __restrict__ packed) {
+  const long V = (long) P.Z * P.Y * P.X;
+  const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= V * P.B) return;
+  const long b = gid / V, vox = gid % V;
+  float v[CP4 * 4];
+#pragma unroll
+  for (int c = 0; c < CP4 * 4; ++c) {
+    float val = 0.f;
+    if (c == 0) val = ldf(dens, b * V + vox);
+    else if (c <= P.K) val = ldf(sem, (b * P.K + (c - 1)) * V + vox);
+    else if (c <= P.K + 3) val = ldf(rgb, (b * 3 + (c - 1 - P.K)) * V + vox);
+    v[c] = val;
+  }
+  float4* dst = reinterpret_cast<float4*>(packed + gid * (CP4 * 4));
+#pragma unroll
+  for (int q = 0; q < CP4; ++q) dst[q] = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
+}
+
+// ---------------------------------------------------------------------------
+// camera branch forward
+// ---------------------------------------------------------------------------
+template <int LPR, int CP4>
+__global__ void __launch_bounds__(256)
+render_cam_fwd_kernel(RenderParams P, const float* __restrict__ geom, const float* __restrict__ mats,
+                      const float* __restrict__ us, const float* __restrict__ vs,
+                      const float* __restrict__ ds, const float* __restrict__ mids,
+                      const float* __restrict__ beta_raw, const float* __restrict__ packed,
+                      float* __restrict__ rgb_out, float* __restrict__ seg_out,
+                      float* __restrict__ depth_out) {
+  constexpr int CP = CP4 * 4;
+  const long t = (long) blockIdx.x * blockDim.x + threadIdx.x;
+  const long nrays = (long) P.B * P.N * P.fH * P.fW;
+  long ray = t / LPR;
+  const int sub = (int) (t % LPR);
+  const bool live = ray < nrays;
+  if (!live) ray = nrays - 1;           // keep the lane for the shuffles, drop its store
+  const int w = ray % P.fW;
+  const int h = (ray / P.fW) % P.fH;
+  const long bn = ray / ((long) P.fW * P.fH);
+  const int b = bn / P.N;
+
+  const DensityParams dp = load_density(P.density_mode, beta_raw, P.beta_min, P.sdf_bias);
+  const int S = P.D - 1;
+  const int L = (S + LPR - 1) / LPR;
+  const int i0 = sub * L, i1 = min(S, i0 + L);
+  const float* m = mats ? mats + bn * 48 : nullptr;
+  const float u = us[w], v = vs[h];
+  const long V = (long) P.Z * P.Y * P.X;
+  const float* vol = packed + (long) b * V * CP;
+  const long pstride = (long) P.fH * P.fW * 3;     // geom plane stride
+  const float* gp = geom ? geom + ((bn * P.D * P.fH + h) * P.fW + w) * 3 : nullptr;
+
+  float px, py, pz;
+  auto point = [&](int i, float& x, float& y, float& z) {
+    if (gp) {
+      const float* q = gp + (long) i * pstride;
+      x = q[0]; y = q[1]; z = q[2];
+    } else {
+      frustum_point(m, u, v, ds[i], x, y, z);
+      x = nan_to_num_geom(x); y = nan_to_num_geom(y); z = nan_to_num_geom(z);
+    }
+  };
+  if (i0 < i1) point(i0, px, py, pz);
+
+  float acc[CP];                         // acc[0] = sum of weights, acc[1..K+3] = sem / rgb sums
+#pragma unroll
+  for (int c = 0; c < CP; ++c) acc[c] = 0.f;
+  float acc_depth = 0.f, cum = 0.f;
+
+  for (int i = i0; i < i1; ++i) {
+    float qx, qy, qz;
+    point(i + 1, qx, qy, qz);
+    const VolTap tp = volume_tap(P, px, py, pz);
+    float s[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) s[c] = 0.f;
+    if (tp.inside) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int iz = tp.iz0 + (k >> 2), iy = tp.iy0 + ((k >> 1) & 1), ix = tp.ix0 + (k & 1);
+        if (iz >= P.Z || iy >= P.Y || ix >= P.X) continue;    // inside => taps >= 0
+        const float wt = ((k & 1) ? tp.wx1 : tp.wx0) * ((k & 2) ? tp.wy1 : tp.wy0) *
+                         ((k & 4) ? tp.wz1 : tp.wz0);
+        const float4* f4 = reinterpret_cast<const float4*>(
+            vol + (((long) iz * P.Y + iy) * P.X + ix) * CP);
+#pragma unroll
+        for (int q = 0; q < CP4; ++q) {
+          const float4 f = f4[q];
+          s[q * 4 + 0] = __builtin_fmaf(wt, f.x, s[q * 4 + 0]);
+          s[q * 4 + 1] = __builtin_fmaf(wt, f.y, s[q * 4 + 1]);
+          s[q * 4 + 2] = __builtin_fmaf(wt, f.z, s[q * 4 + 2]);
+          s[q * 4 + 3] = __builtin_fmaf(wt, f.w, s[q * 4 + 3]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CP; ++c) s[c] = nan_to_num(s[c]);       // bv2:421
+    }
+    const float sigma = density_fwd(dp, s[0]);                    // masked sample -> density(0)
+    const float dx = qx - px, dy = qy - py, dz = qz - pz;
+    const float delta = sqrtf(dx * dx + dy * dy + dz * dz);       // bv2:426
+    const float tau = sigma * delta;
+    const float wgt = (1.0f - expf(-tau)) * expf(-cum);           // bv2:430-434
+    cum += tau;
+    acc[0] += wgt;
+    acc_depth = __builtin_fmaf(wgt, mids[i], acc_depth);
+#pragma unroll
+    for (int c = 1; c < CP; ++c) acc[c] = __builtin_fmaf(wgt, s[c], acc[c]);
+    px = qx; py = qy; pz = qz;
+  }
+
+  if (LPR > 1) {
+    // transmittance of everything in front of this lane's chunk
+    float incl = cum;
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) {
+      const float up = __shfl_up(incl, o, LPR);
+      if (sub >= o) incl += up;
+    }
+    float excl = __shfl_up(incl, 1, LPR);
+    if (sub == 0) excl = 0.f;
+    const float scale = expf(-excl);
+    acc_depth *= scale;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) acc[c] *= scale;
+#pragma unroll
+    for (int o = LPR >> 1; o > 0; o >>= 1) {
+      acc_depth += __shfl_down(acc_depth, o, LPR);
+#pragma unroll
+      for (int c = 0; c < CP; ++c) acc[c] += __shfl_down(acc[c], o, LPR);
+    }
+  }
+  if (!live || sub != 0) return;
+  const long HW = (long) P.fH * P.fW;
+  const long pix = (long) h * P.fW + w;
+  depth_out[bn * HW + pix] = acc_depth + (1.0f - acc[0]) * P.d_far;   // bv2:436,440
+#pragma unroll
+  for (int c = 1; c < CP; ++c) {
+    if (c <= P.K) seg_out[(bn * P.K + (c - 1)) * HW + pix] = acc[c];
+    else if (c <= P.K + 3) rgb_out[(bn * 3 + (c - 1 - P.K)) * HW + pix] = acc[c];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// BEV branch forward: thread per (b, y, x) column, top-down over oZ samples.
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float sample_cf(const RenderParams& P, const T* __restrict__ vol,
+                                           long chan_base, const VolTap& t) {
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int iz = t.iz0 + (k >> 2), iy = t.iy0 + ((k >> 1) & 1), ix = t.ix0 + (k & 1);
+    if (iz < 0 || iz >= P.Z || iy < 0 || iy >= P.Y || ix < 0 || ix >= P.X) continue;
+    const float wt = ((k & 1) ? t.wx1 : t.wx0) * ((k & 2) ? t.wy1 : t.wy0) *
+                     ((k & 4) ? t.wz1 : t.wz0);
+    s = __builtin_fmaf(wt, ldf(vol, chan_base + ((long) iz * P.Y + iy) * P.X + ix), s);
+  }
+  return s;
+}
+
+constexpr int kMaxK = 28;
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+render_bev_fwd_kernel(RenderParams P, const float* __restrict__ oxs, const float* __restrict__ oys,
+                      const float* __restrict__ ozs, const float* __restrict__ bev_mids,
+                      const float* __restrict__ beta_raw, const T* __restrict__ dens,
+                      const T* __restrict__ sem, const T* __restrict__ rgb,
+                      const T* __restrict__ base, float* __restrict__ bev_rgb,
+                      float* __restrict__ bev_seg, float* __restrict__ bev_height,
+                      float* __restrict__ voxel_density, float* __restrict__ voxel_output) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  const int b = blockIdx.z;
+  if (x >= P.oX) return;
+  const DensityParams dp = load_density(P.density_mode, beta_raw, P.beta_min, P.sdf_bias);
+  const long V = (long) P.Z * P.Y * P.X;
+  const long OYX = (long) P.oY * P.oX;
+  const long col = (long) y * P.oX + x;
+  const int CO = P.C + (P.cat_seg ? P.K : 0);
+  const float ox = oxs[x], oy = oys[y];
+
+  float seg[kMaxK];
+#pragma unroll
+  for (int k = 0; k < kMaxK; ++k) seg[k] = 0.f;
+  float col_rgb[3] = {0.f, 0.f, 0.f};
+  float height = 0.f, cum = 0.f;
+
+  for (int j = 0; j < P.oZ; ++j) {
+    const int zi = P.oZ - 1 - j;                                   // flip (bv2:443)
+    const VolTap t = volume_tap(P, ox, oy, ozs[zi]);
+    const float s0 = sample_cf(P, dens, (long) b * V, t);
+    const float sigma = density_fwd(dp, s0);
+    voxel_density[((long) b * P.oZ + j) * OYX + col] = sigma;
+    const float tau = sigma * (1.0f * P.z_step);                   // bv2:451-453
+    const float wgt = (1.0f - expf(-tau)) * expf(-cum);
+    cum += tau;
+    height = __builtin_fmaf(wgt, bev_mids[j], height);
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k) {
+      if (k < P.K) {
+        const float sv = sample_cf(P, sem, ((long) b * P.K + k) * V, t);
+        seg[k] = __builtin_fmaf(wgt, sv, seg[k]);
+        if (P.cat_seg)
+          voxel_output[(((long) b * CO + P.C + k) * P.oZ + j) * OYX + col] = sv;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      col_rgb[c] = __builtin_fmaf(wgt, sample_cf(P, rgb, ((long) b * 3 + c) * V, t), col_rgb[c]);
+    for (int c = 0; c < P.C; ++c)
+      voxel_output[(((long) b * CO + c) * P.oZ + j) * OYX + col] =
+          sample_cf(P, base, ((long) b * P.C + c) * V, t);
+  }
+  bev_height[(long) b * OYX + col] = height;
+#pragma unroll
+  for (int k = 0; k < kMaxK; ++k)
+    if (k < P.K) bev_seg[((long) b * P.K + k) * OYX + col] = seg[k];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) bev_rgb[((long) b * 3 + c) * OYX + col] = col_rgb[c];
+}
+
+// ---------------------------------------------------------------------------
+// diagnostics + standalone geometry
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+render_indices_kernel(RenderParams P, const float* __restrict__ geom, const float* __restrict__ mats,
+                      const float* __restrict__ us, const float* __restrict__ vs,
+                      const float* __restrict__ ds, uint8_t* __restrict__ inside,
+                      int16_t* __restrict__ ix0, int16_t* __restrict__ iy0,
+                      int16_t* __restrict__ iz0) {
+  const long HW = (long) P.fH * P.fW;
+  const long total = (long) P.B * P.N * (P.D - 1) * HW;
+  const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  const int w = gid % P.fW, h = (gid / P.fW) % P.fH;
+  const int i = (gid / HW) % (P.D - 1);
+  const long bn = gid / (HW * (P.D - 1));
+  float x, y, z;
+  if (geom) {
+    const float* q = geom + (((bn * P.D + i) * P.fH + h) * P.fW + w) * 3;
+    x = q[0]; y = q[1]; z = q[2];
+  } else {
+    frustum_point(mats + bn * 48, us[w], vs[h], ds[i], x, y, z);
+    x = nan_to_num_geom(x); y = nan_to_num_geom(y); z = nan_to_num_geom(z);
+  }
+  const VolTap t = volume_tap(P, x, y, z);
+  inside[gid] = t.inside ? 1 : 0;
+  ix0[gid] = t.inside ? (int16_t) t.ix0 : 0;
+  iy0[gid] = t.inside ? (int16_t) t.iy0 : 0;
+  iz0[gid] = t.inside ? (int16_t) t.iz0 : 0;
+}
+
+__global__ void __launch_bounds__(256)
+frustum_geometry_kernel(RenderParams P, const float* __restrict__ mats, const float* __restrict__ us,
+                        const float* __restrict__ vs, const float* __restrict__ ds,
+                        float* __restrict__ geom) {
+  const long HW = (long) P.fH * P.fW;
+  const long total = (long) P.B * P.N * P.D * HW;
+  const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  const int w = gid % P.fW, h = (gid / P.fW) % P.fH;
+  const int i = (gid / HW) % P.D;
+  const long bn = gid / (HW * P.D);
+  float x, y, z;
+  frustum_point(mats + bn * 48, us[w], vs[h], ds[i], x, y, z);
+  geom[gid * 3 + 0] = nan_to_num_geom(x);
+  geom[gid * 3 + 1] = nan_to_num_geom(y);
+  geom[gid * 3 + 2] = nan_to_num_geom(z);
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+int launch_pack(const RenderParams& P, int in_dtype, const void* dens, const void* sem,
+                const void* rgb, float* packed, hipStream_t s) {
+  const long total = (long) P.B * P.Z * P.Y * P.X;
+  const unsigned grid = (unsigned) ((total + 255) / 256);
+#define VAMP_PACK(T, CP4)                                                                  \
+  pack_volume_kernel<T, CP4><<<grid, 256, 0, s>>>(P, static_cast<const T*>(dens),          \
+                                                  static_cast<const T*>(sem),              \
+                                                  static_cast<const T*>(rgb), packed)
+  if (in_dtype == VAMP_F32) {
+    if (P.CP == 12) VAMP_PACK(float, 3); else if (P.CP == 24) VAMP_PACK(float, 6); else VAMP_PACK(float, 8);
+  } else {
+    if (P.CP == 12) VAMP_PACK(__hip_bfloat16, 3); else if (P.CP == 24) VAMP_PACK(__hip_bfloat16, 6); else VAMP_PACK(__hip_bfloat16, 8);
+  }
+#undef VAMP_PACK
+  return check_launch("pack_volume_kernel");
+}
+
+}  // namespace vamp
+
+using namespace vamp;
+
+namespace vamp {
+size_t packed_bytes(const VampRenderDesc* d) {
+  const RenderParams P = to_params(d);
+  return align_up((size_t) d->B * d->Z * d->Y * d->X * P.CP * sizeof(float), 256);
+}
+}  // namespace vamp
+
+extern "C" {
+
+size_t vamp_render_workspace_bytes(const VampRenderDesc* d) {
+  if (!d) return 0;
+  return 2 * packed_bytes(d);   // packed volume + packed gradient volume (backward)
+}
+
+int vamp_render_camera_forward(const VampRenderDesc* d, const float* geom, const float* mats,
+                               const float* us, const float* vs, const float* ds,
+                               const float* mids, const float* beta, const void* density_feature,
+                               const void* semantic, const void* rgb, float* rgb_out,
+                               float* seg_out, float* depth_out, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  VAMP_REQUIRE(geom || (mats && us && vs && ds), "need geom or (mats, us, vs, ds)");
+  VAMP_REQUIRE(mids && density_feature && semantic && rgb && rgb_out && seg_out && depth_out,
+               "null pointer");
+  VAMP_REQUIRE(beta || d->density_mode == VAMP_DENSITY_SIGMOID, "beta is NULL");
+  const size_t need = packed_bytes(d);
+  if (!workspace || workspace_bytes < need)
+    return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) need);
+  const RenderParams P = to_params(d);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* packed = static_cast<float*>(workspace);
+  if (int e = launch_pack(P, d->in_dtype, density_feature, semantic, rgb, packed, s)) return e;
+  constexpr int LPR = 4;
+  const long threads = (long) d->B * d->N * d->fH * d->fW * LPR;
+  const unsigned grid = (unsigned) ((threads + 255) / 256);
+#define VAMP_CAM(CP4)                                                                        \
+  render_cam_fwd_kernel<LPR, CP4><<<grid, 256, 0, s>>>(P, geom, mats, us, vs, ds, mids, beta, \
+                                                       packed, rgb_out, seg_out, depth_out)
+  if (P.CP == 12) VAMP_CAM(3); else if (P.CP == 24) VAMP_CAM(6); else VAMP_CAM(8);
+#undef VAMP_CAM
+  return check_launch("render_cam_fwd_kernel");
+}
+
+int vamp_render_bev_forward(const VampRenderDesc* d, const float* oxs, const float* oys,
+                            const float* ozs, const float* bev_mids, const float* beta,
+                            const void* density_feature, const void* semantic, const void* rgb,
+                            const void* base, float* bev_rgb, float* bev_seg, float* bev_height,
+                            float* voxel_density, float* voxel_output, void* stream) {
+  if (int e = validate(d)) return e;
+  VAMP_REQUIRE(d->oZ > 0 && d->oY > 0 && d->oX > 0, "det grid must be non-empty");
+  VAMP_REQUIRE(oxs && oys && ozs && bev_mids && density_feature && semantic && rgb, "null pointer");
+  VAMP_REQUIRE(base || d->C == 0, "base is NULL");
+  VAMP_REQUIRE(bev_rgb && bev_seg && bev_height && voxel_density && voxel_output, "null output");
+  VAMP_REQUIRE(beta || d->density_mode == VAMP_DENSITY_SIGMOID, "beta is NULL");
+  RenderParams P = to_params(d);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dim3 grid((d->oX + 63) / 64, d->oY, d->B);
+  if (d->in_dtype == VAMP_F32)
+    render_bev_fwd_kernel<float><<<grid, 64, 0, s>>>(
+        P, oxs, oys, ozs, bev_mids, beta, (const float*) density_feature, (const float*) semantic,
+        (const float*) rgb, (const float*) base, bev_rgb, bev_seg, bev_height, voxel_density, voxel_output);
+  else
+    render_bev_fwd_kernel<__hip_bfloat16><<<grid, 64, 0, s>>>(
+        P, oxs, oys, ozs, bev_mids, beta, (const __hip_bfloat16*) density_feature,
+        (const __hip_bfloat16*) semantic, (const __hip_bfloat16*) rgb, (const __hip_bfloat16*) base,
+        bev_rgb, bev_seg, bev_height, voxel_density, voxel_output);
+  return check_launch("render_bev_fwd_kernel");
+}
+
+int vamp_render_indices(const VampRenderDesc* d, const float* geom, const float* mats,
+                        const float* us, const float* vs, const float* ds, uint8_t* inside,
+                        int16_t* ix0, int16_t* iy0, int16_t* iz0, void* stream) {
+  if (int e = validate(d)) return e;
+  VAMP_REQUIRE(geom || (mats && us && vs && ds), "need geom or (mats, us, vs, ds)");
+  VAMP_REQUIRE(inside && ix0 && iy0 && iz0, "null output");
+  RenderParams P = to_params(d);
+  const long total = (long) d->B * d->N * (d->D - 1) * d->fH * d->fW;
+  render_indices_kernel<<<(unsigned) ((total + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      P, geom, mats, us, vs, ds, inside, ix0, iy0, iz0);
+  return check_launch("render_indices_kernel");
+}
+
+int vamp_frustum_geometry(const VampRenderDesc* d, const float* mats, const float* us,
+                          const float* vs, const float* ds, float* geom, void* stream) {
+  if (int e = validate(d)) return e;
+  VAMP_REQUIRE(mats && us && vs && ds && geom, "null pointer");
+  RenderParams P = to_params(d);
+  const long total = (long) d->B * d->N * d->D * d->fH * d->fW;
+  frustum_geometry_kernel<<<(unsigned) ((total + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      P, mats, us, vs, ds, geom);
+  return check_launch("frustum_geometry_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,340 @@
+"""Host-side operators of the lift + render hot path (Python over the C ABI).
+
+`HotPath` owns the per-configuration device constants (axis arrays, descriptors)
+and exposes the operators with autograd support:
+
+  lift(depth, feat, lift_mats)                       ~ bv2:550-553 + get_voxel_feats
+  lift_dense(frustum_feats, lift_mats)               ~ get_voxel_feats signature (bv2:483)
+  render(geom|render_mats, density_feature, semantic_logits, base, rgb, beta)
+                                                     ~ volume_rendering_from_multiple_views (bv2:391)
+
+All heavy work happens in hand-written HIP kernels reached through ctypes
+(`_capi`); torch supplies device memory and the current stream only.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from .config import PathConfig
+from . import geometry as G
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return _capi.VAMP_F32
+    if t.dtype == torch.bfloat16:
+        return _capi.VAMP_BF16
+    raise TypeError(f"unsupported dtype {t.dtype}: the hot path takes fp32 or bf16 inputs")
+
+
+def _chk(t: torch.Tensor, shape, name):
+    if not t.is_cuda:
+        raise _capi.VampireHipError(f"{name} must be a device tensor (no CPU fallback)")
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t.contiguous()
+
+
+class HotPath:
+    """Device constants + operators for one PathConfig on one device."""
+
+    def __init__(self, cfg: PathConfig, device="cuda"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.lib = _capi.load()
+        geo = G.PathGeometry(cfg)
+        dev = self.device
+        f32 = torch.float32
+        # axis arrays (the kernels rebuild points from these; bit-identical to the buffers)
+        self.xs = G.axis_centres(cfg.x_bound_seg).to(dev)
+        self.ys = G.axis_centres(cfg.y_bound_seg).to(dev)
+        self.zs = G.axis_centres(cfg.z_bound_seg).to(dev)
+        self.oxs = G.axis_centres(cfg.x_bound_det).to(dev)
+        self.oys = G.axis_centres(cfg.y_bound_det).to(dev)
+        self.ozs = G.axis_centres(cfg.z_bound_det).to(dev)
+        self.us = geo.frustum[0, 0, :, 0].contiguous().to(dev)
+        self.vs = geo.frustum[0, :, 0, 1].contiguous().to(dev)
+        self.ds = geo.frustum[:, 0, 0, 2].contiguous().to(dev)
+        self.camera_mids = geo.camera_mids.to(dev)
+        self.bev_mids = geo.bev_mids.to(dev)
+        self._ws = {}
+
+    # ---------------------------------------------------------------- descs
+    def lift_desc(self, B, N, C_, dtype_code, use_depth=True) -> _capi.VampLiftDesc:
+        c = self.cfg
+        d = _capi.VampLiftDesc()
+        d.B, d.N, d.C = B, N, C_
+        d.D, d.fH, d.fW = (c.D if use_depth else 1), c.fH, c.fW
+        d.Z, d.Y, d.X = c.vZ, c.vY, c.vX
+        d.u_max, d.v_max = float(c.final_dim[1] - 0.5), float(c.final_dim[0] - 0.5)
+        d.u_div, d.v_div = float(c.final_dim[1] - 1), float(c.final_dim[0] - 1)
+        d.d_lo, d.d_hi = c.d_bound[0], c.d_bound[1]
+        d.d_span = c.d_bound[1] - c.d_bound[0]          # python double -> fp32, as torch does
+        d.use_depth = 1 if use_depth else 0
+        d.in_dtype = dtype_code
+        return d
+
+    def render_desc(self, B, N, dtype_code, C_=None) -> _capi.VampRenderDesc:
+        c = self.cfg
+        d = _capi.VampRenderDesc()
+        d.B, d.N = B, N
+        d.D, d.fH, d.fW = c.D, c.fH, c.fW
+        d.K, d.C = c.num_classes, (c.mid_channels if C_ is None else C_)
+        d.Z, d.Y, d.X = c.vZ, c.vY, c.vX
+        d.oZ, d.oY, d.oX = c.oZ, c.oY, c.oX
+        bounds = (c.x_bound_seg, c.y_bound_seg, c.z_bound_seg)
+        for i, b in enumerate(bounds):
+            d.lo[i] = b[0]
+            d.span[i] = b[1] - b[0]
+        d.d_far = c.d_bound[1]
+        d.z_step_det = c.z_bound_det[2]
+        d.density_mode = (_capi.VAMP_DENSITY_SDF_LAPLACE if c.density_mode == "sdf"
+                          else _capi.VAMP_DENSITY_SIGMOID)
+        d.sdf_bias = c.sdf_bias
+        d.beta_min = 1e-4
+        d.cat_seg = 1 if c.cat_seg else 0
+        d.in_dtype = dtype_code
+        return d
+
+    def _workspace(self, key, nbytes):
+        t = self._ws.get(key)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+            self._ws[key] = t
+        return t
+
+    # ----------------------------------------------------------------- lift
+    def lift(self, depth, feat, lift_mats, use_depth=True):
+        """depth [B,N,D,fH,fW], feat [B,N,C,fH,fW], lift_mats [B,N,3,4,4] -> [B,C,Z,Y,X]."""
+        return _LiftFn.apply(self, depth, feat, lift_mats, use_depth)
+
+    def lift_dense(self, frustum_feats, lift_mats):
+        """frustum_feats [B,N,C,D,fH,fW] (materialised, fp32) -> [B,C,Z,Y,X]."""
+        return _LiftDenseFn.apply(self, frustum_feats, lift_mats)
+
+    def lift_indices(self, lift_mats, use_depth=True):
+        c = self.cfg
+        B, N = lift_mats.shape[:2]
+        d = self.lift_desc(B, N, 4, _capi.VAMP_F32, use_depth)
+        shp = (B, N, c.vZ, c.vY, c.vX)
+        valid = torch.empty(shp, dtype=torch.uint8, device=self.device)
+        ix0, iy0, iz0 = (torch.empty(shp, dtype=torch.int16, device=self.device) for _ in range(3))
+        mats = _chk(lift_mats.float(), (B, N, 3, 4, 4), "lift_mats")
+        _capi.check(self.lib.vamp_lift_indices(C.byref(d), _ptr(mats), _ptr(self.xs), _ptr(self.ys),
+                                               _ptr(self.zs), _ptr(valid), _ptr(ix0), _ptr(iy0),
+                                               _ptr(iz0), _stream()), "vamp_lift_indices")
+        return valid, ix0, iy0, iz0
+
+    # --------------------------------------------------------------- render
+    def frustum_geometry(self, render_mats):
+        c = self.cfg
+        B, N = render_mats.shape[:2]
+        d = self.render_desc(B, N, _capi.VAMP_F32)
+        mats = _chk(render_mats.float(), (B, N, 3, 4, 4), "render_mats")
+        geom = torch.empty(B, N, c.D, c.fH, c.fW, 3, dtype=torch.float32, device=self.device)
+        _capi.check(self.lib.vamp_frustum_geometry(C.byref(d), _ptr(mats), _ptr(self.us), _ptr(self.vs),
+                                                   _ptr(self.ds), _ptr(geom), _stream()),
+                    "vamp_frustum_geometry")
+        return geom
+
+    def render_indices(self, geom=None, render_mats=None):
+        c = self.cfg
+        src = geom if geom is not None else render_mats
+        B, N = src.shape[:2]
+        d = self.render_desc(B, N, _capi.VAMP_F32)
+        shp = (B, N, c.D - 1, c.fH, c.fW)
+        inside = torch.empty(shp, dtype=torch.uint8, device=self.device)
+        ix0, iy0, iz0 = (torch.empty(shp, dtype=torch.int16, device=self.device) for _ in range(3))
+        g = None if geom is None else _chk(geom.float(), (B, N, c.D, c.fH, c.fW, 3), "geom")
+        m = None if render_mats is None else _chk(render_mats.float(), (B, N, 3, 4, 4), "render_mats")
+        _capi.check(self.lib.vamp_render_indices(C.byref(d), _ptr(g), _ptr(m), _ptr(self.us),
+                                                 _ptr(self.vs), _ptr(self.ds), _ptr(inside), _ptr(ix0),
+                                                 _ptr(iy0), _ptr(iz0), _stream()), "vamp_render_indices")
+        return inside, ix0, iy0, iz0
+
+    def render(self, density_feature, semantic_logits, base, rgb, beta=None, *, geom=None,
+               render_mats=None):
+        """The reference's 8-tuple (bv2:462-467).  Give either ``geom`` [B,N,D,fH,fW,3]
+        (API-compatible) or ``render_mats`` [B,N,3,4,4] (geometry evaluated in-kernel)."""
+        if (geom is None) == (render_mats is None):
+            raise ValueError("give exactly one of geom / render_mats")
+        if beta is None:
+            beta = torch.zeros((), device=self.device)
+            if self.cfg.density_mode == "sdf":
+                raise ValueError("density_mode='sdf' needs the beta parameter")
+        return _RenderFn.apply(self, density_feature, semantic_logits, base, rgb, beta, geom,
+                               render_mats)
+
+
+# ===========================================================================
+# autograd glue
+# ===========================================================================
+class _LiftFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hp: HotPath, depth, feat, mats, use_depth):
+        c = hp.cfg
+        B, N, C_ = feat.shape[:3]
+        code = _dtype_code(feat)
+        d = hp.lift_desc(B, N, C_, code, use_depth)
+        feat = _chk(feat, (B, N, C_, c.fH, c.fW), "feat")
+        if use_depth:
+            depth = _chk(depth, (B, N, c.D, c.fH, c.fW), "depth")
+            if depth.dtype != feat.dtype:
+                raise TypeError("depth and feat must share a dtype")
+        mats = _chk(mats.float(), (B, N, 3, 4, 4), "lift_mats")
+        out = torch.empty(B, C_, c.vZ, c.vY, c.vX, dtype=torch.float32, device=feat.device)
+        need_grad = feat.requires_grad or (use_depth and depth.requires_grad)
+        nchunk = (C_ + 15) // 16
+        hits = (torch.empty(B, c.vZ, c.vY, c.vX, nchunk, dtype=torch.int64, device=feat.device)
+                if need_grad else None)
+        nbytes = hp.lib.vamp_lift_workspace_bytes(C.byref(d))
+        ws = hp._workspace("lift", nbytes)
+        _capi.check(hp.lib.vamp_lift_forward(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys), _ptr(hp.zs),
+                                             _ptr(depth if use_depth else None), _ptr(feat), _ptr(out),
+                                             _ptr(hits), _ptr(ws), ws.numel(), _stream()),
+                    "vamp_lift_forward")
+        if need_grad:
+            ctx.hp, ctx.desc, ctx.use_depth = hp, d, use_depth
+            ctx.save_for_backward(depth if use_depth else feat, feat, mats, hits)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        hp, d, use_depth = ctx.hp, ctx.desc, ctx.use_depth
+        depth, feat, mats, hits = ctx.saved_tensors
+        g = g.contiguous().float()
+        gfeat = torch.empty(feat.shape, dtype=torch.float32, device=feat.device)
+        gdepth = (torch.empty(depth.shape, dtype=torch.float32, device=feat.device)
+                  if use_depth else None)
+        nbytes = hp.lib.vamp_lift_workspace_bytes(C.byref(d))
+        ws = hp._workspace("lift", nbytes)
+        _capi.check(hp.lib.vamp_lift_backward(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys), _ptr(hp.zs),
+                                              _ptr(depth if use_depth else None), _ptr(feat), _ptr(g),
+                                              _ptr(hits), _ptr(gdepth), _ptr(gfeat), _ptr(ws),
+                                              ws.numel(), _stream()), "vamp_lift_backward")
+        gd = gdepth.to(depth.dtype) if use_depth else None
+        return None, gd, gfeat.to(feat.dtype), None, None
+
+
+class _LiftDenseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hp: HotPath, ff, mats):
+        c = hp.cfg
+        B, N, C_, D = ff.shape[:4]
+        use_depth = D > 1
+        d = hp.lift_desc(B, N, C_, _capi.VAMP_F32, use_depth)
+        d.D = D
+        ff = _chk(ff.float(), (B, N, C_, D, c.fH, c.fW), "frustum_feats")
+        mats = _chk(mats.float(), (B, N, 3, 4, 4), "lift_mats")
+        out = torch.empty(B, C_, c.vZ, c.vY, c.vX, dtype=torch.float32, device=ff.device)
+        nchunk = (C_ + 15) // 16
+        hits = (torch.empty(B, c.vZ, c.vY, c.vX, nchunk, dtype=torch.int64, device=ff.device)
+                if ff.requires_grad else None)
+        _capi.check(hp.lib.vamp_lift_forward_dense(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys),
+                                                   _ptr(hp.zs), _ptr(ff), _ptr(out), _ptr(hits),
+                                                   _stream()), "vamp_lift_forward_dense")
+        if ff.requires_grad:
+            ctx.hp, ctx.desc, ctx.shape = hp, d, ff.shape
+            ctx.save_for_backward(mats, hits)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        hp, d = ctx.hp, ctx.desc
+        mats, hits = ctx.saved_tensors
+        g = g.contiguous().float()
+        gff = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        _capi.check(hp.lib.vamp_lift_backward_dense(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys),
+                                                    _ptr(hp.zs), _ptr(g), _ptr(hits), _ptr(gff),
+                                                    _stream()), "vamp_lift_backward_dense")
+        return None, gff, None
+
+
+class _RenderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hp: HotPath, dens, sem, base, rgb, beta, geom, mats):
+        c = hp.cfg
+        B = dens.shape[0]
+        N = (geom if geom is not None else mats).shape[1]
+        C_ = base.shape[1]
+        code = _dtype_code(dens)
+        for t in (sem, base, rgb):
+            if t.dtype != dens.dtype:
+                raise TypeError("the four volumes must share a dtype")
+        d = hp.render_desc(B, N, code, C_)
+        vshape = (c.vZ, c.vY, c.vX)
+        dens = _chk(dens, (B, 1) + vshape, "density_feature")
+        sem = _chk(sem, (B, c.num_classes) + vshape, "semantic_logits")
+        base = _chk(base, (B, C_) + vshape, "voxel_features")
+        rgb = _chk(rgb, (B, 3) + vshape, "rgb")
+        if geom is not None:
+            geom = _chk(geom.float(), (B, N, c.D, c.fH, c.fW, 3), "geom_xyz")
+        else:
+            mats = _chk(mats.float(), (B, N, 3, 4, 4), "render_mats")
+        ctx.beta_shape = beta.shape
+        beta = beta.reshape(1).float().contiguous()
+        dev, f32 = dens.device, torch.float32
+        K = c.num_classes
+        rgb_p = torch.empty(B, N, 3, c.fH, c.fW, dtype=f32, device=dev)
+        seg_p = torch.empty(B, N, K, c.fH, c.fW, dtype=f32, device=dev)
+        dep_p = torch.empty(B, N, 1, c.fH, c.fW, dtype=f32, device=dev)
+        nbytes = hp.lib.vamp_render_workspace_bytes(C.byref(d))
+        ws = hp._workspace("render", nbytes)
+        _capi.check(hp.lib.vamp_render_camera_forward(
+            C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
+            _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
+            _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(), _stream()), "vamp_render_camera_forward")
+        CO = C_ + (K if c.cat_seg else 0)
+        bev_rgb = torch.empty(B, 3, c.oY, c.oX, dtype=f32, device=dev)
+        bev_seg = torch.empty(B, K, c.oY, c.oX, dtype=f32, device=dev)
+        bev_h = torch.empty(B, 1, c.oY, c.oX, dtype=f32, device=dev)
+        vdens = torch.empty(B, 1, c.oZ, c.oY, c.oX, dtype=f32, device=dev)
+        vout = torch.empty(B, CO, c.oZ, c.oY, c.oX, dtype=f32, device=dev)
+        _capi.check(hp.lib.vamp_render_bev_forward(
+            C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
+            _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
+            _ptr(vdens), _ptr(vout), _stream()), "vamp_render_bev_forward")
+        ctx.hp, ctx.desc = hp, d
+        ctx.has_geom = geom is not None
+        ctx.save_for_backward(dens, sem, base, rgb, beta, geom if geom is not None else mats)
+        return rgb_p, seg_p, dep_p, bev_rgb, bev_seg, bev_h, vdens, vout
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_seg, g_dep, g_brgb, g_bseg, g_bh, g_vd, g_vo):
+        hp, d = ctx.hp, ctx.desc
+        dens, sem, base, rgb, beta, gm = ctx.saved_tensors
+        geom, mats = (gm, None) if ctx.has_geom else (None, gm)
+        f32 = torch.float32
+        cont = lambda t: None if t is None else t.contiguous().float()
+        g_rgb, g_seg, g_dep, g_brgb, g_bseg, g_bh, g_vd, g_vo = map(
+            cont, (g_rgb, g_seg, g_dep, g_brgb, g_bseg, g_bh, g_vd, g_vo))
+        gd = torch.empty(dens.shape, dtype=f32, device=dens.device)
+        gs = torch.empty(sem.shape, dtype=f32, device=dens.device)
+        gr = torch.empty(rgb.shape, dtype=f32, device=dens.device)
+        gb = torch.zeros(base.shape, dtype=f32, device=dens.device)
+        gbeta = torch.zeros(1, dtype=f32, device=dens.device)
+        nbytes = hp.lib.vamp_render_workspace_bytes(C.byref(d))
+        ws = hp._workspace("render", nbytes)
+        _capi.check(hp.lib.vamp_render_camera_backward(
+            C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
+            _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(g_rgb),
+            _ptr(g_seg), _ptr(g_dep), _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gbeta), _ptr(ws),
+            ws.numel(), _stream()), "vamp_render_camera_backward")
+        _capi.check(hp.lib.vamp_render_bev_backward(
+            C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
+            _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(g_brgb), _ptr(g_bseg), _ptr(g_bh),
+            _ptr(g_vd), _ptr(g_vo), _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gb), _ptr(gbeta),
+            _stream()), "vamp_render_bev_backward")
+        grad_beta = gbeta.reshape(ctx.beta_shape) if hp.cfg.density_mode == "sdf" else None
+        return (None, gd.to(dens.dtype), gs.to(sem.dtype), gb.to(base.dtype), gr.to(rgb.dtype),
+                grad_beta, None, None)
