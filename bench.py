@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Benchmark of the lift + render hot path (driver contract: see the task statement).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--cfg B] [--batch 1]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = lift forward -> render forward (camera + BEV) -> backward of both, for
+`--batch` 6-camera samples per GPU of synthetic data already resident in HBM.
+Metric = BASELINE.json's "6-cam samples/sec (lift+render fwd+bwd)"; the N=1 workload is
+BASELINE.json configs[1] (R50 256x704 features, 200x200x16 voxel grid, bs=1 per GPU).
+Ranks shard samples (data parallel); the only collective is the DDP all-reduce of the
+path's one parameter gradient (density beta) over RCCL.
+
+Extra objects in the JSON line:
+  roofline      dominant kernel of the step: algorithmic bytes per launch / HIP-event
+                duration, against the 8 TB/s HBM peak (in-library event timer)
+  fwd_roofline  the same for the whole fused forward (north_star's 70 % target)
+  cpu_baseline  the oracle (torch-CPU port of the reference's op sequence) timed on this
+                box's host cores on a bounded sample; a reported baseline, not a target
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def kernel_algorithmic_bytes(cfg, B):
+    """Compulsory HBM bytes per launch of each kernel ('Kernels'): every logical
+    input read once, every logical output written once, fp32."""
+    P = cfg.num_cams * cfg.fH * cfg.fW
+    V = cfg.vZ * cfg.vY * cfg.vX
+    C, K, D = cfg.mid_channels, cfg.num_classes, cfg.D
+    YX, oZ = cfg.oY * cfg.oX, cfg.oZ
+    CO = C + (K if cfg.cat_seg else 0)
+    cam_ch = 1 + K + 3
+    return {
+        "lift_fwd": B * (4 * P * (D + C) + 4 * C * V),
+        "lift_bwd": B * (4 * C * V + 2 * 4 * P * (D + C)),
+        "pack_volume": B * (2 * 4 * cam_ch * V),
+        "render_cam_fwd": B * (4 * cam_ch * V + 4 * P * (K + 4)),
+        "render_bev_fwd": B * (4 * (cam_ch + C) * V * min(1.0, (oZ + 1) / cfg.vZ)
+                               + 4 * YX * (K + 4) + 4 * oZ * YX * (1 + CO)),
+        "render_cam_bwd": B * (2 * 4 * cam_ch * V + 4 * P * (K + 4)),
+        "render_bev_bwd": B * (2 * 4 * (cam_ch + C) * V * min(1.0, (oZ + 1) / cfg.vZ)
+                               + 4 * YX * (K + 4) + 4 * oZ * YX * (1 + CO)),
+        "unpack_grad": B * (2 * 4 * cam_ch * V),
+    }
+
+
+def cpu_baseline(cfg, budget_s=30.0):
+    """Oracle fwd+bwd on the host cores, bounded sample: one 6-camera sample of the same
+    workload (more only if a sample takes < budget/4)."""
+    from oracle import aten_oracle as O
+    from vampire_amd.geometry import PathGeometry
+    from vampire_amd import synthetic
+    geo = PathGeometry(cfg)
+    s2e, K, ida = synthetic.camera_rig(cfg, 1)
+    bda = synthetic.bda_matrix(1)
+    depth, feat = synthetic.lift_inputs(cfg, 1)
+    vols = list(synthetic.render_inputs(cfg, 1))
+    beta = torch.tensor(0.1, requires_grad=True)
+    depth.requires_grad_(True); feat.requires_grad_(True)
+    for v in vols:
+        v.requires_grad_(True)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        vox, outs = O.lift_render_forward(cfg, geo, depth, feat, vols, (s2e, K, ida, bda), beta)
+        loss = vox.sum() * 1e-3 + sum(o.sum() for o in outs) * 1e-3
+        loss.backward()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s / 4 or n >= 4:
+            break
+    return {"value": n / el, "unit": "samples/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{n} sample(s) of the same workload, oracle/aten_oracle.py fwd+bwd, "
+                      f"{el:.1f} s on {os.cpu_count()} logical CPUs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cfg", default="B", help="A | B | D (vampire_amd.config.PRESETS)")
+    ap.add_argument("--batch", type=int, default=1, help="samples per GPU per step")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world == 1:
+        # convenience: re-launch ourselves under torch.distributed.run as a child process
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port", "29533",
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+
+    from vampire_amd.config import PRESETS
+    from vampire_amd import _capi
+    from vampire_amd.step import LiftRenderStep, SyntheticBatch, train_step
+
+    cfg = PRESETS[a.cfg]
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)      # "nccl" == RCCL on ROCm
+    dtype = torch.float32 if a.dtype == "f32" else torch.bfloat16
+
+    model = LiftRenderStep(cfg, dev)
+    step_model = model
+    if world > 1:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        step_model = DDP(model, device_ids=[local_rank])
+    batch = SyntheticBatch(cfg, a.batch, dev, seed=rank, dtype=dtype)
+
+    def one_step():
+        model.zero_grad(set_to_none=True)
+        train_step(step_model, batch)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        one_step()
+    fence()
+    _capi.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    _capi.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    prof = _capi.profile_read()
+    if rank == 0:
+        alg = kernel_algorithmic_bytes(cfg, a.batch)
+        kern = {k: {"launches": n, "avg_us": ms / n * 1e3} for k, (n, ms) in prof.items()}
+        per_step_us = {k: ms / a.steps * 1e3 for k, (n, ms) in prof.items()}
+        dom = max((k for k in per_step_us if k in alg), key=lambda k: per_step_us[k])
+        dom_gbs = alg[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e9
+        fwd_names = ["feat_to_channel_last", "lift_fwd", "pack_volume", "render_cam_fwd", "render_bev_fwd"]
+        # forward kernels also run inside backward (re-pack, re-transpose): use per-launch averages
+        fwd_us = sum(kern[k]["avg_us"] for k in fwd_names if k in kern)
+        fwd_bytes = cfg.algorithmic_bytes(4 if a.dtype == "f32" else 2)["fwd"] * a.batch
+        fwd_gbs = fwd_bytes / (fwd_us * 1e-6) / 1e9
+        line = {
+            "metric": "6-cam samples/sec (lift+render fwd+bwd)",
+            "value": a.batch * world * a.steps / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"cfg-{a.cfg}: 6x{cfg.final_dim[0]}x{cfg.final_dim[1]} images, "
+                                   f"D={cfg.D} C={cfg.mid_channels} K={cfg.num_classes}, voxel grid "
+                                   f"{cfg.vX}x{cfg.vY}x{cfg.vZ}, det grid {cfg.oX}x{cfg.oY}x{cfg.oZ}, "
+                                   f"{a.batch} sample(s)/GPU/step, lift+render fwd+bwd",
+                       "per_gpu_batch": a.batch, "global_batch": a.batch * world,
+                       "parallelism": f"dp{world}"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": dom_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg[dom],
+                         "avg_launch_us": kern[dom]["avg_us"]},
+            "fwd_roofline": {"bound": "hbm", "achieved": fwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": fwd_gbs / HBM_PEAK_GBS, "fused_fwd_us": fwd_us,
+                             "algorithmic_bytes": fwd_bytes},
+            "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in sorted(kern.items())},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,6 +42,18 @@ enum { VAMP_DENSITY_SIGMOID = 0, VAMP_DENSITY_SDF_LAPLACE = 1 };
 int vamp_abi_version(void);
 const char* vamp_last_error(void);
 
+/*
+ * In-library kernel timing with HIP events on the launch stream (used by bench.py
+ * for the roofline figure; off by default, zero cost when off).  While enabled,
+ * every launcher brackets each of its kernels with an event pair.
+ * vamp_profile_read synchronises the recorded events and returns, for the kernel
+ * slot `slot` (0 <= slot < vamp_profile_slots()), its name, number of launches
+ * and total milliseconds since the last vamp_profile_enable(1).
+ */
+int vamp_profile_enable(int on);
+int vamp_profile_slots(void);
+int vamp_profile_read(int slot, const char** name, int* launches, double* total_ms);
+
 /* ------------------------------------------------------------------------- *
  * LIFT: voxel <- mean over cameras of trilinear samples of depth (x) feat.
  * Replaces bv2:550-553 (outer product), bv2:351-388 (get_pixel) and

@@ -26,31 +26,47 @@ bv2 = "src/layers/backbones/base_vampire2.py"
 # --------------------------------------------------------------------------
 # geometry: get_geometry (bv2:314-349) and get_pixel (bv2:351-388)
 # --------------------------------------------------------------------------
-def frustum_to_ego(frustum, sensor2ego, intrin, ida, bda):
-    """bv2:328-349.  frustum [D,fH,fW,4] -> ego points [B,N,D,fH,fW,3]."""
-    B, N = sensor2ego.shape[:2]
-    pts = ida.view(B, N, 1, 1, 1, 4, 4).inverse().matmul(frustum.unsqueeze(-1))
+def frustum_to_ego(frustum, sensor2ego, intrin, ida, bda, prepared=None):
+    """bv2:328-349.  frustum [D,fH,fW,4] -> ego points [B,N,D,fH,fW,3].
+
+    ``prepared`` [B,N,3,4,4] = (inv(ida), sensor2ego @ inv(intrin), bda) replaces the three
+    host-side 4x4 products: ``torch.inverse`` is LAPACK and its last bits depend on the CPU,
+    so bit-exact comparisons across machines pin the prepared matrices."""
+    B, N = (sensor2ego if prepared is None else prepared).shape[:2]
+    if prepared is None:
+        inv_ida = ida.view(B, N, 1, 1, 1, 4, 4).inverse()
+        ego_from_cam = sensor2ego.matmul(torch.inverse(intrin)).view(B, N, 1, 1, 1, 4, 4)
+        bda_m = None if bda is None else bda.unsqueeze(1).repeat(1, N, 1, 1).view(B, N, 1, 1, 1, 4, 4)
+    else:
+        inv_ida, ego_from_cam, bda_m = (prepared[:, :, i].reshape(B, N, 1, 1, 1, 4, 4) for i in range(3))
+    pts = inv_ida.matmul(frustum.unsqueeze(-1))
     # (u*d, v*d, d, 1): undo the perspective divide (bv2:336-338)
     pts = torch.cat((pts[..., :2, :] * pts[..., 2:3, :], pts[..., 2:, :]), dim=5)
-    ego_from_cam = sensor2ego.matmul(torch.inverse(intrin))
-    pts = ego_from_cam.view(B, N, 1, 1, 1, 4, 4).matmul(pts)
-    if bda is not None:
-        pts = bda.unsqueeze(1).repeat(1, N, 1, 1).view(B, N, 1, 1, 1, 4, 4) @ pts
+    pts = ego_from_cam.matmul(pts)
+    if bda_m is not None:
+        pts = bda_m @ pts
     return pts.squeeze(-1)[..., :3]
 
 
-def ego_to_pixel(voxel_coords, sensor2ego, intrin, ida, bda):
-    """bv2:365-388.  voxel centres [Z,Y,X,4] -> (u, v, depth) [B,N,Z,Y,X,3]."""
-    B, N = sensor2ego.shape[:2]
+def ego_to_pixel(voxel_coords, sensor2ego, intrin, ida, bda, prepared=None):
+    """bv2:365-388.  voxel centres [Z,Y,X,4] -> (u, v, depth) [B,N,Z,Y,X,3].
+
+    ``prepared`` [B,N,3,4,4] = (inv(bda), intrin @ inv(sensor2ego), ida), see frustum_to_ego."""
+    B, N = (sensor2ego if prepared is None else prepared).shape[:2]
     pts = voxel_coords.unsqueeze(-1)
-    if bda is not None:
-        inv_bda = bda.unsqueeze(1).repeat(1, N, 1, 1).view(B, N, 1, 1, 1, 4, 4).inverse()
+    if prepared is None:
+        inv_bda = None if bda is None else \
+            bda.unsqueeze(1).repeat(1, N, 1, 1).view(B, N, 1, 1, 1, 4, 4).inverse()
+        cam_from_ego = intrin.matmul(torch.inverse(sensor2ego)).view(B, N, 1, 1, 1, 4, 4)
+        ida_m = ida.view(B, N, 1, 1, 1, 4, 4)
+    else:
+        inv_bda, cam_from_ego, ida_m = (prepared[:, :, i].reshape(B, N, 1, 1, 1, 4, 4) for i in range(3))
+    if inv_bda is not None:
         pts = inv_bda.matmul(pts)
-    cam_from_ego = intrin.matmul(torch.inverse(sensor2ego))
-    pts = cam_from_ego.view(B, N, 1, 1, 1, 4, 4).matmul(pts)
+    pts = cam_from_ego.matmul(pts)
     zc = torch.clamp(pts[..., 2:3, :], min=1e-6)           # bv2:383-385
     pts = torch.cat((pts[..., :2, :] / zc, pts[..., 2:, :]), dim=5)
-    pts = ida.view(B, N, 1, 1, 1, 4, 4).matmul(pts).squeeze(-1)
+    pts = ida_m.matmul(pts).squeeze(-1)
     return pts[..., :3]
 
 
@@ -96,9 +112,10 @@ def outer_depth_feat(depth, feat):
     return depth.unsqueeze(2) * feat.unsqueeze(3)
 
 
-def lift(depth, feat, voxel_coords, sensor2ego, intrin, ida, bda, final_dim, d_bound):
+def lift(depth, feat, voxel_coords, sensor2ego, intrin, ida, bda, final_dim, d_bound,
+         prepared=None):
     """bv2:550-563 end to end (outer product + get_pixel + get_voxel_feats)."""
-    pix = ego_to_pixel(voxel_coords, sensor2ego, intrin, ida, bda)
+    pix = ego_to_pixel(voxel_coords, sensor2ego, intrin, ida, bda, prepared)
     return lift_from_frustum_feats(outer_depth_feat(depth, feat), pix, final_dim, d_bound)
 
 
@@ -209,12 +226,14 @@ def render_tap_indices(geom, seg_bounds, vol_shape):
 # --------------------------------------------------------------------------
 # whole hot path, for the timed CPU baseline (bench.py cpu_baseline)
 # --------------------------------------------------------------------------
-def lift_render_forward(cfg, geo, depth, feat, vols, mats, beta_param):
+def lift_render_forward(cfg, geo, depth, feat, vols, mats, beta_param, prepared=(None, None)):
     """One lift + render forward at the reference's op sequence.  ``mats`` =
-    (sensor2ego, intrin, ida, bda); ``vols`` = (density_feature, sem, base, rgb)."""
+    (sensor2ego, intrin, ida, bda); ``vols`` = (density_feature, sem, base, rgb);
+    ``prepared`` = optional (lift_mats, render_mats)."""
     s2e, K, ida, bda = mats
-    vox = lift(depth, feat, geo.voxel_coords, s2e, K, ida, bda, cfg.final_dim, cfg.d_bound)
-    geom = torch.nan_to_num(frustum_to_ego(geo.frustum, s2e, K, ida, bda), -1e3)  # bv2:612
+    vox = lift(depth, feat, geo.voxel_coords, s2e, K, ida, bda, cfg.final_dim, cfg.d_bound,
+               prepared[0])
+    geom = torch.nan_to_num(frustum_to_ego(geo.frustum, s2e, K, ida, bda, prepared[1]), -1e3)  # bv2:612
     outs = render(geom, *vols,
                   seg_bounds=(cfg.x_bound_seg, cfg.y_bound_seg, cfg.z_bound_seg),
                   output_coords=geo.output_coords, camera_mids=geo.camera_mids,

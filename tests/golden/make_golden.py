@@ -142,7 +142,11 @@ def make_tiny(BaseVAMPIRE2, BaseBiLinear):
     geom_n = torch.nan_to_num(geom, -1e3)                              # bv2:612
     inside, rx0, ry0, rz0 = O.render_tap_indices(
         geom_n, (cfg.x_bound_seg, cfg.y_bound_seg, cfg.z_bound_seg), (cfg.vZ, cfg.vY, cfg.vX))
+    from vampire_amd.geometry import lift_matrices, render_matrices
     common = dict(sensor2ego=s2e, intrin=K, ida=ida, bda=bda, depth=depth, feat=feat,
+                  # prepared 4x4s as computed in THIS container (torch.inverse is CPU dependent)
+                  lift_mats=lift_matrices(s2e, K, ida, bda),
+                  render_mats=render_matrices(s2e, K, ida, bda),
                   density_feature=dens, semantic_logits=sem, base=base, rgb=rgb,
                   geom=geom, pix=pix, lift=vox, lift_valid=valid.to(torch.uint8),
                   lift_ix0=ix0.to(torch.int16), lift_iy0=iy0.to(torch.int16),
@@ -184,8 +188,10 @@ def make_tiny(BaseVAMPIRE2, BaseBiLinear):
     vox = m.get_voxel_feats(f_, 0, mats)
     g_vox = torch.randn(vox.shape, generator=g)
     vox.backward(g_vox)
+    from vampire_amd.geometry import lift_matrices
     np.savez_compressed(os.path.join(HERE, "tiny_bilinear.npz"),
                         sensor2ego=s2e.numpy(), intrin=K.numpy(), ida=ida.numpy(), bda=bda.numpy(),
+                        lift_mats=lift_matrices(s2e, K, ida, bda).numpy(),
                         feat=feat.numpy(), lift=vox.detach().numpy(), g_lift=g_vox.numpy(),
                         grad_feat=f_.grad.numpy())
     print("wrote tiny_bilinear.npz")
@@ -205,7 +211,9 @@ def make_full(BaseVAMPIRE2):
         vols = synthetic.render_inputs(cfg, 1, seed=0)
         mats = dict(sensor2ego_mats=s2e[:, None], intrin_mats=K[:, None], ida_mats=ida[:, None],
                     bda_mat=bda)
-        entry = {}
+        from vampire_amd.geometry import lift_matrices, render_matrices
+        entry = {"lift_mats": lift_matrices(s2e, K, ida, bda).tolist(),
+                 "render_mats": render_matrices(s2e, K, ida, bda).tolist()}
         with torch.no_grad():
             pix = m.get_pixel(s2e, K, ida, bda)
             valid, ix0, iy0, iz0 = O.lift_tap_indices(pix, cfg.final_dim, cfg.d_bound,

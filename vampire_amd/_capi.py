@@ -45,6 +45,10 @@ _RD = C.POINTER(VampRenderDesc)
 SIGNATURES = {
     "vamp_abi_version": (C.c_int, []),
     "vamp_last_error": (C.c_char_p, []),
+    "vamp_profile_enable": (C.c_int, [C.c_int]),
+    "vamp_profile_slots": (C.c_int, []),
+    "vamp_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int),
+                                    C.POINTER(C.c_double)]),
     "vamp_lift_workspace_bytes": (C.c_size_t, [_LD]),
     "vamp_lift_forward": (C.c_int, [_LD] + [_P] * 8 + [_P, C.c_size_t, _P]),
     "vamp_lift_backward": (C.c_int, [_LD] + [_P] * 10 + [_P, C.c_size_t, _P]),
@@ -72,6 +76,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must bring in ITS libamdhip64 first: a second HIP runtime (the system copy this
+    # library would otherwise pull in) sees no device inside a torch process.
+    import torch  # noqa: F401
     path = os.environ.get("VAMPIRE_HIP_LIB", lib_path())
     if not os.path.exists(path):
         raise VampireHipError(
@@ -93,3 +100,19 @@ def check(code: int, what: str):
     if code != 0:
         msg = load().vamp_last_error().decode("utf-8", "replace")
         raise VampireHipError(f"{what} failed with code {code}: {msg}")
+
+
+def profile_enable(on: bool):
+    check(load().vamp_profile_enable(1 if on else 0), "vamp_profile_enable")
+
+
+def profile_read():
+    """{kernel name: (launches, total_ms)} since the last profile_enable(True)."""
+    lib = load()
+    out = {}
+    for slot in range(lib.vamp_profile_slots()):
+        name, n, ms = C.c_char_p(), C.c_int(), C.c_double()
+        check(lib.vamp_profile_read(slot, C.byref(name), C.byref(n), C.byref(ms)), "vamp_profile_read")
+        if n.value:
+            out[name.value.decode()] = (n.value, ms.value)
+    return out

@@ -39,6 +39,27 @@ inline int check_launch(const char* what) {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---------------------------------------------------------------------------
+// optional HIP-event kernel timer (runtime.hip); slots name the kernels
+// ---------------------------------------------------------------------------
+enum ProfSlot {
+  kProfFeatCL = 0, kProfLiftFwd, kProfLiftBwd, kProfFeatCF, kProfLiftFwdDense, kProfLiftBwdDense,
+  kProfPack, kProfCamFwd, kProfBevFwd, kProfCamBwd, kProfUnpack, kProfBevBwd, kProfMemset,
+  kProfAux, kProfSlots
+};
+struct ProfScope { int idx; };
+bool prof_enabled();
+void prof_begin(int slot, hipStream_t s, ProfScope* sc);
+void prof_end(hipStream_t s, ProfScope* sc);
+// usage: VAMP_TIMED(slot, stream, kernel<<<...>>>(...));
+#define VAMP_TIMED(slot, stream, launch)              \
+  do {                                                \
+    ::vamp::ProfScope _sc;                            \
+    ::vamp::prof_begin(slot, stream, &_sc);           \
+    launch;                                           \
+    ::vamp::prof_end(stream, &_sc);                   \
+  } while (0)
+
+// ---------------------------------------------------------------------------
 // 4x4 * 4x1 in the evaluation order of torch's CPU bmm for tiny matrices:
 // ((m0*x + m1*y) + m2*z) + m3*w, no fused multiply-add.
 // ---------------------------------------------------------------------------

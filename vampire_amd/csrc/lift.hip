@@ -13,8 +13,6 @@
 
 namespace vamp {
 
-thread_local char g_err[512] = "";
-
 struct LiftParams {
   int B, N, C, D, fH, fW, Z, Y, X;
   float u_max, v_max, u_div, v_div, d_lo, d_hi, d_span;
@@ -424,7 +422,7 @@ static bool fused_channels_ok(int C) { return C == 4 || C == 8 || (C % 16 == 0 &
 template <typename T>
 static void launch_to_cl(const void* feat, float* out, int BN, int C, int HW, hipStream_t s) {
   dim3 grid((HW + 63) / 64, (C + 63) / 64, BN);
-  feat_to_channel_last<T><<<grid, 256, 0, s>>>(static_cast<const T*>(feat), out, C, HW);
+  VAMP_TIMED(kProfFeatCL, s, (feat_to_channel_last<T><<<grid, 256, 0, s>>>(static_cast<const T*>(feat), out, C, HW)));
 }
 
 struct LiftWs {
@@ -453,11 +451,11 @@ static int lift_forward_t(const VampLiftDesc* d, const LiftParams& P, const floa
   dim3 grid((P.X + TX - 1) / TX, (P.Y + TY - 1) / TY, ((P.Z + TZ - 1) / TZ) * P.B);
   const T* dp = static_cast<const T*>(depth);
   if (P.C == 4)
-    lift_fwd_kernel<T, 4, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, out, hits);
+    VAMP_TIMED(kProfLiftFwd, s, (lift_fwd_kernel<T, 4, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, out, hits)));
   else if (P.C == 8)
-    lift_fwd_kernel<T, 8, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, out, hits);
+    VAMP_TIMED(kProfLiftFwd, s, (lift_fwd_kernel<T, 8, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, out, hits)));
   else
-    lift_fwd_kernel<T, 16, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, out, hits);
+    VAMP_TIMED(kProfLiftFwd, s, (lift_fwd_kernel<T, 16, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, out, hits)));
   return check_launch("lift_fwd_kernel");
 }
 
@@ -470,11 +468,11 @@ static int lift_backward_t(const VampLiftDesc* d, const LiftParams& P, const flo
   dim3 grid((P.X + TX - 1) / TX, (P.Y + TY - 1) / TY, ((P.Z + TZ - 1) / TZ) * P.B);
   const T* dp = static_cast<const T*>(depth);
   if (P.C == 4)
-    lift_bwd_kernel<T, 4, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, gout, hits, gdepth, gfeat_cl);
+    VAMP_TIMED(kProfLiftBwd, s, (lift_bwd_kernel<T, 4, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, gout, hits, gdepth, gfeat_cl)));
   else if (P.C == 8)
-    lift_bwd_kernel<T, 8, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, gout, hits, gdepth, gfeat_cl);
+    VAMP_TIMED(kProfLiftBwd, s, (lift_bwd_kernel<T, 8, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, gout, hits, gdepth, gfeat_cl)));
   else
-    lift_bwd_kernel<T, 16, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, gout, hits, gdepth, gfeat_cl);
+    VAMP_TIMED(kProfLiftBwd, s, (lift_bwd_kernel<T, 16, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, gout, hits, gdepth, gfeat_cl)));
   return check_launch("lift_bwd_kernel");
 }
 
@@ -483,9 +481,6 @@ static int lift_backward_t(const VampLiftDesc* d, const LiftParams& P, const flo
 using namespace vamp;
 
 extern "C" {
-
-int vamp_abi_version(void) { return VAMP_ABI_VERSION; }
-const char* vamp_last_error(void) { return g_err; }
 
 size_t vamp_lift_workspace_bytes(const VampLiftDesc* d) {
   if (!d) return 0;
@@ -540,7 +535,7 @@ int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs
               : lift_backward_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, w.feat_cl, grad_out, hits, grad_depth, w.gfeat_cl, s);
   if (e) return e;
   dim3 grid((HW + 63) / 64, (d->C + 63) / 64, BN);
-  feat_to_channel_first<<<grid, 256, 0, s>>>(w.gfeat_cl, grad_feat, d->C, HW);
+  VAMP_TIMED(kProfFeatCF, s, (feat_to_channel_first<<<grid, 256, 0, s>>>(w.gfeat_cl, grad_feat, d->C, HW)));
   return check_launch("feat_to_channel_first");
 }
 
@@ -551,8 +546,9 @@ int vamp_lift_forward_dense(const VampLiftDesc* d, const float* mats, const floa
   VAMP_REQUIRE(mats && xs && ys && zs && frustum_feats && out, "null pointer");
   const LiftParams P = to_params(d);
   const long total = (long) d->B * d->Z * d->Y * d->X;
-  lift_fwd_dense_kernel<<<(unsigned) ((total + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
-      P, mats, xs, ys, zs, frustum_feats, out, hits);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  VAMP_TIMED(kProfLiftFwdDense, s, (lift_fwd_dense_kernel<<<(unsigned) ((total + 255) / 256), 256, 0, s>>>(
+      P, mats, xs, ys, zs, frustum_feats, out, hits)));
   return check_launch("lift_fwd_dense_kernel");
 }
 
@@ -563,8 +559,9 @@ int vamp_lift_backward_dense(const VampLiftDesc* d, const float* mats, const flo
   VAMP_REQUIRE(mats && xs && ys && zs && grad_out && hits && grad_frustum_feats, "null pointer");
   const LiftParams P = to_params(d);
   const long total = (long) d->B * d->Z * d->Y * d->X;
-  lift_bwd_dense_kernel<<<(unsigned) ((total + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
-      P, mats, xs, ys, zs, grad_out, hits, grad_frustum_feats);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  VAMP_TIMED(kProfLiftBwdDense, s, (lift_bwd_dense_kernel<<<(unsigned) ((total + 255) / 256), 256, 0, s>>>(
+      P, mats, xs, ys, zs, grad_out, hits, grad_frustum_feats)));
   return check_launch("lift_bwd_dense_kernel");
 }
 

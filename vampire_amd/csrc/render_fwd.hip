@@ -298,9 +298,8 @@ int launch_pack(const RenderParams& P, int in_dtype, const void* dens, const voi
   const long total = (long) P.B * P.Z * P.Y * P.X;
   const unsigned grid = (unsigned) ((total + 255) / 256);
 #define VAMP_PACK(T, CP4)                                                                  \
-  pack_volume_kernel<T, CP4><<<grid, 256, 0, s>>>(P, static_cast<const T*>(dens),          \
-                                                  static_cast<const T*>(sem),              \
-                                                  static_cast<const T*>(rgb), packed)
+  VAMP_TIMED(kProfPack, s, (pack_volume_kernel<T, CP4><<<grid, 256, 0, s>>>(               \
+      P, static_cast<const T*>(dens), static_cast<const T*>(sem), static_cast<const T*>(rgb), packed)))
   if (in_dtype == VAMP_F32) {
     if (P.CP == 12) VAMP_PACK(float, 3); else if (P.CP == 24) VAMP_PACK(float, 6); else VAMP_PACK(float, 8);
   } else {
@@ -350,8 +349,8 @@ int vamp_render_camera_forward(const VampRenderDesc* d, const float* geom, const
   const long threads = (long) d->B * d->N * d->fH * d->fW * LPR;
   const unsigned grid = (unsigned) ((threads + 255) / 256);
 #define VAMP_CAM(CP4)                                                                        \
-  render_cam_fwd_kernel<LPR, CP4><<<grid, 256, 0, s>>>(P, geom, mats, us, vs, ds, mids, beta, \
-                                                       packed, rgb_out, seg_out, depth_out)
+  VAMP_TIMED(kProfCamFwd, s, (render_cam_fwd_kernel<LPR, CP4><<<grid, 256, 0, s>>>(          \
+      P, geom, mats, us, vs, ds, mids, beta, packed, rgb_out, seg_out, depth_out)))
   if (P.CP == 12) VAMP_CAM(3); else if (P.CP == 24) VAMP_CAM(6); else VAMP_CAM(8);
 #undef VAMP_CAM
   return check_launch("render_cam_fwd_kernel");
@@ -372,14 +371,14 @@ int vamp_render_bev_forward(const VampRenderDesc* d, const float* oxs, const flo
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid((d->oX + 63) / 64, d->oY, d->B);
   if (d->in_dtype == VAMP_F32)
-    render_bev_fwd_kernel<float><<<grid, 64, 0, s>>>(
+    VAMP_TIMED(kProfBevFwd, s, (render_bev_fwd_kernel<float><<<grid, 64, 0, s>>>(
         P, oxs, oys, ozs, bev_mids, beta, (const float*) density_feature, (const float*) semantic,
-        (const float*) rgb, (const float*) base, bev_rgb, bev_seg, bev_height, voxel_density, voxel_output);
+        (const float*) rgb, (const float*) base, bev_rgb, bev_seg, bev_height, voxel_density, voxel_output)));
   else
-    render_bev_fwd_kernel<__hip_bfloat16><<<grid, 64, 0, s>>>(
+    VAMP_TIMED(kProfBevFwd, s, (render_bev_fwd_kernel<__hip_bfloat16><<<grid, 64, 0, s>>>(
         P, oxs, oys, ozs, bev_mids, beta, (const __hip_bfloat16*) density_feature,
         (const __hip_bfloat16*) semantic, (const __hip_bfloat16*) rgb, (const __hip_bfloat16*) base,
-        bev_rgb, bev_seg, bev_height, voxel_density, voxel_output);
+        bev_rgb, bev_seg, bev_height, voxel_density, voxel_output)));
   return check_launch("render_bev_fwd_kernel");
 }
 

@@ -1,0 +1,91 @@
+// Library-wide state: last-error string, ABI version, and the optional HIP-event
+// kernel timer used by bench.py's roofline leg.
+#include "common.hpp"
+
+#include <mutex>
+#include <vector>
+
+namespace vamp {
+
+thread_local char g_err[512] = "";
+
+namespace {
+struct Pair {
+  hipEvent_t a, b;
+  int slot;
+};
+std::mutex g_mu;
+bool g_on = false;
+std::vector<Pair> g_pairs;        // recorded since enable(1)
+std::vector<Pair> g_free;         // recycled events
+const char* g_names[kProfSlots] = {
+    "feat_to_channel_last", "lift_fwd", "lift_bwd", "feat_to_channel_first", "lift_fwd_dense",
+    "lift_bwd_dense", "pack_volume", "render_cam_fwd", "render_bev_fwd", "render_cam_bwd",
+    "unpack_grad", "render_bev_bwd", "memset", "aux"};
+}  // namespace
+
+bool prof_enabled() { return g_on; }
+
+void prof_begin(int slot, hipStream_t s, ProfScope* sc) {
+  sc->idx = -1;
+  if (!g_on) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  Pair p;
+  if (!g_free.empty()) {
+    p = g_free.back();
+    g_free.pop_back();
+  } else {
+    if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+  }
+  p.slot = slot;
+  (void) hipEventRecord(p.a, s);
+  g_pairs.push_back(p);
+  sc->idx = (int) g_pairs.size() - 1;
+}
+
+void prof_end(hipStream_t s, ProfScope* sc) {
+  if (sc->idx < 0) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (sc->idx < (int) g_pairs.size()) (void) hipEventRecord(g_pairs[sc->idx].b, s);
+}
+
+}  // namespace vamp
+
+using namespace vamp;
+
+extern "C" {
+
+int vamp_abi_version(void) { return VAMP_ABI_VERSION; }
+const char* vamp_last_error(void) { return g_err; }
+
+int vamp_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (on) {
+    for (auto& p : g_pairs) g_free.push_back(p);
+    g_pairs.clear();
+  }
+  g_on = on != 0;
+  return VAMP_OK;
+}
+
+int vamp_profile_slots(void) { return kProfSlots; }
+
+int vamp_profile_read(int slot, const char** name, int* launches, double* total_ms) {
+  if (slot < 0 || slot >= kProfSlots || !name || !launches || !total_ms)
+    return fail(VAMP_EINVAL, "%s: bad argument", __func__);
+  std::lock_guard<std::mutex> lk(g_mu);
+  *name = g_names[slot];
+  *launches = 0;
+  *total_ms = 0.0;
+  for (auto& p : g_pairs) {
+    if (p.slot != slot) continue;
+    if (hipEventSynchronize(p.b) != hipSuccess) return fail(VAMP_EHIP, "%s: hipEventSynchronize", __func__);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) != hipSuccess) return fail(VAMP_EHIP, "%s: hipEventElapsedTime", __func__);
+    *launches += 1;
+    *total_ms += ms;
+  }
+  return VAMP_OK;
+}
+
+}  // extern "C"
