@@ -17,6 +17,12 @@ namespace vamp {
 int launch_pack(const RenderParams& P, int in_dtype, const void* dens, const void* sem,
                 const void* rgb, float* packed, hipStream_t s);
 size_t packed_bytes(const VampRenderDesc* d);
+size_t cam_bwd_v2_bytes(const VampRenderDesc* d);
+int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const float* mats,
+                      const float* us, const float* vs, const float* ds, const float* mids,
+                      const float* beta, const float* packed, const float* g_rgb,
+                      const float* g_seg, const float* g_depth, float* gdens, float* gsem,
+                      float* grgb, float* grad_beta, void* scratch, hipStream_t s);
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
   // wave reduce then 4-wave LDS reduce; result valid in thread 0
@@ -349,13 +355,20 @@ int vamp_render_camera_backward(const VampRenderDesc* d, const float* geom, cons
   VAMP_REQUIRE(grad_density_feature && grad_semantic && grad_rgb, "null output");
   VAMP_REQUIRE((beta && grad_beta) || d->density_mode == VAMP_DENSITY_SIGMOID, "beta / grad_beta is NULL");
   const size_t pb = packed_bytes(d);
-  if (!workspace || workspace_bytes < 2 * pb)
-    return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) (2 * pb));
+  const size_t need = vamp_render_workspace_bytes(d);
+  if (!workspace || workspace_bytes < need)
+    return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) need);
   const RenderParams P = to_params(d);
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* packed = static_cast<float*>(workspace);
   float* gpacked = reinterpret_cast<float*>(static_cast<char*>(workspace) + pb);
   if (int e = launch_pack(P, d->in_dtype, density_feature, semantic, rgb, packed, s)) return e;
+  // v2 (owner-computes bricks, no global atomics) needs the matrices to bound candidate
+  // boxes; a caller-supplied geom tensor falls back to the v1 atomic splat.
+  const char* force = getenv("VAMP_CAM_BWD");
+  if (!geom && mats && !(force && force[0] == 'v' && force[1] == '1'))
+    return launch_cam_bwd_v2(d, P, mats, us, vs, ds, mids, beta, packed, g_rgb, g_seg, g_depth,
+                             grad_density_feature, grad_semantic, grad_rgb, grad_beta, gpacked, s);
   {
     ProfScope sc;
     prof_begin(kProfMemset, s, &sc);

@@ -1,0 +1,427 @@
+// Camera-branch render backward, v2: gather formulation -- no atomics on the volume, every
+// output element written exactly once, deterministic.
+//
+//  1. invert_mats      device 4x4 inverses of the three render matrices (ego -> frustum
+//                      coordinates), used only to bound candidate boxes
+//  2. cam_bwd_ray      LPR lanes per ray re-march the samples once (8-tap gather of the
+//                      packed volume), keep (s0, delta, q) per sample in LDS, merge the
+//                      chunks with wave shuffles and emit one record per sample: the
+//                      compositing weight w_i, dL/ds_i[0], and the continuous tap coordinates
+//                      (fx, fy, fz) exactly as the forward computed them (NaN = masked)
+//  3. cam_bwd_gather   GL lanes per voxel: bound, per camera, the (depth, h, w) index box of
+//                      samples whose trilinear support can contain the voxel, stream the
+//                      sample records of the box, and accumulate
+//                      w_tap * dL/ds_i[c] for the 1+K+3 channels in registers; a shuffle
+//                      reduction and an LDS transpose give coalesced channel-first stores.
+// See render_bwd.hip for the compositing algebra.
+#include "render_common.hpp"
+
+namespace vamp {
+
+// ---------------------------------------------------------------------------
+// 1. 4x4 inverses (Gauss-Jordan, partial pivoting, double)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+invert_mats_kernel(const float* __restrict__ mats, float* __restrict__ inv, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double a[4][8];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) {
+      a[r][c] = mats[i * 16 + r * 4 + c];
+      a[r][4 + c] = (r == c) ? 1.0 : 0.0;
+    }
+  for (int col = 0; col < 4; ++col) {
+    int piv = col;
+    double best = fabs(a[col][col]);
+    for (int r = col + 1; r < 4; ++r)
+      if (fabs(a[r][col]) > best) { best = fabs(a[r][col]); piv = r; }
+    if (piv != col)
+      for (int c = 0; c < 8; ++c) { double t = a[col][c]; a[col][c] = a[piv][c]; a[piv][c] = t; }
+    const double d = a[col][col];
+    const double id = (d != 0.0) ? 1.0 / d : 0.0;      // singular -> zeros -> full-image boxes
+    for (int c = 0; c < 8; ++c) a[col][c] *= id;
+    for (int r = 0; r < 4; ++r) {
+      if (r == col) continue;
+      const double f = a[r][col];
+      for (int c = 0; c < 8; ++c) a[r][c] -= f * a[col][c];
+    }
+  }
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) inv[i * 16 + r * 4 + c] = (float) a[r][4 + c];
+}
+
+// ---------------------------------------------------------------------------
+// 2. per-ray pass
+// ---------------------------------------------------------------------------
+template <int LPR, int CP4>
+__global__ void __launch_bounds__(256)
+cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* __restrict__ us,
+                   const float* __restrict__ vs, const float* __restrict__ ds,
+                   const float* __restrict__ mids, const float* __restrict__ beta_raw,
+                   const float* __restrict__ packed, const float* __restrict__ g_rgb,
+                   const float* __restrict__ g_seg, const float* __restrict__ g_depth,
+                   float* __restrict__ Wbuf, float* __restrict__ G0buf, float* __restrict__ FX,
+                   float* __restrict__ FY, float* __restrict__ FZ, float* __restrict__ Gcl,
+                   float* __restrict__ grad_beta, int L) {
+  constexpr int CP = CP4 * 4;
+  extern __shared__ float lds[];              // [3][L][256]: s0, delta (sign = no-grad flag), q
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  float* l_s0 = lds;
+  float* l_dl = lds + (long) L * 256;
+  float* l_q = lds + (long) 2 * L * 256;
+
+  const long t = (long) blockIdx.x * blockDim.x + tid;
+  const long nrays = (long) P.B * P.N * P.fH * P.fW;
+  long ray = t / LPR;
+  const int sub = (int) (t % LPR);
+  const bool live = ray < nrays;
+  if (!live) ray = nrays - 1;
+  const int w = ray % P.fW;
+  const int h = (ray / P.fW) % P.fH;
+  const long bn = ray / ((long) P.fW * P.fH);
+  const int b = bn / P.N;
+  const DensityParams dp = load_density(P.density_mode, beta_raw, P.beta_min, P.sdf_bias);
+  const int S = P.D - 1;
+  const int i0 = min(S, sub * L), i1 = min(S, i0 + L);
+  const float* m = mats + bn * 48;
+  const float u = us[w], v = vs[h];
+  const long V = (long) P.Z * P.Y * P.X;
+  const float* vol = packed + (long) b * V * CP;
+  const long HW = (long) P.fH * P.fW;
+  const long pix = (long) h * P.fW + w;
+
+  float G[CP];
+#pragma unroll
+  for (int c = 0; c < CP; ++c) {
+    float gv = 0.f;
+    if (live) {
+      if (c >= 1 && c <= P.K) gv = g_seg ? g_seg[(bn * P.K + (c - 1)) * HW + pix] : 0.f;
+      else if (c > P.K && c <= P.K + 3) gv = g_rgb ? g_rgb[(bn * 3 + (c - 1 - P.K)) * HW + pix] : 0.f;
+    }
+    G[c] = gv;
+  }
+  const float Gd = (live && g_depth) ? g_depth[bn * HW + pix] : 0.f;
+  if (live && sub == 0) {
+    float4* dst = reinterpret_cast<float4*>(Gcl + ray * CP);
+#pragma unroll
+    for (int q = 0; q < CP4; ++q) dst[q] = make_float4(G[q * 4], G[q * 4 + 1], G[q * 4 + 2], G[q * 4 + 3]);
+  }
+
+  // ---- march the chunk once ----
+  float px, py, pz, qx, qy, qz;
+  auto point = [&](int i, float& x, float& y, float& z) {
+    frustum_point(m, u, v, ds[i], x, y, z);
+    x = nan_to_num_geom(x); y = nan_to_num_geom(y); z = nan_to_num_geom(z);
+  };
+  if (i0 < i1) point(i0, px, py, pz);
+  float cum = 0.f, A = 0.f;
+  for (int i = i0; i < i1; ++i) {
+    point(i + 1, qx, qy, qz);
+    const VolTap tp = volume_tap(P, px, py, pz);
+    float s[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) s[c] = 0.f;
+    if (tp.inside) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int iz = tp.iz0 + (k >> 2), iy = tp.iy0 + ((k >> 1) & 1), ix = tp.ix0 + (k & 1);
+        if (iz >= P.Z || iy >= P.Y || ix >= P.X) continue;
+        const float wt = ((k & 1) ? tp.wx1 : tp.wx0) * ((k & 2) ? tp.wy1 : tp.wy0) *
+                         ((k & 4) ? tp.wz1 : tp.wz0);
+        const float4* f4 = reinterpret_cast<const float4*>(
+            vol + (((long) iz * P.Y + iy) * P.X + ix) * CP);
+#pragma unroll
+        for (int q = 0; q < CP4; ++q) {
+          const float4 f = f4[q];
+          s[q * 4 + 0] = __builtin_fmaf(wt, f.x, s[q * 4 + 0]);
+          s[q * 4 + 1] = __builtin_fmaf(wt, f.y, s[q * 4 + 1]);
+          s[q * 4 + 2] = __builtin_fmaf(wt, f.z, s[q * 4 + 2]);
+          s[q * 4 + 3] = __builtin_fmaf(wt, f.w, s[q * 4 + 3]);
+        }
+      }
+    }
+    const bool fin = (s[0] == s[0]) && (fabsf(s[0]) <= 3.402823466e+38f);
+    const float s0 = nan_to_num(s[0]);
+    float qv = Gd * (mids[i] - P.d_far);
+#pragma unroll
+    for (int c = 1; c < CP; ++c) qv = __builtin_fmaf(G[c], nan_to_num(s[c]), qv);
+    const float dx = qx - px, dy = qy - py, dz = qz - pz;
+    const float delta = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float tau = density_fwd(dp, s0) * delta;
+    A = __builtin_fmaf((1.0f - expf(-tau)) * expf(-cum), qv, A);
+    cum += tau;
+    const int j = i - i0;
+    l_s0[j * 256 + tid] = s0;
+    // a sample passes gradient to s[0] only if it is inside and finite: flag in the sign
+    l_dl[j * 256 + tid] = (tp.inside && fin) ? delta : -delta;
+    l_q[j * 256 + tid] = qv;
+    if (live) {
+      const long sidx = ((bn * S + i) * P.fH + h) * P.fW + w;
+      const float nanv = __builtin_nanf("");
+      FX[sidx] = tp.inside ? tp.fx : nanv;     // NaN: masked sample, matches no voxel
+      FY[sidx] = tp.fy;
+      FZ[sidx] = tp.fz;
+    }
+    px = qx; py = qy; pz = qz;
+  }
+
+  // ---- merge the LPR chunks of the ray ----
+  float scale = 1.f, suffix = 0.f;
+  if (LPR > 1) {
+    float incl = cum;
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) {
+      const float up = __shfl_up(incl, o, LPR);
+      if (sub >= o) incl += up;
+    }
+    float excl = __shfl_up(incl, 1, LPR);
+    if (sub == 0) excl = 0.f;
+    scale = expf(-excl);
+    // suffix_k = sum_{m > k} scale_m A_m
+    const float Bk = scale * A;
+    float sfx = Bk;                      // inclusive suffix
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) {
+      const float dn = __shfl_down(sfx, o, LPR);
+      if (sub + o < LPR) sfx += dn;
+    }
+    const float nb = __shfl_down(sfx, 1, LPR);       // exclusive suffix = neighbour's inclusive
+    suffix = (sub == LPR - 1) ? 0.f : nb;
+  }
+
+  // ---- second loop over the LDS copies: emit w_i and dL/ds_i[0] ----
+  float cl = 0.f, prefix = 0.f, dbeta = 0.f;
+  for (int i = i0; i < i1; ++i) {
+    const int j = i - i0;
+    const float s0 = l_s0[j * 256 + tid];
+    const float dl = l_dl[j * 256 + tid];
+    const float qv = l_q[j * 256 + tid];
+    const float delta = fabsf(dl);
+    const float tau = density_fwd(dp, s0) * delta;
+    const float wloc = (1.0f - expf(-tau)) * expf(-cl);
+    const float Tn = scale * expf(-(cl + tau));
+    cl += tau;
+    prefix = __builtin_fmaf(wloc, qv, prefix);
+    const float R = scale * (A - prefix) + suffix;
+    const float dtau = qv * Tn - R;
+    float dsig_ds, dsig_db;
+    density_bwd(dp, s0, dsig_ds, dsig_db);
+    dbeta = __builtin_fmaf(dtau * delta, dsig_db, dbeta);
+    if (live) {
+      const long sidx = ((bn * S + i) * P.fH + h) * P.fW + w;
+      Wbuf[sidx] = scale * wloc;
+      G0buf[sidx] = (dl > 0.f) ? dtau * delta * dsig_ds : 0.f;
+    }
+  }
+  if (P.density_mode == VAMP_DENSITY_SDF_LAPLACE) {
+    float vsum = live ? dbeta : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vsum += __shfl_down(vsum, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = vsum;
+    __syncthreads();
+    if (tid == 0) {
+      const float tot = red[0] + red[1] + red[2] + red[3];
+      const float sgn = (beta_raw[0] > 0.f) ? 1.f : ((beta_raw[0] < 0.f) ? -1.f : 0.f);
+      atomicAdd(grad_beta, sgn * tot);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 3. per-voxel gather
+// ---------------------------------------------------------------------------
+constexpr int GL = 16;              // lanes per voxel
+constexpr int VPB = 256 / GL;       // voxels per workgroup: an x-run
+
+// ego -> (u, v, depth) in frustum coordinates (inverse of get_geometry, bv2:328-349)
+__device__ __forceinline__ void project_corner(const float* __restrict__ pm, float x, float y,
+                                               float z, float& u, float& v, float& dd) {
+  // pm holds the inverses in the order of the render matrices: [ida, inv(E), inv(bda)]
+  Vec4 p{x, y, z, 1.0f};
+  p = matvec(pm + 32, p);
+  p = matvec(pm + 16, p);
+  dd = p.z;
+  const float zc = fmaxf(p.z, 1e-6f);
+  p.x = p.x / zc;
+  p.y = p.y / zc;
+  p = matvec(pm, p);
+  u = p.x;
+  v = p.y;
+}
+
+// weight of tap index `iv` for continuous coordinate f (aten: w0 = floor+1-f, w1 = f-floor)
+__device__ __forceinline__ float tap_weight(float f, float iv) {
+  const float fl = floorf(f);
+  return (fl == iv) ? (fl + 1.0f) - f : ((fl + 1.0f == iv) ? f - fl : 0.f);
+}
+
+template <int CP4>
+__global__ void __launch_bounds__(256)
+cam_bwd_gather_kernel(RenderParams P, const float* __restrict__ pmats, const float* __restrict__ us,
+                      const float* __restrict__ vs, const float* __restrict__ ds,
+                      const float* __restrict__ FX, const float* __restrict__ FY,
+                      const float* __restrict__ FZ, const float* __restrict__ Wbuf,
+                      const float* __restrict__ G0buf, const float* __restrict__ Gcl,
+                      float* __restrict__ gdens, float* __restrict__ gsem, float* __restrict__ grgb) {
+  constexpr int CP = CP4 * 4;
+  __shared__ float outs[CP][VPB + 1];
+  const int tid = threadIdx.x;
+  const int g = tid / GL, l = tid % GL;
+  const int ix = blockIdx.x * VPB + g, iy = blockIdx.y;
+  const int iz = blockIdx.z % P.Z, b = blockIdx.z / P.Z;
+  const bool vox_ok = ix < P.X;
+  const int S = P.D - 1;
+  const int nch = 1 + P.K + 3;
+  const float ex = P.span[0] / (float) (P.X - 1), ey = P.span[1] / (float) (P.Y - 1),
+              ez = P.span[2] / (float) (P.Z - 1);
+  // ego-space box of sample positions whose taps can include this voxel: |f - index| < 1
+  const float X0 = P.lo[0] + ((float) ix - 1.01f) * ex, X1 = P.lo[0] + ((float) ix + 1.01f) * ex;
+  const float Y0 = P.lo[1] + ((float) iy - 1.01f) * ey, Y1 = P.lo[1] + ((float) iy + 1.01f) * ey;
+  const float Z0 = P.lo[2] + ((float) iz - 1.01f) * ez, Z1 = P.lo[2] + ((float) iz + 1.01f) * ez;
+  const float du = (P.fW > 1) ? (us[P.fW - 1] - us[0]) / (float) (P.fW - 1) : 1.f;
+  const float dv = (P.fH > 1) ? (vs[P.fH - 1] - vs[0]) / (float) (P.fH - 1) : 1.f;
+  const float d0 = ds[0];
+  const float dstep = (ds[P.D - 1] - d0) / (float) (P.D - 1);
+  const long HW = (long) P.fH * P.fW;
+  const float fix = (float) ix, fiy = (float) iy, fiz = (float) iz;
+
+  float acc[CP];
+#pragma unroll
+  for (int c = 0; c < CP; ++c) acc[c] = 0.f;
+
+  for (int n = 0; n < P.N; ++n) {
+    const long bn = (long) b * P.N + n;
+    // lane l projects corner (l & 7); min/max over the 8 corners with xor shuffles
+    float cu, cv, cd;
+    project_corner(pmats + bn * 48, (l & 1) ? X1 : X0, (l & 2) ? Y1 : Y0, (l & 4) ? Z1 : Z0, cu, cv, cd);
+    float bad = (!(cd > 0.05f) || !(cu == cu) || !(cv == cv)) ? 1.f : 0.f;
+    float umin = cu, umax = cu, vmin = cv, vmax = cv, zmin = cd, zmax = cd;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      umin = fminf(umin, __shfl_xor(umin, o, GL)); umax = fmaxf(umax, __shfl_xor(umax, o, GL));
+      vmin = fminf(vmin, __shfl_xor(vmin, o, GL)); vmax = fmaxf(vmax, __shfl_xor(vmax, o, GL));
+      zmin = fminf(zmin, __shfl_xor(zmin, o, GL)); zmax = fmaxf(zmax, __shfl_xor(zmax, o, GL));
+      bad = fmaxf(bad, __shfl_xor(bad, o, GL));
+    }
+    if (!vox_ok || !(zmax >= d0 - dstep)) continue;
+    int w_lo = 0, w_hi = P.fW - 1, h_lo = 0, h_hi = P.fH - 1, i_lo = 0;
+    const int i_hi = min(S - 1, (int) ceilf((zmax - d0) / dstep + 0.02f));
+    if (bad == 0.f) {
+      i_lo = max(0, (int) floorf((zmin - d0) / dstep - 0.02f));
+      w_lo = max(0, (int) floorf((umin - us[0]) / du - 0.05f));
+      w_hi = min(P.fW - 1, (int) ceilf((umax - us[0]) / du + 0.05f));
+      h_lo = max(0, (int) floorf((vmin - vs[0]) / dv - 0.05f));
+      h_hi = min(P.fH - 1, (int) ceilf((vmax - vs[0]) / dv + 0.05f));
+    }
+    if (i_lo > i_hi || w_lo > w_hi || h_lo > h_hi) continue;
+    const int nw = w_hi - w_lo + 1, nh = h_hi - h_lo + 1;
+    const int count = nw * nh * (i_hi - i_lo + 1);
+    const long sbase = bn * S * HW;
+    for (int idx = l; idx < count; idx += GL) {
+      const int w = w_lo + idx % nw;
+      const int r = idx / nw;
+      const int h = h_lo + r % nh;
+      const int i = i_lo + r / nh;
+      const long sidx = sbase + ((long) i * P.fH + h) * P.fW + w;
+      const float fx = FX[sidx];
+      if (!(fabsf(fx - fix) < 1.0f)) continue;          // NaN (masked sample) fails too
+      const float fy = FY[sidx];
+      if (!(fabsf(fy - fiy) < 1.0f)) continue;
+      const float fz = FZ[sidx];
+      if (!(fabsf(fz - fiz) < 1.0f)) continue;
+      const float wt = tap_weight(fx, fix) * tap_weight(fy, fiy) * tap_weight(fz, fiz);
+      const float Wv = wt * Wbuf[sidx];
+      acc[0] = __builtin_fmaf(wt, G0buf[sidx], acc[0]);
+      const float4* g4 = reinterpret_cast<const float4*>(Gcl + (bn * HW + (long) h * P.fW + w) * CP);
+#pragma unroll
+      for (int q = 0; q < CP4; ++q) {
+        const float4 f = g4[q];
+        if (q > 0) acc[q * 4] = __builtin_fmaf(Wv, f.x, acc[q * 4]);
+        acc[q * 4 + 1] = __builtin_fmaf(Wv, f.y, acc[q * 4 + 1]);
+        acc[q * 4 + 2] = __builtin_fmaf(Wv, f.z, acc[q * 4 + 2]);
+        acc[q * 4 + 3] = __builtin_fmaf(Wv, f.w, acc[q * 4 + 3]);
+      }
+    }
+  }
+  // reduce over the GL lanes of the voxel, transpose through LDS, store x-runs
+#pragma unroll
+  for (int c = 0; c < CP; ++c) {
+    float v = acc[c];
+#pragma unroll
+    for (int o = GL >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, GL);
+    if (l == 0) outs[c][g] = v;
+  }
+  __syncthreads();
+  const long V = (long) P.Z * P.Y * P.X;
+  const long vox0 = ((long) iz * P.Y + iy) * P.X + (long) blockIdx.x * VPB;
+  for (int e = tid; e < nch * VPB; e += 256) {
+    const int c = e / VPB, gx = e % VPB;
+    if (blockIdx.x * VPB + gx >= P.X) continue;
+    const float v = outs[c][gx];
+    if (c == 0) gdens[(long) b * V + vox0 + gx] = v;
+    else if (c <= P.K) gsem[((long) b * P.K + (c - 1)) * V + vox0 + gx] = v;
+    else grgb[((long) b * 3 + (c - 1 - P.K)) * V + vox0 + gx] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+size_t cam_bwd_v2_bytes(const VampRenderDesc* d) {
+  const RenderParams P = to_params(d);
+  const size_t samples = (size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW;
+  const size_t rays = (size_t) d->B * d->N * d->fH * d->fW;
+  return 5 * align_up(samples * sizeof(float), 256) + align_up(rays * P.CP * sizeof(float), 256) +
+         align_up((size_t) d->B * d->N * 48 * sizeof(float), 256);
+}
+
+// scratch = workspace region after the packed volume
+int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const float* mats,
+                      const float* us, const float* vs, const float* ds, const float* mids,
+                      const float* beta, const float* packed, const float* g_rgb,
+                      const float* g_seg, const float* g_depth, float* gdens, float* gsem,
+                      float* grgb, float* grad_beta, void* scratch, hipStream_t s) {
+  const size_t samples = (size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW;
+  const size_t rays = (size_t) d->B * d->N * d->fH * d->fW;
+  char* p = static_cast<char*>(scratch);
+  float* Wbuf = reinterpret_cast<float*>(p); p += align_up(samples * sizeof(float), 256);
+  float* G0buf = reinterpret_cast<float*>(p); p += align_up(samples * sizeof(float), 256);
+  float* FX = reinterpret_cast<float*>(p); p += align_up(samples * sizeof(float), 256);
+  float* FY = reinterpret_cast<float*>(p); p += align_up(samples * sizeof(float), 256);
+  float* FZ = reinterpret_cast<float*>(p); p += align_up(samples * sizeof(float), 256);
+  float* Gcl = reinterpret_cast<float*>(p); p += align_up(rays * P.CP * sizeof(float), 256);
+  float* pmats = reinterpret_cast<float*>(p);
+
+  const int nm = d->B * d->N * 3;
+  VAMP_TIMED(kProfAux, s, (invert_mats_kernel<<<(nm + 63) / 64, 64, 0, s>>>(mats, pmats, nm)));
+  if (int e = check_launch("invert_mats_kernel")) return e;
+
+  constexpr int LPR = 4;
+  const int S = d->D - 1;
+  const int L = (S + LPR - 1) / LPR;
+  const size_t lds = (size_t) 3 * L * 256 * sizeof(float);
+  if (lds > 150 * 1024) return fail(VAMP_EINVAL, "%s: too many depth samples for the LDS staging", __func__);
+  const unsigned grid = (unsigned) ((rays * LPR + 255) / 256);
+  dim3 bgrid((d->X + VPB - 1) / VPB, d->Y, d->Z * d->B);
+#define VAMP_V2(CP4)                                                                              \
+  do {                                                                                            \
+    auto kr = cam_bwd_ray_kernel<LPR, CP4>;                                                       \
+    if (lds > 64 * 1024 &&                                                                        \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kr),                                    \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) \
+      return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);                           \
+    VAMP_TIMED(kProfCamBwd, s, (kr<<<grid, 256, lds, s>>>(P, mats, us, vs, ds, mids, beta, packed, \
+                                                           g_rgb, g_seg, g_depth, Wbuf, G0buf, FX, FY, FZ, \
+                                                           Gcl, grad_beta, L)));                  \
+    if (int e = check_launch("cam_bwd_ray_kernel")) return e;                                     \
+    VAMP_TIMED(kProfCamBwdBrick, s, (cam_bwd_gather_kernel<CP4><<<bgrid, 256, 0, s>>>(            \
+        P, pmats, us, vs, ds, FX, FY, FZ, Wbuf, G0buf, Gcl, gdens, gsem, grgb)));                 \
+  } while (0)
+  if (P.CP == 12) VAMP_V2(3); else if (P.CP == 24) VAMP_V2(6); else VAMP_V2(8);
+#undef VAMP_V2
+  return check_launch("cam_bwd_gather_kernel");
+}
+
+}  // namespace vamp

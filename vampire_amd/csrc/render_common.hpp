@@ -66,6 +66,7 @@ struct VolTap {
   bool inside;
   int ix0, iy0, iz0;
   float wx0, wx1, wy0, wy1, wz0, wz1;
+  float fx, fy, fz;      // continuous tap coordinates
 };
 
 __device__ __forceinline__ VolTap volume_tap(const RenderParams& P, float x, float y, float z) {
@@ -83,6 +84,7 @@ __device__ __forceinline__ VolTap volume_tap(const RenderParams& P, float x, flo
   t.wx1 = fx - flx; t.wx0 = (flx + 1.0f) - fx;
   t.wy1 = fy - fly; t.wy0 = (fly + 1.0f) - fy;
   t.wz1 = fz - flz; t.wz0 = (flz + 1.0f) - fz;
+  t.fx = fx; t.fy = fy; t.fz = fz;
   return t;
 }
 

@@ -314,6 +314,7 @@ int launch_pack(const RenderParams& P, int in_dtype, const void* dens, const voi
 using namespace vamp;
 
 namespace vamp {
+size_t cam_bwd_v2_bytes(const VampRenderDesc* d);
 size_t packed_bytes(const VampRenderDesc* d) {
   const RenderParams P = to_params(d);
   return align_up((size_t) d->B * d->Z * d->Y * d->X * P.CP * sizeof(float), 256);
@@ -324,7 +325,9 @@ extern "C" {
 
 size_t vamp_render_workspace_bytes(const VampRenderDesc* d) {
   if (!d) return 0;
-  return 2 * packed_bytes(d);   // packed volume + packed gradient volume (backward)
+  // packed volume + backward scratch (v1: packed gradient volume; v2: per-sample buffers)
+  const size_t pb = packed_bytes(d), v2 = cam_bwd_v2_bytes(d);
+  return pb + (pb > v2 ? pb : v2);
 }
 
 int vamp_render_camera_forward(const VampRenderDesc* d, const float* geom, const float* mats,
