@@ -199,7 +199,11 @@ int vamp_render_bev_forward(const VampRenderDesc* d, const float* oxs, const flo
  * BEV branch, backward.  The four volume gradients are ACCUMULATED into (so that
  * the camera-branch backward can run first into the same buffers); grad_base is
  * written only by this call and must be zero-filled (or hold a running sum).
+ * ozs_host is a HOST copy of ozs (used to find the volume planes the det grid
+ * touches); workspace needs vamp_render_bev_workspace_bytes(d) bytes.  With
+ * ozs_host == NULL the call falls back to the slower atomic formulation.
  */
+size_t vamp_render_bev_workspace_bytes(const VampRenderDesc* d);
 int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const float* oys,
                              const float* ozs, const float* bev_mids, const float* beta,
                              const void* density_feature, const void* semantic,
@@ -208,6 +212,7 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
                              const float* g_voxel_density, const float* g_voxel_output,
                              float* grad_density_feature, float* grad_semantic,
                              float* grad_rgb, float* grad_base, float* grad_beta,
+                             const float* ozs_host, void* workspace, size_t workspace_bytes,
                              void* stream);
 
 /*

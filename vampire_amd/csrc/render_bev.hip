@@ -1,0 +1,519 @@
+// BEV (top-down) branch of the renderer for gfx950: base_vampire2.py:408-418, 442-461.
+//
+// The det-grid sample lattice is regular, so every access pattern here is coalesced
+// (lanes along x) and the work splits per channel:
+//
+//  forward   bev_density   thread per column: density samples -> sigma_j (= voxel_density)
+//                          and the height expectation
+//            bev_channels  thread per (channel, column): trilinear samples of one channel at
+//                          the oZ heights; composite (sem / rgb) with weights rebuilt from
+//                          voxel_density, or pass through (base -> voxel_output)
+//  backward  bev_q         thread per (channel-lane, column): q_j = sum_c G_c s_j[c]
+//            bev_scan      thread per column: weights, dL/dtau_j, dL/ds_j[0], d beta
+//            bev_gather    thread per (channel, voxel): sums w_tap * dL/ds over the <= 3^3
+//                          lattice samples whose taps include the voxel -- no atomics; adds
+//                          onto the camera-branch gradient already in the buffers
+#include "render_common.hpp"
+
+namespace vamp {
+
+int launch_bev_bwd_v1(const VampRenderDesc* d, const float* oxs, const float* oys,
+                      const float* ozs, const float* bev_mids, const float* beta,
+                      const void* density_feature, const void* semantic, const void* rgb,
+                      const void* base, const float* g_bev_rgb, const float* g_bev_seg,
+                      const float* g_bev_height, const float* g_voxel_density,
+                      const float* g_voxel_output, float* grad_density_feature,
+                      float* grad_semantic, float* grad_rgb, float* grad_base, float* grad_beta,
+                      void* stream);
+
+// x/y part of a column's taps (shared by all heights) and the z part per height
+struct AxisTap {
+  int i0;
+  float w0, w1;
+};
+
+__device__ __forceinline__ AxisTap axis_tap(float pos, float lo, float span, int n) {
+  const float g = ((pos - lo) / span) * 2.0f - 1.0f;
+  const float f = ((g + 1.0f) / 2.0f) * (float) (n - 1);
+  const float fl = floorf(f);
+  AxisTap t;
+  t.i0 = (int) fl;
+  t.w1 = f - fl;
+  t.w0 = (fl + 1.0f) - f;
+  return t;
+}
+
+template <typename T>
+__device__ __forceinline__ float sample8(const RenderParams& P, const T* __restrict__ vol, long cb,
+                                         const AxisTap& tx, const AxisTap& ty, const AxisTap& tz) {
+  // aten tap order: x fastest, then y, then z; zero padding outside the volume
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int iz = tz.i0 + (k >> 2), iy = ty.i0 + ((k >> 1) & 1), ix = tx.i0 + (k & 1);
+    if (iz < 0 || iz >= P.Z || iy < 0 || iy >= P.Y || ix < 0 || ix >= P.X) continue;
+    const float wt = ((k & 1) ? tx.w1 : tx.w0) * ((k & 2) ? ty.w1 : ty.w0) * ((k & 4) ? tz.w1 : tz.w0);
+    s = __builtin_fmaf(wt, ldf(vol, cb + ((long) iz * P.Y + iy) * P.X + ix), s);
+  }
+  return s;
+}
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+bev_density_kernel(RenderParams P, const float* __restrict__ oxs, const float* __restrict__ oys,
+                   const float* __restrict__ ozs, const float* __restrict__ bev_mids,
+                   const float* __restrict__ beta_raw, const T* __restrict__ dens,
+                   float* __restrict__ voxel_density, float* __restrict__ bev_height) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  if (x >= P.oX || y >= P.oY) return;
+  const DensityParams dp = load_density(P.density_mode, beta_raw, P.beta_min, P.sdf_bias);
+  const long V = (long) P.Z * P.Y * P.X, OYX = (long) P.oY * P.oX, col = (long) y * P.oX + x;
+  const AxisTap tx = axis_tap(oxs[x], P.lo[0], P.span[0], P.X);
+  const AxisTap ty = axis_tap(oys[y], P.lo[1], P.span[1], P.Y);
+  float cum = 0.f, height = 0.f;
+  for (int j = 0; j < P.oZ; ++j) {
+    const AxisTap tz = axis_tap(ozs[P.oZ - 1 - j], P.lo[2], P.span[2], P.Z);     // flip (bv2:443)
+    const float sigma = density_fwd(dp, sample8(P, dens, (long) b * V, tx, ty, tz));
+    voxel_density[((long) b * P.oZ + j) * OYX + col] = sigma;
+    const float tau = sigma * (1.0f * P.z_step);                                  // bv2:451-453
+    height = __builtin_fmaf((1.0f - expf(-tau)) * expf(-cum), bev_mids[j], height);
+    cum += tau;
+  }
+  bev_height[(long) b * OYX + col] = height;
+}
+
+// channel index space of bev_channels: [0, K) semantic, [K, K+3) rgb, [K+3, K+3+C) base
+template <typename T>
+__global__ void __launch_bounds__(256)
+bev_channels_kernel(RenderParams P, const float* __restrict__ oxs, const float* __restrict__ oys,
+                    const float* __restrict__ ozs, const T* __restrict__ sem,
+                    const T* __restrict__ rgb, const T* __restrict__ base,
+                    const float* __restrict__ voxel_density, float* __restrict__ bev_rgb,
+                    float* __restrict__ bev_seg, float* __restrict__ voxel_output) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int nch = P.K + 3 + P.C;
+  const int b = blockIdx.z / nch, ch = blockIdx.z % nch;
+  if (x >= P.oX || y >= P.oY) return;
+  const long V = (long) P.Z * P.Y * P.X, OYX = (long) P.oY * P.oX, col = (long) y * P.oX + x;
+  const int CO = P.C + (P.cat_seg ? P.K : 0);
+  const AxisTap tx = axis_tap(oxs[x], P.lo[0], P.span[0], P.X);
+  const AxisTap ty = axis_tap(oys[y], P.lo[1], P.span[1], P.Y);
+  const T* vol;
+  long cb;
+  if (ch < P.K) { vol = sem; cb = ((long) b * P.K + ch) * V; }
+  else if (ch < P.K + 3) { vol = rgb; cb = ((long) b * 3 + (ch - P.K)) * V; }
+  else { vol = base; cb = ((long) b * P.C + (ch - P.K - 3)) * V; }
+  const bool composite = ch < P.K + 3;
+  float cum = 0.f, acc = 0.f;
+  for (int j = 0; j < P.oZ; ++j) {
+    const AxisTap tz = axis_tap(ozs[P.oZ - 1 - j], P.lo[2], P.span[2], P.Z);
+    const float sv = sample8(P, vol, cb, tx, ty, tz);
+    if (composite) {
+      const float tau = voxel_density[((long) b * P.oZ + j) * OYX + col] * (1.0f * P.z_step);
+      acc = __builtin_fmaf((1.0f - expf(-tau)) * expf(-cum), sv, acc);
+      cum += tau;
+      if (ch < P.K && P.cat_seg)
+        voxel_output[(((long) b * CO + P.C + ch) * P.oZ + j) * OYX + col] = sv;     // bv2:449-450
+    } else {
+      voxel_output[(((long) b * CO + (ch - P.K - 3)) * P.oZ + j) * OYX + col] = sv;
+    }
+  }
+  if (ch < P.K) bev_seg[((long) b * P.K + ch) * OYX + col] = acc;
+  else if (ch < P.K + 3) bev_rgb[((long) b * 3 + (ch - P.K)) * OYX + col] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------
+// Q[b][j][col] = sum over sem / rgb channels of G_c * s_j[c]; 4 channel-lanes per column
+template <typename T>
+__global__ void __launch_bounds__(256)
+bev_q_kernel(RenderParams P, const float* __restrict__ oxs, const float* __restrict__ oys,
+             const float* __restrict__ ozs, const T* __restrict__ sem, const T* __restrict__ rgb,
+             const float* __restrict__ g_brgb, const float* __restrict__ g_bseg,
+             float* __restrict__ Q) {
+  extern __shared__ float red[];                      // [3][oZ][64]
+  const int lx = threadIdx.x & 63, cl = threadIdx.x >> 6;
+  const int x = blockIdx.x * 64 + lx, y = blockIdx.y, b = blockIdx.z;
+  const bool live = x < P.oX;
+  const int xc = live ? x : P.oX - 1;
+  const long V = (long) P.Z * P.Y * P.X, OYX = (long) P.oY * P.oX, col = (long) y * P.oX + xc;
+  const AxisTap tx = axis_tap(oxs[xc], P.lo[0], P.span[0], P.X);
+  const AxisTap ty = axis_tap(oys[y], P.lo[1], P.span[1], P.Y);
+  const int nch = P.K + 3;
+  for (int j = 0; j < P.oZ; ++j) {
+    const AxisTap tz = axis_tap(ozs[P.oZ - 1 - j], P.lo[2], P.span[2], P.Z);
+    float q = 0.f;
+    for (int ch = cl; ch < nch; ch += 4) {
+      float gc;
+      const T* vol;
+      long cb;
+      if (ch < P.K) {
+        gc = g_bseg ? g_bseg[((long) b * P.K + ch) * OYX + col] : 0.f;
+        vol = sem; cb = ((long) b * P.K + ch) * V;
+      } else {
+        gc = g_brgb ? g_brgb[((long) b * 3 + (ch - P.K)) * OYX + col] : 0.f;
+        vol = rgb; cb = ((long) b * 3 + (ch - P.K)) * V;
+      }
+      if (gc != 0.f) q = __builtin_fmaf(gc, sample8(P, vol, cb, tx, ty, tz), q);
+    }
+    if (cl > 0) red[((cl - 1) * P.oZ + j) * 64 + lx] = q;
+    __syncthreads();
+    if (cl == 0 && live) {
+      q += red[(0 * P.oZ + j) * 64 + lx] + red[(1 * P.oZ + j) * 64 + lx] + red[(2 * P.oZ + j) * 64 + lx];
+      Q[((long) b * P.oZ + j) * OYX + col] = q;
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+bev_scan_kernel(RenderParams P, const float* __restrict__ oxs, const float* __restrict__ oys,
+                const float* __restrict__ ozs, const float* __restrict__ bev_mids,
+                const float* __restrict__ beta_raw, const T* __restrict__ dens,
+                const float* __restrict__ g_bh, const float* __restrict__ g_vd,
+                const float* __restrict__ Q, float* __restrict__ Wb, float* __restrict__ DS0,
+                float* __restrict__ grad_beta) {
+  __shared__ float red[4];
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  const bool live = x < P.oX && y < P.oY;
+  const int xc = min(x, P.oX - 1), yc = min(y, P.oY - 1);
+  const DensityParams dp = load_density(P.density_mode, beta_raw, P.beta_min, P.sdf_bias);
+  const long V = (long) P.Z * P.Y * P.X, OYX = (long) P.oY * P.oX, col = (long) yc * P.oX + xc;
+  const AxisTap tx = axis_tap(oxs[xc], P.lo[0], P.span[0], P.X);
+  const AxisTap ty = axis_tap(oys[yc], P.lo[1], P.span[1], P.Y);
+  const float Gh = g_bh ? g_bh[(long) b * OYX + col] : 0.f;
+  const float dz = 1.0f * P.z_step;
+  float total = 0.f, cum = 0.f;
+  for (int j = 0; j < P.oZ; ++j) {
+    const AxisTap tz = axis_tap(ozs[P.oZ - 1 - j], P.lo[2], P.span[2], P.Z);
+    const float tau = density_fwd(dp, sample8(P, dens, (long) b * V, tx, ty, tz)) * dz;
+    const float qv = Q[((long) b * P.oZ + j) * OYX + col] + Gh * bev_mids[j];
+    total = __builtin_fmaf((1.0f - expf(-tau)) * expf(-cum), qv, total);
+    cum += tau;
+  }
+  float prefix = 0.f, dbeta = 0.f;
+  cum = 0.f;
+  for (int j = 0; j < P.oZ; ++j) {
+    const AxisTap tz = axis_tap(ozs[P.oZ - 1 - j], P.lo[2], P.span[2], P.Z);
+    const float s0 = sample8(P, dens, (long) b * V, tx, ty, tz);
+    const float tau = density_fwd(dp, s0) * dz;
+    const float qv = Q[((long) b * P.oZ + j) * OYX + col] + Gh * bev_mids[j];
+    const float wgt = (1.0f - expf(-tau)) * expf(-cum);
+    const float Tn = expf(-(cum + tau));
+    cum += tau;
+    prefix = __builtin_fmaf(wgt, qv, prefix);
+    const float dtau = qv * Tn - (total - prefix);
+    float dsig_ds, dsig_db;
+    density_bwd(dp, s0, dsig_ds, dsig_db);
+    const float gvd = g_vd ? g_vd[((long) b * P.oZ + j) * OYX + col] : 0.f;
+    const float dsigma = dtau * dz + gvd;          // sigma feeds tau and voxel_density
+    dbeta = __builtin_fmaf(dsigma, dsig_db, dbeta);
+    if (live) {
+      Wb[((long) b * P.oZ + j) * OYX + col] = wgt;
+      DS0[((long) b * P.oZ + j) * OYX + col] = dsigma * dsig_ds;
+    }
+  }
+  if (P.density_mode == VAMP_DENSITY_SDF_LAPLACE) {
+    float v = live ? dbeta : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float sgn = (beta_raw[0] > 0.f) ? 1.f : ((beta_raw[0] < 0.f) ? -1.f : 0.f);
+      atomicAdd(grad_beta, sgn * (red[0] + red[1] + red[2] + red[3]));
+    }
+  }
+}
+
+// candidate lattice indices along one axis for voxel index iv: the lattice positions are
+// axis[k], uniformly spaced; returns [k_lo, k_hi] (clamped), possibly empty
+__device__ __forceinline__ void lattice_range(const float* __restrict__ axis, int n, float lo,
+                                              float span, int nvox, int iv, int& k_lo, int& k_hi) {
+  // voxel tap coordinate f = (p - lo) / span * (nvox - 1); |f - iv| < 1  <=>  p in (p0, p1)
+  const float e = span / (float) (nvox - 1);
+  const float p0 = lo + ((float) iv - 1.0f) * e, p1 = lo + ((float) iv + 1.0f) * e;
+  if (n == 1) { k_lo = 0; k_hi = 0; return; }
+  const float a0 = axis[0], step = (axis[n - 1] - a0) / (float) (n - 1);
+  float t0 = (p0 - a0) / step, t1 = (p1 - a0) / step;
+  if (t0 > t1) { const float t = t0; t0 = t1; t1 = t; }
+  k_lo = max(0, (int) floorf(t0 - 0.01f));
+  k_hi = min(n - 1, (int) ceilf(t1 + 0.01f));
+}
+
+__device__ __forceinline__ float tap_w(const AxisTap& t, int iv) {
+  return (t.i0 == iv) ? t.w0 : ((t.i0 + 1 == iv) ? t.w1 : 0.f);
+}
+
+// thread per voxel (z, y, x); the <= kMaxT lattice taps per axis and their weights are found
+// once and reused for all 1+K+3+C channels.
+constexpr int kMaxT = 4;
+
+struct AxisHits {
+  int k[kMaxT];
+  float w[kMaxT];
+  int n;
+  bool overflow;     // more than kMaxT lattice points touch this voxel: use the generic path
+};
+
+__device__ __forceinline__ AxisHits axis_hits(const float* __restrict__ axis, int n, float lo,
+                                              float span, int nvox, int iv) {
+  AxisHits h;
+  h.n = 0;
+  h.overflow = false;
+#pragma unroll
+  for (int i = 0; i < kMaxT; ++i) { h.k[i] = 0; h.w[i] = 0.f; }
+  int k_lo, k_hi;
+  lattice_range(axis, n, lo, span, nvox, iv, k_lo, k_hi);
+  for (int k = k_lo; k <= k_hi; ++k) {
+    const float w = tap_w(axis_tap(axis[k], lo, span, nvox), iv);
+    if (w != 0.f && h.n >= kMaxT) h.overflow = true;
+    if (w != 0.f && h.n < kMaxT) {
+#pragma unroll
+      for (int i = 0; i < kMaxT; ++i)
+        if (i == h.n) { h.k[i] = k; h.w[i] = w; }
+      ++h.n;
+    }
+  }
+  return h;
+}
+
+// any number of lattice points per voxel: weights recomputed inside the loops (slow, rare)
+__device__ __noinline__ void bev_gather_generic(
+    const RenderParams& P, const float* __restrict__ oxs, const float* __restrict__ oys,
+    const float* __restrict__ ozs, const float* __restrict__ g_brgb,
+    const float* __restrict__ g_bseg, const float* __restrict__ g_vo,
+    const float* __restrict__ Wb, const float* __restrict__ DS0, float* __restrict__ gdens,
+    float* __restrict__ gsem, float* __restrict__ grgb, float* __restrict__ gbase, int b, int x,
+    int y, int z) {
+  const long V = (long) P.Z * P.Y * P.X, OYX = (long) P.oY * P.oX;
+  const int CO = P.C + (P.cat_seg ? P.K : 0);
+  const long vox = ((long) z * P.Y + y) * P.X + x;
+  int kx0, kx1, ky0, ky1, kz0, kz1;
+  lattice_range(oxs, P.oX, P.lo[0], P.span[0], P.X, x, kx0, kx1);
+  lattice_range(oys, P.oY, P.lo[1], P.span[1], P.Y, y, ky0, ky1);
+  lattice_range(ozs, P.oZ, P.lo[2], P.span[2], P.Z, z, kz0, kz1);
+  const int nch = 1 + P.K + 3 + P.C;
+  for (int ch = 0; ch < nch; ++ch) {
+    float sum = 0.f;
+    for (int kz = kz0; kz <= kz1; ++kz) {
+      const float wz = tap_w(axis_tap(ozs[kz], P.lo[2], P.span[2], P.Z), z);
+      const int j = P.oZ - 1 - kz;
+      for (int ky = ky0; ky <= ky1; ++ky) {
+        const float wy = tap_w(axis_tap(oys[ky], P.lo[1], P.span[1], P.Y), y);
+        for (int kx = kx0; kx <= kx1; ++kx) {
+          const float wx = tap_w(axis_tap(oxs[kx], P.lo[0], P.span[0], P.X), x);
+          const float wt = wz * wy * wx;
+          if (wt == 0.f) continue;
+          const long cc = (long) ky * P.oX + kx;
+          const long sc = ((long) b * P.oZ + j) * OYX + cc;
+          float dsv = 0.f;
+          if (ch == 0) dsv = DS0[sc];
+          else if (ch <= P.K) {
+            if (g_bseg) dsv = Wb[sc] * g_bseg[((long) b * P.K + ch - 1) * OYX + cc];
+            if (P.cat_seg && g_vo) dsv += g_vo[(((long) b * CO + P.C + ch - 1) * P.oZ + j) * OYX + cc];
+          } else if (ch <= P.K + 3) {
+            if (g_brgb) dsv = Wb[sc] * g_brgb[((long) b * 3 + ch - 1 - P.K) * OYX + cc];
+          } else if (g_vo) {
+            dsv = g_vo[(((long) b * CO + ch - 4 - P.K) * P.oZ + j) * OYX + cc];
+          }
+          sum = __builtin_fmaf(wt, dsv, sum);
+        }
+      }
+    }
+    float* out = (ch == 0) ? gdens + (long) b * V
+                 : (ch <= P.K) ? gsem + ((long) b * P.K + ch - 1) * V
+                 : (ch <= P.K + 3) ? grgb + ((long) b * 3 + ch - 1 - P.K) * V
+                                   : gbase + ((long) b * P.C + ch - 4 - P.K) * V;
+    out[vox] += sum;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+bev_gather_kernel(RenderParams P, const float* __restrict__ oxs, const float* __restrict__ oys,
+                  const float* __restrict__ ozs, const float* __restrict__ g_brgb,
+                  const float* __restrict__ g_bseg, const float* __restrict__ g_vo,
+                  const float* __restrict__ Wb, const float* __restrict__ DS0,
+                  float* __restrict__ gdens, float* __restrict__ gsem, float* __restrict__ grgb,
+                  float* __restrict__ gbase, int z_lo, int z_hi) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int nz = z_hi - z_lo + 1;
+  const int z = z_lo + blockIdx.z % nz;
+  const int b = blockIdx.z / nz;
+  if (x >= P.X || y >= P.Y) return;
+  const long V = (long) P.Z * P.Y * P.X, OYX = (long) P.oY * P.oX;
+  const int CO = P.C + (P.cat_seg ? P.K : 0);
+  const AxisHits hx = axis_hits(oxs, P.oX, P.lo[0], P.span[0], P.X, x);
+  const AxisHits hy = axis_hits(oys, P.oY, P.lo[1], P.span[1], P.Y, y);
+  const AxisHits hz = axis_hits(ozs, P.oZ, P.lo[2], P.span[2], P.Z, z);
+  if (hx.n == 0 || hy.n == 0 || hz.n == 0) return;
+  const long vox = ((long) z * P.Y + y) * P.X + x;
+  if (hx.overflow || hy.overflow || hz.overflow) {      // det lattice much finer than the volume
+    bev_gather_generic(P, oxs, oys, ozs, g_brgb, g_bseg, g_vo, Wb, DS0, gdens, gsem, grgb, gbase,
+                       b, x, y, z);
+    return;
+  }
+
+  // density channel and the compositing weights of the hit samples
+  float s_dens = 0.f;
+  for (int a = 0; a < hz.n; ++a)
+    for (int c2 = 0; c2 < hy.n; ++c2)
+      for (int e = 0; e < hx.n; ++e) {
+        const long sc = ((long) b * P.oZ + (P.oZ - 1 - hz.k[a])) * OYX + (long) hy.k[c2] * P.oX + hx.k[e];
+        s_dens = __builtin_fmaf(hz.w[a] * hy.w[c2] * hx.w[e], DS0[sc], s_dens);
+      }
+  gdens[(long) b * V + vox] += s_dens;
+
+  const int nch = P.K + 3 + P.C;           // [0,K) sem, [K,K+3) rgb, [K+3, ..) base
+  for (int ch = 0; ch < nch; ++ch) {
+    const float* gcol = nullptr;
+    long gcol_base = 0, vo_base = -1;
+    float* out;
+    if (ch < P.K) {
+      out = gsem + ((long) b * P.K + ch) * V;
+      gcol = g_bseg; gcol_base = ((long) b * P.K + ch) * OYX;
+      if (P.cat_seg) vo_base = ((long) b * CO + P.C + ch) * P.oZ * OYX;
+    } else if (ch < P.K + 3) {
+      out = grgb + ((long) b * 3 + (ch - P.K)) * V;
+      gcol = g_brgb; gcol_base = ((long) b * 3 + (ch - P.K)) * OYX;
+    } else {
+      out = gbase + ((long) b * P.C + (ch - P.K - 3)) * V;
+      vo_base = ((long) b * CO + (ch - P.K - 3)) * P.oZ * OYX;
+    }
+    const bool use_col = gcol != nullptr, use_vo = (vo_base >= 0) && g_vo;
+    if (!use_col && !use_vo) continue;
+    float sum = 0.f;
+    for (int a = 0; a < hz.n; ++a) {
+      const int j = P.oZ - 1 - hz.k[a];
+      for (int c2 = 0; c2 < hy.n; ++c2)
+        for (int e = 0; e < hx.n; ++e) {
+          const long cc = (long) hy.k[c2] * P.oX + hx.k[e];
+          float dsv = 0.f;
+          if (use_col) dsv = Wb[((long) b * P.oZ + j) * OYX + cc] * gcol[gcol_base + cc];
+          if (use_vo) dsv += g_vo[vo_base + (long) j * OYX + cc];
+          sum = __builtin_fmaf(hz.w[a] * hy.w[c2] * hx.w[e], dsv, sum);
+        }
+    }
+    out[vox] += sum;
+  }
+}
+
+static size_t bev_ws_bytes(const VampRenderDesc* d) {
+  return 3 * align_up((size_t) d->B * d->oZ * d->oY * d->oX * sizeof(float), 256);
+}
+
+}  // namespace vamp
+
+using namespace vamp;
+
+extern "C" {
+
+size_t vamp_render_bev_workspace_bytes(const VampRenderDesc* d) { return d ? bev_ws_bytes(d) : 0; }
+
+int vamp_render_bev_forward(const VampRenderDesc* d, const float* oxs, const float* oys,
+                            const float* ozs, const float* bev_mids, const float* beta,
+                            const void* density_feature, const void* semantic, const void* rgb,
+                            const void* base, float* bev_rgb, float* bev_seg, float* bev_height,
+                            float* voxel_density, float* voxel_output, void* stream) {
+  if (int e = validate(d)) return e;
+  VAMP_REQUIRE(d->oZ > 0 && d->oY > 0 && d->oX > 0, "det grid must be non-empty");
+  VAMP_REQUIRE(oxs && oys && ozs && bev_mids && density_feature && semantic && rgb, "null pointer");
+  VAMP_REQUIRE(base || d->C == 0, "base is NULL");
+  VAMP_REQUIRE(bev_rgb && bev_seg && bev_height && voxel_density && voxel_output, "null output");
+  VAMP_REQUIRE(beta || d->density_mode == VAMP_DENSITY_SIGMOID, "beta is NULL");
+  const RenderParams P = to_params(d);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  dim3 g1((d->oX + 63) / 64, (d->oY + 3) / 4, d->B);
+  dim3 g2((d->oX + 63) / 64, (d->oY + 3) / 4, d->B * (d->K + 3 + d->C));
+#define VAMP_BEVF(T)                                                                              \
+  do {                                                                                            \
+    VAMP_TIMED(kProfBevFwd, s, (bev_density_kernel<T><<<g1, 256, 0, s>>>(                         \
+        P, oxs, oys, ozs, bev_mids, beta, (const T*) density_feature, voxel_density, bev_height))); \
+    if (int e = check_launch("bev_density_kernel")) return e;                                     \
+    VAMP_TIMED(kProfBevFwdCh, s, (bev_channels_kernel<T><<<g2, 256, 0, s>>>(                      \
+        P, oxs, oys, ozs, (const T*) semantic, (const T*) rgb, (const T*) base, voxel_density,    \
+        bev_rgb, bev_seg, voxel_output)));                                                        \
+  } while (0)
+  if (d->in_dtype == VAMP_F32) VAMP_BEVF(float); else VAMP_BEVF(__hip_bfloat16);
+#undef VAMP_BEVF
+  return check_launch("bev_channels_kernel");
+}
+
+int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const float* oys,
+                             const float* ozs, const float* bev_mids, const float* beta,
+                             const void* density_feature, const void* semantic, const void* rgb,
+                             const void* base, const float* g_bev_rgb, const float* g_bev_seg,
+                             const float* g_bev_height, const float* g_voxel_density,
+                             const float* g_voxel_output, float* grad_density_feature,
+                             float* grad_semantic, float* grad_rgb, float* grad_base,
+                             float* grad_beta, const float* ozs_host, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  VAMP_REQUIRE(d->oZ > 0 && d->oY > 0 && d->oX > 0, "det grid must be non-empty");
+  VAMP_REQUIRE(oxs && oys && ozs && bev_mids && density_feature && semantic && rgb, "null input");
+  VAMP_REQUIRE(grad_density_feature && grad_semantic && grad_rgb, "null output");
+  VAMP_REQUIRE(grad_base || d->C == 0 || !g_voxel_output, "grad_base is NULL");
+  VAMP_REQUIRE((beta && grad_beta) || d->density_mode == VAMP_DENSITY_SIGMOID, "beta / grad_beta is NULL");
+  const char* force = getenv("VAMP_BEV_BWD");
+  if (!ozs_host || (force && force[0] == 'v' && force[1] == '1'))
+    return launch_bev_bwd_v1(d, oxs, oys, ozs, bev_mids, beta, density_feature, semantic, rgb, base,
+                             g_bev_rgb, g_bev_seg, g_bev_height, g_voxel_density, g_voxel_output,
+                             grad_density_feature, grad_semantic, grad_rgb, grad_base, grad_beta,
+                             stream);
+  const size_t need = bev_ws_bytes(d);
+  if (!workspace || workspace_bytes < need)
+    return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) need);
+  const RenderParams P = to_params(d);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t one = need / 3;
+  float* Q = static_cast<float*>(workspace);
+  float* Wb = reinterpret_cast<float*>(static_cast<char*>(workspace) + one);
+  float* DS0 = reinterpret_cast<float*>(static_cast<char*>(workspace) + 2 * one);
+
+  // z-range of volume planes the lattice touches (host copy of the det-grid heights)
+  int z_lo = d->Z, z_hi = -1;
+  for (int k = 0; k < d->oZ; ++k) {
+    const float g = ((ozs_host[k] - d->lo[2]) / d->span[2]) * 2.0f - 1.0f;
+    const float f = ((g + 1.0f) / 2.0f) * (float) (d->Z - 1);
+    const int i0 = (int) floorf(f);
+    z_lo = i0 < z_lo ? i0 : z_lo;
+    z_hi = i0 + 1 > z_hi ? i0 + 1 : z_hi;
+  }
+  z_lo = z_lo < 0 ? 0 : z_lo;
+  z_hi = z_hi > d->Z - 1 ? d->Z - 1 : z_hi;
+  if (z_lo > z_hi) return VAMP_OK;
+
+  dim3 gq((d->oX + 63) / 64, d->oY, d->B);
+  dim3 gs((d->oX + 63) / 64, (d->oY + 3) / 4, d->B);
+  dim3 gg((d->X + 63) / 64, (d->Y + 3) / 4, d->B * (z_hi - z_lo + 1));
+  const size_t qlds = (size_t) 3 * d->oZ * 64 * sizeof(float);
+#define VAMP_BEVB(T)                                                                              \
+  do {                                                                                            \
+    VAMP_TIMED(kProfBevBwdQ, s, (bev_q_kernel<T><<<gq, 256, qlds, s>>>(                           \
+        P, oxs, oys, ozs, (const T*) semantic, (const T*) rgb, g_bev_rgb, g_bev_seg, Q)));        \
+    if (int e = check_launch("bev_q_kernel")) return e;                                           \
+    VAMP_TIMED(kProfBevBwd, s, (bev_scan_kernel<T><<<gs, 256, 0, s>>>(                            \
+        P, oxs, oys, ozs, bev_mids, beta, (const T*) density_feature, g_bev_height,               \
+        g_voxel_density, Q, Wb, DS0, grad_beta)));                                                \
+    if (int e = check_launch("bev_scan_kernel")) return e;                                        \
+  } while (0)
+  if (d->in_dtype == VAMP_F32) VAMP_BEVB(float); else VAMP_BEVB(__hip_bfloat16);
+#undef VAMP_BEVB
+  VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_kernel<<<gg, 256, 0, s>>>(
+      P, oxs, oys, ozs, g_bev_rgb, g_bev_seg, g_voxel_output, Wb, DS0, grad_density_feature,
+      grad_semantic, grad_rgb, grad_base, z_lo, z_hi)));
+  return check_launch("bev_gather_kernel");
+}
+
+}  // extern "C"

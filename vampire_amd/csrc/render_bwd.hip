@@ -393,14 +393,18 @@ int vamp_render_camera_backward(const VampRenderDesc* d, const float* geom, cons
   return check_launch("unpack_grad_kernel");
 }
 
-int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const float* oys,
-                             const float* ozs, const float* bev_mids, const float* beta,
-                             const void* density_feature, const void* semantic, const void* rgb,
-                             const void* base, const float* g_bev_rgb, const float* g_bev_seg,
-                             const float* g_bev_height, const float* g_voxel_density,
-                             const float* g_voxel_output, float* grad_density_feature,
-                             float* grad_semantic, float* grad_rgb, float* grad_base,
-                             float* grad_beta, void* stream) {
+}  // extern "C"
+
+namespace vamp {
+// v1 BEV backward (column threads + float atomics); kept as an independent cross-check
+int launch_bev_bwd_v1(const VampRenderDesc* d, const float* oxs, const float* oys,
+                      const float* ozs, const float* bev_mids, const float* beta,
+                      const void* density_feature, const void* semantic, const void* rgb,
+                      const void* base, const float* g_bev_rgb, const float* g_bev_seg,
+                      const float* g_bev_height, const float* g_voxel_density,
+                      const float* g_voxel_output, float* grad_density_feature,
+                      float* grad_semantic, float* grad_rgb, float* grad_base, float* grad_beta,
+                      void* stream) {
   if (int e = validate(d)) return e;
   VAMP_REQUIRE(d->oZ > 0 && d->oY > 0 && d->oX > 0, "det grid must be non-empty");
   VAMP_REQUIRE(oxs && oys && ozs && bev_mids && density_feature && semantic && rgb, "null input");
@@ -423,5 +427,4 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
         grad_rgb, grad_base, grad_beta)));
   return check_launch("render_bev_bwd_kernel");
 }
-
-}  // extern "C"
+}  // namespace vamp

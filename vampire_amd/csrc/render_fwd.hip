@@ -5,8 +5,7 @@
 //  render_cam_fwd      LPR lanes per ray march the D-1 samples; each sample is one
 //                      8-tap gather of CP contiguous floats; per-lane partial
 //                      composites are merged with wave shuffles
-//  render_bev_fwd      one thread per det-grid column, reads the channel-first volumes
-//                      directly (lanes along x -> coalesced)
+//  (the BEV branch lives in render_bev.hip)
 // HBM/L2-bound gathers and a short scan: no MFMA.
 #include "render_common.hpp"
 
@@ -162,86 +161,6 @@ render_cam_fwd_kernel(RenderParams P, const float* __restrict__ geom, const floa
 }
 
 // ---------------------------------------------------------------------------
-// BEV branch forward: thread per (b, y, x) column, top-down over oZ samples.
-// ---------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ float sample_cf(const RenderParams& P, const T* __restrict__ vol,
-                                           long chan_base, const VolTap& t) {
-  float s = 0.f;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int iz = t.iz0 + (k >> 2), iy = t.iy0 + ((k >> 1) & 1), ix = t.ix0 + (k & 1);
-    if (iz < 0 || iz >= P.Z || iy < 0 || iy >= P.Y || ix < 0 || ix >= P.X) continue;
-    const float wt = ((k & 1) ? t.wx1 : t.wx0) * ((k & 2) ? t.wy1 : t.wy0) *
-                     ((k & 4) ? t.wz1 : t.wz0);
-    s = __builtin_fmaf(wt, ldf(vol, chan_base + ((long) iz * P.Y + iy) * P.X + ix), s);
-  }
-  return s;
-}
-
-constexpr int kMaxK = 28;
-
-template <typename T>
-__global__ void __launch_bounds__(256)
-render_bev_fwd_kernel(RenderParams P, const float* __restrict__ oxs, const float* __restrict__ oys,
-                      const float* __restrict__ ozs, const float* __restrict__ bev_mids,
-                      const float* __restrict__ beta_raw, const T* __restrict__ dens,
-                      const T* __restrict__ sem, const T* __restrict__ rgb,
-                      const T* __restrict__ base, float* __restrict__ bev_rgb,
-                      float* __restrict__ bev_seg, float* __restrict__ bev_height,
-                      float* __restrict__ voxel_density, float* __restrict__ voxel_output) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y;
-  const int b = blockIdx.z;
-  if (x >= P.oX) return;
-  const DensityParams dp = load_density(P.density_mode, beta_raw, P.beta_min, P.sdf_bias);
-  const long V = (long) P.Z * P.Y * P.X;
-  const long OYX = (long) P.oY * P.oX;
-  const long col = (long) y * P.oX + x;
-  const int CO = P.C + (P.cat_seg ? P.K : 0);
-  const float ox = oxs[x], oy = oys[y];
-
-  float seg[kMaxK];
-#pragma unroll
-  for (int k = 0; k < kMaxK; ++k) seg[k] = 0.f;
-  float col_rgb[3] = {0.f, 0.f, 0.f};
-  float height = 0.f, cum = 0.f;
-
-  for (int j = 0; j < P.oZ; ++j) {
-    const int zi = P.oZ - 1 - j;                                   // flip (bv2:443)
-    const VolTap t = volume_tap(P, ox, oy, ozs[zi]);
-    const float s0 = sample_cf(P, dens, (long) b * V, t);
-    const float sigma = density_fwd(dp, s0);
-    voxel_density[((long) b * P.oZ + j) * OYX + col] = sigma;
-    const float tau = sigma * (1.0f * P.z_step);                   // bv2:451-453
-    const float wgt = (1.0f - expf(-tau)) * expf(-cum);
-    cum += tau;
-    height = __builtin_fmaf(wgt, bev_mids[j], height);
-#pragma unroll
-    for (int k = 0; k < kMaxK; ++k) {
-      if (k < P.K) {
-        const float sv = sample_cf(P, sem, ((long) b * P.K + k) * V, t);
-        seg[k] = __builtin_fmaf(wgt, sv, seg[k]);
-        if (P.cat_seg)
-          voxel_output[(((long) b * CO + P.C + k) * P.oZ + j) * OYX + col] = sv;
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-      col_rgb[c] = __builtin_fmaf(wgt, sample_cf(P, rgb, ((long) b * 3 + c) * V, t), col_rgb[c]);
-    for (int c = 0; c < P.C; ++c)
-      voxel_output[(((long) b * CO + c) * P.oZ + j) * OYX + col] =
-          sample_cf(P, base, ((long) b * P.C + c) * V, t);
-  }
-  bev_height[(long) b * OYX + col] = height;
-#pragma unroll
-  for (int k = 0; k < kMaxK; ++k)
-    if (k < P.K) bev_seg[((long) b * P.K + k) * OYX + col] = seg[k];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) bev_rgb[((long) b * 3 + c) * OYX + col] = col_rgb[c];
-}
-
-// ---------------------------------------------------------------------------
 // diagnostics + standalone geometry
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -357,32 +276,6 @@ int vamp_render_camera_forward(const VampRenderDesc* d, const float* geom, const
   if (P.CP == 12) VAMP_CAM(3); else if (P.CP == 24) VAMP_CAM(6); else VAMP_CAM(8);
 #undef VAMP_CAM
   return check_launch("render_cam_fwd_kernel");
-}
-
-int vamp_render_bev_forward(const VampRenderDesc* d, const float* oxs, const float* oys,
-                            const float* ozs, const float* bev_mids, const float* beta,
-                            const void* density_feature, const void* semantic, const void* rgb,
-                            const void* base, float* bev_rgb, float* bev_seg, float* bev_height,
-                            float* voxel_density, float* voxel_output, void* stream) {
-  if (int e = validate(d)) return e;
-  VAMP_REQUIRE(d->oZ > 0 && d->oY > 0 && d->oX > 0, "det grid must be non-empty");
-  VAMP_REQUIRE(oxs && oys && ozs && bev_mids && density_feature && semantic && rgb, "null pointer");
-  VAMP_REQUIRE(base || d->C == 0, "base is NULL");
-  VAMP_REQUIRE(bev_rgb && bev_seg && bev_height && voxel_density && voxel_output, "null output");
-  VAMP_REQUIRE(beta || d->density_mode == VAMP_DENSITY_SIGMOID, "beta is NULL");
-  RenderParams P = to_params(d);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  dim3 grid((d->oX + 63) / 64, d->oY, d->B);
-  if (d->in_dtype == VAMP_F32)
-    VAMP_TIMED(kProfBevFwd, s, (render_bev_fwd_kernel<float><<<grid, 64, 0, s>>>(
-        P, oxs, oys, ozs, bev_mids, beta, (const float*) density_feature, (const float*) semantic,
-        (const float*) rgb, (const float*) base, bev_rgb, bev_seg, bev_height, voxel_density, voxel_output)));
-  else
-    VAMP_TIMED(kProfBevFwd, s, (render_bev_fwd_kernel<__hip_bfloat16><<<grid, 64, 0, s>>>(
-        P, oxs, oys, ozs, bev_mids, beta, (const __hip_bfloat16*) density_feature,
-        (const __hip_bfloat16*) semantic, (const __hip_bfloat16*) rgb, (const __hip_bfloat16*) base,
-        bev_rgb, bev_seg, bev_height, voxel_density, voxel_output)));
-  return check_launch("render_bev_fwd_kernel");
 }
 
 int vamp_render_indices(const VampRenderDesc* d, const float* geom, const float* mats,

@@ -67,6 +67,8 @@ class HotPath:
         self.ds = geo.frustum[:, 0, 0, 2].contiguous().to(dev)
         self.camera_mids = geo.camera_mids.to(dev)
         self.bev_mids = geo.bev_mids.to(dev)
+        ozs_cpu = G.axis_centres(cfg.z_bound_det)
+        self.ozs_host = (C.c_float * ozs_cpu.numel())(*ozs_cpu.tolist())
         self._ws = {}
 
     # ---------------------------------------------------------------- descs
@@ -330,11 +332,12 @@ class _RenderFn(torch.autograd.Function):
             _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(g_rgb),
             _ptr(g_seg), _ptr(g_dep), _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gbeta), _ptr(ws),
             ws.numel(), _stream()), "vamp_render_camera_backward")
+        ws_bev = hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d)))
         _capi.check(hp.lib.vamp_render_bev_backward(
             C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
             _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(g_brgb), _ptr(g_bseg), _ptr(g_bh),
             _ptr(g_vd), _ptr(g_vo), _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gb), _ptr(gbeta),
-            _stream()), "vamp_render_bev_backward")
+            hp.ozs_host, _ptr(ws_bev), ws_bev.numel(), _stream()), "vamp_render_bev_backward")
         grad_beta = gbeta.reshape(ctx.beta_shape) if hp.cfg.density_mode == "sdf" else None
         return (None, gd.to(dens.dtype), gs.to(sem.dtype), gb.to(base.dtype), gr.to(rgb.dtype),
                 grad_beta, None, None)
