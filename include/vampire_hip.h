@@ -139,6 +139,7 @@ typedef struct VampRenderDesc {
   float span[3];         /* (float)(bound[1] - bound[0])             (bv2:399)   */
   float d_far;           /* d_bound[1], background depth             (bv2:436)   */
   float z_step_det;      /* z_bound_det[2], BEV delta                (bv2:451)   */
+  float det_step[3];     /* (x, y, z)_bound_det[2]: spacing of the det-grid lattice      */
   int32_t density_mode;  /* VAMP_DENSITY_*                                       */
   float sdf_bias;        /* ModifyLaplaceDensity.bias                            */
   float beta_min;        /* ModifyLaplaceDensity.beta_min (1e-4)                 */

@@ -38,7 +38,7 @@ def test_exports_every_declared_symbol(lib):
 def test_struct_layout_matches_header(lib):
     # 9+... ints and floats, no padding surprises: sizes are part of the ABI
     assert C.sizeof(_capi.VampLiftDesc) == 18 * 4
-    assert C.sizeof(_capi.VampRenderDesc) == 26 * 4
+    assert C.sizeof(_capi.VampRenderDesc) == 29 * 4
 
 
 def test_bad_descriptor_is_rejected_without_gpu(lib):

@@ -32,7 +32,7 @@ class VampRenderDesc(C.Structure):
                 ("Z", C.c_int32), ("Y", C.c_int32), ("X", C.c_int32),
                 ("oZ", C.c_int32), ("oY", C.c_int32), ("oX", C.c_int32),
                 ("lo", C.c_float * 3), ("span", C.c_float * 3),
-                ("d_far", C.c_float), ("z_step_det", C.c_float),
+                ("d_far", C.c_float), ("z_step_det", C.c_float), ("det_step", C.c_float * 3),
                 ("density_mode", C.c_int32), ("sdf_bias", C.c_float), ("beta_min", C.c_float),
                 ("cat_seg", C.c_int32), ("in_dtype", C.c_int32)]
 

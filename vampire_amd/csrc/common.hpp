@@ -50,6 +50,8 @@ struct ProfScope { int idx; };
 bool prof_enabled();
 void prof_begin(int slot, hipStream_t s, ProfScope* sc);
 void prof_end(hipStream_t s, ProfScope* sc);
+// device-side 4x4 inverses (runtime.hip)
+int launch_invert_mats(const float* mats, float* inv, int count, bool reverse3, hipStream_t s);
 // usage: VAMP_TIMED(slot, stream, kernel<<<...>>>(...));
 #define VAMP_TIMED(slot, stream, launch)              \
   do {                                                \

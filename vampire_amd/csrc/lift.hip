@@ -9,66 +9,9 @@
 // Memory-bound gather; no MFMA.  One thread per voxel, lanes along x so the
 // [B,C,Z,Y,X] stores coalesce; features are read channel-last (one 64-byte run
 // per tap for C = 16) from a transposed copy made by a tiny pre-pass.
-#include "common.hpp"
+#include "lift_common.hpp"
 
 namespace vamp {
-
-struct LiftParams {
-  int B, N, C, D, fH, fW, Z, Y, X;
-  float u_max, v_max, u_div, v_div, d_lo, d_hi, d_span;
-  int use_depth;
-};
-
-static LiftParams to_params(const VampLiftDesc* d) {
-  LiftParams p;
-  p.B = d->B; p.N = d->N; p.C = d->C; p.D = d->D; p.fH = d->fH; p.fW = d->fW;
-  p.Z = d->Z; p.Y = d->Y; p.X = d->X;
-  p.u_max = d->u_max; p.v_max = d->v_max; p.u_div = d->u_div; p.v_div = d->v_div;
-  p.d_lo = d->d_lo; p.d_hi = d->d_hi; p.d_span = d->d_span; p.use_depth = d->use_depth;
-  return p;
-}
-
-// Result of projecting one voxel centre into one camera.
-struct LiftTap {
-  bool valid;
-  int ix0, iy0, iz0;
-  float wx0, wx1, wy0, wy1, wz0, wz1;
-};
-
-// get_pixel (bv2:365-388) + validity / normalisation (bv2:493-505) + aten's
-// grid_sampler_unnormalize for align_corners=False.  Evaluation order is part of
-// the contract (bit-exact tap indices): do not reassociate, do not fuse.
-__device__ __forceinline__ LiftTap lift_project(const LiftParams& P, const float* __restrict__ m,
-                                                float x, float y, float z) {
-  Vec4 p{x, y, z, 1.0f};
-  p = matvec(m, p);        // inv(bda)
-  p = matvec(m + 16, p);   // intrin @ inv(sensor2ego)
-  float zc = (p.z < 1e-6f) ? 1e-6f : p.z;   // clamp(min=eps); NaN stays NaN
-  p.x = p.x / zc;
-  p.y = p.y / zc;
-  p = matvec(m + 32, p);   // ida
-  const float u = p.x, v = p.y, zz = p.z;
-  LiftTap t;
-  bool ok = (u > -0.5f) && (u < P.u_max) && (v > -0.5f) && (v < P.v_max);
-  if (P.use_depth) ok = ok && (zz > P.d_lo) && (zz < P.d_hi);
-  else ok = ok && (zz > 0.0f);
-  t.valid = ok;
-  float nx = 2.0f * (u / P.u_div) - 1.0f;
-  float ny = 2.0f * (v / P.v_div) - 1.0f;
-  float nz = P.use_depth ? (2.0f * ((zz - P.d_lo) / P.d_span) - 1.0f) : 0.0f;
-  nx = fminf(fmaxf(nx, -2.0f), 2.0f);
-  ny = fminf(fmaxf(ny, -2.0f), 2.0f);
-  nz = fminf(fmaxf(nz, -2.0f), 2.0f);
-  const float fx = ((nx + 1.0f) * (float) P.fW - 1.0f) / 2.0f;
-  const float fy = ((ny + 1.0f) * (float) P.fH - 1.0f) / 2.0f;
-  const float fz = ((nz + 1.0f) * (float) P.D - 1.0f) / 2.0f;
-  const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
-  t.ix0 = (int) flx; t.iy0 = (int) fly; t.iz0 = (int) flz;
-  t.wx1 = fx - flx; t.wx0 = (flx + 1.0f) - fx;
-  t.wy1 = fy - fly; t.wy0 = (fly + 1.0f) - fy;
-  t.wz1 = fz - flz; t.wz0 = (flz + 1.0f) - fz;
-  return t;
-}
 
 // ---------------------------------------------------------------------------
 // feat [BN, C, HW] (f32 or bf16) -> channel-last fp32 [BN, HW, C]
@@ -522,6 +465,12 @@ int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs
   hipStream_t s = static_cast<hipStream_t>(stream);
   const LiftParams P = to_params(d);
   const int BN = d->B * d->N, HW = d->fH * d->fW;
+  // v2 (default): one workgroup per pixel tile with LDS accumulators, no global atomics.
+  // VAMP_LIFT_BWD=v1 selects the per-voxel atomic splat, kept as an independent cross-check.
+  const char* force = getenv("VAMP_LIFT_BWD");
+  if (!(force && force[0] == 'v' && force[1] == '1'))
+    return launch_lift_bwd_tile(d, mats, xs, ys, zs, depth, feat, grad_out, hits, grad_depth,
+                                grad_feat, workspace, s);
   if (d->in_dtype == VAMP_F32) launch_to_cl<float>(feat, w.feat_cl, BN, d->C, HW, s);
   else launch_to_cl<__hip_bfloat16>(feat, w.feat_cl, BN, d->C, HW, s);
   if (int e = check_launch("feat_to_channel_last")) return e;

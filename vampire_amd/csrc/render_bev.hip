@@ -257,7 +257,7 @@ __device__ __forceinline__ float tap_w(const AxisTap& t, int iv) {
 
 // thread per voxel (z, y, x); the <= kMaxT lattice taps per axis and their weights are found
 // once and reused for all 1+K+3+C channels.
-constexpr int kMaxT = 4;
+constexpr int kMaxT = 3;
 
 struct AxisHits {
   int k[kMaxT];
@@ -288,14 +288,22 @@ __device__ __forceinline__ AxisHits axis_hits(const float* __restrict__ axis, in
   return h;
 }
 
-// any number of lattice points per voxel: weights recomputed inside the loops (slow, rare)
-__device__ __noinline__ void bev_gather_generic(
-    const RenderParams& P, const float* __restrict__ oxs, const float* __restrict__ oys,
-    const float* __restrict__ ozs, const float* __restrict__ g_brgb,
-    const float* __restrict__ g_bseg, const float* __restrict__ g_vo,
-    const float* __restrict__ Wb, const float* __restrict__ DS0, float* __restrict__ gdens,
-    float* __restrict__ gsem, float* __restrict__ grgb, float* __restrict__ gbase, int b, int x,
-    int y, int z) {
+// any number of lattice points per voxel: weights recomputed inside the loops (slow; only
+// launched when the det lattice is much finer than the volume)
+__global__ void __launch_bounds__(256)
+bev_gather_generic_kernel(RenderParams P, const float* __restrict__ oxs,
+                          const float* __restrict__ oys, const float* __restrict__ ozs,
+                          const float* __restrict__ g_brgb, const float* __restrict__ g_bseg,
+                          const float* __restrict__ g_vo, const float* __restrict__ Wb,
+                          const float* __restrict__ DS0, float* __restrict__ gdens,
+                          float* __restrict__ gsem, float* __restrict__ grgb,
+                          float* __restrict__ gbase, int z_lo, int z_hi) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int nz = z_hi - z_lo + 1;
+  const int z = z_lo + blockIdx.z % nz;
+  const int b = blockIdx.z / nz;
+  if (x >= P.X || y >= P.Y) return;
   const long V = (long) P.Z * P.Y * P.X, OYX = (long) P.oY * P.oX;
   const int CO = P.C + (P.cat_seg ? P.K : 0);
   const long vox = ((long) z * P.Y + y) * P.X + x;
@@ -359,17 +367,16 @@ bev_gather_kernel(RenderParams P, const float* __restrict__ oxs, const float* __
   const AxisHits hz = axis_hits(ozs, P.oZ, P.lo[2], P.span[2], P.Z, z);
   if (hx.n == 0 || hy.n == 0 || hz.n == 0) return;
   const long vox = ((long) z * P.Y + y) * P.X + x;
-  if (hx.overflow || hy.overflow || hz.overflow) {      // det lattice much finer than the volume
-    bev_gather_generic(P, oxs, oys, ozs, g_brgb, g_bseg, g_vo, Wb, DS0, gdens, gsem, grgb, gbase,
-                       b, x, y, z);
-    return;
-  }
 
   // density channel and the compositing weights of the hit samples
   float s_dens = 0.f;
-  for (int a = 0; a < hz.n; ++a)
-    for (int c2 = 0; c2 < hy.n; ++c2)
-      for (int e = 0; e < hx.n; ++e) {
+#pragma unroll
+  for (int a = 0; a < kMaxT; ++a)
+#pragma unroll
+    for (int c2 = 0; c2 < kMaxT; ++c2)
+#pragma unroll
+      for (int e = 0; e < kMaxT; ++e) {
+        if (a >= hz.n || c2 >= hy.n || e >= hx.n) continue;
         const long sc = ((long) b * P.oZ + (P.oZ - 1 - hz.k[a])) * OYX + (long) hy.k[c2] * P.oX + hx.k[e];
         s_dens = __builtin_fmaf(hz.w[a] * hy.w[c2] * hx.w[e], DS0[sc], s_dens);
       }
@@ -394,17 +401,20 @@ bev_gather_kernel(RenderParams P, const float* __restrict__ oxs, const float* __
     const bool use_col = gcol != nullptr, use_vo = (vo_base >= 0) && g_vo;
     if (!use_col && !use_vo) continue;
     float sum = 0.f;
-    for (int a = 0; a < hz.n; ++a) {
-      const int j = P.oZ - 1 - hz.k[a];
-      for (int c2 = 0; c2 < hy.n; ++c2)
-        for (int e = 0; e < hx.n; ++e) {
+#pragma unroll
+    for (int a = 0; a < kMaxT; ++a)
+#pragma unroll
+      for (int c2 = 0; c2 < kMaxT; ++c2)
+#pragma unroll
+        for (int e = 0; e < kMaxT; ++e) {
+          if (a >= hz.n || c2 >= hy.n || e >= hx.n) continue;
+          const int j = P.oZ - 1 - hz.k[a];
           const long cc = (long) hy.k[c2] * P.oX + hx.k[e];
           float dsv = 0.f;
           if (use_col) dsv = Wb[((long) b * P.oZ + j) * OYX + cc] * gcol[gcol_base + cc];
           if (use_vo) dsv += g_vo[vo_base + (long) j * OYX + cc];
           sum = __builtin_fmaf(hz.w[a] * hy.w[c2] * hx.w[e], dsv, sum);
         }
-    }
     out[vox] += sum;
   }
 }
@@ -510,9 +520,21 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
   } while (0)
   if (d->in_dtype == VAMP_F32) VAMP_BEVB(float); else VAMP_BEVB(__hip_bfloat16);
 #undef VAMP_BEVB
-  VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_kernel<<<gg, 256, 0, s>>>(
-      P, oxs, oys, ozs, g_bev_rgb, g_bev_seg, g_voxel_output, Wb, DS0, grad_density_feature,
-      grad_semantic, grad_rgb, grad_base, z_lo, z_hi)));
+  // lattice points within one voxel's trilinear support, per axis
+  bool fits = true;
+  const int nvox[3] = {d->X, d->Y, d->Z};
+  for (int a = 0; a < 3; ++a) {
+    const float e = d->span[a] / (float) (nvox[a] - 1);
+    if (!(d->det_step[a] > 0.f) || (int) floorf(2.0f * e / d->det_step[a]) + 1 > kMaxT) fits = false;
+  }
+  if (fits)
+    VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_kernel<<<gg, 256, 0, s>>>(
+        P, oxs, oys, ozs, g_bev_rgb, g_bev_seg, g_voxel_output, Wb, DS0, grad_density_feature,
+        grad_semantic, grad_rgb, grad_base, z_lo, z_hi)));
+  else
+    VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_generic_kernel<<<gg, 256, 0, s>>>(
+        P, oxs, oys, ozs, g_bev_rgb, g_bev_seg, g_voxel_output, Wb, DS0, grad_density_feature,
+        grad_semantic, grad_rgb, grad_base, z_lo, z_hi)));
   return check_launch("bev_gather_kernel");
 }
 

@@ -19,39 +19,6 @@
 namespace vamp {
 
 // ---------------------------------------------------------------------------
-// 1. 4x4 inverses (Gauss-Jordan, partial pivoting, double)
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
-invert_mats_kernel(const float* __restrict__ mats, float* __restrict__ inv, int count) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  double a[4][8];
-  for (int r = 0; r < 4; ++r)
-    for (int c = 0; c < 4; ++c) {
-      a[r][c] = mats[i * 16 + r * 4 + c];
-      a[r][4 + c] = (r == c) ? 1.0 : 0.0;
-    }
-  for (int col = 0; col < 4; ++col) {
-    int piv = col;
-    double best = fabs(a[col][col]);
-    for (int r = col + 1; r < 4; ++r)
-      if (fabs(a[r][col]) > best) { best = fabs(a[r][col]); piv = r; }
-    if (piv != col)
-      for (int c = 0; c < 8; ++c) { double t = a[col][c]; a[col][c] = a[piv][c]; a[piv][c] = t; }
-    const double d = a[col][col];
-    const double id = (d != 0.0) ? 1.0 / d : 0.0;      // singular -> zeros -> full-image boxes
-    for (int c = 0; c < 8; ++c) a[col][c] *= id;
-    for (int r = 0; r < 4; ++r) {
-      if (r == col) continue;
-      const double f = a[r][col];
-      for (int c = 0; c < 8; ++c) a[r][c] -= f * a[col][c];
-    }
-  }
-  for (int r = 0; r < 4; ++r)
-    for (int c = 0; c < 4; ++c) inv[i * 16 + r * 4 + c] = (float) a[r][4 + c];
-}
-
-// ---------------------------------------------------------------------------
 // 2. per-ray pass
 // ---------------------------------------------------------------------------
 template <int LPR, int CP4>
@@ -72,16 +39,11 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
   float* l_dl = lds + (long) L * 256;
   float* l_q = lds + (long) 2 * L * 256;
 
-  const long t = (long) blockIdx.x * blockDim.x + tid;
-  const long nrays = (long) P.B * P.N * P.fH * P.fW;
-  long ray = t / LPR;
-  const int sub = (int) (t % LPR);
-  const bool live = ray < nrays;
-  if (!live) ray = nrays - 1;
-  const int w = ray % P.fW;
-  const int h = (ray / P.fW) % P.fH;
-  const long bn = ray / ((long) P.fW * P.fH);
-  const int b = bn / P.N;
+  const RayId id = decode_ray<LPR>(P);
+  const bool live = id.live;
+  const int w = id.w, h = id.h, sub = id.sub, b = id.b;
+  const long bn = id.bn;
+  const long ray = (bn * P.fH + h) * P.fW + w;
   const DensityParams dp = load_density(P.density_mode, beta_raw, P.beta_min, P.sdf_bias);
   const int S = P.D - 1;
   const int i0 = min(S, sub * L), i1 = min(S, i0 + L);
@@ -170,25 +132,8 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
   // ---- merge the LPR chunks of the ray ----
   float scale = 1.f, suffix = 0.f;
   if (LPR > 1) {
-    float incl = cum;
-#pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) {
-      const float up = __shfl_up(incl, o, LPR);
-      if (sub >= o) incl += up;
-    }
-    float excl = __shfl_up(incl, 1, LPR);
-    if (sub == 0) excl = 0.f;
-    scale = expf(-excl);
-    // suffix_k = sum_{m > k} scale_m A_m
-    const float Bk = scale * A;
-    float sfx = Bk;                      // inclusive suffix
-#pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) {
-      const float dn = __shfl_down(sfx, o, LPR);
-      if (sub + o < LPR) sfx += dn;
-    }
-    const float nb = __shfl_down(sfx, 1, LPR);       // exclusive suffix = neighbour's inclusive
-    suffix = (sub == LPR - 1) ? 0.f : nb;
+    scale = expf(-ray_excl_prefix<LPR>(cum, sub));
+    suffix = ray_excl_suffix<LPR>(scale * A, sub);      // sum_{m > sub} scale_m A_m
   }
 
   // ---- second loop over the LDS copies: emit w_i and dL/ds_i[0] ----
@@ -319,18 +264,21 @@ cam_bwd_gather_kernel(RenderParams P, const float* __restrict__ pmats, const flo
     const int nw = w_hi - w_lo + 1, nh = h_hi - h_lo + 1;
     const int count = nw * nh * (i_hi - i_lo + 1);
     const long sbase = bn * S * HW;
+    const float inv_nw = 1.0f / (float) nw, inv_nh = 1.0f / (float) nh;
     for (int idx = l; idx < count; idx += GL) {
-      const int w = w_lo + idx % nw;
-      const int r = idx / nw;
-      const int h = h_lo + r % nh;
-      const int i = i_lo + r / nh;
-      const long sidx = sbase + ((long) i * P.fH + h) * P.fW + w;
-      const float fx = FX[sidx];
-      if (!(fabsf(fx - fix) < 1.0f)) continue;          // NaN (masked sample) fails too
-      const float fy = FY[sidx];
-      if (!(fabsf(fy - fiy) < 1.0f)) continue;
-      const float fz = FZ[sidx];
-      if (!(fabsf(fz - fiz) < 1.0f)) continue;
+      // idx -> (i, h, w) without integer division (count < 2^20, quotients exact)
+      int r = (int) (((float) idx + 0.5f) * inv_nw);
+      int w = idx - r * nw;
+      if (w < 0) { w += nw; --r; } else if (w >= nw) { w -= nw; ++r; }
+      int i = (int) (((float) r + 0.5f) * inv_nh);
+      int h = r - i * nh;
+      if (h < 0) { h += nh; --i; } else if (h >= nh) { h -= nh; ++i; }
+      const long sidx = sbase + ((long) (i_lo + i) * P.fH + (h_lo + h)) * P.fW + (w_lo + w);
+      w += w_lo; h += h_lo;
+      // the three coordinate loads are independent: issue them together, test afterwards
+      const float fx = FX[sidx], fy = FY[sidx], fz = FZ[sidx];
+      if (!(fabsf(fx - fix) < 1.0f) || !(fabsf(fy - fiy) < 1.0f) || !(fabsf(fz - fiz) < 1.0f))
+        continue;                                         // NaN fx = masked sample fails too
       const float wt = tap_weight(fx, fix) * tap_weight(fy, fiy) * tap_weight(fz, fiz);
       const float Wv = wt * Wbuf[sidx];
       acc[0] = __builtin_fmaf(wt, G0buf[sidx], acc[0]);
@@ -394,16 +342,14 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
   float* Gcl = reinterpret_cast<float*>(p); p += align_up(rays * P.CP * sizeof(float), 256);
   float* pmats = reinterpret_cast<float*>(p);
 
-  const int nm = d->B * d->N * 3;
-  VAMP_TIMED(kProfAux, s, (invert_mats_kernel<<<(nm + 63) / 64, 64, 0, s>>>(mats, pmats, nm)));
-  if (int e = check_launch("invert_mats_kernel")) return e;
+  if (int e = launch_invert_mats(mats, pmats, d->B * d->N * 3, false, s)) return e;
 
   constexpr int LPR = 4;
   const int S = d->D - 1;
   const int L = (S + LPR - 1) / LPR;
   const size_t lds = (size_t) 3 * L * 256 * sizeof(float);
   if (lds > 150 * 1024) return fail(VAMP_EINVAL, "%s: too many depth samples for the LDS staging", __func__);
-  const unsigned grid = (unsigned) ((rays * LPR + 255) / 256);
+  const unsigned grid = ray_grid<LPR>(P);
   dim3 bgrid((d->X + VPB - 1) / VPB, d->Y, d->Z * d->B);
 #define VAMP_V2(CP4)                                                                              \
   do {                                                                                            \

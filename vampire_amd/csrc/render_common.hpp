@@ -41,6 +41,93 @@ inline int validate(const VampRenderDesc* d) {
   return VAMP_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Ray -> thread mapping of the per-ray kernels.  A 256-thread workgroup owns an
+// 8 x (32 / LPR) pixel tile of one camera; within a wave the lanes are laid out
+// [sub][ray] so that neighbouring lanes march neighbouring rays at the same depth
+// (shared taps -> L1 hits, contiguous per-sample stores).  Workgroups are dealt to
+// the 8 XCDs round-robin by the hardware; the tile index is permuted so that each
+// XCD works on one contiguous range of tiles (~3/4 of a camera) and its private L2
+// keeps that camera's part of the volume.
+// ---------------------------------------------------------------------------
+struct RayId {
+  bool live;     // false: lane only takes part in shuffles
+  int w, h, sub;
+  long bn;
+  int b;
+};
+
+template <int LPR>
+__device__ __forceinline__ int ray_tile_h() { return 32 / LPR; }
+
+template <int LPR>
+inline unsigned ray_grid(const RenderParams& P) {
+  const int th = 32 / LPR;
+  const long tiles = (long) P.B * P.N * ((P.fH + th - 1) / th) * ((P.fW + 7) / 8);
+  return (unsigned) ((tiles + 7) / 8 * 8);
+}
+
+template <int LPR>
+__device__ __forceinline__ RayId decode_ray(const RenderParams& P) {
+  constexpr int RPW = 64 / LPR;                   // rays per wave
+  constexpr int THt = 32 / LPR;                   // tile height (tile width is 8)
+  const int tiles_w = (P.fW + 7) / 8, tiles_h = (P.fH + THt - 1) / THt;
+  const long tiles = (long) P.B * P.N * tiles_h * tiles_w;
+  const long per_xcd = (tiles + 7) / 8;
+  const long t = (long) (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = wave * RPW + (lane % RPW);        // ray slot inside the tile
+  RayId id;
+  id.sub = lane / RPW;
+  const long tc = t < tiles ? t : tiles - 1;
+  id.bn = tc / (tiles_h * tiles_w);
+  const int tt = (int) (tc % (tiles_h * tiles_w));
+  id.h = (tt / tiles_w) * THt + r / 8;
+  id.w = (tt % tiles_w) * 8 + r % 8;
+  id.live = t < tiles && id.h < P.fH && id.w < P.fW;
+  if (id.h >= P.fH) id.h = P.fH - 1;
+  if (id.w >= P.fW) id.w = P.fW - 1;
+  id.b = (int) (id.bn / P.N);
+  return id;
+}
+
+// exclusive prefix sum over the LPR lanes of a ray ([sub][ray] lane layout)
+template <int LPR>
+__device__ __forceinline__ float ray_excl_prefix(float v, int sub) {
+  constexpr int RPW = 64 / LPR;
+  float incl = v;
+#pragma unroll
+  for (int o = 1; o < LPR; o <<= 1) {
+    const float up = __shfl_up(incl, o * RPW, 64);
+    if (sub >= o) incl += up;
+  }
+  const float ex = __shfl_up(incl, RPW, 64);
+  return sub == 0 ? 0.f : ex;
+}
+
+// sum over the LPR lanes of a ray, valid in the sub == 0 lane
+template <int LPR>
+__device__ __forceinline__ float ray_sum(float v) {
+  constexpr int RPW = 64 / LPR;
+#pragma unroll
+  for (int o = LPR >> 1; o > 0; o >>= 1) v += __shfl_down(v, o * RPW, 64);
+  return v;
+}
+
+// exclusive suffix sum over the LPR lanes of a ray
+template <int LPR>
+__device__ __forceinline__ float ray_excl_suffix(float v, int sub) {
+  constexpr int RPW = 64 / LPR;
+  float incl = v;
+#pragma unroll
+  for (int o = 1; o < LPR; o <<= 1) {
+    const float dn = __shfl_down(incl, o * RPW, 64);
+    if (sub + o < LPR) incl += dn;
+  }
+  const float ex = __shfl_down(incl, RPW, 64);
+  return sub == LPR - 1 ? 0.f : ex;
+}
+
 // One frustum point in the ego frame: get_geometry (bv2:328-349) followed by
 // nan_to_num(nan=-1e3) (bv2:612).  m = [inv(ida), sensor2ego @ inv(intrin), bda].
 __device__ __forceinline__ void frustum_point(const float* __restrict__ m, float u, float v,

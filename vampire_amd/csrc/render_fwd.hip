@@ -48,16 +48,10 @@ render_cam_fwd_kernel(RenderParams P, const float* __restrict__ geom, const floa
                       float* __restrict__ rgb_out, float* __restrict__ seg_out,
                       float* __restrict__ depth_out) {
   constexpr int CP = CP4 * 4;
-  const long t = (long) blockIdx.x * blockDim.x + threadIdx.x;
-  const long nrays = (long) P.B * P.N * P.fH * P.fW;
-  long ray = t / LPR;
-  const int sub = (int) (t % LPR);
-  const bool live = ray < nrays;
-  if (!live) ray = nrays - 1;           // keep the lane for the shuffles, drop its store
-  const int w = ray % P.fW;
-  const int h = (ray / P.fW) % P.fH;
-  const long bn = ray / ((long) P.fW * P.fH);
-  const int b = bn / P.N;
+  const RayId id = decode_ray<LPR>(P);
+  const bool live = id.live;
+  const int w = id.w, h = id.h, sub = id.sub, b = id.b;
+  const long bn = id.bn;
 
   const DensityParams dp = load_density(P.density_mode, beta_raw, P.beta_min, P.sdf_bias);
   const int S = P.D - 1;
@@ -130,24 +124,10 @@ render_cam_fwd_kernel(RenderParams P, const float* __restrict__ geom, const floa
 
   if (LPR > 1) {
     // transmittance of everything in front of this lane's chunk
-    float incl = cum;
+    const float scale = expf(-ray_excl_prefix<LPR>(cum, sub));
+    acc_depth = ray_sum<LPR>(acc_depth * scale);
 #pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) {
-      const float up = __shfl_up(incl, o, LPR);
-      if (sub >= o) incl += up;
-    }
-    float excl = __shfl_up(incl, 1, LPR);
-    if (sub == 0) excl = 0.f;
-    const float scale = expf(-excl);
-    acc_depth *= scale;
-#pragma unroll
-    for (int c = 0; c < CP; ++c) acc[c] *= scale;
-#pragma unroll
-    for (int o = LPR >> 1; o > 0; o >>= 1) {
-      acc_depth += __shfl_down(acc_depth, o, LPR);
-#pragma unroll
-      for (int c = 0; c < CP; ++c) acc[c] += __shfl_down(acc[c], o, LPR);
-    }
+    for (int c = 0; c < CP; ++c) acc[c] = ray_sum<LPR>(acc[c] * scale);
   }
   if (!live || sub != 0) return;
   const long HW = (long) P.fH * P.fW;
@@ -268,8 +248,7 @@ int vamp_render_camera_forward(const VampRenderDesc* d, const float* geom, const
   float* packed = static_cast<float*>(workspace);
   if (int e = launch_pack(P, d->in_dtype, density_feature, semantic, rgb, packed, s)) return e;
   constexpr int LPR = 4;
-  const long threads = (long) d->B * d->N * d->fH * d->fW * LPR;
-  const unsigned grid = (unsigned) ((threads + 255) / 256);
+  const unsigned grid = ray_grid<LPR>(P);
 #define VAMP_CAM(CP4)                                                                        \
   VAMP_TIMED(kProfCamFwd, s, (render_cam_fwd_kernel<LPR, CP4><<<grid, 256, 0, s>>>(          \
       P, geom, mats, us, vs, ds, mids, beta, packed, rgb_out, seg_out, depth_out)))

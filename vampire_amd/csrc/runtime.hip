@@ -50,6 +50,48 @@ void prof_end(hipStream_t s, ProfScope* sc) {
   if (sc->idx < (int) g_pairs.size()) (void) hipEventRecord(g_pairs[sc->idx].b, s);
 }
 
+
+// ---------------------------------------------------------------------------
+// 4x4 inverses (Gauss-Jordan, partial pivoting, double).  With reverse3 the matrices are taken
+// in triples and each triple is written in reverse order (inverse of a 3-matrix chain).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+invert_mats_kernel(const float* __restrict__ mats, float* __restrict__ inv, int count, int reverse3) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double a[4][8];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) {
+      a[r][c] = mats[i * 16 + r * 4 + c];
+      a[r][4 + c] = (r == c) ? 1.0 : 0.0;
+    }
+  for (int col = 0; col < 4; ++col) {
+    int piv = col;
+    double best = fabs(a[col][col]);
+    for (int r = col + 1; r < 4; ++r)
+      if (fabs(a[r][col]) > best) { best = fabs(a[r][col]); piv = r; }
+    if (piv != col)
+      for (int c = 0; c < 8; ++c) { double t = a[col][c]; a[col][c] = a[piv][c]; a[piv][c] = t; }
+    const double d = a[col][col];
+    const double id = (d != 0.0) ? 1.0 / d : 0.0;      // singular -> zeros -> full-image boxes
+    for (int c = 0; c < 8; ++c) a[col][c] *= id;
+    for (int r = 0; r < 4; ++r) {
+      if (r == col) continue;
+      const double f = a[r][col];
+      for (int c = 0; c < 8; ++c) a[r][c] -= f * a[col][c];
+    }
+  }
+  const int o = reverse3 ? (i / 3) * 3 + (2 - i % 3) : i;
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) inv[o * 16 + r * 4 + c] = (float) a[r][4 + c];
+}
+
+
+int launch_invert_mats(const float* mats, float* inv, int count, bool reverse3, hipStream_t s) {
+  VAMP_TIMED(kProfAux, s, (invert_mats_kernel<<<(count + 63) / 64, 64, 0, s>>>(mats, inv, count, reverse3 ? 1 : 0)));
+  return check_launch("invert_mats_kernel");
+}
+
 }  // namespace vamp
 
 using namespace vamp;

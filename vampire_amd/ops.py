@@ -100,6 +100,8 @@ class HotPath:
             d.span[i] = b[1] - b[0]
         d.d_far = c.d_bound[1]
         d.z_step_det = c.z_bound_det[2]
+        for i, bnd in enumerate((c.x_bound_det, c.y_bound_det, c.z_bound_det)):
+            d.det_step[i] = bnd[2]
         d.density_mode = (_capi.VAMP_DENSITY_SDF_LAPLACE if c.density_mode == "sdf"
                           else _capi.VAMP_DENSITY_SIGMOID)
         d.sdf_bias = c.sdf_bias
