@@ -380,6 +380,8 @@ static LiftWs carve(const VampLiftDesc* d, void* ws) {
   w.feat_cl = static_cast<float*>(ws);
   w.gfeat_cl = reinterpret_cast<float*>(static_cast<char*>(ws) + n);
   w.bytes = 2 * n;
+  const size_t v2 = lift_bwd_tile_ws_bytes(d);      // backward v2 scratch overlays the same region
+  if (v2 > w.bytes) w.bytes = v2;
   return w;
 }
 

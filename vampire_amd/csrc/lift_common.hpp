@@ -25,6 +25,7 @@ struct LiftTap {
   int ix0, iy0, iz0;
   float wx0, wx1, wy0, wy1, wz0, wz1;
   float zz;              // projected depth (camera z), used to bin voxels into depth slabs
+  float fx, fy, fz;      // continuous tap coordinates
 };
 
 // get_pixel (bv2:365-388) + validity / normalisation (bv2:493-505) + aten's
@@ -60,11 +61,13 @@ __device__ __forceinline__ LiftTap lift_project(const LiftParams& P, const float
   t.wx1 = fx - flx; t.wx0 = (flx + 1.0f) - fx;
   t.wy1 = fy - fly; t.wy0 = (fly + 1.0f) - fy;
   t.wz1 = fz - flz; t.wz0 = (flz + 1.0f) - fz;
+  t.fx = fx; t.fy = fy; t.fz = fz;
   return t;
 }
 
 
 // lift_bwd_tile.hip
+size_t lift_bwd_tile_ws_bytes(const VampLiftDesc* d);
 int launch_lift_bwd_tile(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                          const float* zs, const void* depth, const void* feat, const float* gout,
                          const uint64_t* hits, float* gdepth, float* gfeat, void* scratch,

@@ -202,6 +202,58 @@ __device__ __forceinline__ float tap_weight(float f, float iv) {
   return (fl == iv) ? (fl + 1.0f) - f : ((fl + 1.0f == iv) ? f - fl : 0.f);
 }
 
+// One thread per gather workgroup (an x-run of VPB voxels): bit n of the result is set when
+// camera n's sample lattice can reach the run's trilinear support (same bound as the
+// per-voxel box below, over the whole run).
+__global__ void __launch_bounds__(256)
+cam_bwd_cull_kernel(RenderParams P, const float* __restrict__ pmats, const float* __restrict__ us,
+                    const float* __restrict__ vs, const float* __restrict__ ds,
+                    unsigned* __restrict__ cull, int runs_x) {
+  const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long) runs_x * P.Y * P.Z * P.B;
+  if (gid >= total) return;
+  const int rx = gid % runs_x, iy = (gid / runs_x) % P.Y;
+  const int iz = (gid / ((long) runs_x * P.Y)) % P.Z, b = gid / ((long) runs_x * P.Y * P.Z);
+  const int S = P.D - 1;
+  const float ex = P.span[0] / (float) (P.X - 1), ey = P.span[1] / (float) (P.Y - 1),
+              ez = P.span[2] / (float) (P.Z - 1);
+  const int x0 = rx * VPB, x1 = min(P.X, x0 + VPB) - 1;
+  const float X0 = P.lo[0] + ((float) x0 - 1.01f) * ex, X1 = P.lo[0] + ((float) x1 + 1.01f) * ex;
+  const float Y0 = P.lo[1] + ((float) iy - 1.01f) * ey, Y1 = P.lo[1] + ((float) iy + 1.01f) * ey;
+  const float Z0 = P.lo[2] + ((float) iz - 1.01f) * ez, Z1 = P.lo[2] + ((float) iz + 1.01f) * ez;
+  const float du = (P.fW > 1) ? (us[P.fW - 1] - us[0]) / (float) (P.fW - 1) : 1.f;
+  const float dv = (P.fH > 1) ? (vs[P.fH - 1] - vs[0]) / (float) (P.fH - 1) : 1.f;
+  const float d0 = ds[0], dstep = (ds[P.D - 1] - d0) / (float) (P.D - 1);
+  unsigned mask = 0;
+  for (int n = 0; n < P.N; ++n) {
+    const float* pm = pmats + ((long) b * P.N + n) * 48;
+    float umin = 3e38f, umax = -3e38f, vmin = 3e38f, vmax = -3e38f, zmin = 3e38f, zmax = -3e38f;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float cu, cv, cd;
+      project_corner(pm, (k & 1) ? X1 : X0, (k & 2) ? Y1 : Y0, (k & 4) ? Z1 : Z0, cu, cv, cd);
+      bad = bad || !(cd > 0.05f) || !(cu == cu) || !(cv == cv);
+      umin = fminf(umin, cu); umax = fmaxf(umax, cu);
+      vmin = fminf(vmin, cv); vmax = fmaxf(vmax, cv);
+      zmin = fminf(zmin, cd); zmax = fmaxf(zmax, cd);
+    }
+    if (!(zmax >= d0 - dstep)) continue;
+    bool seen = true;
+    if (!bad) {
+      const int i_hi = min(S - 1, (int) ceilf((zmax - d0) / dstep + 0.02f));
+      const int i_lo = max(0, (int) floorf((zmin - d0) / dstep - 0.02f));
+      const int w_lo = max(0, (int) floorf((umin - us[0]) / du - 0.05f));
+      const int w_hi = min(P.fW - 1, (int) ceilf((umax - us[0]) / du + 0.05f));
+      const int h_lo = max(0, (int) floorf((vmin - vs[0]) / dv - 0.05f));
+      const int h_hi = min(P.fH - 1, (int) ceilf((vmax - vs[0]) / dv + 0.05f));
+      seen = i_lo <= i_hi && w_lo <= w_hi && h_lo <= h_hi;
+    }
+    if (seen) mask |= 1u << n;
+  }
+  cull[gid] = mask;
+}
+
 template <int CP4>
 __global__ void __launch_bounds__(256)
 cam_bwd_gather_kernel(RenderParams P, const float* __restrict__ pmats, const float* __restrict__ us,
@@ -209,7 +261,8 @@ cam_bwd_gather_kernel(RenderParams P, const float* __restrict__ pmats, const flo
                       const float* __restrict__ FX, const float* __restrict__ FY,
                       const float* __restrict__ FZ, const float* __restrict__ Wbuf,
                       const float* __restrict__ G0buf, const float* __restrict__ Gcl,
-                      float* __restrict__ gdens, float* __restrict__ gsem, float* __restrict__ grgb) {
+                      const unsigned* __restrict__ cull, float* __restrict__ gdens,
+                      float* __restrict__ gsem, float* __restrict__ grgb) {
   constexpr int CP = CP4 * 4;
   __shared__ float outs[CP][VPB + 1];
   const int tid = threadIdx.x;
@@ -236,7 +289,9 @@ cam_bwd_gather_kernel(RenderParams P, const float* __restrict__ pmats, const flo
 #pragma unroll
   for (int c = 0; c < CP; ++c) acc[c] = 0.f;
 
+  const unsigned vis = cull[((long) blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x];
   for (int n = 0; n < P.N; ++n) {
+    if (!((vis >> n) & 1u)) continue;                 // no sample of camera n can reach this x-run
     const long bn = (long) b * P.N + n;
     // lane l projects corner (l & 7); min/max over the 8 corners with xor shuffles
     float cu, cv, cd;
@@ -265,31 +320,48 @@ cam_bwd_gather_kernel(RenderParams P, const float* __restrict__ pmats, const flo
     const int count = nw * nh * (i_hi - i_lo + 1);
     const long sbase = bn * S * HW;
     const float inv_nw = 1.0f / (float) nw, inv_nh = 1.0f / (float) nh;
-    for (int idx = l; idx < count; idx += GL) {
-      // idx -> (i, h, w) without integer division (count < 2^20, quotients exact)
-      int r = (int) (((float) idx + 0.5f) * inv_nw);
-      int w = idx - r * nw;
-      if (w < 0) { w += nw; --r; } else if (w >= nw) { w -= nw; ++r; }
-      int i = (int) (((float) r + 0.5f) * inv_nh);
-      int h = r - i * nh;
-      if (h < 0) { h += nh; --i; } else if (h >= nh) { h -= nh; ++i; }
-      const long sidx = sbase + ((long) (i_lo + i) * P.fH + (h_lo + h)) * P.fW + (w_lo + w);
-      w += w_lo; h += h_lo;
-      // the three coordinate loads are independent: issue them together, test afterwards
-      const float fx = FX[sidx], fy = FY[sidx], fz = FZ[sidx];
-      if (!(fabsf(fx - fix) < 1.0f) || !(fabsf(fy - fiy) < 1.0f) || !(fabsf(fz - fiz) < 1.0f))
-        continue;                                         // NaN fx = masked sample fails too
-      const float wt = tap_weight(fx, fix) * tap_weight(fy, fiy) * tap_weight(fz, fiz);
-      const float Wv = wt * Wbuf[sidx];
-      acc[0] = __builtin_fmaf(wt, G0buf[sidx], acc[0]);
-      const float4* g4 = reinterpret_cast<const float4*>(Gcl + (bn * HW + (long) h * P.fW + w) * CP);
+    // U candidates per lane per round: all coordinate loads of a round are issued before any
+    // is tested, so a round costs one memory latency instead of U.
+    constexpr int U = 4;
+    for (int base = l; base < count; base += U * GL) {
+      long sidx[U];
+      int pw[U], ph[U];
+      float fx[U], fy[U], fz[U];
 #pragma unroll
-      for (int q = 0; q < CP4; ++q) {
-        const float4 f = g4[q];
-        if (q > 0) acc[q * 4] = __builtin_fmaf(Wv, f.x, acc[q * 4]);
-        acc[q * 4 + 1] = __builtin_fmaf(Wv, f.y, acc[q * 4 + 1]);
-        acc[q * 4 + 2] = __builtin_fmaf(Wv, f.z, acc[q * 4 + 2]);
-        acc[q * 4 + 3] = __builtin_fmaf(Wv, f.w, acc[q * 4 + 3]);
+      for (int q = 0; q < U; ++q) {
+        const int idx = base + q * GL;
+        // idx -> (i, h, w) without integer division (count < 2^20, quotients exact)
+        int r = (int) (((float) idx + 0.5f) * inv_nw);
+        int w = idx - r * nw;
+        if (w < 0) { w += nw; --r; } else if (w >= nw) { w -= nw; ++r; }
+        int i = (int) (((float) r + 0.5f) * inv_nh);
+        int h = r - i * nh;
+        if (h < 0) { h += nh; --i; } else if (h >= nh) { h -= nh; ++i; }
+        pw[q] = w_lo + w; ph[q] = h_lo + h;
+        sidx[q] = sbase + ((long) (i_lo + i) * P.fH + ph[q]) * P.fW + pw[q];
+        const bool in = idx < count;
+        fx[q] = in ? FX[sidx[q]] : __builtin_nanf("");
+        fy[q] = in ? FY[sidx[q]] : 0.f;
+        fz[q] = in ? FZ[sidx[q]] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        // NaN fx (masked sample / past the end) fails the first test
+        if (!(fabsf(fx[q] - fix) < 1.0f) || !(fabsf(fy[q] - fiy) < 1.0f) ||
+            !(fabsf(fz[q] - fiz) < 1.0f)) continue;
+        const float wt = tap_weight(fx[q], fix) * tap_weight(fy[q], fiy) * tap_weight(fz[q], fiz);
+        const float Wv = wt * Wbuf[sidx[q]];
+        acc[0] = __builtin_fmaf(wt, G0buf[sidx[q]], acc[0]);
+        const float4* g4 =
+            reinterpret_cast<const float4*>(Gcl + (bn * HW + (long) ph[q] * P.fW + pw[q]) * CP);
+#pragma unroll
+        for (int c4 = 0; c4 < CP4; ++c4) {
+          const float4 f = g4[c4];
+          if (c4 > 0) acc[c4 * 4] = __builtin_fmaf(Wv, f.x, acc[c4 * 4]);
+          acc[c4 * 4 + 1] = __builtin_fmaf(Wv, f.y, acc[c4 * 4 + 1]);
+          acc[c4 * 4 + 2] = __builtin_fmaf(Wv, f.z, acc[c4 * 4 + 2]);
+          acc[c4 * 4 + 3] = __builtin_fmaf(Wv, f.w, acc[c4 * 4 + 3]);
+        }
       }
     }
   }
@@ -322,7 +394,8 @@ size_t cam_bwd_v2_bytes(const VampRenderDesc* d) {
   const size_t samples = (size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW;
   const size_t rays = (size_t) d->B * d->N * d->fH * d->fW;
   return 5 * align_up(samples * sizeof(float), 256) + align_up(rays * P.CP * sizeof(float), 256) +
-         align_up((size_t) d->B * d->N * 48 * sizeof(float), 256);
+         align_up((size_t) d->B * d->N * 48 * sizeof(float), 256) +
+         align_up((size_t) d->B * d->Z * d->Y * ((d->X + VPB - 1) / VPB) * sizeof(unsigned), 256);
 }
 
 // scratch = workspace region after the packed volume
@@ -340,7 +413,8 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
   float* FY = reinterpret_cast<float*>(p); p += align_up(samples * sizeof(float), 256);
   float* FZ = reinterpret_cast<float*>(p); p += align_up(samples * sizeof(float), 256);
   float* Gcl = reinterpret_cast<float*>(p); p += align_up(rays * P.CP * sizeof(float), 256);
-  float* pmats = reinterpret_cast<float*>(p);
+  float* pmats = reinterpret_cast<float*>(p); p += align_up((size_t) d->B * d->N * 48 * sizeof(float), 256);
+  unsigned* cull = reinterpret_cast<unsigned*>(p);
 
   if (int e = launch_invert_mats(mats, pmats, d->B * d->N * 3, false, s)) return e;
 
@@ -351,6 +425,13 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
   if (lds > 150 * 1024) return fail(VAMP_EINVAL, "%s: too many depth samples for the LDS staging", __func__);
   const unsigned grid = ray_grid<LPR>(P);
   dim3 bgrid((d->X + VPB - 1) / VPB, d->Y, d->Z * d->B);
+  {
+    const int runs_x = (d->X + VPB - 1) / VPB;
+    const long total = (long) runs_x * d->Y * d->Z * d->B;
+    VAMP_TIMED(kProfAux, s, (cam_bwd_cull_kernel<<<(unsigned) ((total + 255) / 256), 256, 0, s>>>(
+        P, pmats, us, vs, ds, cull, runs_x)));
+    if (int e = check_launch("cam_bwd_cull_kernel")) return e;
+  }
 #define VAMP_V2(CP4)                                                                              \
   do {                                                                                            \
     auto kr = cam_bwd_ray_kernel<LPR, CP4>;                                                       \
@@ -363,7 +444,7 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
                                                            Gcl, grad_beta, L)));                  \
     if (int e = check_launch("cam_bwd_ray_kernel")) return e;                                     \
     VAMP_TIMED(kProfCamBwdBrick, s, (cam_bwd_gather_kernel<CP4><<<bgrid, 256, 0, s>>>(            \
-        P, pmats, us, vs, ds, FX, FY, FZ, Wbuf, G0buf, Gcl, gdens, gsem, grgb)));                 \
+        P, pmats, us, vs, ds, FX, FY, FZ, Wbuf, G0buf, Gcl, cull, gdens, gsem, grgb)));           \
   } while (0)
   if (P.CP == 12) VAMP_V2(3); else if (P.CP == 24) VAMP_V2(6); else VAMP_V2(8);
 #undef VAMP_V2

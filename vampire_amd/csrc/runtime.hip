@@ -22,7 +22,7 @@ const char* g_names[kProfSlots] = {
     "feat_to_channel_last", "lift_fwd", "lift_bwd", "feat_to_channel_first", "lift_fwd_dense",
     "lift_bwd_dense", "pack_volume", "render_cam_fwd", "render_bev_fwd", "render_cam_bwd",
     "unpack_grad", "render_bev_bwd", "memset", "aux", "render_cam_bwd_gather", "render_bev_fwd_channels",
-    "render_bev_bwd_q", "render_bev_bwd_gather"};
+    "render_bev_bwd_q", "render_bev_bwd_gather", "lift_bwd_prep"};
 }  // namespace
 
 bool prof_enabled() { return g_on; }
