@@ -323,8 +323,11 @@ def test_lift_backward_tile_matches_atomic_splat_full_size(dev, monkeypatch):
         out.backward(torch.randn(out.shape, device=dev, generator=gen))
         return depth.grad.clone(), feat.grad.clone()
 
-    d2, f2 = run("v2")
-    d1, f1 = run("v1")
+    d3, f3 = run("v3")          # default: binned lists + tile owners
+    d2, f2 = run("v2")          # tile enumeration (the overflow fallback)
+    d1, f1 = run("v1")          # per-voxel float-atomic splat
     assert float(d1.abs().max()) > 0 and float(f1.abs().max()) > 0
+    close(d3, d1, atol=1e-6, rtol=2e-5, scale="max", what="bin vs splat grad_depth")
+    close(f3, f1, atol=1e-6, rtol=2e-5, scale="max", chan_dim=2, what="bin vs splat grad_feat")
     close(d2, d1, atol=1e-6, rtol=2e-5, scale="max", what="tile vs splat grad_depth")
     close(f2, f1, atol=1e-6, rtol=2e-5, scale="max", chan_dim=2, what="tile vs splat grad_feat")

@@ -44,7 +44,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 enum ProfSlot {
   kProfFeatCL = 0, kProfLiftFwd, kProfLiftBwd, kProfFeatCF, kProfLiftFwdDense, kProfLiftBwdDense,
   kProfPack, kProfCamFwd, kProfBevFwd, kProfCamBwd, kProfUnpack, kProfBevBwd, kProfMemset,
-  kProfAux, kProfCamBwdBrick, kProfBevFwdCh, kProfBevBwdQ, kProfBevBwdGather, kProfLiftBwdPrep, kProfSlots
+  kProfAux, kProfCamBwdBrick, kProfBevFwdCh, kProfBevBwdQ, kProfBevBwdGather, kProfLiftBwdPrep, kProfLiftBwdCount, kProfLiftBwdFill, kProfSlots
 };
 struct ProfScope { int idx; };
 bool prof_enabled();
@@ -52,6 +52,8 @@ void prof_begin(int slot, hipStream_t s, ProfScope* sc);
 void prof_end(hipStream_t s, ProfScope* sc);
 // device-side 4x4 inverses (runtime.hip)
 int launch_invert_mats(const float* mats, float* inv, int count, bool reverse3, hipStream_t s);
+// device-side exclusive scan of bin counts (runtime.hip): off[i] = sum_{j<i} cnt[j], fill[i] = 0
+int launch_exclusive_scan(const int* cnt, int* off, int* fill, int n, int* total, hipStream_t s);
 // usage: VAMP_TIMED(slot, stream, kernel<<<...>>>(...));
 #define VAMP_TIMED(slot, stream, launch)              \
   do {                                                \

@@ -380,7 +380,8 @@ static LiftWs carve(const VampLiftDesc* d, void* ws) {
   w.feat_cl = static_cast<float*>(ws);
   w.gfeat_cl = reinterpret_cast<float*>(static_cast<char*>(ws) + n);
   w.bytes = 2 * n;
-  const size_t v2 = lift_bwd_tile_ws_bytes(d);      // backward v2 scratch overlays the same region
+  // backward v3 lists + v2 fallback scratch overlay the same region
+  const size_t v2 = lift_bwd_bin_ws_bytes(d) + lift_bwd_tile_ws_bytes(d);
   if (v2 > w.bytes) w.bytes = v2;
   return w;
 }
@@ -470,9 +471,20 @@ int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs
   // v2 (default): one workgroup per pixel tile with LDS accumulators, no global atomics.
   // VAMP_LIFT_BWD=v1 selects the per-voxel atomic splat, kept as an independent cross-check.
   const char* force = getenv("VAMP_LIFT_BWD");
-  if (!(force && force[0] == 'v' && force[1] == '1'))
+  if (!(force && force[0] == 'v' && force[1] == '1')) {
+    // v3 (default): bin (voxel, camera) pairs into per-tile lists, then one workgroup per tile
+    // accumulates in LDS.  v2 (tile enumeration) runs only if the lists overflow the workspace
+    // (decided on the device) or when forced with VAMP_LIFT_BWD=v2.
+    const int* total = nullptr;
+    int cap = 0;
+    char* tile_ws = static_cast<char*>(workspace) + lift_bwd_bin_ws_bytes(d);
+    if (!(force && force[0] == 'v' && force[1] == '2'))
+      if (int e = launch_lift_bwd_bin(d, mats, xs, ys, zs, depth, feat, grad_out, hits, grad_depth,
+                                      grad_feat, workspace, &total, &cap, s))
+        return e;
     return launch_lift_bwd_tile(d, mats, xs, ys, zs, depth, feat, grad_out, hits, grad_depth,
-                                grad_feat, workspace, s);
+                                grad_feat, tile_ws, total, cap, s);
+  }
   if (d->in_dtype == VAMP_F32) launch_to_cl<float>(feat, w.feat_cl, BN, d->C, HW, s);
   else launch_to_cl<__hip_bfloat16>(feat, w.feat_cl, BN, d->C, HW, s);
   if (int e = check_launch("feat_to_channel_last")) return e;

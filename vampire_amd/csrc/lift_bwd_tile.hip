@@ -43,7 +43,9 @@ __device__ __forceinline__ void unproject(const float* __restrict__ gm, float u,
 // bv2:512-514 folded in, channel-last so that a voxel's C values are one contiguous run.
 __global__ void __launch_bounds__(256)
 lift_bwd_prep_kernel(const float* __restrict__ gout, const uint64_t* __restrict__ hits,
-                     float* __restrict__ gs, int C, long V, int B, int hits_per_word) {
+                     float* __restrict__ gs, int C, long V, int B, int hits_per_word,
+                     const int* __restrict__ total, int cap) {
+  if (total && *total <= cap) return;
   const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= V * B) return;
   const long b = gid / V, vox = gid % V;
@@ -67,7 +69,9 @@ lift_bwd_tile_kernel(LiftParams P, const float* __restrict__ mats, const float* 
                      const float* __restrict__ xs, const float* __restrict__ ys,
                      const float* __restrict__ zs, const T* __restrict__ depth,
                      const T* __restrict__ feat, const float* __restrict__ gs_cl,
-                     float* __restrict__ gdepth, float* __restrict__ gfeat, float slab_len) {
+                     float* __restrict__ gdepth, float* __restrict__ gfeat, float slab_len,
+                     const int* __restrict__ total, int cap) {
+  if (total && *total <= cap) return;          // fallback only: the binned lists fit
   extern __shared__ float lds[];
   __shared__ Hit queue[QCAP];
   __shared__ int qn;
@@ -265,7 +269,7 @@ template <typename T>
 static int launch_t(const VampLiftDesc* d, const LiftParams& P, const float* mats,
                     const float* gmats, const float* xs, const float* ys, const float* zs,
                     const void* depth, const void* feat, const float* gs_cl, float* gdepth,
-                    float* gfeat, float slab_len, hipStream_t s) {
+                    float* gfeat, float slab_len, const int* total, int cap, hipStream_t s) {
   const int tiles = ((P.fW + TW - 1) / TW) * ((P.fH + TH - 1) / TH);
   const unsigned grid = (unsigned) ((long) d->B * d->N * tiles);
   const int Dd = d->use_depth ? d->D : 0;
@@ -278,7 +282,7 @@ static int launch_t(const VampLiftDesc* d, const LiftParams& P, const float* mat
     return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);
   VAMP_TIMED(kProfLiftBwd, s, (k<<<grid, 256, lds, s>>>(
       P, mats, gmats, xs, ys, zs, static_cast<const T*>(depth), static_cast<const T*>(feat), gs_cl,
-      gdepth, gfeat, slab_len)));
+      gdepth, gfeat, slab_len, total, cap)));
   return check_launch("lift_bwd_tile_kernel");
 }
 
@@ -291,7 +295,7 @@ size_t lift_bwd_tile_ws_bytes(const VampLiftDesc* d) {
 int launch_lift_bwd_tile(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                          const float* zs, const void* depth, const void* feat, const float* gout,
                          const uint64_t* hits, float* gdepth, float* gfeat, void* scratch,
-                         hipStream_t s) {
+                         const int* total, int cap, hipStream_t s) {
   const LiftParams P = to_params(d);
   float* gmats = static_cast<float*>(scratch);
   float* gs_cl = reinterpret_cast<float*>(static_cast<char*>(scratch) +
@@ -302,14 +306,14 @@ int launch_lift_bwd_tile(const VampLiftDesc* d, const float* mats, const float* 
     // the forward packs per-channel hit counters 16 to a word (4 or 8 when C is 4 or 8)
     const int hits_per_word = d->C < 16 ? d->C : 16;
     VAMP_TIMED(kProfLiftBwdPrep, s, (lift_bwd_prep_kernel<<<(unsigned) ((V * d->B + 255) / 256), 256, 0, s>>>(
-        gout, hits, gs_cl, d->C, V, d->B, hits_per_word)));
+        gout, hits, gs_cl, d->C, V, d->B, hits_per_word, total, cap)));
     if (int e = check_launch("lift_bwd_prep_kernel")) return e;
   }
   const char* sl = getenv("VAMP_LIFT_SLAB");
   const float slab_len = sl ? (float) atof(sl) : 3.2f;
   if (d->in_dtype == VAMP_F32)
-    return launch_t<float>(d, P, mats, gmats, xs, ys, zs, depth, feat, gs_cl, gdepth, gfeat, slab_len, s);
-  return launch_t<__hip_bfloat16>(d, P, mats, gmats, xs, ys, zs, depth, feat, gs_cl, gdepth, gfeat, slab_len, s);
+    return launch_t<float>(d, P, mats, gmats, xs, ys, zs, depth, feat, gs_cl, gdepth, gfeat, slab_len, total, cap, s);
+  return launch_t<__hip_bfloat16>(d, P, mats, gmats, xs, ys, zs, depth, feat, gs_cl, gdepth, gfeat, slab_len, total, cap, s);
 }
 
 }  // namespace vamp

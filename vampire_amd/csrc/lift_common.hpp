@@ -71,6 +71,12 @@ size_t lift_bwd_tile_ws_bytes(const VampLiftDesc* d);
 int launch_lift_bwd_tile(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                          const float* zs, const void* depth, const void* feat, const float* gout,
                          const uint64_t* hits, float* gdepth, float* gfeat, void* scratch,
-                         hipStream_t s);
+                         const int* total, int cap, hipStream_t s);
+// lift_bwd_bin.hip
+size_t lift_bwd_bin_ws_bytes(const VampLiftDesc* d);
+int launch_lift_bwd_bin(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
+                        const float* zs, const void* depth, const void* feat, const float* gout,
+                        const uint64_t* hits, float* gdepth, float* gfeat, void* scratch,
+                        const int** total_out, int* cap_out, hipStream_t s);
 
 }  // namespace vamp

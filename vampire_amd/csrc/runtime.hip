@@ -22,7 +22,8 @@ const char* g_names[kProfSlots] = {
     "feat_to_channel_last", "lift_fwd", "lift_bwd", "feat_to_channel_first", "lift_fwd_dense",
     "lift_bwd_dense", "pack_volume", "render_cam_fwd", "render_bev_fwd", "render_cam_bwd",
     "unpack_grad", "render_bev_bwd", "memset", "aux", "render_cam_bwd_gather", "render_bev_fwd_channels",
-    "render_bev_bwd_q", "render_bev_bwd_gather", "lift_bwd_prep"};
+    "render_bev_bwd_q", "render_bev_bwd_gather", "lift_bwd_prep", "lift_bwd_count",
+    "lift_bwd_fill"};
 }  // namespace
 
 bool prof_enabled() { return g_on; }
@@ -90,6 +91,49 @@ invert_mats_kernel(const float* __restrict__ mats, float* __restrict__ inv, int 
 int launch_invert_mats(const float* mats, float* inv, int count, bool reverse3, hipStream_t s) {
   VAMP_TIMED(kProfAux, s, (invert_mats_kernel<<<(count + 63) / 64, 64, 0, s>>>(mats, inv, count, reverse3 ? 1 : 0)));
   return check_launch("invert_mats_kernel");
+}
+
+// ---------------------------------------------------------------------------
+// Exclusive prefix sum of per-owner counts (bin sizes -> list offsets) in one 1024-thread
+// workgroup; also zeroes the fill cursors and publishes the total.  n is a few thousand to a
+// few hundred thousand: one pass per 1024 elements, wave scans + LDS.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+exclusive_scan_kernel(const int* __restrict__ cnt, int* __restrict__ off, int* __restrict__ fill,
+                      int n, int* __restrict__ total) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    const int v = i < n ? cnt[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int k = 0; k < wv; ++k) wbase += wsum[k];
+    const int c0 = carry;
+    if (i < n) {
+      off[i] = c0 + wbase + incl - v;
+      fill[i] = 0;
+    }
+    __syncthreads();
+    if (tid == 1023) carry = c0 + wbase + incl;
+    __syncthreads();
+  }
+  if (tid == 0) *total = carry;
+}
+
+int launch_exclusive_scan(const int* cnt, int* off, int* fill, int n, int* total, hipStream_t s) {
+  VAMP_TIMED(kProfAux, s, (exclusive_scan_kernel<<<1, 1024, 0, s>>>(cnt, off, fill, n, total)));
+  return check_launch("exclusive_scan_kernel");
 }
 
 }  // namespace vamp
