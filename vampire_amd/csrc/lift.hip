@@ -66,19 +66,24 @@ __device__ __forceinline__ void depth_taps(const LiftParams& P, const T* __restr
     dep[0] = dep[1] = dep[2] = dep[3] = w;
     return;
   }
+  // branch-free (clamped address, zero weight for taps outside the volume): the eight loads
+  // are independent and issue together
   const long plane = (long) P.fH * P.fW;
+  const bool x0in = t.ix0 >= 0 && t.ix0 < P.fW, x1in = t.ix0 + 1 >= 0 && t.ix0 + 1 < P.fW;
+  const int x0c = min(max(t.ix0, 0), P.fW - 1), x1c = min(max(t.ix0 + 1, 0), P.fW - 1);
 #pragma unroll
   for (int kz = 0; kz < 2; ++kz) {
     const int iz = t.iz0 + kz;
-    if (iz < 0 || iz >= P.D) continue;
-    const float wz = kz ? t.wz1 : t.wz0;
+    const bool zin = iz >= 0 && iz < P.D;
+    const float wz = zin ? (kz ? t.wz1 : t.wz0) : 0.f;
+    const int izc = min(max(iz, 0), P.D - 1);
 #pragma unroll
     for (int ky = 0; ky < 2; ++ky) {
       const int iy = t.iy0 + ky;
-      if (iy < 0 || iy >= P.fH) continue;
-      const long row = iz * plane + (long) iy * P.fW;
-      if (t.ix0 >= 0 && t.ix0 < P.fW) dep[ky * 2 + 0] += wz * ldf(dptr, row + t.ix0);
-      if (t.ix0 + 1 >= 0 && t.ix0 + 1 < P.fW) dep[ky * 2 + 1] += wz * ldf(dptr, row + t.ix0 + 1);
+      const bool yin = iy >= 0 && iy < P.fH;
+      const long row = izc * plane + (long) min(max(iy, 0), P.fH - 1) * P.fW;
+      dep[ky * 2 + 0] += ((yin && x0in) ? wz : 0.f) * ldf(dptr, row + x0c);
+      dep[ky * 2 + 1] += ((yin && x1in) ? wz : 0.f) * ldf(dptr, row + x1c);
     }
   }
 }
@@ -125,10 +130,11 @@ lift_fwd_kernel(LiftParams P, const float* __restrict__ mats, const float* __res
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int iy = t.iy0 + (j >> 1), ix = t.ix0 + (j & 1);
-        if (iy < 0 || iy >= P.fH || ix < 0 || ix >= P.fW) continue;
-        const float wd = w[j] * dep[j];
+        const bool in = iy >= 0 && iy < P.fH && ix >= 0 && ix < P.fW;
+        const float wd = in ? w[j] * dep[j] : 0.f;         // branch-free: clamp + zero weight
         const float4* f4 = reinterpret_cast<const float4*>(
-            feat_cl + (bn * HW + (long) iy * P.fW + ix) * P.C + chunk * CH);
+            feat_cl + (bn * HW + (long) min(max(iy, 0), P.fH - 1) * P.fW + min(max(ix, 0), P.fW - 1)) * P.C +
+            chunk * CH);
 #pragma unroll
         for (int q = 0; q < CH / 4; ++q) {
           const float4 f = f4[q];

@@ -53,6 +53,19 @@ __device__ __forceinline__ int wave_bin_add(int* __restrict__ counters, int bin,
   return res;
 }
 
+// Same aggregation without a result: fire-and-forget atomics, the wave never waits on them.
+__device__ __forceinline__ void wave_bin_count(int* __restrict__ counters, int bin, bool active) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(active);
+  while (todo) {
+    const int leader = __ffsll((long long) todo) - 1;
+    const int lb = __shfl(bin, leader, 64);
+    const unsigned long long m = __ballot(active && bin == lb);
+    if (lane == leader) atomicAdd(counters + lb, (int) __popcll(m));
+    todo &= ~m;
+  }
+}
+
 template <typename T, int CH, bool FILL>
 __global__ void __launch_bounds__(256)
 lift_bwd_bin_kernel(LiftParams P, BinGeom G, const float* __restrict__ mats,
@@ -113,7 +126,7 @@ lift_bwd_bin_kernel(LiftParams P, BinGeom G, const float* __restrict__ mats,
       if (!__any(act)) continue;                    // wave-uniform
       const int bin = act ? (int) (bn * ntile + (long) ty * G.tiles_w + tx) : 0;
       if (!FILL) {
-        wave_bin_add(cnt, bin, act);
+        wave_bin_count(cnt, bin, act);
       } else {
         const int rank = wave_bin_add(fill, bin, act);
         if (!act) continue;

@@ -47,13 +47,33 @@ template <typename T>
 __device__ __forceinline__ float sample8(const RenderParams& P, const T* __restrict__ vol, long cb,
                                          const AxisTap& tx, const AxisTap& ty, const AxisTap& tz) {
   // aten tap order: x fastest, then y, then z; zero padding outside the volume
+  // branch-free: out-of-volume taps are clamped to a legal address and given zero weight, so
+  // the eight loads are independent (a bounds branch per tap serialises the round trips)
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int iz = tz.i0 + (k >> 2), iy = ty.i0 + ((k >> 1) & 1), ix = tx.i0 + (k & 1);
-    if (iz < 0 || iz >= P.Z || iy < 0 || iy >= P.Y || ix < 0 || ix >= P.X) continue;
-    const float wt = ((k & 1) ? tx.w1 : tx.w0) * ((k & 2) ? ty.w1 : ty.w0) * ((k & 4) ? tz.w1 : tz.w0);
-    s = __builtin_fmaf(wt, ldf(vol, cb + ((long) iz * P.Y + iy) * P.X + ix), s);
+    const bool in = iz >= 0 && iz < P.Z && iy >= 0 && iy < P.Y && ix >= 0 && ix < P.X;
+    const float wt = in ? ((k & 1) ? tx.w1 : tx.w0) * ((k & 2) ? ty.w1 : ty.w0) * ((k & 4) ? tz.w1 : tz.w0) : 0.f;
+    const long at = ((long) min(max(iz, 0), P.Z - 1) * P.Y + min(max(iy, 0), P.Y - 1)) * P.X + min(max(ix, 0), P.X - 1);
+    s = __builtin_fmaf(wt, ldf(vol, cb + at), s);
+  }
+  return s;
+}
+
+// bilinear (x, y) sample of one volume plane, zero padding (also for a plane outside the volume)
+template <typename T>
+__device__ __forceinline__ float bilinear_plane(const RenderParams& P, const T* __restrict__ vol,
+                                                long cb, const AxisTap& tx, const AxisTap& ty, int iz) {
+  const bool zin = iz >= 0 && iz < P.Z;
+  const int izc = min(max(iz, 0), P.Z - 1);
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int iy = ty.i0 + (k >> 1), ix = tx.i0 + (k & 1);
+    const bool in = zin && iy >= 0 && iy < P.Y && ix >= 0 && ix < P.X;
+    const float wt = in ? ((k & 1) ? tx.w1 : tx.w0) * ((k & 2) ? ty.w1 : ty.w0) : 0.f;
+    s = __builtin_fmaf(wt, ldf(vol, cb + ((long) izc * P.Y + min(max(iy, 0), P.Y - 1)) * P.X + min(max(ix, 0), P.X - 1)), s);
   }
   return s;
 }
@@ -111,9 +131,19 @@ bev_channels_kernel(RenderParams P, const float* __restrict__ oxs, const float* 
   else { vol = base; cb = ((long) b * P.C + (ch - P.K - 3)) * V; }
   const bool composite = ch < P.K + 3;
   float cum = 0.f, acc = 0.f;
+  // consecutive heights share a volume plane (det and seg grids have equal spacing): keep the
+  // two bilinear plane values and reload only what changed -> 4 loads per sample, not 8
+  int p_lo = -0x7fffffff, p_hi = -0x7fffffff;
+  float v_lo = 0.f, v_hi = 0.f;
   for (int j = 0; j < P.oZ; ++j) {
     const AxisTap tz = axis_tap(ozs[P.oZ - 1 - j], P.lo[2], P.span[2], P.Z);
-    const float sv = sample8(P, vol, cb, tx, ty, tz);
+    float n_lo, n_hi;
+    if (tz.i0 == p_lo) n_lo = v_lo; else if (tz.i0 == p_hi) n_lo = v_hi;
+    else n_lo = bilinear_plane(P, vol, cb, tx, ty, tz.i0);
+    if (tz.i0 + 1 == p_lo) n_hi = v_lo; else if (tz.i0 + 1 == p_hi) n_hi = v_hi;
+    else n_hi = bilinear_plane(P, vol, cb, tx, ty, tz.i0 + 1);
+    p_lo = tz.i0; p_hi = tz.i0 + 1; v_lo = n_lo; v_hi = n_hi;
+    const float sv = __builtin_fmaf(tz.w1, n_hi, tz.w0 * n_lo);
     if (composite) {
       const float tau = voxel_density[((long) b * P.oZ + j) * OYX + col] * (1.0f * P.z_step);
       acc = __builtin_fmaf((1.0f - expf(-tau)) * expf(-cum), sv, acc);
@@ -138,16 +168,18 @@ bev_q_kernel(RenderParams P, const float* __restrict__ oxs, const float* __restr
              const float* __restrict__ ozs, const T* __restrict__ sem, const T* __restrict__ rgb,
              const float* __restrict__ g_brgb, const float* __restrict__ g_bseg,
              float* __restrict__ Q) {
-  extern __shared__ float red[];                      // [3][oZ][64]
+  __shared__ float red[3 * 64];
   const int lx = threadIdx.x & 63, cl = threadIdx.x >> 6;
-  const int x = blockIdx.x * 64 + lx, y = blockIdx.y, b = blockIdx.z;
+  // one workgroup per (x-run, y, sample height j, b): the heights are independent
+  const int x = blockIdx.x * 64 + lx, y = blockIdx.y;
+  const int j = blockIdx.z % P.oZ, b = blockIdx.z / P.oZ;
   const bool live = x < P.oX;
   const int xc = live ? x : P.oX - 1;
   const long V = (long) P.Z * P.Y * P.X, OYX = (long) P.oY * P.oX, col = (long) y * P.oX + xc;
   const AxisTap tx = axis_tap(oxs[xc], P.lo[0], P.span[0], P.X);
   const AxisTap ty = axis_tap(oys[y], P.lo[1], P.span[1], P.Y);
   const int nch = P.K + 3;
-  for (int j = 0; j < P.oZ; ++j) {
+  {
     const AxisTap tz = axis_tap(ozs[P.oZ - 1 - j], P.lo[2], P.span[2], P.Z);
     float q = 0.f;
     for (int ch = cl; ch < nch; ch += 4) {
@@ -163,13 +195,12 @@ bev_q_kernel(RenderParams P, const float* __restrict__ oxs, const float* __restr
       }
       if (gc != 0.f) q = __builtin_fmaf(gc, sample8(P, vol, cb, tx, ty, tz), q);
     }
-    if (cl > 0) red[((cl - 1) * P.oZ + j) * 64 + lx] = q;
+    if (cl > 0) red[(cl - 1) * 64 + lx] = q;
     __syncthreads();
     if (cl == 0 && live) {
-      q += red[(0 * P.oZ + j) * 64 + lx] + red[(1 * P.oZ + j) * 64 + lx] + red[(2 * P.oZ + j) * 64 + lx];
+      q += red[lx] + red[64 + lx] + red[128 + lx];
       Q[((long) b * P.oZ + j) * OYX + col] = q;
     }
-    __syncthreads();
   }
 }
 
@@ -347,6 +378,8 @@ bev_gather_generic_kernel(RenderParams P, const float* __restrict__ oxs,
   }
 }
 
+constexpr int kPer = 4;                // channels per thread of bev_gather
+
 __global__ void __launch_bounds__(256)
 bev_gather_kernel(RenderParams P, const float* __restrict__ oxs, const float* __restrict__ oys,
                   const float* __restrict__ ozs, const float* __restrict__ g_brgb,
@@ -357,8 +390,12 @@ bev_gather_kernel(RenderParams P, const float* __restrict__ oxs, const float* __
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int nz = z_hi - z_lo + 1;
-  const int z = z_lo + blockIdx.z % nz;
-  const int b = blockIdx.z / nz;
+  // blockIdx.z = ((b * nz) + z) * ngrp + channel group: splitting the channels over
+  // workgroups gives the latency-bound loads enough waves to hide behind
+  const int ngrp = (P.K + 3 + P.C + kPer - 1) / kPer;
+  const int cg = blockIdx.z % ngrp;
+  const int z = z_lo + (blockIdx.z / ngrp) % nz;
+  const int b = blockIdx.z / (ngrp * nz);
   if (x >= P.X || y >= P.Y) return;
   const long V = (long) P.Z * P.Y * P.X, OYX = (long) P.oY * P.oX;
   const int CO = P.C + (P.cat_seg ? P.K : 0);
@@ -370,53 +407,81 @@ bev_gather_kernel(RenderParams P, const float* __restrict__ oxs, const float* __
 
   // density channel and the compositing weights of the hit samples
   float s_dens = 0.f;
+  if (cg == 0)
 #pragma unroll
   for (int a = 0; a < kMaxT; ++a)
 #pragma unroll
     for (int c2 = 0; c2 < kMaxT; ++c2)
 #pragma unroll
       for (int e = 0; e < kMaxT; ++e) {
-        if (a >= hz.n || c2 >= hy.n || e >= hx.n) continue;
         const long sc = ((long) b * P.oZ + (P.oZ - 1 - hz.k[a])) * OYX + (long) hy.k[c2] * P.oX + hx.k[e];
         s_dens = __builtin_fmaf(hz.w[a] * hy.w[c2] * hx.w[e], DS0[sc], s_dens);
       }
-  gdens[(long) b * V + vox] += s_dens;
+  if (cg == 0) gdens[(long) b * V + vox] += s_dens;
 
+  // kPer channels per thread, fully unrolled: the tap loads of all of them are in flight together
+  // and the read-modify-writes come last, so a thread pays ~2 memory round trips, not 2 per channel
   const int nch = P.K + 3 + P.C;           // [0,K) sem, [K,K+3) rgb, [K+3, ..) base
-  for (int ch = 0; ch < nch; ++ch) {
+  float sum[kPer];
+  float* outp[kPer];
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int ch = cg * kPer + u;
+    sum[u] = 0.f;
+    outp[u] = nullptr;
+    if (ch >= nch) continue;
     const float* gcol = nullptr;
     long gcol_base = 0, vo_base = -1;
-    float* out;
     if (ch < P.K) {
-      out = gsem + ((long) b * P.K + ch) * V;
+      outp[u] = gsem + ((long) b * P.K + ch) * V;
       gcol = g_bseg; gcol_base = ((long) b * P.K + ch) * OYX;
       if (P.cat_seg) vo_base = ((long) b * CO + P.C + ch) * P.oZ * OYX;
     } else if (ch < P.K + 3) {
-      out = grgb + ((long) b * 3 + (ch - P.K)) * V;
+      outp[u] = grgb + ((long) b * 3 + (ch - P.K)) * V;
       gcol = g_brgb; gcol_base = ((long) b * 3 + (ch - P.K)) * OYX;
     } else {
-      out = gbase + ((long) b * P.C + (ch - P.K - 3)) * V;
+      outp[u] = gbase + ((long) b * P.C + (ch - P.K - 3)) * V;
       vo_base = ((long) b * CO + (ch - P.K - 3)) * P.oZ * OYX;
     }
     const bool use_col = gcol != nullptr, use_vo = (vo_base >= 0) && g_vo;
-    if (!use_col && !use_vo) continue;
-    float sum = 0.f;
+    if (!use_col && !use_vo) { outp[u] = nullptr; continue; }
+    // the first two hits per axis (all there are, except when a lattice point sits exactly on
+    // the edge of the support) are loaded without bounds branches: unused slots carry k = 0,
+    // w = 0, so the 8 x 2 loads are legal, independent and in flight together
 #pragma unroll
-    for (int a = 0; a < kMaxT; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int c2 = 0; c2 < kMaxT; ++c2)
+      for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
-        for (int e = 0; e < kMaxT; ++e) {
-          if (a >= hz.n || c2 >= hy.n || e >= hx.n) continue;
+        for (int e = 0; e < 2; ++e) {
           const int j = P.oZ - 1 - hz.k[a];
           const long cc = (long) hy.k[c2] * P.oX + hx.k[e];
           float dsv = 0.f;
           if (use_col) dsv = Wb[((long) b * P.oZ + j) * OYX + cc] * gcol[gcol_base + cc];
           if (use_vo) dsv += g_vo[vo_base + (long) j * OYX + cc];
-          sum = __builtin_fmaf(hz.w[a] * hy.w[c2] * hx.w[e], dsv, sum);
+          sum[u] = __builtin_fmaf(hz.w[a] * hy.w[c2] * hx.w[e], dsv, sum[u]);
         }
-    out[vox] += sum;
+    if (hz.n > 2 || hy.n > 2 || hx.n > 2) {           // rare third hit on some axis
+#pragma unroll
+      for (int a = 0; a < kMaxT; ++a)
+#pragma unroll
+        for (int c2 = 0; c2 < kMaxT; ++c2)
+#pragma unroll
+          for (int e = 0; e < kMaxT; ++e) {
+            if (a < 2 && c2 < 2 && e < 2) continue;
+            if (a >= hz.n || c2 >= hy.n || e >= hx.n) continue;
+            const int j = P.oZ - 1 - hz.k[a];
+            const long cc = (long) hy.k[c2] * P.oX + hx.k[e];
+            float dsv = 0.f;
+            if (use_col) dsv = Wb[((long) b * P.oZ + j) * OYX + cc] * gcol[gcol_base + cc];
+            if (use_vo) dsv += g_vo[vo_base + (long) j * OYX + cc];
+            sum[u] = __builtin_fmaf(hz.w[a] * hy.w[c2] * hx.w[e], dsv, sum[u]);
+          }
+    }
   }
+#pragma unroll
+  for (int u = 0; u < kPer; ++u)
+    if (outp[u]) outp[u][vox] += sum[u];
 }
 
 static size_t bev_ws_bytes(const VampRenderDesc* d) {
@@ -504,13 +569,12 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
   z_hi = z_hi > d->Z - 1 ? d->Z - 1 : z_hi;
   if (z_lo > z_hi) return VAMP_OK;
 
-  dim3 gq((d->oX + 63) / 64, d->oY, d->B);
+  dim3 gq((d->oX + 63) / 64, d->oY, d->B * d->oZ);
   dim3 gs((d->oX + 63) / 64, (d->oY + 3) / 4, d->B);
   dim3 gg((d->X + 63) / 64, (d->Y + 3) / 4, d->B * (z_hi - z_lo + 1));
-  const size_t qlds = (size_t) 3 * d->oZ * 64 * sizeof(float);
 #define VAMP_BEVB(T)                                                                              \
   do {                                                                                            \
-    VAMP_TIMED(kProfBevBwdQ, s, (bev_q_kernel<T><<<gq, 256, qlds, s>>>(                           \
+    VAMP_TIMED(kProfBevBwdQ, s, (bev_q_kernel<T><<<gq, 256, 0, s>>>(                              \
         P, oxs, oys, ozs, (const T*) semantic, (const T*) rgb, g_bev_rgb, g_bev_seg, Q)));        \
     if (int e = check_launch("bev_q_kernel")) return e;                                           \
     VAMP_TIMED(kProfBevBwd, s, (bev_scan_kernel<T><<<gs, 256, 0, s>>>(                            \
@@ -527,8 +591,9 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
     const float e = d->span[a] / (float) (nvox[a] - 1);
     if (!(d->det_step[a] > 0.f) || (int) floorf(2.0f * e / d->det_step[a]) + 1 > kMaxT) fits = false;
   }
+  dim3 ggf(gg.x, gg.y, gg.z * ((d->K + 3 + d->C + kPer - 1) / kPer));
   if (fits)
-    VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_kernel<<<gg, 256, 0, s>>>(
+    VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_kernel<<<ggf, 256, 0, s>>>(
         P, oxs, oys, ozs, g_bev_rgb, g_bev_seg, g_voxel_output, Wb, DS0, grad_density_feature,
         grad_semantic, grad_rgb, grad_base, z_lo, z_hi)));
   else

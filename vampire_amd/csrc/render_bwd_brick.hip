@@ -86,23 +86,7 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
 #pragma unroll
     for (int c = 0; c < CP; ++c) s[c] = 0.f;
     if (tp.inside) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int iz = tp.iz0 + (k >> 2), iy = tp.iy0 + ((k >> 1) & 1), ix = tp.ix0 + (k & 1);
-        if (iz >= P.Z || iy >= P.Y || ix >= P.X) continue;
-        const float wt = ((k & 1) ? tp.wx1 : tp.wx0) * ((k & 2) ? tp.wy1 : tp.wy0) *
-                         ((k & 4) ? tp.wz1 : tp.wz0);
-        const float4* f4 = reinterpret_cast<const float4*>(
-            vol + (((long) iz * P.Y + iy) * P.X + ix) * CP);
-#pragma unroll
-        for (int q = 0; q < CP4; ++q) {
-          const float4 f = f4[q];
-          s[q * 4 + 0] = __builtin_fmaf(wt, f.x, s[q * 4 + 0]);
-          s[q * 4 + 1] = __builtin_fmaf(wt, f.y, s[q * 4 + 1]);
-          s[q * 4 + 2] = __builtin_fmaf(wt, f.z, s[q * 4 + 2]);
-          s[q * 4 + 3] = __builtin_fmaf(wt, f.w, s[q * 4 + 3]);
-        }
-      }
+      gather_taps<CP4>(P, vol, tp, s);
     }
     const bool fin = (s[0] == s[0]) && (fabsf(s[0]) <= 3.402823466e+38f);
     const float s0 = nan_to_num(s[0]);

@@ -175,4 +175,35 @@ __device__ __forceinline__ VolTap volume_tap(const RenderParams& P, float x, flo
   return t;
 }
 
+// 8-tap trilinear gather of CP4*4 packed channels for an INSIDE sample, branch-free: all
+// 8 * CP4 16-byte loads are independent and can be in flight together (a per-tap bounds
+// branch would serialise eight memory round trips).  Inside => tap indices >= 0; a "+1" tap
+// can only fall outside when its weight is exactly zero, so it is clamped and zero-weighted.
+template <int CP4>
+__device__ __forceinline__ void gather_taps(const RenderParams& P, const float* __restrict__ vol,
+                                            const VolTap& tp, float* __restrict__ s) {
+  constexpr int CP = CP4 * 4;
+  const int x1 = min(tp.ix0 + 1, P.X - 1), y1 = min(tp.iy0 + 1, P.Y - 1), z1 = min(tp.iz0 + 1, P.Z - 1);
+  const float wx1 = (tp.ix0 + 1 < P.X) ? tp.wx1 : 0.f;
+  const float wy1 = (tp.iy0 + 1 < P.Y) ? tp.wy1 : 0.f;
+  const float wz1 = (tp.iz0 + 1 < P.Z) ? tp.wz1 : 0.f;
+  const long rx0 = (long) tp.ix0 * CP, rx1 = (long) x1 * CP;
+  const long ry0 = (long) tp.iy0 * P.X * CP, ry1 = (long) y1 * P.X * CP;
+  const long rz0 = (long) tp.iz0 * P.Y * P.X * CP, rz1 = (long) z1 * P.Y * P.X * CP;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float wt = ((k & 1) ? wx1 : tp.wx0) * ((k & 2) ? wy1 : tp.wy0) * ((k & 4) ? wz1 : tp.wz0);
+    const float4* f4 = reinterpret_cast<const float4*>(
+        vol + ((k & 4) ? rz1 : rz0) + ((k & 2) ? ry1 : ry0) + ((k & 1) ? rx1 : rx0));
+#pragma unroll
+    for (int q = 0; q < CP4; ++q) {
+      const float4 f = f4[q];
+      s[q * 4 + 0] = __builtin_fmaf(wt, f.x, s[q * 4 + 0]);
+      s[q * 4 + 1] = __builtin_fmaf(wt, f.y, s[q * 4 + 1]);
+      s[q * 4 + 2] = __builtin_fmaf(wt, f.z, s[q * 4 + 2]);
+      s[q * 4 + 3] = __builtin_fmaf(wt, f.w, s[q * 4 + 3]);
+    }
+  }
+}
+
 }  // namespace vamp
