@@ -34,26 +34,56 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
 def kernel_algorithmic_bytes(cfg, B):
-    """Compulsory HBM bytes per launch of each kernel ('Kernels'): every logical
-    input read once, every logical output written once, fp32."""
+    """Compulsory HBM bytes per launch of each kernel: the reference-layout
+    tensors the kernel logically consumes are read once and the ones it produces are written
+    once, fp32; scratch traffic (packed copies, sample records, bin lists) is NOT counted, so
+    `achieved` is a lower bound on what the kernel really moves.  Kernels with no compulsory
+    traffic of their own (count passes, cull, scans) have no entry and cannot be `dominant`."""
     P = cfg.num_cams * cfg.fH * cfg.fW
     V = cfg.vZ * cfg.vY * cfg.vX
     C, K, D = cfg.mid_channels, cfg.num_classes, cfg.D
     YX, oZ = cfg.oY * cfg.oX, cfg.oZ
     CO = C + (K if cfg.cat_seg else 0)
-    cam_ch = 1 + K + 3
+    cam = 1 + K + 3
+    zf = min(1.0, (oZ + 1) / cfg.vZ)                 # fraction of volume planes the det grid touches
     return {
         "lift_fwd": B * (4 * P * (D + C) + 4 * C * V),
-        "lift_bwd": B * (4 * C * V + 2 * 4 * P * (D + C)),
-        "pack_volume": B * (2 * 4 * cam_ch * V),
-        "render_cam_fwd": B * (4 * cam_ch * V + 4 * P * (K + 4)),
-        "render_bev_fwd": B * (4 * (cam_ch + C) * V * min(1.0, (oZ + 1) / cfg.vZ)
-                               + 4 * YX * (K + 4) + 4 * oZ * YX * (1 + CO)),
-        "render_cam_bwd": B * (2 * 4 * cam_ch * V + 4 * P * (K + 4)),
-        "render_bev_bwd": B * (2 * 4 * (cam_ch + C) * V * min(1.0, (oZ + 1) / cfg.vZ)
-                               + 4 * YX * (K + 4) + 4 * oZ * YX * (1 + CO)),
-        "unpack_grad": B * (2 * 4 * cam_ch * V),
+        "lift_bwd_fill": B * (4 * C * V + 8 * V),                 # grad_out + hit words in
+        "lift_bwd": B * (2 * 4 * P * (D + C)),                    # depth/feat in, their grads out
+        "pack_volume": B * (4 * cam * V),                         # the three volumes in
+        "render_cam_fwd": B * (4 * cam * V + 4 * P * (K + 4)),
+        "render_bev_fwd": B * (4 * V * zf + 4 * YX * (oZ + 1)),
+        "render_bev_fwd_channels": B * (4 * (K + 3 + C) * V * zf + 4 * YX * (K + 3) + 4 * oZ * YX * CO),
+        "render_cam_bwd": B * (4 * cam * V + 4 * P * (K + 4)),
+        "render_cam_bwd_gather": B * (4 * cam * V),               # the three volume gradients out
+        "render_bev_bwd_q": B * (4 * (K + 3) * V * zf + 4 * YX * (K + 3)),
+        "render_bev_bwd": B * (4 * V * zf + 4 * YX * (oZ + 2)),
+        "render_bev_bwd_gather": B * (2 * 4 * (cam + C) * V * zf + 4 * oZ * YX * (1 + CO)),
     }
+
+
+STAGES = {   # SURVEY.md section 8(d) stage names -> kernels of this build
+    "lift_fwd": ["feat_to_channel_last", "lift_fwd"],
+    "render_fwd": ["pack_volume", "render_cam_fwd", "render_bev_fwd", "render_bev_fwd_channels"],
+    "lift_bwd": ["lift_bwd_prep", "lift_bwd_count", "lift_bwd_fill", "lift_bwd", "feat_to_channel_first"],
+    "render_bwd": ["render_cam_bwd", "render_cam_bwd_gather", "render_bev_bwd_q", "render_bev_bwd",
+                   "render_bev_bwd_gather", "unpack_grad", "memset"],
+}
+
+
+def measured_traffic(cfg_name, kernel, batch):
+    """HBM bytes per launch from a committed rocprofv3 PMC run (profiles/traffic_*.json, made
+    by tools/collect_traffic.py on the GPU box), or None when no run matches."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                t = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if t.get("cfg") == cfg_name and t.get("batch") == batch and kernel in t.get("kernels", {}):
+            return t["kernels"][kernel]["hbm_bytes_per_launch"]
+    return None
 
 
 def cpu_baseline(cfg, budget_s=30.0):
@@ -117,24 +147,20 @@ def main():
     cfg = PRESETS[a.cfg]
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)      # "nccl" == RCCL on ROCm
+    from vampire_amd import dist as vdist
+    vdist.init("nccl", dev)                                  # "nccl" == RCCL on ROCm
     dtype = torch.float32 if a.dtype == "f32" else torch.bfloat16
 
     model = LiftRenderStep(cfg, dev)
-    step_model = model
-    if world > 1:
-        from torch.nn.parallel import DistributedDataParallel as DDP
-        step_model = DDP(model, device_ids=[local_rank])
-    batch = SyntheticBatch(cfg, a.batch, dev, seed=rank, dtype=dtype)
+    step_model = vdist.wrap_ddp(model, dev)
+    batch = SyntheticBatch(cfg, a.batch, dev, seed=vdist.shard_seed(0, rank), dtype=dtype)
 
     def one_step():
         model.zero_grad(set_to_none=True)
         train_step(step_model, batch)
 
     def fence():
-        if world > 1:
-            dist.barrier()
+        vdist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
@@ -147,10 +173,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     _capi.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = vdist.max_over_ranks(elapsed, dev)
 
     prof = _capi.profile_read()
     if rank == 0:
@@ -159,10 +182,17 @@ def main():
         per_step_us = {k: ms / a.steps * 1e3 for k, (n, ms) in prof.items()}
         dom = max((k for k in per_step_us if k in alg), key=lambda k: per_step_us[k])
         dom_gbs = alg[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e9
-        fwd_names = ["feat_to_channel_last", "lift_fwd", "pack_volume", "render_cam_fwd", "render_bev_fwd"]
-        # forward kernels also run inside backward (re-pack, re-transpose): use per-launch averages
-        fwd_us = sum(kern[k]["avg_us"] for k in fwd_names if k in kern)
-        fwd_bytes = cfg.algorithmic_bytes(4 if a.dtype == "f32" else 2)["fwd"] * a.batch
+        # stage view with SURVEY.md section 8(d)'s algorithmic bytes; the forward kernels also run
+        # inside the backward (re-pack), hence per-launch averages rather than per-step sums
+        sb = cfg.algorithmic_bytes(4 if a.dtype == "f32" else 2)
+        stages = {}
+        for st, names in STAGES.items():
+            us = sum(kern[k]["avg_us"] for k in names if k in kern)
+            stages[st] = {"us": round(us, 1), "algorithmic_bytes": sb[st] * a.batch,
+                          "frac_of_hbm_peak": round(sb[st] * a.batch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                          if us > 0 else None}
+        fwd_us = stages["lift_fwd"]["us"] + stages["render_fwd"]["us"]
+        fwd_bytes = sb["fwd"] * a.batch
         fwd_gbs = fwd_bytes / (fwd_us * 1e-6) / 1e9
         line = {
             "metric": "6-cam samples/sec (lift+render fwd+bwd)",
@@ -179,20 +209,20 @@ def main():
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": dom_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": dom_gbs / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(a.cfg, dom, a.batch),
                          "algorithmic_bytes_per_launch": alg[dom],
                          "avg_launch_us": kern[dom]["avg_us"]},
             "fwd_roofline": {"bound": "hbm", "achieved": fwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": fwd_gbs / HBM_PEAK_GBS, "fused_fwd_us": fwd_us,
                              "algorithmic_bytes": fwd_bytes},
+            "stages": stages,
             "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in sorted(kern.items())},
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    vdist.shutdown()
 
 
 if __name__ == "__main__":

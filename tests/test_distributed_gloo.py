@@ -1,0 +1,101 @@
+"""World-size-2 data-parallel harness on CPU (gloo): sample sharding, DDP all-reduce of the
+path's parameter gradient, max-over-ranks timing.  The HIP operators cannot run here, so the
+step module gets the oracle as an injected stand-in for HotPath -- this tests the distributed
+plumbing of vampire_amd.dist / vampire_amd.step, not the kernels."""
+import dataclasses
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleHotPath:
+    """Test-only stand-in with HotPath's lift/render signatures, computed by the oracle on CPU."""
+
+    def __init__(self, cfg, mats_host):
+        from vampire_amd.geometry import PathGeometry
+        self.cfg, self.geo, self.mats_host = cfg, PathGeometry(cfg), mats_host
+
+    def lift(self, depth, feat, lift_mats):
+        from oracle import aten_oracle as O
+        c = self.cfg
+        return O.lift(depth, feat, self.geo.voxel_coords, None, None, None, None, c.final_dim, c.d_bound,
+                      prepared=lift_mats)
+
+    def render(self, dens, sem, base, rgb, beta, render_mats=None):
+        from oracle import aten_oracle as O
+        c = self.cfg
+        geom = torch.nan_to_num(O.frustum_to_ego(self.geo.frustum, None, None, None, None,
+                                                 prepared=render_mats), -1e3)
+        return O.render(geom, dens, sem, base, rgb,
+                        seg_bounds=(c.x_bound_seg, c.y_bound_seg, c.z_bound_seg),
+                        output_coords=self.geo.output_coords, camera_mids=self.geo.camera_mids,
+                        bev_mids=self.geo.bev_mids, d_far=c.d_bound[1], z_step_det=c.z_bound_det[2],
+                        num_classes=c.num_classes, density_mode=c.density_mode, beta_param=beta,
+                        sdf_bias=c.sdf_bias, cat_seg=c.cat_seg)
+
+
+def _one_rank_grad(cfg, seed):
+    from vampire_amd.step import LiftRenderStep, SyntheticBatch, train_step
+    batch = SyntheticBatch(cfg, 1, "cpu", seed=seed)
+    model = LiftRenderStep(cfg, "cpu", hot_path=OracleHotPath(cfg, batch.mats_host))
+    train_step(model, batch)
+    return float(model.beta.grad), float(batch.depth.grad.abs().sum())
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from vampire_amd import dist as vdist
+    from vampire_amd.config import CFG_TINY
+    from vampire_amd.step import LiftRenderStep, SyntheticBatch, train_step
+    cfg = dataclasses.replace(CFG_TINY, density_mode="sdf")
+    r, w = vdist.init("gloo")
+    assert (r, w) == (rank, world)
+    batch = SyntheticBatch(cfg, 1, "cpu", seed=vdist.shard_seed(0, rank))
+    model = LiftRenderStep(cfg, "cpu", hot_path=OracleHotPath(cfg, batch.mats_host))
+    ddp = vdist.wrap_ddp(model)
+    assert ddp is not model
+    train_step(ddp, batch)
+    elapsed = vdist.max_over_ranks(1.0 + rank)
+    out[rank] = (float(model.beta.grad), float(batch.depth.grad.abs().sum()), elapsed)
+    vdist.shutdown()
+
+
+def test_two_rank_gloo_harness():
+    sys.path.insert(0, ROOT)
+    from vampire_amd import dist as vdist
+    from vampire_amd.config import CFG_TINY
+    cfg = dataclasses.replace(CFG_TINY, density_mode="sdf")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    g0, d0 = _one_rank_grad(cfg, vdist.shard_seed(0, 0))
+    g1, d1 = _one_rank_grad(cfg, vdist.shard_seed(0, 1))
+    # the shards differ, activations' gradients stay local, the parameter gradient is averaged
+    assert abs(d0 - d1) > 1e-6
+    assert out[0][1] == pytest.approx(d0, rel=1e-5) and out[1][1] == pytest.approx(d1, rel=1e-5)
+    mean = 0.5 * (g0 + g1)
+    assert out[0][0] == pytest.approx(mean, rel=1e-4, abs=1e-6)
+    assert out[1][0] == pytest.approx(mean, rel=1e-4, abs=1e-6)
+    # timing contract: every rank sees the slowest rank's time
+    assert out[0][2] == out[1][2] == 2.0
+
+
+def test_single_process_helpers_are_identity():
+    sys.path.insert(0, ROOT)
+    from vampire_amd import dist as vdist
+    m = torch.nn.Linear(2, 2)
+    assert vdist.wrap_ddp(m) is m
+    assert vdist.max_over_ranks(0.25) == 0.25
+    assert vdist.shard_seed(3, 0) == 3 and vdist.shard_seed(3, 1) != vdist.shard_seed(3, 2)

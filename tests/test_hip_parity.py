@@ -331,3 +331,71 @@ def test_lift_backward_tile_matches_atomic_splat_full_size(dev, monkeypatch):
     close(f3, f1, atol=1e-6, rtol=2e-5, scale="max", chan_dim=2, what="bin vs splat grad_feat")
     close(d2, d1, atol=1e-6, rtol=2e-5, scale="max", what="tile vs splat grad_depth")
     close(f2, f1, atol=1e-6, rtol=2e-5, scale="max", chan_dim=2, what="tile vs splat grad_feat")
+
+
+def test_backbone_forward_backward(dev):
+    """The drop-in BaseVAMPIRE2 module end to end on the GPU against the same module with the lift
+    and the renderer swapped for the oracle on CPU (same weights, same inputs): all 12 outputs."""
+    import copy
+    from oracle import aten_oracle as O
+    from vampire_amd.backbone import BaseVAMPIRE2
+    c = CFG_TINY
+    kw = dict(x_bound_seg=list(c.x_bound_seg), y_bound_seg=list(c.y_bound_seg), z_bound_seg=list(c.z_bound_seg),
+              x_bound_det=list(c.x_bound_det), y_bound_det=list(c.y_bound_det), z_bound_det=list(c.z_bound_det),
+              d_bound=list(c.d_bound), final_dim=c.final_dim, downsample_factor=4, upsample_factor=4,
+              mid_channels=4, output_channels=8, img_backbone_conf=dict(), img_neck_conf=dict(out_channels=[8] * 4),
+              num_classes=5, density_mode="sdf", sdf_bias=-1.0, cat_pos=True, cat_seg=True)
+    torch.manual_seed(0)
+    ref = BaseVAMPIRE2(**kw).eval()
+    with torch.no_grad():
+        ref.density_conv.bias.fill_(-1.0)          # bring densities into an informative range
+    mod = copy.deepcopy(ref).to(dev)
+    B = 2
+    s2e, K, ida = synthetic.camera_rig(c, B, src_hw=(64, 176), focal=60.0, centre=(88.0, 34.0), jitter=2.0, seed=4)
+    s2e[:, :, :3, 3] *= 0.3
+    bda = synthetic.bda_matrix(B, rot_deg=8.0)
+    mats = dict(sensor2ego_mats=s2e[:, None], intrin_mats=K[:, None], ida_mats=ida[:, None],
+                sensor2sensor_mats=torch.eye(4).expand(B, 1, 6, 4, 4), bda_mat=bda)
+    imgs = torch.randn(B, 1, 6, 3, *c.final_dim)
+    pts = [torch.rand(50, 3) * 8 - 4 for _ in range(B)]
+    imgs_d = imgs.to(dev).requires_grad_(True)
+    out = mod(imgs_d, {k: v.to(dev) for k, v in mats.items()}, inrange_pts=[p.to(dev) for p in pts])
+    assert len(out) == 12
+
+    # the same forward with oracle lift/render on CPU
+    def oracle_forward(m, imgs):
+        feats = m.get_cam_feats(imgs)
+        src = feats[:, 0].reshape(B * 6, -1, feats.shape[-2], feats.shape[-1])
+        depth = m.mapping_along_depth(src).softmax(dim=1).reshape(B, 6, -1, *src.shape[-2:])
+        feat = m.channel_lower(src).reshape(B, 6, -1, *src.shape[-2:])
+        vox = O.lift(depth, feat, m.voxel_coords, s2e, K, ida, bda, c.final_dim, c.d_bound)
+        vox = torch.cat([vox, m.norm_voxel_coords.permute(3, 0, 1, 2)[None].repeat(B, 1, 1, 1, 1)], 1)
+        base = m.base_conv(vox)
+        dens, sem, rgb = m.density_conv(base), m.seg_conv(base), m.rgb_conv(base)
+        geom = torch.nan_to_num(O.frustum_to_ego(m.frustum, s2e, K, ida, bda), -1e3)
+        r = O.render(geom, dens, sem, base, rgb,
+                     seg_bounds=(c.x_bound_seg, c.y_bound_seg, c.z_bound_seg),
+                     output_coords=m.output_coords, camera_mids=m.camera_mids, bev_mids=m.bev_mids,
+                     d_far=c.d_bound[1], z_step_det=c.z_bound_det[2], num_classes=5, density_mode="sdf",
+                     beta_param=m.density.beta, sdf_bias=-1.0, cat_seg=True)
+        return vox, r
+
+    imgs_c = imgs.clone().requires_grad_(True)
+    vox_o, r = oracle_forward(ref, imgs_c)
+    up = lambda t: ref.upsample2d(t.reshape(B * 6, -1, ref.fH, ref.fW)).reshape(B, 6, -1, ref.fH * 4, ref.fW * 4)
+    close(out[1], up(r[0]), what="rgb_preds")
+    close(out[2], up(r[1]), what="seg_logits_preds")
+    close(out[3], up(r[2]), atol=2e-4, what="depth_preds")
+    for i, j in ((4, 3), (5, 4), (6, 5), (7, 6)):
+        close(out[i], r[j], what=f"output {i}")
+    bev_feat = ref.voxel_output((r[7] * r[6].tanh()).reshape(B, -1, *r[7].shape[-2:]))
+    close(out[0], bev_feat, atol=2e-4, what="bev feature")
+    assert len(out[8]) == B and out[8][0].shape == (50, 5) and out[10].shape == (B, 200, 200, 16, 5)
+
+    # backward through everything: gradient w.r.t. the images and beta
+    loss = sum((o.float() ** 2).mean() for o in out[:8])
+    loss.backward()
+    loss_o = (bev_feat ** 2).mean() + sum((t ** 2).mean() for t in (up(r[0]), up(r[1]), up(r[2]), r[3], r[4], r[5], r[6]))
+    loss_o.backward()
+    close(imgs_d.grad, imgs_c.grad, atol=1e-6, rtol=2e-3, scale="max", what="grad images")
+    close(mod.density.beta.grad.reshape(1), ref.density.beta.grad.reshape(1), atol=1e-5, rtol=2e-3, what="grad beta")

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun): collects the rocprofv3 evidence bench.py's numbers are judged
+# against and writes it under gpurun_out/ (copy the summaries into profiles/ afterwards).
+#   1. --kernel-trace --stats of the default bench command
+#   2. PMC passes (FETCH_SIZE, then WRITE_SIZE; separate passes, no trace domains) of the same step
+# usage: tools/collect_profiles.sh <round-tag> [cfg] [batch]
+set -u
+TAG=${1:-r01}; CFG=${2:-B}; BATCH=${3:-1}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/profiles_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --cfg $CFG --batch $BATCH --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/tools/time_bwd.py $CFG $BATCH > /dev/null 2> $OUT/pmc_fetch.log
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/tools/time_bwd.py $CFG $BATCH > /dev/null 2> $OUT/pmc_write.log
+cd $ROOT
+python3 tools/summarize_profiles.py $OUT $TAG $CFG $BATCH

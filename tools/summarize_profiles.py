@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (tools/collect_profiles.sh) into two small files:
+  <out>/kernel_stats_<tag>.csv   per-kernel calls / average / total from --kernel-trace --stats
+  <out>/traffic_<tag>.json       per-kernel HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE
+                                 PMC passes (units and gfx950 correction per MI355X_MICROARCH.md:
+                                 counters are KiB; FETCH_SIZE under-reports wide coalesced reads
+                                 by 2x on gfx950, so both the raw and the doubled figure are kept)
+"""
+import collections, csv, glob, json, os, sys
+
+out, tag, cfg, batch = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+
+SLOTS = [("lift_fwd_kernel", "lift_fwd"), ("lift_bwd_own_kernel", "lift_bwd"),
+         ("lift_bwd_bin_kernel", None), ("lift_bwd_tile_kernel", "lift_bwd_tile"),
+         ("feat_to_channel_last", "feat_to_channel_last"), ("pack_volume_kernel", "pack_volume"),
+         ("render_cam_fwd_kernel", "render_cam_fwd"), ("bev_density_kernel", "render_bev_fwd"),
+         ("bev_channels_kernel", "render_bev_fwd_channels"), ("cam_bwd_ray_kernel", "render_cam_bwd"),
+         ("cam_bwd_gather_kernel", "render_cam_bwd_gather"), ("cam_bwd_cull_kernel", "cam_bwd_cull"),
+         ("bev_q_kernel", "render_bev_bwd_q"), ("bev_scan_kernel", "render_bev_bwd"),
+         ("bev_gather_kernel", "render_bev_bwd_gather"), ("lift_bwd_prep_kernel", "lift_bwd_prep"),
+         ("exclusive_scan_kernel", "scan"), ("invert_mats_kernel", "invert_mats")]
+
+
+def slot(name):
+    for key, s in SLOTS:
+        if key in name:
+            if key == "lift_bwd_bin_kernel":
+                return "lift_bwd_fill" if "true>" in name.replace(" ", "") else "lift_bwd_count"
+            return s
+    return None
+
+
+def read_pmc(d, counter):
+    acc, n = collections.defaultdict(float), collections.Counter()
+    for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            s = slot(r["Kernel_Name"])
+            if s:
+                acc[s] += float(r["Counter_Value"]); n[s] += 1
+    return {k: acc[k] / n[k] for k in acc}
+
+stats_rows = []
+for f in glob.glob(os.path.join(out, "stats", "*", "*kernel_stats.csv")):
+    for r in csv.DictReader(open(f)):
+        stats_rows.append((r["Name"], int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6,
+                           float(r["Percentage"])))
+stats_rows.sort(key=lambda r: -r[3])
+with open(os.path.join(out, f"kernel_stats_{tag}.csv"), "w") as fh:
+    fh.write("kernel,calls,avg_us,total_ms,percent\n")
+    for name, calls, avg, tot, pct in stats_rows:
+        fh.write(f"\"{name[:120]}\",{calls},{avg:.2f},{tot:.3f},{pct:.2f}\n")
+
+fetch, write = read_pmc(os.path.join(out, "pmc_fetch"), "FETCH_SIZE"), read_pmc(os.path.join(out, "pmc_write"), "WRITE_SIZE")
+kernels = {}
+for k in sorted(set(fetch) | set(write)):
+    fr, wr = fetch.get(k, 0.0) * 1024, write.get(k, 0.0) * 1024
+    kernels[k] = {"fetch_bytes_raw": fr, "write_bytes": wr, "hbm_bytes_per_launch": 2 * fr + wr,
+                  "hbm_bytes_per_launch_uncorrected": fr + wr}
+json.dump({"tag": tag, "cfg": cfg, "batch": batch, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)",
+           "note": "KiB counters x1024; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 under-reports wide "
+                   "coalesced reads by 2x; other access widths uncalibrated)", "kernels": kernels},
+          open(os.path.join(out, f"traffic_{tag}.json"), "w"), indent=1)
+print(open(os.path.join(out, f"kernel_stats_{tag}.csv")).read()[:3000])
+print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e6, 1) for k, v in kernels.items()}))

@@ -16,10 +16,12 @@ from . import synthetic
 
 
 class LiftRenderStep(nn.Module):
-    def __init__(self, cfg: PathConfig, device):
+    def __init__(self, cfg: PathConfig, device, hot_path=None):
         super().__init__()
         self.cfg = cfg
-        self.hp = HotPath(cfg, device)
+        # hot_path is injectable so that the multi-process harness can be exercised on CPU (gloo)
+        # in tests with a stand-in; the product always uses the HIP HotPath.
+        self.hp = HotPath(cfg, device) if hot_path is None else hot_path
         self.beta = nn.Parameter(torch.tensor(0.1, device=device))      # ModifyLaplaceDensity(beta=0.1)
 
     def forward(self, depth, feat, vols, lift_mats, render_mats):
