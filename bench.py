@@ -56,6 +56,7 @@ def kernel_algorithmic_bytes(cfg, B):
         "render_bev_fwd_channels": B * (4 * (K + 3 + C) * V * zf + 4 * YX * (K + 3) + 4 * oZ * YX * CO),
         "render_cam_bwd": B * (4 * cam * V + 4 * P * (K + 4)),
         "render_cam_bwd_gather": B * (4 * cam * V),               # the three volume gradients out
+        "render_cam_bwd_own": B * (4 * cam * V),                  # (same, bin-then-own scatter)
         "render_bev_bwd_q": B * (4 * (K + 3) * V * zf + 4 * YX * (K + 3)),
         "render_bev_bwd": B * (4 * V * zf + 4 * YX * (oZ + 2)),
         "render_bev_bwd_gather": B * (2 * 4 * (cam + C) * V * zf + 4 * oZ * YX * (1 + CO)),
@@ -66,7 +67,8 @@ STAGES = {   # SURVEY.md section 8(d) stage names -> kernels of this build
     "lift_fwd": ["feat_to_channel_last", "lift_fwd"],
     "render_fwd": ["pack_volume", "render_cam_fwd", "render_bev_fwd", "render_bev_fwd_channels"],
     "lift_bwd": ["lift_bwd_prep", "lift_bwd_count", "lift_bwd_fill", "lift_bwd", "feat_to_channel_first"],
-    "render_bwd": ["render_cam_bwd", "render_cam_bwd_gather", "render_bev_bwd_q", "render_bev_bwd",
+    "render_bwd": ["render_cam_bwd", "render_cam_bwd_count", "render_cam_bwd_fill", "render_cam_bwd_own",
+                   "render_cam_bwd_gather", "render_bev_bwd_q", "render_bev_bwd",
                    "render_bev_bwd_gather", "unpack_grad", "memset"],
 }
 

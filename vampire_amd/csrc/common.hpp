@@ -44,7 +44,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 enum ProfSlot {
   kProfFeatCL = 0, kProfLiftFwd, kProfLiftBwd, kProfFeatCF, kProfLiftFwdDense, kProfLiftBwdDense,
   kProfPack, kProfCamFwd, kProfBevFwd, kProfCamBwd, kProfUnpack, kProfBevBwd, kProfMemset,
-  kProfAux, kProfCamBwdBrick, kProfBevFwdCh, kProfBevBwdQ, kProfBevBwdGather, kProfLiftBwdPrep, kProfLiftBwdCount, kProfLiftBwdFill, kProfSlots
+  kProfAux, kProfCamBwdBrick, kProfBevFwdCh, kProfBevBwdQ, kProfBevBwdGather, kProfLiftBwdPrep, kProfLiftBwdCount, kProfLiftBwdFill, kProfCamBwdCount, kProfCamBwdFill, kProfCamBwdOwn, kProfSlots
 };
 struct ProfScope { int idx; };
 bool prof_enabled();

@@ -192,7 +192,9 @@ __device__ __forceinline__ float tap_weight(float f, float iv) {
 __global__ void __launch_bounds__(256)
 cam_bwd_cull_kernel(RenderParams P, const float* __restrict__ pmats, const float* __restrict__ us,
                     const float* __restrict__ vs, const float* __restrict__ ds,
-                    unsigned* __restrict__ cull, int runs_x) {
+                    unsigned* __restrict__ cull, int runs_x, const int* __restrict__ total_e,
+                    int cap_e) {
+  if (total_e && *total_e <= cap_e) return;       // fallback only: the binned lists fit
   const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long) runs_x * P.Y * P.Z * P.B;
   if (gid >= total) return;
@@ -246,7 +248,9 @@ cam_bwd_gather_kernel(RenderParams P, const float* __restrict__ pmats, const flo
                       const float* __restrict__ FZ, const float* __restrict__ Wbuf,
                       const float* __restrict__ G0buf, const float* __restrict__ Gcl,
                       const unsigned* __restrict__ cull, float* __restrict__ gdens,
-                      float* __restrict__ gsem, float* __restrict__ grgb) {
+                      float* __restrict__ gsem, float* __restrict__ grgb,
+                      const int* __restrict__ total_e, int cap_e) {
+  if (total_e && *total_e <= cap_e) return;       // fallback only: the binned lists fit
   constexpr int CP = CP4 * 4;
   __shared__ float outs[CP][VPB + 1];
   const int tid = threadIdx.x;
@@ -373,14 +377,23 @@ cam_bwd_gather_kernel(RenderParams P, const float* __restrict__ pmats, const flo
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+size_t cam_bwd_bin_bytes(const VampRenderDesc* d);     // render_bwd_bin.hip
+
 size_t cam_bwd_v2_bytes(const VampRenderDesc* d) {
   const RenderParams P = to_params(d);
   const size_t samples = (size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW;
   const size_t rays = (size_t) d->B * d->N * d->fH * d->fW;
   return 5 * align_up(samples * sizeof(float), 256) + align_up(rays * P.CP * sizeof(float), 256) +
          align_up((size_t) d->B * d->N * 48 * sizeof(float), 256) +
-         align_up((size_t) d->B * d->Z * d->Y * ((d->X + VPB - 1) / VPB) * sizeof(unsigned), 256);
+         align_up((size_t) d->B * d->Z * d->Y * ((d->X + VPB - 1) / VPB) * sizeof(unsigned), 256) +
+         cam_bwd_bin_bytes(d);
 }
+
+size_t cam_bwd_bin_bytes(const VampRenderDesc* d);
+int launch_cam_bwd_bin(const VampRenderDesc* d, const RenderParams& P, const float* FX,
+                       const float* FY, const float* FZ, const float* Wbuf, const float* G0buf,
+                       const float* Gcl, float* gdens, float* gsem, float* grgb, void* scratch,
+                       const int** total_out, int* cap_out, hipStream_t s);
 
 // scratch = workspace region after the packed volume
 int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const float* mats,
@@ -399,8 +412,8 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
   float* Gcl = reinterpret_cast<float*>(p); p += align_up(rays * P.CP * sizeof(float), 256);
   float* pmats = reinterpret_cast<float*>(p); p += align_up((size_t) d->B * d->N * 48 * sizeof(float), 256);
   unsigned* cull = reinterpret_cast<unsigned*>(p);
-
-  if (int e = launch_invert_mats(mats, pmats, d->B * d->N * 3, false, s)) return e;
+  p += align_up((size_t) d->B * d->Z * d->Y * ((d->X + VPB - 1) / VPB) * sizeof(unsigned), 256);
+  void* bin_scratch = p;
 
   constexpr int LPR = 4;
   const int S = d->D - 1;
@@ -408,15 +421,8 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
   const size_t lds = (size_t) 3 * L * 256 * sizeof(float);
   if (lds > 150 * 1024) return fail(VAMP_EINVAL, "%s: too many depth samples for the LDS staging", __func__);
   const unsigned grid = ray_grid<LPR>(P);
-  dim3 bgrid((d->X + VPB - 1) / VPB, d->Y, d->Z * d->B);
-  {
-    const int runs_x = (d->X + VPB - 1) / VPB;
-    const long total = (long) runs_x * d->Y * d->Z * d->B;
-    VAMP_TIMED(kProfAux, s, (cam_bwd_cull_kernel<<<(unsigned) ((total + 255) / 256), 256, 0, s>>>(
-        P, pmats, us, vs, ds, cull, runs_x)));
-    if (int e = check_launch("cam_bwd_cull_kernel")) return e;
-  }
-#define VAMP_V2(CP4)                                                                              \
+  // 1. per-ray pass: one record per sample
+#define VAMP_RAY(CP4)                                                                             \
   do {                                                                                            \
     auto kr = cam_bwd_ray_kernel<LPR, CP4>;                                                       \
     if (lds > 64 * 1024 &&                                                                        \
@@ -426,12 +432,36 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
     VAMP_TIMED(kProfCamBwd, s, (kr<<<grid, 256, lds, s>>>(P, mats, us, vs, ds, mids, beta, packed, \
                                                            g_rgb, g_seg, g_depth, Wbuf, G0buf, FX, FY, FZ, \
                                                            Gcl, grad_beta, L)));                  \
-    if (int e = check_launch("cam_bwd_ray_kernel")) return e;                                     \
-    VAMP_TIMED(kProfCamBwdBrick, s, (cam_bwd_gather_kernel<CP4><<<bgrid, 256, 0, s>>>(            \
-        P, pmats, us, vs, ds, FX, FY, FZ, Wbuf, G0buf, Gcl, cull, gdens, gsem, grgb)));           \
   } while (0)
-  if (P.CP == 12) VAMP_V2(3); else if (P.CP == 24) VAMP_V2(6); else VAMP_V2(8);
-#undef VAMP_V2
+  if (P.CP == 12) VAMP_RAY(3); else if (P.CP == 24) VAMP_RAY(6); else VAMP_RAY(8);
+#undef VAMP_RAY
+  if (int e = check_launch("cam_bwd_ray_kernel")) return e;
+
+  // 2. scatter stage.  Default: bin the records into per-brick lists and let one workgroup own
+  //    each brick (render_bwd_bin.hip).  The per-voxel gather below runs only if the lists
+  //    overflow the workspace (device-side decision) or when forced with VAMP_CAM_BWD=gather.
+  const int* total = nullptr;
+  int cap = 0;
+  const char* force = getenv("VAMP_CAM_BWD");
+  const bool gather_only = force && force[0] == 'g';
+  if (!gather_only)
+    if (int e = launch_cam_bwd_bin(d, P, FX, FY, FZ, Wbuf, G0buf, Gcl, gdens, gsem, grgb,
+                                   bin_scratch, &total, &cap, s))
+      return e;
+  if (int e = launch_invert_mats(mats, pmats, d->B * d->N * 3, false, s)) return e;
+  dim3 bgrid((d->X + VPB - 1) / VPB, d->Y, d->Z * d->B);
+  {
+    const int runs_x = (d->X + VPB - 1) / VPB;
+    const long nrun = (long) runs_x * d->Y * d->Z * d->B;
+    VAMP_TIMED(kProfAux, s, (cam_bwd_cull_kernel<<<(unsigned) ((nrun + 255) / 256), 256, 0, s>>>(
+        P, pmats, us, vs, ds, cull, runs_x, total, cap)));
+    if (int e = check_launch("cam_bwd_cull_kernel")) return e;
+  }
+#define VAMP_GATHER(CP4)                                                                          \
+  VAMP_TIMED(kProfCamBwdBrick, s, (cam_bwd_gather_kernel<CP4><<<bgrid, 256, 0, s>>>(              \
+      P, pmats, us, vs, ds, FX, FY, FZ, Wbuf, G0buf, Gcl, cull, gdens, gsem, grgb, total, cap)))
+  if (P.CP == 12) VAMP_GATHER(3); else if (P.CP == 24) VAMP_GATHER(6); else VAMP_GATHER(8);
+#undef VAMP_GATHER
   return check_launch("cam_bwd_gather_kernel");
 }
 

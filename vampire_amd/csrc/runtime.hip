@@ -23,7 +23,7 @@ const char* g_names[kProfSlots] = {
     "lift_bwd_dense", "pack_volume", "render_cam_fwd", "render_bev_fwd", "render_cam_bwd",
     "unpack_grad", "render_bev_bwd", "memset", "aux", "render_cam_bwd_gather", "render_bev_fwd_channels",
     "render_bev_bwd_q", "render_bev_bwd_gather", "lift_bwd_prep", "lift_bwd_count",
-    "lift_bwd_fill"};
+    "lift_bwd_fill", "render_cam_bwd_count", "render_cam_bwd_fill", "render_cam_bwd_own"};
 }  // namespace
 
 bool prof_enabled() { return g_on; }
