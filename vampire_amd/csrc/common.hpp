@@ -54,6 +54,9 @@ void prof_end(hipStream_t s, ProfScope* sc);
 int launch_invert_mats(const float* mats, float* inv, int count, bool reverse3, hipStream_t s);
 // device-side exclusive scan of bin counts (runtime.hip): off[i] = sum_{j<i} cnt[j], fill[i] = 0
 int launch_exclusive_scan(const int* cnt, int* off, int* fill, int n, int* total, hipStream_t s);
+// work items (bin, chunk) for lists split into chunks of `chunk` entries; upper bound on the
+// item count: n + total / chunk
+int launch_build_worklist(const int* cnt, int n, int chunk, int* work, int* nwork, hipStream_t s);
 // usage: VAMP_TIMED(slot, stream, kernel<<<...>>>(...));
 #define VAMP_TIMED(slot, stream, launch)              \
   do {                                                \

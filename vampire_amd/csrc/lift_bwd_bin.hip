@@ -66,8 +66,16 @@ __device__ __forceinline__ void wave_bin_count(int* __restrict__ counters, int b
   }
 }
 
+// Per-workgroup LDS histogram over this sample's (camera, tile) bins: same-address global
+// integer atomics serialise (~1 us each under contention), so a 1024-voxel workgroup touches
+// each global counter at most once.
+//   count: pass A builds the histogram, the non-zero bins are flushed (fire-and-forget);
+//   fill : pass A, then each non-zero bin reserves a contiguous range with ONE returned
+//          atomic, pass B re-walks the voxels and ranks them inside the range with LDS atomics.
+constexpr int kBinThreads = 1024;
+
 template <typename T, int CH, bool FILL>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kBinThreads)
 lift_bwd_bin_kernel(LiftParams P, BinGeom G, const float* __restrict__ mats,
                     const float* __restrict__ xs, const float* __restrict__ ys,
                     const float* __restrict__ zs, const T* __restrict__ depth,
@@ -75,77 +83,104 @@ lift_bwd_bin_kernel(LiftParams P, BinGeom G, const float* __restrict__ mats,
                     int* __restrict__ cnt, const int* __restrict__ off, int* __restrict__ fill,
                     float* __restrict__ entries, const int* __restrict__ total, int cap) {
   if (FILL && *total > cap) return;                 // lists do not fit: the fallback runs instead
+  extern __shared__ int ltab[];                     // [2][N * ntile]: histogram / reserved bases
+  const int ntile = G.tiles_w * G.tiles_h;
+  const int NT = P.N * ntile;
+  int* hist = ltab;
+  int* lbase = ltab + NT;
   const int tid = threadIdx.x;
+  for (int e = tid; e < 2 * NT; e += kBinThreads) ltab[e] = 0;
   const int x = blockIdx.x * 64 + (tid & 63);
-  const int y = blockIdx.y * 4 + (tid >> 6);
+  const int y = blockIdx.y * (kBinThreads / 64) + (tid >> 6);
   const int z = blockIdx.z % P.Z, b = blockIdx.z / P.Z;
-  const bool live = x < P.X && y < P.Y;             // dead lanes still take part in the ballots
+  const bool live = x < P.X && y < P.Y;
   const int xc = min(x, P.X - 1), yc = min(y, P.Y - 1);
   const float vx = xs[xc], vy = ys[yc], vz = zs[z];
   const long V = (long) P.Z * P.Y * P.X;
   const long vox = ((long) z * P.Y + yc) * P.X + xc;
   const long HW = (long) P.fH * P.fW;
   const int ES = 8 + P.C;
-  const int ntile = G.tiles_w * G.tiles_h;
+  __syncthreads();
 
+  // ---- pass A: histogram ----
   for (int n = 0; n < P.N; ++n) {
     const long bn = (long) b * P.N + n;
     const LiftTap t = lift_project(P, mats + bn * 48, vx, vy, vz);
-    int txa = -1, txb = -1, tya = -1, tyb = -1;
-    if (live && t.valid) {
-      axis_tiles(t.ix0, P.fW, BTW, txa, txb);
-      axis_tiles(t.iy0, P.fH, BTH, tya, tyb);
+    if (!live || !t.valid) continue;
+    int txa, txb, tya, tyb;
+    axis_tiles(t.ix0, P.fW, BTW, txa, txb);
+    axis_tiles(t.iy0, P.fH, BTH, tya, tyb);
+    if (txa < 0 || tya < 0) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int tx = (q & 1) ? txb : txa, ty = (q & 2) ? tyb : tya;
+      if (tx >= 0 && ty >= 0) atomicAdd(hist + n * ntile + ty * G.tiles_w + tx, 1);
     }
-    const bool pair_ok = txa >= 0 && tya >= 0;
-    if (!__any(pair_ok)) continue;                  // wave-uniform
+  }
+  __syncthreads();
+  if (!FILL) {
+    for (int e = tid; e < NT; e += kBinThreads)
+      if (hist[e]) atomicAdd(cnt + (long) b * NT + e, hist[e]);
+    return;
+  }
+  for (int e = tid; e < NT; e += kBinThreads)
+    if (hist[e]) {
+      lbase[e] = atomicAdd(fill + (long) b * NT + e, hist[e]);
+      hist[e] = 0;
+    }
+  __syncthreads();
+
+  // ---- pass B: rank inside the reserved ranges and write the records ----
+  for (int n = 0; n < P.N; ++n) {
+    const long bn = (long) b * P.N + n;
+    const LiftTap t = lift_project(P, mats + bn * 48, vx, vy, vz);
+    if (!live || !t.valid) continue;
+    int txa, txb, tya, tyb;
+    axis_tiles(t.ix0, P.fW, BTW, txa, txb);
+    axis_tiles(t.iy0, P.fH, BTH, tya, tyb);
+    if (txa < 0 || tya < 0) continue;
     float dep[4] = {0.f, 0.f, 0.f, 0.f};
-    if (FILL && pair_ok) {
-      if (P.use_depth) {
-        const T* dptr = depth + bn * P.D * HW;
+    if (P.use_depth) {
+      const T* dptr = depth + bn * P.D * HW;
 #pragma unroll
-        for (int kz = 0; kz < 2; ++kz) {
-          const int iz = t.iz0 + kz;
-          if (iz < 0 || iz >= P.D) continue;
-          const float wz = kz ? t.wz1 : t.wz0;
+      for (int kz = 0; kz < 2; ++kz) {
+        const int iz = t.iz0 + kz;
+        const bool zin = iz >= 0 && iz < P.D;
+        const float wz = zin ? (kz ? t.wz1 : t.wz0) : 0.f;
+        const long zo = (long) min(max(iz, 0), P.D - 1) * HW;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int iy = t.iy0 + (j >> 1), ix = t.ix0 + (j & 1);
-            if (iy < 0 || iy >= P.fH || ix < 0 || ix >= P.fW) continue;
-            dep[j] += wz * ldf(dptr, iz * HW + (long) iy * P.fW + ix);
-          }
+        for (int j = 0; j < 4; ++j) {
+          const int iy = t.iy0 + (j >> 1), ix = t.ix0 + (j & 1);
+          const bool in = iy >= 0 && iy < P.fH && ix >= 0 && ix < P.fW;
+          dep[j] += (in ? wz : 0.f) *
+                    ldf(dptr, zo + (long) min(max(iy, 0), P.fH - 1) * P.fW + min(max(ix, 0), P.fW - 1));
         }
-      } else {
-        const float w = (t.iz0 == 0 ? t.wz0 : 0.f) + (t.iz0 == -1 ? t.wz1 : 0.f);
-        dep[0] = dep[1] = dep[2] = dep[3] = w;
       }
+    } else {
+      const float w = (t.iz0 == 0 ? t.wz0 : 0.f) + (t.iz0 == -1 ? t.wz1 : 0.f);
+      dep[0] = dep[1] = dep[2] = dep[3] = w;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int tx = (q & 1) ? txb : txa, ty = (q & 2) ? tyb : tya;
-      const bool act = pair_ok && tx >= 0 && ty >= 0;
-      if (!__any(act)) continue;                    // wave-uniform
-      const int bin = act ? (int) (bn * ntile + (long) ty * G.tiles_w + tx) : 0;
-      if (!FILL) {
-        wave_bin_count(cnt, bin, act);
-      } else {
-        const int rank = wave_bin_add(fill, bin, act);
-        if (!act) continue;
-        const long slot = (long) off[bin] + rank;
-        float* e = entries + slot * ES;
-        *reinterpret_cast<float4*>(e) = make_float4(t.fx, t.fy, t.fz, 0.f);
-        *reinterpret_cast<float4*>(e + 4) = make_float4(dep[0], dep[1], dep[2], dep[3]);
-        // grad_out / (hit count + 1e-6), the camera-mean factor of bv2:512-514
-        for (int chunk = 0; chunk < P.C / CH; ++chunk) {
-          const uint64_t hw = hits[((long) b * V + vox) * (P.C / CH) + chunk];
-          const float* g = gout + ((long) b * P.C + chunk * CH) * V + vox;
+      if (tx < 0 || ty < 0) continue;
+      const int le = n * ntile + ty * G.tiles_w + tx;
+      const long bin = (long) b * NT + le;
+      const long slot = (long) off[bin] + lbase[le] + atomicAdd(hist + le, 1);
+      float* e = entries + slot * ES;
+      *reinterpret_cast<float4*>(e) = make_float4(t.fx, t.fy, t.fz, 0.f);
+      *reinterpret_cast<float4*>(e + 4) = make_float4(dep[0], dep[1], dep[2], dep[3]);
+      // grad_out / (hit count + 1e-6), the camera-mean factor of bv2:512-514
+      for (int chunk = 0; chunk < P.C / CH; ++chunk) {
+        const uint64_t hw = hits[((long) b * V + vox) * (P.C / CH) + chunk];
+        const float* g = gout + ((long) b * P.C + chunk * CH) * V + vox;
 #pragma unroll
-          for (int c4 = 0; c4 < CH; c4 += 4) {
-            float v[4];
+        for (int c4 = 0; c4 < CH; c4 += 4) {
+          float v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-              v[k] = g[(long) (c4 + k) * V] / ((float) ((hw >> (4 * (c4 + k))) & 15) + 1e-6f);
-            *reinterpret_cast<float4*>(e + 8 + chunk * CH + c4) = make_float4(v[0], v[1], v[2], v[3]);
-          }
+          for (int k = 0; k < 4; ++k)
+            v[k] = g[(long) (c4 + k) * V] / ((float) ((hw >> (4 * (c4 + k))) & 15) + 1e-6f);
+          *reinterpret_cast<float4*>(e + 8 + chunk * CH + c4) = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
     }
@@ -281,11 +316,13 @@ static int launch_bin_t(const VampLiftDesc* d, const LiftParams& P, const float*
   BinGeom G{(d->fW + BTW - 1) / BTW, (d->fH + BTH - 1) / BTH};
   if (hipMemsetAsync(cnt, 0, (size_t) nb * sizeof(int), s) != hipSuccess)
     return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
-  dim3 grid((d->X + 63) / 64, (d->Y + 3) / 4, d->Z * d->B);
+  dim3 grid((d->X + 63) / 64, (d->Y + kBinThreads / 64 - 1) / (kBinThreads / 64), d->Z * d->B);
+  const size_t tab = (size_t) 2 * d->N * G.tiles_w * G.tiles_h * sizeof(int);
+  if (tab > 60 * 1024) return fail(VAMP_EINVAL, "%s: too many (camera, tile) bins for the LDS histogram", __func__);
   const T* dp = static_cast<const T*>(depth);
 #define VAMP_BIN(CH, FILLV)                                                                     \
   VAMP_TIMED(FILLV ? kProfLiftBwdFill : kProfLiftBwdCount, s,                                   \
-             (lift_bwd_bin_kernel<T, CH, FILLV><<<grid, 256, 0, s>>>(                           \
+             (lift_bwd_bin_kernel<T, CH, FILLV><<<grid, kBinThreads, tab, s>>>(                           \
                  P, G, mats, xs, ys, zs, dp, gout, hits, cnt, off, fill, entries, total, cap)))
   if (P.C == 4) VAMP_BIN(4, false); else if (P.C == 8) VAMP_BIN(8, false); else VAMP_BIN(16, false);
   if (int e = check_launch("lift_bwd_bin_kernel<count>")) return e;

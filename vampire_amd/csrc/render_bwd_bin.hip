@@ -20,7 +20,8 @@
 namespace vamp {
 
 constexpr int KBX = 8, KBY = 4, KBZ = 4, KNV = KBX * KBY * KBZ;
-constexpr int kOwnThreadsCam = 1024;
+constexpr int kOwnThreadsCam = 256;
+constexpr int kChunk = 1024;             // list entries per work item
 
 struct BrickGrid {
   int nbx, nby, nbz;
@@ -113,77 +114,94 @@ cam_bwd_bin_kernel(RenderParams P, BrickGrid G, const float* __restrict__ FX,
   }
 }
 
+// One workgroup per work item = (brick, chunk of <= kChunk list entries).  The chunk is staged in
+// LDS with one coalesced read; each 32-lane group (lane = channel) then walks a CONTIGUOUS run of
+// it.  Neighbouring entries are neighbouring pixels, which in the near field land on the same
+// eight taps for dozens of entries: their contributions are summed in registers and flushed to
+// the LDS brick only when the tap base changes (same-address LDS float atomics serialise badly).
+// A brick owned by a single work item is stored; a brick split over several is accumulated into
+// the (pre-zeroed) outputs with float atomics.
 template <int CP4>
 __global__ void __launch_bounds__(kOwnThreadsCam)
 cam_bwd_own_kernel(RenderParams P, BrickGrid G, const int* __restrict__ cnt,
-                   const int* __restrict__ off, const float4* __restrict__ E4,
+                   const int* __restrict__ off, const int* __restrict__ work,
+                   const int* __restrict__ nwork, const float4* __restrict__ E4,
                    const float2* __restrict__ E2, const float* __restrict__ Gcl,
                    float* __restrict__ gdens, float* __restrict__ gsem, float* __restrict__ grgb,
-                   const int* __restrict__ total, int cap, int dbg) {
-  if (*total > cap) return;
+                   const int* __restrict__ total, int cap) {
+  if (*total > cap || (int) blockIdx.x >= *nwork) return;
   constexpr int CP = CP4 * 4;
   constexpr int STRIDE = CP + 1;                 // odd: lane c of any voxel -> its own bank
-  constexpr int NG = kOwnThreadsCam / 32;        // 32 groups of 32 lanes, lane = channel
-  constexpr int UB = 8;                          // entries per group per batch (loads in flight)
+  constexpr int NG = kOwnThreadsCam / 32;        // groups of 32 lanes, lane = channel
+  constexpr int PER = kChunk / NG;               // contiguous entries per group
   __shared__ float acc[KNV * STRIDE];
-  __shared__ float4 t4[kOwnThreadsCam];          // staged tile of entries
-  __shared__ float2 t2[kOwnThreadsCam];
+  __shared__ float4 t4[kChunk];
+  __shared__ float2 t2[kChunk];
   const int tid = threadIdx.x;
-  const int bin = blockIdx.x;
+  const int bin = work[2 * blockIdx.x], chunk = work[2 * blockIdx.x + 1];
   const int bx = bin % G.nbx, by = (bin / G.nbx) % G.nby, bz = (bin / (G.nbx * G.nby)) % G.nbz;
   const int b = bin / (G.nbx * G.nby * G.nbz);
   const int x0 = bx * KBX, y0 = by * KBY, z0 = bz * KBZ;
   const int x1 = min(P.X, x0 + KBX) - 1, y1 = min(P.Y, y0 + KBY) - 1, z1 = min(P.Z, z0 + KBZ) - 1;
   for (int i = tid; i < KNV * STRIDE; i += kOwnThreadsCam) acc[i] = 0.f;
+  const int n_all = cnt[bin];
+  const long first = (long) off[bin] + (long) chunk * kChunk;
+  const int n_ent = min(kChunk, n_all - chunk * kChunk);
+  for (int i = tid; i < n_ent; i += kOwnThreadsCam) {
+    t4[i] = E4[first + i];
+    t2[i] = E2[first + i];
+  }
+  __syncthreads();
 
   const int nch = 1 + P.K + 3;
   const int grp = tid >> 5, c = tid & 31;
   const int cc = min(c, nch - 1);                // idle lanes load a legal address, add nothing
-  const long first = off[bin];
-  const int n_ent = cnt[bin];
-  for (int base = 0; base < n_ent; base += kOwnThreadsCam) {
-    // stage a tile: one coalesced round trip for up to 1024 entries
-    __syncthreads();
-    if (base + tid < n_ent) {
-      t4[tid] = E4[first + base + tid];
-      t2[tid] = E2[first + base + tid];
+  float run[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) run[k] = 0.f;
+  int rx = -0x40000000, ry = 0, rz = 0;          // tap base of the open run
+  auto flush = [&]() {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ix = rx + (k & 1), iy = ry + ((k >> 1) & 1), iz = rz + (k >> 2);
+      if (ix >= x0 && ix <= x1 && iy >= y0 && iy <= y1 && iz >= z0 && iz <= z1 && c < nch && run[k] != 0.f)
+        atomicAdd(acc + (((iz - z0) * KBY + (iy - y0)) * KBX + (ix - x0)) * STRIDE + c, run[k]);
+      run[k] = 0.f;
     }
-    __syncthreads();
-    const int n_tile = min(kOwnThreadsCam, n_ent - base);
-    // entries grp, grp + NG, ... of the tile, UB at a time: the dependent G loads of a batch
-    // are issued together
-    for (int j0 = grp; j0 < n_tile; j0 += NG * UB) {
-      float val[UB];
+  };
+  const int j_lo = grp * PER, j_hi = min(n_ent, j_lo + PER);
+  constexpr int UB = 16;
+  for (int j0 = j_lo; j0 < j_hi; j0 += UB) {
+    float val[UB];
 #pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int j = j0 + u * NG;
-        const int jj = j < n_tile ? j : j0;
-        const float2 g = t2[jj];
-        const float gv = (dbg & 2) ? 1.f : Gcl[(long) __float_as_int(g.y) * CP + cc];
-        val[u] = (c == 0) ? g.x : t4[jj].w * gv;
+    for (int u = 0; u < UB; ++u) {                // the dependent G loads of a batch go out together
+      const int jj = min(j0 + u, j_hi - 1);
+      const float2 g = t2[jj];
+      const float gv = Gcl[(long) __float_as_int(g.y) * CP + cc];
+      val[u] = (c == 0) ? g.x : t4[jj].w * gv;
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (j0 + u >= j_hi) continue;
+      const float4 e = t4[j0 + u];
+      const float flx = floorf(e.x), fly = floorf(e.y), flz = floorf(e.z);
+      const int ix0 = (int) flx, iy0 = (int) fly, iz0 = (int) flz;
+      if (ix0 != rx || iy0 != ry || iz0 != rz) {  // group-uniform
+        flush();
+        rx = ix0; ry = iy0; rz = iz0;
       }
+      const float wx1 = e.x - flx, wx0 = (flx + 1.0f) - e.x;
+      const float wy1 = e.y - fly, wy0 = (fly + 1.0f) - e.y;
+      const float wz1 = e.z - flz, wz0 = (flz + 1.0f) - e.z;
 #pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        const int j = j0 + u * NG;
-        if (j >= n_tile || c >= nch) continue;
-        const float4 e = t4[j];
-        const float flx = floorf(e.x), fly = floorf(e.y), flz = floorf(e.z);
-        const int ix0 = (int) flx, iy0 = (int) fly, iz0 = (int) flz;
-        const float wx1 = e.x - flx, wx0 = (flx + 1.0f) - e.x;
-        const float wy1 = e.y - fly, wy0 = (fly + 1.0f) - e.y;
-        const float wz1 = e.z - flz, wz0 = (flz + 1.0f) - e.z;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int ix = ix0 + (k & 1), iy = iy0 + ((k >> 1) & 1), iz = iz0 + (k >> 2);
-          if (ix < x0 || ix > x1 || iy < y0 || iy > y1 || iz < z0 || iz > z1) continue;   // group-uniform
-          const float wt = ((k & 1) ? wx1 : wx0) * ((k & 2) ? wy1 : wy0) * ((k & 4) ? wz1 : wz0);
-          if (!(dbg & 1)) atomicAdd(acc + (((iz - z0) * KBY + (iy - y0)) * KBX + (ix - x0)) * STRIDE + c, wt * val[u]);
-          else if (wt * val[u] == 12345.f) acc[0] = 1.f;
-        }
-      }
+      for (int k = 0; k < 8; ++k)
+        run[k] = __builtin_fmaf(((k & 1) ? wx1 : wx0) * ((k & 2) ? wy1 : wy0) * ((k & 4) ? wz1 : wz0),
+                                val[u], run[k]);
     }
   }
+  flush();
   __syncthreads();
+  const bool sole = n_all <= kChunk;              // this work item owns the whole brick
   const long V = (long) P.Z * P.Y * P.X;
   for (int e = tid; e < nch * KNV; e += kOwnThreadsCam) {
     const int ch = e / KNV, lv = e % KNV;
@@ -192,9 +210,11 @@ cam_bwd_own_kernel(RenderParams P, BrickGrid G, const int* __restrict__ cnt,
     if (x > x1 || y > y1 || z > z1) continue;
     const long vox = ((long) z * P.Y + y) * P.X + x;
     const float v = acc[lv * STRIDE + ch];
-    if (ch == 0) gdens[(long) b * V + vox] = v;
-    else if (ch <= P.K) gsem[((long) b * P.K + (ch - 1)) * V + vox] = v;
-    else grgb[((long) b * 3 + (ch - 1 - P.K)) * V + vox] = v;
+    float* dst = (ch == 0) ? gdens + (long) b * V + vox
+                 : (ch <= P.K) ? gsem + ((long) b * P.K + (ch - 1)) * V + vox
+                               : grgb + ((long) b * 3 + (ch - 1 - P.K)) * V + vox;
+    if (sole) *dst = v;
+    else if (v != 0.f) atomicAdd(dst, v);
   }
 }
 
@@ -212,10 +232,13 @@ static long entry_cap(const VampRenderDesc* d) {
   return c > 0x7fffffffL ? 0x7fffffffL : c;
 }
 
+static long max_work(const VampRenderDesc* d) { return n_bricks(d) + entry_cap(d) / kChunk + 1; }
+
 size_t cam_bwd_bin_bytes(const VampRenderDesc* d) {
   return align_up((size_t) (3 * n_bricks(d) + 4) * sizeof(int), 256) +
          align_up((size_t) entry_cap(d) * sizeof(float4), 256) +
-         align_up((size_t) entry_cap(d) * sizeof(float2), 256);
+         align_up((size_t) entry_cap(d) * sizeof(float2), 256) +
+         align_up((size_t) 2 * max_work(d) * sizeof(int), 256);
 }
 
 int launch_cam_bwd_bin(const VampRenderDesc* d, const RenderParams& P, const float* FX,
@@ -232,6 +255,9 @@ int launch_cam_bwd_bin(const VampRenderDesc* d, const RenderParams& P, const flo
   float4* E4 = reinterpret_cast<float4*>(p);
   p += align_up((size_t) entry_cap(d) * sizeof(float4), 256);
   float2* E2 = reinterpret_cast<float2*>(p);
+  p += align_up((size_t) entry_cap(d) * sizeof(float2), 256);
+  int* work = reinterpret_cast<int*>(p);
+  int* nwork = total + 1;
   const int cap = (int) entry_cap(d);
   *total_out = total;
   *cap_out = cap;
@@ -247,9 +273,22 @@ int launch_cam_bwd_bin(const VampRenderDesc* d, const RenderParams& P, const flo
   VAMP_TIMED(kProfCamBwdFill, s, (cam_bwd_bin_kernel<true><<<grid, 256, 0, s>>>(
       P, G, FX, FY, FZ, Wbuf, G0buf, cnt, off, fill, E4, E2, total, cap)));
   if (int e = check_launch("cam_bwd_bin_kernel<fill>")) return e;
+  if (int e = launch_build_worklist(cnt, (int) nb, kChunk, work, nwork, s)) return e;
+  {
+    // bricks split over several work items accumulate with float atomics: pre-zero the outputs
+    const size_t V = (size_t) d->B * d->Z * d->Y * d->X * sizeof(float);
+    ProfScope sc;
+    prof_begin(kProfMemset, s, &sc);
+    const bool ok = hipMemsetAsync(gdens, 0, V, s) == hipSuccess &&
+                    hipMemsetAsync(gsem, 0, V * d->K, s) == hipSuccess &&
+                    hipMemsetAsync(grgb, 0, V * 3, s) == hipSuccess;
+    prof_end(s, &sc);
+    if (!ok) return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
+  }
+  const unsigned ogrid = (unsigned) max_work(d);
 #define VAMP_OWN(CP4)                                                                            \
-  VAMP_TIMED(kProfCamBwdOwn, s, (cam_bwd_own_kernel<CP4><<<(unsigned) nb, kOwnThreadsCam, 0, s>>>( \
-      P, G, cnt, off, E4, E2, Gcl, gdens, gsem, grgb, total, cap, getenv("VAMP_DBG") ? atoi(getenv("VAMP_DBG")) : 0)))
+  VAMP_TIMED(kProfCamBwdOwn, s, (cam_bwd_own_kernel<CP4><<<ogrid, kOwnThreadsCam, 0, s>>>(       \
+      P, G, cnt, off, work, nwork, E4, E2, Gcl, gdens, gsem, grgb, total, cap)))
   if (P.CP == 12) VAMP_OWN(3); else if (P.CP == 24) VAMP_OWN(6); else VAMP_OWN(8);
 #undef VAMP_OWN
   return check_launch("cam_bwd_own_kernel");

@@ -437,13 +437,15 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
 #undef VAMP_RAY
   if (int e = check_launch("cam_bwd_ray_kernel")) return e;
 
-  // 2. scatter stage.  Default: bin the records into per-brick lists and let one workgroup own
-  //    each brick (render_bwd_bin.hip).  The per-voxel gather below runs only if the lists
-  //    overflow the workspace (device-side decision) or when forced with VAMP_CAM_BWD=gather.
+  // 2. scatter stage: the per-voxel gather below, or (VAMP_CAM_BWD=bin) the records binned into
+  //    per-brick lists with one workgroup owning each brick (render_bwd_bin.hip), in which case
+  //    the gather runs only if the lists overflow the workspace (device-side decision).
   const int* total = nullptr;
   int cap = 0;
   const char* force = getenv("VAMP_CAM_BWD");
-  const bool gather_only = force && force[0] == 'g';
+  // measured at cfg-B (profiles/): gather 0.77 ms vs count+fill+own 0.97 ms -> gather is the default,
+  // the bin-then-own path is selected with VAMP_CAM_BWD=bin
+  const bool gather_only = !(force && force[0] == 'b');
   if (!gather_only)
     if (int e = launch_cam_bwd_bin(d, P, FX, FY, FZ, Wbuf, G0buf, Gcl, gdens, gsem, grgb,
                                    bin_scratch, &total, &cap, s))

@@ -131,6 +131,48 @@ exclusive_scan_kernel(const int* __restrict__ cnt, int* __restrict__ off, int* _
   if (tid == 0) *total = carry;
 }
 
+// Work list for the "own" kernels: a bin with cnt entries becomes max(1, ceil(cnt / chunk)) work
+// items (bin, chunk index), so that one very long list (near-field bricks, horizon tiles) is
+// spread over several workgroups.  work[2*k] = bin, work[2*k+1] = chunk; *nwork = item count.
+__global__ void __launch_bounds__(1024)
+build_worklist_kernel(const int* __restrict__ cnt, int n, int chunk, int* __restrict__ work,
+                      int* __restrict__ nwork) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    const int k = i < n ? max(1, (cnt[i] + chunk - 1) / chunk) : 0;
+    int incl = k;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int q = 0; q < wv; ++q) wbase += wsum[q];
+    const int c0 = carry;
+    const int first = c0 + wbase + incl - k;
+    for (int j = 0; j < k; ++j) {
+      work[2 * (first + j)] = i;
+      work[2 * (first + j) + 1] = j;
+    }
+    __syncthreads();
+    if (tid == 1023) carry = c0 + wbase + incl;
+    __syncthreads();
+  }
+  if (tid == 0) *nwork = carry;
+}
+
+int launch_build_worklist(const int* cnt, int n, int chunk, int* work, int* nwork, hipStream_t s) {
+  VAMP_TIMED(kProfAux, s, (build_worklist_kernel<<<1, 1024, 0, s>>>(cnt, n, chunk, work, nwork)));
+  return check_launch("build_worklist_kernel");
+}
+
 int launch_exclusive_scan(const int* cnt, int* off, int* fill, int n, int* total, hipStream_t s) {
   VAMP_TIMED(kProfAux, s, (exclusive_scan_kernel<<<1, 1024, 0, s>>>(cnt, off, fill, n, total)));
   return check_launch("exclusive_scan_kernel");
