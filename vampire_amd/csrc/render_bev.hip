@@ -380,88 +380,64 @@ bev_gather_generic_kernel(RenderParams P, const float* __restrict__ oxs,
 
 constexpr int kPer = 4;                // channels per thread of bev_gather
 
+// Per-axis hit tables, built once per call: for every voxel index along an axis the (<= kMaxT)
+// lattice samples whose taps include it, and their weights.  Layout: tab[(slot * n + index)] for
+// slot in [0, kMaxT): k as int bits in tk, weight in tw; count in tn.  overflow[0] is set when some
+// voxel has more than kMaxT hits (then the generic kernel must run).
 __global__ void __launch_bounds__(256)
-bev_gather_kernel(RenderParams P, const float* __restrict__ oxs, const float* __restrict__ oys,
-                  const float* __restrict__ ozs, const float* __restrict__ g_brgb,
-                  const float* __restrict__ g_bseg, const float* __restrict__ g_vo,
-                  const float* __restrict__ Wb, const float* __restrict__ DS0,
-                  float* __restrict__ gdens, float* __restrict__ gsem, float* __restrict__ grgb,
-                  float* __restrict__ gbase, int z_lo, int z_hi) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  const int nz = z_hi - z_lo + 1;
-  // blockIdx.z = ((b * nz) + z) * ngrp + channel group: splitting the channels over
-  // workgroups gives the latency-bound loads enough waves to hide behind
-  const int ngrp = (P.K + 3 + P.C + kPer - 1) / kPer;
-  const int cg = blockIdx.z % ngrp;
-  const int z = z_lo + (blockIdx.z / ngrp) % nz;
-  const int b = blockIdx.z / (ngrp * nz);
-  if (x >= P.X || y >= P.Y) return;
-  const long V = (long) P.Z * P.Y * P.X, OYX = (long) P.oY * P.oX;
-  const int CO = P.C + (P.cat_seg ? P.K : 0);
-  const AxisHits hx = axis_hits(oxs, P.oX, P.lo[0], P.span[0], P.X, x);
-  const AxisHits hy = axis_hits(oys, P.oY, P.lo[1], P.span[1], P.Y, y);
-  const AxisHits hz = axis_hits(ozs, P.oZ, P.lo[2], P.span[2], P.Z, z);
-  if (hx.n == 0 || hy.n == 0 || hz.n == 0) return;
-  const long vox = ((long) z * P.Y + y) * P.X + x;
+bev_axis_table_kernel(RenderParams P, const float* __restrict__ oxs, const float* __restrict__ oys,
+                      const float* __restrict__ ozs, int* __restrict__ tk, float* __restrict__ tw,
+                      int* __restrict__ tn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int NX = P.X, NY = P.Y, NZ = P.Z;
+  if (i >= NX + NY + NZ) return;
+  AxisHits h;
+  int base, n;
+  if (i < NX) { h = axis_hits(oxs, P.oX, P.lo[0], P.span[0], P.X, i); base = 0; n = i; }
+  else if (i < NX + NY) { h = axis_hits(oys, P.oY, P.lo[1], P.span[1], P.Y, i - NX); base = NX; n = i - NX; }
+  else { h = axis_hits(ozs, P.oZ, P.lo[2], P.span[2], P.Z, i - NX - NY); base = NX + NY; n = i - NX - NY; }
+  const int tot = NX + NY + NZ;
+#pragma unroll
+  for (int sl = 0; sl < kMaxT; ++sl) {
+    tk[sl * tot + base + n] = h.k[sl];
+    tw[sl * tot + base + n] = h.w[sl];
+  }
+  tn[base + n] = h.n;
+}
 
-  // density channel and the compositing weights of the hit samples
-  float s_dens = 0.f;
-  if (cg == 0)
+// USE_COL: the channel's sample gradient is Wb * gcol (composited sem / rgb); USE_VO: the
+// voxel_output gradient passes straight through (base channels, and sem when cat_seg)
+template <bool USE_COL, bool USE_VO>
+__device__ __forceinline__ void bev_gather_channels(
+    const RenderParams& P, int b, long OYX, const AxisHits& hx, const AxisHits& hy, const AxisHits& hz,
+    const float* __restrict__ Wb, const float* const* gcol, const long* gcol_base,
+    const float* __restrict__ g_vo, const long* vo_base, const bool* on, float* sum) {
+  // first two hits per axis, no bounds branches (unused slots: k = 0, w = 0): all loads of all
+  // kPer channels are independent and in flight together
+  float wgt[8], wW[8];
+  long cc8[8];
+  int j8[8];
 #pragma unroll
-  for (int a = 0; a < kMaxT; ++a)
-#pragma unroll
-    for (int c2 = 0; c2 < kMaxT; ++c2)
-#pragma unroll
-      for (int e = 0; e < kMaxT; ++e) {
-        const long sc = ((long) b * P.oZ + (P.oZ - 1 - hz.k[a])) * OYX + (long) hy.k[c2] * P.oX + hx.k[e];
-        s_dens = __builtin_fmaf(hz.w[a] * hy.w[c2] * hx.w[e], DS0[sc], s_dens);
-      }
-  if (cg == 0) gdens[(long) b * V + vox] += s_dens;
-
-  // kPer channels per thread, fully unrolled: the tap loads of all of them are in flight together
-  // and the read-modify-writes come last, so a thread pays ~2 memory round trips, not 2 per channel
-  const int nch = P.K + 3 + P.C;           // [0,K) sem, [K,K+3) rgb, [K+3, ..) base
-  float sum[kPer];
-  float* outp[kPer];
+  for (int t = 0; t < 8; ++t) {
+    const int a = t >> 2, c2 = (t >> 1) & 1, e = t & 1;
+    j8[t] = P.oZ - 1 - hz.k[a];
+    cc8[t] = (long) hy.k[c2] * P.oX + hx.k[e];
+    wgt[t] = hz.w[a] * hy.w[c2] * hx.w[e];
+    wW[t] = USE_COL ? wgt[t] * Wb[((long) b * P.oZ + j8[t]) * OYX + cc8[t]] : 0.f;
+  }
 #pragma unroll
   for (int u = 0; u < kPer; ++u) {
-    const int ch = cg * kPer + u;
-    sum[u] = 0.f;
-    outp[u] = nullptr;
-    if (ch >= nch) continue;
-    const float* gcol = nullptr;
-    long gcol_base = 0, vo_base = -1;
-    if (ch < P.K) {
-      outp[u] = gsem + ((long) b * P.K + ch) * V;
-      gcol = g_bseg; gcol_base = ((long) b * P.K + ch) * OYX;
-      if (P.cat_seg) vo_base = ((long) b * CO + P.C + ch) * P.oZ * OYX;
-    } else if (ch < P.K + 3) {
-      outp[u] = grgb + ((long) b * 3 + (ch - P.K)) * V;
-      gcol = g_brgb; gcol_base = ((long) b * 3 + (ch - P.K)) * OYX;
-    } else {
-      outp[u] = gbase + ((long) b * P.C + (ch - P.K - 3)) * V;
-      vo_base = ((long) b * CO + (ch - P.K - 3)) * P.oZ * OYX;
+    if (!on[u]) continue;                               // workgroup-uniform
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (USE_COL) sum[u] = __builtin_fmaf(wW[t], gcol[u][gcol_base[u] + cc8[t]], sum[u]);
+      if (USE_VO) sum[u] = __builtin_fmaf(wgt[t], g_vo[vo_base[u] + (long) j8[t] * OYX + cc8[t]], sum[u]);
     }
-    const bool use_col = gcol != nullptr, use_vo = (vo_base >= 0) && g_vo;
-    if (!use_col && !use_vo) { outp[u] = nullptr; continue; }
-    // the first two hits per axis (all there are, except when a lattice point sits exactly on
-    // the edge of the support) are loaded without bounds branches: unused slots carry k = 0,
-    // w = 0, so the 8 x 2 loads are legal, independent and in flight together
+  }
+  if (hz.n > 2 || hy.n > 2 || hx.n > 2) {             // rare third hit on some axis
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int j = P.oZ - 1 - hz.k[a];
-          const long cc = (long) hy.k[c2] * P.oX + hx.k[e];
-          float dsv = 0.f;
-          if (use_col) dsv = Wb[((long) b * P.oZ + j) * OYX + cc] * gcol[gcol_base + cc];
-          if (use_vo) dsv += g_vo[vo_base + (long) j * OYX + cc];
-          sum[u] = __builtin_fmaf(hz.w[a] * hy.w[c2] * hx.w[e], dsv, sum[u]);
-        }
-    if (hz.n > 2 || hy.n > 2 || hx.n > 2) {           // rare third hit on some axis
+    for (int u = 0; u < kPer; ++u) {
+      if (!on[u]) continue;
 #pragma unroll
       for (int a = 0; a < kMaxT; ++a)
 #pragma unroll
@@ -473,19 +449,106 @@ bev_gather_kernel(RenderParams P, const float* __restrict__ oxs, const float* __
             const int j = P.oZ - 1 - hz.k[a];
             const long cc = (long) hy.k[c2] * P.oX + hx.k[e];
             float dsv = 0.f;
-            if (use_col) dsv = Wb[((long) b * P.oZ + j) * OYX + cc] * gcol[gcol_base + cc];
-            if (use_vo) dsv += g_vo[vo_base + (long) j * OYX + cc];
+            if (USE_COL) dsv = Wb[((long) b * P.oZ + j) * OYX + cc] * gcol[u][gcol_base[u] + cc];
+            if (USE_VO) dsv += g_vo[vo_base[u] + (long) j * OYX + cc];
             sum[u] = __builtin_fmaf(hz.w[a] * hy.w[c2] * hx.w[e], dsv, sum[u]);
           }
     }
   }
+}
+
+// Channel groups never mix kinds: [semantic groups | rgb group | base groups], kPer channels each.
+__global__ void __launch_bounds__(256)
+bev_gather_kernel(RenderParams P, const int* __restrict__ tk, const float* __restrict__ tw,
+                  const int* __restrict__ tn, const float* __restrict__ g_brgb,
+                  const float* __restrict__ g_bseg, const float* __restrict__ g_vo,
+                  const float* __restrict__ Wb, const float* __restrict__ DS0,
+                  float* __restrict__ gdens, float* __restrict__ gsem, float* __restrict__ grgb,
+                  float* __restrict__ gbase, int z_lo, int z_hi) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int nz = z_hi - z_lo + 1;
+  const int g_sem = (P.K + kPer - 1) / kPer, g_rgb = 1, g_base = (P.C + kPer - 1) / kPer;
+  const int ngrp = g_sem + g_rgb + g_base;
+  const int cg = blockIdx.z % ngrp;
+  const int z = z_lo + (blockIdx.z / ngrp) % nz;
+  const int b = blockIdx.z / (ngrp * nz);
+  if (x >= P.X || y >= P.Y) return;
+  const long V = (long) P.Z * P.Y * P.X, OYX = (long) P.oY * P.oX;
+  const int CO = P.C + (P.cat_seg ? P.K : 0);
+  const int tot = P.X + P.Y + P.Z;
+  AxisHits hx, hy, hz;
+  hx.n = tn[x]; hy.n = tn[P.X + y]; hz.n = tn[P.X + P.Y + z];
+  if (hx.n == 0 || hy.n == 0 || hz.n == 0) return;
+#pragma unroll
+  for (int sl = 0; sl < kMaxT; ++sl) {
+    hx.k[sl] = tk[sl * tot + x]; hx.w[sl] = tw[sl * tot + x];
+    hy.k[sl] = tk[sl * tot + P.X + y]; hy.w[sl] = tw[sl * tot + P.X + y];
+    hz.k[sl] = tk[sl * tot + P.X + P.Y + z]; hz.w[sl] = tw[sl * tot + P.X + P.Y + z];
+  }
+  const long vox = ((long) z * P.Y + y) * P.X + x;
+
+  if (cg == 0) {                                       // the density channel rides with group 0
+    float s_dens = 0.f;
+#pragma unroll
+    for (int a = 0; a < kMaxT; ++a)
+#pragma unroll
+      for (int c2 = 0; c2 < kMaxT; ++c2)
+#pragma unroll
+        for (int e = 0; e < kMaxT; ++e) {
+          const long sc = ((long) b * P.oZ + (P.oZ - 1 - hz.k[a])) * OYX + (long) hy.k[c2] * P.oX + hx.k[e];
+          s_dens = __builtin_fmaf(hz.w[a] * hy.w[c2] * hx.w[e], DS0[sc], s_dens);
+        }
+    gdens[(long) b * V + vox] += s_dens;
+  }
+
+  float sum[kPer];
+  float* outp[kPer];
+  const float* gcol[kPer];
+  long gcol_base[kPer], vo_base[kPer];
+  bool on[kPer];
+  int kind;                                            // 0 sem, 1 rgb, 2 base
+  int c_first, c_count;
+  if (cg < g_sem) { kind = 0; c_first = cg * kPer; c_count = P.K; }
+  else if (cg < g_sem + g_rgb) { kind = 1; c_first = 0; c_count = 3; }
+  else { kind = 2; c_first = (cg - g_sem - g_rgb) * kPer; c_count = P.C; }
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int ch = c_first + u;
+    on[u] = ch < c_count;
+    const int cs = on[u] ? ch : 0;
+    sum[u] = 0.f;
+    if (kind == 0) {
+      outp[u] = gsem + ((long) b * P.K + cs) * V;
+      gcol[u] = g_bseg; gcol_base[u] = ((long) b * P.K + cs) * OYX;
+      vo_base[u] = ((long) b * CO + P.C + cs) * P.oZ * OYX;
+    } else if (kind == 1) {
+      outp[u] = grgb + ((long) b * 3 + cs) * V;
+      gcol[u] = g_brgb; gcol_base[u] = ((long) b * 3 + cs) * OYX;
+      vo_base[u] = 0;
+    } else {
+      outp[u] = gbase + ((long) b * P.C + cs) * V;
+      gcol[u] = nullptr; gcol_base[u] = 0;
+      vo_base[u] = ((long) b * CO + cs) * P.oZ * OYX;
+    }
+  }
+  const bool has_col = (kind == 0 && g_bseg) || (kind == 1 && g_brgb);
+  const bool has_vo = g_vo && (kind == 2 || (kind == 0 && P.cat_seg));
+  if (!has_col && !has_vo) return;
+  if (has_col && has_vo)
+    bev_gather_channels<true, true>(P, b, OYX, hx, hy, hz, Wb, gcol, gcol_base, g_vo, vo_base, on, sum);
+  else if (has_col)
+    bev_gather_channels<true, false>(P, b, OYX, hx, hy, hz, Wb, gcol, gcol_base, g_vo, vo_base, on, sum);
+  else
+    bev_gather_channels<false, true>(P, b, OYX, hx, hy, hz, Wb, gcol, gcol_base, g_vo, vo_base, on, sum);
 #pragma unroll
   for (int u = 0; u < kPer; ++u)
-    if (outp[u]) outp[u][vox] += sum[u];
+    if (on[u]) outp[u][vox] += sum[u];
 }
 
 static size_t bev_ws_bytes(const VampRenderDesc* d) {
-  return 3 * align_up((size_t) d->B * d->oZ * d->oY * d->oX * sizeof(float), 256);
+  return 3 * align_up((size_t) d->B * d->oZ * d->oY * d->oX * sizeof(float), 256) +
+         align_up((size_t) (2 * kMaxT + 1) * (d->X + d->Y + d->Z) * sizeof(float), 256);
 }
 
 }  // namespace vamp
@@ -551,7 +614,11 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
     return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) need);
   const RenderParams P = to_params(d);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const size_t one = need / 3;
+  const size_t one = align_up((size_t) d->B * d->oZ * d->oY * d->oX * sizeof(float), 256);
+  const int tot_ax = d->X + d->Y + d->Z;
+  int* tk = reinterpret_cast<int*>(static_cast<char*>(workspace) + 3 * one);
+  float* tw = reinterpret_cast<float*>(tk + (size_t) kMaxT * tot_ax);
+  int* tn = reinterpret_cast<int*>(tw + (size_t) kMaxT * tot_ax);
   float* Q = static_cast<float*>(workspace);
   float* Wb = reinterpret_cast<float*>(static_cast<char*>(workspace) + one);
   float* DS0 = reinterpret_cast<float*>(static_cast<char*>(workspace) + 2 * one);
@@ -591,11 +658,15 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
     const float e = d->span[a] / (float) (nvox[a] - 1);
     if (!(d->det_step[a] > 0.f) || (int) floorf(2.0f * e / d->det_step[a]) + 1 > kMaxT) fits = false;
   }
-  dim3 ggf(gg.x, gg.y, gg.z * ((d->K + 3 + d->C + kPer - 1) / kPer));
-  if (fits)
+  const int ngrp = (d->K + kPer - 1) / kPer + 1 + (d->C + kPer - 1) / kPer;
+  dim3 ggf(gg.x, gg.y, gg.z * ngrp);
+  if (fits) {
+    VAMP_TIMED(kProfAux, s, (bev_axis_table_kernel<<<(tot_ax + 255) / 256, 256, 0, s>>>(P, oxs, oys, ozs, tk, tw, tn)));
+    if (int e = check_launch("bev_axis_table_kernel")) return e;
     VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_kernel<<<ggf, 256, 0, s>>>(
-        P, oxs, oys, ozs, g_bev_rgb, g_bev_seg, g_voxel_output, Wb, DS0, grad_density_feature,
+        P, tk, tw, tn, g_bev_rgb, g_bev_seg, g_voxel_output, Wb, DS0, grad_density_feature,
         grad_semantic, grad_rgb, grad_base, z_lo, z_hi)));
+  }
   else
     VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_generic_kernel<<<gg, 256, 0, s>>>(
         P, oxs, oys, ozs, g_bev_rgb, g_bev_seg, g_voxel_output, Wb, DS0, grad_density_feature,
