@@ -128,7 +128,7 @@ cam_bwd_own_kernel(RenderParams P, BrickGrid G, const int* __restrict__ cnt,
                    const int* __restrict__ nwork, const float4* __restrict__ E4,
                    const float2* __restrict__ E2, const float* __restrict__ Gcl,
                    float* __restrict__ gdens, float* __restrict__ gsem, float* __restrict__ grgb,
-                   const int* __restrict__ total, int cap) {
+                   const int* __restrict__ total, int cap, int dbg) {
   if (*total > cap || (int) blockIdx.x >= *nwork) return;
   constexpr int CP = CP4 * 4;
   constexpr int STRIDE = CP + 1;                 // odd: lane c of any voxel -> its own bank
@@ -160,12 +160,19 @@ cam_bwd_own_kernel(RenderParams P, BrickGrid G, const int* __restrict__ cnt,
 #pragma unroll
   for (int k = 0; k < 8; ++k) run[k] = 0.f;
   int rx = -0x40000000, ry = 0, rz = 0;          // tap base of the open run
+  // flush the open run: which of the two taps per axis fall inside the brick is decided once,
+  // the eight LDS addresses are the base plus constant offsets
   auto flush = [&]() {
+    const bool ax0 = rx >= x0 && rx <= x1, ax1 = rx + 1 >= x0 && rx + 1 <= x1;
+    const bool ay0 = ry >= y0 && ry <= y1, ay1 = ry + 1 >= y0 && ry + 1 <= y1;
+    const bool az0 = rz >= z0 && rz <= z1, az1 = rz + 1 >= z0 && rz + 1 <= z1;
+    float* base = acc + (((rz - z0) * KBY + (ry - y0)) * KBX + (rx - x0)) * STRIDE + c;
+    const bool lane_on = c < nch;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int ix = rx + (k & 1), iy = ry + ((k >> 1) & 1), iz = rz + (k >> 2);
-      if (ix >= x0 && ix <= x1 && iy >= y0 && iy <= y1 && iz >= z0 && iz <= z1 && c < nch && run[k] != 0.f)
-        atomicAdd(acc + (((iz - z0) * KBY + (iy - y0)) * KBX + (ix - x0)) * STRIDE + c, run[k]);
+      const bool in = ((k & 1) ? ax1 : ax0) && ((k & 2) ? ay1 : ay0) && ((k & 4) ? az1 : az0);
+      if (in && lane_on && run[k] != 0.f && !(dbg & 1))
+        atomicAdd(base + ((k & 1) + ((k >> 1) & 1) * KBX + (k >> 2) * KBX * KBY) * STRIDE, run[k]);
       run[k] = 0.f;
     }
   };
@@ -177,7 +184,7 @@ cam_bwd_own_kernel(RenderParams P, BrickGrid G, const int* __restrict__ cnt,
     for (int u = 0; u < UB; ++u) {                // the dependent G loads of a batch go out together
       const int jj = min(j0 + u, j_hi - 1);
       const float2 g = t2[jj];
-      const float gv = Gcl[(long) __float_as_int(g.y) * CP + cc];
+      const float gv = (dbg & 4) ? 1.f : Gcl[(long) __float_as_int(g.y) * CP + cc];
       val[u] = (c == 0) ? g.x : t4[jj].w * gv;
     }
 #pragma unroll
@@ -213,7 +220,8 @@ cam_bwd_own_kernel(RenderParams P, BrickGrid G, const int* __restrict__ cnt,
     float* dst = (ch == 0) ? gdens + (long) b * V + vox
                  : (ch <= P.K) ? gsem + ((long) b * P.K + (ch - 1)) * V + vox
                                : grgb + ((long) b * 3 + (ch - 1 - P.K)) * V + vox;
-    if (sole) *dst = v;
+    if (dbg & 2) { if (v == 12345.f) *dst = v; }
+    else if (sole) *dst = v;
     else if (v != 0.f) atomicAdd(dst, v);
   }
 }
@@ -288,7 +296,7 @@ int launch_cam_bwd_bin(const VampRenderDesc* d, const RenderParams& P, const flo
   const unsigned ogrid = (unsigned) max_work(d);
 #define VAMP_OWN(CP4)                                                                            \
   VAMP_TIMED(kProfCamBwdOwn, s, (cam_bwd_own_kernel<CP4><<<ogrid, kOwnThreadsCam, 0, s>>>(       \
-      P, G, cnt, off, work, nwork, E4, E2, Gcl, gdens, gsem, grgb, total, cap)))
+      P, G, cnt, off, work, nwork, E4, E2, Gcl, gdens, gsem, grgb, total, cap, getenv("VAMP_DBG") ? atoi(getenv("VAMP_DBG")) : 0)))
   if (P.CP == 12) VAMP_OWN(3); else if (P.CP == 24) VAMP_OWN(6); else VAMP_OWN(8);
 #undef VAMP_OWN
   return check_launch("cam_bwd_own_kernel");
