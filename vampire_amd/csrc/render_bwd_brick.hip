@@ -39,7 +39,10 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
   float* l_dl = lds + (long) L * 256;
   float* l_q = lds + (long) 2 * L * 256;
 
-  const RayId id = decode_ray<LPR>(P);
+  // wave-per-depth-chunk mapping (render_common.hpp): lanes = the 64 rays of an 8x8 tile
+  static_assert(LPR == 4, "the four waves of the workgroup are the four depth chunks");
+  __shared__ float xm[2 * 4 * 64];
+  const RayId id = decode_ray_wps(P);
   const bool live = id.live;
   const int w = id.w, h = id.h, sub = id.sub, b = id.b;
   const long bn = id.bn;
@@ -115,9 +118,20 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
 
   // ---- merge the LPR chunks of the ray ----
   float scale = 1.f, suffix = 0.f;
-  if (LPR > 1) {
-    scale = expf(-ray_excl_prefix<LPR>(cum, sub));
-    suffix = ray_excl_suffix<LPR>(scale * A, sub);      // sum_{m > sub} scale_m A_m
+  {
+    const int lane = tid & 63;
+    xm[sub * 64 + lane] = cum;
+    __syncthreads();
+    float excl = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < sub) excl += xm[k * 64 + lane];
+    scale = expf(-excl);
+    xm[(4 + sub) * 64 + lane] = scale * A;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k > sub) suffix += xm[(4 + k) * 64 + lane];     // sum_{m > sub} scale_m A_m
   }
 
   // ---- second loop over the LDS copies: emit w_i and dL/ds_i[0] ----

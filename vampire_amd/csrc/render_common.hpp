@@ -91,6 +91,31 @@ __device__ __forceinline__ RayId decode_ray(const RenderParams& P) {
   return id;
 }
 
+// Alternative mapping ("wave per depth chunk"): the 64 lanes of a wave are the 64 rays of the
+// 8 x 8 tile and the wave index is the depth chunk.  All lanes of a load instruction then sit at
+// the same depth on neighbouring rays, so lanes that need the same tap are merged by the texture
+// addresser (one fetch), which matters in the near and mid field where many rays cross a voxel.
+// The chunks are merged through LDS instead of shuffles.  Needs 4 waves (LPR = 4).
+__device__ __forceinline__ RayId decode_ray_wps(const RenderParams& P) {
+  const int tiles_w = (P.fW + 7) / 8, tiles_h = (P.fH + 7) / 8;
+  const long tiles = (long) P.B * P.N * tiles_h * tiles_w;
+  const long per_xcd = (tiles + 7) / 8;
+  const long t = (long) (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  const int r = threadIdx.x & 63;
+  RayId id;
+  id.sub = threadIdx.x >> 6;
+  const long tc = t < tiles ? t : tiles - 1;
+  id.bn = tc / (tiles_h * tiles_w);
+  const int tt = (int) (tc % (tiles_h * tiles_w));
+  id.h = (tt / tiles_w) * 8 + r / 8;
+  id.w = (tt % tiles_w) * 8 + r % 8;
+  id.live = t < tiles && id.h < P.fH && id.w < P.fW;
+  if (id.h >= P.fH) id.h = P.fH - 1;
+  if (id.w >= P.fW) id.w = P.fW - 1;
+  id.b = (int) (id.bn / P.N);
+  return id;
+}
+
 // exclusive prefix sum over the LPR lanes of a ray ([sub][ray] lane layout)
 template <int LPR>
 __device__ __forceinline__ float ray_excl_prefix(float v, int sub) {

@@ -39,7 +39,7 @@ pack_volume_kernel(RenderParams P, const T* __restrict__ dens, const T* __restri
 // ---------------------------------------------------------------------------
 // camera branch forward
 // ---------------------------------------------------------------------------
-template <int LPR, int CP4>
+template <int LPR, int CP4, bool WPS>
 __global__ void __launch_bounds__(256)
 render_cam_fwd_kernel(RenderParams P, const float* __restrict__ geom, const float* __restrict__ mats,
                       const float* __restrict__ us, const float* __restrict__ vs,
@@ -48,7 +48,9 @@ render_cam_fwd_kernel(RenderParams P, const float* __restrict__ geom, const floa
                       float* __restrict__ rgb_out, float* __restrict__ seg_out,
                       float* __restrict__ depth_out) {
   constexpr int CP = CP4 * 4;
-  const RayId id = decode_ray<LPR>(P);
+  static_assert(!WPS || LPR == 4, "wave-per-chunk mapping uses the 4 waves of the workgroup");
+  __shared__ float xmerge[WPS ? 4 * (CP + 2) * 64 : 1];
+  const RayId id = WPS ? decode_ray_wps(P) : decode_ray<LPR>(P);
   const bool live = id.live;
   const int w = id.w, h = id.h, sub = id.sub, b = id.b;
   const long bn = id.bn;
@@ -106,7 +108,35 @@ render_cam_fwd_kernel(RenderParams P, const float* __restrict__ geom, const floa
     px = qx; py = qy; pz = qz;
   }
 
-  if (LPR > 1) {
+  if (WPS) {
+    // merge the four depth chunks (= waves) of each ray through LDS
+    const int lane = threadIdx.x & 63;
+    float* xc = xmerge;                                // [4][64] optical depth of each chunk
+    float* xa = xmerge + 4 * 64;                       // [4][CP + 1][64] scaled partial sums
+    xc[sub * 64 + lane] = cum;
+    __syncthreads();
+    float excl = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < sub) excl += xc[k * 64 + lane];
+    const float scale = expf(-excl);                   // transmittance in front of this chunk
+    xa[(sub * (CP + 1) + CP) * 64 + lane] = acc_depth * scale;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) xa[(sub * (CP + 1) + c) * 64 + lane] = acc[c] * scale;
+    __syncthreads();
+    if (sub == 0) {
+      acc_depth = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc_depth += xa[(k * (CP + 1) + CP) * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < CP; ++c) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t += xa[(k * (CP + 1) + c) * 64 + lane];
+        acc[c] = t;
+      }
+    }
+  } else if (LPR > 1) {
     // transmittance of everything in front of this lane's chunk
     const float scale = expf(-ray_excl_prefix<LPR>(cum, sub));
     acc_depth = ray_sum<LPR>(acc_depth * scale);
@@ -234,7 +264,7 @@ int vamp_render_camera_forward(const VampRenderDesc* d, const float* geom, const
   constexpr int LPR = 4;
   const unsigned grid = ray_grid<LPR>(P);
 #define VAMP_CAM(CP4)                                                                        \
-  VAMP_TIMED(kProfCamFwd, s, (render_cam_fwd_kernel<LPR, CP4><<<grid, 256, 0, s>>>(          \
+  VAMP_TIMED(kProfCamFwd, s, (render_cam_fwd_kernel<LPR, CP4, true><<<grid, 256, 0, s>>>(    \
       P, geom, mats, us, vs, ds, mids, beta, packed, rgb_out, seg_out, depth_out)))
   if (P.CP == 12) VAMP_CAM(3); else if (P.CP == 24) VAMP_CAM(6); else VAMP_CAM(8);
 #undef VAMP_CAM
