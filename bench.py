@@ -147,10 +147,13 @@ def main():
     from vampire_amd.step import LiftRenderStep, SyntheticBatch, train_step
 
     cfg = PRESETS[a.cfg]
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; (the modulo only matters for the 2-ranks-on-1-GPU gloo self-test)
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     from vampire_amd import dist as vdist
-    vdist.init("nccl", dev)                                  # "nccl" == RCCL on ROCm
+    # "nccl" == RCCL over xGMI on ROCm; VAMP_DIST_BACKEND=gloo exists for self-tests only
+    vdist.init(os.environ.get("VAMP_DIST_BACKEND", "nccl"), dev)
     dtype = torch.float32 if a.dtype == "f32" else torch.bfloat16
 
     model = LiftRenderStep(cfg, dev)
