@@ -52,6 +52,8 @@ const char* vamp_last_error(void);
  */
 int vamp_profile_enable(int on);
 int vamp_profile_slots(void);
+/* time only this kernel slot (-1 = all): one event pair per step instead of ~40 */
+int vamp_profile_select(int slot);
 int vamp_profile_read(int slot, const char** name, int* launches, double* total_ms);
 
 /* ------------------------------------------------------------------------- *

@@ -47,6 +47,7 @@ SIGNATURES = {
     "vamp_last_error": (C.c_char_p, []),
     "vamp_profile_enable": (C.c_int, [C.c_int]),
     "vamp_profile_slots": (C.c_int, []),
+    "vamp_profile_select": (C.c_int, [C.c_int]),
     "vamp_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int),
                                     C.POINTER(C.c_double)]),
     "vamp_lift_workspace_bytes": (C.c_size_t, [_LD]),
@@ -105,6 +106,21 @@ def check(code: int, what: str):
 
 def profile_enable(on: bool):
     check(load().vamp_profile_enable(1 if on else 0), "vamp_profile_enable")
+
+
+def profile_select(name=None):
+    """Restrict the event timer to one kernel slot (by name); None = all slots."""
+    lib = load()
+    slot = -1
+    if name is not None:
+        for i in range(lib.vamp_profile_slots()):
+            nm, n, ms = C.c_char_p(), C.c_int(), C.c_double()
+            check(lib.vamp_profile_read(i, C.byref(nm), C.byref(n), C.byref(ms)), "vamp_profile_read")
+            if nm.value.decode() == name:
+                slot = i
+        if slot < 0:
+            raise KeyError(name)
+    check(lib.vamp_profile_select(slot), "vamp_profile_select")
 
 
 def profile_read():

@@ -16,6 +16,7 @@ struct Pair {
 };
 std::mutex g_mu;
 bool g_on = false;
+int g_only = -1;                   // >= 0: time this slot only (keeps the timed region light)
 std::vector<Pair> g_pairs;        // recorded since enable(1)
 std::vector<Pair> g_free;         // recycled events
 const char* g_names[kProfSlots] = {
@@ -30,7 +31,7 @@ bool prof_enabled() { return g_on; }
 
 void prof_begin(int slot, hipStream_t s, ProfScope* sc) {
   sc->idx = -1;
-  if (!g_on) return;
+  if (!g_on || (g_only >= 0 && slot != g_only)) return;
   std::lock_guard<std::mutex> lk(g_mu);
   Pair p;
   if (!g_free.empty()) {
@@ -198,6 +199,13 @@ int vamp_profile_enable(int on) {
 }
 
 int vamp_profile_slots(void) { return kProfSlots; }
+
+int vamp_profile_select(int slot) {
+  if (slot >= kProfSlots) return fail(VAMP_EINVAL, "%s: bad slot", __func__);
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_only = slot < 0 ? -1 : slot;
+  return VAMP_OK;
+}
 
 int vamp_profile_read(int slot, const char** name, int* launches, double* total_ms) {
   if (slot < 0 || slot >= kProfSlots || !name || !launches || !total_ms)
