@@ -29,8 +29,8 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
                    const float* __restrict__ packed, const float* __restrict__ g_rgb,
                    const float* __restrict__ g_seg, const float* __restrict__ g_depth,
                    float* __restrict__ Wbuf, float* __restrict__ G0buf, float* __restrict__ FX,
-                   float* __restrict__ FY, float* __restrict__ FZ, float* __restrict__ Gcl,
-                   float* __restrict__ grad_beta, int L) {
+                   float* __restrict__ FY, float* __restrict__ FZ, int* __restrict__ KEY,
+                   float* __restrict__ Gcl, float* __restrict__ grad_beta, int L) {
   constexpr int CP = CP4 * 4;
   extern __shared__ float lds[];              // [3][L][256]: s0, delta (sign = no-grad flag), q
   __shared__ float red[4];
@@ -112,6 +112,9 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
       FX[sidx] = tp.inside ? tp.fx : nanv;     // NaN: masked sample, matches no voxel
       FY[sidx] = tp.fy;
       FZ[sidx] = tp.fz;
+      // floor taps packed 11/11/10 bits (+1 so that 0 = masked): the gather tests candidates
+      // with one load and integer compares
+      KEY[sidx] = tp.inside ? ((tp.ix0 + 1) | ((tp.iy0 + 1) << 11) | ((tp.iz0 + 1) << 22)) : 0;
     }
     px = qx; py = qy; pz = qz;
   }
@@ -259,9 +262,9 @@ __global__ void __launch_bounds__(256)
 cam_bwd_gather_kernel(RenderParams P, const float* __restrict__ pmats, const float* __restrict__ us,
                       const float* __restrict__ vs, const float* __restrict__ ds,
                       const float* __restrict__ FX, const float* __restrict__ FY,
-                      const float* __restrict__ FZ, const float* __restrict__ Wbuf,
-                      const float* __restrict__ G0buf, const float* __restrict__ Gcl,
-                      const unsigned* __restrict__ cull, float* __restrict__ gdens,
+                      const float* __restrict__ FZ, const int* __restrict__ KEY,
+                      const float* __restrict__ Wbuf, const float* __restrict__ G0buf,
+                      const float* __restrict__ Gcl, const unsigned* __restrict__ cull, float* __restrict__ gdens,
                       float* __restrict__ gsem, float* __restrict__ grgb,
                       const int* __restrict__ total_e, int cap_e) {
   if (total_e && *total_e <= cap_e) return;       // fallback only: the binned lists fit
@@ -327,8 +330,7 @@ cam_bwd_gather_kernel(RenderParams P, const float* __restrict__ pmats, const flo
     constexpr int U = 4;
     for (int base = l; base < count; base += U * GL) {
       long sidx[U];
-      int pw[U], ph[U];
-      float fx[U], fy[U], fz[U];
+      int pw[U], ph[U], key[U];
 #pragma unroll
       for (int q = 0; q < U; ++q) {
         const int idx = base + q * GL;
@@ -342,16 +344,17 @@ cam_bwd_gather_kernel(RenderParams P, const float* __restrict__ pmats, const flo
         pw[q] = w_lo + w; ph[q] = h_lo + h;
         sidx[q] = sbase + ((long) (i_lo + i) * P.fH + ph[q]) * P.fW + pw[q];
         const bool in = idx < count;
-        fx[q] = in ? FX[sidx[q]] : __builtin_nanf("");
-        fy[q] = in ? FY[sidx[q]] : 0.f;
-        fz[q] = in ? FZ[sidx[q]] : 0.f;
+        key[q] = in ? KEY[sidx[q]] : 0;
       }
 #pragma unroll
       for (int q = 0; q < U; ++q) {
-        // NaN fx (masked sample / past the end) fails the first test
-        if (!(fabsf(fx[q] - fix) < 1.0f) || !(fabsf(fy[q] - fiy) < 1.0f) ||
-            !(fabsf(fz[q] - fiz) < 1.0f)) continue;
-        const float wt = tap_weight(fx[q], fix) * tap_weight(fy[q], fiy) * tap_weight(fz[q], fiz);
+        // key 0 = masked sample / past the end; a sample touches this voxel iff each floor tap
+        // is the voxel index or one below it
+        const int kx = (key[q] & 2047) - 1, ky = ((key[q] >> 11) & 2047) - 1, kz = (key[q] >> 22) - 1;
+        if (key[q] == 0 || (unsigned) (ix - kx) > 1u || (unsigned) (iy - ky) > 1u ||
+            (unsigned) (iz - kz) > 1u) continue;
+        const float wt = tap_weight(FX[sidx[q]], fix) * tap_weight(FY[sidx[q]], fiy) *
+                         tap_weight(FZ[sidx[q]], fiz);
         const float Wv = wt * Wbuf[sidx[q]];
         acc[0] = __builtin_fmaf(wt, G0buf[sidx[q]], acc[0]);
         const float4* g4 =
@@ -397,7 +400,7 @@ size_t cam_bwd_v2_bytes(const VampRenderDesc* d) {
   const RenderParams P = to_params(d);
   const size_t samples = (size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW;
   const size_t rays = (size_t) d->B * d->N * d->fH * d->fW;
-  return 5 * align_up(samples * sizeof(float), 256) + align_up(rays * P.CP * sizeof(float), 256) +
+  return 6 * align_up(samples * sizeof(float), 256) + align_up(rays * P.CP * sizeof(float), 256) +
          align_up((size_t) d->B * d->N * 48 * sizeof(float), 256) +
          align_up((size_t) d->B * d->Z * d->Y * ((d->X + VPB - 1) / VPB) * sizeof(unsigned), 256) +
          cam_bwd_bin_bytes(d);
@@ -423,6 +426,7 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
   float* FX = reinterpret_cast<float*>(p); p += align_up(samples * sizeof(float), 256);
   float* FY = reinterpret_cast<float*>(p); p += align_up(samples * sizeof(float), 256);
   float* FZ = reinterpret_cast<float*>(p); p += align_up(samples * sizeof(float), 256);
+  int* KEY = reinterpret_cast<int*>(p); p += align_up(samples * sizeof(float), 256);
   float* Gcl = reinterpret_cast<float*>(p); p += align_up(rays * P.CP * sizeof(float), 256);
   float* pmats = reinterpret_cast<float*>(p); p += align_up((size_t) d->B * d->N * 48 * sizeof(float), 256);
   unsigned* cull = reinterpret_cast<unsigned*>(p);
@@ -445,7 +449,7 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
       return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);                           \
     VAMP_TIMED(kProfCamBwd, s, (kr<<<grid, 256, lds, s>>>(P, mats, us, vs, ds, mids, beta, packed, \
                                                            g_rgb, g_seg, g_depth, Wbuf, G0buf, FX, FY, FZ, \
-                                                           Gcl, grad_beta, L)));                  \
+                                                           KEY, Gcl, grad_beta, L)));                  \
   } while (0)
   if (P.CP == 12) VAMP_RAY(3); else if (P.CP == 24) VAMP_RAY(6); else VAMP_RAY(8);
 #undef VAMP_RAY
@@ -475,7 +479,7 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
   }
 #define VAMP_GATHER(CP4)                                                                          \
   VAMP_TIMED(kProfCamBwdBrick, s, (cam_bwd_gather_kernel<CP4><<<bgrid, 256, 0, s>>>(              \
-      P, pmats, us, vs, ds, FX, FY, FZ, Wbuf, G0buf, Gcl, cull, gdens, gsem, grgb, total, cap)))
+      P, pmats, us, vs, ds, FX, FY, FZ, KEY, Wbuf, G0buf, Gcl, cull, gdens, gsem, grgb, total, cap)))
   if (P.CP == 12) VAMP_GATHER(3); else if (P.CP == 24) VAMP_GATHER(6); else VAMP_GATHER(8);
 #undef VAMP_GATHER
   return check_launch("cam_bwd_gather_kernel");
