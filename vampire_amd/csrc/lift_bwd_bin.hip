@@ -222,49 +222,98 @@ lift_bwd_own_kernel(LiftParams P, BinGeom G, const T* __restrict__ feat,
   const int grp = tid / GLN, gl = tid % GLN;
   const long first = off[blockIdx.x];
   const int n_ent = cnt[blockIdx.x];
-  for (int i = grp; i < n_ent; i += kOwnThreads / GLN) {
-    const float* e = entries + (first + i) * ES;
-    const float4 f = *reinterpret_cast<const float4*>(e);
-    const float4 dp = *reinterpret_cast<const float4*>(e + 4);
-    const float flx = floorf(f.x), fly = floorf(f.y), flz = floorf(f.z);
-    const int ix0 = (int) flx, iy0 = (int) fly, iz0 = (int) flz;
-    const float wx1 = f.x - flx, wx0 = (flx + 1.0f) - f.x;
-    const float wy1 = f.y - fly, wy0 = (fly + 1.0f) - f.y;
-    const float wz1 = f.z - flz, wz0 = (flz + 1.0f) - f.z;
-    const float wj[4] = {wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};
-    const float dep[4] = {dp.x, dp.y, dp.z, dp.w};
-    int pj[4];
+  // Each group walks a CONTIGUOUS slice of the list (records were appended in voxel order, so
+  // neighbours in the list are neighbouring voxels, which in the far field project onto the same
+  // four pixels).  The grad_feat contributions of such a run are summed in registers and flushed
+  // with one ds_add per pixel when the (ix0, iy0) base changes: same-address LDS float atomics
+  // are slow, and the hot pixels are exactly the ones with long runs.
+  constexpr int NGRP = kOwnThreads / GLN;
+  const int per = (n_ent + NGRP - 1) / NGRP;
+  const int j_lo = min(n_ent, grp * per), j_hi = min(n_ent, j_lo + per);
+  float run[4] = {0.f, 0.f, 0.f, 0.f};
+  int rx = -0x40000000, ry = 0;
+  auto flush = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int iy = iy0 + (j >> 1), ix = ix0 + (j & 1);
+      const int iy = ry + (j >> 1), ix = rx + (j & 1);
       const bool own = iy >= h0 && iy < h0 + BTH && ix >= w0 && ix < w0 + BTW && iy < P.fH && ix < P.fW;
-      pj[j] = own ? (iy - h0) * BTW + (ix - w0) : -1;
+      if (own && gl < C && run[j] != 0.f) atomicAdd(gf + ((iy - h0) * BTW + (ix - w0)) * CS + gl, run[j]);
+      run[j] = 0.f;
     }
-    float dot[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c0 = 0; c0 < C; c0 += GLN) {
-      const int c = c0 + gl;
-      if (c >= C) continue;
-      const float gs = e[8 + c];
+  };
+  constexpr int UB = 4;                          // entries per batch: their loads go out together
+  for (int i0 = j_lo; i0 < j_hi; i0 += UB) {
+    float4 fb[UB], db[UB];
+    float gsb[UB];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (pj[j] < 0) continue;
-        atomicAdd(gf + pj[j] * CS + c, wj[j] * dep[j] * gs);
-        dot[j] = __builtin_fmaf(ft[pj[j] * CS + c], gs, dot[j]);
+    for (int u = 0; u < UB; ++u) {
+      const int iu = min(i0 + u, j_hi - 1);
+      const float* e = entries + (first + iu) * ES;
+      fb[u] = *reinterpret_cast<const float4*>(e);
+      db[u] = *reinterpret_cast<const float4*>(e + 4);
+      gsb[u] = (gl < C) ? e[8 + gl] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (i0 + u >= j_hi) continue;
+      const float* e = entries + (first + i0 + u) * ES;
+      const float4 f = fb[u];
+      const float4 dp = db[u];
+      const float flx = floorf(f.x), fly = floorf(f.y), flz = floorf(f.z);
+      const int ix0 = (int) flx, iy0 = (int) fly, iz0 = (int) flz;
+      const float wx1 = f.x - flx, wx0 = (flx + 1.0f) - f.x;
+      const float wy1 = f.y - fly, wy0 = (fly + 1.0f) - f.y;
+      const float wz1 = f.z - flz, wz0 = (flz + 1.0f) - f.z;
+      const float wj[4] = {wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};
+      const float dep[4] = {dp.x, dp.y, dp.z, dp.w};
+      if (ix0 != rx || iy0 != ry) {              // group-uniform
+        flush();
+        rx = ix0; ry = iy0;
       }
-    }
-    if (P.use_depth) {
+      int pj[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (pj[j] < 0) continue;                           // uniform over the group
-        float dj = dot[j];
+        const int iy = iy0 + (j >> 1), ix = ix0 + (j & 1);
+        const bool own = iy >= h0 && iy < h0 + BTH && ix >= w0 && ix < w0 + BTW && iy < P.fH && ix < P.fW;
+        pj[j] = own ? (iy - h0) * BTW + (ix - w0) : -1;
+      }
+      float dot[4] = {0.f, 0.f, 0.f, 0.f};
+      if (C <= GLN) {
+        const float gs = gsb[u];
 #pragma unroll
-        for (int o = GLN >> 1; o > 0; o >>= 1) dj += __shfl_xor(dj, o, GLN);
-        const float gdj = wj[j] * dj;
-        if (gl == 0 && iz0 >= 0 && iz0 < P.D) atomicAdd(gd + iz0 * BTP + pj[j], wz0 * gdj);
-        if (gl == 1 && iz0 + 1 >= 0 && iz0 + 1 < P.D) atomicAdd(gd + (iz0 + 1) * BTP + pj[j], wz1 * gdj);
+        for (int j = 0; j < 4; ++j) {
+          if (pj[j] < 0) continue;
+          run[j] = __builtin_fmaf(wj[j] * dep[j], gs, run[j]);
+          if (gl < C) dot[j] = ft[pj[j] * CS + gl] * gs;
+        }
+      } else {
+        for (int c0 = 0; c0 < C; c0 += GLN) {    // more than 16 channels: no run accumulation
+          const int c = c0 + gl;
+          if (c >= C) continue;
+          const float gs = (c0 == 0) ? gsb[u] : e[8 + c];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (pj[j] < 0) continue;
+            atomicAdd(gf + pj[j] * CS + c, wj[j] * dep[j] * gs);
+            dot[j] = __builtin_fmaf(ft[pj[j] * CS + c], gs, dot[j]);
+          }
+        }
+      }
+      if (P.use_depth) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (pj[j] < 0) continue;                           // uniform over the group
+          float dj = dot[j];
+#pragma unroll
+          for (int o = GLN >> 1; o > 0; o >>= 1) dj += __shfl_xor(dj, o, GLN);
+          const float gdj = wj[j] * dj;
+          if (gl == 0 && iz0 >= 0 && iz0 < P.D) atomicAdd(gd + iz0 * BTP + pj[j], wz0 * gdj);
+          if (gl == 1 && iz0 + 1 >= 0 && iz0 + 1 < P.D) atomicAdd(gd + (iz0 + 1) * BTP + pj[j], wz1 * gdj);
+        }
       }
     }
   }
+  flush();
   __syncthreads();
   for (int e = tid; e < BTP * C; e += kOwnThreads) {
     const int c = e / BTP, p = e % BTP;
