@@ -266,13 +266,16 @@ def test_camera_backward_brick_matches_atomic_splat_full_size(dev, monkeypatch):
         torch.autograd.backward(outs, gs)
         return [v.grad.clone() for v in vols], beta.grad.clone()
 
-    g3, b3 = run("bin")         # default: per-brick lists + owners
-    g2, b2 = run("gather")      # per-voxel gather (the overflow fallback)
+    g4, b4 = run("cell")        # default: cell list + per-voxel owners
+    g3, b3 = run("bin")         # per-brick lists + owners
+    g2, b2 = run("gather")      # per-voxel candidate-box gather
     g1, b1 = run("v1")          # float-atomic splat
-    for name, a3, a2, b in zip(("density_feature", "semantic_logits", "base", "rgb"), g3, g2, g1):
+    for name, a4, a3, a2, b in zip(("density_feature", "semantic_logits", "base", "rgb"), g4, g3, g2, g1):
+        close(a4, b, atol=1e-5, rtol=2e-5, scale="max", what="cell vs v1 grad_" + name)
         close(a3, b, atol=1e-5, rtol=2e-5, scale="max", what="bin vs v1 grad_" + name)
         close(a2, b, atol=1e-5, rtol=2e-5, scale="max", what="gather vs v1 grad_" + name)
         assert float(b.abs().max()) > 0 or name == "base"
+    close(b4.reshape(1), b1.reshape(1), atol=1e-3, rtol=1e-3, what="grad_beta")
     close(b3.reshape(1), b1.reshape(1), atol=1e-3, rtol=1e-3, what="grad_beta")
     close(b2.reshape(1), b1.reshape(1), atol=1e-3, rtol=1e-3, what="grad_beta")
 

@@ -16,6 +16,8 @@
 // See render_bwd.hip for the compositing algebra.
 #include "render_common.hpp"
 
+#include <algorithm>
+
 namespace vamp {
 
 // ---------------------------------------------------------------------------
@@ -395,6 +397,11 @@ cam_bwd_gather_kernel(RenderParams P, const float* __restrict__ pmats, const flo
 // host side
 // ---------------------------------------------------------------------------
 size_t cam_bwd_bin_bytes(const VampRenderDesc* d);     // render_bwd_bin.hip
+size_t cam_bwd_cell_bytes(const VampRenderDesc* d);    // render_bwd_cell.hip
+int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const float* FX,
+                        const float* FY, const float* FZ, const int* KEY, const float* Wbuf,
+                        const float* G0buf, const float* Gcl, float* gdens, float* gsem,
+                        float* grgb, void* scratch, hipStream_t s);
 
 size_t cam_bwd_v2_bytes(const VampRenderDesc* d) {
   const RenderParams P = to_params(d);
@@ -403,7 +410,7 @@ size_t cam_bwd_v2_bytes(const VampRenderDesc* d) {
   return 6 * align_up(samples * sizeof(float), 256) + align_up(rays * P.CP * sizeof(float), 256) +
          align_up((size_t) d->B * d->N * 48 * sizeof(float), 256) +
          align_up((size_t) d->B * d->Z * d->Y * ((d->X + VPB - 1) / VPB) * sizeof(unsigned), 256) +
-         cam_bwd_bin_bytes(d);
+         std::max(cam_bwd_bin_bytes(d), cam_bwd_cell_bytes(d));
 }
 
 size_t cam_bwd_bin_bytes(const VampRenderDesc* d);
@@ -433,6 +440,11 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
   p += align_up((size_t) d->B * d->Z * d->Y * ((d->X + VPB - 1) / VPB) * sizeof(unsigned), 256);
   void* bin_scratch = p;
 
+  // scatter stage: cell list (default, render_bwd_cell.hip); VAMP_CAM_BWD=gather selects the
+  // candidate-box gather below, VAMP_CAM_BWD=bin the brick lists of render_bwd_bin.hip
+  const char* force = getenv("VAMP_CAM_BWD");
+  const bool use_cell = !(force && (force[0] == 'g' || force[0] == 'b'));
+
   constexpr int LPR = 4;
   const int S = d->D - 1;
   const int L = (S + LPR - 1) / LPR;
@@ -454,16 +466,16 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
   if (P.CP == 12) VAMP_RAY(3); else if (P.CP == 24) VAMP_RAY(6); else VAMP_RAY(8);
 #undef VAMP_RAY
   if (int e = check_launch("cam_bwd_ray_kernel")) return e;
+  if (use_cell)
+    return launch_cam_bwd_cell(d, P, FX, FY, FZ, KEY, Wbuf, G0buf, Gcl, gdens, gsem, grgb,
+                               bin_scratch, s);
 
-  // 2. scatter stage: the per-voxel gather below, or (VAMP_CAM_BWD=bin) the records binned into
-  //    per-brick lists with one workgroup owning each brick (render_bwd_bin.hip), in which case
-  //    the gather runs only if the lists overflow the workspace (device-side decision).
+  // 2. candidate-box gather, or the records binned into per-brick lists with one workgroup
+  //    owning each brick (render_bwd_bin.hip), in which case the gather runs only if the lists
+  //    overflow the workspace (device-side decision).
   const int* total = nullptr;
   int cap = 0;
-  const char* force = getenv("VAMP_CAM_BWD");
-  // measured at cfg-B (profiles/): gather 0.77 ms vs count+fill+own 0.97 ms -> gather is the default,
-  // the bin-then-own path is selected with VAMP_CAM_BWD=bin
-  const bool gather_only = !(force && force[0] == 'b');
+  const bool gather_only = force[0] != 'b';
   if (!gather_only)
     if (int e = launch_cam_bwd_bin(d, P, FX, FY, FZ, Wbuf, G0buf, Gcl, gdens, gsem, grgb,
                                    bin_scratch, &total, &cap, s))

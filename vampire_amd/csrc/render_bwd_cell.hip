@@ -1,0 +1,398 @@
+// Camera-branch render backward, scatter stage as a cell list ("sort, then own"):
+//
+//   count   (inside cam_bwd_ray_kernel) every inside sample increments the counter of its
+//           cell = the voxel-grid cube whose lower corner is its floor tap, grid padded by one
+//           on the low side: (Z+1) x (Y+1) x (X+1) cells per sample of the batch; the value the
+//           atomic returns is the sample's rank inside the cell
+//   scan    two-level exclusive prefix sum of the cell counters -> cell start offsets
+//   fill    every inside sample moves its record {fx, fy, fz, w | dL/ds0, ray} to slot
+//           start[cell] + rank: records of a cell, and of x-neighbouring cells, are contiguous
+//   gather  GL lanes per voxel: the samples whose trilinear support contains voxel (x, y, z)
+//           are exactly those of the 2x2x2 cells (x..x+1, y..y+1, z..z+1), i.e. four contiguous
+//           record ranges; the lanes stream them, accumulate weight * dL/ds[c] in registers
+//           and store every output element once.  Voxels with more than kHeavy records go to
+//           a queue that a second kernel drains with one workgroup per voxel (the voxels next
+//           to a camera collect thousands of samples).
+//
+// No search, no failed candidates: the work is the 8 * (inside samples) real contributions.
+// The order of a cell's records follows the order in which the count atomics were served, so
+// the fp32 sums can differ in the last bit between runs (as the reference's CUDA atomics do).
+// Autograd of render_utils.py:140-141 (grid_sample backward w.r.t. the volume).
+#include "render_common.hpp"
+
+#include <algorithm>
+
+namespace vamp {
+
+constexpr int CGL = 16;              // lanes per voxel
+constexpr int CVPB = 256 / CGL;      // voxels per workgroup: an x-run
+constexpr int kHeavy = 256;          // records per voxel beyond which the whole-workgroup kernel runs
+constexpr int kScanTile = 2048;      // cells per scan workgroup (256 threads x 8)
+
+static long cell_count_padded(int B, int Z, int Y, int X) {
+  const long nc = (long) B * (Z + 1) * (Y + 1) * (X + 1) + 2;      // +2: the gather reads start[c + 2]
+  return (nc + kScanTile - 1) / kScanTile * kScanTile;
+}
+
+__device__ __forceinline__ long sample_cell(const RenderParams& P, int key, unsigned b, long ncell_b) {
+  return (long) b * ncell_b +
+         ((long) (key >> 22) * (P.Y + 1) + ((key >> 11) & 2047)) * (P.X + 1) + (key & 2047);
+}
+
+// ---------------------------------------------------------------------------
+// count + rank: thread per sample in depth-major order, so the 64 lanes of a wave are 64
+// neighbouring pixels of one image row at one depth and fall into a few cells, in runs.
+// Device-scope atomics are served at the memory side on this part (~1 us, and they are the
+// bottleneck of this pass), so each run of equal cells issues ONE atomic: the run head adds
+// the run length and the lanes of the run take base + position.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+cam_bwd_rank_kernel(RenderParams P, const int* __restrict__ KEY, int* __restrict__ cnt,
+                    int* __restrict__ RANK, unsigned samples, long ncell_b) {
+  const unsigned sidx = blockIdx.x * 256u + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const unsigned HW = (unsigned) (P.fH * P.fW), S = (unsigned) (P.D - 1);
+  const int key = sidx < samples ? KEY[sidx] : 0;
+  const bool valid = key != 0;
+  const unsigned b = sidx / (S * HW) / (unsigned) P.N;
+  const long cell = sample_cell(P, key, b, ncell_b);
+  const long pcell = __shfl_up(cell, 1, 64);
+  const unsigned long long vm = __ballot(valid);
+  const bool pvalid = lane > 0 && ((vm >> (lane - 1)) & 1ull);
+  const bool head = valid && (!pvalid || pcell != cell);
+  const unsigned long long hm = __ballot(head);
+  // run start: highest head at or below this lane; run end: next head or invalid lane above it
+  const unsigned long long upto = ~0ull >> (63 - lane);
+  const int start = 63 - __clzll((long long) (hm & upto));
+  const unsigned long long brk = (hm | ~vm) & ~upto;
+  const int end = brk ? __ffsll((long long) brk) - 1 : 64;
+  int base = 0;
+  if (head) base = atomicAdd(cnt + cell, end - lane);
+  base = __shfl(base, valid ? start : lane, 64);
+  if (valid) RANK[sidx] = base + (lane - start);
+}
+
+// ---------------------------------------------------------------------------
+// scan, level 1: exclusive scan inside each 2048-cell tile, tile totals to bsum
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+cell_scan_tile_kernel(const int* __restrict__ cnt, int* __restrict__ off, int* __restrict__ bsum) {
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long base = (long) blockIdx.x * kScanTile + tid * 8;
+  const int4* c4 = reinterpret_cast<const int4*>(cnt + base);
+  const int4 a = c4[0], b = c4[1];
+  const int v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  int tsum = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) tsum += v[k];
+  int incl = tsum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  int wbase = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < wv) wbase += wsum[k];
+  int run = wbase + incl - tsum;
+  int o8[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    o8[k] = run;
+    run += v[k];
+  }
+  int4* o4 = reinterpret_cast<int4*>(off + base);
+  o4[0] = make_int4(o8[0], o8[1], o8[2], o8[3]);
+  o4[1] = make_int4(o8[4], o8[5], o8[6], o8[7]);
+  if (tid == 255) bsum[blockIdx.x] = run;
+}
+
+// ---------------------------------------------------------------------------
+// fill: thread per sample (depth-major sample index, coalesced reads); inside samples write
+// their record to start[cell] + rank
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+cam_bwd_fill_kernel(RenderParams P, const int* __restrict__ KEY, const int* __restrict__ RANK,
+                    const float* __restrict__ FX, const float* __restrict__ FY,
+                    const float* __restrict__ FZ, const float* __restrict__ Wbuf,
+                    const float* __restrict__ G0buf, const int* __restrict__ off,
+                    const int* __restrict__ boff, float4* __restrict__ R, unsigned samples,
+                    long ncell_b) {
+  const unsigned sidx = blockIdx.x * 256u + threadIdx.x;
+  if (sidx >= samples) return;
+  const int key = KEY[sidx];
+  if (key == 0) return;
+  const unsigned HW = (unsigned) (P.fH * P.fW), S = (unsigned) (P.D - 1);
+  const unsigned bn = sidx / (S * HW);
+  const unsigned b = bn / (unsigned) P.N;
+  const long cell = (long) b * ncell_b +
+                    ((long) (key >> 22) * (P.Y + 1) + ((key >> 11) & 2047)) * (P.X + 1) + (key & 2047);
+  const long slot = (long) boff[cell / kScanTile] + off[cell] + RANK[sidx];
+  const unsigned ray = bn * HW + sidx % HW;
+  R[2 * slot] = make_float4(FX[sidx], FY[sidx], FZ[sidx], Wbuf[sidx]);
+  R[2 * slot + 1] = make_float4(G0buf[sidx], __uint_as_float(ray), 0.f, 0.f);
+}
+
+// weight of tap index `iv` for continuous coordinate f (aten: w0 = floor+1-f, w1 = f-floor)
+__device__ __forceinline__ float cell_tap_weight(float f, float iv) {
+  const float fl = floorf(f);
+  return (fl == iv) ? (fl + 1.0f) - f : ((fl + 1.0f == iv) ? f - fl : 0.f);
+}
+
+// The four record ranges of voxel (ix, iy, iz): lanes 0..7 of the group load the range ends.
+struct CellRanges {
+  int beg[4];
+  int pre[4];     // exclusive prefix of the range lengths
+  int tot;
+};
+
+template <int W>
+__device__ __forceinline__ CellRanges cell_ranges(const RenderParams& P, const int* __restrict__ off,
+                                                  const int* __restrict__ boff, long ncell_b, int b,
+                                                  int ix, int iy, int iz, int l) {
+  const int r = (l >> 1) & 3;
+  const long c = (long) b * ncell_b +
+                 ((long) (iz + (r >> 1)) * (P.Y + 1) + (iy + (r & 1))) * (P.X + 1) + ix + 2 * (l & 1);
+  const int sv = off[c] + boff[c / kScanTile];
+  CellRanges cr;
+  int run = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    cr.beg[q] = __shfl(sv, 2 * q, W);
+    const int end = __shfl(sv, 2 * q + 1, W);
+    cr.pre[q] = run;
+    run += end - cr.beg[q];
+  }
+  cr.tot = run;
+  return cr;
+}
+
+// record position of the k-th entry of the concatenated ranges (k clamped by the caller)
+__device__ __forceinline__ long cell_pos(const CellRanges& cr, int k) {
+  const int q = (k >= cr.pre[1]) + (k >= cr.pre[2]) + (k >= cr.pre[3]);
+  const int pre = q == 0 ? cr.pre[0] : (q == 1 ? cr.pre[1] : (q == 2 ? cr.pre[2] : cr.pre[3]));
+  const int beg = q == 0 ? cr.beg[0] : (q == 1 ? cr.beg[1] : (q == 2 ? cr.beg[2] : cr.beg[3]));
+  return (long) beg + (k - pre);
+}
+
+// U entries per lane per round (k, k + stride, ...): the record loads of a round go out
+// together, then the ray-gradient rows, so a round costs two memory latencies.
+template <int CP4, int U>
+__device__ __forceinline__ void cell_accumulate(const CellRanges& cr, int k0, int stride,
+                                                const float4* __restrict__ R,
+                                                const float* __restrict__ Gcl, float fix, float fiy,
+                                                float fiz, float (&acc)[CP4 * 4]) {
+  constexpr int CP = CP4 * 4;
+  float4 a[U], g[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int k = k0 + u * stride;
+    const long pos = cell_pos(cr, min(k, cr.tot - 1));
+    a[u] = R[2 * pos];
+    g[u] = R[2 * pos + 1];
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const bool in = k0 + u * stride < cr.tot;
+    float wt = cell_tap_weight(a[u].x, fix) * cell_tap_weight(a[u].y, fiy) * cell_tap_weight(a[u].z, fiz);
+    wt = in ? wt : 0.f;
+    const float Wv = wt * a[u].w;
+    acc[0] = __builtin_fmaf(wt, g[u].x, acc[0]);
+    const float4* g4 = reinterpret_cast<const float4*>(Gcl + (long) __float_as_uint(g[u].y) * CP);
+#pragma unroll
+    for (int c4 = 0; c4 < CP4; ++c4) {
+      const float4 f = g4[c4];
+      if (c4 > 0) acc[c4 * 4] = __builtin_fmaf(Wv, f.x, acc[c4 * 4]);
+      acc[c4 * 4 + 1] = __builtin_fmaf(Wv, f.y, acc[c4 * 4 + 1]);
+      acc[c4 * 4 + 2] = __builtin_fmaf(Wv, f.z, acc[c4 * 4 + 2]);
+      acc[c4 * 4 + 3] = __builtin_fmaf(Wv, f.w, acc[c4 * 4 + 3]);
+    }
+  }
+}
+
+template <int CP4>
+__global__ void __launch_bounds__(256)
+cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const int* __restrict__ boff,
+                           const float4* __restrict__ R, const float* __restrict__ Gcl,
+                           float* __restrict__ gdens, float* __restrict__ gsem,
+                           float* __restrict__ grgb, int* __restrict__ heavy,
+                           int* __restrict__ nheavy, long ncell_b) {
+  constexpr int CP = CP4 * 4;
+  __shared__ float outs[CP][CVPB + 1];
+  const int tid = threadIdx.x;
+  const int g = tid / CGL, l = tid % CGL;
+  const int ix = blockIdx.x * CVPB + g, iy = blockIdx.y;
+  const int iz = blockIdx.z % P.Z, b = blockIdx.z / P.Z;
+  const bool vox_ok = ix < P.X;
+  const int nch = 1 + P.K + 3;
+  const int ixc = min(ix, P.X - 1);
+  const CellRanges cr = cell_ranges<CGL>(P, off, boff, ncell_b, b, ixc, iy, iz, l);
+
+  float acc[CP];
+#pragma unroll
+  for (int c = 0; c < CP; ++c) acc[c] = 0.f;
+
+  if (vox_ok && cr.tot > kHeavy) {
+    if (l == 0) {
+      const int q = atomicAdd(nheavy, 1);
+      heavy[q] = ((b * P.Z + iz) * P.Y + iy) * P.X + ix;
+    }
+  } else if (vox_ok) {
+    const float fix = (float) ix, fiy = (float) iy, fiz = (float) iz;
+    constexpr int U = 1;              // U = 2 costs a wave of occupancy and measured slower
+    for (int k = l; k < cr.tot; k += U * CGL)
+      cell_accumulate<CP4, U>(cr, k, CGL, R, Gcl, fix, fiy, fiz, acc);
+  }
+  // reduce over the lanes of the voxel, transpose through LDS, store x-runs
+#pragma unroll
+  for (int c = 0; c < CP; ++c) {
+    float v = acc[c];
+#pragma unroll
+    for (int o = CGL >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, CGL);
+    if (l == 0) outs[c][g] = v;
+  }
+  __syncthreads();
+  const long V = (long) P.Z * P.Y * P.X;
+  const long vox0 = ((long) iz * P.Y + iy) * P.X + (long) blockIdx.x * CVPB;
+  for (int e = tid; e < nch * CVPB; e += 256) {
+    const int c = e / CVPB, gx = e % CVPB;
+    if (blockIdx.x * CVPB + gx >= P.X) continue;
+    const float v = outs[c][gx];
+    if (c == 0) gdens[(long) b * V + vox0 + gx] = v;
+    else if (c <= P.K) gsem[((long) b * P.K + (c - 1)) * V + vox0 + gx] = v;
+    else grgb[((long) b * 3 + (c - 1 - P.K)) * V + vox0 + gx] = v;
+  }
+}
+
+// One workgroup per queued voxel: 256 lanes stream its records, fixed-order reduction.
+template <int CP4>
+__global__ void __launch_bounds__(256)
+cam_bwd_cell_heavy_kernel(RenderParams P, const int* __restrict__ off, const int* __restrict__ boff,
+                          const float4* __restrict__ R, const float* __restrict__ Gcl,
+                          float* __restrict__ gdens, float* __restrict__ gsem,
+                          float* __restrict__ grgb, const int* __restrict__ heavy,
+                          const int* __restrict__ nheavy, long ncell_b) {
+  constexpr int CP = CP4 * 4;
+  __shared__ float part[4][CP];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nch = 1 + P.K + 3;
+  const long V = (long) P.Z * P.Y * P.X;
+  const int n = *nheavy;
+  for (int item = blockIdx.x; item < n; item += gridDim.x) {
+    int vid = heavy[item];
+    const int ix = vid % P.X; vid /= P.X;
+    const int iy = vid % P.Y; vid /= P.Y;
+    const int iz = vid % P.Z, b = vid / P.Z;
+    const CellRanges cr = cell_ranges<64>(P, off, boff, ncell_b, b, ix, iy, iz, lane);
+    float acc[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) acc[c] = 0.f;
+    const float fix = (float) ix, fiy = (float) iy, fiz = (float) iz;
+    constexpr int U = 2;
+    for (int k = tid; k < cr.tot; k += U * 256)
+      cell_accumulate<CP4, U>(cr, k, 256, R, Gcl, fix, fiy, fiz, acc);
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      float v = acc[c];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) part[wv][c] = v;
+    }
+    __syncthreads();
+    if (tid < nch) {
+      const float v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+      const long vox = ((long) iz * P.Y + iy) * P.X + ix;
+      if (tid == 0) gdens[(long) b * V + vox] = v;
+      else if (tid <= P.K) gsem[((long) b * P.K + (tid - 1)) * V + vox] = v;
+      else grgb[((long) b * 3 + (tid - 1 - P.K)) * V + vox] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct CellWs {
+  int* cnt;        // [ncell] counters
+  int* off;        // [ncell] tile-local exclusive offsets
+  int* bsum;       // [ntile] tile totals
+  int* boff;       // [ntile] exclusive scan of the tile totals
+  int* aux;        // [ntile] scratch of the level-2 scan, then [ntile] = total, [ntile+1] = heavy count
+  int* heavy;      // [voxels] queue
+  int* rank;       // [samples] rank of the sample inside its cell
+  float4* R;       // [samples][2] records in cell order
+  size_t bytes;
+};
+
+static CellWs cell_ws(const VampRenderDesc* d, void* scratch) {
+  const long ncell = cell_count_padded(d->B, d->Z, d->Y, d->X);
+  const long ntile = ncell / kScanTile;
+  const size_t samples = (size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW;
+  const size_t voxels = (size_t) d->B * d->Z * d->Y * d->X;
+  char* p = static_cast<char*>(scratch);
+  CellWs w;
+  w.cnt = reinterpret_cast<int*>(p); p += align_up((size_t) ncell * sizeof(int), 256);
+  w.off = reinterpret_cast<int*>(p); p += align_up((size_t) ncell * sizeof(int), 256);
+  w.bsum = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
+  w.boff = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
+  w.aux = reinterpret_cast<int*>(p); p += align_up((size_t) (ntile + 4) * sizeof(int), 256);
+  w.heavy = reinterpret_cast<int*>(p); p += align_up(voxels * sizeof(int), 256);
+  w.rank = reinterpret_cast<int*>(p); p += align_up(samples * sizeof(int), 256);
+  w.R = reinterpret_cast<float4*>(p); p += align_up(samples * 2 * sizeof(float4), 256);
+  w.bytes = (size_t) (p - static_cast<char*>(scratch));
+  return w;
+}
+
+size_t cam_bwd_cell_bytes(const VampRenderDesc* d) { return cell_ws(d, nullptr).bytes; }
+
+int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const float* FX,
+                        const float* FY, const float* FZ, const int* KEY, const float* Wbuf,
+                        const float* G0buf, const float* Gcl, float* gdens, float* gsem,
+                        float* grgb, void* scratch, hipStream_t s) {
+  const CellWs w = cell_ws(d, scratch);
+  const long ncell = cell_count_padded(d->B, d->Z, d->Y, d->X);
+  const long ntile = ncell / kScanTile;
+  const size_t samples = (size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW;
+  const size_t voxels = (size_t) d->B * d->Z * d->Y * d->X;
+  VAMP_REQUIRE(samples < 0x7fffffffu && voxels < 0x7fffffffu && ncell < 0x7fffffffL,
+               "sample / voxel / cell count exceeds 2^31");
+  const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
+
+  if (hipMemsetAsync(w.cnt, 0, (size_t) ncell * sizeof(int), s) != hipSuccess)
+    return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
+  const unsigned sgrid = (unsigned) ((samples + 255) / 256);
+  VAMP_TIMED(kProfCamBwdCount, s, (cam_bwd_rank_kernel<<<sgrid, 256, 0, s>>>(
+      P, KEY, w.cnt, w.rank, (unsigned) samples, ncell_b)));
+  if (int e = check_launch("cam_bwd_rank_kernel")) return e;
+  VAMP_TIMED(kProfAux, s, (cell_scan_tile_kernel<<<(unsigned) ntile, 256, 0, s>>>(w.cnt, w.off, w.bsum)));
+  if (int e = check_launch("cell_scan_tile_kernel")) return e;
+  // level 2: exclusive scan of the tile totals; aux[ntile] receives the record total
+  if (int e = launch_exclusive_scan(w.bsum, w.boff, w.aux, (int) ntile, w.aux + ntile, s)) return e;
+  int* nheavy = w.aux + ntile + 1;
+  if (hipMemsetAsync(nheavy, 0, sizeof(int), s) != hipSuccess)
+    return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
+
+  VAMP_TIMED(kProfCamBwdFill, s, (cam_bwd_fill_kernel<<<(unsigned) ((samples + 255) / 256), 256, 0, s>>>(
+      P, KEY, w.rank, FX, FY, FZ, Wbuf, G0buf, w.off, w.boff, w.R, (unsigned) samples, ncell_b)));
+  if (int e = check_launch("cam_bwd_fill_kernel")) return e;
+
+  dim3 grid((d->X + CVPB - 1) / CVPB, d->Y, d->Z * d->B);
+  const unsigned hgrid = (unsigned) std::min<size_t>(voxels, 8192);
+#define VAMP_CELL(CP4)                                                                              \
+  do {                                                                                              \
+    VAMP_TIMED(kProfCamBwdBrick, s, (cam_bwd_cell_gather_kernel<CP4><<<grid, 256, 0, s>>>(          \
+        P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, w.heavy, nheavy, ncell_b)));                 \
+    VAMP_TIMED(kProfCamBwdOwn, s, (cam_bwd_cell_heavy_kernel<CP4><<<hgrid, 256, 0, s>>>(            \
+        P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, w.heavy, nheavy, ncell_b)));                 \
+  } while (0)
+  if (P.CP == 12) VAMP_CELL(3); else if (P.CP == 24) VAMP_CELL(6); else VAMP_CELL(8);
+#undef VAMP_CELL
+  return check_launch("cam_bwd_cell_gather_kernel");
+}
+
+}  // namespace vamp
