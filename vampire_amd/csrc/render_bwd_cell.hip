@@ -1,9 +1,9 @@
 // Camera-branch render backward, scatter stage as a cell list ("sort, then own"):
 //
-//   count   (inside cam_bwd_ray_kernel) every inside sample increments the counter of its
-//           cell = the voxel-grid cube whose lower corner is its floor tap, grid padded by one
-//           on the low side: (Z+1) x (Y+1) x (X+1) cells per sample of the batch; the value the
-//           atomic returns is the sample's rank inside the cell
+//   rank    every inside sample (KEY != 0, written by cam_bwd_ray_kernel) increments the counter
+//           of its cell = the voxel-grid cube whose lower corner is its floor tap, grid padded by
+//           one on the low side: (Z+1) x (Y+1) x (X+1) cells per sample of the batch; the value
+//           the atomic returns is the sample's rank inside the cell
 //   scan    two-level exclusive prefix sum of the cell counters -> cell start offsets
 //   fill    every inside sample moves its record {fx, fy, fz, w | dL/ds0, ray} to slot
 //           start[cell] + rank: records of a cell, and of x-neighbouring cells, are contiguous
@@ -24,8 +24,6 @@
 
 namespace vamp {
 
-constexpr int CGL = 16;              // lanes per voxel
-constexpr int CVPB = 256 / CGL;      // voxels per workgroup: an x-run
 constexpr int kHeavy = 256;          // records per voxel beyond which the whole-workgroup kernel runs
 constexpr int kScanTile = 2048;      // cells per scan workgroup (256 threads x 8)
 
@@ -214,19 +212,66 @@ __device__ __forceinline__ void cell_accumulate(const CellRanges& cr, int k0, in
   }
 }
 
-template <int CP4>
+// Sum N per-lane values over the lanes of a W-wide group with recursive halving: at every xor
+// step with an even count each lane keeps one half of the values and hands the other half to its
+// partner, so the step moves N/2 values instead of N (an odd count falls back to a plain
+// butterfly).  On return a[0 .. reduce_left<N, W/2>()) are the complete sums of channels
+// cbase .. ; lanes that differ only in the bits of reduce_dups<N, W/2>() hold copies.
+template <int N, int O>
+constexpr int reduce_left() {
+  if constexpr (O == 0) return N;
+  else if constexpr (N % 2 == 0) return reduce_left<N / 2, O / 2>();
+  else return reduce_left<N, O / 2>();
+}
+template <int N, int O>
+constexpr int reduce_dups() {
+  if constexpr (O == 0) return 0;
+  else if constexpr (N % 2 == 0) return reduce_dups<N / 2, O / 2>();
+  else return O | reduce_dups<N, O / 2>();
+}
+template <int N, int O, int W, int CP>
+__device__ __forceinline__ void reduce_halving(float (&a)[CP], int l, int& cbase) {
+  if constexpr (O == 0) {
+    return;
+  } else if constexpr (N % 2 == 0) {
+    constexpr int H = N / 2;
+    const bool up = (l & O) != 0;
+#pragma unroll
+    for (int c = 0; c < H; ++c) {
+      const float send = up ? a[c] : a[c + H];
+      const float keep = up ? a[c + H] : a[c];
+      a[c] = keep + __shfl_xor(send, O, W);
+    }
+    cbase += up ? H : 0;
+    reduce_halving<H, O / 2, W, CP>(a, l, cbase);
+  } else {
+#pragma unroll
+    for (int c = 0; c < N; ++c) a[c] += __shfl_xor(a[c], O, W);
+    reduce_halving<N, O / 2, W, CP>(a, l, cbase);
+  }
+}
+
+// CGL lanes per voxel, 256 / CGL voxels (an x-run) per workgroup
+template <int CP4, int CGL>
 __global__ void __launch_bounds__(256)
 cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const int* __restrict__ boff,
                            const float4* __restrict__ R, const float* __restrict__ Gcl,
                            float* __restrict__ gdens, float* __restrict__ gsem,
                            float* __restrict__ grgb, int* __restrict__ heavy,
-                           int* __restrict__ nheavy, long ncell_b) {
+                           int* __restrict__ nheavy, long ncell_b, int runs_x, int heavy_thresh) {
   constexpr int CP = CP4 * 4;
+  constexpr int CVPB = 256 / CGL;
   __shared__ float outs[CP][CVPB + 1];
   const int tid = threadIdx.x;
   const int g = tid / CGL, l = tid % CGL;
-  const int ix = blockIdx.x * CVPB + g, iy = blockIdx.y;
-  const int iz = blockIdx.z % P.Z, b = blockIdx.z / P.Z;
+  // (giving each XCD a contiguous slab of x-runs instead of the round-robin deal measured 12 %
+  // slower: the slabs next to the cameras carry most of the records)
+  const unsigned lin = blockIdx.x;
+  const int bx = lin % (unsigned) runs_x;
+  const unsigned rest = lin / (unsigned) runs_x;
+  const int ix = bx * CVPB + g, iy = rest % (unsigned) P.Y;
+  const int zb = rest / (unsigned) P.Y;
+  const int iz = zb % P.Z, b = zb / P.Z;
   const bool vox_ok = ix < P.X;
   const int nch = 1 + P.K + 3;
   const int ixc = min(ix, P.X - 1);
@@ -236,7 +281,7 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
 #pragma unroll
   for (int c = 0; c < CP; ++c) acc[c] = 0.f;
 
-  if (vox_ok && cr.tot > kHeavy) {
+  if (vox_ok && cr.tot > heavy_thresh) {
     if (l == 0) {
       const int q = atomicAdd(nheavy, 1);
       heavy[q] = ((b * P.Z + iz) * P.Y + iy) * P.X + ix;
@@ -248,19 +293,22 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
       cell_accumulate<CP4, U>(cr, k, CGL, R, Gcl, fix, fiy, fiz, acc);
   }
   // reduce over the lanes of the voxel, transpose through LDS, store x-runs
+  {
+    int cbase = 0;
+    reduce_halving<CP, CGL / 2, CGL, CP>(acc, l, cbase);
+    constexpr int NL = reduce_left<CP, CGL / 2>();
+    constexpr int DUP = reduce_dups<CP, CGL / 2>();
+    if ((l & DUP) == 0) {
 #pragma unroll
-  for (int c = 0; c < CP; ++c) {
-    float v = acc[c];
-#pragma unroll
-    for (int o = CGL >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, CGL);
-    if (l == 0) outs[c][g] = v;
+      for (int c = 0; c < NL; ++c) outs[cbase + c][g] = acc[c];
+    }
   }
   __syncthreads();
   const long V = (long) P.Z * P.Y * P.X;
-  const long vox0 = ((long) iz * P.Y + iy) * P.X + (long) blockIdx.x * CVPB;
+  const long vox0 = ((long) iz * P.Y + iy) * P.X + (long) bx * CVPB;
   for (int e = tid; e < nch * CVPB; e += 256) {
     const int c = e / CVPB, gx = e % CVPB;
-    if (blockIdx.x * CVPB + gx >= P.X) continue;
+    if (bx * CVPB + gx >= P.X) continue;
     const float v = outs[c][gx];
     if (c == 0) gdens[(long) b * V + vox0 + gx] = v;
     else if (c <= P.K) gsem[((long) b * P.K + (c - 1)) * V + vox0 + gx] = v;
@@ -295,12 +343,15 @@ cam_bwd_cell_heavy_kernel(RenderParams P, const int* __restrict__ off, const int
     constexpr int U = 2;
     for (int k = tid; k < cr.tot; k += U * 256)
       cell_accumulate<CP4, U>(cr, k, 256, R, Gcl, fix, fiy, fiz, acc);
+    {
+      int cbase = 0;
+      reduce_halving<CP, 32, 64, CP>(acc, lane, cbase);
+      constexpr int NL = reduce_left<CP, 32>();
+      constexpr int DUP = reduce_dups<CP, 32>();
+      if ((lane & DUP) == 0) {
 #pragma unroll
-    for (int c = 0; c < CP; ++c) {
-      float v = acc[c];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == 0) part[wv][c] = v;
+        for (int c = 0; c < NL; ++c) part[wv][cbase + c] = acc[c];
+      }
     }
     __syncthreads();
     if (tid < nch) {
@@ -381,17 +432,28 @@ int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const fl
       P, KEY, w.rank, FX, FY, FZ, Wbuf, G0buf, w.off, w.boff, w.R, (unsigned) samples, ncell_b)));
   if (int e = check_launch("cam_bwd_fill_kernel")) return e;
 
-  dim3 grid((d->X + CVPB - 1) / CVPB, d->Y, d->Z * d->B);
+  // measured at cfg-B (gather + heavy, us): 8 lanes 145 + 56, 16 lanes 173 + 56, 32 lanes 249 + 56;
+  // threshold 128 / 256 / 512 with 8 lanes: 131 + 107, 145 + 56, 159 + 40
+  constexpr int gl = 8;
+  const int heavy_thresh = kHeavy;
+  const int vpb = 256 / gl;
+  const int runs_x = (d->X + vpb - 1) / vpb;
+  const long nblk = (long) runs_x * d->Y * d->Z * d->B;
+  VAMP_REQUIRE(nblk < 0x7fffffffL, "too many x-runs");
+  const unsigned grid = (unsigned) nblk;
   const unsigned hgrid = (unsigned) std::min<size_t>(voxels, 8192);
+#define VAMP_CELL_G(CP4, GLV)                                                                       \
+  VAMP_TIMED(kProfCamBwdBrick, s, (cam_bwd_cell_gather_kernel<CP4, GLV><<<grid, 256, 0, s>>>(       \
+      P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, w.heavy, nheavy, ncell_b, runs_x, heavy_thresh)))
 #define VAMP_CELL(CP4)                                                                              \
   do {                                                                                              \
-    VAMP_TIMED(kProfCamBwdBrick, s, (cam_bwd_cell_gather_kernel<CP4><<<grid, 256, 0, s>>>(          \
-        P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, w.heavy, nheavy, ncell_b)));                 \
+    VAMP_CELL_G(CP4, gl);                                                                           \
     VAMP_TIMED(kProfCamBwdOwn, s, (cam_bwd_cell_heavy_kernel<CP4><<<hgrid, 256, 0, s>>>(            \
         P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, w.heavy, nheavy, ncell_b)));                 \
   } while (0)
   if (P.CP == 12) VAMP_CELL(3); else if (P.CP == 24) VAMP_CELL(6); else VAMP_CELL(8);
 #undef VAMP_CELL
+#undef VAMP_CELL_G
   return check_launch("cam_bwd_cell_gather_kernel");
 }
 
