@@ -329,10 +329,19 @@ def test_lift_backward_tile_matches_atomic_splat_full_size(dev, monkeypatch):
         out.backward(torch.randn(out.shape, device=dev, generator=gen))
         return depth.grad.clone(), feat.grad.clone()
 
-    d3, f3 = run("v3")          # default: binned lists + tile owners
-    d2, f2 = run("v2")          # tile enumeration (the overflow fallback)
+    d4, f4 = run("cell")        # default: cell list + a wave per pixel
+    monkeypatch.setenv("VAMP_LIFT_WPP", "4")
+    d5, f5 = run("cell")        # same, four waves per pixel (the dense-pixel configuration)
+    monkeypatch.setenv("VAMP_LIFT_WPP", "16")
+    d6, f6 = run("cell")
+    monkeypatch.delenv("VAMP_LIFT_WPP")
+    d3, f3 = run("v3")          # binned lists + tile owners
+    d2, f2 = run("v2")          # tile enumeration
     d1, f1 = run("v1")          # per-voxel float-atomic splat
     assert float(d1.abs().max()) > 0 and float(f1.abs().max()) > 0
+    for tag, dd, ff in (("cell", d4, f4), ("cell wpp4", d5, f5), ("cell wpp16", d6, f6)):
+        close(dd, d1, atol=1e-6, rtol=2e-5, scale="max", what=tag + " vs splat grad_depth")
+        close(ff, f1, atol=1e-6, rtol=2e-5, scale="max", chan_dim=2, what=tag + " vs splat grad_feat")
     close(d3, d1, atol=1e-6, rtol=2e-5, scale="max", what="bin vs splat grad_depth")
     close(f3, f1, atol=1e-6, rtol=2e-5, scale="max", chan_dim=2, what="bin vs splat grad_feat")
     close(d2, d1, atol=1e-6, rtol=2e-5, scale="max", what="tile vs splat grad_depth")

@@ -57,6 +57,12 @@ int launch_exclusive_scan(const int* cnt, int* off, int* fill, int n, int* total
 // work items (bin, chunk) for lists split into chunks of `chunk` entries; upper bound on the
 // item count: n + total / chunk
 int launch_build_worklist(const int* cnt, int n, int chunk, int* work, int* nwork, hipStream_t s);
+// Two-level exclusive scan of `ncell` counters (ncell a multiple of kScanTile) for the cell lists:
+// afterwards the start offset of cell c is off[c] + boff[c / kScanTile]; bsum / boff / aux hold
+// ncell / kScanTile ints (aux two more) and aux[ncell / kScanTile] receives the grand total.
+constexpr int kScanTile = 2048;
+int launch_cell_scan(const int* cnt, int* off, int* bsum, int* boff, int* aux, long ncell,
+                     hipStream_t s);
 // usage: VAMP_TIMED(slot, stream, kernel<<<...>>>(...));
 #define VAMP_TIMED(slot, stream, launch)              \
   do {                                                \
@@ -93,6 +99,48 @@ __device__ __forceinline__ float nan_to_num(float v) {
   // torch.nan_to_num defaults: nan -> 0, +-inf -> +-FLT_MAX
   if (v != v) return 0.f;
   return fminf(fmaxf(v, -3.402823466e+38f), 3.402823466e+38f);
+}
+
+// ---------------------------------------------------------------------------
+// lane-group reductions
+// ---------------------------------------------------------------------------
+// Sum N per-lane values over the lanes of a W-wide group with recursive halving: at every xor
+// step with an even count each lane keeps one half of the values and hands the other half to its
+// partner, so the step moves N/2 values instead of N (an odd count falls back to a plain
+// butterfly).  On return a[0 .. reduce_left<N, W/2>()) are the complete sums of channels
+// cbase .. ; lanes that differ only in the bits of reduce_dups<N, W/2>() hold copies.
+template <int N, int O>
+constexpr int reduce_left() {
+  if constexpr (O == 0) return N;
+  else if constexpr (N % 2 == 0) return reduce_left<N / 2, O / 2>();
+  else return reduce_left<N, O / 2>();
+}
+template <int N, int O>
+constexpr int reduce_dups() {
+  if constexpr (O == 0) return 0;
+  else if constexpr (N % 2 == 0) return reduce_dups<N / 2, O / 2>();
+  else return O | reduce_dups<N, O / 2>();
+}
+template <int N, int O, int W, int CP>
+__device__ __forceinline__ void reduce_halving(float (&a)[CP], int l, int& cbase) {
+  if constexpr (O == 0) {
+    return;
+  } else if constexpr (N % 2 == 0) {
+    constexpr int H = N / 2;
+    const bool up = (l & O) != 0;
+#pragma unroll
+    for (int c = 0; c < H; ++c) {
+      const float send = up ? a[c] : a[c + H];
+      const float keep = up ? a[c + H] : a[c];
+      a[c] = keep + __shfl_xor(send, O, W);
+    }
+    cbase += up ? H : 0;
+    reduce_halving<H, O / 2, W, CP>(a, l, cbase);
+  } else {
+#pragma unroll
+    for (int c = 0; c < N; ++c) a[c] += __shfl_xor(a[c], O, W);
+    reduce_halving<N, O / 2, W, CP>(a, l, cbase);
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -389,6 +389,8 @@ static LiftWs carve(const VampLiftDesc* d, void* ws) {
   // backward v3 lists + v2 fallback scratch overlay the same region
   const size_t v2 = lift_bwd_bin_ws_bytes(d) + lift_bwd_tile_ws_bytes(d);
   if (v2 > w.bytes) w.bytes = v2;
+  const size_t v4 = lift_bwd_cell_ws_bytes(d);
+  if (v4 > w.bytes) w.bytes = v4;
   return w;
 }
 
@@ -477,6 +479,11 @@ int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs
   // v2 (default): one workgroup per pixel tile with LDS accumulators, no global atomics.
   // VAMP_LIFT_BWD=v1 selects the per-voxel atomic splat, kept as an independent cross-check.
   const char* force = getenv("VAMP_LIFT_BWD");
+  // default: cell list + one wave per pixel (lift_bwd_cell.hip); v3 / v2 / v1 are the earlier
+  // implementations, kept as independent cross-checks
+  if (!(force && force[0] == 'v' && (force[1] == '1' || force[1] == '2' || force[1] == '3')))
+    return launch_lift_bwd_cell(d, mats, xs, ys, zs, depth, feat, grad_out, hits, grad_depth,
+                                grad_feat, workspace, s);
   if (!(force && force[0] == 'v' && force[1] == '1')) {
     // v3 (default): bin (voxel, camera) pairs into per-tile lists, then one workgroup per tile
     // accumulates in LDS.  v2 (tile enumeration) runs only if the lists overflow the workspace

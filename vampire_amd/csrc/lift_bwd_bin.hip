@@ -187,10 +187,10 @@ lift_bwd_bin_kernel(LiftParams P, BinGeom G, const float* __restrict__ mats,
   }
 }
 
-constexpr int kOwnThreads = 1024;       // 64 entry groups per tile: short per-group chains
-
-template <typename T>
-__global__ void __launch_bounds__(kOwnThreads)
+// OT threads per tile = OT / 16 entry groups; MINW = minimum waves per SIMD the register
+// allocation must allow (two 1024-thread workgroups per CU need 8).
+template <typename T, int OT, int MINW>
+__global__ void __launch_bounds__(OT, MINW)
 lift_bwd_own_kernel(LiftParams P, BinGeom G, const T* __restrict__ feat,
                     const int* __restrict__ cnt, const int* __restrict__ off,
                     const float* __restrict__ entries, float* __restrict__ gdepth,
@@ -210,13 +210,13 @@ lift_bwd_own_kernel(LiftParams P, BinGeom G, const T* __restrict__ feat,
   const long HW = (long) P.fH * P.fW;
   const int ES = 8 + C;
 
-  for (int e = tid; e < BTP * C; e += kOwnThreads) {
+  for (int e = tid; e < BTP * C; e += OT) {
     const int c = e / BTP, p = e % BTP;
     const int h = h0 + p / BTW, w = w0 + p % BTW;
     ft[p * CS + c] = (h < P.fH && w < P.fW) ? ldf(feat, (bn * C + c) * HW + (long) h * P.fW + w) : 0.f;
   }
-  for (int e = tid; e < BTP * CS; e += kOwnThreads) gf[e] = 0.f;
-  for (int e = tid; e < D * BTP; e += kOwnThreads) gd[e] = 0.f;
+  for (int e = tid; e < BTP * CS; e += OT) gf[e] = 0.f;
+  for (int e = tid; e < D * BTP; e += OT) gd[e] = 0.f;
   __syncthreads();
 
   const int grp = tid / GLN, gl = tid % GLN;
@@ -227,7 +227,7 @@ lift_bwd_own_kernel(LiftParams P, BinGeom G, const T* __restrict__ feat,
   // four pixels).  The grad_feat contributions of such a run are summed in registers and flushed
   // with one ds_add per pixel when the (ix0, iy0) base changes: same-address LDS float atomics
   // are slow, and the hot pixels are exactly the ones with long runs.
-  constexpr int NGRP = kOwnThreads / GLN;
+  constexpr int NGRP = OT / GLN;
   const int per = (n_ent + NGRP - 1) / NGRP;
   const int j_lo = min(n_ent, grp * per), j_hi = min(n_ent, j_lo + per);
   float run[4] = {0.f, 0.f, 0.f, 0.f};
@@ -300,28 +300,28 @@ lift_bwd_own_kernel(LiftParams P, BinGeom G, const T* __restrict__ feat,
         }
       }
       if (P.use_depth) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (pj[j] < 0) continue;                           // uniform over the group
-          float dj = dot[j];
-#pragma unroll
-          for (int o = GLN >> 1; o > 0; o >>= 1) dj += __shfl_xor(dj, o, GLN);
-          const float gdj = wj[j] * dj;
-          if (gl == 0 && iz0 >= 0 && iz0 < P.D) atomicAdd(gd + iz0 * BTP + pj[j], wz0 * gdj);
-          if (gl == 1 && iz0 + 1 >= 0 && iz0 + 1 < P.D) atomicAdd(gd + (iz0 + 1) * BTP + pj[j], wz1 * gdj);
-        }
+        // channel dot products of the four taps, summed over the 16 lanes by recursive halving:
+        // afterwards lane l holds tap (l >> 2); its lanes 0 / 1 (of 4) add the two depth planes
+        int tj = 0;
+        reduce_halving<4, GLN / 2, GLN, 4>(dot, gl, tj);
+        const int pjs = tj == 0 ? pj[0] : (tj == 1 ? pj[1] : (tj == 2 ? pj[2] : pj[3]));
+        const float wjs = tj == 0 ? wj[0] : (tj == 1 ? wj[1] : (tj == 2 ? wj[2] : wj[3]));
+        const int sub = gl & 3;
+        const int iz = iz0 + sub;
+        if (sub < 2 && pjs >= 0 && iz >= 0 && iz < P.D)
+          atomicAdd(gd + iz * BTP + pjs, (sub ? wz1 : wz0) * (wjs * dot[0]));
       }
     }
   }
   flush();
   __syncthreads();
-  for (int e = tid; e < BTP * C; e += kOwnThreads) {
+  for (int e = tid; e < BTP * C; e += OT) {
     const int c = e / BTP, p = e % BTP;
     const int h = h0 + p / BTW, w = w0 + p % BTW;
     if (h < P.fH && w < P.fW) gfeat[(bn * C + c) * HW + (long) h * P.fW + w] = gf[p * CS + c];
   }
   if (P.use_depth && gdepth)
-    for (int e = tid; e < D * BTP; e += kOwnThreads) {
+    for (int e = tid; e < D * BTP; e += OT) {
       const int dz = e / BTP, p = e % BTP;
       const int h = h0 + p / BTW, w = w0 + p % BTW;
       if (h < P.fH && w < P.fW) gdepth[(bn * P.D + dz) * HW + (long) h * P.fW + w] = gd[e];
@@ -382,13 +382,21 @@ static int launch_bin_t(const VampLiftDesc* d, const LiftParams& P, const float*
   const int Dd = d->use_depth ? d->D : 0;
   const size_t lds = ((size_t) 2 * BTP * (d->C + 1) + (size_t) Dd * BTP) * sizeof(float);
   if (lds > 150 * 1024) return fail(VAMP_EINVAL, "%s: D too large for the LDS tile", __func__);
-  auto k = lift_bwd_own_kernel<T>;
-  if (lds > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int) lds) != hipSuccess)
-    return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);
-  VAMP_TIMED(kProfLiftBwd, s, (k<<<(unsigned) nb, kOwnThreads, lds, s>>>(
-      P, G, static_cast<const T*>(feat), cnt, off, entries, gdepth, gfeat, total, cap)));
+  const char* eot = getenv("VAMP_LIFT_OWN");
+  const int variant = eot ? atoi(eot) : 0;
+#define VAMP_OWN(OT, MINW)                                                                        \
+  do {                                                                                            \
+    auto k = lift_bwd_own_kernel<T, OT, MINW>;                                                    \
+    if (lds > 64 * 1024 &&                                                                        \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                     \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) \
+      return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);                           \
+    VAMP_TIMED(kProfLiftBwd, s, (k<<<(unsigned) nb, OT, lds, s>>>(                                \
+        P, G, static_cast<const T*>(feat), cnt, off, entries, gdepth, gfeat, total, cap)));       \
+  } while (0)
+  if (variant == 1) VAMP_OWN(512, 1); else if (variant == 2) VAMP_OWN(1024, 8);
+  else if (variant == 3) VAMP_OWN(512, 8); else if (variant == 4) VAMP_OWN(256, 1); else VAMP_OWN(1024, 1);
+#undef VAMP_OWN
   return check_launch("lift_bwd_own_kernel");
 }
 

@@ -1,0 +1,375 @@
+// LIFT backward as a cell list ("sort, then own").  Autograd of base_vampire2.py:507-514
+// (grid_sampler_3d backward + the camera mean):
+//
+//   count   thread per voxel, forward's bit-exact projection: every valid (voxel, camera) pair
+//           increments the counter of its cell = (camera, floor tap row + 1, floor tap column + 1),
+//           (fH + 1) x (fW + 1) cells per camera
+//   scan    two-level exclusive prefix sum of the counters -> cell start offsets (runtime.hip)
+//   fill    same walk; the pair's record {ix0, iy0, iz0, wz0, wz1 | w[4]*dep[4] | w[4] | gs[C]} --
+//           tap weights, depth-interpolated values, grad_out / (hits + 1e-6) -- goes to the next
+//           slot of its cell (slots handed out by atomics on the cell cursor)
+//   gather  one wave (or 4, or 16) per feature-map pixel: the pairs whose 2x2 pixel taps include pixel (x, y)
+//           are exactly those of the cells (x..x+1, y..y+1), two contiguous record ranges.  The
+//           four 16-lane quarters of the wave take records in turn, lane = channel: grad_feat
+//           accumulates in registers, the channel dot product feeds the two depth bins of the
+//           pixel's private LDS column.  Every output element is stored once.
+//
+// Both atomic passes aggregate runs of equal cells across the lanes of a wave (x-neighbouring
+// voxels share a cell in the far field), one atomic per run: device-scope atomics are served at
+// the memory side on this part and cost ~1 us each.
+// No float atomics on global memory, no memset of the outputs, no layout transposes.
+#include "lift_common.hpp"
+
+namespace vamp {
+
+constexpr int LGL = 16;              // lanes per record = channel lanes
+constexpr int LPB = 16;              // pixels (waves) per gather workgroup
+constexpr int kRecHead = 16;         // floats before gs[] in a record
+
+struct LiftCells {
+  int cw, ch;                        // cells per row / column of one camera
+  long ncell;                        // padded to the scan tile, + 2 for the range ends
+};
+
+static LiftCells lift_cells(const VampLiftDesc* d) {
+  LiftCells g;
+  g.cw = d->fW + 1;
+  g.ch = d->fH + 1;
+  const long nc = (long) d->B * d->N * g.cw * g.ch + 2;
+  g.ncell = (nc + kScanTile - 1) / kScanTile * kScanTile;
+  return g;
+}
+
+// Run aggregation over the lanes of a wave: lanes with act and equal `cell` that are adjacent form
+// a run; returns the run's first lane and length (valid for act lanes), `head` for the first lane.
+struct LaneRun {
+  bool head;
+  int start, len;
+};
+__device__ __forceinline__ LaneRun lane_run(bool act, long cell, int lane) {
+  const long pcell = __shfl_up(cell, 1, 64);
+  const unsigned long long vm = __ballot(act);
+  const bool pact = lane > 0 && ((vm >> (lane - 1)) & 1ull);
+  LaneRun r;
+  r.head = act && (!pact || pcell != cell);
+  const unsigned long long hm = __ballot(r.head);
+  const unsigned long long upto = ~0ull >> (63 - lane);
+  r.start = 63 - __clzll((long long) (hm & upto));
+  const unsigned long long brk = (hm | ~vm) & ~upto;
+  const int end = brk ? __ffsll((long long) brk) - 1 : 64;
+  r.len = end - r.start;
+  return r;
+}
+
+// ---------------------------------------------------------------------------
+// count / fill: thread per voxel, the 64 lanes of a wave are 64 x-consecutive voxels
+// ---------------------------------------------------------------------------
+template <typename T, int CH, bool FILL>
+__global__ void __launch_bounds__(256)
+lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mats,
+                     const float* __restrict__ xs, const float* __restrict__ ys,
+                     const float* __restrict__ zs, const T* __restrict__ depth,
+                     const float* __restrict__ gout, const uint64_t* __restrict__ hits,
+                     int* __restrict__ cnt, const int* __restrict__ off,
+                     const int* __restrict__ boff, float* __restrict__ entries) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int x = blockIdx.x * 64 + lane;
+  const int y = blockIdx.y * 4 + (tid >> 6);
+  const int z = blockIdx.z % P.Z, b = blockIdx.z / P.Z;
+  const bool live = x < P.X && y < P.Y;
+  const int xc = min(x, P.X - 1), yc = min(y, P.Y - 1);
+  const float vx = xs[xc], vy = ys[yc], vz = zs[z];
+  const long V = (long) P.Z * P.Y * P.X;
+  const long vox = ((long) z * P.Y + yc) * P.X + xc;
+  const long HW = (long) P.fH * P.fW;
+  const int ES = kRecHead + P.C;
+
+  for (int n = 0; n < P.N; ++n) {
+    const long bn = (long) b * P.N + n;
+    const LiftTap t = lift_project(P, mats + bn * 48, vx, vy, vz);
+    // at least one of the four pixel taps must exist
+    const bool act = live && t.valid && t.ix0 >= -1 && t.ix0 < P.fW && t.iy0 >= -1 && t.iy0 < P.fH;
+    const long cell = (bn * ch + (t.iy0 + 1)) * cw + (t.ix0 + 1);
+    const LaneRun r = lane_run(act, cell, lane);
+    if (!FILL) {
+      if (r.head) atomicAdd(cnt + cell, r.len);
+      continue;
+    }
+    int base = 0;
+    if (r.head) base = atomicAdd(cnt + cell, r.len);
+    base = __shfl(base, act ? r.start : lane, 64);
+    if (!act) continue;
+    const long slot = (long) off[cell] + boff[cell / kScanTile] + base + (lane - r.start);
+    float* e = entries + slot * ES;
+
+    const float wj[4] = {t.wy0 * t.wx0, t.wy0 * t.wx1, t.wy1 * t.wx0, t.wy1 * t.wx1};
+    float dep[4] = {0.f, 0.f, 0.f, 0.f};
+    if (P.use_depth) {
+      const T* dptr = depth + bn * P.D * HW;
+#pragma unroll
+      for (int kz = 0; kz < 2; ++kz) {
+        const int iz = t.iz0 + kz;
+        const bool zin = iz >= 0 && iz < P.D;
+        const float wz = zin ? (kz ? t.wz1 : t.wz0) : 0.f;
+        const long zo = (long) min(max(iz, 0), P.D - 1) * HW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int iy = t.iy0 + (j >> 1), ix = t.ix0 + (j & 1);
+          const bool in = iy >= 0 && iy < P.fH && ix >= 0 && ix < P.fW;
+          dep[j] += (in ? wz : 0.f) *
+                    ldf(dptr, zo + (long) min(max(iy, 0), P.fH - 1) * P.fW + min(max(ix, 0), P.fW - 1));
+        }
+      }
+    } else {
+      const float w = (t.iz0 == 0 ? t.wz0 : 0.f) + (t.iz0 == -1 ? t.wz1 : 0.f);
+      dep[0] = dep[1] = dep[2] = dep[3] = w;
+    }
+    float4* e4 = reinterpret_cast<float4*>(e);
+    e4[0] = make_float4(__int_as_float(t.ix0), __int_as_float(t.iy0), __int_as_float(t.iz0), 0.f);
+    e4[1] = make_float4(t.wz0, t.wz1, 0.f, 0.f);
+    e4[2] = make_float4(wj[0] * dep[0], wj[1] * dep[1], wj[2] * dep[2], wj[3] * dep[3]);
+    e4[3] = make_float4(wj[0], wj[1], wj[2], wj[3]);
+    // grad_out / (hit count + 1e-6), the camera-mean factor of bv2:512-514
+    for (int chunk = 0; chunk < P.C / CH; ++chunk) {
+      const uint64_t hw = hits[((long) b * V + vox) * (P.C / CH) + chunk];
+      const float* g = gout + ((long) b * P.C + chunk * CH) * V + vox;
+#pragma unroll
+      for (int c4 = 0; c4 < CH; c4 += 4) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          v[k] = g[(long) (c4 + k) * V] / ((float) ((hw >> (4 * (c4 + k))) & 15) + 1e-6f);
+        *reinterpret_cast<float4*>(e + kRecHead + chunk * CH + c4) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// gather: wpp waves per pixel (1, 4 or 16, chosen on the host from the expected records per
+// pixel), LPB waves per workgroup
+// ---------------------------------------------------------------------------
+// NCH = ceil(C / 16) channel chunks per lane
+template <typename T, int NCH>
+__global__ void __launch_bounds__(LPB * 64)
+lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, const T* __restrict__ feat,
+                            const int* __restrict__ off, const int* __restrict__ boff,
+                            const float* __restrict__ entries, float* __restrict__ gdepth,
+                            float* __restrict__ gfeat) {
+  extern __shared__ float smem[];                // [ppb][Dp] depth columns, then [LPB][NCH * 16]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int q = lane >> 4, l = lane & 15;        // quarter of the wave, channel lane
+  const int C = P.C, D = P.use_depth ? P.D : 0;
+  const int Dp = D | 1;
+  const int ppb = LPB / wpp;                     // pixels per workgroup
+  const int pw = wv / wpp, ws = wv % wpp;        // pixel of this wave, wave index inside the pixel
+  float* gd = smem;
+  float* accbuf = smem + ppb * Dp;
+  const long HW = (long) P.fH * P.fW;
+  const long npix = (long) P.B * P.N * HW;
+  const long pid0 = (long) blockIdx.x * ppb;
+  const long pid = min(pid0 + pw, npix - 1);
+  const bool pix_ok = pid0 + pw < npix;
+  const long bn = pid / HW;
+  const int pix = (int) (pid % HW);
+  const int iy = pix / P.fW, ix = pix % P.fW;
+  const int ES = kRecHead + C;
+
+  float* gcol = gd + pw * Dp;
+  for (int dz = ws * 64 + lane; dz < D; dz += wpp * 64) gcol[dz] = 0.f;
+  __syncthreads();
+
+  // record ranges of cell rows iy and iy + 1, columns ix .. ix + 1
+  int beg0, n0, beg1, tot;
+  {
+    const int r = (lane >> 1) & 1;
+    const long c = (bn * ch + iy + r) * cw + ix + 2 * (lane & 1);
+    const int sv = off[c] + boff[c / kScanTile];
+    beg0 = __shfl(sv, 0, 64);
+    n0 = __shfl(sv, 1, 64) - beg0;
+    beg1 = __shfl(sv, 2, 64);
+    tot = n0 + __shfl(sv, 3, 64) - beg1;
+  }
+  if (!pix_ok) tot = 0;
+
+  float ftc[NCH], acc[NCH];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int c = l + 16 * k;
+    ftc[k] = (c < C) ? ldf(feat, (bn * C + c) * HW + pix) : 0.f;
+    acc[k] = 0.f;
+  }
+
+  constexpr int UB = 2;                          // records per quarter per round: loads go out together
+  for (int k0 = ws * 4 * UB; k0 < tot; k0 += wpp * 4 * UB) {
+    float4 ha[UB], hb[UB], pwv[UB], ww[UB];
+    float gs[UB][NCH];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int kc = min(k0 + u * 4 + q, tot - 1);
+      const long pos = kc < n0 ? (long) beg0 + kc : (long) beg1 + (kc - n0);
+      const float* e = entries + pos * ES;
+      ha[u] = *reinterpret_cast<const float4*>(e);
+      hb[u] = *reinterpret_cast<const float4*>(e + 4);
+      pwv[u] = *reinterpret_cast<const float4*>(e + 8);
+      ww[u] = *reinterpret_cast<const float4*>(e + 12);
+#pragma unroll
+      for (int kk = 0; kk < NCH; ++kk) gs[u][kk] = (l + 16 * kk < C) ? e[kRecHead + l + 16 * kk] : 0.f;
+    }
+    float dots[UB], wz0s[UB], wz1s[UB];
+    int iz0s[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int ix0 = __float_as_int(ha[u].x), iy0 = __float_as_int(ha[u].y);
+      const int j = (iy - iy0) * 2 + (ix - ix0);         // which of the record's taps this pixel is
+      const float pwj = j == 0 ? pwv[u].x : (j == 1 ? pwv[u].y : (j == 2 ? pwv[u].z : pwv[u].w));
+      const float wj = j == 0 ? ww[u].x : (j == 1 ? ww[u].y : (j == 2 ? ww[u].z : ww[u].w));
+      const float live = (k0 + u * 4 + q < tot) ? 1.f : 0.f;
+      float dot = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < NCH; ++kk) {
+        acc[kk] = __builtin_fmaf(live * pwj, gs[u][kk], acc[kk]);
+        dot = __builtin_fmaf(ftc[kk], gs[u][kk], dot);
+      }
+      dots[u] = live * wj * dot;
+      iz0s[u] = __float_as_int(ha[u].z);
+      wz0s[u] = hb[u].x;
+      wz1s[u] = hb[u].y;
+    }
+    if (D > 0) {
+      // channel sums of the UB records over the 16 lanes of the quarter by recursive halving:
+      // lanes 8u .. 8u+7 end up with record u, and the first two of them add the two depth planes
+      int tu = 0;
+      reduce_halving<UB, 8, 16, UB>(dots, l, tu);
+      const int iz0 = tu ? iz0s[1] : iz0s[0];
+      const int sub = l & 7;
+      const int iz = iz0 + sub;
+      const float wz = sub ? (tu ? wz1s[1] : wz1s[0]) : (tu ? wz0s[1] : wz0s[0]);
+      if (sub < 2 && iz >= 0 && iz < D && dots[0] != 0.f) atomicAdd(gcol + iz, wz * dots[0]);
+    }
+  }
+  // sum the four quarters' grad_feat partials (lanes l, l+16, l+32, l+48), then the pixel's waves
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    float v = acc[k];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (q == 0) accbuf[wv * (NCH * 16) + l + 16 * k] = v;
+  }
+  __syncthreads();
+  if (ws == 0 && q == 0 && pix_ok) {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int c = l + 16 * k;
+      float v = 0.f;
+      for (int s2 = 0; s2 < wpp; ++s2) v += accbuf[(wv + s2) * (NCH * 16) + c];
+      if (c < C) gfeat[(bn * C + c) * HW + pix] = v;
+    }
+  }
+  if (D > 0 && gdepth) {
+    // consecutive threads = consecutive pixels of one depth plane
+    for (int e = tid; e < D * ppb; e += LPB * 64) {
+      const int dz = e / ppb, p = e % ppb;
+      const long pp = pid0 + p;
+      if (pp >= npix) continue;
+      gdepth[((pp / HW) * P.D + dz) * HW + pp % HW] = gd[p * Dp + dz];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct LiftCellWs {
+  int *cnt, *off, *bsum, *boff, *aux;
+  float* entries;
+  size_t bytes;
+};
+
+static LiftCellWs lift_cell_ws(const VampLiftDesc* d, void* scratch) {
+  const LiftCells g = lift_cells(d);
+  const long ntile = g.ncell / kScanTile;
+  // every (voxel, camera) pair can be valid
+  const size_t cap = (size_t) d->B * d->N * d->Z * d->Y * d->X;
+  char* p = static_cast<char*>(scratch);
+  LiftCellWs w;
+  w.cnt = reinterpret_cast<int*>(p); p += align_up((size_t) g.ncell * sizeof(int), 256);
+  w.off = reinterpret_cast<int*>(p); p += align_up((size_t) g.ncell * sizeof(int), 256);
+  w.bsum = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
+  w.boff = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
+  w.aux = reinterpret_cast<int*>(p); p += align_up((size_t) (ntile + 4) * sizeof(int), 256);
+  w.entries = reinterpret_cast<float*>(p); p += align_up(cap * (kRecHead + d->C) * sizeof(float), 256);
+  w.bytes = (size_t) (p - static_cast<char*>(scratch));
+  return w;
+}
+
+size_t lift_bwd_cell_ws_bytes(const VampLiftDesc* d) { return lift_cell_ws(d, nullptr).bytes; }
+
+template <typename T>
+static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float* mats,
+                         const float* xs, const float* ys, const float* zs, const void* depth,
+                         const void* feat, const float* gout, const uint64_t* hits, float* gdepth,
+                         float* gfeat, void* scratch, hipStream_t s) {
+  const LiftCells g = lift_cells(d);
+  const LiftCellWs w = lift_cell_ws(d, scratch);
+  const size_t cap = (size_t) d->B * d->N * d->Z * d->Y * d->X;
+  VAMP_REQUIRE(cap < 0x7fffffffu && g.ncell < 0x7fffffffL, "pair / cell count exceeds 2^31");
+  if (hipMemsetAsync(w.cnt, 0, (size_t) g.ncell * sizeof(int), s) != hipSuccess)
+    return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
+  dim3 grid((d->X + 63) / 64, (d->Y + 3) / 4, d->Z * d->B);
+  const T* dp = static_cast<const T*>(depth);
+#define VAMP_CELL(CH, FILLV)                                                                     \
+  VAMP_TIMED(FILLV ? kProfLiftBwdFill : kProfLiftBwdCount, s,                                   \
+             (lift_bwd_cell_kernel<T, CH, FILLV><<<grid, 256, 0, s>>>(                          \
+                 P, g.cw, g.ch, mats, xs, ys, zs, dp, gout, hits, w.cnt, w.off, w.boff, w.entries)))
+  if (P.C == 4) VAMP_CELL(4, false); else if (P.C == 8) VAMP_CELL(8, false); else VAMP_CELL(16, false);
+  if (int e = check_launch("lift_bwd_cell_kernel<count>")) return e;
+  if (int e = launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, g.ncell, s)) return e;
+  // the counters become the fill cursors
+  if (hipMemsetAsync(w.cnt, 0, (size_t) g.ncell * sizeof(int), s) != hipSuccess)
+    return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
+  if (P.C == 4) VAMP_CELL(4, true); else if (P.C == 8) VAMP_CELL(8, true); else VAMP_CELL(16, true);
+#undef VAMP_CELL
+  if (int e = check_launch("lift_bwd_cell_kernel<fill>")) return e;
+
+  // waves per pixel from the expected records per pixel (4 taps x voxels per camera pixel)
+  const long npix = (long) d->B * d->N * d->fH * d->fW;
+  const double per_pix = 4.0 * (double) d->B * d->Z * d->Y * d->X / (double) npix;
+  const char* ew = getenv("VAMP_LIFT_WPP");
+  int wpp = per_pix <= 96.0 ? 1 : (per_pix <= 768.0 ? 4 : 16);
+  if (ew && (atoi(ew) == 1 || atoi(ew) == 4 || atoi(ew) == 16)) wpp = atoi(ew);
+  const int ppb = LPB / wpp;
+  const int Dd = d->use_depth ? d->D : 0;
+  const size_t lds = ((size_t) ppb * (Dd | 1) + (size_t) LPB * ((d->C + 15) / 16) * 16) * sizeof(float);
+  if (lds > 150 * 1024) return fail(VAMP_EINVAL, "%s: D too large for the LDS depth columns", __func__);
+  const unsigned ggrid = (unsigned) ((npix + ppb - 1) / ppb);
+  const int nch = (d->C + 15) / 16;
+#define VAMP_GATHER(NCH)                                                                          \
+  do {                                                                                            \
+    auto k = lift_bwd_cell_gather_kernel<T, NCH>;                                                 \
+    if (lds > 64 * 1024 &&                                                                        \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                     \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) \
+      return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);                           \
+    VAMP_TIMED(kProfLiftBwd, s, (k<<<ggrid, LPB * 64, lds, s>>>(                                  \
+        P, g.cw, g.ch, wpp, static_cast<const T*>(feat), w.off, w.boff, w.entries, gdepth,      \
+        gfeat)));                                                                                 \
+  } while (0)
+  if (nch == 1) VAMP_GATHER(1); else if (nch == 2) VAMP_GATHER(2); else if (nch == 3) VAMP_GATHER(3);
+  else VAMP_GATHER(4);
+#undef VAMP_GATHER
+  return check_launch("lift_bwd_cell_gather_kernel");
+}
+
+int launch_lift_bwd_cell(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
+                         const float* zs, const void* depth, const void* feat, const float* gout,
+                         const uint64_t* hits, float* gdepth, float* gfeat, void* scratch,
+                         hipStream_t s) {
+  const LiftParams P = to_params(d);
+  if (d->in_dtype == VAMP_F32)
+    return launch_cell_t<float>(d, P, mats, xs, ys, zs, depth, feat, gout, hits, gdepth, gfeat, scratch, s);
+  return launch_cell_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, feat, gout, hits, gdepth, gfeat,
+                                       scratch, s);
+}
+
+}  // namespace vamp

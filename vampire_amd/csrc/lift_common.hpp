@@ -79,4 +79,11 @@ int launch_lift_bwd_bin(const VampLiftDesc* d, const float* mats, const float* x
                         const uint64_t* hits, float* gdepth, float* gfeat, void* scratch,
                         const int** total_out, int* cap_out, hipStream_t s);
 
+// lift_bwd_cell.hip
+size_t lift_bwd_cell_ws_bytes(const VampLiftDesc* d);
+int launch_lift_bwd_cell(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
+                         const float* zs, const void* depth, const void* feat, const float* gout,
+                         const uint64_t* hits, float* gdepth, float* gfeat, void* scratch,
+                         hipStream_t s);
+
 }  // namespace vamp

@@ -25,7 +25,6 @@
 namespace vamp {
 
 constexpr int kHeavy = 256;          // records per voxel beyond which the whole-workgroup kernel runs
-constexpr int kScanTile = 2048;      // cells per scan workgroup (256 threads x 8)
 
 static long cell_count_padded(int B, int Z, int Y, int X) {
   const long nc = (long) B * (Z + 1) * (Y + 1) * (X + 1) + 2;      // +2: the gather reads start[c + 2]
@@ -68,45 +67,6 @@ cam_bwd_rank_kernel(RenderParams P, const int* __restrict__ KEY, int* __restrict
   if (head) base = atomicAdd(cnt + cell, end - lane);
   base = __shfl(base, valid ? start : lane, 64);
   if (valid) RANK[sidx] = base + (lane - start);
-}
-
-// ---------------------------------------------------------------------------
-// scan, level 1: exclusive scan inside each 2048-cell tile, tile totals to bsum
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-cell_scan_tile_kernel(const int* __restrict__ cnt, int* __restrict__ off, int* __restrict__ bsum) {
-  __shared__ int wsum[4];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const long base = (long) blockIdx.x * kScanTile + tid * 8;
-  const int4* c4 = reinterpret_cast<const int4*>(cnt + base);
-  const int4 a = c4[0], b = c4[1];
-  const int v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-  int tsum = 0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) tsum += v[k];
-  int incl = tsum;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int up = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += up;
-  }
-  if (lane == 63) wsum[wv] = incl;
-  __syncthreads();
-  int wbase = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (k < wv) wbase += wsum[k];
-  int run = wbase + incl - tsum;
-  int o8[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    o8[k] = run;
-    run += v[k];
-  }
-  int4* o4 = reinterpret_cast<int4*>(off + base);
-  o4[0] = make_int4(o8[0], o8[1], o8[2], o8[3]);
-  o4[1] = make_int4(o8[4], o8[5], o8[6], o8[7]);
-  if (tid == 255) bsum[blockIdx.x] = run;
 }
 
 // ---------------------------------------------------------------------------
@@ -209,45 +169,6 @@ __device__ __forceinline__ void cell_accumulate(const CellRanges& cr, int k0, in
       acc[c4 * 4 + 2] = __builtin_fmaf(Wv, f.z, acc[c4 * 4 + 2]);
       acc[c4 * 4 + 3] = __builtin_fmaf(Wv, f.w, acc[c4 * 4 + 3]);
     }
-  }
-}
-
-// Sum N per-lane values over the lanes of a W-wide group with recursive halving: at every xor
-// step with an even count each lane keeps one half of the values and hands the other half to its
-// partner, so the step moves N/2 values instead of N (an odd count falls back to a plain
-// butterfly).  On return a[0 .. reduce_left<N, W/2>()) are the complete sums of channels
-// cbase .. ; lanes that differ only in the bits of reduce_dups<N, W/2>() hold copies.
-template <int N, int O>
-constexpr int reduce_left() {
-  if constexpr (O == 0) return N;
-  else if constexpr (N % 2 == 0) return reduce_left<N / 2, O / 2>();
-  else return reduce_left<N, O / 2>();
-}
-template <int N, int O>
-constexpr int reduce_dups() {
-  if constexpr (O == 0) return 0;
-  else if constexpr (N % 2 == 0) return reduce_dups<N / 2, O / 2>();
-  else return O | reduce_dups<N, O / 2>();
-}
-template <int N, int O, int W, int CP>
-__device__ __forceinline__ void reduce_halving(float (&a)[CP], int l, int& cbase) {
-  if constexpr (O == 0) {
-    return;
-  } else if constexpr (N % 2 == 0) {
-    constexpr int H = N / 2;
-    const bool up = (l & O) != 0;
-#pragma unroll
-    for (int c = 0; c < H; ++c) {
-      const float send = up ? a[c] : a[c + H];
-      const float keep = up ? a[c + H] : a[c];
-      a[c] = keep + __shfl_xor(send, O, W);
-    }
-    cbase += up ? H : 0;
-    reduce_halving<H, O / 2, W, CP>(a, l, cbase);
-  } else {
-#pragma unroll
-    for (int c = 0; c < N; ++c) a[c] += __shfl_xor(a[c], O, W);
-    reduce_halving<N, O / 2, W, CP>(a, l, cbase);
   }
 }
 
@@ -420,10 +341,7 @@ int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const fl
   VAMP_TIMED(kProfCamBwdCount, s, (cam_bwd_rank_kernel<<<sgrid, 256, 0, s>>>(
       P, KEY, w.cnt, w.rank, (unsigned) samples, ncell_b)));
   if (int e = check_launch("cam_bwd_rank_kernel")) return e;
-  VAMP_TIMED(kProfAux, s, (cell_scan_tile_kernel<<<(unsigned) ntile, 256, 0, s>>>(w.cnt, w.off, w.bsum)));
-  if (int e = check_launch("cell_scan_tile_kernel")) return e;
-  // level 2: exclusive scan of the tile totals; aux[ntile] receives the record total
-  if (int e = launch_exclusive_scan(w.bsum, w.boff, w.aux, (int) ntile, w.aux + ntile, s)) return e;
+  if (int e = launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, ncell, s)) return e;
   int* nheavy = w.aux + ntile + 1;
   if (hipMemsetAsync(nheavy, 0, sizeof(int), s) != hipSuccess)
     return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);

@@ -169,6 +169,54 @@ build_worklist_kernel(const int* __restrict__ cnt, int n, int chunk, int* __rest
   if (tid == 0) *nwork = carry;
 }
 
+// Level 1 of the cell-list scan: exclusive scan inside each kScanTile-cell tile (256 threads x 8
+// cells), tile totals to bsum.
+__global__ void __launch_bounds__(256)
+cell_scan_tile_kernel(const int* __restrict__ cnt, int* __restrict__ off, int* __restrict__ bsum) {
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long base = (long) blockIdx.x * kScanTile + tid * 8;
+  const int4* c4 = reinterpret_cast<const int4*>(cnt + base);
+  const int4 a = c4[0], b = c4[1];
+  const int v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  int tsum = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) tsum += v[k];
+  int incl = tsum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  int wbase = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < wv) wbase += wsum[k];
+  int run = wbase + incl - tsum;
+  int o8[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    o8[k] = run;
+    run += v[k];
+  }
+  int4* o4 = reinterpret_cast<int4*>(off + base);
+  o4[0] = make_int4(o8[0], o8[1], o8[2], o8[3]);
+  o4[1] = make_int4(o8[4], o8[5], o8[6], o8[7]);
+  if (tid == 255) bsum[blockIdx.x] = run;
+}
+
+int launch_cell_scan(const int* cnt, int* off, int* bsum, int* boff, int* aux, long ncell,
+                     hipStream_t s) {
+  const long ntile = ncell / kScanTile;
+  if (ncell % kScanTile != 0 || ntile > 0x7fffffffL)
+    return fail(VAMP_EINVAL, "%s: cell count must be a multiple of the scan tile", __func__);
+  VAMP_TIMED(kProfAux, s, (cell_scan_tile_kernel<<<(unsigned) ntile, 256, 0, s>>>(cnt, off, bsum)));
+  if (int e = check_launch("cell_scan_tile_kernel")) return e;
+  return launch_exclusive_scan(bsum, boff, aux, (int) ntile, aux + ntile, s);
+}
+
 int launch_build_worklist(const int* cnt, int n, int chunk, int* work, int* nwork, hipStream_t s) {
   VAMP_TIMED(kProfAux, s, (build_worklist_kernel<<<1, 1024, 0, s>>>(cnt, n, chunk, work, nwork)));
   return check_launch("build_worklist_kernel");
