@@ -20,10 +20,12 @@
 // No float atomics on global memory, no memset of the outputs, no layout transposes.
 #include "lift_common.hpp"
 
+#include <algorithm>
+
 namespace vamp {
 
 constexpr int LGL = 16;              // lanes per record = channel lanes
-constexpr int LPB = 16;              // pixels (waves) per gather workgroup
+constexpr int kMinWaves = 4;         // waves per gather workgroup (more when a pixel takes more)
 constexpr int kRecHead = 16;         // floats before gs[] in a record
 
 struct LiftCells {
@@ -84,84 +86,119 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
   const long HW = (long) P.fH * P.fW;
   const int ES = kRecHead + P.C;
 
-  for (int n = 0; n < P.N; ++n) {
-    const long bn = (long) b * P.N + n;
-    const LiftTap t = lift_project(P, mats + bn * 48, vx, vy, vz);
-    // at least one of the four pixel taps must exist
-    const bool act = live && t.valid && t.ix0 >= -1 && t.ix0 < P.fW && t.iy0 >= -1 && t.iy0 < P.fH;
-    const long cell = (bn * ch + (t.iy0 + 1)) * cw + (t.ix0 + 1);
-    const LaneRun r = lane_run(act, cell, lane);
-    if (!FILL) {
-      if (r.head) atomicAdd(cnt + cell, r.len);
-      continue;
-    }
-    int base = 0;
-    if (r.head) base = atomicAdd(cnt + cell, r.len);
-    base = __shfl(base, act ? r.start : lane, 64);
-    if (!act) continue;
-    const long slot = (long) off[cell] + boff[cell / kScanTile] + base + (lane - r.start);
-    float* e = entries + slot * ES;
+  constexpr int NB = 8;                          // cameras per batch: their atomics are in flight together
+  const bool first_chunk_only = P.C == CH;
+  // grad_out / (hit count + 1e-6), the camera-mean factor of bv2:512-514: the same for every
+  // camera of the voxel, loaded before the atomics so that both latencies overlap
+  float gs0[CH];
+  if (FILL) {
+    const uint64_t hw = live ? hits[((long) b * V + vox) * (P.C / CH)] : 0;
+    const float* g = gout + (long) b * P.C * V + vox;
+#pragma unroll
+    for (int k = 0; k < CH; ++k)
+      gs0[k] = (live ? g[(long) k * V] : 0.f) / ((float) ((hw >> (4 * k)) & 15) + 1e-6f);
+  }
 
-    const float wj[4] = {t.wy0 * t.wx0, t.wy0 * t.wx1, t.wy1 * t.wx0, t.wy1 * t.wx1};
-    float dep[4] = {0.f, 0.f, 0.f, 0.f};
-    if (P.use_depth) {
-      const T* dptr = depth + bn * P.D * HW;
+  for (int n0 = 0; n0 < P.N; n0 += NB) {
+    int base[NB], start[NB];
+    unsigned actm = 0;
 #pragma unroll
-      for (int kz = 0; kz < 2; ++kz) {
-        const int iz = t.iz0 + kz;
-        const bool zin = iz >= 0 && iz < P.D;
-        const float wz = zin ? (kz ? t.wz1 : t.wz0) : 0.f;
-        const long zo = (long) min(max(iz, 0), P.D - 1) * HW;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int iy = t.iy0 + (j >> 1), ix = t.ix0 + (j & 1);
-          const bool in = iy >= 0 && iy < P.fH && ix >= 0 && ix < P.fW;
-          dep[j] += (in ? wz : 0.f) *
-                    ldf(dptr, zo + (long) min(max(iy, 0), P.fH - 1) * P.fW + min(max(ix, 0), P.fW - 1));
-        }
+    for (int k = 0; k < NB; ++k) {
+      const int n = n0 + k;
+      base[k] = 0;
+      start[k] = lane;
+      if (n >= P.N) continue;                    // uniform
+      const long bn = (long) b * P.N + n;
+      const LiftTap t = lift_project(P, mats + bn * 48, vx, vy, vz);
+      // at least one of the four pixel taps must exist
+      const bool act = live && t.valid && t.ix0 >= -1 && t.ix0 < P.fW && t.iy0 >= -1 && t.iy0 < P.fH;
+      const long cell = (bn * ch + (t.iy0 + 1)) * cw + (t.ix0 + 1);
+      const LaneRun r = lane_run(act, cell, lane);
+      if (r.head) {
+        if (FILL) base[k] = atomicAdd(cnt + cell, r.len);
+        else atomicAdd(cnt + cell, r.len);
       }
-    } else {
-      const float w = (t.iz0 == 0 ? t.wz0 : 0.f) + (t.iz0 == -1 ? t.wz1 : 0.f);
-      dep[0] = dep[1] = dep[2] = dep[3] = w;
+      if (act) { actm |= 1u << k; start[k] = r.start; }
     }
-    float4* e4 = reinterpret_cast<float4*>(e);
-    e4[0] = make_float4(__int_as_float(t.ix0), __int_as_float(t.iy0), __int_as_float(t.iz0), 0.f);
-    e4[1] = make_float4(t.wz0, t.wz1, 0.f, 0.f);
-    e4[2] = make_float4(wj[0] * dep[0], wj[1] * dep[1], wj[2] * dep[2], wj[3] * dep[3]);
-    e4[3] = make_float4(wj[0], wj[1], wj[2], wj[3]);
-    // grad_out / (hit count + 1e-6), the camera-mean factor of bv2:512-514
-    for (int chunk = 0; chunk < P.C / CH; ++chunk) {
-      const uint64_t hw = hits[((long) b * V + vox) * (P.C / CH) + chunk];
-      const float* g = gout + ((long) b * P.C + chunk * CH) * V + vox;
+    if (!FILL) continue;
 #pragma unroll
-      for (int c4 = 0; c4 < CH; c4 += 4) {
-        float v[4];
+    for (int k = 0; k < NB; ++k) {
+      const int n = n0 + k;
+      if (n >= P.N) continue;                    // uniform
+      const int rb = __shfl(base[k], start[k], 64);
+      if (!((actm >> k) & 1u)) continue;
+      const long bn = (long) b * P.N + n;
+      const LiftTap t = lift_project(P, mats + bn * 48, vx, vy, vz);
+      const long cell = (bn * ch + (t.iy0 + 1)) * cw + (t.ix0 + 1);
+      const long slot = (long) off[cell] + boff[cell / kScanTile] + rb + (lane - start[k]);
+      float* e = entries + slot * ES;
+
+      const float wj[4] = {t.wy0 * t.wx0, t.wy0 * t.wx1, t.wy1 * t.wx0, t.wy1 * t.wx1};
+      float dep[4] = {0.f, 0.f, 0.f, 0.f};
+      if (P.use_depth) {
+        const T* dptr = depth + bn * P.D * HW;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          v[k] = g[(long) (c4 + k) * V] / ((float) ((hw >> (4 * (c4 + k))) & 15) + 1e-6f);
-        *reinterpret_cast<float4*>(e + kRecHead + chunk * CH + c4) = make_float4(v[0], v[1], v[2], v[3]);
+        for (int kz = 0; kz < 2; ++kz) {
+          const int iz = t.iz0 + kz;
+          const bool zin = iz >= 0 && iz < P.D;
+          const float wz = zin ? (kz ? t.wz1 : t.wz0) : 0.f;
+          const long zo = (long) min(max(iz, 0), P.D - 1) * HW;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int iy = t.iy0 + (j >> 1), ix = t.ix0 + (j & 1);
+            const bool in = iy >= 0 && iy < P.fH && ix >= 0 && ix < P.fW;
+            dep[j] += (in ? wz : 0.f) *
+                      ldf(dptr, zo + (long) min(max(iy, 0), P.fH - 1) * P.fW + min(max(ix, 0), P.fW - 1));
+          }
+        }
+      } else {
+        const float w = (t.iz0 == 0 ? t.wz0 : 0.f) + (t.iz0 == -1 ? t.wz1 : 0.f);
+        dep[0] = dep[1] = dep[2] = dep[3] = w;
       }
+      float4* e4 = reinterpret_cast<float4*>(e);
+      e4[0] = make_float4(__int_as_float(t.ix0), __int_as_float(t.iy0), __int_as_float(t.iz0), 0.f);
+      e4[1] = make_float4(t.wz0, t.wz1, 0.f, 0.f);
+      e4[2] = make_float4(wj[0] * dep[0], wj[1] * dep[1], wj[2] * dep[2], wj[3] * dep[3]);
+      e4[3] = make_float4(wj[0], wj[1], wj[2], wj[3]);
+#pragma unroll
+      for (int c4 = 0; c4 < CH; c4 += 4)
+        *reinterpret_cast<float4*>(e + kRecHead + c4) = make_float4(gs0[c4], gs0[c4 + 1], gs0[c4 + 2], gs0[c4 + 3]);
+      if (!first_chunk_only)
+        for (int chunk = 1; chunk < P.C / CH; ++chunk) {
+          const uint64_t hw = hits[((long) b * V + vox) * (P.C / CH) + chunk];
+          const float* g = gout + ((long) b * P.C + chunk * CH) * V + vox;
+#pragma unroll
+          for (int c4 = 0; c4 < CH; c4 += 4) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              v[q] = g[(long) (c4 + q) * V] / ((float) ((hw >> (4 * (c4 + q))) & 15) + 1e-6f);
+            *reinterpret_cast<float4*>(e + kRecHead + chunk * CH + c4) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
     }
   }
 }
 
 // ---------------------------------------------------------------------------
 // gather: wpp waves per pixel (1, 4 or 16, chosen on the host from the expected records per
-// pixel), LPB waves per workgroup
+// pixel), max(kMinWaves, wpp) waves per workgroup: small workgroups, because a workgroup lives as
+// long as its slowest pixel (16 / 8 / 4 waves measured 145 / 131 / 125 us at cfg-B)
 // ---------------------------------------------------------------------------
 // NCH = ceil(C / 16) channel chunks per lane
-template <typename T, int NCH>
-__global__ void __launch_bounds__(LPB * 64)
+template <typename T, int NCH, int UB>
+__global__ void __launch_bounds__(1024)
 lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, const T* __restrict__ feat,
                             const int* __restrict__ off, const int* __restrict__ boff,
                             const float* __restrict__ entries, float* __restrict__ gdepth,
                             float* __restrict__ gfeat) {
-  extern __shared__ float smem[];                // [ppb][Dp] depth columns, then [LPB][NCH * 16]
+  extern __shared__ float smem[];                // [ppb][Dp] depth columns, then [waves][NCH * 16]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int q = lane >> 4, l = lane & 15;        // quarter of the wave, channel lane
   const int C = P.C, D = P.use_depth ? P.D : 0;
   const int Dp = D | 1;
-  const int ppb = LPB / wpp;                     // pixels per workgroup
+  const int nw = blockDim.x >> 6;
+  const int ppb = nw / wpp;                      // pixels per workgroup
   const int pw = wv / wpp, ws = wv % wpp;        // pixel of this wave, wave index inside the pixel
   float* gd = smem;
   float* accbuf = smem + ppb * Dp;
@@ -200,7 +237,7 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, const T* __re
     acc[k] = 0.f;
   }
 
-  constexpr int UB = 2;                          // records per quarter per round: loads go out together
+  // UB records per quarter per round: their loads go out together
   for (int k0 = ws * 4 * UB; k0 < tot; k0 += wpp * 4 * UB) {
     float4 ha[UB], hb[UB], pwv[UB], ww[UB];
     float gs[UB][NCH];
@@ -238,14 +275,17 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, const T* __re
     }
     if (D > 0) {
       // channel sums of the UB records over the 16 lanes of the quarter by recursive halving:
-      // lanes 8u .. 8u+7 end up with record u, and the first two of them add the two depth planes
+      // lanes (16 / UB) u .. end up with record u, and the first two of them add the two depth planes
       int tu = 0;
       reduce_halving<UB, 8, 16, UB>(dots, l, tu);
-      const int iz0 = tu ? iz0s[1] : iz0s[0];
-      const int sub = l & 7;
+      int iz0 = iz0s[0];
+      float wz0 = wz0s[0], wz1 = wz1s[0];
+#pragma unroll
+      for (int u = 1; u < UB; ++u)
+        if (tu == u) { iz0 = iz0s[u]; wz0 = wz0s[u]; wz1 = wz1s[u]; }
+      const int sub = l & (16 / UB - 1);
       const int iz = iz0 + sub;
-      const float wz = sub ? (tu ? wz1s[1] : wz1s[0]) : (tu ? wz0s[1] : wz0s[0]);
-      if (sub < 2 && iz >= 0 && iz < D && dots[0] != 0.f) atomicAdd(gcol + iz, wz * dots[0]);
+      if (sub < 2 && iz >= 0 && iz < D && dots[0] != 0.f) atomicAdd(gcol + iz, (sub ? wz1 : wz0) * dots[0]);
     }
   }
   // sum the four quarters' grad_feat partials (lanes l, l+16, l+32, l+48), then the pixel's waves
@@ -268,7 +308,7 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, const T* __re
   }
   if (D > 0 && gdepth) {
     // consecutive threads = consecutive pixels of one depth plane
-    for (int e = tid; e < D * ppb; e += LPB * 64) {
+    for (int e = tid; e < D * ppb; e += nw * 64) {
       const int dz = e / ppb, p = e % ppb;
       const long pp = pid0 + p;
       if (pp >= npix) continue;
@@ -337,21 +377,23 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
   const double per_pix = 4.0 * (double) d->B * d->Z * d->Y * d->X / (double) npix;
   const char* ew = getenv("VAMP_LIFT_WPP");
   int wpp = per_pix <= 96.0 ? 1 : (per_pix <= 768.0 ? 4 : 16);
+
   if (ew && (atoi(ew) == 1 || atoi(ew) == 4 || atoi(ew) == 16)) wpp = atoi(ew);
-  const int ppb = LPB / wpp;
+  const int nw = std::max(kMinWaves, wpp);
+  const int ppb = nw / wpp;
   const int Dd = d->use_depth ? d->D : 0;
-  const size_t lds = ((size_t) ppb * (Dd | 1) + (size_t) LPB * ((d->C + 15) / 16) * 16) * sizeof(float);
+  const size_t lds = ((size_t) ppb * (Dd | 1) + (size_t) nw * ((d->C + 15) / 16) * 16) * sizeof(float);
   if (lds > 150 * 1024) return fail(VAMP_EINVAL, "%s: D too large for the LDS depth columns", __func__);
   const unsigned ggrid = (unsigned) ((npix + ppb - 1) / ppb);
   const int nch = (d->C + 15) / 16;
-#define VAMP_GATHER(NCH)                                                                          \
+#define VAMP_GATHER(NCH)                                                                        \
   do {                                                                                            \
-    auto k = lift_bwd_cell_gather_kernel<T, NCH>;                                                 \
+    auto k = lift_bwd_cell_gather_kernel<T, NCH, 2>;   /* UB = 4: 93 VGPRs, measured 20 % slower */ \
     if (lds > 64 * 1024 &&                                                                        \
         hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                     \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) \
       return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);                           \
-    VAMP_TIMED(kProfLiftBwd, s, (k<<<ggrid, LPB * 64, lds, s>>>(                                  \
+    VAMP_TIMED(kProfLiftBwd, s, (k<<<ggrid, nw * 64, lds, s>>>(                                   \
         P, g.cw, g.ch, wpp, static_cast<const T*>(feat), w.off, w.boff, w.entries, gdepth,      \
         gfeat)));                                                                                 \
   } while (0)
