@@ -185,6 +185,25 @@ int vamp_render_camera_backward(const VampRenderDesc* d, const float* geom, cons
                                 void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Same, for callers that run the two render branches on two streams (they are independent up
+ * to these three buffers):
+ *   accumulate  != 0: the gradients are ADDED to what grad_density_feature / grad_semantic /
+ *               grad_rgb hold (e.g. the BEV branch's contribution, written first)
+ *   wait_event  a hipEvent_t (or NULL) the stream waits for right before those buffers are first
+ *               touched, i.e. after the per-ray pass and the sample sort have been queued
+ * Both need the default (cell-list) implementation with mats (geom == NULL).
+ */
+int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, const float* mats,
+                                    const float* us, const float* vs, const float* ds,
+                                    const float* mids, const float* beta,
+                                    const void* density_feature, const void* semantic,
+                                    const void* rgb, const float* g_rgb, const float* g_seg,
+                                    const float* g_depth, float* grad_density_feature,
+                                    float* grad_semantic, float* grad_rgb, float* grad_beta,
+                                    void* workspace, size_t workspace_bytes, int accumulate,
+                                    void* wait_event, void* stream);
+
+/*
  * BEV (top-down) branch, forward (bv2:408-418, 442-461).
  *   oxs[oX], oys[oY], ozs[oZ]  det-grid centres (bv2:160), bev_mids [oZ] (bv2:248-251)
  *   base [B,C,Z,Y,X]

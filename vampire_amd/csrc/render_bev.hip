@@ -381,13 +381,11 @@ bev_gather_generic_kernel(RenderParams P, const float* __restrict__ oxs,
 constexpr int kPer = 4;                // channels per thread of bev_gather
 
 // Per-axis hit tables, built once per call: for every voxel index along an axis the (<= kMaxT)
-// lattice samples whose taps include it, and their weights.  Layout: tab[(slot * n + index)] for
-// slot in [0, kMaxT): k as int bits in tk, weight in tw; count in tn.  overflow[0] is set when some
-// voxel has more than kMaxT hits (then the generic kernel must run).
+// lattice samples whose taps include it, and their weights, as one 32-byte record
+// {k0, k1, k2, count | w0, w1, w2, -} so that the gather needs a single round of loads per axis.
 __global__ void __launch_bounds__(256)
 bev_axis_table_kernel(RenderParams P, const float* __restrict__ oxs, const float* __restrict__ oys,
-                      const float* __restrict__ ozs, int* __restrict__ tk, float* __restrict__ tw,
-                      int* __restrict__ tn) {
+                      const float* __restrict__ ozs, int4* __restrict__ tab) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int NX = P.X, NY = P.Y, NZ = P.Z;
   if (i >= NX + NY + NZ) return;
@@ -396,159 +394,173 @@ bev_axis_table_kernel(RenderParams P, const float* __restrict__ oxs, const float
   if (i < NX) { h = axis_hits(oxs, P.oX, P.lo[0], P.span[0], P.X, i); base = 0; n = i; }
   else if (i < NX + NY) { h = axis_hits(oys, P.oY, P.lo[1], P.span[1], P.Y, i - NX); base = NX; n = i - NX; }
   else { h = axis_hits(ozs, P.oZ, P.lo[2], P.span[2], P.Z, i - NX - NY); base = NX + NY; n = i - NX - NY; }
-  const int tot = NX + NY + NZ;
-#pragma unroll
-  for (int sl = 0; sl < kMaxT; ++sl) {
-    tk[sl * tot + base + n] = h.k[sl];
-    tw[sl * tot + base + n] = h.w[sl];
-  }
-  tn[base + n] = h.n;
+  static_assert(kMaxT == 3, "one 32-byte record per axis index: k[3], n | w[3], pad");
+  tab[2 * (base + n)] = make_int4(h.k[0], h.k[1], h.k[2], h.n);
+  tab[2 * (base + n) + 1] = make_int4(__float_as_int(h.w[0]), __float_as_int(h.w[1]), __float_as_int(h.w[2]), 0);
 }
 
-// USE_COL: the channel's sample gradient is Wb * gcol (composited sem / rgb); USE_VO: the
-// voxel_output gradient passes straight through (base channels, and sem when cat_seg)
-template <bool USE_COL, bool USE_VO>
-__device__ __forceinline__ void bev_gather_channels(
-    const RenderParams& P, int b, long OYX, const AxisHits& hx, const AxisHits& hy, const AxisHits& hz,
-    const float* __restrict__ Wb, const float* const* gcol, const long* gcol_base,
-    const float* __restrict__ g_vo, const long* vo_base, const bool* on, float* sum) {
-  // first two hits per axis, no bounds branches (unused slots: k = 0, w = 0): all loads of all
-  // kPer channels are independent and in flight together
-  float wgt[8], wW[8];
-  long cc8[8];
-  int j8[8];
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const int a = t >> 2, c2 = (t >> 1) & 1, e = t & 1;
-    j8[t] = P.oZ - 1 - hz.k[a];
-    cc8[t] = (long) hy.k[c2] * P.oX + hx.k[e];
-    wgt[t] = hz.w[a] * hy.w[c2] * hx.w[e];
-    wW[t] = USE_COL ? wgt[t] * Wb[((long) b * P.oZ + j8[t]) * OYX + cc8[t]] : 0.f;
-  }
-#pragma unroll
-  for (int u = 0; u < kPer; ++u) {
-    if (!on[u]) continue;                               // workgroup-uniform
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      if (USE_COL) sum[u] = __builtin_fmaf(wW[t], gcol[u][gcol_base[u] + cc8[t]], sum[u]);
-      if (USE_VO) sum[u] = __builtin_fmaf(wgt[t], g_vo[vo_base[u] + (long) j8[t] * OYX + cc8[t]], sum[u]);
-    }
-  }
-  if (hz.n > 2 || hy.n > 2 || hx.n > 2) {             // rare third hit on some axis
-#pragma unroll
-    for (int u = 0; u < kPer; ++u) {
-      if (!on[u]) continue;
-#pragma unroll
-      for (int a = 0; a < kMaxT; ++a)
-#pragma unroll
-        for (int c2 = 0; c2 < kMaxT; ++c2)
-#pragma unroll
-          for (int e = 0; e < kMaxT; ++e) {
-            if (a < 2 && c2 < 2 && e < 2) continue;
-            if (a >= hz.n || c2 >= hy.n || e >= hx.n) continue;
-            const int j = P.oZ - 1 - hz.k[a];
-            const long cc = (long) hy.k[c2] * P.oX + hx.k[e];
-            float dsv = 0.f;
-            if (USE_COL) dsv = Wb[((long) b * P.oZ + j) * OYX + cc] * gcol[u][gcol_base[u] + cc];
-            if (USE_VO) dsv += g_vo[vo_base[u] + (long) j * OYX + cc];
-            sum[u] = __builtin_fmaf(hz.w[a] * hy.w[c2] * hx.w[e], dsv, sum[u]);
-          }
-    }
-  }
+__device__ __forceinline__ AxisHits load_axis_hits(const int4* __restrict__ tab, int i) {
+  const int4 a = tab[2 * i], w = tab[2 * i + 1];
+  AxisHits h;
+  h.k[0] = a.x; h.k[1] = a.y; h.k[2] = a.z; h.n = a.w;
+  h.w[0] = __int_as_float(w.x); h.w[1] = __int_as_float(w.y); h.w[2] = __int_as_float(w.z);
+  h.overflow = false;
+  return h;
 }
 
-// Channel groups never mix kinds: [semantic groups | rgb group | base groups], kPer channels each.
+// KIND 0 / 1 / 2 = semantic / rgb / base channels, kPer channels per thread, one launch per kind.
+//   KIND 0, 1: the sample gradient of a composited channel is Wb * gcol (gcol = g_bev_seg /
+//              g_bev_rgb, one value per BEV column, so the height taps fold into the weights)
+//   KIND 0 with cat_seg, KIND 2: the voxel_output gradient passes straight through
+// with_dens: group 0 of this launch also carries the density channel.
+// The first two hits per axis are handled without branches (unused slots: k = 0, w = 0), so all
+// loads of a thread are independent and in flight together; a third hit on some axis adds
+// its slot combinations at the end.  Offsets are 32-bit (the host checks the tensor sizes).
+__device__ __forceinline__ AxisHits uniform_hits(AxisHits h) {
+#pragma unroll
+  for (int i = 0; i < kMaxT; ++i) {
+    h.k[i] = __builtin_amdgcn_readfirstlane(h.k[i]);
+    h.w[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(h.w[i])));
+  }
+  h.n = __builtin_amdgcn_readfirstlane(h.n);
+  return h;
+}
+
+template <int KIND>
 __global__ void __launch_bounds__(256)
-bev_gather_kernel(RenderParams P, const int* __restrict__ tk, const float* __restrict__ tw,
-                  const int* __restrict__ tn, const float* __restrict__ g_brgb,
-                  const float* __restrict__ g_bseg, const float* __restrict__ g_vo,
-                  const float* __restrict__ Wb, const float* __restrict__ DS0,
-                  float* __restrict__ gdens, float* __restrict__ gsem, float* __restrict__ grgb,
-                  float* __restrict__ gbase, int z_lo, int z_hi) {
+bev_gather_kernel(RenderParams P, const int4* __restrict__ tab, const float* __restrict__ gcol,
+                  const float* __restrict__ g_vo, const float* __restrict__ Wb,
+                  const float* __restrict__ DS0, float* __restrict__ gdens,
+                  float* __restrict__ gout, int z_lo, int z_hi, int with_dens) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int nz = z_hi - z_lo + 1;
-  const int g_sem = (P.K + kPer - 1) / kPer, g_rgb = 1, g_base = (P.C + kPer - 1) / kPer;
-  const int ngrp = g_sem + g_rgb + g_base;
+  const int nchan = KIND == 0 ? P.K : (KIND == 1 ? 3 : P.C);
+  const int ngrp = (nchan + kPer - 1) / kPer;
   const int cg = blockIdx.z % ngrp;
   const int z = z_lo + (blockIdx.z / ngrp) % nz;
   const int b = blockIdx.z / (ngrp * nz);
   if (x >= P.X || y >= P.Y) return;
-  const long V = (long) P.Z * P.Y * P.X, OYX = (long) P.oY * P.oX;
-  const int CO = P.C + (P.cat_seg ? P.K : 0);
-  const int tot = P.X + P.Y + P.Z;
-  AxisHits hx, hy, hz;
-  hx.n = tn[x]; hy.n = tn[P.X + y]; hz.n = tn[P.X + P.Y + z];
+  // y and z are the same for the whole wave: their hits go to scalar registers, which turns the
+  // tap addresses into (scalar base) + (per-lane x offset) and most of the index arithmetic into
+  // scalar instructions
+  const AxisHits hx = load_axis_hits(tab, x), hy = uniform_hits(load_axis_hits(tab, P.X + y)),
+                 hz = uniform_hits(load_axis_hits(tab, P.X + P.Y + z));
   if (hx.n == 0 || hy.n == 0 || hz.n == 0) return;
-#pragma unroll
-  for (int sl = 0; sl < kMaxT; ++sl) {
-    hx.k[sl] = tk[sl * tot + x]; hx.w[sl] = tw[sl * tot + x];
-    hy.k[sl] = tk[sl * tot + P.X + y]; hy.w[sl] = tw[sl * tot + P.X + y];
-    hz.k[sl] = tk[sl * tot + P.X + P.Y + z]; hz.w[sl] = tw[sl * tot + P.X + P.Y + z];
-  }
-  const long vox = ((long) z * P.Y + y) * P.X + x;
+  const unsigned V = (unsigned) (P.Z * P.Y * P.X), OYX = (unsigned) (P.oY * P.oX);
+  const unsigned vox = ((unsigned) z * P.Y + y) * P.X + x;
+  const int CO = P.C + (P.cat_seg ? P.K : 0);
+  const bool use_col = KIND != 2 && gcol != nullptr;
+  const bool use_vo = g_vo != nullptr && (KIND == 2 || (KIND == 0 && P.cat_seg));
+  const int vo_c0 = KIND == 2 ? 0 : P.C;
+  const bool dens = with_dens && cg == 0;
+  const bool any = use_col || use_vo;
 
-  if (cg == 0) {                                       // the density channel rides with group 0
-    float s_dens = 0.f;
-#pragma unroll
-    for (int a = 0; a < kMaxT; ++a)
-#pragma unroll
-      for (int c2 = 0; c2 < kMaxT; ++c2)
-#pragma unroll
-        for (int e = 0; e < kMaxT; ++e) {
-          const long sc = ((long) b * P.oZ + (P.oZ - 1 - hz.k[a])) * OYX + (long) hy.k[c2] * P.oX + hx.k[e];
-          s_dens = __builtin_fmaf(hz.w[a] * hy.w[c2] * hx.w[e], DS0[sc], s_dens);
-        }
-    gdens[(long) b * V + vox] += s_dens;
-  }
-
-  float sum[kPer];
-  float* outp[kPer];
-  const float* gcol[kPer];
-  long gcol_base[kPer], vo_base[kPer];
+  // The values accumulated onto are loaded first and everything is stored at the end: none of
+  // these loads depends on the taps, so their latency overlaps the taps' instead of following it.
   bool on[kPer];
-  int kind;                                            // 0 sem, 1 rgb, 2 base
-  int c_first, c_count;
-  if (cg < g_sem) { kind = 0; c_first = cg * kPer; c_count = P.K; }
-  else if (cg < g_sem + g_rgb) { kind = 1; c_first = 0; c_count = 3; }
-  else { kind = 2; c_first = (cg - g_sem - g_rgb) * kPer; c_count = P.C; }
+  unsigned oo[kPer];
+  float prev[kPer], sum[kPer];
 #pragma unroll
   for (int u = 0; u < kPer; ++u) {
-    const int ch = c_first + u;
-    on[u] = ch < c_count;
-    const int cs = on[u] ? ch : 0;
+    const int ch = cg * kPer + u;
+    on[u] = any && ch < nchan;
+    oo[u] = ((unsigned) b * nchan + (on[u] ? ch : 0)) * V + vox;
+    prev[u] = on[u] ? gout[oo[u]] : 0.f;
     sum[u] = 0.f;
-    if (kind == 0) {
-      outp[u] = gsem + ((long) b * P.K + cs) * V;
-      gcol[u] = g_bseg; gcol_base[u] = ((long) b * P.K + cs) * OYX;
-      vo_base[u] = ((long) b * CO + P.C + cs) * P.oZ * OYX;
-    } else if (kind == 1) {
-      outp[u] = grgb + ((long) b * 3 + cs) * V;
-      gcol[u] = g_brgb; gcol_base[u] = ((long) b * 3 + cs) * OYX;
-      vo_base[u] = 0;
-    } else {
-      outp[u] = gbase + ((long) b * P.C + cs) * V;
-      gcol[u] = nullptr; gcol_base[u] = 0;
-      vo_base[u] = ((long) b * CO + cs) * P.oZ * OYX;
+  }
+  const float prev_d = dens ? gdens[(unsigned) b * V + vox] : 0.f;
+  float s_dens = 0.f;
+
+  unsigned cc[4], jo[2];
+  float wyx[4], wz[2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    cc[q] = (unsigned) hy.k[q >> 1] * P.oX + hx.k[q & 1];
+    wyx[q] = hy.w[q >> 1] * hx.w[q & 1];
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    jo[a] = ((unsigned) b * P.oZ + (P.oZ - 1 - hz.k[a])) * OYX;
+    wz[a] = hz.w[a];
+  }
+  float wcol[4] = {0.f, 0.f, 0.f, 0.f};
+  if (use_col) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wcol[q] = __builtin_fmaf(wz[a] * wyx[q], Wb[jo[a] + cc[q]], wcol[q]);
+  }
+  if (dens) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s_dens = __builtin_fmaf(wz[a] * wyx[q], DS0[jo[a] + cc[q]], s_dens);
+  }
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    if (!on[u]) continue;                               // workgroup-uniform
+    const int ch = cg * kPer + u;
+    if (use_col) {
+      const unsigned cb = ((unsigned) b * nchan + ch) * OYX;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sum[u] = __builtin_fmaf(wcol[q], gcol[cb + cc[q]], sum[u]);
+    }
+    if (use_vo) {
+      const unsigned vb = ((unsigned) b * CO + vo_c0 + ch) * P.oZ * OYX - (unsigned) b * P.oZ * OYX;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sum[u] = __builtin_fmaf(wz[a] * wyx[q], g_vo[vb + jo[a] + cc[q]], sum[u]);
     }
   }
-  const bool has_col = (kind == 0 && g_bseg) || (kind == 1 && g_brgb);
-  const bool has_vo = g_vo && (kind == 2 || (kind == 0 && P.cat_seg));
-  if (!has_col && !has_vo) return;
-  if (has_col && has_vo)
-    bev_gather_channels<true, true>(P, b, OYX, hx, hy, hz, Wb, gcol, gcol_base, g_vo, vo_base, on, sum);
-  else if (has_col)
-    bev_gather_channels<true, false>(P, b, OYX, hx, hy, hz, Wb, gcol, gcol_base, g_vo, vo_base, on, sum);
-  else
-    bev_gather_channels<false, true>(P, b, OYX, hx, hy, hz, Wb, gcol, gcol_base, g_vo, vo_base, on, sum);
+  // Third hit on an axis (the det lattice is slightly finer than the volume grid, so about one
+  // voxel index in a hundred has one): the extra (z, y, x) slot combinations, unrolled, each
+  // group behind a wave-level test.  A slot an axis does not have carries weight 0 and k = 0.
+  auto add_combo = [&](int kz, float wzv, int ky, float wyv, int kx, float wxv) {
+    const unsigned j0 = ((unsigned) b * P.oZ + (P.oZ - 1 - kz)) * OYX;
+    const unsigned c0 = (unsigned) ky * P.oX + kx;
+    const float wt = wzv * wyv * wxv;
+    const float wW = use_col ? wt * Wb[j0 + c0] : 0.f;
+    if (dens) s_dens = __builtin_fmaf(wt, DS0[j0 + c0], s_dens);
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      if (!on[u]) continue;
+      const int ch = cg * kPer + u;
+      if (use_col) sum[u] = __builtin_fmaf(wW, gcol[((unsigned) b * nchan + ch) * OYX + c0], sum[u]);
+      if (use_vo)
+        sum[u] = __builtin_fmaf(
+            wt, g_vo[((unsigned) b * CO + vo_c0 + ch) * P.oZ * OYX - (unsigned) b * P.oZ * OYX + j0 + c0],
+            sum[u]);
+    }
+  };
+  if (hx.n > 2) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) add_combo(hz.k[a], hz.w[a], hy.k[c2], hy.w[c2], hx.k[2], hx.w[2]);
+  }
+  if (hy.n > 2) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int e = 0; e < 3; ++e) add_combo(hz.k[a], hz.w[a], hy.k[2], hy.w[2], hx.k[e], hx.w[e]);
+  }
+  if (hz.n > 2) {
+#pragma unroll
+    for (int c2 = 0; c2 < 3; ++c2)
+#pragma unroll
+      for (int e = 0; e < 3; ++e) add_combo(hz.k[2], hz.w[2], hy.k[c2], hy.w[c2], hx.k[e], hx.w[e]);
+  }
+  if (dens) gdens[(unsigned) b * V + vox] = prev_d + s_dens;
 #pragma unroll
   for (int u = 0; u < kPer; ++u)
-    if (on[u]) outp[u][vox] += sum[u];
+    if (on[u]) gout[oo[u]] = prev[u] + sum[u];
 }
 
 static size_t bev_ws_bytes(const VampRenderDesc* d) {
   return 3 * align_up((size_t) d->B * d->oZ * d->oY * d->oX * sizeof(float), 256) +
-         align_up((size_t) (2 * kMaxT + 1) * (d->X + d->Y + d->Z) * sizeof(float), 256);
+         align_up((size_t) 2 * (d->X + d->Y + d->Z) * sizeof(int4), 256);
 }
 
 }  // namespace vamp
@@ -616,9 +628,7 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t one = align_up((size_t) d->B * d->oZ * d->oY * d->oX * sizeof(float), 256);
   const int tot_ax = d->X + d->Y + d->Z;
-  int* tk = reinterpret_cast<int*>(static_cast<char*>(workspace) + 3 * one);
-  float* tw = reinterpret_cast<float*>(tk + (size_t) kMaxT * tot_ax);
-  int* tn = reinterpret_cast<int*>(tw + (size_t) kMaxT * tot_ax);
+  int4* tab = reinterpret_cast<int4*>(static_cast<char*>(workspace) + 3 * one);
   float* Q = static_cast<float*>(workspace);
   float* Wb = reinterpret_cast<float*>(static_cast<char*>(workspace) + one);
   float* DS0 = reinterpret_cast<float*>(static_cast<char*>(workspace) + 2 * one);
@@ -658,14 +668,28 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
     const float e = d->span[a] / (float) (nvox[a] - 1);
     if (!(d->det_step[a] > 0.f) || (int) floorf(2.0f * e / d->det_step[a]) + 1 > kMaxT) fits = false;
   }
-  const int ngrp = (d->K + kPer - 1) / kPer + 1 + (d->C + kPer - 1) / kPer;
-  dim3 ggf(gg.x, gg.y, gg.z * ngrp);
   if (fits) {
-    VAMP_TIMED(kProfAux, s, (bev_axis_table_kernel<<<(tot_ax + 255) / 256, 256, 0, s>>>(P, oxs, oys, ozs, tk, tw, tn)));
+    // 32-bit element offsets inside the gather
+    const size_t lim = 0x7fffffffu;
+    VAMP_REQUIRE((size_t) d->B * (d->K > d->C ? d->K : d->C) * d->Z * d->Y * d->X < lim &&
+                 (size_t) d->B * (d->C + d->K) * d->oZ * d->oY * d->oX < lim,
+                 "tensor too large for the 32-bit offsets of the BEV gather");
+    VAMP_TIMED(kProfAux, s, (bev_axis_table_kernel<<<(tot_ax + 255) / 256, 256, 0, s>>>(P, oxs, oys, ozs, tab)));
     if (int e = check_launch("bev_axis_table_kernel")) return e;
-    VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_kernel<<<ggf, 256, 0, s>>>(
-        P, tk, tw, tn, g_bev_rgb, g_bev_seg, g_voxel_output, Wb, DS0, grad_density_feature,
-        grad_semantic, grad_rgb, grad_base, z_lo, z_hi)));
+    const bool vo_sem = g_voxel_output && d->cat_seg;
+    // rgb launch (one group) also carries the density channel
+    VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_kernel<1><<<gg, 256, 0, s>>>(
+        P, tab, g_bev_rgb, g_voxel_output, Wb, DS0, grad_density_feature, grad_rgb, z_lo, z_hi, 1)));
+    if (d->K > 0 && (g_bev_seg || vo_sem)) {
+      dim3 g0(gg.x, gg.y, gg.z * ((d->K + kPer - 1) / kPer));
+      VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_kernel<0><<<g0, 256, 0, s>>>(
+          P, tab, g_bev_seg, g_voxel_output, Wb, DS0, grad_density_feature, grad_semantic, z_lo, z_hi, 0)));
+    }
+    if (d->C > 0 && g_voxel_output) {
+      dim3 g2(gg.x, gg.y, gg.z * ((d->C + kPer - 1) / kPer));
+      VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_kernel<2><<<g2, 256, 0, s>>>(
+          P, tab, nullptr, g_voxel_output, Wb, DS0, grad_density_feature, grad_base, z_lo, z_hi, 0)));
+    }
   }
   else
     VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_generic_kernel<<<gg, 256, 0, s>>>(

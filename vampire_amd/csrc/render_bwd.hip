@@ -22,7 +22,8 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
                       const float* us, const float* vs, const float* ds, const float* mids,
                       const float* beta, const float* packed, const float* g_rgb,
                       const float* g_seg, const float* g_depth, float* gdens, float* gsem,
-                      float* grgb, float* grad_beta, void* scratch, hipStream_t s);
+                      float* grgb, float* grad_beta, void* scratch, int accumulate,
+                      hipEvent_t wait_event, hipStream_t s);
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
   // wave reduce then 4-wave LDS reduce; result valid in thread 0
@@ -349,6 +350,21 @@ int vamp_render_camera_backward(const VampRenderDesc* d, const float* geom, cons
                                 float* grad_density_feature, float* grad_semantic, float* grad_rgb,
                                 float* grad_beta, void* workspace, size_t workspace_bytes,
                                 void* stream) {
+  return vamp_render_camera_backward_acc(d, geom, mats, us, vs, ds, mids, beta, density_feature,
+                                         semantic, rgb, g_rgb, g_seg, g_depth, grad_density_feature,
+                                         grad_semantic, grad_rgb, grad_beta, workspace,
+                                         workspace_bytes, 0, nullptr, stream);
+}
+
+int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, const float* mats,
+                                    const float* us, const float* vs, const float* ds,
+                                    const float* mids, const float* beta,
+                                    const void* density_feature, const void* semantic,
+                                    const void* rgb, const float* g_rgb, const float* g_seg,
+                                    const float* g_depth, float* grad_density_feature,
+                                    float* grad_semantic, float* grad_rgb, float* grad_beta,
+                                    void* workspace, size_t workspace_bytes, int accumulate,
+                                    void* wait_event, void* stream) {
   if (int e = validate(d)) return e;
   VAMP_REQUIRE(geom || (mats && us && vs && ds), "need geom or (mats, us, vs, ds)");
   VAMP_REQUIRE(mids && density_feature && semantic && rgb, "null input");
@@ -368,7 +384,9 @@ int vamp_render_camera_backward(const VampRenderDesc* d, const float* geom, cons
   const char* force = getenv("VAMP_CAM_BWD");
   if (!geom && mats && !(force && force[0] == 'v' && force[1] == '1'))
     return launch_cam_bwd_v2(d, P, mats, us, vs, ds, mids, beta, packed, g_rgb, g_seg, g_depth,
-                             grad_density_feature, grad_semantic, grad_rgb, grad_beta, gpacked, s);
+                             grad_density_feature, grad_semantic, grad_rgb, grad_beta, gpacked,
+                             accumulate, static_cast<hipEvent_t>(wait_event), s);
+  VAMP_REQUIRE(!accumulate && !wait_event, "accumulate / wait_event need the cell-list path");
   {
     ProfScope sc;
     prof_begin(kProfMemset, s, &sc);

@@ -401,7 +401,8 @@ size_t cam_bwd_cell_bytes(const VampRenderDesc* d);    // render_bwd_cell.hip
 int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const float* FX,
                         const float* FY, const float* FZ, const int* KEY, const float* Wbuf,
                         const float* G0buf, const float* Gcl, float* gdens, float* gsem,
-                        float* grgb, void* scratch, hipStream_t s);
+                        float* grgb, void* scratch, int accumulate, hipEvent_t wait_event,
+                        hipStream_t s);
 
 size_t cam_bwd_v2_bytes(const VampRenderDesc* d) {
   const RenderParams P = to_params(d);
@@ -424,7 +425,8 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
                       const float* us, const float* vs, const float* ds, const float* mids,
                       const float* beta, const float* packed, const float* g_rgb,
                       const float* g_seg, const float* g_depth, float* gdens, float* gsem,
-                      float* grgb, float* grad_beta, void* scratch, hipStream_t s) {
+                      float* grgb, float* grad_beta, void* scratch, int accumulate,
+                      hipEvent_t wait_event, hipStream_t s) {
   const size_t samples = (size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW;
   const size_t rays = (size_t) d->B * d->N * d->fH * d->fW;
   char* p = static_cast<char*>(scratch);
@@ -444,6 +446,8 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
   // candidate-box gather below, VAMP_CAM_BWD=bin the brick lists of render_bwd_bin.hip
   const char* force = getenv("VAMP_CAM_BWD");
   const bool use_cell = !(force && (force[0] == 'g' || force[0] == 'b'));
+  if ((accumulate || wait_event) && !use_cell)
+    return fail(VAMP_EINVAL, "%s: accumulate / wait_event need the cell-list path", __func__);
 
   constexpr int LPR = 4;
   const int S = d->D - 1;
@@ -468,7 +472,7 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
   if (int e = check_launch("cam_bwd_ray_kernel")) return e;
   if (use_cell)
     return launch_cam_bwd_cell(d, P, FX, FY, FZ, KEY, Wbuf, G0buf, Gcl, gdens, gsem, grgb,
-                               bin_scratch, s);
+                               bin_scratch, accumulate, wait_event, s);
 
   // 2. candidate-box gather, or the records binned into per-brick lists with one workgroup
   //    owning each brick (render_bwd_bin.hip), in which case the gather runs only if the lists

@@ -179,7 +179,8 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
                            const float4* __restrict__ R, const float* __restrict__ Gcl,
                            float* __restrict__ gdens, float* __restrict__ gsem,
                            float* __restrict__ grgb, int* __restrict__ heavy,
-                           int* __restrict__ nheavy, long ncell_b, int runs_x, int heavy_thresh) {
+                           int* __restrict__ nheavy, long ncell_b, int runs_x, int heavy_thresh,
+                           int accumulate) {
   constexpr int CP = CP4 * 4;
   constexpr int CVPB = 256 / CGL;
   __shared__ float outs[CP][CVPB + 1];
@@ -197,6 +198,24 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
   const int nch = 1 + P.K + 3;
   const int ixc = min(ix, P.X - 1);
   const CellRanges cr = cell_ranges<CGL>(P, off, boff, ncell_b, b, ixc, iy, iz, l);
+
+  // output elements this thread stores at the end; with accumulate their current values (the
+  // BEV branch's gradient) are fetched now, so that the load overlaps the record streaming
+  const long V = (long) P.Z * P.Y * P.X;
+  const long vox0 = ((long) iz * P.Y + iy) * P.X + (long) bx * CVPB;
+  constexpr int PE = (CP * CVPB + 255) / 256;
+  float* optr[PE];
+  float prevv[PE];
+#pragma unroll
+  for (int i = 0; i < PE; ++i) {
+    const int e = tid + i * 256;
+    const int c = e / CVPB, gx = e % CVPB;
+    float* o = (c == 0) ? gdens + (long) b * V
+               : (c <= P.K) ? gsem + ((long) b * P.K + (c - 1)) * V
+                            : grgb + ((long) b * 3 + (c - 1 - P.K)) * V;
+    optr[i] = (e < nch * CVPB && bx * CVPB + gx < P.X) ? o + vox0 + gx : nullptr;
+    prevv[i] = (accumulate && optr[i]) ? *optr[i] : 0.f;
+  }
 
   float acc[CP];
 #pragma unroll
@@ -225,15 +244,10 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
     }
   }
   __syncthreads();
-  const long V = (long) P.Z * P.Y * P.X;
-  const long vox0 = ((long) iz * P.Y + iy) * P.X + (long) bx * CVPB;
-  for (int e = tid; e < nch * CVPB; e += 256) {
-    const int c = e / CVPB, gx = e % CVPB;
-    if (bx * CVPB + gx >= P.X) continue;
-    const float v = outs[c][gx];
-    if (c == 0) gdens[(long) b * V + vox0 + gx] = v;
-    else if (c <= P.K) gsem[((long) b * P.K + (c - 1)) * V + vox0 + gx] = v;
-    else grgb[((long) b * 3 + (c - 1 - P.K)) * V + vox0 + gx] = v;
+#pragma unroll
+  for (int i = 0; i < PE; ++i) {
+    const int e = tid + i * 256;
+    if (optr[i]) *optr[i] = prevv[i] + outs[e / CVPB][e % CVPB];
   }
 }
 
@@ -244,7 +258,7 @@ cam_bwd_cell_heavy_kernel(RenderParams P, const int* __restrict__ off, const int
                           const float4* __restrict__ R, const float* __restrict__ Gcl,
                           float* __restrict__ gdens, float* __restrict__ gsem,
                           float* __restrict__ grgb, const int* __restrict__ heavy,
-                          const int* __restrict__ nheavy, long ncell_b) {
+                          const int* __restrict__ nheavy, long ncell_b, int accumulate) {
   constexpr int CP = CP4 * 4;
   __shared__ float part[4][CP];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -257,6 +271,13 @@ cam_bwd_cell_heavy_kernel(RenderParams P, const int* __restrict__ off, const int
     const int iy = vid % P.Y; vid /= P.Y;
     const int iz = vid % P.Z, b = vid / P.Z;
     const CellRanges cr = cell_ranges<64>(P, off, boff, ncell_b, b, ix, iy, iz, lane);
+    const long vox = ((long) iz * P.Y + iy) * P.X + ix;
+    float* optr = nullptr;
+    if (tid < nch)
+      optr = (tid == 0) ? gdens + (long) b * V + vox
+             : (tid <= P.K) ? gsem + ((long) b * P.K + (tid - 1)) * V + vox
+                            : grgb + ((long) b * 3 + (tid - 1 - P.K)) * V + vox;
+    const float prev = (accumulate && optr) ? *optr : 0.f;
     float acc[CP];
 #pragma unroll
     for (int c = 0; c < CP; ++c) acc[c] = 0.f;
@@ -275,13 +296,7 @@ cam_bwd_cell_heavy_kernel(RenderParams P, const int* __restrict__ off, const int
       }
     }
     __syncthreads();
-    if (tid < nch) {
-      const float v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-      const long vox = ((long) iz * P.Y + iy) * P.X + ix;
-      if (tid == 0) gdens[(long) b * V + vox] = v;
-      else if (tid <= P.K) gsem[((long) b * P.K + (tid - 1)) * V + vox] = v;
-      else grgb[((long) b * 3 + (tid - 1 - P.K)) * V + vox] = v;
-    }
+    if (optr) *optr = prev + ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
     __syncthreads();
   }
 }
@@ -325,7 +340,8 @@ size_t cam_bwd_cell_bytes(const VampRenderDesc* d) { return cell_ws(d, nullptr).
 int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const float* FX,
                         const float* FY, const float* FZ, const int* KEY, const float* Wbuf,
                         const float* G0buf, const float* Gcl, float* gdens, float* gsem,
-                        float* grgb, void* scratch, hipStream_t s) {
+                        float* grgb, void* scratch, int accumulate, hipEvent_t wait_event,
+                        hipStream_t s) {
   const CellWs w = cell_ws(d, scratch);
   const long ncell = cell_count_padded(d->B, d->Z, d->Y, d->X);
   const long ntile = ncell / kScanTile;
@@ -355,6 +371,10 @@ int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const fl
   constexpr int gl = 8;
   const int heavy_thresh = kHeavy;
   const int vpb = 256 / gl;
+  // the gradient buffers are first touched here: whoever else accumulates into them (the BEV
+  // branch on another stream) must be done
+  if (wait_event && hipStreamWaitEvent(s, wait_event, 0) != hipSuccess)
+    return fail(VAMP_EHIP, "%s: hipStreamWaitEvent failed", __func__);
   const int runs_x = (d->X + vpb - 1) / vpb;
   const long nblk = (long) runs_x * d->Y * d->Z * d->B;
   VAMP_REQUIRE(nblk < 0x7fffffffL, "too many x-runs");
@@ -362,12 +382,13 @@ int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const fl
   const unsigned hgrid = (unsigned) std::min<size_t>(voxels, 8192);
 #define VAMP_CELL_G(CP4, GLV)                                                                       \
   VAMP_TIMED(kProfCamBwdBrick, s, (cam_bwd_cell_gather_kernel<CP4, GLV><<<grid, 256, 0, s>>>(       \
-      P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, w.heavy, nheavy, ncell_b, runs_x, heavy_thresh)))
+      P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, w.heavy, nheavy, ncell_b, runs_x, heavy_thresh, \
+      accumulate)))
 #define VAMP_CELL(CP4)                                                                              \
   do {                                                                                              \
     VAMP_CELL_G(CP4, gl);                                                                           \
     VAMP_TIMED(kProfCamBwdOwn, s, (cam_bwd_cell_heavy_kernel<CP4><<<hgrid, 256, 0, s>>>(            \
-        P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, w.heavy, nheavy, ncell_b)));                 \
+        P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, w.heavy, nheavy, ncell_b, accumulate)));     \
   } while (0)
   if (P.CP == 12) VAMP_CELL(3); else if (P.CP == 24) VAMP_CELL(6); else VAMP_CELL(8);
 #undef VAMP_CELL

@@ -12,6 +12,7 @@ All heavy work happens in hand-written HIP kernels reached through ctypes
 (`_capi`); torch supplies device memory and the current stream only.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -25,8 +26,8 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(stream=None):
+    return C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
 
 
 def _dtype_code(t: torch.Tensor) -> int:
@@ -109,6 +110,15 @@ class HotPath:
         d.cat_seg = 1 if c.cat_seg else 0
         d.in_dtype = dtype_code
         return d
+
+    def _side_stream(self):
+        """Second HIP stream for the BEV branch of the renderer: it shares no kernel with the camera
+        branch, and at batch 1 neither fills the 256 CUs alone (VAMP_OVERLAP=0 disables)."""
+        if os.environ.get("VAMP_OVERLAP", "1") == "0":
+            return None
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     def _workspace(self, key, nbytes):
         t = self._ws.get(key)
@@ -294,20 +304,26 @@ class _RenderFn(torch.autograd.Function):
         dep_p = torch.empty(B, N, 1, c.fH, c.fW, dtype=f32, device=dev)
         nbytes = hp.lib.vamp_render_workspace_bytes(C.byref(d))
         ws = hp._workspace("render", nbytes)
-        _capi.check(hp.lib.vamp_render_camera_forward(
-            C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
-            _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
-            _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(), _stream()), "vamp_render_camera_forward")
         CO = C_ + (K if c.cat_seg else 0)
         bev_rgb = torch.empty(B, 3, c.oY, c.oX, dtype=f32, device=dev)
         bev_seg = torch.empty(B, K, c.oY, c.oX, dtype=f32, device=dev)
         bev_h = torch.empty(B, 1, c.oY, c.oX, dtype=f32, device=dev)
         vdens = torch.empty(B, 1, c.oZ, c.oY, c.oX, dtype=f32, device=dev)
         vout = torch.empty(B, CO, c.oZ, c.oY, c.oX, dtype=f32, device=dev)
+        # the two branches share only their inputs: BEV on the side stream, camera on this one
+        cur, side = torch.cuda.current_stream(), hp._side_stream()
+        if side is not None:
+            side.wait_stream(cur)
         _capi.check(hp.lib.vamp_render_bev_forward(
             C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
             _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
-            _ptr(vdens), _ptr(vout), _stream()), "vamp_render_bev_forward")
+            _ptr(vdens), _ptr(vout), _stream(side)), "vamp_render_bev_forward")
+        _capi.check(hp.lib.vamp_render_camera_forward(
+            C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
+            _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
+            _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(), _stream(cur)), "vamp_render_camera_forward")
+        if side is not None:
+            cur.wait_stream(side)
         ctx.hp, ctx.desc = hp, d
         ctx.has_geom = geom is not None
         ctx.save_for_backward(dens, sem, base, rgb, beta, geom if geom is not None else mats)
@@ -322,24 +338,47 @@ class _RenderFn(torch.autograd.Function):
         cont = lambda t: None if t is None else t.contiguous().float()
         g_rgb, g_seg, g_dep, g_brgb, g_bseg, g_bh, g_vd, g_vo = map(
             cont, (g_rgb, g_seg, g_dep, g_brgb, g_bseg, g_bh, g_vd, g_vo))
-        gd = torch.empty(dens.shape, dtype=f32, device=dens.device)
-        gs = torch.empty(sem.shape, dtype=f32, device=dens.device)
-        gr = torch.empty(rgb.shape, dtype=f32, device=dens.device)
-        gb = torch.zeros(base.shape, dtype=f32, device=dens.device)
-        gbeta = torch.zeros(1, dtype=f32, device=dens.device)
         nbytes = hp.lib.vamp_render_workspace_bytes(C.byref(d))
         ws = hp._workspace("render", nbytes)
-        _capi.check(hp.lib.vamp_render_camera_backward(
-            C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
-            _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(g_rgb),
-            _ptr(g_seg), _ptr(g_dep), _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gbeta), _ptr(ws),
-            ws.numel(), _stream()), "vamp_render_camera_backward")
         ws_bev = hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d)))
-        _capi.check(hp.lib.vamp_render_bev_backward(
-            C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
-            _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(g_brgb), _ptr(g_bseg), _ptr(g_bh),
-            _ptr(g_vd), _ptr(g_vo), _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gb), _ptr(gbeta),
-            hp.ozs_host, _ptr(ws_bev), ws_bev.numel(), _stream()), "vamp_render_bev_backward")
+        gb = torch.zeros(base.shape, dtype=f32, device=dens.device)
+        gbeta = torch.zeros(1, dtype=f32, device=dens.device)
+
+        def bev_backward(stream):
+            _capi.check(hp.lib.vamp_render_bev_backward(
+                C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
+                _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(g_brgb), _ptr(g_bseg), _ptr(g_bh),
+                _ptr(g_vd), _ptr(g_vo), _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gb), _ptr(gbeta),
+                hp.ozs_host, _ptr(ws_bev), ws_bev.numel(), _stream(stream)), "vamp_render_bev_backward")
+
+        cam_args = (C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
+                    _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(g_rgb),
+                    _ptr(g_seg), _ptr(g_dep))
+        cur, side = torch.cuda.current_stream(), hp._side_stream()
+        default_impl = os.environ.get("VAMP_CAM_BWD", "cell")[0] == "c"
+        if side is not None and geom is None and default_impl:
+            # Two streams: the BEV branch accumulates into zeroed buffers on the side stream while
+            # the camera branch marches its rays and sorts its samples on this one; the camera
+            # gather then waits for the BEV event and adds on top.
+            gd = torch.zeros(dens.shape, dtype=f32, device=dens.device)
+            gs = torch.zeros(sem.shape, dtype=f32, device=dens.device)
+            gr = torch.zeros(rgb.shape, dtype=f32, device=dens.device)
+            side.wait_stream(cur)
+            bev_backward(side)
+            done = torch.cuda.Event()
+            done.record(side)
+            _capi.check(hp.lib.vamp_render_camera_backward_acc(
+                *cam_args, _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gbeta), _ptr(ws), ws.numel(), 1,
+                C.c_void_p(done.cuda_event), _stream(cur)), "vamp_render_camera_backward_acc")
+            cur.wait_stream(side)
+        else:
+            gd = torch.empty(dens.shape, dtype=f32, device=dens.device)
+            gs = torch.empty(sem.shape, dtype=f32, device=dens.device)
+            gr = torch.empty(rgb.shape, dtype=f32, device=dens.device)
+            _capi.check(hp.lib.vamp_render_camera_backward(
+                *cam_args, _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gbeta), _ptr(ws), ws.numel(),
+                _stream(cur)), "vamp_render_camera_backward")
+            bev_backward(cur)
         grad_beta = gbeta.reshape(ctx.beta_shape) if hp.cfg.density_mode == "sdf" else None
         return (None, gd.to(dens.dtype), gs.to(sem.dtype), gb.to(base.dtype), gr.to(rgb.dtype),
                 grad_beta, None, None)
