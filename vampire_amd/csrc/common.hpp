@@ -102,6 +102,25 @@ __device__ __forceinline__ float nan_to_num(float v) {
 }
 
 // ---------------------------------------------------------------------------
+// XCD-aware workgroup order.  The hardware deals consecutive workgroups round-robin to the 8
+// XCDs, each with its own L2, so spatial neighbours (which share input lines) land in eight
+// different caches and every line is fetched up to eight times.  xcd_block() returns the logical
+// (x, y, z) block such that XCD k walks the contiguous eighth [k n/8, (k+1) n/8) of the grid in
+// launch order (identity when the workgroup count is not a multiple of 8).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ dim3 xcd_block() {
+  const unsigned n = gridDim.x * gridDim.y * gridDim.z;
+  unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  if ((n & 7u) == 0) lin = (lin & 7u) * (n >> 3) + (lin >> 3);
+  dim3 r;
+  r.x = lin % gridDim.x;
+  lin /= gridDim.x;
+  r.y = lin % gridDim.y;
+  r.z = lin / gridDim.y;
+  return r;
+}
+
+// ---------------------------------------------------------------------------
 // lane-group reductions
 // ---------------------------------------------------------------------------
 // Sum N per-lane values over the lanes of a W-wide group with recursive halving: at every xor

@@ -432,14 +432,17 @@ bev_gather_kernel(RenderParams P, const int4* __restrict__ tab, const float* __r
                   const float* __restrict__ g_vo, const float* __restrict__ Wb,
                   const float* __restrict__ DS0, float* __restrict__ gdens,
                   float* __restrict__ gout, int z_lo, int z_hi, int with_dens) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const dim3 blk = xcd_block();      // neighbouring rows / planes share lattice lines: keep them in one L2
+  const int x = blk.x * 64 + (threadIdx.x & 63);
+  const int y = blk.y * 4 + (threadIdx.x >> 6);
   const int nz = z_hi - z_lo + 1;
   const int nchan = KIND == 0 ? P.K : (KIND == 1 ? 3 : P.C);
   const int ngrp = (nchan + kPer - 1) / kPer;
-  const int cg = blockIdx.z % ngrp;
-  const int z = z_lo + (blockIdx.z / ngrp) % nz;
-  const int b = blockIdx.z / (ngrp * nz);
+  // z fastest, then channel group: the two height taps of a voxel plane are shared with the
+  // plane above and below
+  const int z = z_lo + blk.z % nz;
+  const int cg = (blk.z / nz) % ngrp;
+  const int b = blk.z / (ngrp * nz);
   if (x >= P.X || y >= P.Y) return;
   // y and z are the same for the whole wave: their hits go to scalar registers, which turns the
   // tap addresses into (scalar base) + (per-lane x offset) and most of the index arithmetic into
