@@ -187,12 +187,17 @@ int vamp_render_camera_backward(const VampRenderDesc* d, const float* geom, cons
 /*
  * Same, for callers that run the two render branches on two streams (they are independent up
  * to these three buffers):
- *   accumulate  != 0: the gradients are ADDED to what grad_density_feature / grad_semantic /
- *               grad_rgb hold (e.g. the BEV branch's contribution, written first)
+ *   flags       VAMP_CAMBWD_ACCUMULATE: the gradients are ADDED to what grad_density_feature /
+ *               grad_semantic / grad_rgb hold (e.g. the BEV branch's contribution, written first)
+ *               VAMP_CAMBWD_PACKED_VALID: `workspace` is the buffer vamp_render_camera_forward
+ *               ran with for these same volumes and nothing has written to it since, so its
+ *               channel-last copy of the volumes is reused instead of rebuilt
  *   wait_event  a hipEvent_t (or NULL) the stream waits for right before those buffers are first
  *               touched, i.e. after the per-ray pass and the sample sort have been queued
- * Both need the default (cell-list) implementation with mats (geom == NULL).
+ * ACCUMULATE and wait_event need the default (cell-list) implementation with mats (geom == NULL).
  */
+#define VAMP_CAMBWD_ACCUMULATE 1
+#define VAMP_CAMBWD_PACKED_VALID 2
 int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, const float* mats,
                                     const float* us, const float* vs, const float* ds,
                                     const float* mids, const float* beta,
@@ -200,7 +205,7 @@ int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, 
                                     const void* rgb, const float* g_rgb, const float* g_seg,
                                     const float* g_depth, float* grad_density_feature,
                                     float* grad_semantic, float* grad_rgb, float* grad_beta,
-                                    void* workspace, size_t workspace_bytes, int accumulate,
+                                    void* workspace, size_t workspace_bytes, int flags,
                                     void* wait_event, void* stream);
 
 /*

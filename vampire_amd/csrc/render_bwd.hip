@@ -363,8 +363,9 @@ int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, 
                                     const void* rgb, const float* g_rgb, const float* g_seg,
                                     const float* g_depth, float* grad_density_feature,
                                     float* grad_semantic, float* grad_rgb, float* grad_beta,
-                                    void* workspace, size_t workspace_bytes, int accumulate,
+                                    void* workspace, size_t workspace_bytes, int flags,
                                     void* wait_event, void* stream) {
+  const int accumulate = (flags & VAMP_CAMBWD_ACCUMULATE) ? 1 : 0;
   if (int e = validate(d)) return e;
   VAMP_REQUIRE(geom || (mats && us && vs && ds), "need geom or (mats, us, vs, ds)");
   VAMP_REQUIRE(mids && density_feature && semantic && rgb, "null input");
@@ -378,7 +379,9 @@ int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* packed = static_cast<float*>(workspace);
   float* gpacked = reinterpret_cast<float*>(static_cast<char*>(workspace) + pb);
-  if (int e = launch_pack(P, d->in_dtype, density_feature, semantic, rgb, packed, s)) return e;
+  // the channel-last copy of the three volumes: the forward left it at the head of the workspace
+  if (!(flags & VAMP_CAMBWD_PACKED_VALID))
+    if (int e = launch_pack(P, d->in_dtype, density_feature, semantic, rgb, packed, s)) return e;
   // v2 (owner-computes bricks, no global atomics) needs the matrices to bound candidate
   // boxes; a caller-supplied geom tensor falls back to the v1 atomic splat.
   const char* force = getenv("VAMP_CAM_BWD");

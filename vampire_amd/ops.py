@@ -325,6 +325,10 @@ class _RenderFn(torch.autograd.Function):
         if side is not None:
             cur.wait_stream(side)
         ctx.hp, ctx.desc = hp, d
+        # the workspace now starts with the channel-last copy of (dens, sem, rgb); the backward
+        # reuses it if no other render call has touched the workspace in between
+        hp._pack_gen = getattr(hp, "_pack_gen", 0) + 1
+        ctx.pack_key = (hp._pack_gen, ws.data_ptr())
         ctx.has_geom = geom is not None
         ctx.save_for_backward(dens, sem, base, rgb, beta, geom if geom is not None else mats)
         return rgb_p, seg_p, dep_p, bev_rgb, bev_seg, bev_h, vdens, vout
@@ -356,6 +360,9 @@ class _RenderFn(torch.autograd.Function):
                     _ptr(g_seg), _ptr(g_dep))
         cur, side = torch.cuda.current_stream(), hp._side_stream()
         default_impl = os.environ.get("VAMP_CAM_BWD", "cell")[0] == "c"
+        packed_valid = 2 if ctx.pack_key == (getattr(hp, "_pack_gen", 0), ws.data_ptr()) else 0
+        hp._pack_gen = getattr(hp, "_pack_gen", 0) + 1          # the backward scribbles after the copy only,
+        ctx.pack_key = None                                     # but a second backward must not assume so
         if side is not None and geom is None and default_impl:
             # Two streams: the BEV branch accumulates into zeroed buffers on the side stream while
             # the camera branch marches its rays and sorts its samples on this one; the camera
@@ -368,16 +375,16 @@ class _RenderFn(torch.autograd.Function):
             done = torch.cuda.Event()
             done.record(side)
             _capi.check(hp.lib.vamp_render_camera_backward_acc(
-                *cam_args, _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gbeta), _ptr(ws), ws.numel(), 1,
+                *cam_args, _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gbeta), _ptr(ws), ws.numel(), 1 | packed_valid,
                 C.c_void_p(done.cuda_event), _stream(cur)), "vamp_render_camera_backward_acc")
             cur.wait_stream(side)
         else:
             gd = torch.empty(dens.shape, dtype=f32, device=dens.device)
             gs = torch.empty(sem.shape, dtype=f32, device=dens.device)
             gr = torch.empty(rgb.shape, dtype=f32, device=dens.device)
-            _capi.check(hp.lib.vamp_render_camera_backward(
+            _capi.check(hp.lib.vamp_render_camera_backward_acc(
                 *cam_args, _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gbeta), _ptr(ws), ws.numel(),
-                _stream(cur)), "vamp_render_camera_backward")
+                packed_valid, None, _stream(cur)), "vamp_render_camera_backward_acc")
             bev_backward(cur)
         grad_beta = gbeta.reshape(ctx.beta_shape) if hp.cfg.density_mode == "sdf" else None
         return (None, gd.to(dens.dtype), gs.to(sem.dtype), gb.to(base.dtype), gr.to(rgb.dtype),
