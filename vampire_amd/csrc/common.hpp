@@ -120,6 +120,16 @@ __device__ __forceinline__ dim3 xcd_block() {
   return r;
 }
 
+// Same idea for 1-D grids with uneven work: runs of `group` consecutive logical blocks stay on
+// one XCD (so that neighbours share an L2 and their partial-line stores merge there), and the
+// runs are dealt round-robin, which keeps the load of the XCDs even.  Identity unless the grid
+// is a multiple of 8 * group.
+__device__ __forceinline__ unsigned xcd_grouped(unsigned lin, unsigned n, unsigned group) {
+  const unsigned span = 8u * group;
+  if (group == 0 || n % span != 0) return lin;
+  return (lin / span) * span + (lin & 7u) * group + (lin % span) / 8u;
+}
+
 // ---------------------------------------------------------------------------
 // lane-group reductions
 // ---------------------------------------------------------------------------

@@ -8,11 +8,11 @@
 //   fill    same walk; the pair's record {ix0, iy0, iz0, wz0, wz1 | w[4]*dep[4] | w[4] | gs[C]} --
 //           tap weights, depth-interpolated values, grad_out / (hits + 1e-6) -- goes to the next
 //           slot of its cell (slots handed out by atomics on the cell cursor)
-//   gather  one wave (or 4, or 16) per feature-map pixel: the pairs whose 2x2 pixel taps include pixel (x, y)
-//           are exactly those of the cells (x..x+1, y..y+1), two contiguous record ranges.  The
-//           four 16-lane quarters of the wave take records in turn, lane = channel: grad_feat
-//           accumulates in registers, the channel dot product feeds the two depth bins of the
-//           pixel's private LDS column.  Every output element is stored once.
+//   gather  one wave (or 4, or 16) per feature-map pixel: the pairs whose 2x2 pixel taps include
+//           pixel (x, y) are exactly those of the cells (x..x+1, y..y+1), two contiguous record
+//           ranges.  Lane = record: grad_feat partial sums in registers (folded over the lanes at
+//           the end), the channel dot product feeds the two depth bins of the pixel's private
+//           LDS column.  Every output element is stored once.
 //
 // Both atomic passes aggregate runs of equal cells across the lanes of a wave (x-neighbouring
 // voxels share a cell in the far field), one atomic per run: device-scope atomics are served at
@@ -181,20 +181,24 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
 }
 
 // ---------------------------------------------------------------------------
-// gather: wpp waves per pixel (1, 4 or 16, chosen on the host from the expected records per
-// pixel), max(kMinWaves, wpp) waves per workgroup: small workgroups, because a workgroup lives as
-// long as its slowest pixel (16 / 8 / 4 waves measured 145 / 131 / 125 us at cfg-B)
+// gather: one wave per feature-map pixel (or wpp = 4 / 16 waves for dense configurations, chosen
+// on the host from the expected records per pixel), lane = RECORD: every lane loads one record
+// (64-byte head + its 16 channel gradients -- all of it data only that lane needs, which is what
+// the L1 -> register path is paid for), keeps 16 grad_feat partial sums in registers and adds its
+// two depth-plane terms to the pixel's LDS column.  The 16 x 64 partial sums are folded with a
+// recursive-halving reduction at the end.  C > 16 runs in chunks of 16 channels.
+// max(kMinWaves, wpp) waves per workgroup: small workgroups, because a workgroup lives as long
+// as its slowest pixel.
 // ---------------------------------------------------------------------------
-// NCH = ceil(C / 16) channel chunks per lane
-template <typename T, int NCH, int UB>
+template <typename T>
 __global__ void __launch_bounds__(1024)
-lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, const T* __restrict__ feat,
+lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
+                            const T* __restrict__ feat,
                             const int* __restrict__ off, const int* __restrict__ boff,
                             const float* __restrict__ entries, float* __restrict__ gdepth,
                             float* __restrict__ gfeat) {
-  extern __shared__ float smem[];                // [ppb][Dp] depth columns, then [waves][NCH * 16]
+  extern __shared__ float smem[];                // [ppb][Dp] depth columns, then [waves][16]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int q = lane >> 4, l = lane & 15;        // quarter of the wave, channel lane
   const int C = P.C, D = P.use_depth ? P.D : 0;
   const int Dp = D | 1;
   const int nw = blockDim.x >> 6;
@@ -204,7 +208,9 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, const T* __re
   float* accbuf = smem + ppb * Dp;
   const long HW = (long) P.fH * P.fW;
   const long npix = (long) P.B * P.N * HW;
-  const long pid0 = (long) blockIdx.x * ppb;
+  // the workgroups of one image row run on one XCD: their 16-byte pieces of a depth plane's row
+  // merge into whole lines in that L2
+  const long pid0 = (long) xcd_grouped(blockIdx.x, gridDim.x, xgroup) * ppb;
   const long pid = min(pid0 + pw, npix - 1);
   const bool pix_ok = pid0 + pw < npix;
   const long bn = pid / HW;
@@ -229,84 +235,72 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, const T* __re
   }
   if (!pix_ok) tot = 0;
 
-  float ftc[NCH], acc[NCH];
+  for (int c0 = 0; c0 < C; c0 += 16) {           // channel chunk
+    const int nq = min(4, (C - c0) / 4);         // float4 pieces of this chunk
+    // the pixel's features of this chunk, wave-uniform: one load, then scalar broadcasts
+    const float ftv = (lane < 16 && c0 + lane < C) ? ldf(feat, (bn * C + c0 + lane) * HW + pix) : 0.f;
+    float ft[16];
 #pragma unroll
-  for (int k = 0; k < NCH; ++k) {
-    const int c = l + 16 * k;
-    ftc[k] = (c < C) ? ldf(feat, (bn * C + c) * HW + pix) : 0.f;
-    acc[k] = 0.f;
-  }
+    for (int c = 0; c < 16; ++c)
+      ft[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ftv), c));
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
 
-  // UB records per quarter per round: their loads go out together
-  for (int k0 = ws * 4 * UB; k0 < tot; k0 += wpp * 4 * UB) {
-    float4 ha[UB], hb[UB], pwv[UB], ww[UB];
-    float gs[UB][NCH];
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int kc = min(k0 + u * 4 + q, tot - 1);
+    for (int k0 = ws * 64; k0 < tot; k0 += wpp * 64) {
+      const int k = k0 + lane;
+      const bool in = k < tot;
+      const int kc = min(k, tot - 1);
       const long pos = kc < n0 ? (long) beg0 + kc : (long) beg1 + (kc - n0);
       const float* e = entries + pos * ES;
-      ha[u] = *reinterpret_cast<const float4*>(e);
-      hb[u] = *reinterpret_cast<const float4*>(e + 4);
-      pwv[u] = *reinterpret_cast<const float4*>(e + 8);
-      ww[u] = *reinterpret_cast<const float4*>(e + 12);
+      const float4 ha = *reinterpret_cast<const float4*>(e);
+      const float4 hb = *reinterpret_cast<const float4*>(e + 4);
+      const float4 pwv = *reinterpret_cast<const float4*>(e + 8);
+      const float4 ww = *reinterpret_cast<const float4*>(e + 12);
+      float gs[16];
 #pragma unroll
-      for (int kk = 0; kk < NCH; ++kk) gs[u][kk] = (l + 16 * kk < C) ? e[kRecHead + l + 16 * kk] : 0.f;
-    }
-    float dots[UB], wz0s[UB], wz1s[UB];
-    int iz0s[UB];
-#pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      const int ix0 = __float_as_int(ha[u].x), iy0 = __float_as_int(ha[u].y);
+      for (int q = 0; q < 4; ++q) {
+        float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < nq) g4 = *reinterpret_cast<const float4*>(e + kRecHead + c0 + 4 * q);   // uniform branch
+        gs[4 * q] = g4.x; gs[4 * q + 1] = g4.y; gs[4 * q + 2] = g4.z; gs[4 * q + 3] = g4.w;
+      }
+      const int ix0 = __float_as_int(ha.x), iy0 = __float_as_int(ha.y), iz0 = __float_as_int(ha.z);
       const int j = (iy - iy0) * 2 + (ix - ix0);         // which of the record's taps this pixel is
-      const float pwj = j == 0 ? pwv[u].x : (j == 1 ? pwv[u].y : (j == 2 ? pwv[u].z : pwv[u].w));
-      const float wj = j == 0 ? ww[u].x : (j == 1 ? ww[u].y : (j == 2 ? ww[u].z : ww[u].w));
-      const float live = (k0 + u * 4 + q < tot) ? 1.f : 0.f;
+      const float pwj = in ? (j == 0 ? pwv.x : (j == 1 ? pwv.y : (j == 2 ? pwv.z : pwv.w))) : 0.f;
+      const float wj = in ? (j == 0 ? ww.x : (j == 1 ? ww.y : (j == 2 ? ww.z : ww.w))) : 0.f;
       float dot = 0.f;
 #pragma unroll
-      for (int kk = 0; kk < NCH; ++kk) {
-        acc[kk] = __builtin_fmaf(live * pwj, gs[u][kk], acc[kk]);
-        dot = __builtin_fmaf(ftc[kk], gs[u][kk], dot);
+      for (int c = 0; c < 16; ++c) {
+        acc[c] = __builtin_fmaf(pwj, gs[c], acc[c]);
+        dot = __builtin_fmaf(ft[c], gs[c], dot);
       }
-      dots[u] = live * wj * dot;
-      iz0s[u] = __float_as_int(ha[u].z);
-      wz0s[u] = hb[u].x;
-      wz1s[u] = hb[u].y;
+      if (D > 0 && in) {
+        const float wd = wj * dot;
+        if (wd != 0.f) {
+          if (iz0 >= 0 && iz0 < D) atomicAdd(gcol + iz0, hb.x * wd);
+          if (iz0 + 1 >= 0 && iz0 + 1 < D) atomicAdd(gcol + iz0 + 1, hb.y * wd);
+        }
+      }
     }
-    if (D > 0) {
-      // channel sums of the UB records over the 16 lanes of the quarter by recursive halving:
-      // lanes (16 / UB) u .. end up with record u, and the first two of them add the two depth planes
-      int tu = 0;
-      reduce_halving<UB, 8, 16, UB>(dots, l, tu);
-      int iz0 = iz0s[0];
-      float wz0 = wz0s[0], wz1 = wz1s[0];
-#pragma unroll
-      for (int u = 1; u < UB; ++u)
-        if (tu == u) { iz0 = iz0s[u]; wz0 = wz0s[u]; wz1 = wz1s[u]; }
-      const int sub = l & (16 / UB - 1);
-      const int iz = iz0 + sub;
-      if (sub < 2 && iz >= 0 && iz < D && dots[0] != 0.f) atomicAdd(gcol + iz, (sub ? wz1 : wz0) * dots[0]);
-    }
-  }
-  // sum the four quarters' grad_feat partials (lanes l, l+16, l+32, l+48), then the pixel's waves
-#pragma unroll
-  for (int k = 0; k < NCH; ++k) {
-    float v = acc[k];
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    if (q == 0) accbuf[wv * (NCH * 16) + l + 16 * k] = v;
-  }
-  __syncthreads();
-  if (ws == 0 && q == 0 && pix_ok) {
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-      const int c = l + 16 * k;
-      float v = 0.f;
-      for (int s2 = 0; s2 < wpp; ++s2) v += accbuf[(wv + s2) * (NCH * 16) + c];
-      if (c < C) gfeat[(bn * C + c) * HW + pix] = v;
+    // fold the 64 lanes' partial sums: afterwards lane l holds channel c0 + (l >> 2)
+    int cb = 0;
+    reduce_halving<16, 32, 64, 16>(acc, lane, cb);
+    static_assert(reduce_left<16, 32>() == 1 && reduce_dups<16, 32>() == 3, "16 values over 64 lanes");
+    if (wpp == 1) {
+      if (pix_ok && (lane & 3) == 0 && c0 + cb < C) gfeat[(bn * C + c0 + cb) * HW + pix] = acc[0];
+    } else {
+      if ((lane & 3) == 0) accbuf[wv * 16 + cb] = acc[0];
+      __syncthreads();
+      if (ws == 0 && lane < 16 && pix_ok && c0 + lane < C) {
+        float v = 0.f;
+        for (int s2 = 0; s2 < wpp; ++s2) v += accbuf[(wv + s2) * 16 + lane];
+        gfeat[(bn * C + c0 + lane) * HW + pix] = v;
+      }
+      __syncthreads();
     }
   }
   if (D > 0 && gdepth) {
+    __syncthreads();
     // consecutive threads = consecutive pixels of one depth plane
     for (int e = tid; e < D * ppb; e += nw * 64) {
       const int dz = e / ppb, p = e % ppb;
@@ -382,24 +376,19 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
   const int nw = std::max(kMinWaves, wpp);
   const int ppb = nw / wpp;
   const int Dd = d->use_depth ? d->D : 0;
-  const size_t lds = ((size_t) ppb * (Dd | 1) + (size_t) nw * ((d->C + 15) / 16) * 16) * sizeof(float);
+  const size_t lds = ((size_t) ppb * (Dd | 1) + (size_t) nw * 16) * sizeof(float);
   if (lds > 150 * 1024) return fail(VAMP_EINVAL, "%s: D too large for the LDS depth columns", __func__);
   const unsigned ggrid = (unsigned) ((npix + ppb - 1) / ppb);
-  const int nch = (d->C + 15) / 16;
-#define VAMP_GATHER(NCH)                                                                        \
-  do {                                                                                            \
-    auto k = lift_bwd_cell_gather_kernel<T, NCH, 2>;   /* UB = 4: 93 VGPRs, measured 20 % slower */ \
-    if (lds > 64 * 1024 &&                                                                        \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                     \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) \
-      return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);                           \
-    VAMP_TIMED(kProfLiftBwd, s, (k<<<ggrid, nw * 64, lds, s>>>(                                   \
-        P, g.cw, g.ch, wpp, static_cast<const T*>(feat), w.off, w.boff, w.entries, gdepth,      \
-        gfeat)));                                                                                 \
-  } while (0)
-  if (nch == 1) VAMP_GATHER(1); else if (nch == 2) VAMP_GATHER(2); else if (nch == 3) VAMP_GATHER(3);
-  else VAMP_GATHER(4);
-#undef VAMP_GATHER
+  {
+    auto k = lift_bwd_cell_gather_kernel<T>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess)
+      return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);
+    VAMP_TIMED(kProfLiftBwd, s, (k<<<ggrid, nw * 64, lds, s>>>(
+        P, g.cw, g.ch, wpp, (d->fW % ppb == 0) ? d->fW / ppb : 0, static_cast<const T*>(feat), w.off,
+        w.boff, w.entries, gdepth, gfeat)));
+  }
   return check_launch("lift_bwd_cell_gather_kernel");
 }
 
