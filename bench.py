@@ -36,9 +36,9 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 def kernel_algorithmic_bytes(cfg, B):
     """Compulsory HBM bytes per launch of each kernel: the reference-layout
     tensors the kernel logically consumes are read once and the ones it produces are written
-    once, fp32; scratch traffic (packed copies, sample records, bin lists) is NOT counted, so
+    once, fp32; scratch traffic (packed copies, sample records, cell lists) is NOT counted, so
     `achieved` is a lower bound on what the kernel really moves.  Kernels with no compulsory
-    traffic of their own (count passes, cull, scans) have no entry and cannot be `dominant`."""
+    traffic of their own (count / rank passes, scans, the heavy-voxel pass) have no entry and cannot be `dominant`."""
     P = cfg.num_cams * cfg.fH * cfg.fW
     V = cfg.vZ * cfg.vY * cfg.vX
     C, K, D = cfg.mid_channels, cfg.num_classes, cfg.D
@@ -48,17 +48,16 @@ def kernel_algorithmic_bytes(cfg, B):
     zf = min(1.0, (oZ + 1) / cfg.vZ)                 # fraction of volume planes the det grid touches
     return {
         "lift_fwd": B * (4 * P * (D + C) + 4 * C * V),
-        "lift_bwd_fill": B * (4 * C * V + 8 * V),                 # grad_out + hit words in
-        "lift_bwd": B * (2 * 4 * P * (D + C)),                    # depth/feat in, their grads out
+        "lift_bwd_fill": B * (4 * C * V + 8 * V + 4 * P * D),     # grad_out, hit words, depth in
+        "lift_bwd_gather": B * (4 * P * C + 4 * P * (D + C)),     # feat in, grad_depth / grad_feat out
         "pack_volume": B * (4 * cam * V),                         # the three volumes in
         "render_cam_fwd": B * (4 * cam * V + 4 * P * (K + 4)),
         "render_bev_fwd": B * (4 * V * zf + 4 * YX * (oZ + 1)),
         "render_bev_fwd_channels": B * (4 * (K + 3 + C) * V * zf + 4 * YX * (K + 3) + 4 * oZ * YX * CO),
-        "render_cam_bwd": B * (4 * cam * V + 4 * P * (K + 4)),
+        "render_cam_bwd_ray": B * (4 * cam * V + 4 * P * (K + 4)),  # volumes + upstream gradients in
         "render_cam_bwd_gather": B * (4 * cam * V),               # the three volume gradients out
-        "render_cam_bwd_own": B * (4 * cam * V),                  # (same, bin-then-own scatter)
         "render_bev_bwd_q": B * (4 * (K + 3) * V * zf + 4 * YX * (K + 3)),
-        "render_bev_bwd": B * (4 * V * zf + 4 * YX * (oZ + 2)),
+        "render_bev_bwd_scan": B * (4 * V * zf + 4 * YX * (oZ + 2)),
         "render_bev_bwd_gather": B * (2 * 4 * (cam + C) * V * zf + 4 * oZ * YX * (1 + CO)),
     }
 
@@ -66,9 +65,9 @@ def kernel_algorithmic_bytes(cfg, B):
 STAGES = {   # SURVEY.md section 8(d) stage names -> kernels of this build
     "lift_fwd": ["feat_to_channel_last", "lift_fwd"],
     "render_fwd": ["pack_volume", "render_cam_fwd", "render_bev_fwd", "render_bev_fwd_channels"],
-    "lift_bwd": ["lift_bwd_prep", "lift_bwd_count", "lift_bwd_fill", "lift_bwd", "feat_to_channel_first"],
-    "render_bwd": ["render_cam_bwd", "render_cam_bwd_count", "render_cam_bwd_fill", "render_cam_bwd_own",
-                   "render_cam_bwd_gather", "render_bev_bwd_q", "render_bev_bwd",
+    "lift_bwd": ["lift_bwd_count", "lift_bwd_fill", "lift_bwd_gather", "lift_bwd_v1", "feat_to_channel_first"],
+    "render_bwd": ["render_cam_bwd_ray", "render_cam_bwd_rank", "render_cam_bwd_fill", "render_cam_bwd_gather",
+                   "render_cam_bwd_heavy", "render_cam_bwd_v1", "render_bev_bwd_q", "render_bev_bwd_scan",
                    "render_bev_bwd_gather", "unpack_grad", "memset"],
 }
 
@@ -182,7 +181,7 @@ def main():
         one_step()
     fence()
     _capi.profile_enable(False)
-    warm = _capi.profile_read()
+    warm = {k: (n, ms, n_prof) for k, (n, ms) in _capi.profile_read().items()}
     alg = kernel_algorithmic_bytes(cfg, a.batch)
     dom = None
     if warm:
@@ -200,18 +199,20 @@ def main():
     elapsed = vdist.max_over_ranks(elapsed, dev)
 
     prof = dict(warm)
-    prof.update(_capi.profile_read())            # the dominant kernel: measured over the timed region
+    # the dominant kernel: measured over the timed region
+    prof.update({k: (n, ms, a.steps) for k, (n, ms) in _capi.profile_read().items()})
     if rank == 0:
-        kern = {k: {"launches": n, "avg_us": ms / n * 1e3} for k, (n, ms) in prof.items()}
+        kern = {k: {"launches": n, "avg_us": ms / n * 1e3, "us_per_step": ms / st * 1e3}
+                for k, (n, ms, st) in prof.items()}
         if dom is None:
             dom = max((k for k in kern if k in alg), key=lambda k: kern[k]["avg_us"])
         dom_gbs = alg[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e9
-        # stage view with SURVEY.md section 8(d)'s algorithmic bytes; the forward kernels also run
-        # inside the backward (re-pack), hence per-launch averages rather than per-step sums
+        # stage view with SURVEY.md section 8(d)'s algorithmic bytes: kernel time per step, summed
+        # (with the two render branches on two streams the stage's wall time is below this sum)
         sb = cfg.algorithmic_bytes(4 if a.dtype == "f32" else 2)
         stages = {}
         for st, names in STAGES.items():
-            us = sum(kern[k]["avg_us"] for k in names if k in kern)
+            us = sum(kern[k]["us_per_step"] for k in names if k in kern)
             stages[st] = {"us": round(us, 1), "algorithmic_bytes": sb[st] * a.batch,
                           "frac_of_hbm_peak": round(sb[st] * a.batch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                           if us > 0 else None}
@@ -242,6 +243,7 @@ def main():
                              "algorithmic_bytes": fwd_bytes},
             "stages": stages,
             "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in sorted(kern.items())},
+            "kernels_us_per_step": {k: round(v["us_per_step"], 2) for k, v in sorted(kern.items())},
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)

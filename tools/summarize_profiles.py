@@ -10,21 +10,22 @@ import collections, csv, glob, json, os, sys
 
 out, tag, cfg, batch = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 
-SLOTS = [("lift_fwd_kernel", "lift_fwd"), ("lift_bwd_own_kernel", "lift_bwd"),
-         ("lift_bwd_bin_kernel", None), ("lift_bwd_tile_kernel", "lift_bwd_tile"),
+SLOTS = [("lift_fwd_kernel", "lift_fwd"), ("lift_bwd_cell_gather_kernel", "lift_bwd_gather"),
+         ("lift_bwd_cell_kernel", None), ("lift_bwd_kernel", "lift_bwd_v1"),
          ("feat_to_channel_last", "feat_to_channel_last"), ("pack_volume_kernel", "pack_volume"),
          ("render_cam_fwd_kernel", "render_cam_fwd"), ("bev_density_kernel", "render_bev_fwd"),
-         ("bev_channels_kernel", "render_bev_fwd_channels"), ("cam_bwd_ray_kernel", "render_cam_bwd"),
-         ("cam_bwd_gather_kernel", "render_cam_bwd_gather"), ("cam_bwd_cull_kernel", "cam_bwd_cull"),
-         ("bev_q_kernel", "render_bev_bwd_q"), ("bev_scan_kernel", "render_bev_bwd"),
-         ("bev_gather_kernel", "render_bev_bwd_gather"), ("lift_bwd_prep_kernel", "lift_bwd_prep"),
-         ("exclusive_scan_kernel", "scan"), ("invert_mats_kernel", "invert_mats")]
+         ("bev_channels_kernel", "render_bev_fwd_channels"), ("cam_bwd_ray_kernel", "render_cam_bwd_ray"),
+         ("cam_bwd_cell_gather_kernel", "render_cam_bwd_gather"), ("cam_bwd_cell_heavy_kernel", "render_cam_bwd_heavy"),
+         ("cam_bwd_rank_kernel", "render_cam_bwd_rank"), ("cam_bwd_fill_kernel", "render_cam_bwd_fill"),
+         ("bev_q_kernel", "render_bev_bwd_q"), ("bev_scan_kernel", "render_bev_bwd_scan"),
+         ("bev_gather_kernel", "render_bev_bwd_gather"), ("cell_scan_tile_kernel", "cell_scan"),
+         ("exclusive_scan_kernel", "scan")]
 
 
 def slot(name):
     for key, s in SLOTS:
         if key in name:
-            if key == "lift_bwd_bin_kernel":
+            if key == "lift_bwd_cell_kernel":
                 return "lift_bwd_fill" if "true>" in name.replace(" ", "") else "lift_bwd_count"
             return s
     return None

@@ -44,19 +44,16 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 enum ProfSlot {
   kProfFeatCL = 0, kProfLiftFwd, kProfLiftBwd, kProfFeatCF, kProfLiftFwdDense, kProfLiftBwdDense,
   kProfPack, kProfCamFwd, kProfBevFwd, kProfCamBwd, kProfUnpack, kProfBevBwd, kProfMemset,
-  kProfAux, kProfCamBwdBrick, kProfBevFwdCh, kProfBevBwdQ, kProfBevBwdGather, kProfLiftBwdPrep, kProfLiftBwdCount, kProfLiftBwdFill, kProfCamBwdCount, kProfCamBwdFill, kProfCamBwdOwn, kProfSlots
+  kProfAux, kProfCamBwdBrick, kProfBevFwdCh, kProfBevBwdQ, kProfBevBwdGather, kProfLiftBwdV1,
+  kProfLiftBwdCount, kProfLiftBwdFill, kProfCamBwdCount, kProfCamBwdFill, kProfCamBwdOwn, kProfCamBwdV1,
+  kProfSlots
 };
 struct ProfScope { int idx; };
 bool prof_enabled();
 void prof_begin(int slot, hipStream_t s, ProfScope* sc);
 void prof_end(hipStream_t s, ProfScope* sc);
-// device-side 4x4 inverses (runtime.hip)
-int launch_invert_mats(const float* mats, float* inv, int count, bool reverse3, hipStream_t s);
 // device-side exclusive scan of bin counts (runtime.hip): off[i] = sum_{j<i} cnt[j], fill[i] = 0
 int launch_exclusive_scan(const int* cnt, int* off, int* fill, int n, int* total, hipStream_t s);
-// work items (bin, chunk) for lists split into chunks of `chunk` entries; upper bound on the
-// item count: n + total / chunk
-int launch_build_worklist(const int* cnt, int n, int chunk, int* work, int* nwork, hipStream_t s);
 // Two-level exclusive scan of `ncell` counters (ncell a multiple of kScanTile) for the cell lists:
 // afterwards the start offset of cell c is off[c] + boff[c / kScanTile]; bsum / boff / aux hold
 // ncell / kScanTile ints (aux two more) and aux[ncell / kScanTile] receives the grand total.

@@ -386,9 +386,7 @@ static LiftWs carve(const VampLiftDesc* d, void* ws) {
   w.feat_cl = static_cast<float*>(ws);
   w.gfeat_cl = reinterpret_cast<float*>(static_cast<char*>(ws) + n);
   w.bytes = 2 * n;
-  // backward v3 lists + v2 fallback scratch overlay the same region
-  const size_t v2 = lift_bwd_bin_ws_bytes(d) + lift_bwd_tile_ws_bytes(d);
-  if (v2 > w.bytes) w.bytes = v2;
+  // the backward's cell lists overlay the same region
   const size_t v4 = lift_bwd_cell_ws_bytes(d);
   if (v4 > w.bytes) w.bytes = v4;
   return w;
@@ -422,11 +420,11 @@ static int lift_backward_t(const VampLiftDesc* d, const LiftParams& P, const flo
   dim3 grid((P.X + TX - 1) / TX, (P.Y + TY - 1) / TY, ((P.Z + TZ - 1) / TZ) * P.B);
   const T* dp = static_cast<const T*>(depth);
   if (P.C == 4)
-    VAMP_TIMED(kProfLiftBwd, s, (lift_bwd_kernel<T, 4, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, gout, hits, gdepth, gfeat_cl)));
+    VAMP_TIMED(kProfLiftBwdV1, s, (lift_bwd_kernel<T, 4, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, gout, hits, gdepth, gfeat_cl)));
   else if (P.C == 8)
-    VAMP_TIMED(kProfLiftBwd, s, (lift_bwd_kernel<T, 8, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, gout, hits, gdepth, gfeat_cl)));
+    VAMP_TIMED(kProfLiftBwdV1, s, (lift_bwd_kernel<T, 8, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, gout, hits, gdepth, gfeat_cl)));
   else
-    VAMP_TIMED(kProfLiftBwd, s, (lift_bwd_kernel<T, 16, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, gout, hits, gdepth, gfeat_cl)));
+    VAMP_TIMED(kProfLiftBwdV1, s, (lift_bwd_kernel<T, 16, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, gout, hits, gdepth, gfeat_cl)));
   return check_launch("lift_bwd_kernel");
 }
 
@@ -476,28 +474,12 @@ int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs
   hipStream_t s = static_cast<hipStream_t>(stream);
   const LiftParams P = to_params(d);
   const int BN = d->B * d->N, HW = d->fH * d->fW;
-  // v2 (default): one workgroup per pixel tile with LDS accumulators, no global atomics.
-  // VAMP_LIFT_BWD=v1 selects the per-voxel atomic splat, kept as an independent cross-check.
+  // default: cell list + one wave per pixel (lift_bwd_cell.hip), no float atomics.
+  // VAMP_LIFT_BWD=v1 selects the per-voxel atomic splat below, kept as an independent cross-check.
   const char* force = getenv("VAMP_LIFT_BWD");
-  // default: cell list + one wave per pixel (lift_bwd_cell.hip); v3 / v2 / v1 are the earlier
-  // implementations, kept as independent cross-checks
-  if (!(force && force[0] == 'v' && (force[1] == '1' || force[1] == '2' || force[1] == '3')))
+  if (!(force && force[0] == 'v' && force[1] == '1'))
     return launch_lift_bwd_cell(d, mats, xs, ys, zs, depth, feat, grad_out, hits, grad_depth,
                                 grad_feat, workspace, s);
-  if (!(force && force[0] == 'v' && force[1] == '1')) {
-    // v3 (default): bin (voxel, camera) pairs into per-tile lists, then one workgroup per tile
-    // accumulates in LDS.  v2 (tile enumeration) runs only if the lists overflow the workspace
-    // (decided on the device) or when forced with VAMP_LIFT_BWD=v2.
-    const int* total = nullptr;
-    int cap = 0;
-    char* tile_ws = static_cast<char*>(workspace) + lift_bwd_bin_ws_bytes(d);
-    if (!(force && force[0] == 'v' && force[1] == '2'))
-      if (int e = launch_lift_bwd_bin(d, mats, xs, ys, zs, depth, feat, grad_out, hits, grad_depth,
-                                      grad_feat, workspace, &total, &cap, s))
-        return e;
-    return launch_lift_bwd_tile(d, mats, xs, ys, zs, depth, feat, grad_out, hits, grad_depth,
-                                grad_feat, tile_ws, total, cap, s);
-  }
   if (d->in_dtype == VAMP_F32) launch_to_cl<float>(feat, w.feat_cl, BN, d->C, HW, s);
   else launch_to_cl<__hip_bfloat16>(feat, w.feat_cl, BN, d->C, HW, s);
   if (int e = check_launch("feat_to_channel_last")) return e;

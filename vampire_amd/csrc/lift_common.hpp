@@ -66,19 +66,6 @@ __device__ __forceinline__ LiftTap lift_project(const LiftParams& P, const float
 }
 
 
-// lift_bwd_tile.hip
-size_t lift_bwd_tile_ws_bytes(const VampLiftDesc* d);
-int launch_lift_bwd_tile(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
-                         const float* zs, const void* depth, const void* feat, const float* gout,
-                         const uint64_t* hits, float* gdepth, float* gfeat, void* scratch,
-                         const int* total, int cap, hipStream_t s);
-// lift_bwd_bin.hip
-size_t lift_bwd_bin_ws_bytes(const VampLiftDesc* d);
-int launch_lift_bwd_bin(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
-                        const float* zs, const void* depth, const void* feat, const float* gout,
-                        const uint64_t* hits, float* gdepth, float* gfeat, void* scratch,
-                        const int** total_out, int* cap_out, hipStream_t s);
-
 // lift_bwd_cell.hip
 size_t lift_bwd_cell_ws_bytes(const VampLiftDesc* d);
 int launch_lift_bwd_cell(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,

@@ -382,8 +382,9 @@ int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, 
   // the channel-last copy of the three volumes: the forward left it at the head of the workspace
   if (!(flags & VAMP_CAMBWD_PACKED_VALID))
     if (int e = launch_pack(P, d->in_dtype, density_feature, semantic, rgb, packed, s)) return e;
-  // v2 (owner-computes bricks, no global atomics) needs the matrices to bound candidate
-  // boxes; a caller-supplied geom tensor falls back to the v1 atomic splat.
+  // Default: per-ray pass + cell-list gather (render_bwd_ray.hip, render_bwd_cell.hip), which
+  // evaluates the frustum points itself from the matrices.  A caller-supplied geom tensor, or
+  // VAMP_CAM_BWD=v1, takes the v1 float-atomic splat below (the independent cross-check).
   const char* force = getenv("VAMP_CAM_BWD");
   if (!geom && mats && !(force && force[0] == 'v' && force[1] == '1'))
     return launch_cam_bwd_v2(d, P, mats, us, vs, ds, mids, beta, packed, g_rgb, g_seg, g_depth,
@@ -403,7 +404,7 @@ int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, 
   const unsigned ugrid = (unsigned) ((nvox + 255) / 256);
 #define VAMP_CAMB(CP4)                                                                           \
   do {                                                                                           \
-    VAMP_TIMED(kProfCamBwd, s, (render_cam_bwd_kernel<CP4><<<grid, 256, 0, s>>>(                \
+    VAMP_TIMED(kProfCamBwdV1, s, (render_cam_bwd_kernel<CP4><<<grid, 256, 0, s>>>(                \
         P, geom, mats, us, vs, ds, mids, beta, packed, g_rgb, g_seg, g_depth, gpacked, grad_beta))); \
     if (int e = check_launch("render_cam_bwd_kernel")) return e;                                 \
     VAMP_TIMED(kProfUnpack, s, (unpack_grad_kernel<CP4><<<ugrid, 256, 0, s>>>(                   \

@@ -1,0 +1,232 @@
+// Camera-branch render backward, per-ray pass (the default path; render_bwd.hip holds the v1
+// float-atomic splat kept as an independent cross-check, and the compositing algebra).
+//
+//  cam_bwd_ray   four waves per 8x8 ray tile, one per depth chunk: each re-marches its samples
+//                once (8-tap gather of the packed volume), keeps (s0, delta, q) per sample in
+//                LDS, merges the chunks through LDS and emits one record per sample: the
+//                compositing weight w_i, dL/ds_i[0], the continuous tap coordinates (fx, fy, fz)
+//                exactly as the forward computed them, and the packed floor taps (KEY, 0 =
+//                masked); plus the ray's upstream gradient row (Gcl).
+//  The records are then sorted into voxel cells and gathered per voxel: render_bwd_cell.hip.
+#include "render_common.hpp"
+
+namespace vamp {
+
+// ---------------------------------------------------------------------------
+// per-ray pass
+// ---------------------------------------------------------------------------
+template <int LPR, int CP4>
+__global__ void __launch_bounds__(256)
+cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* __restrict__ us,
+                   const float* __restrict__ vs, const float* __restrict__ ds,
+                   const float* __restrict__ mids, const float* __restrict__ beta_raw,
+                   const float* __restrict__ packed, const float* __restrict__ g_rgb,
+                   const float* __restrict__ g_seg, const float* __restrict__ g_depth,
+                   float* __restrict__ Wbuf, float* __restrict__ G0buf, float* __restrict__ FX,
+                   float* __restrict__ FY, float* __restrict__ FZ, int* __restrict__ KEY,
+                   float* __restrict__ Gcl, float* __restrict__ grad_beta, int L) {
+  constexpr int CP = CP4 * 4;
+  extern __shared__ float lds[];              // [3][L][256]: s0, delta (sign = no-grad flag), q
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  float* l_s0 = lds;
+  float* l_dl = lds + (long) L * 256;
+  float* l_q = lds + (long) 2 * L * 256;
+
+  // wave-per-depth-chunk mapping (render_common.hpp): lanes = the 64 rays of an 8x8 tile
+  static_assert(LPR == 4, "the four waves of the workgroup are the four depth chunks");
+  __shared__ float xm[2 * 4 * 64];
+  const RayId id = decode_ray_wps(P);
+  const bool live = id.live;
+  const int w = id.w, h = id.h, sub = id.sub, b = id.b;
+  const long bn = id.bn;
+  const long ray = (bn * P.fH + h) * P.fW + w;
+  const DensityParams dp = load_density(P.density_mode, beta_raw, P.beta_min, P.sdf_bias);
+  const int S = P.D - 1;
+  const int i0 = min(S, sub * L), i1 = min(S, i0 + L);
+  const float* m = mats + bn * 48;
+  const float u = us[w], v = vs[h];
+  const long V = (long) P.Z * P.Y * P.X;
+  const float* vol = packed + (long) b * V * CP;
+  const long HW = (long) P.fH * P.fW;
+  const long pix = (long) h * P.fW + w;
+
+  float G[CP];
+#pragma unroll
+  for (int c = 0; c < CP; ++c) {
+    float gv = 0.f;
+    if (live) {
+      if (c >= 1 && c <= P.K) gv = g_seg ? g_seg[(bn * P.K + (c - 1)) * HW + pix] : 0.f;
+      else if (c > P.K && c <= P.K + 3) gv = g_rgb ? g_rgb[(bn * 3 + (c - 1 - P.K)) * HW + pix] : 0.f;
+    }
+    G[c] = gv;
+  }
+  const float Gd = (live && g_depth) ? g_depth[bn * HW + pix] : 0.f;
+  if (live && sub == 0) {
+    float4* dst = reinterpret_cast<float4*>(Gcl + ray * CP);
+#pragma unroll
+    for (int q = 0; q < CP4; ++q) dst[q] = make_float4(G[q * 4], G[q * 4 + 1], G[q * 4 + 2], G[q * 4 + 3]);
+  }
+
+  // ---- march the chunk once ----
+  float px, py, pz, qx, qy, qz;
+  auto point = [&](int i, float& x, float& y, float& z) {
+    frustum_point(m, u, v, ds[i], x, y, z);
+    x = nan_to_num_geom(x); y = nan_to_num_geom(y); z = nan_to_num_geom(z);
+  };
+  if (i0 < i1) point(i0, px, py, pz);
+  float cum = 0.f, A = 0.f;
+  for (int i = i0; i < i1; ++i) {
+    point(i + 1, qx, qy, qz);
+    const VolTap tp = volume_tap(P, px, py, pz);
+    float s[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) s[c] = 0.f;
+    if (tp.inside) {
+      gather_taps<CP4>(P, vol, tp, s);
+    }
+    const bool fin = (s[0] == s[0]) && (fabsf(s[0]) <= 3.402823466e+38f);
+    const float s0 = nan_to_num(s[0]);
+    float qv = Gd * (mids[i] - P.d_far);
+#pragma unroll
+    for (int c = 1; c < CP; ++c) qv = __builtin_fmaf(G[c], nan_to_num(s[c]), qv);
+    const float dx = qx - px, dy = qy - py, dz = qz - pz;
+    const float delta = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float tau = density_fwd(dp, s0) * delta;
+    A = __builtin_fmaf((1.0f - expf(-tau)) * expf(-cum), qv, A);
+    cum += tau;
+    const int j = i - i0;
+    l_s0[j * 256 + tid] = s0;
+    // a sample passes gradient to s[0] only if it is inside and finite: flag in the sign
+    l_dl[j * 256 + tid] = (tp.inside && fin) ? delta : -delta;
+    l_q[j * 256 + tid] = qv;
+    if (live) {
+      const long sidx = ((bn * S + i) * P.fH + h) * P.fW + w;
+      const float nanv = __builtin_nanf("");
+      FX[sidx] = tp.inside ? tp.fx : nanv;     // NaN: masked sample, matches no voxel
+      FY[sidx] = tp.fy;
+      FZ[sidx] = tp.fz;
+      // floor taps packed 11/11/10 bits (+1 so that 0 = masked): the cell id of the sample
+      KEY[sidx] = tp.inside ? ((tp.ix0 + 1) | ((tp.iy0 + 1) << 11) | ((tp.iz0 + 1) << 22)) : 0;
+    }
+    px = qx; py = qy; pz = qz;
+  }
+
+  // ---- merge the LPR chunks of the ray ----
+  float scale = 1.f, suffix = 0.f;
+  {
+    const int lane = tid & 63;
+    xm[sub * 64 + lane] = cum;
+    __syncthreads();
+    float excl = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < sub) excl += xm[k * 64 + lane];
+    scale = expf(-excl);
+    xm[(4 + sub) * 64 + lane] = scale * A;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k > sub) suffix += xm[(4 + k) * 64 + lane];     // sum_{m > sub} scale_m A_m
+  }
+
+  // ---- second loop over the LDS copies: emit w_i and dL/ds_i[0] ----
+  float cl = 0.f, prefix = 0.f, dbeta = 0.f;
+  for (int i = i0; i < i1; ++i) {
+    const int j = i - i0;
+    const float s0 = l_s0[j * 256 + tid];
+    const float dl = l_dl[j * 256 + tid];
+    const float qv = l_q[j * 256 + tid];
+    const float delta = fabsf(dl);
+    const float tau = density_fwd(dp, s0) * delta;
+    const float wloc = (1.0f - expf(-tau)) * expf(-cl);
+    const float Tn = scale * expf(-(cl + tau));
+    cl += tau;
+    prefix = __builtin_fmaf(wloc, qv, prefix);
+    const float R = scale * (A - prefix) + suffix;
+    const float dtau = qv * Tn - R;
+    float dsig_ds, dsig_db;
+    density_bwd(dp, s0, dsig_ds, dsig_db);
+    dbeta = __builtin_fmaf(dtau * delta, dsig_db, dbeta);
+    if (live) {
+      const long sidx = ((bn * S + i) * P.fH + h) * P.fW + w;
+      Wbuf[sidx] = scale * wloc;
+      G0buf[sidx] = (dl > 0.f) ? dtau * delta * dsig_ds : 0.f;
+    }
+  }
+  if (P.density_mode == VAMP_DENSITY_SDF_LAPLACE) {
+    float vsum = live ? dbeta : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vsum += __shfl_down(vsum, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = vsum;
+    __syncthreads();
+    if (tid == 0) {
+      const float tot = red[0] + red[1] + red[2] + red[3];
+      const float sgn = (beta_raw[0] > 0.f) ? 1.f : ((beta_raw[0] < 0.f) ? -1.f : 0.f);
+      atomicAdd(grad_beta, sgn * tot);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+size_t cam_bwd_cell_bytes(const VampRenderDesc* d);    // render_bwd_cell.hip
+int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const float* FX,
+                        const float* FY, const float* FZ, const int* KEY, const float* Wbuf,
+                        const float* G0buf, const float* Gcl, float* gdens, float* gsem,
+                        float* grgb, void* scratch, int accumulate, hipEvent_t wait_event,
+                        hipStream_t s);
+
+size_t cam_bwd_v2_bytes(const VampRenderDesc* d) {
+  const RenderParams P = to_params(d);
+  const size_t samples = (size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW;
+  const size_t rays = (size_t) d->B * d->N * d->fH * d->fW;
+  return 6 * align_up(samples * sizeof(float), 256) + align_up(rays * P.CP * sizeof(float), 256) +
+         cam_bwd_cell_bytes(d);
+}
+
+// scratch = workspace region after the packed volume
+int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const float* mats,
+                      const float* us, const float* vs, const float* ds, const float* mids,
+                      const float* beta, const float* packed, const float* g_rgb,
+                      const float* g_seg, const float* g_depth, float* gdens, float* gsem,
+                      float* grgb, float* grad_beta, void* scratch, int accumulate,
+                      hipEvent_t wait_event, hipStream_t s) {
+  const size_t samples = (size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW;
+  const size_t rays = (size_t) d->B * d->N * d->fH * d->fW;
+  char* p = static_cast<char*>(scratch);
+  float* Wbuf = reinterpret_cast<float*>(p); p += align_up(samples * sizeof(float), 256);
+  float* G0buf = reinterpret_cast<float*>(p); p += align_up(samples * sizeof(float), 256);
+  float* FX = reinterpret_cast<float*>(p); p += align_up(samples * sizeof(float), 256);
+  float* FY = reinterpret_cast<float*>(p); p += align_up(samples * sizeof(float), 256);
+  float* FZ = reinterpret_cast<float*>(p); p += align_up(samples * sizeof(float), 256);
+  int* KEY = reinterpret_cast<int*>(p); p += align_up(samples * sizeof(float), 256);
+  float* Gcl = reinterpret_cast<float*>(p); p += align_up(rays * P.CP * sizeof(float), 256);
+  void* cell_scratch = p;
+
+  constexpr int LPR = 4;
+  const int S = d->D - 1;
+  const int L = (S + LPR - 1) / LPR;
+  const size_t lds = (size_t) 3 * L * 256 * sizeof(float);
+  if (lds > 150 * 1024) return fail(VAMP_EINVAL, "%s: too many depth samples for the LDS staging", __func__);
+  const unsigned grid = ray_grid<LPR>(P);
+#define VAMP_RAY(CP4)                                                                             \
+  do {                                                                                            \
+    auto kr = cam_bwd_ray_kernel<LPR, CP4>;                                                       \
+    if (lds > 64 * 1024 &&                                                                        \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kr),                                    \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) \
+      return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);                           \
+    VAMP_TIMED(kProfCamBwd, s, (kr<<<grid, 256, lds, s>>>(P, mats, us, vs, ds, mids, beta, packed, \
+                                                           g_rgb, g_seg, g_depth, Wbuf, G0buf, FX, FY, FZ, \
+                                                           KEY, Gcl, grad_beta, L)));                  \
+  } while (0)
+  if (P.CP == 12) VAMP_RAY(3); else if (P.CP == 24) VAMP_RAY(6); else VAMP_RAY(8);
+#undef VAMP_RAY
+  if (int e = check_launch("cam_bwd_ray_kernel")) return e;
+  return launch_cam_bwd_cell(d, P, FX, FY, FZ, KEY, Wbuf, G0buf, Gcl, gdens, gsem, grgb,
+                             cell_scratch, accumulate, wait_event, s);
+}
+
+}  // namespace vamp

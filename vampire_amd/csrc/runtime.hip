@@ -20,11 +20,11 @@ int g_only = -1;                   // >= 0: time this slot only (keeps the timed
 std::vector<Pair> g_pairs;        // recorded since enable(1)
 std::vector<Pair> g_free;         // recycled events
 const char* g_names[kProfSlots] = {
-    "feat_to_channel_last", "lift_fwd", "lift_bwd", "feat_to_channel_first", "lift_fwd_dense",
-    "lift_bwd_dense", "pack_volume", "render_cam_fwd", "render_bev_fwd", "render_cam_bwd",
-    "unpack_grad", "render_bev_bwd", "memset", "aux", "render_cam_bwd_gather", "render_bev_fwd_channels",
-    "render_bev_bwd_q", "render_bev_bwd_gather", "lift_bwd_prep", "lift_bwd_count",
-    "lift_bwd_fill", "render_cam_bwd_count", "render_cam_bwd_fill", "render_cam_bwd_own"};
+    "feat_to_channel_last", "lift_fwd", "lift_bwd_gather", "feat_to_channel_first", "lift_fwd_dense",
+    "lift_bwd_dense", "pack_volume", "render_cam_fwd", "render_bev_fwd", "render_cam_bwd_ray",
+    "unpack_grad", "render_bev_bwd_scan", "memset", "aux", "render_cam_bwd_gather", "render_bev_fwd_channels",
+    "render_bev_bwd_q", "render_bev_bwd_gather", "lift_bwd_v1", "lift_bwd_count",
+    "lift_bwd_fill", "render_cam_bwd_rank", "render_cam_bwd_fill", "render_cam_bwd_heavy", "render_cam_bwd_v1"};
 }  // namespace
 
 bool prof_enabled() { return g_on; }
@@ -52,47 +52,6 @@ void prof_end(hipStream_t s, ProfScope* sc) {
   if (sc->idx < (int) g_pairs.size()) (void) hipEventRecord(g_pairs[sc->idx].b, s);
 }
 
-
-// ---------------------------------------------------------------------------
-// 4x4 inverses (Gauss-Jordan, partial pivoting, double).  With reverse3 the matrices are taken
-// in triples and each triple is written in reverse order (inverse of a 3-matrix chain).
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
-invert_mats_kernel(const float* __restrict__ mats, float* __restrict__ inv, int count, int reverse3) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  double a[4][8];
-  for (int r = 0; r < 4; ++r)
-    for (int c = 0; c < 4; ++c) {
-      a[r][c] = mats[i * 16 + r * 4 + c];
-      a[r][4 + c] = (r == c) ? 1.0 : 0.0;
-    }
-  for (int col = 0; col < 4; ++col) {
-    int piv = col;
-    double best = fabs(a[col][col]);
-    for (int r = col + 1; r < 4; ++r)
-      if (fabs(a[r][col]) > best) { best = fabs(a[r][col]); piv = r; }
-    if (piv != col)
-      for (int c = 0; c < 8; ++c) { double t = a[col][c]; a[col][c] = a[piv][c]; a[piv][c] = t; }
-    const double d = a[col][col];
-    const double id = (d != 0.0) ? 1.0 / d : 0.0;      // singular -> zeros -> full-image boxes
-    for (int c = 0; c < 8; ++c) a[col][c] *= id;
-    for (int r = 0; r < 4; ++r) {
-      if (r == col) continue;
-      const double f = a[r][col];
-      for (int c = 0; c < 8; ++c) a[r][c] -= f * a[col][c];
-    }
-  }
-  const int o = reverse3 ? (i / 3) * 3 + (2 - i % 3) : i;
-  for (int r = 0; r < 4; ++r)
-    for (int c = 0; c < 4; ++c) inv[o * 16 + r * 4 + c] = (float) a[r][4 + c];
-}
-
-
-int launch_invert_mats(const float* mats, float* inv, int count, bool reverse3, hipStream_t s) {
-  VAMP_TIMED(kProfAux, s, (invert_mats_kernel<<<(count + 63) / 64, 64, 0, s>>>(mats, inv, count, reverse3 ? 1 : 0)));
-  return check_launch("invert_mats_kernel");
-}
 
 // ---------------------------------------------------------------------------
 // Exclusive prefix sum of per-owner counts (bin sizes -> list offsets) in one 1024-thread
@@ -130,43 +89,6 @@ exclusive_scan_kernel(const int* __restrict__ cnt, int* __restrict__ off, int* _
     __syncthreads();
   }
   if (tid == 0) *total = carry;
-}
-
-// Work list for the "own" kernels: a bin with cnt entries becomes max(1, ceil(cnt / chunk)) work
-// items (bin, chunk index), so that one very long list (near-field bricks, horizon tiles) is
-// spread over several workgroups.  work[2*k] = bin, work[2*k+1] = chunk; *nwork = item count.
-__global__ void __launch_bounds__(1024)
-build_worklist_kernel(const int* __restrict__ cnt, int n, int chunk, int* __restrict__ work,
-                      int* __restrict__ nwork) {
-  __shared__ int wsum[16];
-  __shared__ int carry;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + tid;
-    const int k = i < n ? max(1, (cnt[i] + chunk - 1) / chunk) : 0;
-    int incl = k;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int up = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += up;
-    }
-    if (lane == 63) wsum[wv] = incl;
-    __syncthreads();
-    int wbase = 0;
-    for (int q = 0; q < wv; ++q) wbase += wsum[q];
-    const int c0 = carry;
-    const int first = c0 + wbase + incl - k;
-    for (int j = 0; j < k; ++j) {
-      work[2 * (first + j)] = i;
-      work[2 * (first + j) + 1] = j;
-    }
-    __syncthreads();
-    if (tid == 1023) carry = c0 + wbase + incl;
-    __syncthreads();
-  }
-  if (tid == 0) *nwork = carry;
 }
 
 // Level 1 of the cell-list scan: exclusive scan inside each kScanTile-cell tile (256 threads x 8
@@ -215,11 +137,6 @@ int launch_cell_scan(const int* cnt, int* off, int* bsum, int* boff, int* aux, l
   VAMP_TIMED(kProfAux, s, (cell_scan_tile_kernel<<<(unsigned) ntile, 256, 0, s>>>(cnt, off, bsum)));
   if (int e = check_launch("cell_scan_tile_kernel")) return e;
   return launch_exclusive_scan(bsum, boff, aux, (int) ntile, aux + ntile, s);
-}
-
-int launch_build_worklist(const int* cnt, int n, int chunk, int* work, int* nwork, hipStream_t s) {
-  VAMP_TIMED(kProfAux, s, (build_worklist_kernel<<<1, 1024, 0, s>>>(cnt, n, chunk, work, nwork)));
-  return check_launch("build_worklist_kernel");
 }
 
 int launch_exclusive_scan(const int* cnt, int* off, int* fill, int n, int* total, hipStream_t s) {
