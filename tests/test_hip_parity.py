@@ -166,6 +166,60 @@ def test_render_forward_backward_tiny(tiny_common, dev, mode, cat_seg, use_geom)
         close(beta.grad.reshape(1), r["grad_beta"], atol=1e-3, rtol=1e-3, what="grad_beta")
 
 
+def test_render_non_finite_volume_entries(tiny_common, dev, monkeypatch):
+    """nan / +-inf voxels: the sampled features go through nan_to_num (bv2:421) before density and
+    compositing.  The kernels sanitise only where a sample is not finite (fast path otherwise);
+    forward against the oracle, camera-branch backward against the v1 implementation."""
+    from oracle import aten_oracle as O
+    g = tiny_common
+    cfg = dataclasses.replace(CFG_TINY, density_mode="sdf", cat_seg=False)
+    hp = hot(cfg, dev)
+    geo = PathGeometry(cfg)
+    _, rm = tiny_mats(g, dev)
+    vols = [g[k].clone() for k in ("density_feature", "semantic_logits", "base", "rgb")]
+    gen = torch.Generator().manual_seed(4)
+    # +-inf only in the density feature (it saturates the density); in the composited channels an
+    # inf becomes +-FLT_MAX, whose sums are not comparable at any tolerance
+    for t, vals in zip((vols[0], vols[0], vols[1], vols[3]),
+                       ((float("nan"), float("inf")), (float("nan"), -float("inf")),
+                        (float("nan"), float("nan")), (float("nan"), float("nan")))):
+        flat = t.view(-1)
+        idx = torch.randperm(flat.numel(), generator=gen)[:24]
+        flat[idx[:12]] = vals[0]
+        flat[idx[12:]] = vals[1]
+    beta = torch.tensor(0.1)
+    geom = torch.nan_to_num(g["geom"], -1e3)
+    ref = O.render(geom, *vols, seg_bounds=(cfg.x_bound_seg, cfg.y_bound_seg, cfg.z_bound_seg),
+                   output_coords=geo.output_coords, camera_mids=geo.camera_mids, bev_mids=geo.bev_mids,
+                   d_far=cfg.d_bound[1], z_step_det=cfg.z_bound_det[2], num_classes=cfg.num_classes,
+                   density_mode="sdf", beta_param=beta, sdf_bias=cfg.sdf_bias, cat_seg=False)
+
+    def run(impl):
+        monkeypatch.setenv("VAMP_CAM_BWD", impl)
+        dv = [v.to(dev).requires_grad_(True) for v in vols]
+        b = beta.to(dev).requires_grad_(True)
+        outs = hp.render(*dv, b, render_mats=rm)
+        gg = torch.Generator(device=dev).manual_seed(3)
+        gs = [torch.randn(o.shape, device=dev, generator=gg) for o in outs]
+        for i in (3, 4, 5, 6, 7):
+            gs[i].zero_()
+        torch.autograd.backward(outs, gs)
+        return outs, [v.grad for v in dv], b.grad
+
+    outs, grads, _ = run("cell")
+    for name, o, r in list(zip(NAMES, outs, ref))[:3]:          # camera branch
+        close(o, r, atol=2e-4, rtol=1e-4, what="non-finite volume: " + name)
+    _, grads1, _ = run("v1")
+    # the BEV branch has no nan_to_num in the reference (bv2:442-461), so its backward puts nan into
+    # the gradients around the non-finite voxels in both runs: same places, and equal elsewhere
+    for name, a, b in zip(("density_feature", "semantic_logits", "base", "rgb"), grads, grads1):
+        fin = torch.isfinite(b)
+        assert torch.equal(torch.isfinite(a), fin), name
+        assert float(fin.float().mean()) > 0.5, name
+        close(torch.where(fin, a, 0.0), torch.where(fin, b, 0.0), atol=1e-5, rtol=2e-5, scale="max",
+              what="non-finite volume: cell vs v1 grad_" + name)
+
+
 # --------------------------------------------------------------------------- full size
 def _sha(t):
     return hashlib.sha256(np.ascontiguousarray(t.cpu().numpy()).tobytes()).hexdigest()

@@ -87,9 +87,19 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
     }
     const bool fin = (s[0] == s[0]) && (fabsf(s[0]) <= 3.402823466e+38f);
     const float s0 = nan_to_num(s[0]);
-    float qv = Gd * (mids[i] - P.d_far);
+    // q = G_depth (mid - d_far) + sum_c G_c nan_to_num(s_c).  A non-finite s_c always leaves the
+    // plain chain non-finite (inf * 0 and nan * 0 are nan), so the 4-instruction sanitiser per
+    // channel only runs on the rare lanes whose plain result is not finite; otherwise the plain
+    // chain IS the sanitised one, bit for bit.
+    const float qbase = Gd * (mids[i] - P.d_far);
+    float qv = qbase;
 #pragma unroll
-    for (int c = 1; c < CP; ++c) qv = __builtin_fmaf(G[c], nan_to_num(s[c]), qv);
+    for (int c = 1; c < CP; ++c) qv = __builtin_fmaf(G[c], s[c], qv);
+    if (!(fabsf(qv) <= 3.402823466e+38f)) {
+      qv = qbase;
+#pragma unroll
+      for (int c = 1; c < CP; ++c) qv = __builtin_fmaf(G[c], nan_to_num(s[c]), qv);
+    }
     const float dx = qx - px, dy = qy - py, dz = qz - pz;
     const float delta = sqrtf(dx * dx + dy * dy + dz * dz);
     const float tau = density_fwd(dp, s0) * delta;

@@ -92,8 +92,15 @@ render_cam_fwd_kernel(RenderParams P, const float* __restrict__ geom, const floa
     for (int c = 0; c < CP; ++c) s[c] = 0.f;
     if (tp.inside) {
       gather_taps<CP4>(P, vol, tp, s);
+      // nan_to_num of the sampled features (bv2:421) only where something is not finite:
+      // sum_c 0 * s_c is nan exactly then
+      float chk = 0.f;
 #pragma unroll
-      for (int c = 0; c < CP; ++c) s[c] = nan_to_num(s[c]);       // bv2:421
+      for (int c = 0; c < CP; ++c) chk = __builtin_fmaf(s[c], 0.f, chk);
+      if (chk != chk) {
+#pragma unroll
+        for (int c = 0; c < CP; ++c) s[c] = nan_to_num(s[c]);
+      }
     }
     const float sigma = density_fwd(dp, s[0]);                    // masked sample -> density(0)
     const float dx = qx - px, dy = qy - py, dz = qz - pz;
