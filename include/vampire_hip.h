@@ -104,6 +104,23 @@ int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs
                        size_t workspace_bytes, void* stream);
 
 /*
+ * The backward first sorts the valid (voxel, camera) pairs by feature-map pixel; the counting
+ * half of that depends on the geometry only.  vamp_lift_prepare runs it ahead of time into
+ * `workspace` (e.g. on a second stream beside vamp_lift_forward, which leaves that part of the
+ * workspace alone), and vamp_lift_backward_ex with VAMP_LIFTBWD_CELLS_VALID then skips it: the
+ * caller asserts that `workspace` is the same buffer, d / mats / xs / ys / zs are unchanged and
+ * no other lift backward has run on it since.  flags == 0 is vamp_lift_backward.
+ */
+#define VAMP_LIFTBWD_CELLS_VALID 1
+int vamp_lift_prepare(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
+                      const float* zs, void* workspace, size_t workspace_bytes, void* stream);
+int vamp_lift_backward_ex(const VampLiftDesc* d, const float* mats, const float* xs,
+                          const float* ys, const float* zs, const void* depth,
+                          const void* feat, const float* grad_out, const uint64_t* hits,
+                          float* grad_depth, float* grad_feat, void* workspace,
+                          size_t workspace_bytes, int flags, void* stream);
+
+/*
  * Signature-compatible path for get_voxel_feats(frustum_feats, ...) (bv2:483):
  * gathers from the materialised [B, N, C, D, fH, fW] fp32 tensor.
  */

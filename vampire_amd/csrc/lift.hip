@@ -376,7 +376,8 @@ static void launch_to_cl(const void* feat, float* out, int BN, int C, int HW, hi
 
 struct LiftWs {
   float* feat_cl;     // [B*N, HW, C]
-  float* gfeat_cl;    // [B*N, HW, C] (backward only)
+  float* gfeat_cl;    // [B*N, HW, C] (v1 backward only)
+  void* cells;        // cell lists of the backward; vamp_lift_prepare fills their offsets
   size_t bytes;
 };
 
@@ -385,10 +386,9 @@ static LiftWs carve(const VampLiftDesc* d, void* ws) {
   const size_t n = align_up((size_t) d->B * d->N * d->fH * d->fW * d->C * sizeof(float), 256);
   w.feat_cl = static_cast<float*>(ws);
   w.gfeat_cl = reinterpret_cast<float*>(static_cast<char*>(ws) + n);
-  w.bytes = 2 * n;
-  // the backward's cell lists overlay the same region
-  const size_t v4 = lift_bwd_cell_ws_bytes(d);
-  if (v4 > w.bytes) w.bytes = v4;
+  // the cell lists live behind the copies: the forward must not disturb prepared offsets
+  w.cells = static_cast<char*>(ws) + 2 * n;
+  w.bytes = 2 * n + lift_bwd_cell_ws_bytes(d);
   return w;
 }
 
@@ -460,10 +460,29 @@ int vamp_lift_forward(const VampLiftDesc* d, const float* mats, const float* xs,
   return lift_forward_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, s);
 }
 
+int vamp_lift_prepare(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
+                      const float* zs, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  VAMP_REQUIRE(mats && xs && ys && zs, "null pointer");
+  const LiftWs w = carve(d, workspace);
+  if (!workspace || workspace_bytes < w.bytes)
+    return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) w.bytes);
+  return launch_lift_cell_prepare(d, mats, xs, ys, zs, w.cells, static_cast<hipStream_t>(stream));
+}
+
 int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                        const float* zs, const void* depth, const void* feat,
                        const float* grad_out, const uint64_t* hits, float* grad_depth,
                        float* grad_feat, void* workspace, size_t workspace_bytes, void* stream) {
+  return vamp_lift_backward_ex(d, mats, xs, ys, zs, depth, feat, grad_out, hits, grad_depth, grad_feat,
+                               workspace, workspace_bytes, 0, stream);
+}
+
+int vamp_lift_backward_ex(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
+                          const float* zs, const void* depth, const void* feat,
+                          const float* grad_out, const uint64_t* hits, float* grad_depth,
+                          float* grad_feat, void* workspace, size_t workspace_bytes, int flags,
+                          void* stream) {
   if (int e = validate(d)) return e;
   VAMP_REQUIRE(mats && xs && ys && zs && feat && grad_out && hits && grad_feat, "null pointer");
   VAMP_REQUIRE((depth && grad_depth) || !d->use_depth, "depth / grad_depth is NULL");
@@ -479,7 +498,7 @@ int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs
   const char* force = getenv("VAMP_LIFT_BWD");
   if (!(force && force[0] == 'v' && force[1] == '1'))
     return launch_lift_bwd_cell(d, mats, xs, ys, zs, depth, feat, grad_out, hits, grad_depth,
-                                grad_feat, workspace, s);
+                                grad_feat, w.cells, (flags & VAMP_LIFTBWD_CELLS_VALID) != 0, s);
   if (d->in_dtype == VAMP_F32) launch_to_cl<float>(feat, w.feat_cl, BN, d->C, HW, s);
   else launch_to_cl<__hip_bfloat16>(feat, w.feat_cl, BN, d->C, HW, s);
   if (int e = check_launch("feat_to_channel_last")) return e;

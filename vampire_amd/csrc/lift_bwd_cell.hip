@@ -339,11 +339,10 @@ static LiftCellWs lift_cell_ws(const VampLiftDesc* d, void* scratch) {
 
 size_t lift_bwd_cell_ws_bytes(const VampLiftDesc* d) { return lift_cell_ws(d, nullptr).bytes; }
 
-template <typename T>
-static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float* mats,
-                         const float* xs, const float* ys, const float* zs, const void* depth,
-                         const void* feat, const float* gout, const uint64_t* hits, float* gdepth,
-                         float* gfeat, void* scratch, hipStream_t s) {
+// count + scan: geometry only, so the host may run it beside the forward (vamp_lift_prepare)
+int launch_lift_cell_prepare(const VampLiftDesc* d, const float* mats, const float* xs,
+                             const float* ys, const float* zs, void* scratch, hipStream_t s) {
+  const LiftParams P = to_params(d);
   const LiftCells g = lift_cells(d);
   const LiftCellWs w = lift_cell_ws(d, scratch);
   const size_t cap = (size_t) d->B * d->N * d->Z * d->Y * d->X;
@@ -351,18 +350,30 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
   if (hipMemsetAsync(w.cnt, 0, (size_t) g.ncell * sizeof(int), s) != hipSuccess)
     return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
   dim3 grid((d->X + 63) / 64, (d->Y + 3) / 4, d->Z * d->B);
-  const T* dp = static_cast<const T*>(depth);
-#define VAMP_CELL(CH, FILLV)                                                                     \
-  VAMP_TIMED(FILLV ? kProfLiftBwdFill : kProfLiftBwdCount, s,                                   \
-             (lift_bwd_cell_kernel<T, CH, FILLV><<<grid, 256, 0, s>>>(                          \
-                 P, g.cw, g.ch, mats, xs, ys, zs, dp, gout, hits, w.cnt, w.off, w.boff, w.entries)))
-  if (P.C == 4) VAMP_CELL(4, false); else if (P.C == 8) VAMP_CELL(8, false); else VAMP_CELL(16, false);
+  VAMP_TIMED(kProfLiftBwdCount, s, (lift_bwd_cell_kernel<float, 16, false><<<grid, 256, 0, s>>>(
+      P, g.cw, g.ch, mats, xs, ys, zs, nullptr, nullptr, nullptr, w.cnt, w.off, w.boff, w.entries)));
   if (int e = check_launch("lift_bwd_cell_kernel<count>")) return e;
-  if (int e = launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, g.ncell, s)) return e;
+  return launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, g.ncell, s);
+}
+
+template <typename T>
+static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float* mats,
+                         const float* xs, const float* ys, const float* zs, const void* depth,
+                         const void* feat, const float* gout, const uint64_t* hits, float* gdepth,
+                         float* gfeat, void* scratch, bool cells_valid, hipStream_t s) {
+  const LiftCells g = lift_cells(d);
+  const LiftCellWs w = lift_cell_ws(d, scratch);
+  if (!cells_valid)
+    if (int e = launch_lift_cell_prepare(d, mats, xs, ys, zs, scratch, s)) return e;
   // the counters become the fill cursors
   if (hipMemsetAsync(w.cnt, 0, (size_t) g.ncell * sizeof(int), s) != hipSuccess)
     return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
-  if (P.C == 4) VAMP_CELL(4, true); else if (P.C == 8) VAMP_CELL(8, true); else VAMP_CELL(16, true);
+  dim3 grid((d->X + 63) / 64, (d->Y + 3) / 4, d->Z * d->B);
+  const T* dp = static_cast<const T*>(depth);
+#define VAMP_CELL(CH)                                                                            \
+  VAMP_TIMED(kProfLiftBwdFill, s, (lift_bwd_cell_kernel<T, CH, true><<<grid, 256, 0, s>>>(       \
+      P, g.cw, g.ch, mats, xs, ys, zs, dp, gout, hits, w.cnt, w.off, w.boff, w.entries)))
+  if (P.C == 4) VAMP_CELL(4); else if (P.C == 8) VAMP_CELL(8); else VAMP_CELL(16);
 #undef VAMP_CELL
   if (int e = check_launch("lift_bwd_cell_kernel<fill>")) return e;
 
@@ -395,12 +406,13 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
 int launch_lift_bwd_cell(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                          const float* zs, const void* depth, const void* feat, const float* gout,
                          const uint64_t* hits, float* gdepth, float* gfeat, void* scratch,
-                         hipStream_t s) {
+                         bool cells_valid, hipStream_t s) {
   const LiftParams P = to_params(d);
   if (d->in_dtype == VAMP_F32)
-    return launch_cell_t<float>(d, P, mats, xs, ys, zs, depth, feat, gout, hits, gdepth, gfeat, scratch, s);
+    return launch_cell_t<float>(d, P, mats, xs, ys, zs, depth, feat, gout, hits, gdepth, gfeat, scratch,
+                                cells_valid, s);
   return launch_cell_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, feat, gout, hits, gdepth, gfeat,
-                                       scratch, s);
+                                       scratch, cells_valid, s);
 }
 
 }  // namespace vamp

@@ -213,10 +213,24 @@ class _LiftFn(torch.autograd.Function):
                 if need_grad else None)
         nbytes = hp.lib.vamp_lift_workspace_bytes(C.byref(d))
         ws = hp._workspace("lift", nbytes)
+        cur = torch.cuda.current_stream()
+        side = hp._side_stream() if (need_grad and os.environ.get("VAMP_PREPARE", "1") != "0") else None
+        hp._lift_gen = getattr(hp, "_lift_gen", 0) + 1
+        ctx.cells_key = None
+        if side is not None:
+            # the counting half of the backward's pixel sort depends on the geometry only: it runs
+            # on the side stream beside the forward kernel
+            side.wait_stream(cur)
+            _capi.check(hp.lib.vamp_lift_prepare(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys),
+                                                 _ptr(hp.zs), _ptr(ws), ws.numel(), _stream(side)),
+                        "vamp_lift_prepare")
+            ctx.cells_key = (hp._lift_gen, ws.data_ptr())
         _capi.check(hp.lib.vamp_lift_forward(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys), _ptr(hp.zs),
                                              _ptr(depth if use_depth else None), _ptr(feat), _ptr(out),
-                                             _ptr(hits), _ptr(ws), ws.numel(), _stream()),
+                                             _ptr(hits), _ptr(ws), ws.numel(), _stream(cur)),
                     "vamp_lift_forward")
+        if side is not None:
+            cur.wait_stream(side)
         if need_grad:
             ctx.hp, ctx.desc, ctx.use_depth = hp, d, use_depth
             ctx.save_for_backward(depth if use_depth else feat, feat, mats, hits)
@@ -232,10 +246,12 @@ class _LiftFn(torch.autograd.Function):
                   if use_depth else None)
         nbytes = hp.lib.vamp_lift_workspace_bytes(C.byref(d))
         ws = hp._workspace("lift", nbytes)
-        _capi.check(hp.lib.vamp_lift_backward(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys), _ptr(hp.zs),
-                                              _ptr(depth if use_depth else None), _ptr(feat), _ptr(g),
-                                              _ptr(hits), _ptr(gdepth), _ptr(gfeat), _ptr(ws),
-                                              ws.numel(), _stream()), "vamp_lift_backward")
+        valid = 1 if ctx.cells_key == (getattr(hp, "_lift_gen", 0), ws.data_ptr()) else 0
+        hp._lift_gen = getattr(hp, "_lift_gen", 0) + 1       # the backward consumes the prepared counters
+        _capi.check(hp.lib.vamp_lift_backward_ex(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys), _ptr(hp.zs),
+                                                 _ptr(depth if use_depth else None), _ptr(feat), _ptr(g),
+                                                 _ptr(hits), _ptr(gdepth), _ptr(gfeat), _ptr(ws),
+                                                 ws.numel(), valid, _stream()), "vamp_lift_backward_ex")
         gd = gdepth.to(depth.dtype) if use_depth else None
         return None, gd, gfeat.to(feat.dtype), None, None
 
