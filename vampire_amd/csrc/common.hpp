@@ -175,6 +175,8 @@ __device__ __forceinline__ void reduce_halving(float (&a)[CP], int l, int& cbase
 struct DensityParams {
   int mode;
   float beta;   // |beta_raw| + beta_min
+  float ib;     // 1 / beta, divided once per thread: |t| * ib stands for the reference's |t| / beta
+                // (one ulp in the exponent's argument; the values are held to 1e-4, not bit-exact)
   float bias;
 };
 
@@ -182,29 +184,36 @@ __device__ __forceinline__ float density_fwd(const DensityParams& dp, float s) {
   if (dp.mode == VAMP_DENSITY_SIGMOID) return 1.f / (1.f + expf(-s));
   float t = s - dp.bias;
   float sg = (t > 0.f) ? 1.f : ((t < 0.f) ? -1.f : 0.f);
-  return (1.f / dp.beta) * (0.5f + 0.5f * sg * expm1f(-fabsf(t) / dp.beta));
+  return dp.ib * (0.5f + 0.5f * sg * expm1f(-fabsf(t) * dp.ib));
 }
 
-// d sigma / d s, and d sigma / d beta_eff (beta_eff = |beta_raw| + beta_min)
-__device__ __forceinline__ void density_bwd(const DensityParams& dp, float s, float& dsig_ds,
-                                            float& dsig_dbeta) {
+// sigma, d sigma / d s and d sigma / d beta_eff (beta_eff = |beta_raw| + beta_min) with one
+// transcendental: exp(x) is taken as expm1(x) + 1 (x <= 0)
+__device__ __forceinline__ void density_all(const DensityParams& dp, float s, float& sigma,
+                                            float& dsig_ds, float& dsig_dbeta) {
   if (dp.mode == VAMP_DENSITY_SIGMOID) {
-    float y = 1.f / (1.f + expf(-s));
-    dsig_ds = y * (1.f - y);
+    sigma = 1.f / (1.f + expf(-s));
+    dsig_ds = sigma * (1.f - sigma);
     dsig_dbeta = 0.f;
     return;
   }
-  float t = s - dp.bias;
-  float a = fabsf(t);
-  float sg = (t > 0.f) ? 1.f : ((t < 0.f) ? -1.f : 0.f);
-  float ib = 1.f / dp.beta;
-  float e = expf(-a * ib);                 // exp(-|t|/beta)
-  float em1 = expm1f(-a * ib);
-  // sigma = ib * (0.5 + 0.5*sg*em1)
+  const float t = s - dp.bias;
+  const float a = fabsf(t);
+  const float sg = (t > 0.f) ? 1.f : ((t < 0.f) ? -1.f : 0.f);
+  const float ib = dp.ib;
+  const float em1 = expm1f(-a * ib);         // exp(-|t|/beta) - 1
+  const float e = em1 + 1.0f;
+  sigma = ib * (0.5f + 0.5f * sg * em1);
   // d/ds: ib * 0.5*sg * e * (-sg*ib) = -0.5*ib^2*e*sg^2   (sign(t)' = 0 a.e.)
   dsig_ds = -0.5f * ib * ib * e * (sg * sg);
   // d/dbeta: -ib^2*(0.5+0.5*sg*em1) + ib*0.5*sg*e*(a*ib^2)
   dsig_dbeta = -ib * ib * (0.5f + 0.5f * sg * em1) + 0.5f * sg * e * a * ib * ib * ib;
+}
+
+__device__ __forceinline__ void density_bwd(const DensityParams& dp, float s, float& dsig_ds,
+                                            float& dsig_dbeta) {
+  float sigma;
+  density_all(dp, s, sigma, dsig_ds, dsig_dbeta);
 }
 
 __device__ __forceinline__ DensityParams load_density(int mode, const float* beta_raw,
@@ -213,6 +222,7 @@ __device__ __forceinline__ DensityParams load_density(int mode, const float* bet
   dp.mode = mode;
   dp.bias = bias;
   dp.beta = (mode == VAMP_DENSITY_SDF_LAPLACE) ? (fabsf(beta_raw[0]) + beta_min) : 1.f;
+  dp.ib = 1.f / dp.beta;
   return dp;
 }
 

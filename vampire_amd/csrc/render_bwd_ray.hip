@@ -75,7 +75,7 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
     x = nan_to_num_geom(x); y = nan_to_num_geom(y); z = nan_to_num_geom(z);
   };
   if (i0 < i1) point(i0, px, py, pz);
-  float cum = 0.f, A = 0.f;
+  float cum = 0.f, A = 0.f, E1 = 1.f;
   for (int i = i0; i < i1; ++i) {
     point(i + 1, qx, qy, qz);
     const VolTap tp = volume_tap(P, px, py, pz);
@@ -102,8 +102,13 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
     }
     const float dx = qx - px, dy = qy - py, dz = qz - pz;
     const float delta = sqrtf(dx * dx + dy * dy + dz * dz);
+    // transmittance inside the chunk as a running product E = prod exp(-tau_j) (one exp per
+    // sample instead of two; the second loop forms the same products, so A and its prefix agree
+    // to the bit)
     const float tau = density_fwd(dp, s0) * delta;
-    A = __builtin_fmaf((1.0f - expf(-tau)) * expf(-cum), qv, A);
+    const float etau = expf(-tau);
+    A = __builtin_fmaf((1.0f - etau) * E1, qv, A);
+    E1 *= etau;
     cum += tau;
     const int j = i - i0;
     l_s0[j * 256 + tid] = s0;
@@ -141,22 +146,23 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
   }
 
   // ---- second loop over the LDS copies: emit w_i and dL/ds_i[0] ----
-  float cl = 0.f, prefix = 0.f, dbeta = 0.f;
+  float E2 = 1.f, prefix = 0.f, dbeta = 0.f;
   for (int i = i0; i < i1; ++i) {
     const int j = i - i0;
     const float s0 = l_s0[j * 256 + tid];
     const float dl = l_dl[j * 256 + tid];
     const float qv = l_q[j * 256 + tid];
     const float delta = fabsf(dl);
-    const float tau = density_fwd(dp, s0) * delta;
-    const float wloc = (1.0f - expf(-tau)) * expf(-cl);
-    const float Tn = scale * expf(-(cl + tau));
-    cl += tau;
+    float sigma, dsig_ds, dsig_db;
+    density_all(dp, s0, sigma, dsig_ds, dsig_db);
+    const float tau = sigma * delta;
+    const float etau = expf(-tau);
+    const float wloc = (1.0f - etau) * E2;
+    E2 *= etau;                                        // exp(-(cl + tau)) of this chunk
+    const float Tn = scale * E2;
     prefix = __builtin_fmaf(wloc, qv, prefix);
     const float R = scale * (A - prefix) + suffix;
     const float dtau = qv * Tn - R;
-    float dsig_ds, dsig_db;
-    density_bwd(dp, s0, dsig_ds, dsig_db);
     dbeta = __builtin_fmaf(dtau * delta, dsig_db, dbeta);
     if (live) {
       const long sidx = ((bn * S + i) * P.fH + h) * P.fW + w;
