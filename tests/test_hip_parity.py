@@ -297,11 +297,11 @@ def test_full_size_properties(dev):
         assert torch.equal(x[0], y[1])
 
 
-def test_camera_backward_cell_matches_atomic_splat_full_size(dev, monkeypatch):
+@pytest.mark.parametrize("cfg", [CFG_B, CFG_A], ids=["B", "A"])
+def test_camera_backward_cell_matches_atomic_splat_full_size(dev, monkeypatch, cfg):
     """The default camera backward (per-ray pass, samples sorted into voxel cells, per-voxel
     gather; one- and two-stream form) against the v1 float-atomic splat at cfg-B: two independent
-    HIP implementations of the same gradient."""
-    cfg = CFG_B
+    HIP implementations of the same gradient (cfg-B and the reference's default cfg-A)."""
     hp = hot(cfg, dev)
     s2e, K, ida = synthetic.camera_rig(cfg, 1, jitter=2.0, seed=5)
     bda = synthetic.bda_matrix(1, rot_deg=7.0, flip_dy=True)
@@ -364,11 +364,11 @@ def test_bev_backward_gather_matches_atomic_splat_full_size(dev, monkeypatch):
     close(b2.reshape(1), b1.reshape(1), atol=1e-3, rtol=1e-3, what="grad_beta")
 
 
-def test_lift_backward_cell_matches_atomic_splat_full_size(dev, monkeypatch):
+@pytest.mark.parametrize("cfg", [CFG_B, CFG_A], ids=["B", "A"])
+def test_lift_backward_cell_matches_atomic_splat_full_size(dev, monkeypatch, cfg):
     """Lift backward: cell list + a wave per pixel (default; also with 4 and 16 waves per pixel,
-    the dense-pixel configurations) against the per-voxel atomic splat (v1), cfg-B, B=2 with
-    jittered rigs and a bda rotation."""
-    cfg = CFG_B
+    the dense-pixel configurations) against the per-voxel atomic splat (v1), cfg-B and cfg-A,
+    B=2 with jittered rigs and a bda rotation."""
     hp = hot(cfg, dev)
     s2e, K, ida = synthetic.camera_rig(cfg, 2, jitter=2.0, seed=11)
     bda = synthetic.bda_matrix(2, rot_deg=-6.0, scale=1.02)
