@@ -271,6 +271,45 @@ int vamp_render_indices(const VampRenderDesc* d, const float* geom, const float*
 int vamp_frustum_geometry(const VampRenderDesc* d, const float* mats, const float* us,
                           const float* vs, const float* ds, float* geom, void* stream);
 
+/* --------------------------------------------------------------------------
+ * Point resampling: the occupancy and lidar-point queries of
+ * base_vampire2.py:576-609 -- F.grid_sample(volume, points, align_corners=True) with the
+ * points normalised by the seg bounds.
+ *   occ_logits  bv2:603   padding BORDER                     (points = bda-rotated occ grid, bv2:599-602)
+ *   occ_density bv2:604   padding ZEROS, activation = 1      (density(density_feature) is sampled)
+ *   pts_logits  bv2:590   padding BORDER, channel_last_out   (lidar points of one sample, B = 1)
+ *   pts_sdf     bv2:594   padding ZEROS, mask_outside = 1
+ * -------------------------------------------------------------------------- */
+#define VAMP_PAD_ZEROS 0
+#define VAMP_PAD_BORDER 1
+typedef struct {
+  int32_t B, C;            /* samples, channels of the volume (C <= 32; C == 1 with activation) */
+  int32_t Z, Y, X;
+  float lo[3], span[3];    /* (p - lo) / span * 2 - 1 is the normalised coordinate (bv2:581-586) */
+  int32_t padding;         /* VAMP_PAD_ZEROS | VAMP_PAD_BORDER */
+  int32_t mask_outside;    /* multiply by all(-1 <= n <= 1) (bv2:587-589, 595) */
+  int32_t activation;      /* sample density(volume) instead of volume (bv2:604) */
+  int32_t density_mode;    /* VAMP_DENSITY_*; with sdf_bias / beta_min as in VampRenderDesc */
+  float sdf_bias, beta_min;
+  int32_t channel_last_out;/* out / grad_out are [B, P, C] instead of [B, C, P] */
+  int32_t in_dtype;        /* dtype of `volume` */
+} VampSampleDesc;
+
+/*
+ * volume [B, C, Z, Y, X]; points [B, P, 3] fp32 ego-frame (x, y, z), P = points_per_sample;
+ * out [B, C, P] (or [B, P, C]) fp32; beta as in the render entry points (read only with
+ * activation and the sdf density).
+ */
+int vamp_sample_points_forward(const VampSampleDesc* d, const void* volume, const float* beta,
+                               const float* points, int64_t points_per_sample, float* out,
+                               void* stream);
+size_t vamp_sample_points_workspace_bytes(const VampSampleDesc* d, int64_t points_per_sample);
+/* grad_volume [B, C, Z, Y, X] fp32 is fully overwritten; grad_beta (1 float) is ACCUMULATED into. */
+int vamp_sample_points_backward(const VampSampleDesc* d, const void* volume, const float* beta,
+                                const float* points, int64_t points_per_sample,
+                                const float* grad_out, float* grad_volume, float* grad_beta,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

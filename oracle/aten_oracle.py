@@ -224,6 +224,42 @@ def render_tap_indices(geom, seg_bounds, vol_shape):
 
 
 # --------------------------------------------------------------------------
+# point resampling: occupancy grid and lidar points (bv2:576-609)
+# --------------------------------------------------------------------------
+def normalise_points(points, seg_bounds):
+    """(p - lo) / (hi - lo) * 2 - 1 per axis (bv2:581-586, 599-602); points [..., 3] ego xyz."""
+    lo = torch.as_tensor([b[0] for b in seg_bounds], dtype=points.dtype)
+    span = torch.as_tensor([b[1] - b[0] for b in seg_bounds], dtype=points.dtype)
+    return (points - lo) / span * 2.0 - 1.0
+
+
+def sample_points(volume, points, seg_bounds, padding="zeros", mask_outside=False):
+    """volume [B,C,Z,Y,X], points [B,P,3] ego xyz -> [B,C,P]: the reference's
+    F.grid_sample(volume, norm_pts, padding_mode=..., align_corners=True) (bv2:590, 594, 603-604),
+    optionally times the all(-1 <= n <= 1) mask (bv2:587-589, 595)."""
+    n = normalise_points(points, seg_bounds)
+    out = F.grid_sample(volume, n[:, None, None], padding_mode=padding, align_corners=True)[:, :, 0, 0]
+    if mask_outside:
+        out = out * ((n >= -1.0) & (n <= 1.0)).all(dim=-1).unsqueeze(1)
+    return out
+
+
+def occupancy_queries(semantic_logits, density_feature, occ_coords, bda_mat, seg_bounds, density_mode,
+                      beta_param=None, sdf_bias=-1.0):
+    """bv2:596-604: the fixed occ grid rotated by bda[:3,:3], then occ_logits (border padding) and
+    occ_density (the activated density, zero padding); both [B,c,oz,oy,ox]."""
+    B = semantic_logits.shape[0]
+    rot = bda_mat[:, :3, :3].view(B, 1, 1, 1, 3, 3)
+    occ = (rot @ occ_coords[None, ..., None].expand(B, *occ_coords.shape, 1)).squeeze(-1)
+    pts = occ.reshape(B, -1, 3)
+    shp = occ_coords.shape[:3]
+    logits = sample_points(semantic_logits, pts, seg_bounds, "border").reshape(B, -1, *shp)
+    dens = sample_points(density_apply(density_feature, density_mode, beta_param, sdf_bias), pts,
+                         seg_bounds, "zeros").reshape(B, 1, *shp)
+    return logits, dens
+
+
+# --------------------------------------------------------------------------
 # whole hot path, for the timed CPU baseline (bench.py cpu_baseline)
 # --------------------------------------------------------------------------
 def lift_render_forward(cfg, geo, depth, feat, vols, mats, beta_param, prepared=(None, None)):

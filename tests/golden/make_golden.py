@@ -16,6 +16,10 @@ Fixtures
   tiny_render_<mode>_<plain|catseg>.npz
                        the 8 render outputs, fixed upstream grads, input/beta gradients
   tiny_bilinear.npz    D==1 lift variant (BaseBiLinear.get_voxel_feats)
+  tiny_points.npz      occupancy / lidar-point resampling (bv2:576-609): the reference module's
+                       occ_coords buffer (strided subset), density module and bounds driven
+                       through the same F.grid_sample calls as _forward_single_sweep, which
+                       itself cannot run here (it needs the mmdet image backbone)
   full_checksums.json  per-tensor (sum, abs-sum, max, sha256 of index tensors)
                        for cfg-A and cfg-B at B=1 with the synthetic rig
 """
@@ -247,9 +251,62 @@ def make_full(BaseVAMPIRE2):
         json.dump(res, f, indent=1)
 
 
+def make_points(BaseVAMPIRE2):
+    """SURVEY 8f N1.  bv2:576-609 is inline in _forward_single_sweep; the statements are replayed
+    on the reference module's own state (occ_coords, density, bounds)."""
+    import torch.nn.functional as F
+    from vampire_amd.config import CFG_TINY as cfg
+    from vampire_amd import synthetic
+    B = 2
+    m = ref_module(BaseVAMPIRE2, cfg, "sdf", False)
+    dens, sem, _, _ = synthetic.render_inputs(cfg, B, seed=21)
+    bda = torch.cat([synthetic.bda_matrix(1), synthetic.bda_matrix(1, rot_deg=10.0, scale=1.05,
+                                                                     flip_dx=True)], 0)
+    lo = torch.as_tensor([m.x_bound_seg[0], m.y_bound_seg[0], m.z_bound_seg[0]])
+    span = torch.as_tensor([m.x_bound_seg[1] - m.x_bound_seg[0], m.y_bound_seg[1] - m.y_bound_seg[0],
+                            m.z_bound_seg[1] - m.z_bound_seg[0]])
+    # a central crop of the fixed 200x200x16 occ grid (every other point, +-9.6 m): about half of
+    # it lies outside the tiny +-6.4 m volume, which exercises the border clamp and the zero padding
+    occ_sub = m.occ_coords[76:124:2, 76:124:2, ::2].contiguous()     # buffer is [x, y, z, 3]
+    g = torch.Generator().manual_seed(8)
+    pts = (torch.rand(B, 300, 3, generator=g) * 1.3 - 0.15) * span + lo          # some outside
+    pts[:, :4] = torch.stack([lo, lo + span, lo + 0.5 * span, lo + span * torch.tensor([1.0, 0.0, 1.0])])
+    sem_ = sem.clone().requires_grad_(True)
+    dens_ = dens.clone().requires_grad_(True)
+    # occupancy prediction, bv2:596-604
+    rot = bda[:, :3, :3].view(B, 1, 1, 1, 3, 3)
+    occ = (rot @ occ_sub[None, ..., None].expand(B, *occ_sub.shape, 1)).squeeze(-1)
+    norm_occ = (occ - lo) / span * 2.0 - 1.0
+    occ_logits = F.grid_sample(sem_, norm_occ, padding_mode="border", align_corners=True)
+    occ_density = F.grid_sample(m.density(dens_), norm_occ, align_corners=True)
+    # lidar points, bv2:578-595
+    pts_logits, pts_sdf = [], []
+    for i in range(B):
+        n = ((pts[i] - lo) / span)[None, None, None] * 2.0 - 1.0
+        valid = ((n >= -1.0) & (n <= 1.0)).all(dim=-1)
+        pl = F.grid_sample(sem_[[i]], n, padding_mode="border", align_corners=True)
+        pts_logits.append(pl[0, :, 0, 0, :].permute(1, 0))
+        ps = F.grid_sample(dens_[[i]], n, align_corners=True).squeeze(1) * valid
+        pts_sdf.append(ps[0, 0, 0, :])
+    pts_logits, pts_sdf = torch.stack(pts_logits), torch.stack(pts_sdf)
+    outs = dict(occ_logits=occ_logits, occ_density=occ_density, pts_logits=pts_logits, pts_sdf=pts_sdf)
+    ups = {k: torch.randn(v.shape, generator=g) for k, v in outs.items()}
+    torch.autograd.backward(list(outs.values()), [ups[k] for k in outs])
+    fx = dict(semantic_logits=sem, density_feature=dens, bda=bda, occ_sub=occ_sub, points=pts,
+              beta=m.density.beta.detach().reshape(1), grad_semantic_logits=sem_.grad,
+              grad_density_feature=dens_.grad, grad_beta=m.density.beta.grad.reshape(1))
+    fx.update({k: v.detach() for k, v in outs.items()})
+    fx.update({"g_" + k: v for k, v in ups.items()})
+    path = os.path.join(HERE, "tiny_points.npz")
+    np.savez_compressed(path, **{k: v.detach().cpu().numpy() for k, v in fx.items()})
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB;",
+          "occ points inside volume:", float(((norm_occ.abs() <= 1).all(-1)).float().mean()))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     V2, BL = import_reference()
     make_tiny(V2, BL)
+    make_points(V2)
     if "--tiny-only" not in sys.argv:
         make_full(V2)

@@ -220,6 +220,71 @@ def test_render_non_finite_volume_entries(tiny_common, dev, monkeypatch):
               what="non-finite volume: cell vs v1 grad_" + name)
 
 
+# --------------------------------------------------------------------------- point resampling
+def test_point_resampling_tiny(dev):
+    """occupancy and lidar-point queries (bv2:576-609) against the fixture made with
+    the reference module's occ_coords / density / bounds: values and all input gradients."""
+    g = load_golden("tiny_points.npz")
+    cfg = dataclasses.replace(CFG_TINY, density_mode="sdf")
+    hp = hot(cfg, dev)
+    sem = g["semantic_logits"].to(dev).requires_grad_(True)
+    dens = g["density_feature"].to(dev).requires_grad_(True)
+    beta = g["beta"].reshape(()).to(dev).requires_grad_(True)
+    occ_logits, occ_density = hp.occupancy_queries(sem, dens, g["occ_sub"].to(dev), g["bda"].to(dev), beta)
+    pts = g["points"].to(dev)
+    pts_logits = hp.sample_points(sem, pts, padding="border", channel_last=True)
+    pts_sdf = hp.sample_points(dens, pts, mask_outside=True)[:, 0]
+    outs = dict(occ_logits=occ_logits, occ_density=occ_density, pts_logits=pts_logits, pts_sdf=pts_sdf)
+    for k, v in outs.items():
+        close(v, g[k], atol=1e-5, rtol=1e-5, what=k)
+    torch.autograd.backward(list(outs.values()), [g["g_" + k].to(dev) for k in outs])
+    close(sem.grad, g["grad_semantic_logits"], atol=1e-5, rtol=1e-5, scale="max", what="grad_semantic_logits")
+    close(dens.grad, g["grad_density_feature"], atol=1e-5, rtol=1e-5, scale="max", what="grad_density_feature")
+    close(beta.grad.reshape(1), g["grad_beta"], atol=1e-3, rtol=1e-3, what="grad_beta")
+
+
+def test_occupancy_queries_full_size(dev):
+    """The 200x200x16 occupancy grid at cfg-B (rotated by bda) against the oracle on the host,
+    forward and the gradient of the semantic volume; plus clustered lidar-like points (many per
+    voxel: the heavy-voxel path of the gather)."""
+    from oracle import aten_oracle as O
+    from vampire_amd.geometry import make_occ_coords
+    cfg = CFG_B
+    hp = hot(cfg, dev)
+    bounds = (cfg.x_bound_seg, cfg.y_bound_seg, cfg.z_bound_seg)
+    dens, sem, _, _ = synthetic.render_inputs(cfg, 1, seed=4)
+    bda = synthetic.bda_matrix(1, rot_deg=5.0)
+    occ = make_occ_coords()
+    beta = torch.tensor(0.1)
+    # the rotated grid is computed once on the host and handed to both sides: a matmul on the GPU
+    # rounds differently, and on white-noise volumes 1e-6 m of coordinate is 1e-4 of value
+    rot = bda[:, :3, :3].view(1, 1, 1, 1, 3, 3)
+    pts = (rot @ occ[None, ..., None]).squeeze(-1).reshape(1, -1, 3)
+    ref_logits = O.sample_points(sem, pts, bounds, "border")
+    ref_dens = O.sample_points(O.density_apply(dens, cfg.density_mode, beta, cfg.sdf_bias), pts, bounds)
+    sem_d = sem.to(dev).requires_grad_(True)
+    got_logits = hp.sample_points(sem_d, pts.to(dev), padding="border")
+    got_dens = hp.sample_points(dens.to(dev), pts.to(dev), activation=True, beta=beta.to(dev))
+    close(got_logits, ref_logits, atol=1e-5, rtol=1e-5, what="occ_logits")
+    close(got_dens, ref_dens, atol=1e-5, rtol=1e-5, what="occ_density")
+    gen = torch.Generator().manual_seed(2)
+    up = torch.randn(ref_logits.shape, generator=gen)
+    sem_c = sem.clone().requires_grad_(True)
+    O.sample_points(sem_c, pts, bounds, "border").backward(up)
+    got_logits.backward(up.to(dev))
+    close(sem_d.grad, sem_c.grad, atol=1e-5, rtol=2e-5, scale="max", what="grad_semantic_logits (occ grid)")
+    # 40k points crowded into a 2 m cube: thousands of points per voxel
+    pts = (torch.rand(1, 40000, 3, generator=gen) * 2.0 + torch.tensor([3.0, -7.0, 0.5]))
+    sem_c.grad = None
+    sem_d.grad = None
+    upp = torch.randn(1, cfg.num_classes, 40000, generator=gen)
+    O.sample_points(sem_c, pts, bounds, "border").backward(upp)
+    out = hp.sample_points(sem_d, pts.to(dev), padding="border")
+    close(out, O.sample_points(sem, pts, bounds, "border"), atol=1e-5, rtol=1e-5, what="clustered points")
+    out.backward(upp.to(dev))
+    close(sem_d.grad, sem_c.grad, atol=1e-4, rtol=1e-4, scale="max", what="grad_semantic_logits (clustered)")
+
+
 # --------------------------------------------------------------------------- full size
 def _sha(t):
     return hashlib.sha256(np.ascontiguousarray(t.cpu().numpy()).tobytes()).hexdigest()
@@ -442,10 +507,10 @@ def test_backbone_forward_backward(dev):
                      output_coords=m.output_coords, camera_mids=m.camera_mids, bev_mids=m.bev_mids,
                      d_far=c.d_bound[1], z_step_det=c.z_bound_det[2], num_classes=5, density_mode="sdf",
                      beta_param=m.density.beta, sdf_bias=-1.0, cat_seg=True)
-        return vox, r
+        return vox, r, dens, sem
 
     imgs_c = imgs.clone().requires_grad_(True)
-    vox_o, r = oracle_forward(ref, imgs_c)
+    vox_o, r, dens_o, sem_o = oracle_forward(ref, imgs_c)
     up = lambda t: ref.upsample2d(t.reshape(B * 6, -1, ref.fH, ref.fW)).reshape(B, 6, -1, ref.fH * 4, ref.fW * 4)
     close(out[1], up(r[0]), what="rgb_preds")
     close(out[2], up(r[1]), what="seg_logits_preds")
@@ -455,6 +520,16 @@ def test_backbone_forward_backward(dev):
     bev_feat = ref.voxel_output((r[7] * r[6].tanh()).reshape(B, -1, *r[7].shape[-2:]))
     close(out[0], bev_feat, atol=2e-4, what="bev feature")
     assert len(out[8]) == B and out[8][0].shape == (50, 5) and out[10].shape == (B, 200, 200, 16, 5)
+    # lidar-point and occupancy queries (bv2:576-609)
+    bounds = (c.x_bound_seg, c.y_bound_seg, c.z_bound_seg)
+    for i in range(B):
+        close(out[8][i], O.sample_points(sem_o[[i]], pts[i][None], bounds, "border")[0].T, atol=2e-4,
+              what="pts_logits")
+        close(out[9][i], O.sample_points(dens_o[[i]], pts[i][None], bounds, "zeros", True)[0, 0], atol=2e-4,
+              what="pts_sdf")
+    ol, od = O.occupancy_queries(sem_o, dens_o, ref.occ_coords, bda, bounds, "sdf", ref.density.beta, -1.0)
+    close(out[10], ol.permute(0, 2, 3, 4, 1), atol=2e-4, what="occ_logits")
+    close(out[11], od.permute(0, 2, 3, 4, 1).tanh(), atol=2e-4, what="occ_density")
 
     # backward through everything: gradient w.r.t. the images and beta
     loss = sum((o.float() ** 2).mean() for o in out[:8])

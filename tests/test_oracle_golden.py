@@ -113,3 +113,23 @@ def test_render_indices(tiny_common):
     assert torch.equal(inside.to(torch.uint8), g["render_inside"])
     assert torch.equal(ix0.to(torch.int16), g["render_ix0"])
     assert 0.05 < inside.float().mean() < 0.9
+
+
+def test_point_resampling_oracle():
+    """SURVEY 8f N1 (bv2:576-609): the oracle's occupancy / lidar-point queries against the fixture
+    replayed on the reference module's own occ_coords buffer, density module and bounds."""
+    g = load_golden("tiny_points.npz")
+    sem = g["semantic_logits"].clone().requires_grad_(True)
+    dens = g["density_feature"].clone().requires_grad_(True)
+    beta = g["beta"].clone().reshape(()).requires_grad_(True)
+    occ_logits, occ_density = O.occupancy_queries(sem, dens, g["occ_sub"], g["bda"], SEG_BOUNDS, "sdf",
+                                                  beta, CFG_TINY.sdf_bias)
+    pts_logits = O.sample_points(sem, g["points"], SEG_BOUNDS, "border").permute(0, 2, 1)
+    pts_sdf = O.sample_points(dens, g["points"], SEG_BOUNDS, "zeros", mask_outside=True)[:, 0]
+    outs = dict(occ_logits=occ_logits, occ_density=occ_density, pts_logits=pts_logits, pts_sdf=pts_sdf)
+    for k, v in outs.items():
+        torch.testing.assert_close(v, g[k], rtol=1e-5, atol=1e-6, msg=k)
+    torch.autograd.backward(list(outs.values()), [g["g_" + k] for k in outs])
+    torch.testing.assert_close(sem.grad, g["grad_semantic_logits"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dens.grad, g["grad_density_feature"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(beta.grad.reshape(1), g["grad_beta"], rtol=1e-4, atol=1e-3)

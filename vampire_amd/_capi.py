@@ -37,9 +37,21 @@ class VampRenderDesc(C.Structure):
                 ("cat_seg", C.c_int32), ("in_dtype", C.c_int32)]
 
 
+class VampSampleDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("C", C.c_int32),
+                ("Z", C.c_int32), ("Y", C.c_int32), ("X", C.c_int32),
+                ("lo", C.c_float * 3), ("span", C.c_float * 3),
+                ("padding", C.c_int32), ("mask_outside", C.c_int32), ("activation", C.c_int32),
+                ("density_mode", C.c_int32), ("sdf_bias", C.c_float), ("beta_min", C.c_float),
+                ("channel_last_out", C.c_int32), ("in_dtype", C.c_int32)]
+
+
+VAMP_PAD_ZEROS, VAMP_PAD_BORDER = 0, 1
+
 _P = C.c_void_p
 _LD = C.POINTER(VampLiftDesc)
 _RD = C.POINTER(VampRenderDesc)
+_SD = C.POINTER(VampSampleDesc)
 
 # name -> (restype, argtypes); must list every symbol declared in include/vampire_hip.h
 SIGNATURES = {
@@ -67,6 +79,9 @@ SIGNATURES = {
     "vamp_render_bev_backward": (C.c_int, [_RD] + [_P] * 19 + [C.POINTER(C.c_float), _P, C.c_size_t, _P]),
     "vamp_render_indices": (C.c_int, [_RD] + [_P] * 9 + [_P]),
     "vamp_frustum_geometry": (C.c_int, [_RD] + [_P] * 5 + [_P]),
+    "vamp_sample_points_forward": (C.c_int, [_SD, _P, _P, _P, C.c_int64, _P, _P]),
+    "vamp_sample_points_workspace_bytes": (C.c_size_t, [_SD, C.c_int64]),
+    "vamp_sample_points_backward": (C.c_int, [_SD, _P, _P, _P, C.c_int64, _P, _P, _P, _P, C.c_size_t, _P]),
 }
 
 _lib = None

@@ -299,23 +299,21 @@ class BaseVAMPIRE2(nn.Module):
         semantic_logits = self.seg_conv(base)
         rgb = self.rgb_conv(base)
 
-        # lidar-point queries (bv2:576-596)
+        # lidar-point queries (bv2:576-596) and occupancy resampling on the bda-rotated Occ3D grid
+        # (bv2:597-609): HIP point resampling, `hp` may be an oracle stand-in on CPU
+        hp = self.hot_path()
+        beta = self._beta()
         pts_logits_batch, pts_sdf_batch = [], []
         if inrange_pts is not None:
             for i in range(B):
-                g = self._norm_by_seg_bounds(inrange_pts[i])[None, None, None]
-                inside = ((g >= -1.0) & (g <= 1.0)).all(dim=-1)
-                logits = F.grid_sample(semantic_logits[[i]], g, padding_mode="border", align_corners=True)
-                pts_logits_batch.append(logits[0, :, 0, 0, :].permute(1, 0))
+                pts = inrange_pts[i][None].float()
+                pts_logits_batch.append(hp.sample_points(semantic_logits[[i]].float(), pts, padding="border",
+                                                         channel_last=True)[0])
                 if self.density_mode == "sdf":
-                    sdf = F.grid_sample(density_feature[[i]], g, align_corners=True).squeeze(1) * inside
-                    pts_sdf_batch.append(sdf[0, 0, 0, :])
-        # occupancy resampling on the bda-rotated Occ3D grid (bv2:597-609)
-        rot = mats_dict.get("bda_mat", None)[:, :3, :3].view(B, 1, 1, 1, 3, 3)
-        occ = (rot @ self.occ_coords[None, ..., None].expand(B, *self.occ_coords.shape, 1)).squeeze(-1)
-        occ = self._norm_by_seg_bounds(occ)
-        occ_logits = F.grid_sample(semantic_logits, occ, padding_mode="border", align_corners=True)
-        occ_density = F.grid_sample(self.density(density_feature), occ, align_corners=True)
+                    pts_sdf_batch.append(hp.sample_points(density_feature[[i]].float(), pts,
+                                                          mask_outside=True)[0, 0])
+        occ_logits, occ_density = hp.occupancy_queries(semantic_logits.float(), density_feature.float(),
+                                                       self.occ_coords, mats_dict.get("bda_mat", None), beta)
 
         (rgb_p, seg_p, depth_p, bev_rgb, bev_seg, bev_height, bev_density, voxel_output) = \
             self.render(mats_dict, sweep_index, density_feature, semantic_logits, base, rgb)

@@ -19,6 +19,7 @@
 // the memory side on this part and cost ~1 us each.
 // No float atomics on global memory, no memset of the outputs, no layout transposes.
 #include "lift_common.hpp"
+#include "cell_list.hpp"
 
 #include <algorithm>
 
@@ -40,27 +41,6 @@ static LiftCells lift_cells(const VampLiftDesc* d) {
   const long nc = (long) d->B * d->N * g.cw * g.ch + 2;
   g.ncell = (nc + kScanTile - 1) / kScanTile * kScanTile;
   return g;
-}
-
-// Run aggregation over the lanes of a wave: lanes with act and equal `cell` that are adjacent form
-// a run; returns the run's first lane and length (valid for act lanes), `head` for the first lane.
-struct LaneRun {
-  bool head;
-  int start, len;
-};
-__device__ __forceinline__ LaneRun lane_run(bool act, long cell, int lane) {
-  const long pcell = __shfl_up(cell, 1, 64);
-  const unsigned long long vm = __ballot(act);
-  const bool pact = lane > 0 && ((vm >> (lane - 1)) & 1ull);
-  LaneRun r;
-  r.head = act && (!pact || pcell != cell);
-  const unsigned long long hm = __ballot(r.head);
-  const unsigned long long upto = ~0ull >> (63 - lane);
-  r.start = 63 - __clzll((long long) (hm & upto));
-  const unsigned long long brk = (hm | ~vm) & ~upto;
-  const int end = brk ? __ffsll((long long) brk) - 1 : 64;
-  r.len = end - r.start;
-  return r;
 }
 
 // ---------------------------------------------------------------------------

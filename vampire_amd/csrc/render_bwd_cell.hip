@@ -19,6 +19,7 @@
 // the fp32 sums can differ in the last bit between runs (as the reference's CUDA atomics do).
 // Autograd of render_utils.py:140-141 (grid_sample backward w.r.t. the volume).
 #include "render_common.hpp"
+#include "cell_list.hpp"
 
 #include <algorithm>
 
@@ -26,14 +27,8 @@ namespace vamp {
 
 constexpr int kHeavy = 256;          // records per voxel beyond which the whole-workgroup kernel runs
 
-static long cell_count_padded(int B, int Z, int Y, int X) {
-  const long nc = (long) B * (Z + 1) * (Y + 1) * (X + 1) + 2;      // +2: the gather reads start[c + 2]
-  return (nc + kScanTile - 1) / kScanTile * kScanTile;
-}
-
 __device__ __forceinline__ long sample_cell(const RenderParams& P, int key, unsigned b, long ncell_b) {
-  return (long) b * ncell_b +
-         ((long) (key >> 22) * (P.Y + 1) + ((key >> 11) & 2047)) * (P.X + 1) + (key & 2047);
+  return key_to_cell(key, P.Y, P.X, b, ncell_b);
 }
 
 // ---------------------------------------------------------------------------
@@ -93,48 +88,6 @@ cam_bwd_fill_kernel(RenderParams P, const int* __restrict__ KEY, const int* __re
   const unsigned ray = bn * HW + sidx % HW;
   R[2 * slot] = make_float4(FX[sidx], FY[sidx], FZ[sidx], Wbuf[sidx]);
   R[2 * slot + 1] = make_float4(G0buf[sidx], __uint_as_float(ray), 0.f, 0.f);
-}
-
-// weight of tap index `iv` for continuous coordinate f (aten: w0 = floor+1-f, w1 = f-floor)
-__device__ __forceinline__ float cell_tap_weight(float f, float iv) {
-  const float fl = floorf(f);
-  return (fl == iv) ? (fl + 1.0f) - f : ((fl + 1.0f == iv) ? f - fl : 0.f);
-}
-
-// The four record ranges of voxel (ix, iy, iz): lanes 0..7 of the group load the range ends.
-struct CellRanges {
-  int beg[4];
-  int pre[4];     // exclusive prefix of the range lengths
-  int tot;
-};
-
-template <int W>
-__device__ __forceinline__ CellRanges cell_ranges(const RenderParams& P, const int* __restrict__ off,
-                                                  const int* __restrict__ boff, long ncell_b, int b,
-                                                  int ix, int iy, int iz, int l) {
-  const int r = (l >> 1) & 3;
-  const long c = (long) b * ncell_b +
-                 ((long) (iz + (r >> 1)) * (P.Y + 1) + (iy + (r & 1))) * (P.X + 1) + ix + 2 * (l & 1);
-  const int sv = off[c] + boff[c / kScanTile];
-  CellRanges cr;
-  int run = 0;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    cr.beg[q] = __shfl(sv, 2 * q, W);
-    const int end = __shfl(sv, 2 * q + 1, W);
-    cr.pre[q] = run;
-    run += end - cr.beg[q];
-  }
-  cr.tot = run;
-  return cr;
-}
-
-// record position of the k-th entry of the concatenated ranges (k clamped by the caller)
-__device__ __forceinline__ long cell_pos(const CellRanges& cr, int k) {
-  const int q = (k >= cr.pre[1]) + (k >= cr.pre[2]) + (k >= cr.pre[3]);
-  const int pre = q == 0 ? cr.pre[0] : (q == 1 ? cr.pre[1] : (q == 2 ? cr.pre[2] : cr.pre[3]));
-  const int beg = q == 0 ? cr.beg[0] : (q == 1 ? cr.beg[1] : (q == 2 ? cr.beg[2] : cr.beg[3]));
-  return (long) beg + (k - pre);
 }
 
 // U entries per lane per round (k, k + stride, ...): the record loads of a round go out
@@ -197,7 +150,7 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
   const bool vox_ok = ix < P.X;
   const int nch = 1 + P.K + 3;
   const int ixc = min(ix, P.X - 1);
-  const CellRanges cr = cell_ranges<CGL>(P, off, boff, ncell_b, b, ixc, iy, iz, l);
+  const CellRanges cr = cell_ranges<CGL>(P.Y, P.X, off, boff, ncell_b, b, ixc, iy, iz, l);
 
   // output elements this thread stores at the end; with accumulate their current values (the
   // BEV branch's gradient) are fetched now, so that the load overlaps the record streaming
@@ -270,7 +223,7 @@ cam_bwd_cell_heavy_kernel(RenderParams P, const int* __restrict__ off, const int
     const int ix = vid % P.X; vid /= P.X;
     const int iy = vid % P.Y; vid /= P.Y;
     const int iz = vid % P.Z, b = vid / P.Z;
-    const CellRanges cr = cell_ranges<64>(P, off, boff, ncell_b, b, ix, iy, iz, lane);
+    const CellRanges cr = cell_ranges<64>(P.Y, P.X, off, boff, ncell_b, b, ix, iy, iz, lane);
     const long vox = ((long) iz * P.Y + iy) * P.X + ix;
     float* optr = nullptr;
     if (tid < nch)

@@ -189,6 +189,34 @@ class HotPath:
         return _RenderFn.apply(self, density_feature, semantic_logits, base, rgb, beta, geom,
                                render_mats)
 
+    # ------------------------------------------------------ point resampling
+    def sample_points(self, volume, points, *, padding="zeros", mask_outside=False, activation=False,
+                      beta=None, channel_last=False):
+        """F.grid_sample(volume, normalised points, padding_mode=padding, align_corners=True) as the
+        reference uses it for the occupancy and lidar-point queries (bv2:576-609).
+
+        volume [B,C,Z,Y,X]; points [B,P,3] ego-frame xyz (normalised by the seg bounds inside);
+        returns [B,C,P] (or [B,P,C] with channel_last).  ``activation`` samples density(volume)
+        (occ_density, bv2:604); ``mask_outside`` multiplies by all(-1 <= n <= 1) (pts_sdf, bv2:595)."""
+        if beta is None:
+            beta = torch.zeros((), device=self.device)
+            if activation and self.cfg.density_mode == "sdf":
+                raise ValueError("density_mode='sdf' needs the beta parameter")
+        return _SamplePointsFn.apply(self, volume, points, beta, padding, bool(mask_outside),
+                                     bool(activation), bool(channel_last))
+
+    def occupancy_queries(self, semantic_logits, density_feature, occ_coords, bda_mat, beta=None):
+        """bv2:596-604: (occ_logits [B,K,oz,oy,ox], occ_density [B,1,oz,oy,ox]) on the occ grid
+        rotated by bda[:3,:3] (a tiny torch matmul; the two resamplings are HIP kernels)."""
+        B = semantic_logits.shape[0]
+        rot = bda_mat[:, :3, :3].reshape(B, 1, 1, 1, 3, 3)
+        occ = (rot @ occ_coords[None, ..., None].expand(B, *occ_coords.shape, 1)).squeeze(-1)
+        pts = occ.reshape(B, -1, 3)
+        shp = tuple(occ_coords.shape[:3])
+        logits = self.sample_points(semantic_logits, pts, padding="border")
+        dens = self.sample_points(density_feature, pts, activation=True, beta=beta)
+        return logits.reshape(B, -1, *shp), dens.reshape(B, 1, *shp)
+
 
 # ===========================================================================
 # autograd glue
@@ -405,3 +433,53 @@ class _RenderFn(torch.autograd.Function):
         grad_beta = gbeta.reshape(ctx.beta_shape) if hp.cfg.density_mode == "sdf" else None
         return (None, gd.to(dens.dtype), gs.to(sem.dtype), gb.to(base.dtype), gr.to(rgb.dtype),
                 grad_beta, None, None)
+
+
+class _SamplePointsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hp: HotPath, volume, points, beta, padding, mask_outside, activation, channel_last):
+        c = hp.cfg
+        B, C_ = volume.shape[:2]
+        volume = _chk(volume, (B, C_, c.vZ, c.vY, c.vX), "volume")
+        P = points.shape[1]
+        points = _chk(points.float(), (B, P, 3), "points")
+        d = _capi.VampSampleDesc()
+        d.B, d.C, d.Z, d.Y, d.X = B, C_, c.vZ, c.vY, c.vX
+        for i, bnd in enumerate((c.x_bound_seg, c.y_bound_seg, c.z_bound_seg)):
+            d.lo[i] = bnd[0]
+            d.span[i] = bnd[1] - bnd[0]
+        if padding not in ("zeros", "border"):
+            raise ValueError("padding must be 'zeros' or 'border'")
+        d.padding = _capi.VAMP_PAD_BORDER if padding == "border" else _capi.VAMP_PAD_ZEROS
+        d.mask_outside = 1 if mask_outside else 0
+        d.activation = 1 if activation else 0
+        d.density_mode = (_capi.VAMP_DENSITY_SDF_LAPLACE if c.density_mode == "sdf"
+                          else _capi.VAMP_DENSITY_SIGMOID)
+        d.sdf_bias, d.beta_min = c.sdf_bias, 1e-4
+        d.channel_last_out = 1 if channel_last else 0
+        d.in_dtype = _dtype_code(volume)
+        ctx.beta_shape = beta.shape
+        beta = beta.reshape(1).float().contiguous()
+        out = torch.empty((B, P, C_) if channel_last else (B, C_, P), dtype=torch.float32,
+                          device=volume.device)
+        _capi.check(hp.lib.vamp_sample_points_forward(C.byref(d), _ptr(volume), _ptr(beta), _ptr(points),
+                                                      P, _ptr(out), _stream()),
+                    "vamp_sample_points_forward")
+        ctx.hp, ctx.desc, ctx.P, ctx.activation = hp, d, P, activation
+        ctx.save_for_backward(volume, points, beta)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        hp, d, P = ctx.hp, ctx.desc, ctx.P
+        volume, points, beta = ctx.saved_tensors
+        g = g.contiguous().float()
+        gvol = torch.empty(volume.shape, dtype=torch.float32, device=volume.device)
+        gbeta = torch.zeros(1, dtype=torch.float32, device=volume.device)
+        ws = hp._workspace("sample", hp.lib.vamp_sample_points_workspace_bytes(C.byref(d), P))
+        _capi.check(hp.lib.vamp_sample_points_backward(
+            C.byref(d), _ptr(volume), _ptr(beta), _ptr(points), P, _ptr(g), _ptr(gvol), _ptr(gbeta),
+            _ptr(ws), ws.numel(), _stream()), "vamp_sample_points_backward")
+        grad_beta = (gbeta.reshape(ctx.beta_shape)
+                     if (ctx.activation and hp.cfg.density_mode == "sdf") else None)
+        return None, gvol.to(volume.dtype), None, grad_beta, None, None, None, None
