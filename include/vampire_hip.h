@@ -293,6 +293,10 @@ typedef struct {
   float sdf_bias, beta_min;
   int32_t channel_last_out;/* out / grad_out are [B, P, C] instead of [B, C, P] */
   int32_t in_dtype;        /* dtype of `volume` */
+  int32_t lattice[3];      /* optional hint: the P points are a row-major n0 x n1 x n2 lattice (n2
+                              fastest) whose axis 0 runs along the volume's x, as the occ grid does
+                              ([200, 200, 16, 3], bv2:295-312): threads then walk axis 0 so that
+                              neighbouring lanes read neighbouring voxels.  0, 0, 0 = no structure */
 } VampSampleDesc;
 
 /*

@@ -43,7 +43,7 @@ class VampSampleDesc(C.Structure):
                 ("lo", C.c_float * 3), ("span", C.c_float * 3),
                 ("padding", C.c_int32), ("mask_outside", C.c_int32), ("activation", C.c_int32),
                 ("density_mode", C.c_int32), ("sdf_bias", C.c_float), ("beta_min", C.c_float),
-                ("channel_last_out", C.c_int32), ("in_dtype", C.c_int32)]
+                ("channel_last_out", C.c_int32), ("in_dtype", C.c_int32), ("lattice", C.c_int32 * 3)]
 
 
 VAMP_PAD_ZEROS, VAMP_PAD_BORDER = 0, 1

@@ -28,6 +28,7 @@ struct SampleParams {
   int border, mask_outside, activation, channel_last;
   int density_mode;
   float sdf_bias, beta_min;
+  int n0, n12;             // lattice hint: n0 points along axis 0, n1 * n2 per axis-0 step (0 = none)
 };
 
 static SampleParams to_params(const VampSampleDesc* d, int points_per_sample) {
@@ -39,6 +40,10 @@ static SampleParams to_params(const VampSampleDesc* d, int points_per_sample) {
   p.activation = d->activation;
   p.channel_last = d->channel_last_out;
   p.density_mode = d->density_mode; p.sdf_bias = d->sdf_bias; p.beta_min = d->beta_min;
+  const long n12 = (long) d->lattice[1] * d->lattice[2];
+  const bool lat = d->lattice[0] > 0 && n12 > 0 && (long) d->lattice[0] * n12 == points_per_sample;
+  p.n0 = lat ? d->lattice[0] : 0;
+  p.n12 = lat ? (int) n12 : 0;
   return p;
 }
 
@@ -93,9 +98,12 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 sample_points_fwd_kernel(SampleParams P, const T* __restrict__ vol, const float* __restrict__ beta_raw,
                          const float* __restrict__ pts, float* __restrict__ out) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
+  int p = blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
   if (p >= P.Pb) return;
+  // lattice hint: thread t takes point (t % n0, t / n0) of the [n0][n1 * n2] lattice, i.e.
+  // consecutive lanes walk the lattice axis that runs along the volume's x
+  if (P.n0 > 0) p = (p % P.n0) * P.n12 + p / P.n0;
   const PointTap t = point_tap(P, pts + ((long) b * P.Pb + p) * 3);
   const float flx = floorf(t.fx), fly = floorf(t.fy), flz = floorf(t.fz);
   // out-of-range coordinates (zeros mode) are clamped before the int conversion; their taps
@@ -231,7 +239,8 @@ sample_points_gather_kernel(SampleParams P, const T* __restrict__ vol, const flo
                             const int* __restrict__ off, const int* __restrict__ boff,
                             const float4* __restrict__ R, const float* __restrict__ G,
                             float* __restrict__ gvol, float* __restrict__ grad_beta,
-                            int* __restrict__ heavy, int* __restrict__ nheavy, long ncell_b, int runs_x) {
+                            float* __restrict__ beta_part, int* __restrict__ heavy,
+                            int* __restrict__ nheavy, long ncell_b, int runs_x) {
   constexpr int CP = CP4 * 4;
   __shared__ float outs[CP][PVPB + 1];
   __shared__ float red[4];
@@ -282,11 +291,27 @@ sample_points_gather_kernel(SampleParams P, const T* __restrict__ vol, const flo
     for (int o = 32; o > 0; o >>= 1) dbeta += __shfl_down(dbeta, o, 64);
     if ((tid & 63) == 0) red[tid >> 6] = dbeta;
     __syncthreads();
-    if (tid == 0) {
-      const float tot = (red[0] + red[1]) + (red[2] + red[3]);
-      const float sgn = (beta_raw[0] > 0.f) ? 1.f : ((beta_raw[0] < 0.f) ? -1.f : 0.f);
-      if (tot != 0.f) atomicAdd(grad_beta, sgn * tot);
-    }
+    // one partial per workgroup, summed by sample_points_beta_kernel: 40 000 atomics on one
+    // address would serialise at the memory side (~7 ns each)
+    if (tid == 0) beta_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+sample_points_beta_kernel(const float* __restrict__ part, int n, const float* __restrict__ beta_raw,
+                          float* __restrict__ grad_beta) {
+  __shared__ float red[16];
+  float v = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) v += part[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < 16; ++i) tot += red[i];
+    const float sgn = (beta_raw[0] > 0.f) ? 1.f : ((beta_raw[0] < 0.f) ? -1.f : 0.f);
+    atomicAdd(grad_beta, sgn * tot);
   }
 }
 
@@ -346,7 +371,7 @@ sample_points_heavy_kernel(SampleParams P, const T* __restrict__ vol, const floa
 struct PtsWs {
   int *cnt, *off, *bsum, *boff, *aux, *heavy, *key, *rank;
   float4 *F, *R;
-  float* G;
+  float *G, *beta_part;
   size_t bytes;
 };
 
@@ -369,6 +394,8 @@ static PtsWs pts_ws(const VampSampleDesc* d, long n, void* scratch) {
   w.F = reinterpret_cast<float4*>(p); p += align_up(pts * sizeof(float4), 256);
   w.R = reinterpret_cast<float4*>(p); p += align_up(pts * sizeof(float4), 256);
   w.G = reinterpret_cast<float*>(p); p += align_up(pts * CP * sizeof(float), 256);
+  const size_t nblk = (size_t) ((d->X + PVPB - 1) / PVPB) * d->Y * d->Z * d->B;
+  w.beta_part = reinterpret_cast<float*>(p); p += align_up(nblk * sizeof(float), 256);
   w.bytes = (size_t) (p - static_cast<char*>(scratch));
   return w;
 }
@@ -410,7 +437,8 @@ static int backward_t(const VampSampleDesc* d, const SampleParams& P, const void
 #define VAMP_PTS(CP4V)                                                                              \
   do {                                                                                              \
     sample_points_gather_kernel<T, CP4V><<<(unsigned) nblk, 256, 0, s>>>(                           \
-        P, vol, beta, w.off, w.boff, w.R, w.G, grad_volume, grad_beta, w.heavy, nheavy, ncell_b, runs_x); \
+        P, vol, beta, w.off, w.boff, w.R, w.G, grad_volume, grad_beta, w.beta_part, w.heavy, nheavy,  \
+        ncell_b, runs_x);                                                                           \
     sample_points_heavy_kernel<T, CP4V><<<hgrid, 256, 0, s>>>(                                      \
         P, vol, beta, w.off, w.boff, w.R, w.G, grad_volume, grad_beta, w.heavy, nheavy, ncell_b);  \
   } while (0)
@@ -425,7 +453,12 @@ static int backward_t(const VampSampleDesc* d, const SampleParams& P, const void
     default: VAMP_PTS(8); break;
   }
 #undef VAMP_PTS
-  return check_launch("sample_points_gather_kernel");
+  if (int e = check_launch("sample_points_gather_kernel")) return e;
+  if (P.activation && grad_beta && P.density_mode == VAMP_DENSITY_SDF_LAPLACE) {
+    sample_points_beta_kernel<<<1, 1024, 0, s>>>(w.beta_part, (int) nblk, beta, grad_beta);
+    return check_launch("sample_points_beta_kernel");
+  }
+  return VAMP_OK;
 }
 
 }  // namespace vamp

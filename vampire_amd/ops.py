@@ -191,7 +191,7 @@ class HotPath:
 
     # ------------------------------------------------------ point resampling
     def sample_points(self, volume, points, *, padding="zeros", mask_outside=False, activation=False,
-                      beta=None, channel_last=False):
+                      beta=None, channel_last=False, lattice=None):
         """F.grid_sample(volume, normalised points, padding_mode=padding, align_corners=True) as the
         reference uses it for the occupancy and lidar-point queries (bv2:576-609).
 
@@ -203,7 +203,7 @@ class HotPath:
             if activation and self.cfg.density_mode == "sdf":
                 raise ValueError("density_mode='sdf' needs the beta parameter")
         return _SamplePointsFn.apply(self, volume, points, beta, padding, bool(mask_outside),
-                                     bool(activation), bool(channel_last))
+                                     bool(activation), bool(channel_last), lattice)
 
     def occupancy_queries(self, semantic_logits, density_feature, occ_coords, bda_mat, beta=None):
         """bv2:596-604: (occ_logits [B,K,oz,oy,ox], occ_density [B,1,oz,oy,ox]) on the occ grid
@@ -213,8 +213,8 @@ class HotPath:
         # broadcast of 640k 3x3 matmuls, bv2:599, costs 8 ms on the GPU)
         pts = torch.matmul(occ_coords.reshape(1, -1, 3).float(), bda_mat[:, :3, :3].float().transpose(1, 2))
         shp = tuple(occ_coords.shape[:3])
-        logits = self.sample_points(semantic_logits, pts, padding="border")
-        dens = self.sample_points(density_feature, pts, activation=True, beta=beta)
+        logits = self.sample_points(semantic_logits, pts, padding="border", lattice=shp)
+        dens = self.sample_points(density_feature, pts, activation=True, beta=beta, lattice=shp)
         return logits.reshape(B, -1, *shp), dens.reshape(B, 1, *shp)
 
 
@@ -437,7 +437,8 @@ class _RenderFn(torch.autograd.Function):
 
 class _SamplePointsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, hp: HotPath, volume, points, beta, padding, mask_outside, activation, channel_last):
+    def forward(ctx, hp: HotPath, volume, points, beta, padding, mask_outside, activation, channel_last,
+                lattice=None):
         c = hp.cfg
         B, C_ = volume.shape[:2]
         volume = _chk(volume, (B, C_, c.vZ, c.vY, c.vX), "volume")
@@ -458,6 +459,8 @@ class _SamplePointsFn(torch.autograd.Function):
         d.sdf_bias, d.beta_min = c.sdf_bias, 1e-4
         d.channel_last_out = 1 if channel_last else 0
         d.in_dtype = _dtype_code(volume)
+        for i in range(3):
+            d.lattice[i] = int(lattice[i]) if lattice is not None else 0
         ctx.beta_shape = beta.shape
         beta = beta.reshape(1).float().contiguous()
         out = torch.empty((B, P, C_) if channel_last else (B, C_, P), dtype=torch.float32,
@@ -482,4 +485,4 @@ class _SamplePointsFn(torch.autograd.Function):
             _ptr(ws), ws.numel(), _stream()), "vamp_sample_points_backward")
         grad_beta = (gbeta.reshape(ctx.beta_shape)
                      if (ctx.activation and hp.cfg.density_mode == "sdf") else None)
-        return None, gvol.to(volume.dtype), None, grad_beta, None, None, None, None
+        return None, gvol.to(volume.dtype), None, grad_beta, None, None, None, None, None
