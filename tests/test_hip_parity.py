@@ -362,6 +362,52 @@ def test_full_size_properties(dev):
         assert torch.equal(x[0], y[1])
 
 
+def test_edge_cases(tiny_common, dev):
+    """Degenerate shapes and inputs: one camera and one sample, a camera that sees nothing, all-zero
+    upstream gradients, an empty point list, repeated forward calls (bit-identical)."""
+    from oracle import aten_oracle as O
+    g = tiny_common
+    cfg = dataclasses.replace(CFG_TINY, density_mode="sdf")
+    hp = hot(cfg, dev)
+    geo = PathGeometry(cfg)
+    lm, rm = tiny_mats(g, dev)
+    # --- B = 1, N = 1 against the oracle (camera 2 of sample 1)
+    d1, f1 = g["depth"][1:, 2:3], g["feat"][1:, 2:3]
+    ref = O.lift(d1, f1, geo.voxel_coords, None, None, None, None, cfg.final_dim, cfg.d_bound,
+                 prepared=g["lift_mats"][1:, 2:3])
+    dd, fd = d1.to(dev).requires_grad_(True), f1.to(dev).requires_grad_(True)
+    out = hp.lift(dd, fd, lm[1:, 2:3])
+    close(out, ref, atol=1e-5, what="lift B=1 N=1")
+    out.sum().backward()
+    assert bool(torch.isfinite(dd.grad).all()) and bool(torch.isfinite(fd.grad).all())
+    # --- a camera looking away from every voxel: identical result to leaving it out
+    far = lm.clone()
+    far[:, 0, 1, :3, 3] += 1e4                   # push camera 0's projection far off the image
+    a = hp.lift(g["depth"].to(dev), g["feat"].to(dev), far)
+    valid, *_ = hp.lift_indices(far)
+    assert int(valid[:, 0].sum()) == 0
+    b = hp.lift(g["depth"][:, 1:].to(dev), g["feat"][:, 1:].to(dev), far[:, 1:])
+    assert torch.equal(a, b)
+    # --- zero upstream gradients give zero input gradients (and no nan)
+    vols = [g[k].to(dev).requires_grad_(True) for k in ("density_feature", "semantic_logits", "base", "rgb")]
+    beta = torch.tensor(0.1, device=dev, requires_grad=True)
+    outs = hp.render(*vols, beta, render_mats=rm)
+    torch.autograd.backward(outs, [torch.zeros_like(o) for o in outs])
+    for v in vols:
+        assert float(v.grad.abs().max()) == 0.0
+    assert float(beta.grad.abs()) == 0.0
+    # --- forward is deterministic bit for bit
+    outs2 = hp.render(*[v.detach() for v in vols], beta.detach(), render_mats=rm)
+    for x, y in zip(outs, outs2):
+        assert torch.equal(x, y)
+    # --- empty point list
+    sem = g["semantic_logits"].to(dev).requires_grad_(True)
+    empty = hp.sample_points(sem, torch.zeros(sem.shape[0], 0, 3, device=dev), padding="border")
+    assert empty.shape == (sem.shape[0], sem.shape[1], 0)
+    empty.sum().backward()
+    assert float(sem.grad.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("cfg", [CFG_B, CFG_A], ids=["B", "A"])
 def test_camera_backward_cell_matches_atomic_splat_full_size(dev, monkeypatch, cfg):
     """The default camera backward (per-ray pass, samples sorted into voxel cells, per-voxel
