@@ -181,19 +181,25 @@ bev_q_kernel(RenderParams P, const float* __restrict__ oxs, const float* __restr
   const int nch = P.K + 3;
   {
     const AxisTap tz = axis_tap(ozs[P.oZ - 1 - j], P.lo[2], P.span[2], P.Z);
+    // kQB channels at a time: their upstream gradients and samples are loaded together (testing
+    // gc != 0 before sampling made every channel two dependent round trips)
+    constexpr int kQB = 3;
     float q = 0.f;
-    for (int ch = cl; ch < nch; ch += 4) {
-      float gc;
-      const T* vol;
-      long cb;
-      if (ch < P.K) {
-        gc = g_bseg ? g_bseg[((long) b * P.K + ch) * OYX + col] : 0.f;
-        vol = sem; cb = ((long) b * P.K + ch) * V;
-      } else {
-        gc = g_brgb ? g_brgb[((long) b * 3 + (ch - P.K)) * OYX + col] : 0.f;
-        vol = rgb; cb = ((long) b * 3 + (ch - P.K)) * V;
+    for (int c0 = cl; c0 < nch; c0 += 4 * kQB) {
+      float gcs[kQB], sm[kQB];
+#pragma unroll
+      for (int i = 0; i < kQB; ++i) {
+        const int ch = min(c0 + 4 * i, nch - 1);
+        const bool is_sem = ch < P.K;
+        const float* gp = is_sem ? g_bseg : g_brgb;
+        const long gi = is_sem ? ((long) b * P.K + ch) * OYX + col : ((long) b * 3 + (ch - P.K)) * OYX + col;
+        gcs[i] = (gp && c0 + 4 * i < nch) ? gp[gi] : 0.f;
+        const T* vol = is_sem ? sem : rgb;
+        const long cb = is_sem ? ((long) b * P.K + ch) * V : ((long) b * 3 + (ch - P.K)) * V;
+        sm[i] = sample8(P, vol, cb, tx, ty, tz);
       }
-      if (gc != 0.f) q = __builtin_fmaf(gc, sample8(P, vol, cb, tx, ty, tz), q);
+#pragma unroll
+      for (int i = 0; i < kQB; ++i) q = __builtin_fmaf(gcs[i], sm[i], q);
     }
     if (cl > 0) red[(cl - 1) * 64 + lx] = q;
     __syncthreads();
