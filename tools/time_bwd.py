@@ -13,4 +13,4 @@ for _ in range(3): train_step(model, batch)
 torch.cuda.synchronize(); _capi.profile_enable(True)
 for _ in range(5): train_step(model, batch)
 torch.cuda.synchronize(); _capi.profile_enable(False)
-print(os.environ.get("VAMP_DBG", "-"), {k: round(ms / n * 1e3, 1) for k, (n, ms) in sorted(_capi.profile_read().items())})
+print({k: round(ms / n * 1e3, 1) for k, (n, ms) in sorted(_capi.profile_read().items())})
