@@ -209,12 +209,24 @@ int vamp_render_camera_backward(const VampRenderDesc* d, const float* geom, cons
  *               VAMP_CAMBWD_PACKED_VALID: `workspace` is the buffer vamp_render_camera_forward
  *               ran with for these same volumes and nothing has written to it since, so its
  *               channel-last copy of the volumes is reused instead of rebuilt
+ *               VAMP_CAMBWD_CELLS_VALID: vamp_render_camera_prepare has run on this workspace
+ *               for the same d / mats / us / vs / ds and no camera backward since
  *   wait_event  a hipEvent_t (or NULL) the stream waits for right before those buffers are first
  *               touched, i.e. after the per-ray pass and the sample sort have been queued
  * ACCUMULATE and wait_event need the default (cell-list) implementation with mats (geom == NULL).
  */
+/*
+ * The backward sorts the ray samples by the voxel cell of their floor tap; which sample goes to
+ * which slot depends on the geometry only.  vamp_render_camera_prepare computes that table into
+ * `workspace` ahead of time (e.g. on a second stream beside vamp_render_camera_forward, which
+ * only touches the head of the workspace); without it the backward computes the table itself.
+ */
+int vamp_render_camera_prepare(const VampRenderDesc* d, const float* mats, const float* us,
+                               const float* vs, const float* ds, void* workspace,
+                               size_t workspace_bytes, void* stream);
 #define VAMP_CAMBWD_ACCUMULATE 1
 #define VAMP_CAMBWD_PACKED_VALID 2
+#define VAMP_CAMBWD_CELLS_VALID 4
 int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, const float* mats,
                                     const float* us, const float* vs, const float* ds,
                                     const float* mids, const float* beta,

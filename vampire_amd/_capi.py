@@ -73,6 +73,7 @@ SIGNATURES = {
     "vamp_render_workspace_bytes": (C.c_size_t, [_RD]),
     "vamp_render_camera_forward": (C.c_int, [_RD] + [_P] * 13 + [_P, C.c_size_t, _P]),
     "vamp_render_camera_backward": (C.c_int, [_RD] + [_P] * 17 + [_P, C.c_size_t, _P]),
+    "vamp_render_camera_prepare": (C.c_int, [_RD] + [_P] * 4 + [_P, C.c_size_t, _P]),
     "vamp_render_camera_backward_acc": (C.c_int, [_RD] + [_P] * 17 + [_P, C.c_size_t, C.c_int, _P, _P]),
     "vamp_render_bev_forward": (C.c_int, [_RD] + [_P] * 14 + [_P]),
     "vamp_render_bev_workspace_bytes": (C.c_size_t, [_RD]),

@@ -23,7 +23,10 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
                       const float* beta, const float* packed, const float* g_rgb,
                       const float* g_seg, const float* g_depth, float* gdens, float* gsem,
                       float* grgb, float* grad_beta, void* scratch, int accumulate,
-                      hipEvent_t wait_event, hipStream_t s);
+                      hipEvent_t wait_event, bool cells_valid, hipStream_t s);
+int launch_cam_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
+                       const float* us, const float* vs, const float* ds, void* scratch,
+                       hipStream_t s);
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
   // wave reduce then 4-wave LDS reduce; result valid in thread 0
@@ -342,6 +345,19 @@ using namespace vamp;
 
 extern "C" {
 
+int vamp_render_camera_prepare(const VampRenderDesc* d, const float* mats, const float* us,
+                               const float* vs, const float* ds, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  VAMP_REQUIRE(mats && us && vs && ds, "null pointer");
+  const size_t need = vamp_render_workspace_bytes(d);
+  if (!workspace || workspace_bytes < need)
+    return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) need);
+  const RenderParams P = to_params(d);
+  return launch_cam_prepare(d, P, mats, us, vs, ds, static_cast<char*>(workspace) + packed_bytes(d),
+                            static_cast<hipStream_t>(stream));
+}
+
 int vamp_render_camera_backward(const VampRenderDesc* d, const float* geom, const float* mats,
                                 const float* us, const float* vs, const float* ds,
                                 const float* mids, const float* beta, const void* density_feature,
@@ -389,7 +405,8 @@ int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, 
   if (!geom && mats && !(force && force[0] == 'v' && force[1] == '1'))
     return launch_cam_bwd_v2(d, P, mats, us, vs, ds, mids, beta, packed, g_rgb, g_seg, g_depth,
                              grad_density_feature, grad_semantic, grad_rgb, grad_beta, gpacked,
-                             accumulate, static_cast<hipEvent_t>(wait_event), s);
+                             accumulate, static_cast<hipEvent_t>(wait_event),
+                             (flags & VAMP_CAMBWD_CELLS_VALID) != 0, s);
   VAMP_REQUIRE(!accumulate && !wait_event, "accumulate / wait_event need the cell-list path");
   {
     ProfScope sc;

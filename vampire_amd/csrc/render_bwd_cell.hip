@@ -1,12 +1,14 @@
 // Camera-branch render backward, scatter stage as a cell list ("sort, then own"):
 //
-//   rank    every inside sample (KEY != 0, written by cam_bwd_ray_kernel) increments the counter
-//           of its cell = the voxel-grid cube whose lower corner is its floor tap, grid padded by
-//           one on the low side: (Z+1) x (Y+1) x (X+1) cells per sample of the batch; the value
-//           the atomic returns is the sample's rank inside the cell
-//   scan    two-level exclusive prefix sum of the cell counters -> cell start offsets
-//   fill    every inside sample moves its record {fx, fy, fz, w | dL/ds0, ray} to slot
-//           start[cell] + rank: records of a cell, and of x-neighbouring cells, are contiguous
+//   prepare (geometry only; the host runs it beside the forward):
+//     rank  every inside sample increments the counter of its cell = the voxel-grid cube whose
+//           lower corner is its floor tap, grid padded by one on the low side: (Z+1) x (Y+1) x
+//           (X+1) cells per sample of the batch; the atomic returns the sample's rank in the cell
+//     scan  two-level exclusive prefix sum of the cell counters -> cell start offsets
+//     slot  start[cell] + rank for every inside sample
+//   the per-ray pass (render_bwd_ray.hip) writes each sample's record {fx, fy, fz, - | w,
+//           dL/ds0, ray, -} straight to its slot: records of a cell, and of x-neighbouring cells, are
+//           contiguous
 //   gather  GL lanes per voxel: the samples whose trilinear support contains voxel (x, y, z)
 //           are exactly those of the 2x2x2 cells (x..x+1, y..y+1, z..z+1), i.e. four contiguous
 //           record ranges; the lanes stream them, accumulate weight * dL/ds[c] in registers
@@ -32,62 +34,59 @@ __device__ __forceinline__ long sample_cell(const RenderParams& P, int key, unsi
 }
 
 // ---------------------------------------------------------------------------
-// count + rank: thread per sample in depth-major order, so the 64 lanes of a wave are 64
-// neighbouring pixels of one image row at one depth and fall into a few cells, in runs.
-// Device-scope atomics are served at the memory side on this part (~1 us, and they are the
-// bottleneck of this pass), so each run of equal cells issues ONE atomic: the run head adds
-// the run length and the lanes of the run take base + position.
+// prepare (geometry only, so the host may run it beside the forward): thread per sample in
+// depth-major order -- the 64 lanes of a wave are 64 neighbouring pixels of one image row at one
+// depth and fall into a few cells, in runs.  Each sample's frustum point and floor taps are
+// evaluated exactly as the per-ray pass will (same inline chain, same bits); inside samples are
+// counted into their cell and take their rank there.  Device-scope atomics are served at the
+// memory side on this part (~1 us, and they are the bottleneck of this pass), so each run of
+// equal cells issues ONE atomic: the run head adds the run length and the lanes of the run take
+// base + position.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-cam_bwd_rank_kernel(RenderParams P, const int* __restrict__ KEY, int* __restrict__ cnt,
-                    int* __restrict__ RANK, unsigned samples, long ncell_b) {
+cam_cells_rank_kernel(RenderParams P, const float* __restrict__ mats, const float* __restrict__ us,
+                      const float* __restrict__ vs, const float* __restrict__ ds,
+                      int* __restrict__ cnt, int* __restrict__ KEY, int* __restrict__ RANK,
+                      unsigned samples, long ncell_b) {
   const unsigned sidx = blockIdx.x * 256u + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const unsigned HW = (unsigned) (P.fH * P.fW), S = (unsigned) (P.D - 1);
-  const int key = sidx < samples ? KEY[sidx] : 0;
-  const bool valid = key != 0;
-  const unsigned b = sidx / (S * HW) / (unsigned) P.N;
-  const long cell = sample_cell(P, key, b, ncell_b);
-  const long pcell = __shfl_up(cell, 1, 64);
-  const unsigned long long vm = __ballot(valid);
-  const bool pvalid = lane > 0 && ((vm >> (lane - 1)) & 1ull);
-  const bool head = valid && (!pvalid || pcell != cell);
-  const unsigned long long hm = __ballot(head);
-  // run start: highest head at or below this lane; run end: next head or invalid lane above it
-  const unsigned long long upto = ~0ull >> (63 - lane);
-  const int start = 63 - __clzll((long long) (hm & upto));
-  const unsigned long long brk = (hm | ~vm) & ~upto;
-  const int end = brk ? __ffsll((long long) brk) - 1 : 64;
+  const unsigned sc = min(sidx, samples - 1);
+  const unsigned bn = sc / (S * HW);
+  const unsigned rem = sc % (S * HW);
+  const unsigned i = rem / HW, pix = rem % HW;
+  const unsigned h = pix / (unsigned) P.fW, w = pix % (unsigned) P.fW;
+  float x, y, z;
+  frustum_point(mats + (long) bn * 48, us[w], vs[h], ds[i], x, y, z);
+  const VolTap tp = volume_tap(P, nan_to_num_geom(x), nan_to_num_geom(y), nan_to_num_geom(z));
+  const bool valid = sidx < samples && tp.inside;
+  const int key = valid ? pack_cell_key(tp.ix0, tp.iy0, tp.iz0) : 0;
+  const long cell = sample_cell(P, key, bn / (unsigned) P.N, ncell_b);
+  const LaneRun r = lane_run(valid, cell, lane);
   int base = 0;
-  if (head) base = atomicAdd(cnt + cell, end - lane);
-  base = __shfl(base, valid ? start : lane, 64);
-  if (valid) RANK[sidx] = base + (lane - start);
+  if (r.head) base = atomicAdd(cnt + cell, r.len);
+  base = __shfl(base, valid ? r.start : lane, 64);
+  if (sidx < samples) {
+    KEY[sidx] = key;
+    RANK[sidx] = base + (lane - r.start);
+  }
 }
 
-// ---------------------------------------------------------------------------
-// fill: thread per sample (depth-major sample index, coalesced reads); inside samples write
-// their record to start[cell] + rank
-// ---------------------------------------------------------------------------
+// after the scan: slot of every inside sample in the cell-ordered record array (-1: masked)
 __global__ void __launch_bounds__(256)
-cam_bwd_fill_kernel(RenderParams P, const int* __restrict__ KEY, const int* __restrict__ RANK,
-                    const float* __restrict__ FX, const float* __restrict__ FY,
-                    const float* __restrict__ FZ, const float* __restrict__ Wbuf,
-                    const float* __restrict__ G0buf, const int* __restrict__ off,
-                    const int* __restrict__ boff, float4* __restrict__ R, unsigned samples,
-                    long ncell_b) {
+cam_cells_slot_kernel(RenderParams P, const int* __restrict__ KEY, int* __restrict__ SLOT,
+                      const int* __restrict__ off, const int* __restrict__ boff, unsigned samples,
+                      long ncell_b) {
   const unsigned sidx = blockIdx.x * 256u + threadIdx.x;
   if (sidx >= samples) return;
   const int key = KEY[sidx];
-  if (key == 0) return;
-  const unsigned HW = (unsigned) (P.fH * P.fW), S = (unsigned) (P.D - 1);
-  const unsigned bn = sidx / (S * HW);
-  const unsigned b = bn / (unsigned) P.N;
-  const long cell = (long) b * ncell_b +
-                    ((long) (key >> 22) * (P.Y + 1) + ((key >> 11) & 2047)) * (P.X + 1) + (key & 2047);
-  const long slot = (long) boff[cell / kScanTile] + off[cell] + RANK[sidx];
-  const unsigned ray = bn * HW + sidx % HW;
-  R[2 * slot] = make_float4(FX[sidx], FY[sidx], FZ[sidx], Wbuf[sidx]);
-  R[2 * slot + 1] = make_float4(G0buf[sidx], __uint_as_float(ray), 0.f, 0.f);
+  int slot = -1;
+  if (key != 0) {
+    const unsigned HW = (unsigned) (P.fH * P.fW), S = (unsigned) (P.D - 1);
+    const long cell = sample_cell(P, key, sidx / (S * HW) / (unsigned) P.N, ncell_b);
+    slot = boff[cell / kScanTile] + off[cell] + SLOT[sidx];          // SLOT holds the rank on entry
+  }
+  SLOT[sidx] = slot;
 }
 
 // U entries per lane per round (k, k + stride, ...): the record loads of a round go out
@@ -111,9 +110,10 @@ __device__ __forceinline__ void cell_accumulate(const CellRanges& cr, int k0, in
     const bool in = k0 + u * stride < cr.tot;
     float wt = cell_tap_weight(a[u].x, fix) * cell_tap_weight(a[u].y, fiy) * cell_tap_weight(a[u].z, fiz);
     wt = in ? wt : 0.f;
-    const float Wv = wt * a[u].w;
-    acc[0] = __builtin_fmaf(wt, g[u].x, acc[0]);
-    const float4* g4 = reinterpret_cast<const float4*>(Gcl + (long) __float_as_uint(g[u].y) * CP);
+    // record = {fx, fy, fz, - | w, dL/ds0, ray, -}
+    const float Wv = wt * g[u].x;
+    acc[0] = __builtin_fmaf(wt, g[u].y, acc[0]);
+    const float4* g4 = reinterpret_cast<const float4*>(Gcl + (long) __float_as_uint(g[u].z) * CP);
 #pragma unroll
     for (int c4 = 0; c4 < CP4; ++c4) {
       const float4 f = g4[c4];
@@ -264,7 +264,8 @@ struct CellWs {
   int* boff;       // [ntile] exclusive scan of the tile totals
   int* aux;        // [ntile] scratch of the level-2 scan, then [ntile] = total, [ntile+1] = heavy count
   int* heavy;      // [voxels] queue
-  int* rank;       // [samples] rank of the sample inside its cell
+  int* key;        // [samples] packed floor taps of the sample (0 = masked); scratch of prepare
+  int* slot;       // [samples] rank inside the cell, then slot in R (-1 = masked)
   float4* R;       // [samples][2] records in cell order
   size_t bytes;
 };
@@ -282,7 +283,8 @@ static CellWs cell_ws(const VampRenderDesc* d, void* scratch) {
   w.boff = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
   w.aux = reinterpret_cast<int*>(p); p += align_up((size_t) (ntile + 4) * sizeof(int), 256);
   w.heavy = reinterpret_cast<int*>(p); p += align_up(voxels * sizeof(int), 256);
-  w.rank = reinterpret_cast<int*>(p); p += align_up(samples * sizeof(int), 256);
+  w.key = reinterpret_cast<int*>(p); p += align_up(samples * sizeof(int), 256);
+  w.slot = reinterpret_cast<int*>(p); p += align_up(samples * sizeof(int), 256);
   w.R = reinterpret_cast<float4*>(p); p += align_up(samples * 2 * sizeof(float4), 256);
   w.bytes = (size_t) (p - static_cast<char*>(scratch));
   return w;
@@ -290,34 +292,45 @@ static CellWs cell_ws(const VampRenderDesc* d, void* scratch) {
 
 size_t cam_bwd_cell_bytes(const VampRenderDesc* d) { return cell_ws(d, nullptr).bytes; }
 
-int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const float* FX,
-                        const float* FY, const float* FZ, const int* KEY, const float* Wbuf,
-                        const float* G0buf, const float* Gcl, float* gdens, float* gsem,
-                        float* grgb, void* scratch, int accumulate, hipEvent_t wait_event,
-                        hipStream_t s) {
+// pointers the per-ray pass needs
+const int* cam_cell_slots(const VampRenderDesc* d, void* scratch) { return cell_ws(d, scratch).slot; }
+float4* cam_cell_records(const VampRenderDesc* d, void* scratch) { return cell_ws(d, scratch).R; }
+
+// rank -> scan -> slot.  Depends on (d, mats, us, vs, ds) only.
+int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
+                             const float* us, const float* vs, const float* ds, void* scratch,
+                             hipStream_t s) {
   const CellWs w = cell_ws(d, scratch);
   const long ncell = cell_count_padded(d->B, d->Z, d->Y, d->X);
-  const long ntile = ncell / kScanTile;
   const size_t samples = (size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW;
   const size_t voxels = (size_t) d->B * d->Z * d->Y * d->X;
-  VAMP_REQUIRE(samples < 0x7fffffffu && voxels < 0x7fffffffu && ncell < 0x7fffffffL,
+  VAMP_REQUIRE(samples > 0 && samples < 0x7fffffffu && voxels < 0x7fffffffu && ncell < 0x7fffffffL,
                "sample / voxel / cell count exceeds 2^31");
   const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
-
   if (hipMemsetAsync(w.cnt, 0, (size_t) ncell * sizeof(int), s) != hipSuccess)
     return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
   const unsigned sgrid = (unsigned) ((samples + 255) / 256);
-  VAMP_TIMED(kProfCamBwdCount, s, (cam_bwd_rank_kernel<<<sgrid, 256, 0, s>>>(
-      P, KEY, w.cnt, w.rank, (unsigned) samples, ncell_b)));
-  if (int e = check_launch("cam_bwd_rank_kernel")) return e;
+  VAMP_TIMED(kProfCamBwdCount, s, (cam_cells_rank_kernel<<<sgrid, 256, 0, s>>>(
+      P, mats, us, vs, ds, w.cnt, w.key, w.slot, (unsigned) samples, ncell_b)));
+  if (int e = check_launch("cam_cells_rank_kernel")) return e;
   if (int e = launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, ncell, s)) return e;
+  VAMP_TIMED(kProfCamBwdFill, s, (cam_cells_slot_kernel<<<sgrid, 256, 0, s>>>(
+      P, w.key, w.slot, w.off, w.boff, (unsigned) samples, ncell_b)));
+  return check_launch("cam_cells_slot_kernel");
+}
+
+// per-voxel gather of the records the per-ray pass has written in cell order
+int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const float* Gcl,
+                        float* gdens, float* gsem, float* grgb, void* scratch, int accumulate,
+                        hipEvent_t wait_event, hipStream_t s) {
+  const CellWs w = cell_ws(d, scratch);
+  const long ncell = cell_count_padded(d->B, d->Z, d->Y, d->X);
+  const long ntile = ncell / kScanTile;
+  const size_t voxels = (size_t) d->B * d->Z * d->Y * d->X;
+  const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
   int* nheavy = w.aux + ntile + 1;
   if (hipMemsetAsync(nheavy, 0, sizeof(int), s) != hipSuccess)
     return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
-
-  VAMP_TIMED(kProfCamBwdFill, s, (cam_bwd_fill_kernel<<<(unsigned) ((samples + 255) / 256), 256, 0, s>>>(
-      P, KEY, w.rank, FX, FY, FZ, Wbuf, G0buf, w.off, w.boff, w.R, (unsigned) samples, ncell_b)));
-  if (int e = check_launch("cam_bwd_fill_kernel")) return e;
 
   // measured at cfg-B (gather + heavy, us): 8 lanes 145 + 56, 16 lanes 173 + 56, 32 lanes 249 + 56;
   // threshold 128 / 256 / 512 with 8 lanes: 131 + 107, 145 + 56, 159 + 40

@@ -3,11 +3,13 @@
 //
 //  cam_bwd_ray   four waves per 8x8 ray tile, one per depth chunk: each re-marches its samples
 //                once (8-tap gather of the packed volume), keeps (s0, delta, q) per sample in
-//                LDS, merges the chunks through LDS and emits one record per sample: the
-//                compositing weight w_i, dL/ds_i[0], the continuous tap coordinates (fx, fy, fz)
-//                exactly as the forward computed them, and the packed floor taps (KEY, 0 =
-//                masked); plus the ray's upstream gradient row (Gcl).
-//  The records are then sorted into voxel cells and gathered per voxel: render_bwd_cell.hip.
+//                LDS, merges the chunks through LDS and writes one record per inside sample --
+//                the continuous tap coordinates (fx, fy, fz) exactly as the forward computed
+//                them, the compositing weight w_i, dL/ds_i[0], the ray id -- straight to the
+//                sample's slot in the cell-ordered record array (the slots come from the
+//                geometry-only prepare pass of render_bwd_cell.hip); plus the ray's upstream
+//                gradient row (Gcl).
+//  The records are then gathered per voxel: render_bwd_cell.hip.
 #include "render_common.hpp"
 
 namespace vamp {
@@ -22,8 +24,7 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
                    const float* __restrict__ mids, const float* __restrict__ beta_raw,
                    const float* __restrict__ packed, const float* __restrict__ g_rgb,
                    const float* __restrict__ g_seg, const float* __restrict__ g_depth,
-                   float* __restrict__ Wbuf, float* __restrict__ G0buf, float* __restrict__ FX,
-                   float* __restrict__ FY, float* __restrict__ FZ, int* __restrict__ KEY,
+                   const int* __restrict__ SLOT, float4* __restrict__ REC,
                    float* __restrict__ Gcl, float* __restrict__ grad_beta, int L) {
   constexpr int CP = CP4 * 4;
   extern __shared__ float lds[];              // [3][L][256]: s0, delta (sign = no-grad flag), q
@@ -77,6 +78,9 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
   if (i0 < i1) point(i0, px, py, pz);
   float cum = 0.f, A = 0.f, E1 = 1.f;
   for (int i = i0; i < i1; ++i) {
+    // the sample's slot in the cell-ordered record array (render_bwd_cell.hip: prepare), loaded
+    // ahead of the gather so that its latency hides behind it
+    const int slot = SLOT[((bn * S + i) * P.fH + h) * P.fW + w];
     point(i + 1, qx, qy, qz);
     const VolTap tp = volume_tap(P, px, py, pz);
     float s[CP];
@@ -115,14 +119,9 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
     // a sample passes gradient to s[0] only if it is inside and finite: flag in the sign
     l_dl[j * 256 + tid] = (tp.inside && fin) ? delta : -delta;
     l_q[j * 256 + tid] = qv;
-    if (live) {
-      const long sidx = ((bn * S + i) * P.fH + h) * P.fW + w;
-      const float nanv = __builtin_nanf("");
-      FX[sidx] = tp.inside ? tp.fx : nanv;     // NaN: masked sample, matches no voxel
-      FY[sidx] = tp.fy;
-      FZ[sidx] = tp.fz;
-      // floor taps packed 11/11/10 bits (+1 so that 0 = masked): the cell id of the sample
-      KEY[sidx] = tp.inside ? ((tp.ix0 + 1) | ((tp.iy0 + 1) << 11) | ((tp.iz0 + 1) << 22)) : 0;
+    if (live && tp.inside) {
+      // the continuous tap coordinates go to the record now, the weights follow in the second loop
+      REC[2 * (long) slot] = make_float4(tp.fx, tp.fy, tp.fz, 0.f);
     }
     px = qx; py = qy; pz = qz;
   }
@@ -149,6 +148,7 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
   float E2 = 1.f, prefix = 0.f, dbeta = 0.f;
   for (int i = i0; i < i1; ++i) {
     const int j = i - i0;
+    const int slot = SLOT[((bn * S + i) * P.fH + h) * P.fW + w];
     const float s0 = l_s0[j * 256 + tid];
     const float dl = l_dl[j * 256 + tid];
     const float qv = l_q[j * 256 + tid];
@@ -165,9 +165,10 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
     const float dtau = qv * Tn - R;
     dbeta = __builtin_fmaf(dtau * delta, dsig_db, dbeta);
     if (live) {
-      const long sidx = ((bn * S + i) * P.fH + h) * P.fW + w;
-      Wbuf[sidx] = scale * wloc;
-      G0buf[sidx] = (dl > 0.f) ? dtau * delta * dsig_ds : 0.f;
+      if (slot >= 0) {
+        REC[2 * (long) slot + 1] = make_float4(scale * wloc, (dl > 0.f) ? dtau * delta * dsig_ds : 0.f,
+                                               __uint_as_float((unsigned) ray), 0.f);
+      }
     }
   }
   if (P.density_mode == VAMP_DENSITY_SDF_LAPLACE) {
@@ -187,39 +188,44 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-size_t cam_bwd_cell_bytes(const VampRenderDesc* d);    // render_bwd_cell.hip
-int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const float* FX,
-                        const float* FY, const float* FZ, const int* KEY, const float* Wbuf,
-                        const float* G0buf, const float* Gcl, float* gdens, float* gsem,
-                        float* grgb, void* scratch, int accumulate, hipEvent_t wait_event,
-                        hipStream_t s);
+// render_bwd_cell.hip
+size_t cam_bwd_cell_bytes(const VampRenderDesc* d);
+const int* cam_cell_slots(const VampRenderDesc* d, void* scratch);
+float4* cam_cell_records(const VampRenderDesc* d, void* scratch);
+int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
+                             const float* us, const float* vs, const float* ds, void* scratch,
+                             hipStream_t s);
+int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const float* Gcl,
+                        float* gdens, float* gsem, float* grgb, void* scratch, int accumulate,
+                        hipEvent_t wait_event, hipStream_t s);
 
-size_t cam_bwd_v2_bytes(const VampRenderDesc* d) {
+static size_t gcl_bytes(const VampRenderDesc* d) {
   const RenderParams P = to_params(d);
-  const size_t samples = (size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW;
-  const size_t rays = (size_t) d->B * d->N * d->fH * d->fW;
-  return 6 * align_up(samples * sizeof(float), 256) + align_up(rays * P.CP * sizeof(float), 256) +
-         cam_bwd_cell_bytes(d);
+  return align_up((size_t) d->B * d->N * d->fH * d->fW * P.CP * sizeof(float), 256);
 }
 
-// scratch = workspace region after the packed volume
+size_t cam_bwd_v2_bytes(const VampRenderDesc* d) { return gcl_bytes(d) + cam_bwd_cell_bytes(d); }
+
+// scratch = workspace region after the packed volume: [Gcl | cell lists]
+int launch_cam_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
+                       const float* us, const float* vs, const float* ds, void* scratch,
+                       hipStream_t s) {
+  return launch_cam_cells_prepare(d, P, mats, us, vs, ds, static_cast<char*>(scratch) + gcl_bytes(d), s);
+}
+
 int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                       const float* us, const float* vs, const float* ds, const float* mids,
                       const float* beta, const float* packed, const float* g_rgb,
                       const float* g_seg, const float* g_depth, float* gdens, float* gsem,
                       float* grgb, float* grad_beta, void* scratch, int accumulate,
-                      hipEvent_t wait_event, hipStream_t s) {
-  const size_t samples = (size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW;
-  const size_t rays = (size_t) d->B * d->N * d->fH * d->fW;
-  char* p = static_cast<char*>(scratch);
-  float* Wbuf = reinterpret_cast<float*>(p); p += align_up(samples * sizeof(float), 256);
-  float* G0buf = reinterpret_cast<float*>(p); p += align_up(samples * sizeof(float), 256);
-  float* FX = reinterpret_cast<float*>(p); p += align_up(samples * sizeof(float), 256);
-  float* FY = reinterpret_cast<float*>(p); p += align_up(samples * sizeof(float), 256);
-  float* FZ = reinterpret_cast<float*>(p); p += align_up(samples * sizeof(float), 256);
-  int* KEY = reinterpret_cast<int*>(p); p += align_up(samples * sizeof(float), 256);
-  float* Gcl = reinterpret_cast<float*>(p); p += align_up(rays * P.CP * sizeof(float), 256);
-  void* cell_scratch = p;
+                      hipEvent_t wait_event, bool cells_valid, hipStream_t s) {
+  float* Gcl = static_cast<float*>(scratch);
+  void* cell_scratch = static_cast<char*>(scratch) + gcl_bytes(d);
+  // the sample -> slot table depends on the geometry only; the caller may have prepared it
+  if (!cells_valid)
+    if (int e = launch_cam_cells_prepare(d, P, mats, us, vs, ds, cell_scratch, s)) return e;
+  const int* SLOT = cam_cell_slots(d, cell_scratch);
+  float4* R = cam_cell_records(d, cell_scratch);
 
   constexpr int LPR = 4;
   const int S = d->D - 1;
@@ -235,14 +241,13 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) \
       return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);                           \
     VAMP_TIMED(kProfCamBwd, s, (kr<<<grid, 256, lds, s>>>(P, mats, us, vs, ds, mids, beta, packed, \
-                                                           g_rgb, g_seg, g_depth, Wbuf, G0buf, FX, FY, FZ, \
-                                                           KEY, Gcl, grad_beta, L)));                  \
+                                                           g_rgb, g_seg, g_depth, SLOT, R, Gcl,   \
+                                                           grad_beta, L)));                       \
   } while (0)
   if (P.CP == 12) VAMP_RAY(3); else if (P.CP == 24) VAMP_RAY(6); else VAMP_RAY(8);
 #undef VAMP_RAY
   if (int e = check_launch("cam_bwd_ray_kernel")) return e;
-  return launch_cam_bwd_cell(d, P, FX, FY, FZ, KEY, Wbuf, G0buf, Gcl, gdens, gsem, grgb,
-                             cell_scratch, accumulate, wait_event, s);
+  return launch_cam_bwd_cell(d, P, Gcl, gdens, gsem, grgb, cell_scratch, accumulate, wait_event, s);
 }
 
 }  // namespace vamp

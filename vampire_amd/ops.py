@@ -356,8 +356,16 @@ class _RenderFn(torch.autograd.Function):
         vout = torch.empty(B, CO, c.oZ, c.oY, c.oX, dtype=f32, device=dev)
         # the two branches share only their inputs: BEV on the side stream, camera on this one
         cur, side = torch.cuda.current_stream(), hp._side_stream()
+        ctx.cells = False
         if side is not None:
             side.wait_stream(cur)
+            if any(ctx.needs_input_grad) and geom is None and os.environ.get("VAMP_PREPARE", "1") != "0":
+                # the sample -> cell-slot table of the backward depends on the geometry only: it is
+                # built here, on the side stream, beside the forward kernels
+                _capi.check(hp.lib.vamp_render_camera_prepare(
+                    C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(),
+                    _stream(side)), "vamp_render_camera_prepare")
+                ctx.cells = True
         _capi.check(hp.lib.vamp_render_bev_forward(
             C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
             _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
@@ -405,6 +413,8 @@ class _RenderFn(torch.autograd.Function):
         cur, side = torch.cuda.current_stream(), hp._side_stream()
         default_impl = os.environ.get("VAMP_CAM_BWD", "cell")[0] == "c"
         packed_valid = 2 if ctx.pack_key == (getattr(hp, "_pack_gen", 0), ws.data_ptr()) else 0
+        if packed_valid and ctx.cells:
+            packed_valid |= 4                                    # VAMP_CAMBWD_CELLS_VALID
         hp._pack_gen = getattr(hp, "_pack_gen", 0) + 1          # the backward scribbles after the copy only,
         ctx.pack_key = None                                     # but a second backward must not assume so
         if side is not None and geom is None and default_impl:
