@@ -326,6 +326,31 @@ int vamp_sample_points_backward(const VampSampleDesc* d, const void* volume, con
                                 const float* grad_out, float* grad_volume, float* grad_beta,
                                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* --------------------------------------------------------------------------
+ * Producer / consumer steps either side of the path.
+ *   depth softmax  base_vampire2.py:550  `mapping_along_depth(src).softmax(dim=1)`:
+ *                  logits [images, D, HW] (fp32 | bf16, images = B * N cameras, HW = fH * fW)
+ *                  -> depth [images, D, HW] fp32, the `depth` argument of vamp_lift_forward.
+ *   density gate   base_vampire2.py:627-630  `voxel_output * bev_density.tanh()` (sdf density) or
+ *                  `voxel_output * bev_density` (naive): voxel_output [B, C, cells], voxel_density
+ *                  [B, 1, cells] (cells = oZ * oY * oX, both outputs of vamp_render_forward) ->
+ *                  out [B, C, cells], the input of the `voxel_output` 1x1 conv.
+ * All tensors contiguous; nothing is retained.
+ * -------------------------------------------------------------------------- */
+int vamp_depth_softmax_forward(int64_t images, int32_t D, int64_t HW, const void* logits,
+                               int32_t in_dtype, float* depth, void* stream);
+/* grad_logits = depth * (grad_depth - sum_d depth * grad_depth), fully overwritten */
+int vamp_depth_softmax_backward(int64_t images, int32_t D, int64_t HW, const float* depth,
+                                const float* grad_depth, float* grad_logits, void* stream);
+int vamp_density_gate_forward(int64_t B, int32_t C, int64_t cells, int32_t density_mode,
+                              const float* voxel_output, const float* voxel_density, float* out,
+                              void* stream);
+/* grad_voxel_output [B, C, cells] and grad_voxel_density [B, 1, cells] are fully overwritten */
+int vamp_density_gate_backward(int64_t B, int32_t C, int64_t cells, int32_t density_mode,
+                               const float* grad_out, const float* voxel_output,
+                               const float* voxel_density, float* grad_voxel_output,
+                               float* grad_voxel_density, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -261,6 +261,20 @@ def occupancy_queries(semantic_logits, density_feature, occ_coords, bda_mat, seg
 
 # --------------------------------------------------------------------------
 # whole hot path, for the timed CPU baseline (bench.py cpu_baseline)
+
+# --------------------------------------------------------------------------
+# producer / consumer glue either side of the path (bv2:550, 627-630)
+# --------------------------------------------------------------------------
+def depth_softmax(logits):
+    """`mapping_along_depth(src).softmax(dim=1)` (bv2:550): logits [B*N, D, fH, fW]."""
+    return logits.float().softmax(dim=1)
+
+
+def density_gate(voxel_output, voxel_density, density_mode):
+    """bv2:627-630: `voxel_output * bev_density.tanh()` for the sdf density, `* bev_density` else."""
+    return voxel_output * (voxel_density.tanh() if density_mode == "sdf" else voxel_density)
+
+
 # --------------------------------------------------------------------------
 def lift_render_forward(cfg, geo, depth, feat, vols, mats, beta_param, prepared=(None, None)):
     """One lift + render forward at the reference's op sequence.  ``mats`` =

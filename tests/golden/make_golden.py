@@ -20,6 +20,10 @@ Fixtures
                        occ_coords buffer (strided subset), density module and bounds driven
                        through the same F.grid_sample calls as _forward_single_sweep, which
                        itself cannot run here (it needs the mmdet image backbone)
+  tiny_glue.npz        producer / consumer glue either side of the path (bv2:550, 627-630; SURVEY 8f
+                       N2): the depth softmax over the reference module's own mapping_along_depth
+                       logits and the density gate of voxel_output, replayed as in
+                       _forward_single_sweep
   full_checksums.json  per-tensor (sum, abs-sum, max, sha256 of index tensors)
                        for cfg-A and cfg-B at B=1 with the synthetic rig
 """
@@ -303,10 +307,52 @@ def make_points(BaseVAMPIRE2):
           "occ points inside volume:", float(((norm_occ.abs() <= 1).all(-1)).float().mean()))
 
 
+def make_glue(BaseVAMPIRE2):
+    """SURVEY 8f N2.  bv2:550 and bv2:627-630 are inline in _forward_single_sweep; the statements
+    are replayed on the reference module's own layers."""
+    from vampire_amd.config import CFG_TINY as cfg
+    B, N = 2, cfg.num_cams
+    g = torch.Generator().manual_seed(13)
+    fx = {}
+    m = ref_module(BaseVAMPIRE2, cfg, "sdf", False)
+    cin = m.mapping_along_depth[0].in_channels
+    src = torch.randn(B * N, cin, m.fH, m.fW, generator=g)
+    with torch.no_grad():
+        logits = (m.mapping_along_depth(src) * 8.0).contiguous()      # spread the logits (init weights are small)
+    logits[0, :, 0, 0] = 0.0                                            # a uniform column
+    logits[0, 3, 0, 1] = 60.0                                           # a one-hot column
+    lg = logits.clone().requires_grad_(True)
+    depth = lg.softmax(dim=1)                                           # bv2:550
+    up = torch.randn(depth.shape, generator=g)
+    depth.backward(up)
+    fx.update(depth_logits=logits, depth=depth.detach(), g_depth=up, grad_depth_logits=lg.grad)
+    for mode in ("sdf", "naive"):
+        mm = ref_module(BaseVAMPIRE2, cfg, mode, False)
+        oz = mm.output_coords.shape[0]
+        vo = torch.randn(B, cfg.mid_channels, oz, mm.oY, mm.oY, generator=g).requires_grad_(True)
+        vd = (torch.rand(B, 1, oz, mm.oY, mm.oY, generator=g) * 3.0).requires_grad_(True)
+        if mm.density_mode == "sdf":                                    # bv2:627-630
+            out = vo * vd.tanh()
+        else:
+            out = vo * vd
+        upg = torch.randn(out.shape, generator=g)
+        out.backward(upg)
+        fx.update({f"{mode}_voxel_output": vo.detach(), f"{mode}_voxel_density": vd.detach(),
+                   f"{mode}_gated": out.detach(), f"{mode}_g_gated": upg,
+                   f"{mode}_grad_voxel_output": vo.grad, f"{mode}_grad_voxel_density": vd.grad})
+    path = os.path.join(HERE, "tiny_glue.npz")
+    np.savez_compressed(path, **{k: v.detach().cpu().numpy() for k, v in fx.items()})
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     V2, BL = import_reference()
+    if "--glue-only" in sys.argv:
+        make_glue(V2)
+        sys.exit(0)
     make_tiny(V2, BL)
+    make_glue(V2)
     make_points(V2)
     if "--tiny-only" not in sys.argv:
         make_full(V2)

@@ -220,6 +220,72 @@ def test_render_non_finite_volume_entries(tiny_common, dev, monkeypatch):
               what="non-finite volume: cell vs v1 grad_" + name)
 
 
+# --------------------------------------------------------------------------- producer / consumer glue
+def test_glue_tiny(dev):
+    """depth softmax (bv2:550) and density gate (bv2:627-630) against the fixture made
+    with the reference module's own layers: values and input gradients."""
+    g = load_golden("tiny_glue.npz")
+    hp = hot(CFG_TINY, dev)
+    lg = g["depth_logits"].to(dev).requires_grad_(True)
+    depth = hp.depth_softmax(lg)
+    close(depth, g["depth"], atol=1e-6, rtol=1e-5, what="depth softmax")
+    close(depth.sum(1), torch.ones_like(depth[:, 0]), atol=1e-6, rtol=0, what="softmax sums to one")
+    depth.backward(g["g_depth"].to(dev))
+    close(lg.grad, g["grad_depth_logits"], atol=1e-6, rtol=1e-5, what="grad_depth_logits")
+    for mode in ("sdf", "naive"):
+        hpm = hot(dataclasses.replace(CFG_TINY, density_mode=mode), dev)
+        vo = g[f"{mode}_voxel_output"].to(dev).requires_grad_(True)
+        vd = g[f"{mode}_voxel_density"].to(dev).requires_grad_(True)
+        out = hpm.density_gate(vo, vd)
+        close(out, g[f"{mode}_gated"], atol=1e-6, rtol=1e-5, what=mode + " gated")
+        out.backward(g[f"{mode}_g_gated"].to(dev))
+        close(vo.grad, g[f"{mode}_grad_voxel_output"], atol=1e-6, rtol=1e-5, what=mode + " grad_voxel_output")
+        close(vd.grad, g[f"{mode}_grad_voxel_density"], atol=1e-5, rtol=1e-5, what=mode + " grad_voxel_density")
+
+
+@pytest.mark.parametrize("shape,dtype", [((6, 86, 64, 176), torch.float32), ((6, 86, 64, 176), torch.bfloat16),
+                                         ((3, 5, 7, 9), torch.float32), ((2, 1, 1, 70), torch.float32),
+                                         ((1, 131, 3, 33), torch.float32)])
+def test_depth_softmax_shapes(dev, shape, dtype):
+    """Full-size cfg-B depth head and ragged shapes (pixel count not a multiple of the 64-pixel
+    tile, fewer depth bins than waves) against the oracle, forward and backward; -inf logits."""
+    from oracle import aten_oracle as O
+    gen = torch.Generator().manual_seed(3)
+    lg = (torch.randn(shape, generator=gen) * 4.0).to(dtype)
+    if shape[1] > 2:
+        lg[0, 1, 0, 0] = float("-inf")
+    up = torch.randn(shape, generator=gen)
+    ref_in = lg.float().clone().requires_grad_(True)
+    ref = O.depth_softmax(ref_in)
+    ref.backward(up)
+    x = lg.to(dev).requires_grad_(True)
+    got = hot(CFG_B, dev).depth_softmax(x)
+    assert got.dtype == torch.float32 and x.grad is None
+    close(got, ref, atol=1e-6, rtol=1e-5, what="softmax")
+    got.backward(up.to(dev))
+    assert x.grad.dtype == dtype
+    close(x.grad, ref_in.grad, atol=1e-6 if dtype == torch.float32 else 1e-3,
+          rtol=1e-5 if dtype == torch.float32 else 1e-2, scale="max", what="softmax grad")
+
+
+def test_density_gate_full_size(dev):
+    """cfg-B BEV block [1, 16, 10, 200, 200] (and cat_seg's 34 channels, batch 2) against the oracle."""
+    from oracle import aten_oracle as O
+    gen = torch.Generator().manual_seed(4)
+    for mode, shape in (("sdf", (1, 16, 10, 200, 200)), ("naive", (2, 34, 10, 200, 200))):
+        vo = torch.randn(shape, generator=gen)
+        vd = torch.rand((shape[0], 1) + shape[2:], generator=gen) * 4.0
+        up = torch.randn(shape, generator=gen)
+        a, b = vo.clone().requires_grad_(True), vd.clone().requires_grad_(True)
+        O.density_gate(a, b, mode).backward(up)
+        x, y = vo.to(dev).requires_grad_(True), vd.to(dev).requires_grad_(True)
+        out = hot(dataclasses.replace(CFG_B, density_mode=mode), dev).density_gate(x, y)
+        close(out, O.density_gate(vo, vd, mode), atol=1e-6, rtol=1e-5, what="gated")
+        out.backward(up.to(dev))
+        close(x.grad, a.grad, atol=1e-6, rtol=1e-5, what="grad_voxel_output")
+        close(y.grad, b.grad, atol=1e-5, rtol=1e-5, scale="max", what="grad_voxel_density")
+
+
 # --------------------------------------------------------------------------- point resampling
 def test_point_resampling_tiny(dev):
     """occupancy and lidar-point queries (bv2:576-609) against the fixture made with

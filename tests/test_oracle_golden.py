@@ -133,3 +133,22 @@ def test_point_resampling_oracle():
     torch.testing.assert_close(sem.grad, g["grad_semantic_logits"], rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(dens.grad, g["grad_density_feature"], rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(beta.grad.reshape(1), g["grad_beta"], rtol=1e-4, atol=1e-3)
+
+
+def test_glue_oracle():
+    """SURVEY 8f N2 (bv2:550, 627-630): depth softmax and density gate against the fixture replayed
+    on the reference module's own mapping_along_depth layer."""
+    g = load_golden("tiny_glue.npz")
+    lg = g["depth_logits"].clone().requires_grad_(True)
+    depth = O.depth_softmax(lg)
+    torch.testing.assert_close(depth, g["depth"], rtol=1e-6, atol=1e-7)
+    depth.backward(g["g_depth"])
+    torch.testing.assert_close(lg.grad, g["grad_depth_logits"], rtol=1e-5, atol=1e-7)
+    for mode in ("sdf", "naive"):
+        vo = g[f"{mode}_voxel_output"].clone().requires_grad_(True)
+        vd = g[f"{mode}_voxel_density"].clone().requires_grad_(True)
+        out = O.density_gate(vo, vd, mode)
+        torch.testing.assert_close(out, g[f"{mode}_gated"], rtol=1e-6, atol=1e-7)
+        out.backward(g[f"{mode}_g_gated"])
+        torch.testing.assert_close(vo.grad, g[f"{mode}_grad_voxel_output"], rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(vd.grad, g[f"{mode}_grad_voxel_density"], rtol=1e-5, atol=1e-6)

@@ -83,6 +83,11 @@ SIGNATURES = {
     "vamp_sample_points_forward": (C.c_int, [_SD, _P, _P, _P, C.c_int64, _P, _P]),
     "vamp_sample_points_workspace_bytes": (C.c_size_t, [_SD, C.c_int64]),
     "vamp_sample_points_backward": (C.c_int, [_SD, _P, _P, _P, C.c_int64, _P, _P, _P, _P, C.c_size_t, _P]),
+    "vamp_depth_softmax_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_int64, _P, C.c_int32, _P, _P]),
+    "vamp_depth_softmax_backward": (C.c_int, [C.c_int64, C.c_int32, C.c_int64, _P, _P, _P, _P]),
+    "vamp_density_gate_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, _P]),
+    "vamp_density_gate_backward": (C.c_int, [C.c_int64, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, _P, _P,
+                                             _P]),
 }
 
 _lib = None

@@ -288,9 +288,11 @@ class BaseVAMPIRE2(nn.Module):
         B, S, N = sweep_imgs.shape[:3]
         img_feats = self.get_cam_feats(sweep_imgs)
         src = img_feats[:, 0].reshape(B * N, -1, img_feats.shape[-2], img_feats.shape[-1])
-        depth = self.mapping_along_depth(src).softmax(dim=1).reshape(B, N, -1, *src.shape[-2:])
+        hp = self.hot_path()
+        # depth softmax (bv2:550) as the HIP producer kernel
+        depth = hp.depth_softmax(self.mapping_along_depth(src)).reshape(B, N, -1, *src.shape[-2:])
         feat = self.channel_lower(src).reshape(B, N, -1, *src.shape[-2:])
-        voxel_features = self.lift(depth.float(), feat.float(), sweep_index, mats_dict)
+        voxel_features = self.lift(depth, feat.float(), sweep_index, mats_dict)
         if self.cat_pos:
             pos = self.norm_voxel_coords.permute(3, 0, 1, 2)[None].repeat(B, 1, 1, 1, 1)
             voxel_features = torch.cat([voxel_features, pos], dim=1)
@@ -301,7 +303,6 @@ class BaseVAMPIRE2(nn.Module):
 
         # lidar-point queries (bv2:576-596) and occupancy resampling on the bda-rotated Occ3D grid
         # (bv2:597-609): HIP point resampling, `hp` may be an oracle stand-in on CPU
-        hp = self.hot_path()
         beta = self._beta()
         pts_logits_batch, pts_sdf_batch = [], []
         if inrange_pts is not None:
@@ -321,8 +322,7 @@ class BaseVAMPIRE2(nn.Module):
         up = lambda t: self.upsample2d(t.reshape(B * N, -1, self.fH, self.fW)).reshape(
             B, N, -1, self.fH * self.upsample_factor, self.fW * self.upsample_factor)
         rgb_p, seg_p, depth_p = up(rgb_p), up(seg_p), up(depth_p)
-        gate = bev_density.tanh() if self.density_mode == "sdf" else bev_density
-        voxel_output = voxel_output * gate
+        voxel_output = hp.density_gate(voxel_output, bev_density)      # bv2:627-630, HIP consumer kernel
         bev_feat = self.voxel_output(voxel_output.reshape(B, -1, *voxel_output.shape[-2:])).float()
         return (bev_feat.contiguous(), rgb_p, seg_p, depth_p, bev_rgb, bev_seg, bev_height,
                 bev_density, pts_logits_batch, pts_sdf_batch,

@@ -218,6 +218,18 @@ class HotPath:
         return logits.reshape(B, -1, *shp), dens.reshape(B, 1, *shp)
 
 
+    # ------------------------------------------------- producer / consumer glue
+    def depth_softmax(self, logits):
+        """`mapping_along_depth(src).softmax(dim=1)` (bv2:550): logits [B*N, D, fH, fW] fp32 | bf16
+        -> fp32 depth distribution of the same shape (what `lift` takes as `depth`)."""
+        return _DepthSoftmaxFn.apply(self, logits)
+
+    def density_gate(self, voxel_output, voxel_density):
+        """`voxel_output * bev_density.tanh()` (sdf) / `voxel_output * bev_density` (naive),
+        bv2:627-630: [B,C,oZ,oY,oX] x [B,1,oZ,oY,oX] -> [B,C,oZ,oY,oX]."""
+        return _DensityGateFn.apply(self, voxel_output, voxel_density)
+
+
 # ===========================================================================
 # autograd glue
 # ===========================================================================
@@ -496,3 +508,61 @@ class _SamplePointsFn(torch.autograd.Function):
         grad_beta = (gbeta.reshape(ctx.beta_shape)
                      if (ctx.activation and hp.cfg.density_mode == "sdf") else None)
         return None, gvol.to(volume.dtype), None, grad_beta, None, None, None, None, None
+
+
+class _DepthSoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hp: HotPath, logits):
+        if logits.dim() < 3:
+            raise ValueError("logits: expected [images, D, ...]")
+        if not logits.is_cuda:
+            raise _capi.VampireHipError("logits must be a device tensor (no CPU fallback)")
+        logits = logits.contiguous()
+        images, D = logits.shape[:2]
+        HW = logits[0, 0].numel()
+        out = torch.empty(logits.shape, dtype=torch.float32, device=logits.device)
+        if logits.numel():
+            _capi.check(hp.lib.vamp_depth_softmax_forward(images, D, HW, _ptr(logits), _dtype_code(logits),
+                                                          _ptr(out), _stream()), "vamp_depth_softmax_forward")
+        ctx.hp, ctx.dims, ctx.in_dtype = hp, (images, D, HW), logits.dtype
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        g = g.contiguous().float()
+        gx = torch.empty_like(p)
+        if p.numel():
+            _capi.check(ctx.hp.lib.vamp_depth_softmax_backward(*ctx.dims, _ptr(p), _ptr(g), _ptr(gx), _stream()),
+                        "vamp_depth_softmax_backward")
+        return None, gx.to(ctx.in_dtype)
+
+
+class _DensityGateFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hp: HotPath, vo, vd):
+        if not (vo.is_cuda and vd.is_cuda):
+            raise _capi.VampireHipError("voxel_output / voxel_density must be device tensors (no CPU fallback)")
+        B, C_ = vo.shape[:2]
+        vd = _chk(vd.float(), (B, 1) + tuple(vo.shape[2:]), "voxel_density")
+        vo = vo.float().contiguous()
+        cells = vd[0].numel()
+        mode = (_capi.VAMP_DENSITY_SDF_LAPLACE if hp.cfg.density_mode == "sdf" else _capi.VAMP_DENSITY_SIGMOID)
+        out = torch.empty_like(vo)
+        if vo.numel():
+            _capi.check(hp.lib.vamp_density_gate_forward(B, C_, cells, mode, _ptr(vo), _ptr(vd), _ptr(out),
+                                                         _stream()), "vamp_density_gate_forward")
+        ctx.hp, ctx.dims = hp, (B, C_, cells, mode)
+        ctx.save_for_backward(vo, vd)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        vo, vd = ctx.saved_tensors
+        g = g.contiguous().float()
+        gvo, gvd = torch.empty_like(vo), torch.empty_like(vd)
+        if vo.numel():
+            _capi.check(ctx.hp.lib.vamp_density_gate_backward(*ctx.dims, _ptr(g), _ptr(vo), _ptr(vd), _ptr(gvo),
+                                                              _ptr(gvd), _stream()), "vamp_density_gate_backward")
+        return None, gvo, gvd
