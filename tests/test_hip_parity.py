@@ -286,6 +286,48 @@ def test_density_gate_full_size(dev):
         close(y.grad, b.grad, atol=1e-5, rtol=1e-5, scale="max", what="grad_voxel_density")
 
 
+# --------------------------------------------------------------------------- HIP graph capture
+@pytest.mark.parametrize("cfg,batch", [(CFG_TINY, 2), (CFG_B, 1)], ids=["tiny", "cfg-B"])
+def test_step_is_graph_capturable(dev, cfg, batch):
+    """The whole step (both streams, the prepare passes, workspaces, memsets) captures into one
+    HIP graph; replays reproduce the eager gradients (up to the order in which a cell's records are
+    summed, which the integer rank atomics leave open: 1e-6 of the largest gradient)."""
+    from vampire_amd.step import LiftRenderStep, SyntheticBatch, train_step
+    model = LiftRenderStep(cfg, dev)
+    data = SyntheticBatch(cfg, batch, dev)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        train_step(model, data)
+
+    def grads():
+        return [data.depth.grad, data.feat.grad] + [v.grad for v in data.vols] + [model.beta.grad]
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    ref = [g.detach().clone() for g in grads()]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        step()
+    for _ in range(3):
+        for g in grads():
+            g.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        for name, a, b in zip(("depth", "feat", "density_feature", "semantic_logits", "base", "rgb", "beta"),
+                              grads(), ref):
+            err, top = float((a - b).abs().max()), float(b.abs().max())
+            assert err <= (1e-5 if name == "beta" else 1e-6) * top, "graph replay differs from eager: grad_%s, max |diff| %.3e of %.3e" % (
+                name, err, top)
+
+
 # --------------------------------------------------------------------------- point resampling
 def test_point_resampling_tiny(dev):
     """occupancy and lidar-point queries (bv2:576-609) against the fixture made with
