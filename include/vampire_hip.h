@@ -351,6 +351,22 @@ int vamp_density_gate_backward(int64_t B, int32_t C, int64_t cells, int32_t dens
                                const float* voxel_density, float* grad_voxel_output,
                                float* grad_voxel_density, void* stream);
 
+/* --------------------------------------------------------------------------
+ * Trilinear resize inside the 3-D UNet between lift and render (first piece):
+ * F.interpolate(x, size, mode='trilinear', align_corners=True), base_vampire2.py:66, 72.
+ * in [planes, iz, iy, ix] -> out [planes, oz, oy, ox], planes = batch * channels, fp32 contiguous.
+ * The backward is a gather over a small per-axis table built in `workspace` (no float atomics);
+ * it supports resize factors up to about 6 per axis and returns VAMP_EINVAL beyond.
+ * -------------------------------------------------------------------------- */
+int vamp_upsample_trilinear_forward(int64_t planes, int32_t iz, int32_t iy, int32_t ix, int32_t oz,
+                                    int32_t oy, int32_t ox, const float* in, float* out,
+                                    void* stream);
+size_t vamp_upsample_trilinear_workspace_bytes(int32_t iz, int32_t iy, int32_t ix);
+/* grad_in [planes, iz, iy, ix] is fully overwritten */
+int vamp_upsample_trilinear_backward(int64_t planes, int32_t iz, int32_t iy, int32_t ix, int32_t oz,
+                                     int32_t oy, int32_t ox, const float* grad_out, float* grad_in,
+                                     void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -275,6 +275,12 @@ def density_gate(voxel_output, voxel_density, density_mode):
     return voxel_output * (voxel_density.tanh() if density_mode == "sdf" else voxel_density)
 
 
+def upsample_trilinear(x, size):
+    """The resize inside Hourglass3D (bv2:66, 72): F.interpolate(..., mode='trilinear',
+    align_corners=True)."""
+    return F.interpolate(x, tuple(size), mode="trilinear", align_corners=True)
+
+
 # --------------------------------------------------------------------------
 def lift_render_forward(cfg, geo, depth, feat, vols, mats, beta_param, prepared=(None, None)):
     """One lift + render forward at the reference's op sequence.  ``mats`` =

@@ -24,6 +24,10 @@ Fixtures
                        N2): the depth softmax over the reference module's own mapping_along_depth
                        logits and the density gate of voxel_output, replayed as in
                        _forward_single_sweep
+  tiny_hourglass.npz   the reference's Hourglass3D (bv2:32-78) run on a small volume, twice (second
+                       call with the first one's skip tensors, as Unet3D does): weights, outputs,
+                       input / weight gradients; plus plain trilinear resizes (bv2:66, 72) with odd
+                       sizes (resize piece)
   full_checksums.json  per-tensor (sum, abs-sum, max, sha256 of index tensors)
                        for cfg-A and cfg-B at B=1 with the synthetic rig
 """
@@ -345,14 +349,49 @@ def make_glue(BaseVAMPIRE2):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def make_hourglass(BaseVAMPIRE2):
+    """SURVEY 8f N3, resize piece: the reference's own Hourglass3D class on a small volume."""
+    import torch.nn.functional as F
+    Hourglass3D = sys.modules[BaseVAMPIRE2.__module__].Hourglass3D
+    torch.manual_seed(5)
+    hg = Hourglass3D(4)
+    x = torch.randn(2, 4, 6, 10, 14).requires_grad_(True)
+    out1, pre1, post1 = hg(x, None, None)
+    out2, pre2, post2 = hg(out1 + x, pre1, post1)
+    g = torch.Generator().manual_seed(6)
+    up = torch.randn(out2.shape, generator=g)
+    (out2 + x).backward(up)
+    fx = {"x": x.detach(), "out1": out1.detach(), "pre1": pre1.detach(), "post1": post1.detach(),
+          "out2": out2.detach(), "g_out": up, "grad_x": x.grad}
+    for k, v in hg.state_dict().items():
+        fx["w_" + k] = v.detach().clone()
+    for k, v in hg.named_parameters():
+        fx["gw_" + k] = v.grad.detach().clone()
+    # plain resizes: up (the hourglass' own), ragged up, down, depth-1 source
+    for i, (shape, size) in enumerate([((2, 3, 3, 5, 7), (6, 10, 14)), ((1, 2, 4, 5, 3), (7, 9, 8)),
+                                       ((1, 2, 8, 9, 10), (4, 5, 6)), ((1, 2, 1, 4, 4), (3, 8, 7))]):
+        a = torch.randn(shape, generator=g).requires_grad_(True)
+        r = F.interpolate(a, size, mode="trilinear", align_corners=True)        # bv2:66, 72
+        gr = torch.randn(r.shape, generator=g)
+        r.backward(gr)
+        fx.update({f"rs{i}_x": a.detach(), f"rs{i}_out": r.detach(), f"rs{i}_g": gr, f"rs{i}_grad": a.grad})
+    path = os.path.join(HERE, "tiny_hourglass.npz")
+    np.savez_compressed(path, **{k: v.detach().cpu().numpy() for k, v in fx.items()})
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     V2, BL = import_reference()
     if "--glue-only" in sys.argv:
         make_glue(V2)
         sys.exit(0)
+    if "--hourglass-only" in sys.argv:
+        make_hourglass(V2)
+        sys.exit(0)
     make_tiny(V2, BL)
     make_glue(V2)
+    make_hourglass(V2)
     make_points(V2)
     if "--tiny-only" not in sys.argv:
         make_full(V2)

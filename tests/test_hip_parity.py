@@ -328,6 +328,55 @@ def test_step_is_graph_capturable(dev, cfg, batch):
                 name, err, top)
 
 
+# --------------------------------------------------------------------------- trilinear resize (UNet)
+def test_resize_and_hourglass_tiny(dev):
+    """SURVEY 8f N3, resize piece (bv2:66, 72): the HIP resize against the recorded F.interpolate
+    calls (up, ragged, down, depth-1 source), forward and backward; then the Hourglass3D mirror on
+    the GPU (HIP resize inside) against the reference class's outputs and gradients."""
+    from vampire_amd.ops import upsample_trilinear
+    from test_oracle_golden import _hourglass_from_fixture
+    g = load_golden("tiny_hourglass.npz")
+    for i in range(4):
+        a = g[f"rs{i}_x"].to(dev).requires_grad_(True)
+        r = upsample_trilinear(a, g[f"rs{i}_out"].shape[-3:])
+        close(r, g[f"rs{i}_out"], atol=1e-6, rtol=1e-6, what=f"resize {i}")
+        r.backward(g[f"rs{i}_g"].to(dev))
+        close(a.grad, g[f"rs{i}_grad"], atol=1e-6, rtol=1e-5, what=f"resize {i} grad")
+    hg = _hourglass_from_fixture(g, dev)
+    x = g["x"].to(dev).requires_grad_(True)
+    out1, pre1, post1 = hg(x)
+    out2, _, _ = hg(out1 + x, pre1, post1)
+    for name, t in (("out1", out1), ("pre1", pre1), ("post1", post1), ("out2", out2)):
+        close(t, g[name], atol=1e-5, rtol=1e-4, what=name)
+    (out2 + x).backward(g["g_out"].to(dev))
+    close(x.grad, g["grad_x"], atol=1e-5, rtol=1e-4, scale="max", what="hourglass grad_x")
+    for k, v in hg.named_parameters():
+        close(v.grad, g["gw_" + k], atol=1e-5, rtol=1e-4, scale="max", what="hourglass grad " + k)
+
+
+@pytest.mark.parametrize("shape,size", [((1, 32, 8, 100, 100), (16, 200, 200)), ((2, 32, 4, 50, 50), (8, 100, 100)),
+                                        ((1, 3, 5, 33, 65), (11, 67, 129))])
+def test_resize_full_size(dev, shape, size):
+    """The UNet's two resize levels at cfg-B size (and a ragged one) against aten on the same GPU:
+    forward bit for bit (same expression), backward to summation order."""
+    import torch.nn.functional as F
+    from vampire_amd.ops import upsample_trilinear
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(shape, generator=gen).to(dev)
+    up = torch.randn(shape[:2] + size, generator=gen).to(dev)
+    a = x.clone().requires_grad_(True)
+    ref = F.interpolate(a, size, mode="trilinear", align_corners=True)
+    ref.backward(up)
+    b = x.clone().requires_grad_(True)
+    got = upsample_trilinear(b, size)
+    close(got, ref, atol=1e-6, rtol=1e-6, what="resize")
+    got.backward(up)
+    close(b.grad, a.grad, atol=1e-5, rtol=1e-5, what="resize grad")
+    # adjoint identity <up, R x> == <R^T up, x>
+    lhs, rhs = float((up.double() * got.double()).sum()), float((b.grad.double() * x.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
+
+
 # --------------------------------------------------------------------------- point resampling
 def test_point_resampling_tiny(dev):
     """occupancy and lidar-point queries (bv2:576-609) against the fixture made with

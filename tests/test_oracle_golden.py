@@ -152,3 +152,33 @@ def test_glue_oracle():
         out.backward(g[f"{mode}_g_gated"])
         torch.testing.assert_close(vo.grad, g[f"{mode}_grad_voxel_output"], rtol=1e-6, atol=1e-7)
         torch.testing.assert_close(vd.grad, g[f"{mode}_grad_voxel_density"], rtol=1e-5, atol=1e-6)
+
+
+def _hourglass_from_fixture(g, device="cpu"):
+    from vampire_amd.backbone import Hourglass3D
+    hg = Hourglass3D(4)
+    hg.load_state_dict({k[2:]: v for k, v in g.items() if k.startswith("w_")})
+    return hg.to(device)
+
+
+def test_hourglass_and_resize_oracle():
+    """SURVEY 8f N3, resize piece: the mirror of Hourglass3D (bv2:32-78) with the fixture's weights
+    reproduces the reference class's outputs and gradients on CPU; the oracle's resize equals the
+    recorded F.interpolate calls (bv2:66, 72)."""
+    g = load_golden("tiny_hourglass.npz")
+    hg = _hourglass_from_fixture(g)
+    x = g["x"].clone().requires_grad_(True)
+    out1, pre1, post1 = hg(x)
+    out2, _, _ = hg(out1 + x, pre1, post1)
+    for name, t in (("out1", out1), ("pre1", pre1), ("post1", post1), ("out2", out2)):
+        torch.testing.assert_close(t, g[name], rtol=1e-5, atol=1e-6, msg=name)
+    (out2 + x).backward(g["g_out"])
+    torch.testing.assert_close(x.grad, g["grad_x"], rtol=1e-5, atol=1e-6)
+    for k, v in hg.named_parameters():
+        torch.testing.assert_close(v.grad, g["gw_" + k], rtol=1e-4, atol=1e-5, msg=k)
+    for i in range(4):
+        a = g[f"rs{i}_x"].clone().requires_grad_(True)
+        r = O.upsample_trilinear(a, g[f"rs{i}_out"].shape[-3:])
+        torch.testing.assert_close(r, g[f"rs{i}_out"], rtol=0, atol=0)
+        r.backward(g[f"rs{i}_g"])
+        torch.testing.assert_close(a.grad, g[f"rs{i}_grad"], rtol=1e-6, atol=1e-6)

@@ -43,6 +43,16 @@ from .ops import HotPath
 # ---------------------------------------------------------------------------
 # dense layers around the path (plain torch; bv2:17-78)
 # ---------------------------------------------------------------------------
+def _resize(x, size):
+    """F.interpolate(x, size, mode='trilinear', align_corners=True) (bv2:66, 72): the HIP resize for
+    device tensors (its backward is a gather; aten's atomic scatter is 8.8 ms of the module's
+    backward at cfg-B), torch for CPU tensors like the other dense layers."""
+    if x.is_cuda:
+        from .ops import upsample_trilinear
+        return upsample_trilinear(x, size)
+    return F.interpolate(x, tuple(size), mode="trilinear", align_corners=True)
+
+
 def _conv3(cin, cout, stride=1):
     return nn.Conv3d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=False)
 
@@ -65,10 +75,10 @@ class Hourglass3D(nn.Module):
         pre = self.conv2(down)
         pre = F.leaky_relu(pre if postsqu is None else pre + postsqu, inplace=True)
         bottom = self.conv4(self.conv3(pre))
-        up = F.interpolate(bottom, pre.shape[-3:], mode="trilinear", align_corners=True)
+        up = _resize(bottom, pre.shape[-3:])
         up = self.conv5(up)
         post = F.leaky_relu(up + (pre if presqu is None else presqu), inplace=True)
-        out = F.interpolate(post, x.shape[-3:], mode="trilinear", align_corners=True)
+        out = _resize(post, x.shape[-3:])
         return self.conv6(out), pre, post
 
 
