@@ -367,6 +367,23 @@ int vamp_upsample_trilinear_backward(int64_t planes, int32_t iz, int32_t iy, int
                                      int32_t oy, int32_t ox, const float* grad_out, float* grad_in,
                                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* --------------------------------------------------------------------------
+ * 3x3x3 / stride 1 / padding 1 / no-bias Conv3d of the UNet between lift and render (SURVEY 8f
+ * N3): nn.Conv3d(cin, cout, 3, 1, 1, bias=False) with cin, cout in {16, 32} -- init_dres, conv2,
+ * conv4, conv5, conv6 of the two Hourglass3D blocks, base_vampire2.py:20, 40-60.  fp32 NCDHW
+ * tensors, weight [cout, cin, 3, 3, 3]; fp32 matrix cores (exact fp32 products).
+ * -------------------------------------------------------------------------- */
+typedef struct {
+  int32_t B, cin, cout, Z, Y, X;
+} VampConvDesc;
+int vamp_conv3d_forward(const VampConvDesc* d, const float* in, const float* weight, float* out,
+                        void* stream);
+int vamp_conv3d_backward_data(const VampConvDesc* d, const float* grad_out, const float* weight,
+                              float* grad_in, void* stream);
+/* grad_weight [cout, cin, 3, 3, 3] is fully overwritten */
+int vamp_conv3d_backward_weight(const VampConvDesc* d, const float* in, const float* grad_out,
+                                float* grad_weight, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -377,6 +377,30 @@ def test_resize_full_size(dev, shape, size):
     assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
 
 
+# --------------------------------------------------------------------------- 3x3x3 conv (UNet)
+@pytest.mark.parametrize("cin,cout,vol,batch", [(16, 16, (6, 10, 14), 2), (32, 16, (5, 37, 71), 1),
+                                                (16, 32, (4, 9, 130), 1), (32, 32, (8, 100, 100), 1),
+                                                (16, 16, (16, 200, 200), 1)])
+def test_conv3d_matches_torch(dev, cin, cout, vol, batch):
+    """the fp32 matrix-core 3x3x3 conv (bv2:20, 40-60 layer shapes, ragged sizes)
+    against torch's conv3d evaluated in fp64 on the CPU: output, data and weight gradients."""
+    import torch.nn.functional as F
+    from vampire_amd.ops import conv3d_3x3x3
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(batch, cin, *vol, generator=gen)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=gen) * 0.05
+    up = torch.randn(batch, cout, *vol, generator=gen)
+    a, wa = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    F.conv3d(a, wa, padding=1).backward(up.double())
+    ref = F.conv3d(x.double(), w.double(), padding=1)
+    b, wb = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    out = conv3d_3x3x3(b, wb)
+    close(out, ref, atol=1e-5, rtol=1e-5, scale="max", what="conv out")
+    out.backward(up.to(dev))
+    close(b.grad, a.grad, atol=1e-5, rtol=1e-5, scale="max", what="conv grad_in")
+    close(wb.grad, wa.grad, atol=1e-5, rtol=2e-5, scale="max", what="conv grad_weight")
+
+
 # --------------------------------------------------------------------------- point resampling
 def test_point_resampling_tiny(dev):
     """occupancy and lidar-point queries (bv2:576-609) against the fixture made with

@@ -37,6 +37,11 @@ class VampRenderDesc(C.Structure):
                 ("cat_seg", C.c_int32), ("in_dtype", C.c_int32)]
 
 
+class VampConvDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32),
+                ("Z", C.c_int32), ("Y", C.c_int32), ("X", C.c_int32)]
+
+
 class VampSampleDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("C", C.c_int32),
                 ("Z", C.c_int32), ("Y", C.c_int32), ("X", C.c_int32),
@@ -52,6 +57,7 @@ _P = C.c_void_p
 _LD = C.POINTER(VampLiftDesc)
 _RD = C.POINTER(VampRenderDesc)
 _SD = C.POINTER(VampSampleDesc)
+_CD = C.POINTER(VampConvDesc)
 
 # name -> (restype, argtypes); must list every symbol declared in include/vampire_hip.h
 SIGNATURES = {
@@ -89,6 +95,9 @@ SIGNATURES = {
     "vamp_upsample_trilinear_forward": (C.c_int, [C.c_int64] + [C.c_int32] * 6 + [_P, _P, _P]),
     "vamp_upsample_trilinear_workspace_bytes": (C.c_size_t, [C.c_int32] * 3),
     "vamp_upsample_trilinear_backward": (C.c_int, [C.c_int64] + [C.c_int32] * 6 + [_P, _P, _P, C.c_size_t, _P]),
+    "vamp_conv3d_forward": (C.c_int, [_CD, _P, _P, _P, _P]),
+    "vamp_conv3d_backward_data": (C.c_int, [_CD, _P, _P, _P, _P]),
+    "vamp_conv3d_backward_weight": (C.c_int, [_CD, _P, _P, _P, _P]),
     "vamp_density_gate_backward": (C.c_int, [C.c_int64, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, _P, _P,
                                              _P]),
 }

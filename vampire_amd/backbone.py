@@ -29,6 +29,7 @@ True`` (MIOpen find) the module backward is 23 ms, and under the reference's AMP
 Set that flag in the training script; this module does not touch global torch state.
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -53,8 +54,22 @@ def _resize(x, size):
     return F.interpolate(x, tuple(size), mode="trilinear", align_corners=True)
 
 
+class _Conv3(nn.Conv3d):
+    """nn.Conv3d(cin, cout, 3, stride, 1, bias=False) (same parameter name and shape).  The
+    stride-1 layers with 16 / 32 channels run on the HIP fp32 matrix-core kernel for fp32 device
+    tensors when `VAMP_CONV3D=1` (off by default: see DESIGN.md 7e for where it stands against
+    MIOpen); everything else is torch's conv."""
+
+    def forward(self, x):
+        if os.environ.get("VAMP_CONV3D", "0") == "1":
+            from .ops import conv3d_3x3x3, conv3d_supported
+            if conv3d_supported(x, self.weight, self.stride, self.padding, self.bias):
+                return conv3d_3x3x3(x, self.weight)
+        return super().forward(x)
+
+
 def _conv3(cin, cout, stride=1):
-    return nn.Conv3d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=False)
+    return _Conv3(cin, cout, kernel_size=3, stride=stride, padding=1, bias=False)
 
 
 class Hourglass3D(nn.Module):

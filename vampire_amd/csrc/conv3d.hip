@@ -1,0 +1,266 @@
+// 3x3x3 / stride 1 / pad 1 Conv3d of the UNet between lift and render, gfx950:
+// nn.Conv3d(cin, cout, 3, 1, 1, bias=False) with cin, cout in {16, 32}, base_vampire2.py:20, 40-60
+// (init_dres, conv2, conv4, conv5, conv6 of both Hourglass3D blocks), fp32 in / fp32 out.
+//
+// Implicit GEMM on the f32-input matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products, one
+// rounding per accumulate -- the same numerics as an fmaf chain):
+//     out[voxel][co] = sum_{tap, ci} in[voxel + tap][ci] * w[co][ci][tap]
+// M = voxels (16 consecutive x per MFMA), N = 16 output channels, K = 4 input channels per step.
+//   lane l supplies A[voxel l & 15][ci k0 + (l >> 4)] straight from the NCDHW input (16 consecutive
+//   floats of 4 channel planes; the 27 taps re-read the same lines from L1) and
+//   B[ci k0 + (l >> 4)][co l & 15] from an LDS image of the weights laid out [tap][ci][co].
+//   A wave owns 64 consecutive x of one (z, y) row x all output channels: 4 x (cout / 16)
+//   accumulator tiles, every B value feeds 4 MFMAs and every A value cout / 16.
+// The data gradient is the same kernel on the flipped, transposed weights (FLIP).
+// The weight gradient is a GEMM over the voxels: dw[co][ci][tap] = sum_voxel dout[voxel][co] *
+//   in[voxel + tap][ci]: M = co, N = ci, K = 4 voxels per step; a workgroup reduces a slab of rows
+//   and adds its 27 x cout x cin partial sums to the result with float atomics (cout * cin * 27
+//   addresses, a few hundred workgroups).
+#include "common.hpp"
+
+namespace vamp {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvParams {
+  int B, Z, Y, X;
+};
+
+// ---------------------------------------------------------------------------
+// forward / data gradient
+// ---------------------------------------------------------------------------
+template <int CIN, int COUT, bool FLIP>
+__global__ void __launch_bounds__(256)
+conv3d_fwd_kernel(ConvParams P, const float* __restrict__ in, const float* __restrict__ w,
+                  float* __restrict__ out, int tiles_x, long ntiles) {
+  extern __shared__ float wl[];                       // [27][CIN][COUT]
+  constexpr int NT = COUT / 16;                       // N tiles
+  // weights -> LDS.  forward: wl[t][ci][co] = w[co][ci][t];
+  // data gradient (the roles of the channels swap): wl[t][k][j] = w[co = k][ci = j][26 - t]
+  // (COUT == 32: the two 16-column halves of odd rows are swapped, so that the four K rows a
+  // load touches fall on both halves of the 32 banks)
+  for (int e = threadIdx.x; e < 27 * CIN * COUT; e += 256) {
+    const int j = e % COUT, k = (e / COUT) % CIN, t = e / (COUT * CIN);
+    const int js = COUT == 32 ? (j ^ ((k & 1) << 4)) : j;
+    wl[(t * CIN + k) * COUT + js] = FLIP ? w[((long) k * COUT + j) * 27 + (26 - t)] : w[((long) j * CIN + k) * 27 + t];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const long plane = (long) P.Z * P.Y * P.X;
+  for (long tile = (long) blockIdx.x * 4 + wave; tile < ntiles; tile += (long) gridDim.x * 4) {
+    const int tx = (int) (tile % tiles_x);
+    const long row = tile / tiles_x;                  // (b, z, y)
+    const int y = (int) (row % P.Y), z = (int) ((row / P.Y) % P.Z), b = (int) (row / ((long) P.Y * P.Z));
+    const int x0 = tx * 64;
+    const float* inb = in + (long) b * CIN * plane;
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 27; ++t) {
+      const int dz = t / 9 - 1, dy = (t / 3) % 3 - 1, dx = t % 3 - 1;
+      const int zz = z + dz, yy = y + dy;
+      if (zz < 0 || zz >= P.Z || yy < 0 || yy >= P.Y) continue;          // wave-uniform
+      const float* rowp = inb + ((long) zz * P.Y + yy) * P.X;
+      bool ok[4];
+      int xo[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int xx = x0 + m * 16 + li + dx;
+        ok[m] = xx >= 0 && xx < P.X;
+        xo[m] = ok[m] ? xx : 0;
+      }
+      const float* wt = wl + t * CIN * COUT;
+#pragma unroll 2
+      for (int k0 = 0; k0 < CIN; k0 += 4) {
+        const float* cp = rowp + (long) (k0 + lk) * plane;
+        float a[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[m] = ok[m] ? cp[xo[m]] : 0.f;
+        float bv[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          bv[n] = wt[(k0 + lk) * COUT + (COUT == 32 ? ((n * 16 + li) ^ ((lk & 1) << 4)) : n * 16 + li)];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv[n], acc[m][n], 0, 0, 0);
+      }
+    }
+    // C/D: col (output channel) = lane & 15, row (voxel) = (lane >> 4) * 4 + reg
+    float* ob = out + (long) b * COUT * plane + ((long) z * P.Y + y) * P.X;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int xb = x0 + m * 16 + lk * 4;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        float* op = ob + (long) (n * 16 + li) * plane + xb;
+        if (xb + 3 < P.X && ((P.X & 3) == 0)) {
+          *reinterpret_cast<f32x4*>(op) = acc[m][n];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (xb + r < P.X) op[r] = acc[m][n][r];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient: dw[co][ci][t] = sum_{b, voxel} dout[b][co][voxel] * in[b][ci][voxel + tap t]
+// MFMA: M = co (16 per tile), N = ci (16 per tile), K = 4 consecutive x.
+//   A[co l & 15][x k0 + (l >> 4)] = dout,  B[x k0 + (l >> 4)][ci l & 15] = in (shifted by the tap)
+// A wave takes (tap-group, row) work: for one (b, z, y) row it walks x in steps of 4 and keeps the
+// accumulators of ONE tap triple (dx = -1, 0, 1 of a fixed (dz, dy)) for all channel tiles:
+// 3 * (COUT / 16) * (CIN / 16) tiles.  Rows are dealt to workgroups in slabs; partial sums leave
+// through LDS and float atomics.
+// ---------------------------------------------------------------------------
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256)
+conv3d_wgrad_kernel(ConvParams P, const float* __restrict__ in, const float* __restrict__ dout,
+                    float* __restrict__ dw, long nrows, int rows_per_block) {
+  constexpr int MT = COUT / 16, NTI = CIN / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const long plane = (long) P.Z * P.Y * P.X;
+  const long r0 = (long) blockIdx.x * rows_per_block, r1 = min(nrows, r0 + rows_per_block);
+  // the 9 (dz, dy) pairs are dealt to the 4 waves: wave w takes pairs w, w + 4, w + 8
+  for (int pair = wave; pair < 9; pair += 4) {
+    const int dz = pair / 3 - 1, dy = pair % 3 - 1;
+    f32x4 acc[3][MT][NTI];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NTI; ++n) acc[d][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long row = r0; row < r1; ++row) {
+      const int y = (int) (row % P.Y), z = (int) ((row / P.Y) % P.Z), b = (int) (row / ((long) P.Y * P.Z));
+      const int zz = z + dz, yy = y + dy;
+      if (zz < 0 || zz >= P.Z || yy < 0 || yy >= P.Y) continue;
+      const float* gp = dout + (long) b * COUT * plane + ((long) z * P.Y + y) * P.X;
+      const float* ip = in + (long) b * CIN * plane + ((long) zz * P.Y + yy) * P.X;
+      for (int xk = 0; xk < P.X; xk += 4) {
+        const int x = xk + lk;
+        const bool okx = x < P.X;
+        float a[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = okx ? gp[(long) (m * 16 + li) * plane + x] : 0.f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const int xs = x + d - 1;
+          const bool oks = okx && xs >= 0 && xs < P.X;
+          float bv[NTI];
+#pragma unroll
+          for (int n = 0; n < NTI; ++n) bv[n] = oks ? ip[(long) (n * 16 + li) * plane + xs] : 0.f;
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NTI; ++n)
+              acc[d][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv[n], acc[d][m][n], 0, 0, 0);
+        }
+      }
+    }
+    // C/D: col = ci = lane & 15, row = co = (lane >> 4) * 4 + reg; tap t = (dz+1)*9 + (dy+1)*3 + d
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int t = (dz + 1) * 9 + (dy + 1) * 3 + d;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NTI; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = m * 16 + lk * 4 + r, ci = n * 16 + li;
+            atomicAdd(dw + ((long) co * CIN + ci) * 27 + t, acc[d][m][n][r]);
+          }
+    }
+  }
+}
+
+int check(const VampConvDesc* d) {
+  VAMP_REQUIRE(d != nullptr, "desc is NULL");
+  VAMP_REQUIRE(d->B > 0 && d->Z > 0 && d->Y > 0 && d->X > 0, "sizes must be positive");
+  VAMP_REQUIRE((d->cin == 16 || d->cin == 32) && (d->cout == 16 || d->cout == 32),
+               "cin, cout must be 16 or 32");
+  VAMP_REQUIRE((long) d->B * std::max(d->cin, d->cout) * d->Z * d->Y * d->X < 0x7fffffffL * 4L, "tensor too large");
+  return VAMP_OK;
+}
+
+template <int CIN, int COUT, bool FLIP>
+int launch_fwd(const VampConvDesc* d, const float* in, const float* w, float* out, hipStream_t s) {
+  ConvParams P{d->B, d->Z, d->Y, d->X};
+  const int tiles_x = (d->X + 63) / 64;
+  const long ntiles = (long) d->B * d->Z * d->Y * tiles_x;
+  const size_t lds = (size_t) 27 * CIN * COUT * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_fwd_kernel<CIN, COUT, FLIP>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    attr_set = true;
+  }
+  const unsigned grid = (unsigned) std::min<long>((ntiles + 3) / 4, lds > 80 * 1024 ? 256 : 512);
+  VAMP_TIMED(FLIP ? kProfConvDgrad : kProfConvFwd, s, (conv3d_fwd_kernel<CIN, COUT, FLIP><<<grid, 256, lds, s>>>(
+      P, in, w, out, tiles_x, ntiles)));
+  return check_launch("conv3d_fwd_kernel");
+}
+
+}  // namespace
+}  // namespace vamp
+
+using namespace vamp;
+
+extern "C" {
+
+int vamp_conv3d_forward(const VampConvDesc* d, const float* in, const float* weight, float* out,
+                        void* stream) {
+  if (int e = check(d)) return e;
+  VAMP_REQUIRE(in && weight && out, "NULL tensor");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d->cin == 16 && d->cout == 16) return launch_fwd<16, 16, false>(d, in, weight, out, s);
+  if (d->cin == 16 && d->cout == 32) return launch_fwd<16, 32, false>(d, in, weight, out, s);
+  if (d->cin == 32 && d->cout == 16) return launch_fwd<32, 16, false>(d, in, weight, out, s);
+  return launch_fwd<32, 32, false>(d, in, weight, out, s);
+}
+
+/* grad_in [B, cin, Z, Y, X] from grad_out [B, cout, Z, Y, X]: the forward kernel on the flipped,
+   transposed weights (its "input channels" are cout, its "output channels" cin) */
+int vamp_conv3d_backward_data(const VampConvDesc* d, const float* grad_out, const float* weight,
+                              float* grad_in, void* stream) {
+  if (int e = check(d)) return e;
+  VAMP_REQUIRE(grad_out && weight && grad_in, "NULL tensor");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d->cin == 16 && d->cout == 16) return launch_fwd<16, 16, true>(d, grad_out, weight, grad_in, s);
+  if (d->cin == 16 && d->cout == 32) return launch_fwd<32, 16, true>(d, grad_out, weight, grad_in, s);
+  if (d->cin == 32 && d->cout == 16) return launch_fwd<16, 32, true>(d, grad_out, weight, grad_in, s);
+  return launch_fwd<32, 32, true>(d, grad_out, weight, grad_in, s);
+}
+
+int vamp_conv3d_backward_weight(const VampConvDesc* d, const float* in, const float* grad_out,
+                                float* grad_weight, void* stream) {
+  if (int e = check(d)) return e;
+  VAMP_REQUIRE(in && grad_out && grad_weight, "NULL tensor");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ConvParams P{d->B, d->Z, d->Y, d->X};
+  if (hipMemsetAsync(grad_weight, 0, (size_t) d->cout * d->cin * 27 * sizeof(float), s) != hipSuccess)
+    return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
+  const long nrows = (long) d->B * d->Z * d->Y;
+  const int rows_per_block = (int) std::max<long>(1, (nrows + 1023) / 1024);
+  const unsigned grid = (unsigned) ((nrows + rows_per_block - 1) / rows_per_block);
+#define VAMP_WGRAD(CI, CO)                                                                     \
+  VAMP_TIMED(kProfConvWgrad, s, (conv3d_wgrad_kernel<CI, CO><<<grid, 256, 0, s>>>(              \
+      P, in, grad_out, grad_weight, nrows, rows_per_block)))
+  if (d->cin == 16 && d->cout == 16) VAMP_WGRAD(16, 16);
+  else if (d->cin == 16 && d->cout == 32) VAMP_WGRAD(16, 32);
+  else if (d->cin == 32 && d->cout == 16) VAMP_WGRAD(32, 16);
+  else VAMP_WGRAD(32, 32);
+#undef VAMP_WGRAD
+  return check_launch("conv3d_wgrad_kernel");
+}
+
+}  // extern "C"

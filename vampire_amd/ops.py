@@ -616,3 +616,53 @@ class _UpsampleTrilinearFn(torch.autograd.Function):
         else:
             gin.zero_()
         return gin.to(ctx.in_dtype), None
+
+
+# ===========================================================================
+# 3x3x3 convolutions of the 3-D UNet
+# ===========================================================================
+def conv3d_3x3x3(x, weight):
+    """nn.Conv3d(cin, cout, 3, 1, 1, bias=False) (bv2:20, 40-60) on the fp32 matrix cores:
+    x [B,cin,Z,Y,X], weight [cout,cin,3,3,3], cin / cout in {16, 32}; fp32 device tensors."""
+    return _Conv3dFn.apply(x, weight)
+
+
+def conv3d_supported(x, weight, stride, padding, bias):
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and bias is None
+            and tuple(stride) == (1, 1, 1) and tuple(padding) == (1, 1, 1) and tuple(weight.shape[2:]) == (3, 3, 3)
+            and weight.shape[0] in (16, 32) and weight.shape[1] in (16, 32) and x.dim() == 5
+            and not torch.is_autocast_enabled())
+
+
+class _Conv3dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        lib = _capi.load()
+        x, w = x.contiguous(), w.contiguous()
+        d = _capi.VampConvDesc()
+        d.B, d.cin, d.Z, d.Y, d.X = x.shape
+        d.cout = w.shape[0]
+        if w.shape[1] != d.cin:
+            raise ValueError("weight / input channel mismatch")
+        out = torch.empty((d.B, d.cout, d.Z, d.Y, d.X), dtype=torch.float32, device=x.device)
+        _capi.check(lib.vamp_conv3d_forward(C.byref(d), _ptr(x), _ptr(w), _ptr(out), _stream()),
+                    "vamp_conv3d_forward")
+        ctx.lib, ctx.desc = lib, d
+        ctx.save_for_backward(x, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        lib, d = ctx.lib, ctx.desc
+        g = g.contiguous().float()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _capi.check(lib.vamp_conv3d_backward_data(C.byref(d), _ptr(g), _ptr(w), _ptr(gx), _stream()),
+                        "vamp_conv3d_backward_data")
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w)
+            _capi.check(lib.vamp_conv3d_backward_weight(C.byref(d), _ptr(x), _ptr(g), _ptr(gw), _stream()),
+                        "vamp_conv3d_backward_weight")
+        return gx, gw
