@@ -60,35 +60,57 @@ conv3d_fwd_kernel(ConvParams P, const float* __restrict__ in, const float* __res
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < 27; ++t) {
-      const int dz = t / 9 - 1, dy = (t / 3) % 3 - 1, dx = t % 3 - 1;
+    // the three x-taps of a (dz, dy) row read the same 64 + 2 values: they are loaded once and the
+    // shifted operands come from neighbouring lanes (the load unit, not the matrix core, limits
+    // this kernel when every MFMA has its own global load)
+    bool ok[4];
+    int xo[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int xx = x0 + m * 16 + li;
+      ok[m] = xx < P.X;
+      xo[m] = ok[m] ? xx : 0;
+    }
+    // lane li == 0 also fetches x0 - 1, lane li == 15 fetches x0 + 64
+    const int xe = li == 0 ? x0 - 1 : x0 + 64;
+    const bool oke = (li == 0 || li == 15) && xe >= 0 && xe < P.X;
+    for (int p = 0; p < 9; ++p) {
+      const int dz = p / 3 - 1, dy = p % 3 - 1;
       const int zz = z + dz, yy = y + dy;
       if (zz < 0 || zz >= P.Z || yy < 0 || yy >= P.Y) continue;          // wave-uniform
       const float* rowp = inb + ((long) zz * P.Y + yy) * P.X;
-      bool ok[4];
-      int xo[4];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int xx = x0 + m * 16 + li + dx;
-        ok[m] = xx >= 0 && xx < P.X;
-        xo[m] = ok[m] ? xx : 0;
-      }
-      const float* wt = wl + t * CIN * COUT;
+      const float* wt = wl + p * 3 * CIN * COUT;
 #pragma unroll 2
       for (int k0 = 0; k0 < CIN; k0 += 4) {
         const float* cp = rowp + (long) (k0 + lk) * plane;
-        float a[4];
+        float c[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) a[m] = ok[m] ? cp[xo[m]] : 0.f;
-        float bv[NT];
+        for (int m = 0; m < 4; ++m) c[m] = ok[m] ? cp[xo[m]] : 0.f;
+        const float e = oke ? cp[xe] : 0.f;
+        float lf[4], rt[4];
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-          bv[n] = wt[(k0 + lk) * COUT + (COUT == 32 ? ((n * 16 + li) ^ ((lk & 1) << 4)) : n * 16 + li)];
+        for (int m = 0; m < 4; ++m) {
+          const float t0 = __shfl(c[m], lane - 1, 64);
+          const float u0 = m > 0 ? __shfl(c[m > 0 ? m - 1 : 0], lane + 15, 64) : e;
+          lf[m] = li == 0 ? u0 : t0;
+          const float t1 = __shfl(c[m], lane + 1, 64);
+          const float u1 = m < 3 ? __shfl(c[m < 3 ? m + 1 : 3], lane - 15, 64) : e;
+          rt[m] = li == 15 ? u1 : t1;
+        }
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int d = 0; d < 3; ++d) {
+          float bv[NT];
 #pragma unroll
           for (int n = 0; n < NT; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv[n], acc[m][n], 0, 0, 0);
+            bv[n] = wt[(d * CIN + k0 + lk) * COUT + (COUT == 32 ? ((n * 16 + li) ^ ((lk & 1) << 4)) : n * 16 + li)];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const float av = d == 0 ? lf[m] : (d == 1 ? c[m] : rt[m]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[n], acc[m][n], 0, 0, 0);
+          }
+        }
       }
     }
     // C/D: col (output channel) = lane & 15, row (voxel) = (lane >> 4) * 4 + reg
