@@ -380,9 +380,12 @@ int vamp_conv3d_forward(const VampConvDesc* d, const float* in, const float* wei
                         void* stream);
 int vamp_conv3d_backward_data(const VampConvDesc* d, const float* grad_out, const float* weight,
                               float* grad_in, void* stream);
-/* grad_weight [cout, cin, 3, 3, 3] is fully overwritten */
+size_t vamp_conv3d_workspace_bytes(const VampConvDesc* d);
+/* grad_weight [cout, cin, 3, 3, 3] is fully overwritten; workspace holds the per-workgroup partial
+   sums (vamp_conv3d_workspace_bytes) */
 int vamp_conv3d_backward_weight(const VampConvDesc* d, const float* in, const float* grad_out,
-                                float* grad_weight, void* stream);
+                                float* grad_weight, void* workspace, size_t workspace_bytes,
+                                void* stream);
 
 #ifdef __cplusplus
 }

@@ -52,10 +52,11 @@ def run(train=True):
 for _ in range(3):
     run()
 torch.cuda.synchronize()
-n = 10
+n = 20
 tot = {}
 e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
 fwd = bwd = 0.0
+fl, bl = [], []
 for _ in range(n):
     marks.clear()
     mod.zero_grad(set_to_none=True)
@@ -67,11 +68,26 @@ for _ in range(n):
     e2.record()
     torch.cuda.synchronize()
     fwd += e0.elapsed_time(e1); bwd += e1.elapsed_time(e2)
+    fl.append(e0.elapsed_time(e1)); bl.append(e1.elapsed_time(e2))
     open_ = {}
     for name, kind, e in marks:
         if kind == "b":
             open_[name] = e
         else:
             tot[name] = tot.get(name, 0.0) + open_[name].elapsed_time(e)
-print("BaseVAMPIRE2 at cfg-B, batch %d (stand-in image encoder): forward %.2f ms, backward %.2f ms" % (B, fwd / n, bwd / n))
+fl.sort(); bl.sort()
+print("BaseVAMPIRE2 at cfg-B, batch %d (stand-in image encoder): forward %.2f ms, backward %.2f ms (medians of %d steps; "
+      "means %.2f / %.2f, forward min %.2f max %.2f)" % (B, fl[n // 2], bl[n // 2], n, fwd / n, bwd / n, fl[0], fl[-1]))
 print("forward sections (ms): " + ", ".join("%s %.2f" % (k, v / n) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])))
+# in-library HIP-event timer over three more steps: the HIP kernels of the layers around the path
+from vampire_amd import _capi
+_capi.profile_select(None)
+_capi.profile_enable(True)
+for _ in range(3):
+    run()
+torch.cuda.synchronize()
+_capi.profile_enable(False)
+prof = _capi.profile_read()
+print("HIP kernels per step (us): " + ", ".join("%s %.0f (%d x %.0f)" % (k, ms / 3 * 1e3, n // 3, ms / n * 1e3)
+                                                for k, (n, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1])[:12]))
+

@@ -97,7 +97,8 @@ SIGNATURES = {
     "vamp_upsample_trilinear_backward": (C.c_int, [C.c_int64] + [C.c_int32] * 6 + [_P, _P, _P, C.c_size_t, _P]),
     "vamp_conv3d_forward": (C.c_int, [_CD, _P, _P, _P, _P]),
     "vamp_conv3d_backward_data": (C.c_int, [_CD, _P, _P, _P, _P]),
-    "vamp_conv3d_backward_weight": (C.c_int, [_CD, _P, _P, _P, _P]),
+    "vamp_conv3d_workspace_bytes": (C.c_size_t, [_CD]),
+    "vamp_conv3d_backward_weight": (C.c_int, [_CD, _P, _P, _P, _P, C.c_size_t, _P]),
     "vamp_density_gate_backward": (C.c_int, [C.c_int64, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, _P, _P,
                                              _P]),
 }

@@ -56,14 +56,16 @@ def _resize(x, size):
 
 class _Conv3(nn.Conv3d):
     """nn.Conv3d(cin, cout, 3, stride, 1, bias=False) (same parameter name and shape).  The
-    stride-1 layers with 16 / 32 channels run on the HIP fp32 matrix-core kernel for fp32 device
-    tensors when `VAMP_CONV3D=1` (off by default: see DESIGN.md 7e for where it stands against
-    MIOpen); everything else is torch's conv."""
+    stride-1 layers with 16 / 32 channels run on the HIP fp32 matrix-core kernels for fp32 device
+    tensors of at least `VAMP_CONV3D_MIN_VOXELS` voxels (default 200 000: the full-resolution
+    level, where they are 1.45x faster than MIOpen forward + backward; the coarser levels are
+    latency-bound and stay with MIOpen); `VAMP_CONV3D=0` keeps MIOpen everywhere."""
 
     def forward(self, x):
-        if os.environ.get("VAMP_CONV3D", "0") == "1":
+        if os.environ.get("VAMP_CONV3D", "1") != "0" and x.dim() == 5:
             from .ops import conv3d_3x3x3, conv3d_supported
-            if conv3d_supported(x, self.weight, self.stride, self.padding, self.bias):
+            if (x[0, 0].numel() >= int(os.environ.get("VAMP_CONV3D_MIN_VOXELS", "200000"))
+                    and conv3d_supported(x, self.weight, self.stride, self.padding, self.bias)):
                 return conv3d_3x3x3(x, self.weight)
         return super().forward(x)
 
@@ -315,6 +317,25 @@ class BaseVAMPIRE2(nn.Module):
         return (pts - lo) / span * 2.0 - 1.0
 
     # -- one sweep (bv2:518-649) --------------------------------------------
+    def _heads(self, base):
+        """density_conv / seg_conv / rgb_conv (bv2:186-198): three 3x3x3 convs of the same input.  For
+        fp32 device tensors they run as ONE 16 -> 32 HIP conv on the concatenated (zero-padded)
+        weights -- the volume is read once and MIOpen's three forward / data / weight-gradient
+        launches become one each; biases and the rgb sigmoid follow.  Parameters are untouched."""
+        nout = 1 + self.num_classes + 3
+        if os.environ.get("VAMP_CONV3D", "1") != "0" and nout <= 32 and base.dim() == 5:
+            from .ops import conv3d_3x3x3, conv3d_supported
+            wd, ws, wr = self.density_conv.weight, self.seg_conv.weight, self.rgb_conv[0].weight
+            w = torch.cat([wd, ws, wr, wd.new_zeros((32 - nout,) + tuple(wd.shape[1:]))], 0)
+            if (base[0, 0].numel() >= int(os.environ.get("VAMP_CONV3D_MIN_VOXELS", "200000"))
+                    and conv3d_supported(base, w, (1, 1, 1), (1, 1, 1), None)):
+                y = conv3d_3x3x3(base, w)
+                K = self.num_classes
+                bias = lambda b: b.view(1, -1, 1, 1, 1)
+                return (y[:, :1] + bias(self.density_conv.bias), y[:, 1:1 + K] + bias(self.seg_conv.bias),
+                        torch.sigmoid(y[:, 1 + K:nout] + bias(self.rgb_conv[0].bias)))
+        return self.density_conv(base), self.seg_conv(base), self.rgb_conv(base)
+
     def _forward_single_sweep(self, sweep_index, sweep_imgs, mats_dict, inrange_pts=None):
         B, S, N = sweep_imgs.shape[:3]
         img_feats = self.get_cam_feats(sweep_imgs)
@@ -328,9 +349,7 @@ class BaseVAMPIRE2(nn.Module):
             pos = self.norm_voxel_coords.permute(3, 0, 1, 2)[None].repeat(B, 1, 1, 1, 1)
             voxel_features = torch.cat([voxel_features, pos], dim=1)
         base = self.base_conv(voxel_features)
-        density_feature = self.density_conv(base)
-        semantic_logits = self.seg_conv(base)
-        rgb = self.rgb_conv(base)
+        density_feature, semantic_logits, rgb = self._heads(base)
 
         # lidar-point queries (bv2:576-596) and occupancy resampling on the bda-rotated Occ3D grid
         # (bv2:597-609): HIP point resampling, `hp` may be an oracle stand-in on CPU

@@ -135,74 +135,141 @@ conv3d_fwd_kernel(ConvParams P, const float* __restrict__ in, const float* __res
 
 // ---------------------------------------------------------------------------
 // weight gradient: dw[co][ci][t] = sum_{b, voxel} dout[b][co][voxel] * in[b][ci][voxel + tap t]
-// MFMA: M = co (16 per tile), N = ci (16 per tile), K = 4 consecutive x.
-//   A[co l & 15][x k0 + (l >> 4)] = dout,  B[x k0 + (l >> 4)][ci l & 15] = in (shifted by the tap)
-// A wave takes (tap-group, row) work: for one (b, z, y) row it walks x in steps of 4 and keeps the
-// accumulators of ONE tap triple (dx = -1, 0, 1 of a fixed (dz, dy)) for all channel tiles:
-// 3 * (COUT / 16) * (CIN / 16) tiles.  Rows are dealt to workgroups in slabs; partial sums leave
-// through LDS and float atomics.
+// MFMA: M = co (16 per tile), N = ci (16 per tile), K = 4 consecutive x:
+//   A[co l & 15][x k0 + (l >> 4)] = dout,  B[x k0 + (l >> 4)][ci l & 15] = in shifted by the tap.
+// Both operands are channel-strided in NCDHW memory, so a workgroup stages rows in LDS with
+// coalesced loads: the dout row of its output row (b, z, y) once, then for each of the nine
+// (dz, dy) pairs the input row (z + dz, y + dy) with a one-element halo.  The LDS images are
+// [channel][XS] with XS = 4 (mod 32): lane (li, lk) reads word li * XS + x + lk, bank 4 li + lk,
+// every bank exactly twice per wave -- the minimum.  A wave owns one (co tile, ci tile) pair with
+// the three x-taps and a phase of the x steps, and keeps the 27 accumulator tiles of all nine pairs
+// (108 VGPRs) over the workgroup's slab of rows; partial sums go to a [workgroup][27 cout cin]
+// buffer and a second kernel adds them up in workgroup order (no atomics: the 27 * cout * cin
+// addresses would each see one float atomic per workgroup).
 // ---------------------------------------------------------------------------
 template <int CIN, int COUT>
 __global__ void __launch_bounds__(256)
 conv3d_wgrad_kernel(ConvParams P, const float* __restrict__ in, const float* __restrict__ dout,
-                    float* __restrict__ dw, long nrows, int rows_per_block) {
-  constexpr int MT = COUT / 16, NTI = CIN / 16;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                    float* __restrict__ part, long nrows, int rows_per_block, int XS) {
+  extern __shared__ float lds[];
+  float* G = lds;                      // [COUT][XS]  dout row, G[co][x]
+  float* I = lds + COUT * XS;          // [CIN][XS]   input row, I[ci][x + 1] (I[ci][0] = x -1 = 0)
+  constexpr int MT = COUT / 16, NTI = CIN / 16, NG = MT * NTI;      // NG in {1, 2, 4}
+  constexpr int NPH = 4 / NG;                                       // x phases per group
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
+  const int grp = wave % NG, phase = wave / NG;
+  const int gm = grp % MT, gn = grp / MT;
   const long plane = (long) P.Z * P.Y * P.X;
   const long r0 = (long) blockIdx.x * rows_per_block, r1 = min(nrows, r0 + rows_per_block);
-  // the 9 (dz, dy) pairs are dealt to the 4 waves: wave w takes pairs w, w + 4, w + 8
-  for (int pair = wave; pair < 9; pair += 4) {
-    const int dz = pair / 3 - 1, dy = pair % 3 - 1;
-    f32x4 acc[3][MT][NTI];
+  const int steps = (P.X + 3) / 4;
+  f32x4 acc[9][3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
+  for (int p = 0; p < 9; ++p)
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NTI; ++n) acc[d][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (long row = r0; row < r1; ++row) {
-      const int y = (int) (row % P.Y), z = (int) ((row / P.Y) % P.Z), b = (int) (row / ((long) P.Y * P.Z));
-      const int zz = z + dz, yy = y + dy;
-      if (zz < 0 || zz >= P.Z || yy < 0 || yy >= P.Y) continue;
+    for (int d = 0; d < 3; ++d) acc[p][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // zero the images once: the pads beyond X (and the halo columns) stay zero
+  for (int e = tid; e < (COUT + CIN) * XS; e += 256) lds[e] = 0.f;
+  for (long row = r0; row < r1; ++row) {
+    const int y = (int) (row % P.Y), z = (int) ((row / P.Y) % P.Z), b = (int) (row / ((long) P.Y * P.Z));
+    __syncthreads();
+    {
       const float* gp = dout + (long) b * COUT * plane + ((long) z * P.Y + y) * P.X;
-      const float* ip = in + (long) b * CIN * plane + ((long) zz * P.Y + yy) * P.X;
-      for (int xk = 0; xk < P.X; xk += 4) {
-        const int x = xk + lk;
-        const bool okx = x < P.X;
-        float a[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) a[m] = okx ? gp[(long) (m * 16 + li) * plane + x] : 0.f;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          const int xs = x + d - 1;
-          const bool oks = okx && xs >= 0 && xs < P.X;
-          float bv[NTI];
-#pragma unroll
-          for (int n = 0; n < NTI; ++n) bv[n] = oks ? ip[(long) (n * 16 + li) * plane + xs] : 0.f;
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NTI; ++n)
-              acc[d][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv[n], acc[d][m][n], 0, 0, 0);
-        }
+      for (int e = tid; e < COUT * P.X; e += 256) {
+        const int co = e / P.X, x = e - co * P.X;
+        G[co * XS + x] = gp[(long) co * plane + x];
       }
     }
-    // C/D: col = ci = lane & 15, row = co = (lane >> 4) * 4 + reg; tap t = (dz+1)*9 + (dy+1)*3 + d
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const int t = (dz + 1) * 9 + (dy + 1) * 3 + d;
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NTI; ++n)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int co = m * 16 + lk * 4 + r, ci = n * 16 + li;
-            atomicAdd(dw + ((long) co * CIN + ci) * 27 + t, acc[d][m][n][r]);
-          }
+    for (int p = 0; p < 9; ++p) {
+      const int dz = p / 3 - 1, dy = p % 3 - 1;
+      const int zz = z + dz, yy = y + dy;
+      if (zz < 0 || zz >= P.Z || yy < 0 || yy >= P.Y) continue;          // workgroup-uniform
+      __syncthreads();                                                   // previous pair is consumed
+      {
+        const float* ip = in + (long) b * CIN * plane + ((long) zz * P.Y + yy) * P.X;
+        for (int e = tid; e < CIN * P.X; e += 256) {
+          const int ci = e / P.X, x = e - ci * P.X;
+          I[ci * XS + x + 1] = ip[(long) ci * plane + x];
+        }
+      }
+      __syncthreads();
+      const float* ga = G + (gm * 16 + li) * XS + lk;
+      const float* ib = I + (gn * 16 + li) * XS + lk;
+      for (int st = phase; st < steps; st += NPH) {
+        const int xk = st * 4;
+        const float av = ga[xk];
+        const float b0 = ib[xk], b1 = ib[xk + 1], b2 = ib[xk + 2];
+        acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[p][0], 0, 0, 0);
+        acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[p][1], 0, 0, 0);
+        acc[p][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b2, acc[p][2], 0, 0, 0);
+      }
     }
   }
+  // C/D: col = ci = lane & 15, row = co = (lane >> 4) * 4 + reg; tap t = p * 3 + d.  The NPH phases
+  // of a group are folded into phase 0 through LDS, one phase at a time (27 tiles x 256 floats),
+  // then phase 0 writes the workgroup's partial sums.
+  float* red = lds;                                     // [NG][27][64][4]
+  for (int ph = 1; ph < NPH; ++ph) {
+    __syncthreads();
+    if (phase == ph) {
+#pragma unroll
+      for (int p = 0; p < 9; ++p)
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+          *reinterpret_cast<f32x4*>(red + ((grp * 27 + p * 3 + d) * 64 + lane) * 4) = acc[p][d];
+    }
+    __syncthreads();
+    if (phase == 0) {
+#pragma unroll
+      for (int p = 0; p < 9; ++p)
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+          acc[p][d] += *reinterpret_cast<const f32x4*>(red + ((grp * 27 + p * 3 + d) * 64 + lane) * 4);
+    }
+  }
+  if (phase == 0) {
+    float* pb = part + (long) blockIdx.x * 27 * COUT * CIN;
+#pragma unroll
+    for (int p = 0; p < 9; ++p)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        // partial layout [t][co][ci]: lanes li = consecutive ci
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          pb[((p * 3 + d) * COUT + gm * 16 + lk * 4 + r) * CIN + gn * 16 + li] = acc[p][d][r];
+      }
+  }
+}
+
+// dw[co][ci][t] = sum over workgroups of part[wg][t][co][ci], in workgroup order
+__global__ void __launch_bounds__(256)
+conv3d_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nblk, int cin,
+                           int cout) {
+  const int n = 27 * cout * cin;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 3 < nblk; k += 4) {
+    s0 += part[(long) k * n + e];
+    s1 += part[(long) (k + 1) * n + e];
+    s2 += part[(long) (k + 2) * n + e];
+    s3 += part[(long) (k + 3) * n + e];
+  }
+  for (; k < nblk; ++k) s0 += part[(long) k * n + e];
+  const int ci = e % cin, co = (e / cin) % cout, t = e / (cin * cout);
+  dw[((long) co * cin + ci) * 27 + t] = (s0 + s1) + (s2 + s3);
+}
+
+int wgrad_xs(int X) {                  // row pitch of the LDS images: >= 4 ceil(X / 4) + 4, = 4 mod 32
+  const int need = (X + 3) / 4 * 4 + 4;
+  return (need - 4 + 31) / 32 * 32 + 4;
+}
+
+int wgrad_blocks(const VampConvDesc* d) {
+  const long nrows = (long) d->B * d->Z * d->Y;
+  return (int) std::min<long>(nrows, 512);
 }
 
 int check(const VampConvDesc* d) {
@@ -222,8 +289,8 @@ int launch_fwd(const VampConvDesc* d, const float* in, const float* w, float* ou
   const size_t lds = (size_t) 27 * CIN * COUT * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_fwd_kernel<CIN, COUT, FLIP>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_fwd_kernel<CIN, COUT, FLIP>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     attr_set = true;
   }
   const unsigned grid = (unsigned) std::min<long>((ntiles + 3) / 4, lds > 80 * 1024 ? 256 : 512);
@@ -263,26 +330,47 @@ int vamp_conv3d_backward_data(const VampConvDesc* d, const float* grad_out, cons
   return launch_fwd<32, 32, true>(d, grad_out, weight, grad_in, s);
 }
 
+size_t vamp_conv3d_workspace_bytes(const VampConvDesc* d) {
+  if (check(d)) return 0;
+  return align_up((size_t) wgrad_blocks(d) * 27 * d->cout * d->cin * sizeof(float), 256);
+}
+
 int vamp_conv3d_backward_weight(const VampConvDesc* d, const float* in, const float* grad_out,
-                                float* grad_weight, void* stream) {
+                                float* grad_weight, void* workspace, size_t workspace_bytes,
+                                void* stream) {
   if (int e = check(d)) return e;
-  VAMP_REQUIRE(in && grad_out && grad_weight, "NULL tensor");
+  VAMP_REQUIRE(in && grad_out && grad_weight && workspace, "NULL tensor");
+  VAMP_REQUIRE(workspace_bytes >= vamp_conv3d_workspace_bytes(d), "workspace too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
   ConvParams P{d->B, d->Z, d->Y, d->X};
-  if (hipMemsetAsync(grad_weight, 0, (size_t) d->cout * d->cin * 27 * sizeof(float), s) != hipSuccess)
-    return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
   const long nrows = (long) d->B * d->Z * d->Y;
-  const int rows_per_block = (int) std::max<long>(1, (nrows + 1023) / 1024);
+  const int nblk = wgrad_blocks(d);
+  const int rows_per_block = (int) ((nrows + nblk - 1) / nblk);
   const unsigned grid = (unsigned) ((nrows + rows_per_block - 1) / rows_per_block);
-#define VAMP_WGRAD(CI, CO)                                                                     \
-  VAMP_TIMED(kProfConvWgrad, s, (conv3d_wgrad_kernel<CI, CO><<<grid, 256, 0, s>>>(              \
-      P, in, grad_out, grad_weight, nrows, rows_per_block)))
+  const int XS = wgrad_xs(d->X);
+  const size_t lds = std::max((size_t) (d->cin + d->cout) * XS, (size_t) 2 * 27 * 256) * sizeof(float);
+  VAMP_REQUIRE(lds <= 160 * 1024, "row too long for the LDS images (X <= about 600 at 32 + 32 channels)");
+  float* part = static_cast<float*>(workspace);
+#define VAMP_WGRAD(CI, CO)                                                                          \
+  do {                                                                                              \
+    static bool attr_set = false;                                                                   \
+    if (!attr_set) {                                                                                \
+      (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_kernel<CI, CO>),       \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);           \
+      attr_set = true;                                                                              \
+    }                                                                                               \
+    VAMP_TIMED(kProfConvWgrad, s, (conv3d_wgrad_kernel<CI, CO><<<grid, 256, lds, s>>>(              \
+        P, in, grad_out, part, nrows, rows_per_block, XS)));                                        \
+  } while (0)
   if (d->cin == 16 && d->cout == 16) VAMP_WGRAD(16, 16);
   else if (d->cin == 16 && d->cout == 32) VAMP_WGRAD(16, 32);
   else if (d->cin == 32 && d->cout == 16) VAMP_WGRAD(32, 16);
   else VAMP_WGRAD(32, 32);
 #undef VAMP_WGRAD
-  return check_launch("conv3d_wgrad_kernel");
+  if (int e = check_launch("conv3d_wgrad_kernel")) return e;
+  const int n = 27 * d->cout * d->cin;
+  conv3d_wgrad_reduce_kernel<<<(n + 255) / 256, 256, 0, s>>>(part, grad_weight, (int) grid, d->cin, d->cout);
+  return check_launch("conv3d_wgrad_reduce_kernel");
 }
 
 }  // extern "C"

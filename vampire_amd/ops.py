@@ -663,6 +663,11 @@ class _Conv3dFn(torch.autograd.Function):
                         "vamp_conv3d_backward_data")
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
-            _capi.check(lib.vamp_conv3d_backward_weight(C.byref(d), _ptr(x), _ptr(g), _ptr(gw), _stream()),
-                        "vamp_conv3d_backward_weight")
+            nbytes = lib.vamp_conv3d_workspace_bytes(C.byref(d))
+            key = (g.device, "conv", nbytes)
+            ws = _resize_ws.get(key)
+            if ws is None:
+                ws = _resize_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
+            _capi.check(lib.vamp_conv3d_backward_weight(C.byref(d), _ptr(x), _ptr(g), _ptr(gw), _ptr(ws),
+                                                        ws.numel(), _stream()), "vamp_conv3d_backward_weight")
         return gx, gw
