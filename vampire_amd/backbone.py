@@ -57,14 +57,14 @@ def _resize(x, size):
 class _Conv3(nn.Conv3d):
     """nn.Conv3d(cin, cout, 3, stride, 1, bias=False) (same parameter name and shape).  The
     stride-1 layers with 16 / 32 channels run on the HIP fp32 matrix-core kernels for fp32 device
-    tensors of at least `VAMP_CONV3D_MIN_VOXELS` voxels (default 200 000: the full-resolution
-    level, where they are 1.45x faster than MIOpen forward + backward; the coarser levels are
-    latency-bound and stay with MIOpen); `VAMP_CONV3D=0` keeps MIOpen everywhere."""
+    tensors of at least `VAMP_CONV3D_MIN_VOXELS` voxels (default 50 000: 1.7x MIOpen forward +
+    backward at 16x200x200, 1.1x at 8x100x100; the coarsest level is latency-bound and stays with
+    MIOpen); `VAMP_CONV3D=0` keeps MIOpen everywhere."""
 
     def forward(self, x):
         if os.environ.get("VAMP_CONV3D", "1") != "0" and x.dim() == 5:
             from .ops import conv3d_3x3x3, conv3d_supported
-            if (x[0, 0].numel() >= int(os.environ.get("VAMP_CONV3D_MIN_VOXELS", "200000"))
+            if (x[0, 0].numel() >= int(os.environ.get("VAMP_CONV3D_MIN_VOXELS", "50000"))
                     and conv3d_supported(x, self.weight, self.stride, self.padding, self.bias)):
                 return conv3d_3x3x3(x, self.weight)
         return super().forward(x)
@@ -327,7 +327,7 @@ class BaseVAMPIRE2(nn.Module):
             from .ops import conv3d_3x3x3, conv3d_supported
             wd, ws, wr = self.density_conv.weight, self.seg_conv.weight, self.rgb_conv[0].weight
             w = torch.cat([wd, ws, wr, wd.new_zeros((32 - nout,) + tuple(wd.shape[1:]))], 0)
-            if (base[0, 0].numel() >= int(os.environ.get("VAMP_CONV3D_MIN_VOXELS", "200000"))
+            if (base[0, 0].numel() >= int(os.environ.get("VAMP_CONV3D_MIN_VOXELS", "50000"))
                     and conv3d_supported(base, w, (1, 1, 1), (1, 1, 1), None)):
                 y = conv3d_3x3x3(base, w)
                 K = self.num_classes

@@ -18,6 +18,8 @@
 //   addresses, a few hundred workgroups).
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace vamp {
 namespace {
 
@@ -27,11 +29,23 @@ struct ConvParams {
   int B, Z, Y, X;
 };
 
+// DPP moves inside the 16-lane rows of a wave (a row = the 16 x positions of one K channel)
+template <int N>
+__device__ __forceinline__ float dpp_row_ror(float v) {          // lane i <- lane (i - N) mod 16
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_row_shr1(float old, float v) {   // lane i <- lane i - 1; lane 0 keeps old
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x111, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_row_shl1(float old, float v) {   // lane i <- lane i + 1; lane 15 keeps old
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x101, 0xf, 0xf, false));
+}
+
 // ---------------------------------------------------------------------------
 // forward / data gradient
 // ---------------------------------------------------------------------------
 template <int CIN, int COUT, bool FLIP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 conv3d_fwd_kernel(ConvParams P, const float* __restrict__ in, const float* __restrict__ w,
                   float* __restrict__ out, int tiles_x, long ntiles) {
   extern __shared__ float wl[];                       // [27][CIN][COUT]
@@ -40,7 +54,7 @@ conv3d_fwd_kernel(ConvParams P, const float* __restrict__ in, const float* __res
   // data gradient (the roles of the channels swap): wl[t][k][j] = w[co = k][ci = j][26 - t]
   // (COUT == 32: the two 16-column halves of odd rows are swapped, so that the four K rows a
   // load touches fall on both halves of the 32 banks)
-  for (int e = threadIdx.x; e < 27 * CIN * COUT; e += 256) {
+  for (int e = threadIdx.x; e < 27 * CIN * COUT; e += blockDim.x) {
     const int j = e % COUT, k = (e / COUT) % CIN, t = e / (COUT * CIN);
     const int js = COUT == 32 ? (j ^ ((k & 1) << 4)) : j;
     wl[(t * CIN + k) * COUT + js] = FLIP ? w[((long) k * COUT + j) * 27 + (26 - t)] : w[((long) j * CIN + k) * 27 + t];
@@ -49,7 +63,8 @@ conv3d_fwd_kernel(ConvParams P, const float* __restrict__ in, const float* __res
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const long plane = (long) P.Z * P.Y * P.X;
-  for (long tile = (long) blockIdx.x * 4 + wave; tile < ntiles; tile += (long) gridDim.x * 4) {
+  const int nw = blockDim.x >> 6;
+  for (long tile = (long) blockIdx.x * nw + wave; tile < ntiles; tile += (long) gridDim.x * nw) {
     const int tx = (int) (tile % tiles_x);
     const long row = tile / tiles_x;                  // (b, z, y)
     const int y = (int) (row % P.Y), z = (int) ((row / P.Y) % P.Z), b = (int) (row / ((long) P.Y * P.Z));
@@ -87,15 +102,16 @@ conv3d_fwd_kernel(ConvParams P, const float* __restrict__ in, const float* __res
 #pragma unroll
         for (int m = 0; m < 4; ++m) c[m] = ok[m] ? cp[xo[m]] : 0.f;
         const float e = oke ? cp[xe] : 0.f;
+        // x - 1 / x + 1 operands from the neighbouring lanes of the 16-lane row (DPP, no LDS):
+        // row_shr / row_shl by one, the lane at the end of the row keeps `old`, which is the
+        // rotated neighbour tile's edge value (or the halo value e)
         float lf[4], rt[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          const float t0 = __shfl(c[m], lane - 1, 64);
-          const float u0 = m > 0 ? __shfl(c[m > 0 ? m - 1 : 0], lane + 15, 64) : e;
-          lf[m] = li == 0 ? u0 : t0;
-          const float t1 = __shfl(c[m], lane + 1, 64);
-          const float u1 = m < 3 ? __shfl(c[m < 3 ? m + 1 : 3], lane - 15, 64) : e;
-          rt[m] = li == 15 ? u1 : t1;
+          const float u0 = m > 0 ? dpp_row_ror<1>(c[m > 0 ? m - 1 : 0]) : e;
+          lf[m] = dpp_row_shr1(u0, c[m]);
+          const float u1 = m < 3 ? dpp_row_ror<15>(c[m < 3 ? m + 1 : 3]) : e;
+          rt[m] = dpp_row_shl1(u1, c[m]);
         }
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
@@ -269,7 +285,13 @@ int wgrad_xs(int X) {                  // row pitch of the LDS images: >= 4 ceil
 
 int wgrad_blocks(const VampConvDesc* d) {
   const long nrows = (long) d->B * d->Z * d->Y;
-  return (int) std::min<long>(nrows, 512);
+  static int cap = -1;
+  if (cap < 0) {
+    const char* e = getenv("VAMP_WGRAD_BLOCKS");
+    cap = e ? atoi(e) : 0;
+  }
+  const int per_cu = cap > 0 ? cap : 2;       // measured at 16x200x200: 2 per CU 588 us fwd + bwd, 3: 616, 4: 679
+  return (int) std::min<long>(nrows, 256L * per_cu);
 }
 
 int check(const VampConvDesc* d) {
@@ -293,8 +315,13 @@ int launch_fwd(const VampConvDesc* d, const float* in, const float* w, float* ou
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     attr_set = true;
   }
-  const unsigned grid = (unsigned) std::min<long>((ntiles + 3) / 4, lds > 80 * 1024 ? 256 : 512);
-  VAMP_TIMED(FLIP ? kProfConvDgrad : kProfConvFwd, s, (conv3d_fwd_kernel<CIN, COUT, FLIP><<<grid, 256, lds, s>>>(
+  // persistent workgroups of 8 waves that share one weight image: 1 / 2 / 4 per CU by LDS size
+  // (8 waves: 60-65 TFLOP/s at 16x200x200 against 52-56 with 4; small volumes have too few
+  // tiles for that and keep 4)
+  const int wpb = ntiles >= 1024 ? 8 : 4;
+  const int per_cu = lds > 80 * 1024 ? 1 : (lds > 40 * 1024 ? 2 : 4);
+  const unsigned grid = (unsigned) std::min<long>((ntiles + wpb - 1) / wpb, 256L * per_cu);
+  VAMP_TIMED(FLIP ? kProfConvDgrad : kProfConvFwd, s, (conv3d_fwd_kernel<CIN, COUT, FLIP><<<grid, 64 * wpb, lds, s>>>(
       P, in, w, out, tiles_x, ntiles)));
   return check_launch("conv3d_fwd_kernel");
 }
