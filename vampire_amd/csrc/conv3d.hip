@@ -154,128 +154,179 @@ conv3d_fwd_kernel(ConvParams P, const float* __restrict__ in, const float* __res
 // MFMA: M = co (16 per tile), N = ci (16 per tile), K = 4 consecutive x:
 //   A[co l & 15][x k0 + (l >> 4)] = dout,  B[x k0 + (l >> 4)][ci l & 15] = in shifted by the tap.
 // Both operands are channel-strided in NCDHW memory, so a workgroup stages rows in LDS with
-// coalesced loads: the dout row of its output row (b, z, y) once, then for each of the nine
-// (dz, dy) pairs the input row (z + dz, y + dy) with a one-element halo.  The LDS images are
+// coalesced loads.  A work item is (b, z, dz, a chunk of consecutive y): it walks y with the dout
+// row (z, y) and a RING of three input rows (z + dz, y - 1 .. y + 1) in LDS -- moving to the next
+// y brings in one new dout row and one new input row (the first cut re-staged nine input rows per
+// output row: 483 us for 32 -> 16 at 16x200x200), and the rows of the next y are loaded into
+// registers before the MFMA loop of the current one, so their latency is covered.  The images are
 // [channel][XS] with XS = 4 (mod 32): lane (li, lk) reads word li * XS + x + lk, bank 4 li + lk,
-// every bank exactly twice per wave -- the minimum.  A wave owns one (co tile, ci tile) pair with
-// the three x-taps and a phase of the x steps, and keeps the 27 accumulator tiles of all nine pairs
-// (108 VGPRs) over the workgroup's slab of rows; partial sums go to a [workgroup][27 cout cin]
-// buffer and a second kernel adds them up in workgroup order (no atomics: the 27 * cout * cin
-// addresses would each see one float atomic per workgroup).
+// every bank exactly twice per wave -- the minimum.  A wave owns one (co tile, ci tile) pair and a
+// phase of the x steps and keeps the nine accumulator tiles (dy, dx) of the item's dz; partial
+// sums go to a [dz][item][9 * cout * cin] buffer that a second kernel adds up (no float atomics
+// from the workgroups: 27 * cout * cin addresses would each see one per workgroup).
 // ---------------------------------------------------------------------------
+constexpr int kWgradThreads = 256;
+constexpr int kWgradPre = 40;          // staged floats per thread and y step: (cin + cout) * X <= 40 * 256
+
 template <int CIN, int COUT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kWgradThreads)
 conv3d_wgrad_kernel(ConvParams P, const float* __restrict__ in, const float* __restrict__ dout,
-                    float* __restrict__ part, long nrows, int rows_per_block, int XS) {
+                    float* __restrict__ part, int nchunks, int rows_per_chunk, int XS, int nitems) {
   extern __shared__ float lds[];
-  float* G = lds;                      // [COUT][XS]  dout row, G[co][x]
-  float* I = lds + COUT * XS;          // [CIN][XS]   input row, I[ci][x + 1] (I[ci][0] = x -1 = 0)
+  float* G = lds;                      // [COUT][XS]     dout row, G[co][x]
+  float* I = lds + COUT * XS;          // [3][CIN][XS]   input rows, slot (yy + 3) % 3, I[ci][x + 1]
   constexpr int MT = COUT / 16, NTI = CIN / 16, NG = MT * NTI;      // NG in {1, 2, 4}
-  constexpr int NPH = 4 / NG;                                       // x phases per group
+  constexpr int NW = kWgradThreads / 64, NPH = NW / NG;             // x phases per group
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int grp = wave % NG, phase = wave / NG;
   const int gm = grp % MT, gn = grp / MT;
   const long plane = (long) P.Z * P.Y * P.X;
-  const long r0 = (long) blockIdx.x * rows_per_block, r1 = min(nrows, r0 + rows_per_block);
   const int steps = (P.X + 3) / 4;
-  f32x4 acc[9][3];
+  // item -> (dz, b, z, chunk)
+  const int item = blockIdx.x;
+  const int per_dz = nitems / 3;
+  const int dzi = item / per_dz, rest = item % per_dz;
+  const int chunk = rest % nchunks, bz = rest / nchunks;
+  const int z = bz % P.Z, b = bz / P.Z;
+  const int zz = z + dzi - 1;
+  float* pb = part + (long) item * 9 * COUT * CIN;
+  const int y0 = chunk * rows_per_chunk, y1 = min(P.Y, y0 + rows_per_chunk);
+  f32x4 acc[3][3];
 #pragma unroll
-  for (int p = 0; p < 9; ++p)
+  for (int p = 0; p < 3; ++p)
 #pragma unroll
     for (int d = 0; d < 3; ++d) acc[p][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // zero the images once: the pads beyond X (and the halo columns) stay zero
-  for (int e = tid; e < (COUT + CIN) * XS; e += 256) lds[e] = 0.f;
-  for (long row = r0; row < r1; ++row) {
-    const int y = (int) (row % P.Y), z = (int) ((row / P.Y) % P.Z), b = (int) (row / ((long) P.Y * P.Z));
+  const bool live = zz >= 0 && zz < P.Z && y0 < y1;                  // workgroup-uniform
+  if (live) {
+    const float* gbase = dout + (long) b * COUT * plane + (long) z * P.Y * P.X;
+    const float* ibase = in + (long) b * CIN * plane + (long) zz * P.Y * P.X;
+    const int nG = COUT * P.X, nI = CIN * P.X;
+    // zero the images once: pads, halo columns and rows outside the volume stay zero
+    for (int e = tid; e < (COUT + 3 * CIN) * XS; e += kWgradThreads) lds[e] = 0.f;
     __syncthreads();
-    {
-      const float* gp = dout + (long) b * COUT * plane + ((long) z * P.Y + y) * P.X;
-      for (int e = tid; e < COUT * P.X; e += 256) {
-        const int co = e / P.X, x = e - co * P.X;
-        G[co * XS + x] = gp[(long) co * plane + x];
+    // rows y0 - 1 and y0 of the input plane
+    for (int yy = y0 - 1; yy <= y0; ++yy) {
+      if (yy < 0 || yy >= P.Y) continue;
+      float* slot = I + ((yy + 3) % 3) * CIN * XS;
+      for (int e = tid; e < nI; e += kWgradThreads) {
+        const int ci = e / P.X, x = e - ci * P.X;
+        slot[ci * XS + x + 1] = ibase[(long) ci * plane + (long) yy * P.X + x];
       }
     }
+    // registers for the rows of the coming step: dout row y, input row y + 1.  Element e = tid +
+    // i * 256 of the combined [COUT + CIN][X] rows; (channel, x) advance incrementally (a division
+    // per element made the staging cost more than the MFMAs).
+    const int qstep = kWgradThreads / P.X, rstep = kWgradThreads % P.X;
+    const int c_first = tid / P.X, x_first = tid % P.X;
+    float pre[kWgradPre];
+    // (the loads are unconditional, from clamped addresses, and nothing touches their results
+    // until commit: a select on a loaded value makes the compiler wait for it right away, and
+    // the prefetch then overlaps nothing -- measured 327 us = 180 staging + 110 MFMA + 31)
+    auto fetch = [&](int y) {
+      int c = c_first, x = x_first;
+      const float* grow = gbase + (long) y * P.X;
+      const float* irow = ibase + (long) min(y + 1, P.Y - 1) * P.X - (long) COUT * plane;
 #pragma unroll
-    for (int p = 0; p < 9; ++p) {
-      const int dz = p / 3 - 1, dy = p % 3 - 1;
-      const int zz = z + dz, yy = y + dy;
-      if (zz < 0 || zz >= P.Z || yy < 0 || yy >= P.Y) continue;          // workgroup-uniform
-      __syncthreads();                                                   // previous pair is consumed
-      {
-        const float* ip = in + (long) b * CIN * plane + ((long) zz * P.Y + yy) * P.X;
-        for (int e = tid; e < CIN * P.X; e += 256) {
-          const int ci = e / P.X, x = e - ci * P.X;
-          I[ci * XS + x + 1] = ip[(long) ci * plane + x];
-        }
+      for (int i = 0; i < kWgradPre; ++i) {
+        const int cc = min(c, COUT + CIN - 1);
+        const float* src = (cc < COUT ? grow : irow) + (long) cc * plane + x;
+        pre[i] = *src;
+        x += rstep; c += qstep;
+        if (x >= P.X) { x -= P.X; ++c; }
       }
+    };
+    auto commit = [&](int y) {
+      float* slot = I + ((y + 1) % 3) * CIN * XS + 1 - COUT * XS;   // slot[c * XS + x] for c >= COUT
+      const bool inext = y + 1 < P.Y;
+      int c = c_first, x = x_first;
+#pragma unroll
+      for (int i = 0; i < kWgradPre; ++i) {
+        if (c < COUT) G[c * XS + x] = pre[i];
+        else if (c < COUT + CIN) slot[c * XS + x] = inext ? pre[i] : 0.f;   // zeros outside the volume
+        x += rstep; c += qstep;
+        if (x >= P.X) { x -= P.X; ++c; }
+      }
+    };
+    fetch(y0);
+    for (int y = y0; y < y1; ++y) {
+      __syncthreads();                          // the previous step's MFMAs are done with G / the ring
+      commit(y);
       __syncthreads();
+      if (y + 1 < y1) fetch(y + 1);             // in flight during the MFMA loop
       const float* ga = G + (gm * 16 + li) * XS + lk;
-      const float* ib = I + (gn * 16 + li) * XS + lk;
+      const float* i0 = I + (((y - 1 + 3) % 3) * CIN + gn * 16 + li) * XS + lk;
+      const float* i1 = I + (((y + 3) % 3) * CIN + gn * 16 + li) * XS + lk;
+      const float* i2 = I + (((y + 1) % 3) * CIN + gn * 16 + li) * XS + lk;
       for (int st = phase; st < steps; st += NPH) {
         const int xk = st * 4;
         const float av = ga[xk];
-        const float b0 = ib[xk], b1 = ib[xk + 1], b2 = ib[xk + 2];
-        acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[p][0], 0, 0, 0);
-        acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[p][1], 0, 0, 0);
-        acc[p][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b2, acc[p][2], 0, 0, 0);
+        const float* rows[3] = {i0, i1, i2};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const float b0 = rows[p][xk], b1 = rows[p][xk + 1], b2 = rows[p][xk + 2];
+          acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[p][0], 0, 0, 0);
+          acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[p][1], 0, 0, 0);
+          acc[p][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b2, acc[p][2], 0, 0, 0);
+        }
       }
     }
   }
-  // C/D: col = ci = lane & 15, row = co = (lane >> 4) * 4 + reg; tap t = p * 3 + d.  The NPH phases
-  // of a group are folded into phase 0 through LDS, one phase at a time (27 tiles x 256 floats),
-  // then phase 0 writes the workgroup's partial sums.
-  float* red = lds;                                     // [NG][27][64][4]
+  // The row y0 - 1 slot of the ring: when y0 - 1 < 0 it was never written and is zero.  (Rows
+  // beyond the chunk end were committed as zeros only if outside the volume; inside the volume
+  // they are real data -- the next chunk's rows -- which is what dy = +1 of the last row needs.)
+  // C/D: col = ci = lane & 15, row = co = (lane >> 4) * 4 + reg.  The NPH phases of a group are
+  // folded into phase 0 through LDS, one at a time; phase 0 writes the item's partial sums.
+  float* red = lds;                                     // [NG][9][64][4]
   for (int ph = 1; ph < NPH; ++ph) {
     __syncthreads();
     if (phase == ph) {
 #pragma unroll
-      for (int p = 0; p < 9; ++p)
+      for (int p = 0; p < 3; ++p)
 #pragma unroll
         for (int d = 0; d < 3; ++d)
-          *reinterpret_cast<f32x4*>(red + ((grp * 27 + p * 3 + d) * 64 + lane) * 4) = acc[p][d];
+          *reinterpret_cast<f32x4*>(red + ((grp * 9 + p * 3 + d) * 64 + lane) * 4) = acc[p][d];
     }
     __syncthreads();
     if (phase == 0) {
 #pragma unroll
-      for (int p = 0; p < 9; ++p)
+      for (int p = 0; p < 3; ++p)
 #pragma unroll
         for (int d = 0; d < 3; ++d)
-          acc[p][d] += *reinterpret_cast<const f32x4*>(red + ((grp * 27 + p * 3 + d) * 64 + lane) * 4);
+          acc[p][d] += *reinterpret_cast<const f32x4*>(red + ((grp * 9 + p * 3 + d) * 64 + lane) * 4);
     }
   }
   if (phase == 0) {
-    float* pb = part + (long) blockIdx.x * 27 * COUT * CIN;
 #pragma unroll
-    for (int p = 0; p < 9; ++p)
+    for (int p = 0; p < 3; ++p)
 #pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        // partial layout [t][co][ci]: lanes li = consecutive ci
+      for (int d = 0; d < 3; ++d)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r)      // partial layout [dy dx][co][ci]: lanes li = consecutive ci
           pb[((p * 3 + d) * COUT + gm * 16 + lk * 4 + r) * CIN + gn * 16 + li] = acc[p][d][r];
-      }
   }
 }
 
-// dw[co][ci][t] = sum over workgroups of part[wg][t][co][ci], in workgroup order
+// dw[co][ci][t] = sum over the items of tap t's dz of part[item][t % 9][co][ci]; the items are split
+// over gridDim.y slices whose sums meet in dw (zeroed before) through one float atomic each
 __global__ void __launch_bounds__(256)
-conv3d_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nblk, int cin,
+conv3d_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int per_dz, int cin,
                            int cout) {
-  const int n = 27 * cout * cin;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= n) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int k = 0;
-  for (; k + 3 < nblk; k += 4) {
-    s0 += part[(long) k * n + e];
-    s1 += part[(long) (k + 1) * n + e];
-    s2 += part[(long) (k + 2) * n + e];
-    s3 += part[(long) (k + 3) * n + e];
+  const int n9 = 9 * cout * cin;
+  const int e = blockIdx.x * 256 + threadIdx.x;          // over [dz][9][co][ci]
+  if (e >= 3 * n9) return;
+  const int dzi = e / n9, r = e - dzi * n9;
+  const int k0 = (int) ((long) per_dz * blockIdx.y / gridDim.y), k1 = (int) ((long) per_dz * (blockIdx.y + 1) / gridDim.y);
+  const float* p = part + ((long) dzi * per_dz) * n9 + r;
+  float s0 = 0.f, s1 = 0.f;
+  int k = k0;
+  for (; k + 1 < k1; k += 2) {
+    s0 += p[(long) k * n9];
+    s1 += p[(long) (k + 1) * n9];
   }
-  for (; k < nblk; ++k) s0 += part[(long) k * n + e];
-  const int ci = e % cin, co = (e / cin) % cout, t = e / (cin * cout);
-  dw[((long) co * cin + ci) * 27 + t] = (s0 + s1) + (s2 + s3);
+  if (k < k1) s0 += p[(long) k * n9];
+  const int ci = r % cin, co = (r / cin) % cout, t9 = r / (cin * cout);
+  atomicAdd(dw + ((long) co * cin + ci) * 27 + dzi * 9 + t9, s0 + s1);
 }
 
 int wgrad_xs(int X) {                  // row pitch of the LDS images: >= 4 ceil(X / 4) + 4, = 4 mod 32
@@ -283,15 +334,29 @@ int wgrad_xs(int X) {                  // row pitch of the LDS images: >= 4 ceil
   return (need - 4 + 31) / 32 * 32 + 4;
 }
 
-int wgrad_blocks(const VampConvDesc* d) {
-  const long nrows = (long) d->B * d->Z * d->Y;
-  static int cap = -1;
-  if (cap < 0) {
-    const char* e = getenv("VAMP_WGRAD_BLOCKS");
-    cap = e ? atoi(e) : 0;
+// y chunks per (b, z, dz): as many items as workgroups fit on the chip at once (by LDS), not more --
+// 528 items on 512 slots run a second, nearly empty round
+size_t wgrad_lds(const VampConvDesc* d) {
+  return std::max((size_t) (d->cout + 3 * d->cin) * wgrad_xs(d->X), (size_t) 4 * 9 * 256) * sizeof(float);
+}
+struct WgradPlan {
+  int nchunks, rows_per_chunk, nitems;
+};
+WgradPlan wgrad_plan(const VampConvDesc* d) {
+  const long combos = (long) d->B * d->Z * 3;
+  const size_t lds = wgrad_lds(d);
+  const int per_cu = lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1);
+  static int scale = -1;
+  if (scale < 0) {
+    const char* e = getenv("VAMP_WGRAD_ROUNDS");
+    scale = e ? atoi(e) : 1;
   }
-  const int per_cu = cap > 0 ? cap : 2;       // measured at 16x200x200: 2 per CU 588 us fwd + bwd, 3: 616, 4: 679
-  return (int) std::min<long>(nrows, 256L * per_cu);
+  const int nchunks = (int) std::max<long>(1, std::min<long>(d->Y, 256L * per_cu * scale / combos));
+  WgradPlan p;
+  p.rows_per_chunk = (d->Y + nchunks - 1) / nchunks;
+  p.nchunks = (d->Y + p.rows_per_chunk - 1) / p.rows_per_chunk;
+  p.nitems = (int) (combos * p.nchunks);
+  return p;
 }
 
 int check(const VampConvDesc* d) {
@@ -359,7 +424,7 @@ int vamp_conv3d_backward_data(const VampConvDesc* d, const float* grad_out, cons
 
 size_t vamp_conv3d_workspace_bytes(const VampConvDesc* d) {
   if (check(d)) return 0;
-  return align_up((size_t) wgrad_blocks(d) * 27 * d->cout * d->cin * sizeof(float), 256);
+  return align_up((size_t) wgrad_plan(d).nitems * 9 * d->cout * d->cin * sizeof(float), 256);
 }
 
 int vamp_conv3d_backward_weight(const VampConvDesc* d, const float* in, const float* grad_out,
@@ -368,16 +433,17 @@ int vamp_conv3d_backward_weight(const VampConvDesc* d, const float* in, const fl
   if (int e = check(d)) return e;
   VAMP_REQUIRE(in && grad_out && grad_weight && workspace, "NULL tensor");
   VAMP_REQUIRE(workspace_bytes >= vamp_conv3d_workspace_bytes(d), "workspace too small");
+  VAMP_REQUIRE((long) (d->cin + d->cout) * d->X <= (long) kWgradPre * kWgradThreads,
+               "row too long for the staging registers ((cin + cout) * X <= 10240)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   ConvParams P{d->B, d->Z, d->Y, d->X};
-  const long nrows = (long) d->B * d->Z * d->Y;
-  const int nblk = wgrad_blocks(d);
-  const int rows_per_block = (int) ((nrows + nblk - 1) / nblk);
-  const unsigned grid = (unsigned) ((nrows + rows_per_block - 1) / rows_per_block);
+  const WgradPlan pl = wgrad_plan(d);
   const int XS = wgrad_xs(d->X);
-  const size_t lds = std::max((size_t) (d->cin + d->cout) * XS, (size_t) 2 * 27 * 256) * sizeof(float);
-  VAMP_REQUIRE(lds <= 160 * 1024, "row too long for the LDS images (X <= about 600 at 32 + 32 channels)");
+  const size_t lds = wgrad_lds(d);
+  VAMP_REQUIRE(lds <= 160 * 1024, "row too long for the LDS images");
   float* part = static_cast<float*>(workspace);
+  if (hipMemsetAsync(grad_weight, 0, (size_t) d->cout * d->cin * 27 * sizeof(float), s) != hipSuccess)
+    return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
 #define VAMP_WGRAD(CI, CO)                                                                          \
   do {                                                                                              \
     static bool attr_set = false;                                                                   \
@@ -386,8 +452,8 @@ int vamp_conv3d_backward_weight(const VampConvDesc* d, const float* in, const fl
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);           \
       attr_set = true;                                                                              \
     }                                                                                               \
-    VAMP_TIMED(kProfConvWgrad, s, (conv3d_wgrad_kernel<CI, CO><<<grid, 256, lds, s>>>(              \
-        P, in, grad_out, part, nrows, rows_per_block, XS)));                                        \
+    VAMP_TIMED(kProfConvWgrad, s, (conv3d_wgrad_kernel<CI, CO><<<pl.nitems, kWgradThreads, lds, s>>>( \
+        P, in, grad_out, part, pl.nchunks, pl.rows_per_chunk, XS, pl.nitems)));                     \
   } while (0)
   if (d->cin == 16 && d->cout == 16) VAMP_WGRAD(16, 16);
   else if (d->cin == 16 && d->cout == 32) VAMP_WGRAD(16, 32);
@@ -396,7 +462,9 @@ int vamp_conv3d_backward_weight(const VampConvDesc* d, const float* in, const fl
 #undef VAMP_WGRAD
   if (int e = check_launch("conv3d_wgrad_kernel")) return e;
   const int n = 27 * d->cout * d->cin;
-  conv3d_wgrad_reduce_kernel<<<(n + 255) / 256, 256, 0, s>>>(part, grad_weight, (int) grid, d->cin, d->cout);
+  const int per_dz = pl.nitems / 3;
+  const dim3 rgrid((unsigned) ((n + 255) / 256), (unsigned) std::max(1, std::min(16, per_dz / 8)));
+  conv3d_wgrad_reduce_kernel<<<rgrid, 256, 0, s>>>(part, grad_weight, per_dz, d->cin, d->cout);
   return check_launch("conv3d_wgrad_reduce_kernel");
 }
 
