@@ -40,6 +40,7 @@ def bench(tag, benchmark, dtype=None, cl=False):
 
 # torch caches the solver picked for a shape for the life of the process: the immediate-mode run
 # (367 ms backward: a 53 ms weight-gradient kernel per layer) goes last
+print("VAMP_CONV3D=%s (HIP fp32 matrix-core convs for the two finer levels unless 0)" % os.environ.get("VAMP_CONV3D", "1"))
 bench("fp32 benchmark", True)
 bench("fp32 benchmark NDHWC", True, cl=True)
 bench("bf16 autocast benchmark", True, torch.bfloat16)
