@@ -48,10 +48,10 @@ def _one_rank_grad(cfg, seed):
     return float(model.beta.grad), float(batch.depth.grad.abs().sum())
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, mode):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
-                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VAMP_GRAD_SYNC=mode)
     torch.set_num_threads(2)
     from vampire_amd import dist as vdist
     from vampire_amd.config import CFG_TINY
@@ -63,13 +63,17 @@ def _worker(rank, world, port, out):
     model = LiftRenderStep(cfg, "cpu", hot_path=OracleHotPath(cfg, batch.mats_host))
     ddp = vdist.wrap_ddp(model)
     assert ddp is not model
+    assert isinstance(ddp, vdist.GradSync) == (mode == "hook")
+    train_step(ddp, batch)
+    model.zero_grad(set_to_none=True)      # a second step: gradients are rebuilt, nothing is left pending
     train_step(ddp, batch)
     elapsed = vdist.max_over_ranks(1.0 + rank)
     out[rank] = (float(model.beta.grad), float(batch.depth.grad.abs().sum()), elapsed)
     vdist.shutdown()
 
 
-def test_two_rank_gloo_harness():
+@pytest.mark.parametrize("mode", ["hook", "ddp"])
+def test_two_rank_gloo_harness(mode):
     sys.path.insert(0, ROOT)
     from vampire_amd import dist as vdist
     from vampire_amd.config import CFG_TINY
@@ -79,7 +83,7 @@ def test_two_rank_gloo_harness():
         port = s.getsockname()[1]
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, mode), nprocs=2, join=True)
     g0, d0 = _one_rank_grad(cfg, vdist.shard_seed(0, 0))
     g1, d1 = _one_rank_grad(cfg, vdist.shard_seed(0, 1))
     # the shards differ, activations' gradients stay local, the parameter gradient is averaged

@@ -29,10 +29,50 @@ def shard_seed(base_seed: int, rank: int) -> int:
     return base_seed + 7919 * rank
 
 
+class GradSync(torch.nn.Module):
+    """Minimal overlapped data-parallel gradient averaging for a module with a handful of
+    parameters (the path owns one scalar): a post-accumulate hook launches an asynchronous
+    all-reduce the moment a parameter's gradient is complete -- for `beta` that is the end of the
+    render backward, so the collective runs under the lift backward -- and `finish()` (called by
+    `train_step` after backward) makes the compute stream wait for it.  Same result as
+    DistributedDataParallel (mean over ranks) without its per-step bookkeeping, which costs 45 us
+    of a 1.07 ms step on one MI355X (tools/ddp_overhead.py).  `VAMP_GRAD_SYNC=ddp` selects DDP."""
+
+    def __init__(self, module, group=None):
+        super().__init__()
+        self.module = module
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self._pending = []
+        # NCCL / RCCL has a native average; gloo (CPU tests) sums and the division follows
+        self._avg = dist.get_backend(group) == "nccl"
+        for p in module.parameters():
+            if p.requires_grad:
+                p.register_post_accumulate_grad_hook(self._launch)
+
+    def _launch(self, p):
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        self._pending.append((dist.all_reduce(p.grad, op=op, group=self.group, async_op=True), p))
+
+    def forward(self, *a, **kw):
+        return self.module(*a, **kw)
+
+    def finish(self):
+        """Order the caller's stream after the collectives launched during backward."""
+        for work, p in self._pending:
+            work.wait()
+            if not self._avg:
+                p.grad.div_(self.world)
+        self._pending.clear()
+
+
 def wrap_ddp(module, device=None):
-    """DistributedDataParallel around the step module when running multi-rank, else identity."""
+    """Gradient averaging around the step module when running multi-rank (GradSync, or
+    DistributedDataParallel with VAMP_GRAD_SYNC=ddp), else identity."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return module
+    if os.environ.get("VAMP_GRAD_SYNC", "hook") != "ddp":
+        return GradSync(module)
     from torch.nn.parallel import DistributedDataParallel as DDP
     ids = [device.index] if (device is not None and device.type == "cuda") else None
     return DDP(module, device_ids=ids)

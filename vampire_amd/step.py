@@ -68,4 +68,6 @@ def train_step(model, batch: SyntheticBatch):
     batch.zero_grads()
     vox, outs = model(batch.depth, batch.feat, batch.vols, batch.lift_mats, batch.render_mats)
     torch.autograd.backward((vox,) + tuple(outs), batch.upstream(vox, outs))
+    if hasattr(model, "finish"):          # dist.GradSync: join the gradient all-reduce
+        model.finish()
     return vox, outs
