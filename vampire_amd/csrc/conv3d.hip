@@ -13,9 +13,10 @@
 //   accumulator tiles, every B value feeds 4 MFMAs and every A value cout / 16.
 // The data gradient is the same kernel on the flipped, transposed weights (FLIP).
 // The weight gradient is a GEMM over the voxels: dw[co][ci][tap] = sum_voxel dout[voxel][co] *
-//   in[voxel + tap][ci]: M = co, N = ci, K = 4 voxels per step; a workgroup reduces a slab of rows
-//   and adds its 27 x cout x cin partial sums to the result with float atomics (cout * cin * 27
-//   addresses, a few hundred workgroups).
+//   in[voxel + tap][ci]: M = co, N = ci, K = 4 voxels per step; rows are staged in LDS and the
+//   per-workgroup partial sums are added up by a second kernel (see conv3d_wgrad_kernel).
+// Work is priced against the fp32 matrix peak (157 TFLOP/s dense): this is the one MFMA-bound
+// piece near the path.
 #include "common.hpp"
 
 #include <cstdlib>
