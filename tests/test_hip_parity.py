@@ -626,6 +626,44 @@ def test_camera_backward_cell_matches_atomic_splat_full_size(dev, monkeypatch, c
     close(b2.reshape(1), b1.reshape(1), atol=1e-3, rtol=1e-3, what="grad_beta")
 
 
+@pytest.mark.parametrize("mode,cat_seg,batch", [("naive", True, 2), ("sdf", True, 1), ("naive", False, 1)],
+                         ids=["naive-catseg-b2", "sdf-catseg", "naive"])
+def test_render_variants_full_size_match_atomic_splat(dev, monkeypatch, mode, cat_seg, batch):
+    """cfg-B with the other density mode / cat_seg / batch 2 (per-sample camera rigs): all eight
+    render outputs are finite and every input gradient of the default backward (cell lists, BEV
+    gathers, two streams) equals the v1 float-atomic implementations'."""
+    cfg = dataclasses.replace(CFG_B, density_mode=mode, cat_seg=cat_seg)
+    hp = hot(cfg, dev)
+    s2e, K, ida = synthetic.camera_rig(cfg, batch, jitter=2.0, seed=7)
+    bda = synthetic.bda_matrix(batch, rot_deg=-4.0)
+    rm = render_matrices(s2e, K, ida, bda).to(dev)
+    beta = torch.tensor(0.1, device=dev, requires_grad=True) if mode == "sdf" else None
+    gen = torch.Generator(device=dev).manual_seed(3)
+
+    def run(impl):
+        for k in ("VAMP_CAM_BWD", "VAMP_BEV_BWD"):
+            monkeypatch.setenv(k, impl)
+        vols = [v.requires_grad_(True) for v in synthetic.render_inputs(cfg, batch, seed=6, device=dev)]
+        if beta is not None:
+            beta.grad = None
+        outs = hp.render(*vols, beta, render_mats=rm)
+        gen.manual_seed(3)
+        gs = [torch.randn(o.shape, device=dev, generator=gen) for o in outs]
+        torch.autograd.backward(outs, gs)
+        return outs, [v.grad.clone() for v in vols], (beta.grad.clone() if beta is not None else None)
+
+    outs, g_new, b_new = run("cell")
+    _, g_old, b_old = run("v1")
+    assert outs[7].shape[1] == cfg.mid_channels + (cfg.num_classes if cat_seg else 0)
+    for name, o in zip(NAMES, outs):
+        assert bool(torch.isfinite(o).all()), name
+    for name, a, b in zip(("density_feature", "semantic_logits", "base", "rgb"), g_new, g_old):
+        assert float(b.abs().max()) > 0, name
+        close(a, b, atol=1e-5, rtol=3e-5, scale="max", what=f"{mode} cat_seg={cat_seg}: grad_" + name)
+    if beta is not None:
+        close(b_new.reshape(1), b_old.reshape(1), atol=1e-3, rtol=1e-3, what="grad_beta")
+
+
 def test_bev_backward_gather_matches_atomic_splat_full_size(dev, monkeypatch):
     """BEV-branch backward: per-voxel gather (v2) against the column-thread atomic splat (v1)."""
     import dataclasses
