@@ -39,6 +39,8 @@ def test_struct_layout_matches_header(lib):
     # 9+... ints and floats, no padding surprises: sizes are part of the ABI
     assert C.sizeof(_capi.VampLiftDesc) == 18 * 4
     assert C.sizeof(_capi.VampRenderDesc) == 29 * 4
+    assert C.sizeof(_capi.VampSampleDesc) == 22 * 4
+    assert C.sizeof(_capi.VampConvDesc) == 6 * 4
 
 
 def test_bad_descriptor_is_rejected_without_gpu(lib):
@@ -67,3 +69,21 @@ def test_cpu_tensors_are_refused():
     from vampire_amd.ops import _chk
     with pytest.raises(_capi.VampireHipError):
         _chk(torch.zeros(2, 2), (2, 2), "x")
+    from vampire_amd import ops
+    from vampire_amd.ops import HotPath
+    with pytest.raises(_capi.VampireHipError):
+        ops.upsample_trilinear(torch.zeros(1, 1, 2, 2, 2), (4, 4, 4))
+    with pytest.raises(_capi.VampireHipError):
+        ops.conv3d_3x3x3(torch.zeros(1, 16, 2, 2, 2), torch.zeros(16, 16, 3, 3, 3))
+
+
+def test_new_entry_points_reject_bad_arguments_without_gpu(lib):
+    """The widening rows' entry points validate before touching the device."""
+    cd = _capi.VampConvDesc()
+    cd.B, cd.cin, cd.cout, cd.Z, cd.Y, cd.X = 1, 8, 16, 4, 4, 4           # 8 input channels: unsupported
+    assert lib.vamp_conv3d_forward(C.byref(cd), None, None, None, None) == -1
+    assert b"cin, cout must be 16 or 32" in lib.vamp_last_error()
+    assert lib.vamp_conv3d_workspace_bytes(C.byref(cd)) == 0
+    assert lib.vamp_upsample_trilinear_forward(0, 1, 1, 1, 2, 2, 2, None, None, None) == -1
+    assert lib.vamp_depth_softmax_forward(1, 0, 4, None, 0, None, None) == -1
+    assert lib.vamp_density_gate_forward(1, 4, 8, 7, None, None, None, None) == -1

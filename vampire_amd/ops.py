@@ -637,6 +637,10 @@ def conv3d_supported(x, weight, stride, padding, bias):
 class _Conv3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
+        if not (x.is_cuda and w.is_cuda):
+            raise _capi.VampireHipError("x / weight must be device tensors (no CPU fallback)")
+        if x.dtype != torch.float32 or w.dtype != torch.float32 or x.dim() != 5 or w.dim() != 5:
+            raise TypeError("conv3d_3x3x3 takes fp32 [B,cin,Z,Y,X] and [cout,cin,3,3,3] tensors")
         lib = _capi.load()
         x, w = x.contiguous(), w.contiguous()
         d = _capi.VampConvDesc()
