@@ -376,6 +376,9 @@ int vamp_upsample_trilinear_backward(int64_t planes, int32_t iz, int32_t iy, int
 typedef struct {
   int32_t B, cin, cout, Z, Y, X;
 } VampConvDesc;
+/* 1 when the three entry points below accept the descriptor (cin, cout in {16, 32};
+   (cin + cout) * X <= 12288 and the LDS row images of the weight gradient fit), else 0 */
+int vamp_conv3d_supported(const VampConvDesc* d);
 int vamp_conv3d_forward(const VampConvDesc* d, const float* in, const float* weight, float* out,
                         void* stream);
 int vamp_conv3d_backward_data(const VampConvDesc* d, const float* grad_out, const float* weight,

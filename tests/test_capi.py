@@ -84,6 +84,11 @@ def test_new_entry_points_reject_bad_arguments_without_gpu(lib):
     assert lib.vamp_conv3d_forward(C.byref(cd), None, None, None, None) == -1
     assert b"cin, cout must be 16 or 32" in lib.vamp_last_error()
     assert lib.vamp_conv3d_workspace_bytes(C.byref(cd)) == 0
+    assert lib.vamp_conv3d_supported(C.byref(cd)) == 0
+    cd.cin, cd.X = 32, 256                                                  # cfg-A's conv6 row: supported
+    assert lib.vamp_conv3d_supported(C.byref(cd)) == 1
+    cd.X = 400                                                              # cfg-D: row too long
+    assert lib.vamp_conv3d_supported(C.byref(cd)) == 0
     assert lib.vamp_upsample_trilinear_forward(0, 1, 1, 1, 2, 2, 2, None, None, None) == -1
     assert lib.vamp_depth_softmax_forward(1, 0, 4, None, 0, None, None) == -1
     assert lib.vamp_density_gate_forward(1, 4, 8, 7, None, None, None, None) == -1

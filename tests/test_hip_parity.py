@@ -380,12 +380,14 @@ def test_resize_full_size(dev, shape, size):
 # --------------------------------------------------------------------------- 3x3x3 conv (UNet)
 @pytest.mark.parametrize("cin,cout,vol,batch", [(16, 16, (6, 10, 14), 2), (32, 16, (5, 37, 71), 1),
                                                 (16, 32, (4, 9, 130), 1), (32, 32, (8, 100, 100), 1),
-                                                (16, 16, (16, 200, 200), 1)])
+                                                (16, 16, (16, 200, 200), 1), (32, 16, (4, 12, 256), 1)])
 def test_conv3d_matches_torch(dev, cin, cout, vol, batch):
     """the fp32 matrix-core 3x3x3 conv (bv2:20, 40-60 layer shapes, ragged sizes)
     against torch's conv3d evaluated in fp64 on the CPU: output, data and weight gradients."""
     import torch.nn.functional as F
-    from vampire_amd.ops import conv3d_3x3x3
+    from vampire_amd.ops import conv3d_3x3x3, conv3d_supported
+    assert not conv3d_supported(torch.zeros(1, 32, 2, 2, 400, device=dev), torch.zeros(16, 32, 3, 3, 3, device=dev),
+                                (1, 1, 1), (1, 1, 1), None)            # row too long: the module falls back to MIOpen
     gen = torch.Generator().manual_seed(11)
     x = torch.randn(batch, cin, *vol, generator=gen)
     w = torch.randn(cout, cin, 3, 3, 3, generator=gen) * 0.05

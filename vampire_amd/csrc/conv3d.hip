@@ -167,9 +167,12 @@ conv3d_fwd_kernel(ConvParams P, const float* __restrict__ in, const float* __res
 // from the workgroups: 27 * cout * cin addresses would each see one per workgroup).
 // ---------------------------------------------------------------------------
 constexpr int kWgradThreads = 256;
-constexpr int kWgradPre = 40;          // staged floats per thread and y step: (cin + cout) * X <= 40 * 256
+constexpr int kWgradPre = 48;          // staged floats per thread and y step: (cin + cout) * X <= 48 * 256
 
-template <int CIN, int COUT>
+// NPRE = staged floats per thread and y step (compile-time, so that the staging loops unroll
+// into plain load / store batches): the host picks the smallest of {26, 38, 48} that covers
+// (cin + cout) * X / 256
+template <int CIN, int COUT, int NPRE>
 __global__ void __launch_bounds__(kWgradThreads)
 conv3d_wgrad_kernel(ConvParams P, const float* __restrict__ in, const float* __restrict__ dout,
                     float* __restrict__ part, int nchunks, int rows_per_chunk, int XS, int nitems) {
@@ -220,7 +223,7 @@ conv3d_wgrad_kernel(ConvParams P, const float* __restrict__ in, const float* __r
     // per element made the staging cost more than the MFMAs).
     const int qstep = kWgradThreads / P.X, rstep = kWgradThreads % P.X;
     const int c_first = tid / P.X, x_first = tid % P.X;
-    float pre[kWgradPre];
+    float pre[NPRE];
     // (the loads are unconditional, from clamped addresses, and nothing touches their results
     // until commit: a select on a loaded value makes the compiler wait for it right away, and
     // the prefetch then overlaps nothing -- measured 327 us = 180 staging + 110 MFMA + 31)
@@ -229,7 +232,7 @@ conv3d_wgrad_kernel(ConvParams P, const float* __restrict__ in, const float* __r
       const float* grow = gbase + (long) y * P.X;
       const float* irow = ibase + (long) min(y + 1, P.Y - 1) * P.X - (long) COUT * plane;
 #pragma unroll
-      for (int i = 0; i < kWgradPre; ++i) {
+      for (int i = 0; i < NPRE; ++i) {
         const int cc = min(c, COUT + CIN - 1);
         const float* src = (cc < COUT ? grow : irow) + (long) cc * plane + x;
         pre[i] = *src;
@@ -242,7 +245,7 @@ conv3d_wgrad_kernel(ConvParams P, const float* __restrict__ in, const float* __r
       const bool inext = y + 1 < P.Y;
       int c = c_first, x = x_first;
 #pragma unroll
-      for (int i = 0; i < kWgradPre; ++i) {
+      for (int i = 0; i < NPRE; ++i) {
         if (c < COUT) G[c * XS + x] = pre[i];
         else if (c < COUT + CIN) slot[c * XS + x] = inext ? pre[i] : 0.f;   // zeros outside the volume
         x += rstep; c += qstep;
@@ -423,6 +426,15 @@ int vamp_conv3d_backward_data(const VampConvDesc* d, const float* grad_out, cons
   return launch_fwd<32, 32, true>(d, grad_out, weight, grad_in, s);
 }
 
+/* 1 when all three entry points accept this descriptor (channel counts, row length against the
+   weight-gradient's staging registers and LDS images), else 0 */
+int vamp_conv3d_supported(const VampConvDesc* d) {
+  if (check(d)) return 0;
+  if ((long) (d->cin + d->cout) * d->X > (long) kWgradPre * kWgradThreads) return 0;
+  if (wgrad_lds(d) > 160 * 1024) return 0;
+  return 1;
+}
+
 size_t vamp_conv3d_workspace_bytes(const VampConvDesc* d) {
   if (check(d)) return 0;
   return align_up((size_t) wgrad_plan(d).nitems * 9 * d->cout * d->cin * sizeof(float), 256);
@@ -435,7 +447,7 @@ int vamp_conv3d_backward_weight(const VampConvDesc* d, const float* in, const fl
   VAMP_REQUIRE(in && grad_out && grad_weight && workspace, "NULL tensor");
   VAMP_REQUIRE(workspace_bytes >= vamp_conv3d_workspace_bytes(d), "workspace too small");
   VAMP_REQUIRE((long) (d->cin + d->cout) * d->X <= (long) kWgradPre * kWgradThreads,
-               "row too long for the staging registers ((cin + cout) * X <= 10240)");
+               "row too long for the staging registers ((cin + cout) * X <= 12288)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   ConvParams P{d->B, d->Z, d->Y, d->X};
   const WgradPlan pl = wgrad_plan(d);
@@ -445,21 +457,29 @@ int vamp_conv3d_backward_weight(const VampConvDesc* d, const float* in, const fl
   float* part = static_cast<float*>(workspace);
   if (hipMemsetAsync(grad_weight, 0, (size_t) d->cout * d->cin * 27 * sizeof(float), s) != hipSuccess)
     return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
-#define VAMP_WGRAD(CI, CO)                                                                          \
+#define VAMP_WGRAD_N(CI, CO, NP)                                                                    \
   do {                                                                                              \
     static bool attr_set = false;                                                                   \
     if (!attr_set) {                                                                                \
-      (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_kernel<CI, CO>),       \
+      (void) hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wgrad_kernel<CI, CO, NP>),   \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);           \
       attr_set = true;                                                                              \
     }                                                                                               \
-    VAMP_TIMED(kProfConvWgrad, s, (conv3d_wgrad_kernel<CI, CO><<<pl.nitems, kWgradThreads, lds, s>>>( \
+    VAMP_TIMED(kProfConvWgrad, s, (conv3d_wgrad_kernel<CI, CO, NP><<<pl.nitems, kWgradThreads, lds, s>>>( \
         P, in, grad_out, part, pl.nchunks, pl.rows_per_chunk, XS, pl.nitems)));                     \
+  } while (0)
+  const int npre = (int) (((long) (d->cin + d->cout) * d->X + kWgradThreads - 1) / kWgradThreads);
+#define VAMP_WGRAD(CI, CO)                                                                          \
+  do {                                                                                              \
+    if (npre <= 26) VAMP_WGRAD_N(CI, CO, 26);                                                       \
+    else if (npre <= 38) VAMP_WGRAD_N(CI, CO, 38);                                                  \
+    else VAMP_WGRAD_N(CI, CO, kWgradPre);                                                           \
   } while (0)
   if (d->cin == 16 && d->cout == 16) VAMP_WGRAD(16, 16);
   else if (d->cin == 16 && d->cout == 32) VAMP_WGRAD(16, 32);
   else if (d->cin == 32 && d->cout == 16) VAMP_WGRAD(32, 16);
   else VAMP_WGRAD(32, 32);
+#undef VAMP_WGRAD_N
 #undef VAMP_WGRAD
   if (int e = check_launch("conv3d_wgrad_kernel")) return e;
   const int n = 27 * d->cout * d->cin;

@@ -628,10 +628,14 @@ def conv3d_3x3x3(x, weight):
 
 
 def conv3d_supported(x, weight, stride, padding, bias):
-    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and bias is None
+    if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and bias is None
             and tuple(stride) == (1, 1, 1) and tuple(padding) == (1, 1, 1) and tuple(weight.shape[2:]) == (3, 3, 3)
-            and weight.shape[0] in (16, 32) and weight.shape[1] in (16, 32) and x.dim() == 5
-            and not torch.is_autocast_enabled())
+            and x.dim() == 5 and weight.shape[1] == x.shape[1] and not torch.is_autocast_enabled()):
+        return False
+    d = _capi.VampConvDesc()
+    d.B, d.cin, d.Z, d.Y, d.X = x.shape
+    d.cout = weight.shape[0]
+    return bool(_capi.load().vamp_conv3d_supported(C.byref(d)))
 
 
 class _Conv3dFn(torch.autograd.Function):
