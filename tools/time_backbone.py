@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
-"""Where the drop-in BaseVAMPIRE2 module spends its time at cfg-B on the GPU (SURVEY 8f N3
+"""Where the drop-in BaseVAMPIRE2 module spends its time at cfg-B (or another preset) on the GPU (SURVEY 8f N3
 sizing): forward + backward of the whole module with the stand-in image encoder, HIP events around
-the sections of _forward_single_sweep.  usage: tools/time_backbone.py [batch]"""
+the sections of _forward_single_sweep.  usage: tools/time_backbone.py [batch] [cfg]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vampire_amd.config import CFG_B as c
+from vampire_amd.config import PRESETS
 from vampire_amd.backbone import BaseVAMPIRE2
 from vampire_amd import synthetic
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+cfg_name = sys.argv[2] if len(sys.argv) > 2 else "B"
+c = PRESETS[cfg_name]
 dev = torch.device("cuda:0")
 torch.backends.cudnn.benchmark = os.environ.get("CUDNN_BENCHMARK", "0") == "1"
 kw = dict(x_bound_seg=list(c.x_bound_seg), y_bound_seg=list(c.y_bound_seg), z_bound_seg=list(c.z_bound_seg),
@@ -76,7 +78,7 @@ for _ in range(n):
         else:
             tot[name] = tot.get(name, 0.0) + open_[name].elapsed_time(e)
 fl.sort(); bl.sort()
-print("BaseVAMPIRE2 at cfg-B, batch %d (stand-in image encoder): forward %.2f ms, backward %.2f ms (medians of %d steps; "
+print("BaseVAMPIRE2 at cfg-" + cfg_name + ", batch %d (stand-in image encoder): forward %.2f ms, backward %.2f ms (medians of %d steps; "
       "means %.2f / %.2f, forward min %.2f max %.2f)" % (B, fl[n // 2], bl[n // 2], n, fwd / n, bwd / n, fl[0], fl[-1]))
 print("forward sections (ms): " + ", ".join("%s %.2f" % (k, v / n) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])))
 # in-library HIP-event timer over three more steps: the HIP kernels of the layers around the path
