@@ -403,6 +403,46 @@ def test_conv3d_matches_torch(dev, cin, cout, vol, batch):
     close(wb.grad, wa.grad, atol=1e-5, rtol=2e-5, scale="max", what="conv grad_weight")
 
 
+def test_module_conv_routing_matches_miopen(dev, monkeypatch):
+    """The module mirror's routing of its 3-D convolutions (Unet3D stride-1 layers, the three heads
+    fused into one 16 -> 32 conv) through the HIP kernels against the same modules on MIOpen:
+    outputs, input gradient and every parameter gradient."""
+    from vampire_amd.backbone import BaseVAMPIRE2, Unet3D
+    monkeypatch.setenv("VAMP_CONV3D_MIN_VOXELS", "0")
+    torch.manual_seed(3)
+    net = Unet3D(16, 16).to(dev)
+    c = CFG_TINY
+    mod = BaseVAMPIRE2(x_bound_seg=list(c.x_bound_seg), y_bound_seg=list(c.y_bound_seg), z_bound_seg=list(c.z_bound_seg),
+                       x_bound_det=list(c.x_bound_det), y_bound_det=list(c.y_bound_det), z_bound_det=list(c.z_bound_det),
+                       d_bound=list(c.d_bound), final_dim=c.final_dim, downsample_factor=4, upsample_factor=4,
+                       mid_channels=16, output_channels=8, img_backbone_conf=dict(),
+                       img_neck_conf=dict(out_channels=[8] * 4), num_classes=18, density_mode="sdf").to(dev)
+    x = torch.randn(2, 16, 8, 24, 40, device=dev)
+    up = torch.randn(2, 16, 8, 24, 40, device=dev)
+    ups = [torch.randn(2, k, 8, 24, 40, device=dev) for k in (1, 18, 3)]
+    heads = [mod.density_conv, mod.seg_conv, mod.rgb_conv]
+
+    def run(flag):
+        monkeypatch.setenv("VAMP_CONV3D", flag)
+        for m in [net] + heads:
+            m.zero_grad(set_to_none=True)
+        a = x.clone().requires_grad_(True)
+        y = net(a)
+        outs = mod._heads(y)
+        torch.autograd.backward((y,) + tuple(outs), [up] + ups)
+        grads = [p.grad.clone() for m in [net] + heads for p in m.parameters()]
+        return [y.detach()] + [o.detach() for o in outs], a.grad.clone(), grads
+
+    o1, gx1, gp1 = run("1")
+    o0, gx0, gp0 = run("0")
+    for i, (a, b) in enumerate(zip(o1, o0)):
+        close(a, b, atol=1e-5, rtol=1e-4, scale="max", what=f"module conv routing: output {i}")
+    close(gx1, gx0, atol=1e-5, rtol=1e-4, scale="max", what="module conv routing: grad_in")
+    names = [n for m in [net] + heads for n, _ in m.named_parameters()]
+    for n, a, b in zip(names, gp1, gp0):
+        close(a, b, atol=1e-5, rtol=2e-4, scale="max", what="module conv routing: grad " + n)
+
+
 # --------------------------------------------------------------------------- point resampling
 def test_point_resampling_tiny(dev):
     """occupancy and lidar-point queries (bv2:576-609) against the fixture made with
