@@ -45,12 +45,96 @@ __device__ __forceinline__ float dpp_row_shl1(float old, float v) {   // lane i 
 // ---------------------------------------------------------------------------
 // forward / data gradient
 // ---------------------------------------------------------------------------
+// One wave's tile: NM (2 .. 4) M tiles = 16 NM consecutive x of the row (b, z, y) x all output
+// channels.  A row of T = ceil(X / 16) M tiles is cut into ceil(T / 4) wave tiles of nearly equal
+// size (X = 200: 13 M tiles = 4 + 3 + 3 + 3; four 64-wide tiles would compute 16).
+template <int CIN, int COUT, int NM>
+__device__ __forceinline__ void conv_tile(const ConvParams& P, const float* __restrict__ inb,
+                                          const float* __restrict__ wl, float* __restrict__ ob, int z,
+                                          int y, int x0, int li, int lk, long plane) {
+  constexpr int NT = COUT / 16;
+  f32x4 acc[NM][NT];
+#pragma unroll
+  for (int m = 0; m < NM; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the three x-taps of a (dz, dy) row read the same 16 NM + 2 values: they are loaded once and
+  // the shifted operands come from neighbouring lanes (the load unit, not the matrix core, limits
+  // this kernel when every MFMA has its own global load)
+  bool ok[NM];
+  int xo[NM];
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const int xx = x0 + m * 16 + li;
+    ok[m] = xx < P.X;
+    xo[m] = ok[m] ? xx : 0;
+  }
+  // lane li == 0 also fetches x0 - 1, lane li == 15 fetches x0 + 16 NM
+  const int xe = li == 0 ? x0 - 1 : x0 + 16 * NM;
+  const bool oke = (li == 0 || li == 15) && xe >= 0 && xe < P.X;
+  for (int p = 0; p < 9; ++p) {
+    const int dz = p / 3 - 1, dy = p % 3 - 1;
+    const int zz = z + dz, yy = y + dy;
+    if (zz < 0 || zz >= P.Z || yy < 0 || yy >= P.Y) continue;          // wave-uniform
+    const float* rowp = inb + ((long) zz * P.Y + yy) * P.X;
+    const float* wt = wl + p * 3 * CIN * COUT;
+#pragma unroll 2
+    for (int k0 = 0; k0 < CIN; k0 += 4) {
+      const float* cp = rowp + (long) (k0 + lk) * plane;
+      float c[NM];
+#pragma unroll
+      for (int m = 0; m < NM; ++m) c[m] = ok[m] ? cp[xo[m]] : 0.f;
+      const float e = oke ? cp[xe] : 0.f;
+      // x - 1 / x + 1 operands from the neighbouring lanes of the 16-lane row (DPP, no LDS):
+      // row_shr / row_shl by one, the lane at the end of the row keeps `old`, which is the
+      // rotated neighbour tile's edge value (or the halo value e)
+      float lf[NM], rt[NM];
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        const float u0 = m > 0 ? dpp_row_ror<1>(c[m > 0 ? m - 1 : 0]) : e;
+        lf[m] = dpp_row_shr1(u0, c[m]);
+        const float u1 = m < NM - 1 ? dpp_row_ror<15>(c[m < NM - 1 ? m + 1 : NM - 1]) : e;
+        rt[m] = dpp_row_shl1(u1, c[m]);
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        float bv[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          bv[n] = wt[(d * CIN + k0 + lk) * COUT + (COUT == 32 ? ((n * 16 + li) ^ ((lk & 1) << 4)) : n * 16 + li)];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          const float av = d == 0 ? lf[m] : (d == 1 ? c[m] : rt[m]);
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[n], acc[m][n], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // C/D: col (output channel) = lane & 15, row (voxel) = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const int xb = x0 + m * 16 + lk * 4;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      float* op = ob + (long) (n * 16 + li) * plane + xb;
+      if (xb + 3 < P.X && ((P.X & 3) == 0)) {
+        *reinterpret_cast<f32x4*>(op) = acc[m][n];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (xb + r < P.X) op[r] = acc[m][n][r];
+      }
+    }
+  }
+}
+
 template <int CIN, int COUT, bool FLIP>
 __global__ void __launch_bounds__(512)
 conv3d_fwd_kernel(ConvParams P, const float* __restrict__ in, const float* __restrict__ w,
                   float* __restrict__ out, int tiles_x, long ntiles) {
   extern __shared__ float wl[];                       // [27][CIN][COUT]
-  constexpr int NT = COUT / 16;                       // N tiles
   // weights -> LDS.  forward: wl[t][ci][co] = w[co][ci][t];
   // data gradient (the roles of the channels swap): wl[t][k][j] = w[co = k][ci = j][26 - t]
   // (COUT == 32: the two 16-column halves of odd rows are swapped, so that the four K rows a
@@ -65,88 +149,20 @@ conv3d_fwd_kernel(ConvParams P, const float* __restrict__ in, const float* __res
   const int li = lane & 15, lk = lane >> 4;
   const long plane = (long) P.Z * P.Y * P.X;
   const int nw = blockDim.x >> 6;
+  // M tiles of a row, dealt to tiles_x wave tiles: the first `rem` take base + 1, the rest base
+  const int T = (P.X + 15) / 16, base = T / tiles_x, rem = T % tiles_x;
   for (long tile = (long) blockIdx.x * nw + wave; tile < ntiles; tile += (long) gridDim.x * nw) {
     const int tx = (int) (tile % tiles_x);
     const long row = tile / tiles_x;                  // (b, z, y)
     const int y = (int) (row % P.Y), z = (int) ((row / P.Y) % P.Z), b = (int) (row / ((long) P.Y * P.Z));
-    const int x0 = tx * 64;
+    const int x0 = 16 * (tx * base + min(tx, rem));
+    const int nm = base + (tx < rem ? 1 : 0);         // wave-uniform
     const float* inb = in + (long) b * CIN * plane;
-    f32x4 acc[4][NT];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // the three x-taps of a (dz, dy) row read the same 64 + 2 values: they are loaded once and the
-    // shifted operands come from neighbouring lanes (the load unit, not the matrix core, limits
-    // this kernel when every MFMA has its own global load)
-    bool ok[4];
-    int xo[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int xx = x0 + m * 16 + li;
-      ok[m] = xx < P.X;
-      xo[m] = ok[m] ? xx : 0;
-    }
-    // lane li == 0 also fetches x0 - 1, lane li == 15 fetches x0 + 64
-    const int xe = li == 0 ? x0 - 1 : x0 + 64;
-    const bool oke = (li == 0 || li == 15) && xe >= 0 && xe < P.X;
-    for (int p = 0; p < 9; ++p) {
-      const int dz = p / 3 - 1, dy = p % 3 - 1;
-      const int zz = z + dz, yy = y + dy;
-      if (zz < 0 || zz >= P.Z || yy < 0 || yy >= P.Y) continue;          // wave-uniform
-      const float* rowp = inb + ((long) zz * P.Y + yy) * P.X;
-      const float* wt = wl + p * 3 * CIN * COUT;
-#pragma unroll 2
-      for (int k0 = 0; k0 < CIN; k0 += 4) {
-        const float* cp = rowp + (long) (k0 + lk) * plane;
-        float c[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) c[m] = ok[m] ? cp[xo[m]] : 0.f;
-        const float e = oke ? cp[xe] : 0.f;
-        // x - 1 / x + 1 operands from the neighbouring lanes of the 16-lane row (DPP, no LDS):
-        // row_shr / row_shl by one, the lane at the end of the row keeps `old`, which is the
-        // rotated neighbour tile's edge value (or the halo value e)
-        float lf[4], rt[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const float u0 = m > 0 ? dpp_row_ror<1>(c[m > 0 ? m - 1 : 0]) : e;
-          lf[m] = dpp_row_shr1(u0, c[m]);
-          const float u1 = m < 3 ? dpp_row_ror<15>(c[m < 3 ? m + 1 : 3]) : e;
-          rt[m] = dpp_row_shl1(u1, c[m]);
-        }
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          float bv[NT];
-#pragma unroll
-          for (int n = 0; n < NT; ++n)
-            bv[n] = wt[(d * CIN + k0 + lk) * COUT + (COUT == 32 ? ((n * 16 + li) ^ ((lk & 1) << 4)) : n * 16 + li)];
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const float av = d == 0 ? lf[m] : (d == 1 ? c[m] : rt[m]);
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[n], acc[m][n], 0, 0, 0);
-          }
-        }
-      }
-    }
-    // C/D: col (output channel) = lane & 15, row (voxel) = (lane >> 4) * 4 + reg
     float* ob = out + (long) b * COUT * plane + ((long) z * P.Y + y) * P.X;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int xb = x0 + m * 16 + lk * 4;
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        float* op = ob + (long) (n * 16 + li) * plane + xb;
-        if (xb + 3 < P.X && ((P.X & 3) == 0)) {
-          *reinterpret_cast<f32x4*>(op) = acc[m][n];
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (xb + r < P.X) op[r] = acc[m][n][r];
-        }
-      }
-    }
+    if (nm == 4) conv_tile<CIN, COUT, 4>(P, inb, wl, ob, z, y, x0, li, lk, plane);
+    else if (nm == 3) conv_tile<CIN, COUT, 3>(P, inb, wl, ob, z, y, x0, li, lk, plane);
+    else if (nm == 2) conv_tile<CIN, COUT, 2>(P, inb, wl, ob, z, y, x0, li, lk, plane);
+    else conv_tile<CIN, COUT, 1>(P, inb, wl, ob, z, y, x0, li, lk, plane);
   }
 }
 
@@ -375,7 +391,7 @@ int check(const VampConvDesc* d) {
 template <int CIN, int COUT, bool FLIP>
 int launch_fwd(const VampConvDesc* d, const float* in, const float* w, float* out, hipStream_t s) {
   ConvParams P{d->B, d->Z, d->Y, d->X};
-  const int tiles_x = (d->X + 63) / 64;
+  const int tiles_x = ((d->X + 15) / 16 + 3) / 4;        // wave tiles per row: ceil(M tiles / 4)
   const long ntiles = (long) d->B * d->Z * d->Y * tiles_x;
   const size_t lds = (size_t) 27 * CIN * COUT * sizeof(float);
   static bool attr_set = false;
