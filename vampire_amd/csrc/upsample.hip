@@ -105,10 +105,11 @@ upsample_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int i
   }
 }
 
+template <int MH>
 __device__ __forceinline__ float hit_weight(const AxisHit& h, int k) {
   float w = 0.f;
 #pragma unroll
-  for (int q = 0; q < kMaxHits; ++q)
+  for (int q = 0; q < MH; ++q)
     if (q == k) w = h.w[q];
   return w;
 }
@@ -131,9 +132,9 @@ upsample_bwd_kernel(const float* __restrict__ g, float* __restrict__ gin, const 
     const float* gp = g + (long) pl * ovox;
     float acc = 0.f;
     for (int a = 0; a < hz.n; ++a) {
-      const float wz = hit_weight(hz, a);
+      const float wz = hit_weight<MH>(hz, a);
       for (int b = 0; b < hy.n; ++b) {
-        const float wzy = wz * hit_weight(hy, b);
+        const float wzy = wz * hit_weight<MH>(hy, b);
         const float* row = gp + ((unsigned) (hz.begin + a) * oy + (hy.begin + b)) * (unsigned) ox + hx.begin;
 #pragma unroll
         for (int c = 0; c < MH; ++c)
@@ -201,7 +202,7 @@ int vamp_upsample_trilinear_backward(int64_t planes, int32_t iz, int32_t iy, int
   if (int e = check_launch("upsample_axis_table_kernel")) return e;
   const long ivox = (long) iz * iy * ix;
   const dim3 grid((unsigned) ((ivox + 255) / 256), (unsigned) ((planes + kBwdPlanes - 1) / kBwdPlanes));
-  if (run_fits(ix, ox, 6)) {
+  if (run_fits(ix, ox, 6) && run_fits(iy, oy, 6) && run_fits(iz, oz, 6)) {
     VAMP_TIMED(kProfUpsample, s, (upsample_bwd_kernel<6><<<grid, 256, 0, s>>>(grad_out, grad_in, tab, iz, iy, ix,
                                                                              oz, oy, ox, (int) planes)));
   } else {
