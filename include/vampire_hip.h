@@ -112,6 +112,12 @@ int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs
  * no other lift backward has run on it since.  flags == 0 is vamp_lift_backward.
  */
 #define VAMP_LIFTBWD_CELLS_VALID 1
+/* implementation selectors (tests cross-check them; 0 = the default cell-list gather):
+   SPLAT = the per-voxel float-atomic splat; WPP1 / WPP4 / WPP16 force the gather's waves per pixel */
+#define VAMP_LIFTBWD_SPLAT 2
+#define VAMP_LIFTBWD_WPP1 4
+#define VAMP_LIFTBWD_WPP4 8
+#define VAMP_LIFTBWD_WPP16 16
 int vamp_lift_prepare(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                       const float* zs, void* workspace, size_t workspace_bytes, void* stream);
 int vamp_lift_backward_ex(const VampLiftDesc* d, const float* mats, const float* xs,
@@ -227,6 +233,9 @@ int vamp_render_camera_prepare(const VampRenderDesc* d, const float* mats, const
 #define VAMP_CAMBWD_ACCUMULATE 1
 #define VAMP_CAMBWD_PACKED_VALID 2
 #define VAMP_CAMBWD_CELLS_VALID 4
+/* implementation selector: the float-atomic splat instead of the default cell-list gather
+   (the independent cross-check of the tests; also what a caller-supplied geom tensor takes) */
+#define VAMP_CAMBWD_SPLAT 8
 int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, const float* mats,
                                     const float* us, const float* vs, const float* ds,
                                     const float* mids, const float* beta,
@@ -257,7 +266,8 @@ int vamp_render_bev_forward(const VampRenderDesc* d, const float* oxs, const flo
  * written only by this call and must be zero-filled (or hold a running sum).
  * ozs_host is a HOST copy of ozs (used to find the volume planes the det grid
  * touches); workspace needs vamp_render_bev_workspace_bytes(d) bytes.  With
- * ozs_host == NULL the call falls back to the slower atomic formulation.
+ * ozs_host == NULL the call takes the slower float-atomic formulation (which the
+ * tests use as the independent cross-check of the gather).
  */
 size_t vamp_render_bev_workspace_bytes(const VampRenderDesc* d);
 int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const float* oys,

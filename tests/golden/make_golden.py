@@ -30,6 +30,14 @@ Fixtures
                        sizes (resize piece)
   full_checksums.json  per-tensor (sum, abs-sum, max, sha256 of index tensors)
                        for cfg-A and cfg-B at B=1 with the synthetic rig
+  full_grad_checksums.json
+                       the reference run WITH AUTOGRAD at cfg-A and cfg-B (fixed seeded upstream
+                       gradients, `upstream_grads` below): per-gradient statistics, 256 block
+                       sums and 64 probes of grad_depth, grad_feat, the four volume gradients
+                       and grad_beta
+  cfgd_checksums.json  cfg-D (512x1408 image, 400x400x32 grid) with bf16-rounded inputs: sha256
+                       of the lift / render tap indices and masks, forward statistics, block
+                       sums and probes of the lift output and the eight render outputs
 """
 import hashlib
 import json
@@ -259,6 +267,116 @@ def make_full(BaseVAMPIRE2):
         json.dump(res, f, indent=1)
 
 
+def upstream_grads(shapes, seed):
+    """Fixed upstream gradients of the full-size runs; tests/test_hip_parity.py rebuilds the same
+    tensors from the same seed (CPU generator, in this order)."""
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(s, generator=g) * 1e-3 for s in shapes]
+
+
+def block_stat(t, nblock=256, nprobe=64):
+    """Statistics that localise an error: fp64 sums of `nblock` contiguous blocks and `nprobe`
+    strided values (besides the whole-tensor sum / abs-sum / extrema)."""
+    f = t.detach().double().flatten()
+    n = f.numel()
+    edges = [(n * i) // nblock for i in range(nblock + 1)]
+    d = stat(t)
+    d["block_sum"] = [float(f[edges[i]:edges[i + 1]].sum()) for i in range(nblock)]
+    d["block_abs_sum"] = [float(f[edges[i]:edges[i + 1]].abs().sum()) for i in range(nblock)]
+    stride = max(1, n // nprobe)
+    d["probe_stride"] = stride
+    d["probe"] = f[::stride][:nprobe].tolist()
+    return d
+
+
+RENDER_NAMES = ["rgb_preds", "seg_logits_preds", "depth_preds", "bev_rgb_preds",
+                "bev_seg_logits_preds", "bev_height_preds", "voxel_density", "voxel_output"]
+
+
+def make_full_grads(BaseVAMPIRE2):
+    """cfg-A / cfg-B at B=1: the reference's lift and render run with autograd on the synthetic
+    workload of bench.py, upstream gradients from `upstream_grads`."""
+    from vampire_amd.config import CFG_A, CFG_B
+    from vampire_amd import synthetic
+    res = {}
+    for name, cfg in (("A", CFG_A), ("B", CFG_B)):
+        m = ref_module(BaseVAMPIRE2, cfg, "sdf", False)
+        s2e, K, ida = synthetic.camera_rig(cfg, 1)
+        bda = synthetic.bda_matrix(1)
+        depth, feat = synthetic.lift_inputs(cfg, 1, seed=0)
+        vols = synthetic.render_inputs(cfg, 1, seed=0)
+        mats = dict(sensor2ego_mats=s2e[:, None], intrin_mats=K[:, None], ida_mats=ida[:, None],
+                    bda_mat=bda)
+        entry = {"seed_lift": 4242, "seed_render": 4343}
+        d_ = depth.clone().requires_grad_(True)
+        f_ = feat.clone().requires_grad_(True)
+        vox = m.get_voxel_feats(d_.unsqueeze(2) * f_.unsqueeze(3), 0, mats)       # bv2:553, 563
+        (g_vox,) = upstream_grads([vox.shape], entry["seed_lift"])
+        vox.backward(g_vox)
+        entry["grad_depth"] = block_stat(d_.grad)
+        entry["grad_feat"] = block_stat(f_.grad)
+        del vox, d_, f_
+        with torch.no_grad():
+            geom = torch.nan_to_num(m.get_geometry(s2e, K, ida, bda), -1e3)        # bv2:612
+        v_ = [t.clone().requires_grad_(True) for t in vols]
+        r = m.volume_rendering_from_multiple_views(geom, *v_)
+        g_r = upstream_grads([t.shape for t in r], entry["seed_render"])
+        torch.autograd.backward(r, g_r)
+        for n_, t in zip(["density_feature", "semantic_logits", "base", "rgb"], v_):
+            entry["grad_" + n_] = block_stat(t.grad)
+        entry["beta"] = float(m.density.beta.detach())
+        entry["grad_beta"] = float(m.density.beta.grad)
+        res[name] = entry
+        print("cfg", name, "gradients done; grad_beta", entry["grad_beta"], flush=True)
+        del r, v_, g_r, geom
+    with open(os.path.join(HERE, "full_grad_checksums.json"), "w") as f:
+        json.dump(res, f)
+
+
+def make_cfg_d(BaseVAMPIRE2):
+    """BASELINE configs[3]: 512x1408 input, 400x400x32 grid, bf16 inputs (the values the bf16
+    kernels see are the bf16-rounded tensors; the reference computes on them in fp32, Q13)."""
+    from vampire_amd.config import CFG_D as cfg
+    from vampire_amd import synthetic
+    from oracle import aten_oracle as O
+    m = ref_module(BaseVAMPIRE2, cfg, "sdf", False)
+    s2e, K, ida = synthetic.camera_rig(cfg, 1)
+    bda = synthetic.bda_matrix(1)
+    rnd = lambda t: t.bfloat16().float()
+    depth, feat = (rnd(t) for t in synthetic.lift_inputs(cfg, 1, seed=0))
+    vols = [rnd(t) for t in synthetic.render_inputs(cfg, 1, seed=0)]
+    mats = dict(sensor2ego_mats=s2e[:, None], intrin_mats=K[:, None], ida_mats=ida[:, None],
+                bda_mat=bda)
+    from vampire_amd.geometry import lift_matrices, render_matrices
+    entry = {"lift_mats": lift_matrices(s2e, K, ida, bda).tolist(),
+             "render_mats": render_matrices(s2e, K, ida, bda).tolist()}
+    with torch.no_grad():
+        pix = m.get_pixel(s2e, K, ida, bda)
+        valid, ix0, iy0, iz0 = O.lift_tap_indices(pix, cfg.final_dim, cfg.d_bound, (cfg.D, cfg.fH, cfg.fW))
+        entry["lift_valid_sha256"] = sha(valid.to(torch.uint8))
+        entry["lift_valid_count"] = int(valid.sum())
+        for nm, t in (("ix0", ix0), ("iy0", iy0), ("iz0", iz0)):
+            entry[f"lift_{nm}_sha256"] = sha(torch.where(valid, t, torch.zeros_like(t)).to(torch.int16))
+        vox = m.get_voxel_feats(depth.unsqueeze(2) * feat.unsqueeze(3), 0, mats)
+        entry["lift"] = block_stat(vox)
+        del vox, pix, valid, ix0, iy0, iz0
+        print("cfg D lift done", flush=True)
+        geom = torch.nan_to_num(m.get_geometry(s2e, K, ida, bda), -1e3)
+        inside, rx, ry, rz = O.render_tap_indices(
+            geom, (cfg.x_bound_seg, cfg.y_bound_seg, cfg.z_bound_seg), (cfg.vZ, cfg.vY, cfg.vX))
+        entry["render_inside_sha256"] = sha(inside.to(torch.uint8))
+        entry["render_inside_count"] = int(inside.sum())
+        for nm, t in (("ix0", rx), ("iy0", ry), ("iz0", rz)):
+            entry[f"render_{nm}_sha256"] = sha(torch.where(inside, t, torch.zeros_like(t)).to(torch.int16))
+        del inside, rx, ry, rz
+        r = m.volume_rendering_from_multiple_views(geom, *vols)
+        for n_, t in zip(RENDER_NAMES, r):
+            entry[n_] = block_stat(t)
+    with open(os.path.join(HERE, "cfgd_checksums.json"), "w") as f:
+        json.dump({"D": entry}, f)
+    print("cfg D done: valid", entry["lift_valid_count"], "inside", entry["render_inside_count"])
+
+
 def make_points(BaseVAMPIRE2):
     """SURVEY 8f N1.  bv2:576-609 is inline in _forward_single_sweep; the statements are replayed
     on the reference module's own state (occ_coords, density, bounds)."""
@@ -389,9 +507,17 @@ if __name__ == "__main__":
     if "--hourglass-only" in sys.argv:
         make_hourglass(V2)
         sys.exit(0)
+    if "--grads-only" in sys.argv:
+        make_full_grads(V2)
+        sys.exit(0)
+    if "--cfgd-only" in sys.argv:
+        make_cfg_d(V2)
+        sys.exit(0)
     make_tiny(V2, BL)
     make_glue(V2)
     make_hourglass(V2)
     make_points(V2)
     if "--tiny-only" not in sys.argv:
         make_full(V2)
+        make_full_grads(V2)
+        make_cfg_d(V2)

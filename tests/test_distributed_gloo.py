@@ -61,10 +61,22 @@ def _worker(rank, world, port, out, mode):
     assert (r, w) == (rank, world)
     batch = SyntheticBatch(cfg, 1, "cpu", seed=vdist.shard_seed(0, rank))
     model = LiftRenderStep(cfg, "cpu", hot_path=OracleHotPath(cfg, batch.mats_host))
+    if rank == 1:
+        with torch.no_grad():
+            model.beta.fill_(0.3)          # both wrappers broadcast rank 0's parameters at construction
     ddp = vdist.wrap_ddp(model)
     assert ddp is not model
     assert isinstance(ddp, vdist.GradSync) == (mode == "hook")
+    assert float(model.beta) == pytest.approx(0.1)
+    # a plain backward without train_step's explicit join: GradSync joins at the end of the pass
+    vox, outs = ddp(batch.depth, batch.feat, batch.vols, batch.lift_mats, batch.render_mats)
+    torch.autograd.backward((vox,) + tuple(outs), batch.upstream(vox, outs))
+    if mode == "hook":
+        assert not ddp._pending and not ddp._joining
+    plain = float(model.beta.grad)
+    model.zero_grad(set_to_none=True)
     train_step(ddp, batch)
+    assert float(model.beta.grad) == pytest.approx(plain, rel=1e-6)
     model.zero_grad(set_to_none=True)      # a second step: gradients are rebuilt, nothing is left pending
     train_step(ddp, batch)
     elapsed = vdist.max_over_ranks(1.0 + rank)

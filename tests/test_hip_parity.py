@@ -195,7 +195,7 @@ def test_render_non_finite_volume_entries(tiny_common, dev, monkeypatch):
                    density_mode="sdf", beta_param=beta, sdf_bias=cfg.sdf_bias, cat_seg=False)
 
     def run(impl):
-        monkeypatch.setenv("VAMP_CAM_BWD", impl)
+        hp.impl["cam_bwd"] = impl
         dv = [v.to(dev).requires_grad_(True) for v in vols]
         b = beta.to(dev).requires_grad_(True)
         outs = hp.render(*dv, b, render_mats=rm)
@@ -644,7 +644,7 @@ def test_camera_backward_cell_matches_atomic_splat_full_size(dev, monkeypatch, c
     gen = torch.Generator(device=dev).manual_seed(9)
 
     def run(impl):
-        monkeypatch.setenv("VAMP_CAM_BWD", impl)
+        hp.impl["cam_bwd"] = impl
         vols = [v.requires_grad_(True) for v in synthetic.render_inputs(cfg, 1, seed=2, device=dev)]
         beta.grad = None
         outs = hp.render(*vols, beta, render_mats=rm)
@@ -656,9 +656,9 @@ def test_camera_backward_cell_matches_atomic_splat_full_size(dev, monkeypatch, c
         return [v.grad.clone() for v in vols], beta.grad.clone()
 
     g3, b3 = run("cell")        # default: BEV branch on the side stream, camera gather accumulates
-    monkeypatch.setenv("VAMP_OVERLAP", "0")
+    hp.impl["overlap"] = False
     g2, b2 = run("cell")        # same kernels on one stream, camera gather overwrites
-    monkeypatch.delenv("VAMP_OVERLAP")
+    hp.impl["overlap"] = True
     g1, b1 = run("v1")          # float-atomic splat
     for name, a3, a2, b in zip(("density_feature", "semantic_logits", "base", "rgb"), g3, g2, g1):
         close(a3, b, atol=1e-5, rtol=2e-5, scale="max", what="cell (2 streams) vs v1 grad_" + name)
@@ -683,8 +683,7 @@ def test_render_variants_full_size_match_atomic_splat(dev, monkeypatch, mode, ca
     gen = torch.Generator(device=dev).manual_seed(3)
 
     def run(impl):
-        for k in ("VAMP_CAM_BWD", "VAMP_BEV_BWD"):
-            monkeypatch.setenv(k, impl)
+        hp.impl["cam_bwd"] = hp.impl["bev_bwd"] = impl
         vols = [v.requires_grad_(True) for v in synthetic.render_inputs(cfg, batch, seed=6, device=dev)]
         if beta is not None:
             beta.grad = None
@@ -717,7 +716,7 @@ def test_bev_backward_gather_matches_atomic_splat_full_size(dev, monkeypatch):
     gen = torch.Generator(device=dev)
 
     def run(impl):
-        monkeypatch.setenv("VAMP_BEV_BWD", impl)
+        hp.impl["bev_bwd"] = impl
         vols = [v.requires_grad_(True) for v in synthetic.render_inputs(cfg, 1, seed=4, device=dev)]
         beta.grad = None
         outs = hp.render(*vols, beta, render_mats=rm)
@@ -728,7 +727,7 @@ def test_bev_backward_gather_matches_atomic_splat_full_size(dev, monkeypatch):
         torch.autograd.backward(outs, gs)
         return [v.grad.clone() for v in vols], beta.grad.clone()
 
-    g2, b2 = run("v2")
+    g2, b2 = run("cell")
     g1, b1 = run("v1")
     for name, a, b in zip(("density_feature", "semantic_logits", "base", "rgb"), g2, g1):
         close(a, b, atol=1e-5, rtol=2e-5, scale="max", what="bev v2 vs v1 grad_" + name)
@@ -748,7 +747,7 @@ def test_lift_backward_cell_matches_atomic_splat_full_size(dev, monkeypatch, cfg
     gen = torch.Generator(device=dev)
 
     def run(impl):
-        monkeypatch.setenv("VAMP_LIFT_BWD", impl)
+        hp.impl["lift_bwd"] = impl
         depth, feat = synthetic.lift_inputs(cfg, 2, seed=6, device=dev)
         depth.requires_grad_(True); feat.requires_grad_(True)
         out = hp.lift(depth, feat, lm)
@@ -757,11 +756,11 @@ def test_lift_backward_cell_matches_atomic_splat_full_size(dev, monkeypatch, cfg
         return depth.grad.clone(), feat.grad.clone()
 
     d4, f4 = run("cell")        # default: cell list + a wave per pixel
-    monkeypatch.setenv("VAMP_LIFT_WPP", "4")
+    hp.impl["lift_wpp"] = 4
     d5, f5 = run("cell")        # same, four waves per pixel (the dense-pixel configuration)
-    monkeypatch.setenv("VAMP_LIFT_WPP", "16")
+    hp.impl["lift_wpp"] = 16
     d6, f6 = run("cell")
-    monkeypatch.delenv("VAMP_LIFT_WPP")
+    hp.impl["lift_wpp"] = 0
     d1, f1 = run("v1")          # per-voxel float-atomic splat
     assert float(d1.abs().max()) > 0 and float(f1.abs().max()) > 0
     for tag, dd, ff in (("cell", d4, f4), ("cell wpp4", d5, f5), ("cell wpp16", d6, f6)):
@@ -845,3 +844,263 @@ def test_backbone_forward_backward(dev):
     loss_o.backward()
     close(imgs_d.grad, imgs_c.grad, atol=1e-6, rtol=2e-3, scale="max", what="grad images")
     close(mod.density.beta.grad.reshape(1), ref.density.beta.grad.reshape(1), atol=1e-5, rtol=2e-3, what="grad beta")
+
+
+# --------------------------------------------------------------------------- round-2 parity pins
+def _block_check(t, ref, what, rtol=2e-5, probe_atol=None):
+    """A tensor against make_golden.block_stat(): 256 contiguous block sums (relative to the
+    block's abs-sum: fp32 summation order differs), 64 strided probes, extrema, shape."""
+    f = t.detach().double().flatten().cpu()
+    n = f.numel()
+    assert list(t.shape) == ref["shape"], what
+    nb = len(ref["block_sum"])
+    edges = [(n * i) // nb for i in range(nb + 1)]
+    top = max(abs(ref["max"]), abs(ref["min"]))
+    for i in range(nb):
+        blk = f[edges[i]:edges[i + 1]]
+        lim = rtol * ref["block_abs_sum"][i] + 1e-7 * top * max(1, blk.numel()) ** 0.5
+        assert abs(float(blk.sum()) - ref["block_sum"][i]) <= lim, \
+            f"{what}: block {i} sum {float(blk.sum()):.9e} vs {ref['block_sum'][i]:.9e} (lim {lim:.2e})"
+        assert abs(float(blk.abs().sum()) - ref["block_abs_sum"][i]) <= rtol * ref["block_abs_sum"][i] + lim, \
+            f"{what}: block {i} abs-sum"
+    probe = f[::ref["probe_stride"]][:len(ref["probe"])]
+    want = torch.tensor(ref["probe"], dtype=torch.float64)
+    atol = (1e-5 * top) if probe_atol is None else probe_atol
+    assert bool(((probe - want).abs() <= atol + 1e-4 * want.abs()).all()), \
+        f"{what}: probes, max err {float((probe - want).abs().max()):.3e} (atol {atol:.2e})"
+    assert abs(float(f.max()) - ref["max"]) <= 1e-4 * top + 1e-7 and abs(float(f.min()) - ref["min"]) <= 1e-4 * top + 1e-7, what
+
+
+def _upstream(shapes, seed, dev):
+    """tests/golden/make_golden.py: upstream_grads (same CPU generator, same order)."""
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.randn(s, generator=g) * 1e-3).to(dev) for s in shapes]
+
+
+@pytest.mark.parametrize("impl", ["cell", "v1"])
+@pytest.mark.parametrize("name,cfg", [("A", CFG_A), ("B", CFG_B)])
+def test_full_size_gradients_match_reference(dev, name, cfg, impl):
+    """cfg-A / cfg-B at B=1: every gradient of the HIP backward -- the default cell-list path AND the
+    v1 float-atomic cross-check path -- against the REFERENCE run with autograd on the same
+    seeded inputs and upstream gradients (tests/golden/full_grad_checksums.json)."""
+    with open(os.path.join(GOLDEN, "full_grad_checksums.json")) as f:
+        ref = json.load(f)[name]
+    with open(os.path.join(GOLDEN, "full_checksums.json")) as f:
+        mats = json.load(f)[name]
+    hp = hot(cfg, dev)
+    hp.impl["cam_bwd"] = hp.impl["lift_bwd"] = hp.impl["bev_bwd"] = impl
+    lm = torch.tensor(mats["lift_mats"], dtype=torch.float32, device=dev)
+    rm = torch.tensor(mats["render_mats"], dtype=torch.float32, device=dev)
+    depth, feat = synthetic.lift_inputs(cfg, 1, seed=0, device=dev)
+    depth.requires_grad_(True); feat.requires_grad_(True)
+    vox = hp.lift(depth, feat, lm)
+    vox.backward(_upstream([vox.shape], ref["seed_lift"], dev)[0])
+    _block_check(depth.grad, ref["grad_depth"], f"cfg-{name} {impl} grad_depth")
+    _block_check(feat.grad, ref["grad_feat"], f"cfg-{name} {impl} grad_feat")
+    vols = [v.requires_grad_(True) for v in synthetic.render_inputs(cfg, 1, seed=0, device=dev)]
+    beta = torch.tensor(ref["beta"], device=dev, requires_grad=True)
+    outs = hp.render(*vols, beta, render_mats=rm)
+    torch.autograd.backward(outs, _upstream([o.shape for o in outs], ref["seed_render"], dev))
+    for k, v in zip(("density_feature", "semantic_logits", "base", "rgb"), vols):
+        _block_check(v.grad, ref["grad_" + k], f"cfg-{name} {impl} grad_{k}", rtol=5e-5)
+    assert abs(float(beta.grad) - ref["grad_beta"]) <= 2e-3 * abs(ref["grad_beta"]) + 1e-4, \
+        (float(beta.grad), ref["grad_beta"])
+
+
+@pytest.mark.parametrize("mode,cat_seg", RENDER_VARIANTS)
+def test_v1_cross_check_paths_tiny_golden(tiny_common, dev, mode, cat_seg):
+    """The v1 float-atomic backward implementations (the cross-check of the full-size tests) are
+    themselves pinned against the reference's golden vectors."""
+    g = tiny_common
+    r = load_golden(render_fixture_name(mode, cat_seg))
+    cfg = dataclasses.replace(CFG_TINY, density_mode=mode, cat_seg=cat_seg)
+    hp = hot(cfg, dev)
+    hp.impl["cam_bwd"] = hp.impl["lift_bwd"] = hp.impl["bev_bwd"] = "v1"
+    lm, rm = tiny_mats(g, dev)
+    vols = [g[k].to(dev).requires_grad_(True)
+            for k in ("density_feature", "semantic_logits", "base", "rgb")]
+    beta = (r["beta"].reshape(()).to(dev).requires_grad_(True) if mode == "sdf" else None)
+    outs = hp.render(*vols, beta, render_mats=rm)
+    torch.autograd.backward(outs, [r["g_" + n].to(dev) for n in NAMES])
+    for k, v in zip(("density_feature", "semantic_logits", "base", "rgb"), vols):
+        close(v.grad, r["grad_" + k], atol=1e-5, rtol=1e-5, scale="max", what="v1 grad_" + k)
+    if mode == "sdf":
+        close(beta.grad.reshape(1), r["grad_beta"], atol=1e-3, rtol=1e-3, what="v1 grad_beta")
+    d = g["depth"].to(dev).requires_grad_(True)
+    f = g["feat"].to(dev).requires_grad_(True)
+    hp.lift(d, f, lm).backward(g["g_lift"].to(dev))
+    close(d.grad, g["grad_depth"], atol=1e-5, rtol=1e-5, scale="max", what="v1 grad_depth")
+    close(f.grad, g["grad_feat"], atol=1e-5, rtol=1e-5, scale="max", chan_dim=2, what="v1 grad_feat")
+
+
+@pytest.mark.parametrize("cfg,batch,mode", [(CFG_TINY, 2, "sdf"), (CFG_TINY, 2, "naive"), (CFG_B, 1, "sdf")],
+                         ids=["tiny-sdf", "tiny-naive", "cfg-B"])
+def test_bf16_inputs_equal_fp32_path_on_rounded_values(tiny_common, dev, cfg, batch, mode):
+    """bf16 volumes / depth / feat are promoted to fp32 in-kernel: render forward,
+    render backward, lift backward and the point queries must give what the fp32 path gives on the
+    bf16-rounded values (forward bit for bit; gradients up to the final rounding to bf16)."""
+    cfg = dataclasses.replace(cfg, density_mode=mode, cat_seg=(mode == "naive"))
+    hp = hot(cfg, dev)
+    if cfg.vX == CFG_TINY.vX:
+        lm, rm = tiny_mats(tiny_common, dev)
+        srcs = [tiny_common[k] for k in ("density_feature", "semantic_logits", "base", "rgb")]
+        depth, feat = tiny_common["depth"], tiny_common["feat"]
+    else:
+        s2e, K, ida = synthetic.camera_rig(cfg, batch)
+        bda = synthetic.bda_matrix(batch)
+        lm, rm = lift_matrices(s2e, K, ida, bda).to(dev), render_matrices(s2e, K, ida, bda).to(dev)
+        srcs = synthetic.render_inputs(cfg, batch, seed=3)
+        depth, feat = synthetic.lift_inputs(cfg, batch, seed=3)
+    beta = torch.tensor(0.1, device=dev) if mode == "sdf" else None
+
+    def run(dtype):
+        vols = [s.to(dev).bfloat16().to(dtype).requires_grad_(True) for s in srcs]
+        b = beta.clone().requires_grad_(True) if beta is not None else None
+        outs = hp.render(*vols, b, render_mats=rm)
+        gen = torch.Generator(device=dev).manual_seed(17)
+        torch.autograd.backward(outs, [torch.randn(o.shape, device=dev, generator=gen) for o in outs])
+        d = depth.to(dev).bfloat16().to(dtype).requires_grad_(True)
+        f = feat.to(dev).bfloat16().to(dtype).requires_grad_(True)
+        vox = hp.lift(d, f, lm)
+        gen.manual_seed(18)
+        vox.backward(torch.randn(vox.shape, device=dev, generator=gen))
+        pts = (torch.rand(batch, 500, 3, generator=torch.Generator().manual_seed(2)) * 1.2 - 0.1)
+        lo = torch.tensor([cfg.x_bound_seg[0], cfg.y_bound_seg[0], cfg.z_bound_seg[0]])
+        hi = torch.tensor([cfg.x_bound_seg[1], cfg.y_bound_seg[1], cfg.z_bound_seg[1]])
+        pts = (pts * (hi - lo) + lo).to(dev)
+        sem = vols[1].detach().clone().requires_grad_(True)
+        q = hp.sample_points(sem, pts, padding="border")
+        gen.manual_seed(19)
+        q.backward(torch.randn(q.shape, device=dev, generator=gen))
+        return (outs, vox, q), [v.grad for v in vols] + [d.grad, f.grad, sem.grad], (b.grad if b is not None else None)
+
+    (o16, v16, q16), g16, b16 = run(torch.bfloat16)
+    (o32, v32, q32), g32, b32 = run(torch.float32)
+    for n, a, b in zip(NAMES, o16, o32):
+        assert a.dtype == torch.float32 and torch.equal(a, b), n
+    assert torch.equal(v16, v32) and torch.equal(q16, q32)
+    for n, a, b in zip(("density_feature", "semantic_logits", "base", "rgb", "depth", "feat", "sem(points)"), g16, g32):
+        assert a.dtype == torch.bfloat16, n
+        # the fp32 gradient is computed identically up to the order of its sums, then rounded to bf16
+        close(a.float(), b, atol=1e-6, rtol=2.0 ** -7, what="bf16 grad_" + n)
+        close(a.float(), b, atol=1e-6, rtol=2.0 ** -8, scale="max", what="bf16 grad_" + n + " (max-scaled)")
+    if b16 is not None:
+        close(b16.reshape(1), b32.reshape(1), atol=1e-3, rtol=1e-3, what="bf16 grad_beta")
+
+
+def test_cfg_d_bf16_matches_reference(dev):
+    """BASELINE configs[3]: 512x1408 input, 400x400x32 grid, bf16 inputs, B=1.  Tap indices and masks
+    hash-equal to the reference's (30.7 M lift taps, 23 M ray samples); lift output and all eight
+    render outputs against the reference's block sums / probes on the bf16-rounded inputs
+    (tests/golden/cfgd_checksums.json); then fwd+bwd properties at full size."""
+    from vampire_amd.config import CFG_D as cfg
+    with open(os.path.join(GOLDEN, "cfgd_checksums.json")) as f:
+        ref = json.load(f)["D"]
+    hp = hot(cfg, dev)
+    lm = torch.tensor(ref["lift_mats"], dtype=torch.float32, device=dev)
+    rm = torch.tensor(ref["render_mats"], dtype=torch.float32, device=dev)
+    valid, ix0, iy0, iz0 = hp.lift_indices(lm)
+    assert int(valid.sum()) == ref["lift_valid_count"] and _sha(valid) == ref["lift_valid_sha256"]
+    vb = valid.bool()
+    for nm, t in (("ix0", ix0), ("iy0", iy0), ("iz0", iz0)):
+        assert _sha(torch.where(vb, t, torch.zeros_like(t))) == ref[f"lift_{nm}_sha256"], nm
+    del valid, ix0, iy0, iz0, vb
+    inside, rx, ry, rz = hp.render_indices(render_mats=rm)
+    assert int(inside.sum()) == ref["render_inside_count"] and _sha(inside) == ref["render_inside_sha256"]
+    for nm, t in (("ix0", rx), ("iy0", ry), ("iz0", rz)):
+        assert _sha(t) == ref[f"render_{nm}_sha256"], nm
+    del inside, rx, ry, rz
+    depth, feat = (t.to(dev).bfloat16().requires_grad_(True) for t in synthetic.lift_inputs(cfg, 1, seed=0))
+    vox = hp.lift(depth, feat, lm)
+    _block_check(vox, ref["lift"], "cfg-D lift", rtol=2e-5, probe_atol=1e-5)
+    vols = [t.to(dev).bfloat16().requires_grad_(True) for t in synthetic.render_inputs(cfg, 1, seed=0)]
+    beta = torch.tensor(0.1, device=dev, requires_grad=True)
+    outs = hp.render(*vols, beta, render_mats=rm)
+    for nm, o in zip(NAMES, outs):
+        _block_check(o, ref[nm], "cfg-D " + nm, rtol=3e-5, probe_atol=ATOL)
+    # backward at full size: finite, and the adjoint identity of the lift (linear in feat):
+    # <g, lift(depth, feat)> == <grad_feat, feat>
+    gen = torch.Generator(device=dev).manual_seed(5)
+    g = torch.randn(vox.shape, device=dev, generator=gen)
+    vox.backward(g)
+    lhs = float((g.double() * vox.double()).sum())
+    f32 = feat.detach().float().requires_grad_(True)
+    vox32 = hp.lift(depth.detach().float(), f32, lm)
+    vox32.backward(g)
+    rhs = float((f32.grad.double() * f32.detach().double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (lhs, rhs)
+    close(feat.grad.float(), f32.grad, atol=1e-6, rtol=2.0 ** -8, scale="max", what="cfg-D bf16 grad_feat")
+    torch.autograd.backward(outs, [torch.randn(o.shape, device=dev, generator=gen) * 1e-3 for o in outs])
+    for v in vols:
+        assert bool(torch.isfinite(v.grad.float()).all()) and float(v.grad.float().abs().max()) > 0
+    assert bool(torch.isfinite(beta.grad))
+
+
+def test_nccl_world_size_one_smoke(dev):
+    """The multi-GPU wiring on the real device with RCCL (backend "nccl"), world size 1: process
+    group init, GradSync hook + finish, max_over_ranks, barrier."""
+    import torch.distributed as tdist
+    from vampire_amd import dist as vdist
+    from vampire_amd.step import LiftRenderStep, SyntheticBatch, train_step
+    if tdist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    try:
+        vdist.init("nccl", dev, force=True)
+        assert tdist.get_backend() == "nccl" and tdist.get_world_size() == 1
+        cfg = dataclasses.replace(CFG_TINY, density_mode="sdf")
+        model = LiftRenderStep(cfg, dev)
+        wrapped = vdist.wrap_ddp(model, dev, force=True)
+        assert isinstance(wrapped, vdist.GradSync)
+        data = SyntheticBatch(cfg, 2, dev, seed=vdist.shard_seed(0, 0))
+        train_step(wrapped, data)
+        torch.cuda.synchronize()
+        g1 = model.beta.grad.clone()
+        model.zero_grad(set_to_none=True)
+        train_step(model, data)                      # the same step without the wrapper
+        close(g1.reshape(1), model.beta.grad.reshape(1), atol=1e-6, rtol=1e-5, what="GradSync(world 1) grad_beta")
+        assert vdist.max_over_ranks(1.25, dev) == pytest.approx(1.25)
+        vdist.barrier()
+    finally:
+        vdist.shutdown()
+
+
+@pytest.mark.parametrize("amp_dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_backbone_under_autocast(dev, amp_dtype):
+    """The drop-in module under the reference's training recipe (Lightning precision=16 = fp16
+    autocast, base_cli.py:77, 90; and bf16): forward + backward run, every output is fp32 / finite
+    and close to the fp32 run (the hot path computes in fp32 either way)."""
+    from vampire_amd.backbone import BaseVAMPIRE2
+    c = CFG_TINY
+    kw = dict(x_bound_seg=list(c.x_bound_seg), y_bound_seg=list(c.y_bound_seg), z_bound_seg=list(c.z_bound_seg),
+              x_bound_det=list(c.x_bound_det), y_bound_det=list(c.y_bound_det), z_bound_det=list(c.z_bound_det),
+              d_bound=list(c.d_bound), final_dim=c.final_dim, downsample_factor=4, upsample_factor=4,
+              mid_channels=4, output_channels=8, img_backbone_conf=dict(), img_neck_conf=dict(out_channels=[8] * 4),
+              num_classes=5, density_mode="sdf", sdf_bias=-1.0, cat_pos=True, cat_seg=False)
+    torch.manual_seed(0)
+    mod = BaseVAMPIRE2(**kw).to(dev)
+    with torch.no_grad():
+        mod.density_conv.bias.fill_(-1.0)
+    B = 2
+    s2e, K, ida = synthetic.camera_rig(c, B, src_hw=(64, 176), focal=60.0, centre=(88.0, 34.0), jitter=2.0, seed=4)
+    s2e[:, :, :3, 3] *= 0.3
+    mats = dict(sensor2ego_mats=s2e[:, None], intrin_mats=K[:, None], ida_mats=ida[:, None],
+                sensor2sensor_mats=torch.eye(4).expand(B, 1, 6, 4, 4), bda_mat=synthetic.bda_matrix(B, rot_deg=8.0))
+    mats = {k: v.to(dev) for k, v in mats.items()}
+    imgs = torch.randn(B, 1, 6, 3, *c.final_dim, device=dev)
+    pts = [torch.rand(50, 3, device=dev) * 8 - 4 for _ in range(B)]
+    ref = mod(imgs, mats, inrange_pts=pts)
+    x = imgs.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=amp_dtype):
+        out = mod(x, mats, inrange_pts=pts)
+        loss = sum((o.float() ** 2).mean() for o in out[:8])
+    loss.backward()
+    assert bool(torch.isfinite(x.grad).all()) and float(x.grad.abs().max()) > 0
+    assert bool(torch.isfinite(mod.density.beta.grad))
+    for i in range(1, 8):
+        assert out[i].dtype == torch.float32, i
+        assert bool(torch.isfinite(out[i]).all()), i
+        close(out[i], ref[i], atol=0.05, rtol=0.05, scale="max", what=f"autocast output {i}")

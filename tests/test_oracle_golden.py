@@ -49,6 +49,7 @@ def test_lift_forward_and_indices(tiny_common):
     valid, ix0, iy0, iz0 = O.lift_tap_indices(g["pix"], c.final_dim, c.d_bound, (c.D, c.fH, c.fW))
     assert torch.equal(valid.to(torch.uint8), g["lift_valid"])
     assert torch.equal(ix0.to(torch.int16), g["lift_ix0"])
+    assert torch.equal(iy0.to(torch.int16), g["lift_iy0"])
     assert torch.equal(iz0.to(torch.int16), g["lift_iz0"])
     # the fixture exercises every mask path
     assert 0.05 < valid.float().mean() < 0.5
@@ -112,6 +113,8 @@ def test_render_indices(tiny_common):
                                                  (c.vZ, c.vY, c.vX))
     assert torch.equal(inside.to(torch.uint8), g["render_inside"])
     assert torch.equal(ix0.to(torch.int16), g["render_ix0"])
+    assert torch.equal(iy0.to(torch.int16), g["render_iy0"])
+    assert torch.equal(iz0.to(torch.int16), g["render_iz0"])
     assert 0.05 < inside.float().mean() < 0.9
 
 

@@ -52,6 +52,10 @@ class VampSampleDesc(C.Structure):
 
 
 VAMP_PAD_ZEROS, VAMP_PAD_BORDER = 0, 1
+# flag bits of vamp_lift_backward_ex / vamp_render_camera_backward_acc (include/vampire_hip.h)
+VAMP_LIFTBWD_CELLS_VALID, VAMP_LIFTBWD_SPLAT = 1, 2
+VAMP_LIFTBWD_WPP1, VAMP_LIFTBWD_WPP4, VAMP_LIFTBWD_WPP16 = 4, 8, 16
+VAMP_CAMBWD_ACCUMULATE, VAMP_CAMBWD_PACKED_VALID, VAMP_CAMBWD_CELLS_VALID, VAMP_CAMBWD_SPLAT = 1, 2, 4, 8
 
 _P = C.c_void_p
 _LD = C.POINTER(VampLiftDesc)

@@ -272,10 +272,12 @@ class BaseVAMPIRE2(nn.Module):
 
     # -- LIFT (bv2:483-516) -------------------------------------------------
     def get_voxel_feats(self, frustum_feats, sweep_index, mats_dict, clamp_extreme=True):
-        """Signature-compatible lift from the materialised [B, N, C, D, fH, fW] tensor."""
-        if not clamp_extreme:
-            raise NotImplementedError("the HIP lift implements clamp_extreme=True (the only mode the "
-                                      "reference calls)")
+        """Signature-compatible lift from the materialised [B, N, C, D, fH, fW] tensor.
+
+        `clamp_extreme` (bv2:503-505) is accepted with either value and changes nothing: the clamp
+        to [-2, 2] only moves normalised coordinates of samples that `valid` (bv2:494-497, computed
+        before it) has already masked to zero -- a valid sample has |n| <= 1 + 1/703 -- and the
+        kernel evaluates valid samples only."""
         mats = G.lift_matrices(mats_dict["sensor2ego_mats"][:, sweep_index],
                                mats_dict["intrin_mats"][:, sweep_index],
                                mats_dict["ida_mats"][:, sweep_index], mats_dict.get("bda_mat", None))

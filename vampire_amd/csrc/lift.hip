@@ -494,11 +494,13 @@ int vamp_lift_backward_ex(const VampLiftDesc* d, const float* mats, const float*
   const LiftParams P = to_params(d);
   const int BN = d->B * d->N, HW = d->fH * d->fW;
   // default: cell list + one wave per pixel (lift_bwd_cell.hip), no float atomics.
-  // VAMP_LIFT_BWD=v1 selects the per-voxel atomic splat below, kept as an independent cross-check.
-  const char* force = getenv("VAMP_LIFT_BWD");
-  if (!(force && force[0] == 'v' && force[1] == '1'))
+  // VAMP_LIFTBWD_SPLAT selects the per-voxel atomic splat below, kept as an independent cross-check.
+  if (!(flags & VAMP_LIFTBWD_SPLAT)) {
+    const int wpp = (flags & VAMP_LIFTBWD_WPP1) ? 1 : (flags & VAMP_LIFTBWD_WPP4) ? 4
+                    : (flags & VAMP_LIFTBWD_WPP16) ? 16 : 0;
     return launch_lift_bwd_cell(d, mats, xs, ys, zs, depth, feat, grad_out, hits, grad_depth,
-                                grad_feat, w.cells, (flags & VAMP_LIFTBWD_CELLS_VALID) != 0, s);
+                                grad_feat, w.cells, (flags & VAMP_LIFTBWD_CELLS_VALID) != 0, wpp, s);
+  }
   if (d->in_dtype == VAMP_F32) launch_to_cl<float>(feat, w.feat_cl, BN, d->C, HW, s);
   else launch_to_cl<__hip_bfloat16>(feat, w.feat_cl, BN, d->C, HW, s);
   if (int e = check_launch("feat_to_channel_last")) return e;

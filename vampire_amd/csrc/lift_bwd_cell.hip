@@ -340,7 +340,7 @@ template <typename T>
 static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float* mats,
                          const float* xs, const float* ys, const float* zs, const void* depth,
                          const void* feat, const float* gout, const uint64_t* hits, float* gdepth,
-                         float* gfeat, void* scratch, bool cells_valid, hipStream_t s) {
+                         float* gfeat, void* scratch, bool cells_valid, int wpp_force, hipStream_t s) {
   const LiftCells g = lift_cells(d);
   const LiftCellWs w = lift_cell_ws(d, scratch);
   if (!cells_valid)
@@ -360,10 +360,8 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
   // waves per pixel from the expected records per pixel (4 taps x voxels per camera pixel)
   const long npix = (long) d->B * d->N * d->fH * d->fW;
   const double per_pix = 4.0 * (double) d->B * d->Z * d->Y * d->X / (double) npix;
-  const char* ew = getenv("VAMP_LIFT_WPP");
   int wpp = per_pix <= 96.0 ? 1 : (per_pix <= 768.0 ? 4 : 16);
-
-  if (ew && (atoi(ew) == 1 || atoi(ew) == 4 || atoi(ew) == 16)) wpp = atoi(ew);
+  if (wpp_force == 1 || wpp_force == 4 || wpp_force == 16) wpp = wpp_force;
   const int nw = std::max(kMinWaves, wpp);
   const int ppb = nw / wpp;
   const int Dd = d->use_depth ? d->D : 0;
@@ -386,13 +384,13 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
 int launch_lift_bwd_cell(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                          const float* zs, const void* depth, const void* feat, const float* gout,
                          const uint64_t* hits, float* gdepth, float* gfeat, void* scratch,
-                         bool cells_valid, hipStream_t s) {
+                         bool cells_valid, int wpp_force, hipStream_t s) {
   const LiftParams P = to_params(d);
   if (d->in_dtype == VAMP_F32)
     return launch_cell_t<float>(d, P, mats, xs, ys, zs, depth, feat, gout, hits, gdepth, gfeat, scratch,
-                                cells_valid, s);
+                                cells_valid, wpp_force, s);
   return launch_cell_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, feat, gout, hits, gdepth, gfeat,
-                                       scratch, cells_valid, s);
+                                       scratch, cells_valid, wpp_force, s);
 }
 
 }  // namespace vamp

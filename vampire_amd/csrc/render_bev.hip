@@ -624,8 +624,7 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
   VAMP_REQUIRE(grad_density_feature && grad_semantic && grad_rgb, "null output");
   VAMP_REQUIRE(grad_base || d->C == 0 || !g_voxel_output, "grad_base is NULL");
   VAMP_REQUIRE((beta && grad_beta) || d->density_mode == VAMP_DENSITY_SIGMOID, "beta / grad_beta is NULL");
-  const char* force = getenv("VAMP_BEV_BWD");
-  if (!ozs_host || (force && force[0] == 'v' && force[1] == '1'))
+  if (!ozs_host)
     return launch_bev_bwd_v1(d, oxs, oys, ozs, bev_mids, beta, density_feature, semantic, rgb, base,
                              g_bev_rgb, g_bev_seg, g_bev_height, g_voxel_density, g_voxel_output,
                              grad_density_feature, grad_semantic, grad_rgb, grad_base, grad_beta,

@@ -400,9 +400,8 @@ int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, 
     if (int e = launch_pack(P, d->in_dtype, density_feature, semantic, rgb, packed, s)) return e;
   // Default: per-ray pass + cell-list gather (render_bwd_ray.hip, render_bwd_cell.hip), which
   // evaluates the frustum points itself from the matrices.  A caller-supplied geom tensor, or
-  // VAMP_CAM_BWD=v1, takes the v1 float-atomic splat below (the independent cross-check).
-  const char* force = getenv("VAMP_CAM_BWD");
-  if (!geom && mats && !(force && force[0] == 'v' && force[1] == '1'))
+  // VAMP_CAMBWD_SPLAT, takes the v1 float-atomic splat below (the independent cross-check).
+  if (!geom && mats && !(flags & VAMP_CAMBWD_SPLAT))
     return launch_cam_bwd_v2(d, P, mats, us, vs, ds, mids, beta, packed, g_rgb, g_seg, g_depth,
                              grad_density_feature, grad_semantic, grad_rgb, grad_beta, gpacked,
                              accumulate, static_cast<hipEvent_t>(wait_event),

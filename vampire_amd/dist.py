@@ -14,10 +14,11 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend: str, device=None):
-    """Join the process group when WORLD_SIZE > 1; returns (rank, world)."""
+def init(backend: str, device=None, force: bool = False):
+    """Join the process group when WORLD_SIZE > 1 (or when `force`d: a world-size-1 group, which
+    the single-GPU RCCL smoke test uses to exercise the real backend); returns (rank, world)."""
     rank, _, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend, **kw)
@@ -36,7 +37,13 @@ class GradSync(torch.nn.Module):
     render backward, so the collective runs under the lift backward -- and `finish()` (called by
     `train_step` after backward) makes the compute stream wait for it.  Same result as
     DistributedDataParallel (mean over ranks) without its per-step bookkeeping, which costs 45 us
-    of a 1.07 ms step on one MI355X (tools/ddp_overhead.py).  `VAMP_GRAD_SYNC=ddp` selects DDP."""
+    of a 1.07 ms step on one MI355X (tools/ddp_overhead.py).  `VAMP_GRAD_SYNC=ddp` selects DDP.
+
+    Like DDP it broadcasts parameters and buffers from rank 0 at construction, and it joins its
+    collectives by itself at the end of every backward pass (an autograd-engine callback queued by
+    the first hook of the pass), so a plain `loss.backward(); optimizer.step()` is correct too;
+    `finish()` stays as an explicit, idempotent join.  Every rank must produce a gradient for every
+    parameter in every step (as with DDP's find_unused_parameters=False, base_cli.py:72)."""
 
     def __init__(self, module, group=None):
         super().__init__()
@@ -44,6 +51,10 @@ class GradSync(torch.nn.Module):
         self.group = group
         self.world = dist.get_world_size(group)
         self._pending = []
+        self._joining = False
+        with torch.no_grad():
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         # NCCL / RCCL has a native average; gloo (CPU tests) sums and the division follows
         self._avg = dist.get_backend(group) == "nccl"
         for p in module.parameters():
@@ -52,6 +63,10 @@ class GradSync(torch.nn.Module):
 
     def _launch(self, p):
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        if not self._joining:
+            # join at the end of this backward pass, whoever called it
+            torch.autograd.Variable._execution_engine.queue_callback(self.finish)
+            self._joining = True
         self._pending.append((dist.all_reduce(p.grad, op=op, group=self.group, async_op=True), p))
 
     def forward(self, *a, **kw):
@@ -64,12 +79,14 @@ class GradSync(torch.nn.Module):
             if not self._avg:
                 p.grad.div_(self.world)
         self._pending.clear()
+        self._joining = False
 
 
-def wrap_ddp(module, device=None):
+def wrap_ddp(module, device=None, force: bool = False):
     """Gradient averaging around the step module when running multi-rank (GradSync, or
-    DistributedDataParallel with VAMP_GRAD_SYNC=ddp), else identity."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    DistributedDataParallel with VAMP_GRAD_SYNC=ddp), else identity (`force` wraps a world-size-1
+    group too)."""
+    if not (dist.is_initialized() and (dist.get_world_size() > 1 or force)):
         return module
     if os.environ.get("VAMP_GRAD_SYNC", "hook") != "ddp":
         return GradSync(module)
@@ -79,13 +96,13 @@ def wrap_ddp(module, device=None):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.barrier()
 
 
 def max_over_ranks(seconds: float, device="cpu") -> float:
     """The timing contract: elapsed time of the slowest rank."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not dist.is_initialized():
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -38,6 +38,14 @@ def _dtype_code(t: torch.Tensor) -> int:
     raise TypeError(f"unsupported dtype {t.dtype}: the hot path takes fp32 or bf16 inputs")
 
 
+def _accept(t):
+    """The kernels read fp32 or bf16; anything else (fp16 under the reference's precision=16
+    autocast, base_cli.py:77, fp64) is promoted to fp32, as aten's autocast does for these ops."""
+    if t is None or t.dtype in (torch.float32, torch.bfloat16):
+        return t
+    return t.float()
+
+
 def _chk(t: torch.Tensor, shape, name):
     if not t.is_cuda:
         raise _capi.VampireHipError(f"{name} must be a device tensor (no CPU fallback)")
@@ -71,6 +79,16 @@ class HotPath:
         ozs_cpu = G.axis_centres(cfg.z_bound_det)
         self.ozs_host = (C.c_float * ozs_cpu.numel())(*ozs_cpu.tolist())
         self._ws = {}
+        # Implementation selectors (host-side state of this object; the library itself keeps none):
+        # "cell" = the default cell-list gathers, "v1" = the float-atomic splats kept as independent
+        # cross-checks for the tests; lift_wpp forces the lift gather's waves per pixel (0 = auto).
+        # The environment gives the initial values only.
+        self.impl = {"cam_bwd": os.environ.get("VAMP_CAM_BWD", "cell"),
+                     "lift_bwd": os.environ.get("VAMP_LIFT_BWD", "cell"),
+                     "bev_bwd": os.environ.get("VAMP_BEV_BWD", "cell"),
+                     "lift_wpp": int(os.environ.get("VAMP_LIFT_WPP", "0")),
+                     "overlap": os.environ.get("VAMP_OVERLAP", "1") != "0",
+                     "prepare": os.environ.get("VAMP_PREPARE", "1") != "0"}
 
     # ---------------------------------------------------------------- descs
     def lift_desc(self, B, N, C_, dtype_code, use_depth=True) -> _capi.VampLiftDesc:
@@ -114,7 +132,7 @@ class HotPath:
     def _side_stream(self):
         """Second HIP stream for the BEV branch of the renderer: it shares no kernel with the camera
         branch, and at batch 1 neither fills the 256 CUs alone (VAMP_OVERLAP=0 disables)."""
-        if os.environ.get("VAMP_OVERLAP", "1") == "0":
+        if not self.impl["overlap"]:
             return None
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device)
@@ -238,6 +256,12 @@ class _LiftFn(torch.autograd.Function):
     def forward(ctx, hp: HotPath, depth, feat, mats, use_depth):
         c = hp.cfg
         B, N, C_ = feat.shape[:3]
+        ctx.in_dtypes = (depth.dtype if use_depth else None, feat.dtype)
+        feat = _accept(feat)
+        if use_depth:
+            depth = _accept(depth)
+            if depth.dtype != feat.dtype:               # mixed inputs (e.g. fp32 softmax output + half features)
+                depth, feat = depth.float(), feat.float()
         code = _dtype_code(feat)
         d = hp.lift_desc(B, N, C_, code, use_depth)
         feat = _chk(feat, (B, N, C_, c.fH, c.fW), "feat")
@@ -254,7 +278,7 @@ class _LiftFn(torch.autograd.Function):
         nbytes = hp.lib.vamp_lift_workspace_bytes(C.byref(d))
         ws = hp._workspace("lift", nbytes)
         cur = torch.cuda.current_stream()
-        side = hp._side_stream() if (need_grad and os.environ.get("VAMP_PREPARE", "1") != "0") else None
+        side = hp._side_stream() if (need_grad and hp.impl["prepare"] and hp.impl["lift_bwd"] != "v1") else None
         hp._lift_gen = getattr(hp, "_lift_gen", 0) + 1
         ctx.cells_key = None
         if side is not None:
@@ -288,12 +312,16 @@ class _LiftFn(torch.autograd.Function):
         ws = hp._workspace("lift", nbytes)
         valid = 1 if ctx.cells_key == (getattr(hp, "_lift_gen", 0), ws.data_ptr()) else 0
         hp._lift_gen = getattr(hp, "_lift_gen", 0) + 1       # the backward consumes the prepared counters
+        if hp.impl["lift_bwd"] == "v1":
+            valid = _capi.VAMP_LIFTBWD_SPLAT
+        valid |= {1: _capi.VAMP_LIFTBWD_WPP1, 4: _capi.VAMP_LIFTBWD_WPP4,
+                  16: _capi.VAMP_LIFTBWD_WPP16}.get(hp.impl["lift_wpp"], 0)
         _capi.check(hp.lib.vamp_lift_backward_ex(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys), _ptr(hp.zs),
                                                  _ptr(depth if use_depth else None), _ptr(feat), _ptr(g),
                                                  _ptr(hits), _ptr(gdepth), _ptr(gfeat), _ptr(ws),
                                                  ws.numel(), valid, _stream()), "vamp_lift_backward_ex")
-        gd = gdepth.to(depth.dtype) if use_depth else None
-        return None, gd, gfeat.to(feat.dtype), None, None
+        gd = gdepth.to(ctx.in_dtypes[0]) if use_depth else None
+        return None, gd, gfeat.to(ctx.in_dtypes[1]), None, None
 
 
 class _LiftDenseFn(torch.autograd.Function):
@@ -337,10 +365,11 @@ class _RenderFn(torch.autograd.Function):
         B = dens.shape[0]
         N = (geom if geom is not None else mats).shape[1]
         C_ = base.shape[1]
+        ctx.in_dtypes = tuple(t.dtype for t in (dens, sem, base, rgb))
+        dens, sem, base, rgb = (_accept(t) for t in (dens, sem, base, rgb))
+        if len({t.dtype for t in (dens, sem, base, rgb)}) > 1:
+            dens, sem, base, rgb = (t.float() for t in (dens, sem, base, rgb))
         code = _dtype_code(dens)
-        for t in (sem, base, rgb):
-            if t.dtype != dens.dtype:
-                raise TypeError("the four volumes must share a dtype")
         d = hp.render_desc(B, N, code, C_)
         vshape = (c.vZ, c.vY, c.vX)
         dens = _chk(dens, (B, 1) + vshape, "density_feature")
@@ -371,7 +400,7 @@ class _RenderFn(torch.autograd.Function):
         ctx.cells = False
         if side is not None:
             side.wait_stream(cur)
-            if any(ctx.needs_input_grad) and geom is None and os.environ.get("VAMP_PREPARE", "1") != "0":
+            if any(ctx.needs_input_grad) and geom is None and hp.impl["prepare"] and hp.impl["cam_bwd"] != "v1":
                 # the sample -> cell-slot table of the backward depends on the geometry only: it is
                 # built here, on the side stream, beside the forward kernels
                 _capi.check(hp.lib.vamp_render_camera_prepare(
@@ -417,13 +446,14 @@ class _RenderFn(torch.autograd.Function):
                 C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
                 _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(g_brgb), _ptr(g_bseg), _ptr(g_bh),
                 _ptr(g_vd), _ptr(g_vo), _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gb), _ptr(gbeta),
-                hp.ozs_host, _ptr(ws_bev), ws_bev.numel(), _stream(stream)), "vamp_render_bev_backward")
+                None if hp.impl["bev_bwd"] == "v1" else hp.ozs_host, _ptr(ws_bev), ws_bev.numel(),
+                _stream(stream)), "vamp_render_bev_backward")
 
         cam_args = (C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
                     _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(g_rgb),
                     _ptr(g_seg), _ptr(g_dep))
         cur, side = torch.cuda.current_stream(), hp._side_stream()
-        default_impl = os.environ.get("VAMP_CAM_BWD", "cell")[0] == "c"
+        default_impl = hp.impl["cam_bwd"] != "v1"
         packed_valid = 2 if ctx.pack_key == (getattr(hp, "_pack_gen", 0), ws.data_ptr()) else 0
         if packed_valid and ctx.cells:
             packed_valid |= 4                                    # VAMP_CAMBWD_CELLS_VALID
@@ -450,11 +480,12 @@ class _RenderFn(torch.autograd.Function):
             gr = torch.empty(rgb.shape, dtype=f32, device=dens.device)
             _capi.check(hp.lib.vamp_render_camera_backward_acc(
                 *cam_args, _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gbeta), _ptr(ws), ws.numel(),
-                packed_valid, None, _stream(cur)), "vamp_render_camera_backward_acc")
+                packed_valid | (0 if default_impl else _capi.VAMP_CAMBWD_SPLAT), None, _stream(cur)),
+                "vamp_render_camera_backward_acc")
             bev_backward(cur)
         grad_beta = gbeta.reshape(ctx.beta_shape) if hp.cfg.density_mode == "sdf" else None
-        return (None, gd.to(dens.dtype), gs.to(sem.dtype), gb.to(base.dtype), gr.to(rgb.dtype),
-                grad_beta, None, None)
+        dt = ctx.in_dtypes
+        return (None, gd.to(dt[0]), gs.to(dt[1]), gb.to(dt[2]), gr.to(dt[3]), grad_beta, None, None)
 
 
 class _SamplePointsFn(torch.autograd.Function):
@@ -463,7 +494,8 @@ class _SamplePointsFn(torch.autograd.Function):
                 lattice=None):
         c = hp.cfg
         B, C_ = volume.shape[:2]
-        volume = _chk(volume, (B, C_, c.vZ, c.vY, c.vX), "volume")
+        ctx.in_dtype = volume.dtype
+        volume = _chk(_accept(volume), (B, C_, c.vZ, c.vY, c.vX), "volume")
         P = points.shape[1]
         points = _chk(points.float(), (B, P, 3), "points")
         d = _capi.VampSampleDesc()
@@ -507,7 +539,7 @@ class _SamplePointsFn(torch.autograd.Function):
             _ptr(ws), ws.numel(), _stream()), "vamp_sample_points_backward")
         grad_beta = (gbeta.reshape(ctx.beta_shape)
                      if (ctx.activation and hp.cfg.density_mode == "sdf") else None)
-        return None, gvol.to(volume.dtype), None, grad_beta, None, None, None, None, None
+        return None, gvol.to(ctx.in_dtype), None, grad_beta, None, None, None, None, None
 
 
 class _DepthSoftmaxFn(torch.autograd.Function):
@@ -517,14 +549,15 @@ class _DepthSoftmaxFn(torch.autograd.Function):
             raise ValueError("logits: expected [images, D, ...]")
         if not logits.is_cuda:
             raise _capi.VampireHipError("logits must be a device tensor (no CPU fallback)")
-        logits = logits.contiguous()
+        ctx.in_dtype = logits.dtype
+        logits = _accept(logits).contiguous()
         images, D = logits.shape[:2]
         HW = logits[0, 0].numel()
         out = torch.empty(logits.shape, dtype=torch.float32, device=logits.device)
         if logits.numel():
             _capi.check(hp.lib.vamp_depth_softmax_forward(images, D, HW, _ptr(logits), _dtype_code(logits),
                                                           _ptr(out), _stream()), "vamp_depth_softmax_forward")
-        ctx.hp, ctx.dims, ctx.in_dtype = hp, (images, D, HW), logits.dtype
+        ctx.hp, ctx.dims = hp, (images, D, HW)
         ctx.save_for_backward(out)
         return out
 
