@@ -2,17 +2,17 @@
 // volume_rendering_from_multiple_views, base_vampire2.py:391-467.
 //
 //  pack_volume         [B,c,Z,Y,X] x3  ->  channel-last [B,Z,Y,X,CP] (density, sem, rgb)
-//  render_cam_fwd_plan  (geometry from the matrices) a wave = the 64 rays of an 8 x 8 tile x one
-//                      depth range; a per-tile plan (ray_plan.hpp) finds the depth indices whose
-//                      corner box misses the volume -- they are composited without evaluating the
-//                      frustum chain -- and deals the others evenly to the tile's four waves;
-//                      each inside sample is one 8-tap gather of CP contiguous floats
+//  render_cam_fwd_brick  (geometry from the matrices) a wave = the 64 rays of an 8 x 8 tile x one
+//                      depth chunk; the taps of a depth index come from a voxel brick staged in
+//                      LDS by LDS-DMA (brick.hpp), the next brick is in flight while the current
+//                      one is composited; depth indices whose corner box misses the volume are
+//                      composited without evaluating the frustum chain
 //  render_cam_fwd      (caller-supplied geom tensor) every lane gathers its own 8 taps of CP
 //                      contiguous floats from global memory
 //  (the BEV branch lives in render_bev.hip)
 // HBM/L2-bound gathers and a short scan: no MFMA.
 #include "render_common.hpp"
-#include "ray_plan.hpp"
+#include "brick.hpp"
 
 namespace vamp {
 
@@ -168,19 +168,33 @@ render_cam_fwd_kernel(RenderParams P, const float* __restrict__ geom, const floa
 
 
 // ---------------------------------------------------------------------------
-// camera branch forward with a per-tile plan (geometry evaluated from the matrices)
+// camera branch forward, LDS bricks (geometry evaluated from the matrices)
 // ---------------------------------------------------------------------------
-template <int CP4>
+#ifdef VAMP_STAMP
+// diagnostic build only (tools/ablate.sh): cycle sums per phase of the march, all waves
+__device__ unsigned long long g_stamp[16];
+#define STAMP(t) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); } while (0)
+#define STAMP_ADD(k, a, b) do { st[k] += (b) - (a); } while (0)
+#else
+#define STAMP(t) do { } while (0)
+#define STAMP_ADD(k, a, b) do { } while (0)
+#endif
+template <int CP4, int CAP>
 __global__ void __launch_bounds__(256, 3)
-render_cam_fwd_plan_kernel(RenderParams P, const float* __restrict__ mats, const float* __restrict__ us,
-                           const float* __restrict__ vs, const float* __restrict__ ds,
-                           const float* __restrict__ mids, const float* __restrict__ beta_raw,
-                           const float* __restrict__ packed, float* __restrict__ rgb_out,
-                           float* __restrict__ seg_out, float* __restrict__ depth_out) {
+render_cam_fwd_brick_kernel(RenderParams P, const float* __restrict__ mats, const float* __restrict__ us,
+                            const float* __restrict__ vs, const float* __restrict__ ds,
+                            const float* __restrict__ mids, const float* __restrict__ beta_raw,
+                            const float* __restrict__ packed, float* __restrict__ rgb_out,
+                            float* __restrict__ seg_out, float* __restrict__ depth_out) {
   constexpr int CP = CP4 * 4;
-  __shared__ float xmerge[4 * (CP + 2) * 64];
+  constexpr int kBrick4 = CAP * BrickLayout<CP4>::RS4;            // float4 per wave
+  constexpr int kMerge4 = (CP + 2) * 64;                           // 4 * (CP + 2) * 64 floats
+  __shared__ float4 smem[(4 * kBrick4 > kMerge4) ? 4 * kBrick4 : kMerge4];
   __shared__ int4 plan[kPlanMax];
-  const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave = depth range
+  static_assert(CAP >= 0, "CAP == 0: every lane gathers its own taps from global memory");
+  float* xmerge = reinterpret_cast<float*>(smem);                  // aliases the bricks after the march
+  const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave = depth chunk
+  float4* brick = smem + sub * kBrick4;
   const int lane = threadIdx.x & 63;
   const RayId id = decode_ray_wps(P);
   const bool live = id.live;
@@ -195,13 +209,22 @@ render_cam_fwd_plan_kernel(RenderParams P, const float* __restrict__ mats, const
   const long V = (long) P.Z * P.Y * P.X;
   const float* vol = packed + (long) b * V * CP;
 
-  // which depth indices of the tile can hold inside samples; then this wave's share of the march
+#ifdef VAMP_STAMP
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long cnt[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, tb = 0, te = 0;
+#endif
+  STAMP(tb);
+  // which depth indices of the tile can hold inside samples, and their boxes; then this wave's
+  // share of the march
   plan_tile(P, m, us, vs, ds, __builtin_amdgcn_readlane(w, 0), __builtin_amdgcn_readlane(w, 63),
             __builtin_amdgcn_readlane(h, 0), __builtin_amdgcn_readlane(h, 63), sub, plan);
   __syncthreads();
   const PlanMask mk = plan_mask(plan);
   int i0, i1;
   plan_share(mk, S, sub, i0, i1);
+  STAMP(te);
+  STAMP_ADD(0, tb, te);                                            // plan
 
   auto point = [&](int i, float& x, float& y, float& z) {
     frustum_point(m, u, v, ds[i], x, y, z);
@@ -227,7 +250,12 @@ render_cam_fwd_plan_kernel(RenderParams P, const float* __restrict__ mats, const
     const float sigma_out = density_fwd(dp, 0.f);                  // masked sample -> density(0) (Q6)
     bool have_p = true;                                            // (px, py, pz) is the point of index i0
     int jn = mask_next(mk, i0);
+#ifndef VAMP_ABL_NOPREFETCH
+    if constexpr (CAP > 0)
+      if (jn < i1) brick_prefetch<CP4, CAP>(P, vol, plan_box(plan, jn), brick);
+#endif
     for (int i = i0; i < i1; ++i) {
+      STAMP(t0);
       if (i != jn) {
         // all 64 samples of this depth index lie outside the volume: s = 0
         const float tau = sigma_out * (dl_unit * (ds[i + 1] - ds[i]));
@@ -236,17 +264,62 @@ render_cam_fwd_plan_kernel(RenderParams P, const float* __restrict__ mats, const
         acc[0] += wgt;
         acc_depth = __builtin_fmaf(wgt, mids[i], acc_depth);
         have_p = false;
+        STAMP(t1);
+        STAMP_ADD(1, t0, t1);                                        // skipped index
         continue;
       }
-      jn = mask_next(mk, i + 1);
+#ifdef VAMP_ABL_ONLYDMA
+      VolTap tp;
+      tp.inside = true; tp.ix0 = lane & 1; tp.iy0 = 0; tp.iz0 = 0; tp.wx0 = tp.wx1 = tp.wy0 = tp.wy1 = tp.wz0 = tp.wz1 = 0.5f;
+      tp.fx = tp.fy = tp.fz = 0.f;
+      {
+        const BrickBox b0 = plan_box(plan, i);
+        tp.ix0 = b0.lo[0]; tp.iy0 = b0.lo[1]; tp.iz0 = b0.lo[2];
+      }
+      qx = px; qy = py; qz = pz;
+#else
       if (!have_p) point(i, px, py, pz);
       point(i + 1, qx, qy, qz);
       const VolTap tp = volume_tap(P, px, py, pz);
+#endif
       float s[CP];
 #pragma unroll
       for (int c = 0; c < CP; ++c) s[c] = 0.f;
+      STAMP(t1);
+      STAMP_ADD(2, t0, t1);                                          // points + taps
+      if constexpr (CAP == 0) {
+        if (tp.inside) gather_taps<CP4>(P, vol, tp, s);
+      } else
+      if (__ballot(tp.inside) != 0ull)
+#ifdef VAMP_ABL_NOPREFETCH
+        brick_gather<CP4, CAP>(P, vol, tp, tp.inside, plan_box(plan, i), false, brick, s
+#else
+        brick_gather<CP4, CAP>(P, vol, tp, tp.inside, plan_box(plan, i), true, brick, s
+#endif
+#ifdef VAMP_STAMP
+                               , cnt
+#endif
+                               );
+      STAMP(t2);
+      STAMP_ADD(3, t1, t2);                                          // brick wait + gather
+      // the next brick travels while this sample is composited
+      jn = mask_next(mk, i + 1);
+#ifdef VAMP_ABL_NOPREFETCH
+      if (false) {
+#else
+      if (CAP > 0 && jn < i1) {
+#endif
+        wait_vmem();
+        wait_lds();
+        brick_prefetch<CP4, CAP>(P, vol, plan_box(plan, jn), brick);
+      }
+      STAMP(t3);
+      STAMP_ADD(4, t2, t3);                                          // prefetch issue
+#ifdef VAMP_ABL_ONLYDMA
+      acc[0] += s[0] + s[5];
+      continue;
+#endif
       if (tp.inside) {
-        gather_taps<CP4>(P, vol, tp, s);
         // nan_to_num of the sampled features (bv2:421) only where something is not finite:
         // sum_c 0 * s_c is nan exactly then (two chains, so that they pack)
         float chk0 = 0.f, chk1 = 0.f;
@@ -272,19 +345,32 @@ render_cam_fwd_plan_kernel(RenderParams P, const float* __restrict__ mats, const
       for (int c = 1; c < CP; ++c) acc[c] = __builtin_fmaf(wgt, s[c], acc[c]);
       px = qx; py = qy; pz = qz;
       have_p = true;
+      STAMP(t4);
+      STAMP_ADD(5, t3, t4);                                          // composite
     }
   }
+  wait_vmem();
+#ifdef VAMP_STAMP
+  STAMP(t4);
+  st[6] = t4 - tb;                                                 // whole wave up to the merge
+  if (lane == 0) {
+    for (int k = 0; k < 7; ++k) atomicAdd(&g_stamp[k], st[k]);
+    atomicAdd(&g_stamp[7], 1ull);
+    for (int k = 0; k < 6; ++k) atomicAdd(&g_stamp[8 + k], cnt[k]);
+  }
+#endif
 
-  // merge the four depth ranges (= waves) of each ray through LDS
-  float* xc = xmerge;                                // [4][64] optical depth of each range
+  // merge the four depth chunks (= waves) of each ray through LDS
+  float* xc = xmerge;                                // [4][64] optical depth of each chunk
   float* xa = xmerge + 4 * 64;                       // [4][CP + 1][64] scaled partial sums
+  __syncthreads();                                   // every wave is done with its brick
   xc[sub * 64 + lane] = cum;
   __syncthreads();
   float excl = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k)
     if (k < sub) excl += xc[k * 64 + lane];
-  const float scale = __expf(-excl);                 // transmittance in front of this range
+  const float scale = expf(-excl);                   // transmittance in front of this chunk
   xa[(sub * (CP + 1) + CP) * 64 + lane] = acc_depth * scale;
 #pragma unroll
   for (int c = 0; c < CP; ++c) xa[(sub * (CP + 1) + c) * 64 + lane] = acc[c] * scale;
@@ -392,6 +478,24 @@ size_t packed_bytes(const VampRenderDesc* d) {
 
 extern "C" {
 
+#ifdef VAMP_DUMP_BOXES
+int vamp_debug_boxes(int* out, unsigned* n, int reset) {
+  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(vamp::g_nbox), sizeof(unsigned)) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vamp::g_boxes), 65536 * 8 * sizeof(int)) != hipSuccess) return -1;
+  if (reset) { unsigned z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(vamp::g_nbox), &z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
+#ifdef VAMP_STAMP
+int vamp_debug_stamps(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(vamp::g_stamp), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(vamp::g_stamp), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 size_t vamp_render_workspace_bytes(const VampRenderDesc* d) {
   if (!d) return 0;
@@ -420,14 +524,19 @@ int vamp_render_camera_forward(const VampRenderDesc* d, const float* geom, const
   if (int e = launch_pack(P, d->in_dtype, density_feature, semantic, rgb, packed, s)) return e;
   constexpr int LPR = 4;
   const unsigned grid = ray_grid<LPR>(P);
-  // geometry from the matrices and at most kPlanMax samples per ray: the planned march
-  if (!geom && d->D - 1 <= kPlanMax) {
-#define VAMP_CAMP(CP4)                                                                     \
-  VAMP_TIMED(kProfCamFwd, s, (render_cam_fwd_plan_kernel<CP4><<<grid, 256, 0, s>>>(         \
+  // geometry from the matrices and at most 4 x 32 samples per ray: LDS bricks.  Brick capacity per
+  // wave: 96 rows of 112 B (CP = 24) = 10.5 KB, 43 KB per workgroup -> three workgroups per CU.
+  if (!geom && d->D - 1 <= 128 && (size_t) d->Z * d->Y * d->X * (P.CP / 4) < 0x7fffffffu) {
+#define VAMP_CAMB(CP4, CAP)                                                                   \
+  VAMP_TIMED(kProfCamFwd, s, (render_cam_fwd_brick_kernel<CP4, CAP><<<grid, 256, 0, s>>>(     \
       P, mats, us, vs, ds, mids, beta, packed, rgb_out, seg_out, depth_out)))
-    if (P.CP == 12) VAMP_CAMP(3); else if (P.CP == 24) VAMP_CAMP(6); else VAMP_CAMP(8);
-#undef VAMP_CAMP
-    return check_launch("render_cam_fwd_plan_kernel");
+#ifdef VAMP_CAM_DIRECT
+    if (P.CP == 12) VAMP_CAMB(3, 0); else if (P.CP == 24) VAMP_CAMB(6, 0); else VAMP_CAMB(8, 0);
+#else
+    if (P.CP == 12) VAMP_CAMB(3, 128); else if (P.CP == 24) VAMP_CAMB(6, 96); else VAMP_CAMB(8, 64);
+#endif
+#undef VAMP_CAMB
+    return check_launch("render_cam_fwd_brick_kernel");
   }
 #define VAMP_CAM(CP4)                                                                        \
   VAMP_TIMED(kProfCamFwd, s, (render_cam_fwd_kernel<LPR, CP4, true><<<grid, 256, 0, s>>>(    \
