@@ -14,7 +14,9 @@ path's one parameter gradient (density beta) over RCCL.
 Extra objects in the JSON line:
   roofline      dominant kernel of the step: algorithmic bytes per launch / HIP-event
                 duration, against the 8 TB/s HBM peak (in-library event timer)
-  fwd_roofline  the same for the whole fused forward (north_star's 70 % target)
+  fwd_roofline  the fused forward (north_star's 70 % target) timed as ONE unit: a HIP-event pair
+                around lift + render, 20 warm-up + 100 timed iterations, median
+  extra_configs cfg-A, cfg-B batch 8 and cfg-D bf16 measured in the same run (N = 1 only)
   cpu_baseline  the oracle (torch-CPU port of the reference's op sequence) timed on this
                 box's host cores on a bounded sample; a reported baseline, not a target
 """
@@ -73,8 +75,8 @@ STAGES = {   # SURVEY.md section 8(d) stage names -> kernels of this build
 
 
 def measured_traffic(cfg_name, kernel, batch):
-    """HBM bytes per launch from a committed rocprofv3 PMC run (profiles/traffic_*.json, made
-    by tools/collect_traffic.py on the GPU box), or None when no run matches."""
+    """HBM bytes per launch from a committed rocprofv3 PMC run (profiles/traffic_*.json, made on
+    the GPU box by tools/collect_profiles.sh + tools/summarize_profiles.py), or None when no run matches."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")), reverse=True):
         try:
@@ -87,9 +89,8 @@ def measured_traffic(cfg_name, kernel, batch):
     return None
 
 
-def cpu_baseline(cfg, budget_s=30.0):
-    """Oracle fwd+bwd on the host cores, bounded sample: one 6-camera sample of the same
-    workload (more only if a sample takes < budget/4)."""
+def _cpu_run(cfg, backward):
+    """One oracle pass (forward, or forward + backward) of one 6-camera sample on the host."""
     from oracle import aten_oracle as O
     from vampire_amd.geometry import PathGeometry
     from vampire_amd import synthetic
@@ -98,23 +99,84 @@ def cpu_baseline(cfg, budget_s=30.0):
     bda = synthetic.bda_matrix(1)
     depth, feat = synthetic.lift_inputs(cfg, 1)
     vols = list(synthetic.render_inputs(cfg, 1))
-    beta = torch.tensor(0.1, requires_grad=True)
-    depth.requires_grad_(True); feat.requires_grad_(True)
-    for v in vols:
-        v.requires_grad_(True)
-    n, t0 = 0, time.perf_counter()
-    while True:
+    beta = torch.tensor(0.1, requires_grad=backward)
+    if backward:
+        depth.requires_grad_(True); feat.requires_grad_(True)
+        for v in vols:
+            v.requires_grad_(True)
+    t0 = time.perf_counter()
+    with torch.set_grad_enabled(backward):
         vox, outs = O.lift_render_forward(cfg, geo, depth, feat, vols, (s2e, K, ida, bda), beta)
-        loss = vox.sum() * 1e-3 + sum(o.sum() for o in outs) * 1e-3
-        loss.backward()
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s / 4 or n >= 4:
-            break
-    return {"value": n / el, "unit": "samples/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"{n} sample(s) of the same workload, oracle/aten_oracle.py fwd+bwd, "
-                      f"{el:.1f} s on {os.cpu_count()} logical CPUs"}
+        if backward:
+            loss = vox.sum() * 1e-3 + sum(o.sum() for o in outs) * 1e-3
+            loss.backward()
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(cfg, cfg_name):
+    """The oracle (torch-CPU restatement of the reference's op sequence) on the host cores, bounded
+    sample: one 6-camera sample of the bench workload per run, median of 3 runs for
+    forward + backward (the metric) and for the forward alone; one run each of the reference's
+    default configuration (cfg-A) beside it."""
+    from vampire_amd.config import CFG_A
+    import statistics
+    fb = [_cpu_run(cfg, True) for _ in range(3)]
+    fw = [_cpu_run(cfg, False) for _ in range(3)]
+    med_fb, med_fw = statistics.median(fb), statistics.median(fw)
+    out = {"value": 1.0 / med_fb, "unit": "samples/s", "cores": torch.get_num_threads(),
+           "kind": "port",
+           "sample": f"1 sample of the bench workload (cfg-{cfg_name}) per run, oracle/aten_oracle.py; fwd+bwd median of 3 = "
+                     f"{med_fb:.2f} s, fwd alone median of 3 = {med_fw:.2f} s; {torch.get_num_threads()} torch threads on "
+                     f"{os.cpu_count()} logical CPUs",
+           "fwd_samples_per_s": 1.0 / med_fw, "runs_s": {"fwd_bwd": [round(t, 3) for t in fb], "fwd": [round(t, 3) for t in fw]}}
+    if cfg_name != "A":
+        out["cfg_A"] = {"fwd_bwd_s": round(_cpu_run(CFG_A, True), 3), "fwd_s": round(_cpu_run(CFG_A, False), 3)}
+    return out
+
+
+def forward_pair_us(model, batch, iters=100, warm=20):
+    """the fused forward timed as ONE unit -- lift kernels then render kernels on
+    pre-generated volumes, one HIP-event pair around the pair per iteration (recorded on the stream
+    the kernels are launched on; the side stream's work is joined before the second event), >= 20
+    warm-up + >= 100 timed iterations, median."""
+    with torch.no_grad():
+        def fwd():
+            model(batch.depth, batch.feat, batch.vols, batch.lift_mats, batch.render_mats)
+        for _ in range(warm):
+            fwd()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(iters):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fwd(); b.record()
+            b.synchronize()
+            ts.append(a.elapsed_time(b) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2], ts[len(ts) // 10], ts[(9 * len(ts)) // 10]
+
+
+def extra_config(cfg_name, batch, dtype, steps=10, warm=3):
+    """A secondary configuration, measured the same way as the headline (fwd+bwd step time with a
+    barrier-free single-rank loop) plus its forward pair: driver-observed rather than README prose."""
+    from vampire_amd.config import PRESETS
+    from vampire_amd.step import LiftRenderStep, SyntheticBatch, train_step
+    cfg = PRESETS[cfg_name]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    model = LiftRenderStep(cfg, dev)
+    data = SyntheticBatch(cfg, batch, dev, seed=1, dtype=dtype)
+    for _ in range(warm):
+        model.zero_grad(set_to_none=True); train_step(model, data)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model.zero_grad(set_to_none=True); train_step(model, data)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    fwd_us, _, _ = forward_pair_us(model, data, iters=30, warm=5)
+    ab = cfg.algorithmic_bytes(4 if dtype == torch.float32 else 2)
+    return {"workload": f"cfg-{cfg_name}, {batch} sample(s)/GPU/step, {'f32' if dtype == torch.float32 else 'bf16'} inputs",
+            "samples_per_s": batch / (ms * 1e-3), "ms_per_step": ms, "fwd_us": fwd_us,
+            "fwd_frac_of_hbm_peak": ab["fwd"] * batch / (fwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
 
 def main():
@@ -126,6 +188,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="samples per GPU per step")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations (extra_configs)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -197,6 +260,7 @@ def main():
     _capi.profile_enable(False)
     _capi.profile_select(None)
     elapsed = vdist.max_over_ranks(elapsed, dev)
+    fwd_med, fwd_p10, fwd_p90 = forward_pair_us(model, batch) if rank == 0 else (0.0, 0.0, 0.0)
 
     prof = dict(warm)
     # the dominant kernel: measured over the timed region
@@ -216,7 +280,8 @@ def main():
             stages[st] = {"us": round(us, 1), "algorithmic_bytes": sb[st] * a.batch,
                           "frac_of_hbm_peak": round(sb[st] * a.batch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                           if us > 0 else None}
-        fwd_us = stages["lift_fwd"]["us"] + stages["render_fwd"]["us"]
+        fwd_kernel_sum_us = stages["lift_fwd"]["us"] + stages["render_fwd"]["us"]
+        fwd_us = fwd_med                                 # the pair timed as one unit (forward_pair_us)
         fwd_bytes = sb["fwd"] * a.batch
         fwd_gbs = fwd_bytes / (fwd_us * 1e-6) / 1e9
         line = {
@@ -233,6 +298,7 @@ def main():
                                    f"{a.batch} sample(s)/GPU/step, lift+render fwd+bwd",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"dp{world}"},
+            "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": dom_gbs / HBM_PEAK_GBS,
                          "traffic": measured_traffic(a.cfg, dom, a.batch),
@@ -240,13 +306,19 @@ def main():
                          "avg_launch_us": kern[dom]["avg_us"]},
             "fwd_roofline": {"bound": "hbm", "achieved": fwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": fwd_gbs / HBM_PEAK_GBS, "fused_fwd_us": fwd_us,
-                             "algorithmic_bytes": fwd_bytes},
+                             "p10_us": fwd_p10, "p90_us": fwd_p90, "iters": 100, "warmup": 20,
+                             "timing": "one HIP-event pair around lift + render per iteration, median",
+                             "kernel_sum_us": fwd_kernel_sum_us, "algorithmic_bytes": fwd_bytes},
             "stages": stages,
             "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in sorted(kern.items())},
             "kernels_us_per_step": {k: round(v["us_per_step"], 2) for k, v in sorted(kern.items())},
         }
+        if world == 1 and not a.no_extra:
+            # secondary configurations of BASELINE.json / SURVEY 8(d), measured in this same run
+            line["extra_configs"] = [extra_config("A", 1, torch.float32), extra_config("B", 8, torch.float32),
+                                     extra_config("D", 1, torch.bfloat16)]
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg)
+            line["cpu_baseline"] = cpu_baseline(cfg, a.cfg)
         print(json.dumps(line), flush=True)
     vdist.shutdown()
 

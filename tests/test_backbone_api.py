@@ -92,3 +92,42 @@ def test_get_pixel_matches_oracle():
     got = m.get_pixel(s2e, K, ida, bda)
     want = O.ego_to_pixel(PathGeometry(c).voxel_coords, s2e, K, ida, bda)
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-4)
+
+
+# --------------------------------------------------------------------------- the three sibling backbones
+# numbers below were read off the reference classes themselves (src/layers/backbones/base_lss_impaintor.py:79,
+# base_lss.py:16, base_bilinear.py:80) constructed with KW in the build container
+SIBLINGS = {
+    "BaseLSSImpaintor": dict(params=791511, cat_pos=True, cat_seg=True, occ="norm_occ_coords", unet=True, depth=True),
+    "BaseLSS": dict(params=515047, cat_pos=True, cat_seg=True, occ="norm_occ_coords", unet=False, depth=True),
+    "BaseBiLinear": dict(params=109991, cat_pos=False, cat_seg=False, occ="norm_occ_coords", unet=False, depth=False),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SIBLINGS))
+def test_sibling_backbones_keep_the_reference_interface(name):
+    import vampire_amd.backbone as BB
+    want = SIBLINGS[name]
+    cls = getattr(BB, name)
+    kw = {k: v for k, v in KW.items() if k not in ("cat_pos", "cat_seg")}       # class defaults apply
+    assert list(inspect.signature(cls.__init__).parameters)[1:] == \
+        list(inspect.signature(BaseVAMPIRE2.__init__).parameters)[1:]
+    m = cls(**kw)
+    assert (m.cat_pos, m.cat_seg) == (want["cat_pos"], want["cat_seg"])
+    bufs = dict(m.named_buffers(recurse=False))
+    assert want["occ"] in bufs and "occ_coords" not in bufs
+    assert tuple(bufs["norm_occ_coords"].shape) == (200, 200, 16, 3)
+    # (c - lo) / span * 2 - 1 of the first Occ3D voxel centre (-39.8, -39.8, -0.8) by the seg bounds
+    assert bufs["norm_occ_coords"][0, 0, 0].tolist() == pytest.approx(
+        [(-39.8 + 51.2) / 102.4 * 2 - 1, (-39.8 + 51.2) / 102.4 * 2 - 1, (-0.8 + 5.0) / 8.0 * 2 - 1], abs=1e-6)
+    assert ("norm_voxel_coords" in bufs) == want["cat_pos"]
+    n = sum(p.numel() for k, p in m.named_parameters() if not k.startswith(("img_backbone", "img_neck")))
+    assert n == want["params"]
+    keys = set(m.state_dict())
+    assert ("base_conv.hg1.conv1.0.weight" in keys) == want["unet"]
+    assert ("base_conv.0.bias" in keys) == (not want["unet"])
+    assert ("mapping_along_depth.0.weight" in keys) == want["depth"]
+    assert ("feature_conv.weight" in keys) == (not want["depth"])
+    sig = lambda f: list(inspect.signature(f).parameters)
+    assert sig(m.get_voxel_feats) == ["frustum_feats", "sweep_index", "mats_dict", "clamp_extreme"]
+    assert sig(m.forward) == ["sweep_imgs", "mats_dict", "inrange_pts", "timestamps"]

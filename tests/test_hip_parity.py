@@ -1109,3 +1109,73 @@ def test_backbone_under_autocast(dev, amp_dtype):
         assert out[i].dtype == torch.float32, i
         assert bool(torch.isfinite(out[i]).all()), i
         assert abs(float(out[i].mean()) - float(ref[i].mean())) <= 0.1 * float(ref[i].abs().mean()) + 0.05, i
+
+
+@pytest.mark.parametrize("name", ["BaseLSSImpaintor", "BaseLSS", "BaseBiLinear"])
+def test_sibling_backbones_forward(dev, name):
+    """The drop-in mirrors of the other three backbones (base_lss_impaintor.py:79, base_lss.py:16,
+    base_bilinear.py:80) end to end on the GPU against the same module with lift / render / point
+    queries swapped for the oracle on the CPU: static occupancy grid (no bda rotation), Conv3d +
+    Softplus base, and for BaseBiLinear the D = 1 lift and feature_conv."""
+    import copy
+    from oracle import aten_oracle as O
+    import vampire_amd.backbone as BB
+    c = CFG_TINY
+    cls = getattr(BB, name)
+    kw = dict(x_bound_seg=list(c.x_bound_seg), y_bound_seg=list(c.y_bound_seg), z_bound_seg=list(c.z_bound_seg),
+              x_bound_det=list(c.x_bound_det), y_bound_det=list(c.y_bound_det), z_bound_det=list(c.z_bound_det),
+              d_bound=list(c.d_bound), final_dim=c.final_dim, downsample_factor=4, upsample_factor=4,
+              mid_channels=4, output_channels=8, img_backbone_conf=dict(), img_neck_conf=dict(out_channels=[8] * 4),
+              num_classes=5, density_mode="sdf", sdf_bias=-1.0)
+    torch.manual_seed(1)
+    ref = cls(**kw).eval()
+    with torch.no_grad():
+        ref.density_conv.bias.fill_(-1.0)
+    mod = copy.deepcopy(ref).to(dev)
+    B = 2
+    s2e, K, ida = synthetic.camera_rig(c, B, src_hw=(64, 176), focal=60.0, centre=(88.0, 34.0), jitter=2.0, seed=4)
+    s2e[:, :, :3, 3] *= 0.3
+    bda = synthetic.bda_matrix(B, rot_deg=8.0)
+    mats = dict(sensor2ego_mats=s2e[:, None], intrin_mats=K[:, None], ida_mats=ida[:, None],
+                sensor2sensor_mats=torch.eye(4).expand(B, 1, 6, 4, 4), bda_mat=bda)
+    imgs = torch.randn(B, 1, 6, 3, *c.final_dim)
+    out = mod(imgs.to(dev), {k: v.to(dev) for k, v in mats.items()})
+    assert len(out) == 12
+    with torch.no_grad():
+        m = ref
+        feats = m.get_cam_feats(imgs)
+        src = feats[:, 0].reshape(B * 6, -1, feats.shape[-2], feats.shape[-1])
+        feat = m.channel_lower(src).reshape(B, 6, -1, *src.shape[-2:])
+        if m._USE_DEPTH:
+            depth = m.mapping_along_depth(src).softmax(dim=1).reshape(B, 6, -1, *src.shape[-2:])
+            vox = O.lift(depth, feat, m.voxel_coords, s2e, K, ida, bda, c.final_dim, c.d_bound)
+        else:
+            pix = O.ego_to_pixel(m.voxel_coords, s2e, K, ida, bda)
+            vox = O.lift_from_frustum_feats(feat.unsqueeze(3), pix, c.final_dim, c.d_bound, use_depth=False)
+        if m.cat_pos:
+            vox = torch.cat([vox, m.norm_voxel_coords.permute(3, 0, 1, 2)[None].repeat(B, 1, 1, 1, 1)], 1)
+        base = m.base_conv(vox)
+        dens, sem = m.density_conv(base), m.seg_conv(base)
+        if not m._USE_DEPTH:
+            base = m.feature_conv(base)
+        rgb = m.rgb_conv(base)
+        geom = torch.nan_to_num(O.frustum_to_ego(m.frustum, s2e, K, ida, bda), -1e3)
+        r = O.render(geom, dens, sem, base, rgb, seg_bounds=(c.x_bound_seg, c.y_bound_seg, c.z_bound_seg),
+                     output_coords=m.output_coords, camera_mids=m.camera_mids, bev_mids=m.bev_mids,
+                     d_far=c.d_bound[1], z_step_det=c.z_bound_det[2], num_classes=5, density_mode="sdf",
+                     beta_param=m.density.beta, sdf_bias=-1.0, cat_seg=m.cat_seg)
+        up = lambda t: m.upsample2d(t.reshape(B * 6, -1, m.fH, m.fW)).reshape(B, 6, -1, m.fH * 4, m.fW * 4)
+        close(out[1], up(r[0]), atol=2e-4, what=name + " rgb_preds")
+        close(out[2], up(r[1]), atol=2e-4, what=name + " seg_logits_preds")
+        close(out[3], up(r[2]), atol=5e-4, what=name + " depth_preds")
+        for i, j in ((4, 3), (5, 4), (6, 5), (7, 6)):
+            close(out[i], r[j], atol=2e-4, what=f"{name} output {i}")
+        bev_feat = m.voxel_output((r[7] * r[6].tanh()).reshape(B, -1, *r[7].shape[-2:]))
+        close(out[0], bev_feat, atol=5e-4, what=name + " bev feature")
+        # static occupancy grid: F.grid_sample on the module's own norm_occ_coords buffer
+        import torch.nn.functional as F
+        g = m.norm_occ_coords[None].expand(B, *m.norm_occ_coords.shape)
+        close(out[10], F.grid_sample(sem, g, padding_mode="border", align_corners=True).permute(0, 2, 3, 4, 1),
+              atol=2e-4, what=name + " occ_logits")
+        close(out[11], F.grid_sample(m.density(dens), g, align_corners=True).permute(0, 2, 3, 4, 1).tanh(),
+              atol=2e-4, what=name + " occ_density")

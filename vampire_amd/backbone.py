@@ -159,6 +159,13 @@ def _build_image_encoder(img_backbone_conf, img_neck_conf, downsample):
 # the backbone
 # ---------------------------------------------------------------------------
 class BaseVAMPIRE2(nn.Module):
+    """The headline backbone (bv2:81).  Its three siblings below differ only in the class-level
+    switches `_BASE` (3-D UNet or one Conv3d + Softplus), `_USE_DEPTH` (depth-distribution lift or
+    the D = 1 bilinear lift), `_ROTATE_OCC` (occupancy grid rotated by bda or the static
+    normalised grid) and in their keyword defaults."""
+    _BASE = "unet"
+    _USE_DEPTH = True
+    _ROTATE_OCC = True
 
     def __init__(self, x_bound_seg, y_bound_seg, z_bound_seg, x_bound_det, y_bound_det,
                  z_bound_det, d_bound, final_dim, downsample_factor, upsample_factor,
@@ -193,7 +200,17 @@ class BaseVAMPIRE2(nn.Module):
         self.register_buffer("camera_mids", G.make_camera_mids(d_bound))
         self.register_buffer("bev_mids", G.make_bev_mids(z_bound_det))
         self.register_buffer("voxel_coords", G.make_voxel_coords(x_bound_seg, y_bound_seg, z_bound_seg))
-        self.register_buffer("occ_coords", G.make_occ_coords())
+        occ = G.make_occ_coords()
+        if self._ROTATE_OCC:
+            self.register_buffer("occ_coords", occ)                  # bv2:148
+        else:
+            # base_lss_impaintor.py:152, 297-314 (same in base_lss.py / base_bilinear.py): the grid
+            # normalised by the seg bounds once, at construction
+            lo = torch.as_tensor([x_bound_seg[0], y_bound_seg[0], z_bound_seg[0]])
+            span = torch.as_tensor([x_bound_seg[1] - x_bound_seg[0], y_bound_seg[1] - y_bound_seg[0],
+                                    z_bound_seg[1] - z_bound_seg[0]])
+            self.register_buffer("norm_occ_coords", ((occ - lo) / span) * 2.0 - 1.0)
+            self._occ_points = occ                                   # plain attribute: the kernels normalise themselves
         if cat_pos:
             self.register_buffer("norm_voxel_coords",
                                  G.make_voxel_coords(x_bound_seg, y_bound_seg, z_bound_seg, norm=True))
@@ -205,11 +222,18 @@ class BaseVAMPIRE2(nn.Module):
         self.img_backbone, self.img_neck = _build_image_encoder(img_backbone_conf, img_neck_conf,
                                                                 downsample_factor)
         img_out = sum(img_neck_conf["out_channels"])
-        self.mapping_along_depth = nn.Sequential(nn.Conv2d(img_out, self.depth_channels, 3, 1, 1, bias=False))
+        if self._USE_DEPTH:
+            self.mapping_along_depth = nn.Sequential(nn.Conv2d(img_out, self.depth_channels, 3, 1, 1, bias=False))
         self.channel_lower = nn.Conv2d(img_out, mid_channels, 3, 1, 1, bias=False)
-        self.base_conv = Unet3D(mid_channels + (3 if cat_pos else 0), mid_channels)
+        vin = mid_channels + (3 if cat_pos else 0)
+        if self._BASE == "unet":
+            self.base_conv = Unet3D(vin, mid_channels)
+        else:                                                        # base_lss.py:117-124, base_bilinear.py:173-179
+            self.base_conv = nn.Sequential(nn.Conv3d(vin, mid_channels, 3, 1, 1, bias=True), nn.Softplus(beta=100))
         self.density_conv = nn.Conv3d(mid_channels, 1, 3, 1, 1, bias=True)
         self.seg_conv = nn.Conv3d(mid_channels, num_classes, 3, 1, 1, bias=True)
+        if not self._USE_DEPTH:
+            self.feature_conv = nn.Conv3d(mid_channels, mid_channels, 3, 1, 1, bias=True)   # base_bilinear.py:182
         self.density = nn.Sigmoid() if density_mode == "naive" else \
             ModifyLaplaceDensity(beta=0.1, bias=sdf_bias)
         self.rgb_conv = nn.Sequential(nn.Conv3d(mid_channels, 3, 3, 1, 1, bias=True), nn.Sigmoid())
@@ -281,6 +305,9 @@ class BaseVAMPIRE2(nn.Module):
         mats = G.lift_matrices(mats_dict["sensor2ego_mats"][:, sweep_index],
                                mats_dict["intrin_mats"][:, sweep_index],
                                mats_dict["ida_mats"][:, sweep_index], mats_dict.get("bda_mat", None))
+        if not self._USE_DEPTH:
+            # base_bilinear.py:471-519: img_feats [B, N, C, fH, fW], 2-D bilinear sample, z_valid = z > 0
+            return self.hot_path().lift(None, frustum_feats.float(), mats, use_depth=False)
         return self.hot_path().lift_dense(frustum_feats.float(), mats)
 
     def lift(self, depth, feat, sweep_index, mats_dict):
@@ -343,15 +370,31 @@ class BaseVAMPIRE2(nn.Module):
         img_feats = self.get_cam_feats(sweep_imgs)
         src = img_feats[:, 0].reshape(B * N, -1, img_feats.shape[-2], img_feats.shape[-1])
         hp = self.hot_path()
-        # depth softmax (bv2:550) as the HIP producer kernel
-        depth = hp.depth_softmax(self.mapping_along_depth(src)).reshape(B, N, -1, *src.shape[-2:])
         feat = self.channel_lower(src).reshape(B, N, -1, *src.shape[-2:])
-        voxel_features = self.lift(depth, feat.float(), sweep_index, mats_dict)
+        # the HIP depth-softmax / density-gate kernels are 3-5x faster than aten's as
+        # kernels, but at batch 1 their host glue (ctypes call, autograd.Function, layout fix-ups)
+        # costs what they save (156 vs 149 us and 167 vs 104 us end to end, profiles/widening_rows_r01f.txt),
+        # so the module runs the reference's aten expressions unless VAMP_GLUE=hip asks for the kernels
+        # (they stay available and tested: HotPath.depth_softmax / density_gate).
+        hip_glue = os.environ.get("VAMP_GLUE", "aten") == "hip"
+        if self._USE_DEPTH:
+            logits = self.mapping_along_depth(src)
+            depth = hp.depth_softmax(logits) if hip_glue else logits.float().softmax(dim=1)   # bv2:550
+            depth = depth.reshape(B, N, -1, *src.shape[-2:])
+            voxel_features = self.lift(depth, feat.float(), sweep_index, mats_dict)
+        else:
+            voxel_features = self.get_voxel_feats(feat, sweep_index, mats_dict)     # base_bilinear.py:566
         if self.cat_pos:
             pos = self.norm_voxel_coords.permute(3, 0, 1, 2)[None].repeat(B, 1, 1, 1, 1)
             voxel_features = torch.cat([voxel_features, pos], dim=1)
         base = self.base_conv(voxel_features)
-        density_feature, semantic_logits, rgb = self._heads(base)
+        if self._USE_DEPTH:
+            density_feature, semantic_logits, rgb = self._heads(base)
+        else:
+            # base_bilinear.py:575-578: rgb and the rendered features come from feature_conv(base)
+            density_feature, semantic_logits = self.density_conv(base), self.seg_conv(base)
+            base = self.feature_conv(base)
+            rgb = self.rgb_conv(base)
 
         # lidar-point queries (bv2:576-596) and occupancy resampling on the bda-rotated Occ3D grid
         # (bv2:597-609): HIP point resampling, `hp` may be an oracle stand-in on CPU
@@ -365,8 +408,13 @@ class BaseVAMPIRE2(nn.Module):
                 if self.density_mode == "sdf":
                     pts_sdf_batch.append(hp.sample_points(density_feature[[i]].float(), pts,
                                                           mask_outside=True)[0, 0])
-        occ_logits, occ_density = hp.occupancy_queries(semantic_logits.float(), density_feature.float(),
-                                                       self.occ_coords, mats_dict.get("bda_mat", None), beta)
+        if self._ROTATE_OCC:
+            occ_logits, occ_density = hp.occupancy_queries(semantic_logits.float(), density_feature.float(),
+                                                           self.occ_coords, mats_dict.get("bda_mat", None), beta)
+        else:
+            # static grid (base_lss_impaintor.py:611-616): the same queries without the bda rotation
+            occ_logits, occ_density = hp.occupancy_queries(semantic_logits.float(), density_feature.float(),
+                                                           self._occ_points.to(semantic_logits.device), None, beta)
 
         (rgb_p, seg_p, depth_p, bev_rgb, bev_seg, bev_height, bev_density, voxel_output) = \
             self.render(mats_dict, sweep_index, density_feature, semantic_logits, base, rgb)
@@ -374,7 +422,10 @@ class BaseVAMPIRE2(nn.Module):
         up = lambda t: self.upsample2d(t.reshape(B * N, -1, self.fH, self.fW)).reshape(
             B, N, -1, self.fH * self.upsample_factor, self.fW * self.upsample_factor)
         rgb_p, seg_p, depth_p = up(rgb_p), up(seg_p), up(depth_p)
-        voxel_output = hp.density_gate(voxel_output, bev_density)      # bv2:627-630, HIP consumer kernel
+        if hip_glue:
+            voxel_output = hp.density_gate(voxel_output, bev_density)  # bv2:627-630, HIP consumer kernel
+        else:
+            voxel_output = voxel_output * (bev_density.tanh() if self.density_mode == "sdf" else bev_density)
         bev_feat = self.voxel_output(voxel_output.reshape(B, -1, *voxel_output.shape[-2:])).float()
         return (bev_feat.contiguous(), rgb_p, seg_p, depth_p, bev_rgb, bev_seg, bev_height,
                 bev_density, pts_logits_batch, pts_sdf_batch,
@@ -384,3 +435,35 @@ class BaseVAMPIRE2(nn.Module):
         if sweep_imgs.shape[1] != 1:
             raise NotImplementedError          # as the reference (bv2:690-693)
         return self._forward_single_sweep(0, sweep_imgs[:, 0:1], mats_dict, inrange_pts=inrange_pts)
+
+
+class BaseLSSImpaintor(BaseVAMPIRE2):
+    """src/layers/backbones/base_lss_impaintor.py:79: BaseVAMPIRE2 with the static `norm_occ_coords`
+    buffer (the occupancy grid is not rotated by bda, :611-616) and cat_pos / cat_seg on by default
+    (:100-101)."""
+    _ROTATE_OCC = False
+
+    def __init__(self, x_bound_seg, y_bound_seg, z_bound_seg, x_bound_det, y_bound_det, z_bound_det, d_bound,
+                 final_dim, downsample_factor, upsample_factor, mid_channels, output_channels,
+                 img_backbone_conf, img_neck_conf, num_classes, density_mode="naive", sdf_bias=-1.0,
+                 cat_pos=True, cat_seg=True, use_da=False):
+        super().__init__(x_bound_seg, y_bound_seg, z_bound_seg, x_bound_det, y_bound_det, z_bound_det, d_bound,
+                         final_dim, downsample_factor, upsample_factor, mid_channels, output_channels,
+                         img_backbone_conf, img_neck_conf, num_classes, density_mode, sdf_bias, cat_pos,
+                         cat_seg, use_da)
+
+
+class BaseLSS(BaseLSSImpaintor):
+    """src/layers/backbones/base_lss.py:16: the ablation whose `base_conv` is one Conv3d + Softplus
+    (:117-124) instead of the 3-D UNet."""
+    _BASE = "conv"
+
+
+class BaseBiLinear(BaseVAMPIRE2):
+    """src/layers/backbones/base_bilinear.py:80: no depth distribution -- `get_voxel_feats(img_feats,
+    ...)` is a 2-D bilinear sample of [B, N, C, fH, fW] with z_valid = z > 0 (:471-519; the HIP lift
+    with use_depth = 0), `base_conv` = Conv3d + Softplus, an extra `feature_conv` feeds rgb and the
+    renderer (:575-578), static `norm_occ_coords`."""
+    _BASE = "conv"
+    _USE_DEPTH = False
+    _ROTATE_OCC = False

@@ -217,7 +217,7 @@ bev_scan_kernel(RenderParams P, const float* __restrict__ oxs, const float* __re
                 const float* __restrict__ beta_raw, const T* __restrict__ dens,
                 const float* __restrict__ g_bh, const float* __restrict__ g_vd,
                 const float* __restrict__ Q, float* __restrict__ Wb, float* __restrict__ DS0,
-                float* __restrict__ grad_beta) {
+                float* __restrict__ beta_part) {
   __shared__ float red[4];
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -266,10 +266,9 @@ bev_scan_kernel(RenderParams P, const float* __restrict__ oxs, const float* __re
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) {
-      const float sgn = (beta_raw[0] > 0.f) ? 1.f : ((beta_raw[0] < 0.f) ? -1.f : 0.f);
-      atomicAdd(grad_beta, sgn * (red[0] + red[1] + red[2] + red[3]));
-    }
+    // one partial per workgroup; launch_beta_reduce adds them up in a fixed order
+    if (threadIdx.x == 0)
+      beta_part[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)] = (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
 
@@ -567,9 +566,14 @@ bev_gather_kernel(RenderParams P, const int4* __restrict__ tab, const float* __r
     if (on[u]) gout[oo[u]] = prev[u] + sum[u];
 }
 
+static size_t bev_scan_blocks(const VampRenderDesc* d) {
+  return (size_t) ((d->oX + 63) / 64) * ((d->oY + 3) / 4) * d->B;
+}
+
 static size_t bev_ws_bytes(const VampRenderDesc* d) {
   return 3 * align_up((size_t) d->B * d->oZ * d->oY * d->oX * sizeof(float), 256) +
-         align_up((size_t) 2 * (d->X + d->Y + d->Z) * sizeof(int4), 256);
+         align_up((size_t) 2 * (d->X + d->Y + d->Z) * sizeof(int4), 256) +
+         align_up(bev_scan_blocks(d) * sizeof(float), 256);
 }
 
 }  // namespace vamp
@@ -640,6 +644,8 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
   float* Q = static_cast<float*>(workspace);
   float* Wb = reinterpret_cast<float*>(static_cast<char*>(workspace) + one);
   float* DS0 = reinterpret_cast<float*>(static_cast<char*>(workspace) + 2 * one);
+  float* beta_part = reinterpret_cast<float*>(static_cast<char*>(workspace) + 3 * one +
+                                              align_up((size_t) 2 * (d->X + d->Y + d->Z) * sizeof(int4), 256));
 
   // z-range of volume planes the lattice touches (host copy of the det-grid heights)
   int z_lo = d->Z, z_hi = -1;
@@ -664,11 +670,13 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
     if (int e = check_launch("bev_q_kernel")) return e;                                           \
     VAMP_TIMED(kProfBevBwd, s, (bev_scan_kernel<T><<<gs, 256, 0, s>>>(                            \
         P, oxs, oys, ozs, bev_mids, beta, (const T*) density_feature, g_bev_height,               \
-        g_voxel_density, Q, Wb, DS0, grad_beta)));                                                \
+        g_voxel_density, Q, Wb, DS0, beta_part)));                                                \
     if (int e = check_launch("bev_scan_kernel")) return e;                                        \
   } while (0)
   if (d->in_dtype == VAMP_F32) VAMP_BEVB(float); else VAMP_BEVB(__hip_bfloat16);
 #undef VAMP_BEVB
+  if (d->density_mode == VAMP_DENSITY_SDF_LAPLACE)
+    if (int e = launch_beta_reduce(beta_part, (int) bev_scan_blocks(d), beta, grad_beta, s)) return e;
   // lattice points within one voxel's trilinear support, per axis
   bool fits = true;
   const int nvox[3] = {d->X, d->Y, d->Z};

@@ -25,7 +25,7 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
                    const float* __restrict__ packed, const float* __restrict__ g_rgb,
                    const float* __restrict__ g_seg, const float* __restrict__ g_depth,
                    const int* __restrict__ SLOT, float4* __restrict__ REC,
-                   float* __restrict__ Gcl, float* __restrict__ grad_beta, int L) {
+                   float* __restrict__ Gcl, float* __restrict__ beta_part, int L) {
   constexpr int CP = CP4 * 4;
   extern __shared__ float lds[];              // [3][L][256]: s0, delta (sign = no-grad flag), q
   __shared__ float red[4];
@@ -177,11 +177,8 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
     for (int o = 32; o > 0; o >>= 1) vsum += __shfl_down(vsum, o, 64);
     if ((tid & 63) == 0) red[tid >> 6] = vsum;
     __syncthreads();
-    if (tid == 0) {
-      const float tot = red[0] + red[1] + red[2] + red[3];
-      const float sgn = (beta_raw[0] > 0.f) ? 1.f : ((beta_raw[0] < 0.f) ? -1.f : 0.f);
-      atomicAdd(grad_beta, sgn * tot);
-    }
+    // one partial per workgroup; launch_beta_reduce adds them up in a fixed order
+    if (tid == 0) beta_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
 
@@ -204,9 +201,13 @@ static size_t gcl_bytes(const VampRenderDesc* d) {
   return align_up((size_t) d->B * d->N * d->fH * d->fW * P.CP * sizeof(float), 256);
 }
 
-size_t cam_bwd_v2_bytes(const VampRenderDesc* d) { return gcl_bytes(d) + cam_bwd_cell_bytes(d); }
+static size_t beta_part_bytes(const VampRenderDesc* d) {
+  return align_up((size_t) ray_grid<4>(to_params(d)) * sizeof(float), 256);
+}
 
-// scratch = workspace region after the packed volume: [Gcl | cell lists]
+size_t cam_bwd_v2_bytes(const VampRenderDesc* d) { return gcl_bytes(d) + cam_bwd_cell_bytes(d) + beta_part_bytes(d); }
+
+// scratch = workspace region after the packed volume: [Gcl | cell lists | beta partials]
 int launch_cam_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                        const float* us, const float* vs, const float* ds, void* scratch,
                        hipStream_t s) {
@@ -226,6 +227,7 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
     if (int e = launch_cam_cells_prepare(d, P, mats, us, vs, ds, cell_scratch, s)) return e;
   const int* SLOT = cam_cell_slots(d, cell_scratch);
   float4* R = cam_cell_records(d, cell_scratch);
+  float* beta_part = reinterpret_cast<float*>(static_cast<char*>(cell_scratch) + cam_bwd_cell_bytes(d));
 
   constexpr int LPR = 4;
   const int S = d->D - 1;
@@ -242,11 +244,13 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
       return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);                           \
     VAMP_TIMED(kProfCamBwd, s, (kr<<<grid, 256, lds, s>>>(P, mats, us, vs, ds, mids, beta, packed, \
                                                            g_rgb, g_seg, g_depth, SLOT, R, Gcl,   \
-                                                           grad_beta, L)));                       \
+                                                           beta_part, L)));                       \
   } while (0)
   if (P.CP == 12) VAMP_RAY(3); else if (P.CP == 24) VAMP_RAY(6); else VAMP_RAY(8);
 #undef VAMP_RAY
   if (int e = check_launch("cam_bwd_ray_kernel")) return e;
+  if (P.density_mode == VAMP_DENSITY_SDF_LAPLACE)
+    if (int e = launch_beta_reduce(beta_part, (int) grid, beta, grad_beta, s)) return e;
   return launch_cam_bwd_cell(d, P, Gcl, gdens, gsem, grgb, cell_scratch, accumulate, wait_event, s);
 }
 

@@ -141,6 +141,33 @@ int launch_cell_scan(const int* cnt, int* off, int* bsum, int* boff, int* aux, l
   return launch_exclusive_scan(bsum, boff, aux, (int) ntile, aux + ntile, s);
 }
 
+// grad_beta += sign(beta_raw) * sum(part[0..n)): the per-workgroup partial sums of d loss / d beta_eff
+// are added up in a fixed order by one workgroup (no float atomics on one address, same bits every run)
+__global__ void __launch_bounds__(1024)
+beta_reduce_kernel(const float* __restrict__ part, int n, const float* __restrict__ beta_raw,
+                   float* __restrict__ grad_beta) {
+  __shared__ float red[16];
+  float v = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) v += part[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < 16; ++i) tot += red[i];
+    const float sgn = (beta_raw[0] > 0.f) ? 1.f : ((beta_raw[0] < 0.f) ? -1.f : 0.f);
+    // one atomic per launch: the camera and BEV branches add to the same word from two streams
+    // (two addends commute, so the sum has the same bits every run)
+    atomicAdd(grad_beta, sgn * tot);
+  }
+}
+
+int launch_beta_reduce(const float* part, int n, const float* beta_raw, float* grad_beta, hipStream_t s) {
+  beta_reduce_kernel<<<1, 1024, 0, s>>>(part, n, beta_raw, grad_beta);
+  return check_launch("beta_reduce_kernel");
+}
+
 int launch_exclusive_scan(const int* cnt, int* off, int* fill, int n, int* total, hipStream_t s) {
   VAMP_TIMED(kProfAux, s, (exclusive_scan_kernel<<<1, 1024, 0, s>>>(cnt, off, fill, n, total)));
   return check_launch("exclusive_scan_kernel");

@@ -229,7 +229,10 @@ class HotPath:
         B = semantic_logits.shape[0]
         # R @ c for every grid point as one [P,3] x [3,3] product per sample (the reference's
         # broadcast of 640k 3x3 matmuls, bv2:599, costs 8 ms on the GPU)
-        pts = torch.matmul(occ_coords.reshape(1, -1, 3).float(), bda_mat[:, :3, :3].float().transpose(1, 2))
+        if bda_mat is None:      # the static grid of BaseLSSImpaintor / BaseLSS / BaseBiLinear
+            pts = occ_coords.reshape(1, -1, 3).float().expand(B, -1, 3).contiguous()
+        else:
+            pts = torch.matmul(occ_coords.reshape(1, -1, 3).float(), bda_mat[:, :3, :3].float().transpose(1, 2))
         shp = tuple(occ_coords.shape[:3])
         logits = self.sample_points(semantic_logits, pts, padding="border", lattice=shp)
         dens = self.sample_points(density_feature, pts, activation=True, beta=beta, lattice=shp)
@@ -271,7 +274,9 @@ class _LiftFn(torch.autograd.Function):
                 raise TypeError("depth and feat must share a dtype")
         mats = _chk(mats.float(), (B, N, 3, 4, 4), "lift_mats")
         out = torch.empty(B, C_, c.vZ, c.vY, c.vX, dtype=torch.float32, device=feat.device)
-        need_grad = feat.requires_grad or (use_depth and depth.requires_grad)
+        # (needs_input_grad, not requires_grad: under torch.no_grad() nothing is recorded and the
+        # backward's hit words / prepare pass would be wasted work)
+        need_grad = ctx.needs_input_grad[2] or (use_depth and ctx.needs_input_grad[1])
         nchunk = (C_ + 15) // 16
         hits = (torch.empty(B, c.vZ, c.vY, c.vX, nchunk, dtype=torch.int64, device=feat.device)
                 if need_grad else None)
@@ -337,11 +342,11 @@ class _LiftDenseFn(torch.autograd.Function):
         out = torch.empty(B, C_, c.vZ, c.vY, c.vX, dtype=torch.float32, device=ff.device)
         nchunk = (C_ + 15) // 16
         hits = (torch.empty(B, c.vZ, c.vY, c.vX, nchunk, dtype=torch.int64, device=ff.device)
-                if ff.requires_grad else None)
+                if ctx.needs_input_grad[1] else None)
         _capi.check(hp.lib.vamp_lift_forward_dense(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys),
                                                    _ptr(hp.zs), _ptr(ff), _ptr(out), _ptr(hits),
                                                    _stream()), "vamp_lift_forward_dense")
-        if ff.requires_grad:
+        if ctx.needs_input_grad[1]:
             ctx.hp, ctx.desc, ctx.shape = hp, d, ff.shape
             ctx.save_for_backward(mats, hits)
         return out
