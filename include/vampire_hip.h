@@ -194,6 +194,25 @@ int vamp_render_camera_forward(const VampRenderDesc* d, const float* geom, const
                                void* stream);
 
 /*
+ * Same, for training: with VAMP_CAMFWD_SAVE_SAMPLES the march also stores the trilinear sample
+ * row (the 1 + K + 3 channels, as gathered) of every inside sample, so that the backward's
+ * per-ray pass reads 96 contiguous bytes per sample instead of repeating the 8-tap gather.
+ * The rows live behind the base region of `workspace`, which must then hold
+ * vamp_render_workspace_bytes(d) + vamp_render_samples_bytes(d) bytes (dense addressing by
+ * (camera, depth index, pixel): only the rows of inside samples are ever touched).  Needs the
+ * in-kernel geometry (geom == NULL); otherwise the flag is ignored and the backward gathers.
+ */
+#define VAMP_CAMFWD_SAVE_SAMPLES 1
+size_t vamp_render_samples_bytes(const VampRenderDesc* d);
+int vamp_render_camera_forward_ex(const VampRenderDesc* d, const float* geom, const float* mats,
+                                  const float* us, const float* vs, const float* ds,
+                                  const float* mids, const float* beta,
+                                  const void* density_feature, const void* semantic,
+                                  const void* rgb, float* rgb_out, float* seg_out,
+                                  float* depth_out, void* workspace, size_t workspace_bytes,
+                                  int flags, void* stream);
+
+/*
  * Camera branch, backward.  g_* are the upstream gradients of the three outputs
  * (any may be NULL = zero).  grad_density_feature / grad_semantic / grad_rgb are
  * fp32 [B,c,Z,Y,X], fully overwritten.  grad_beta (1 float) is ACCUMULATED into.
@@ -236,6 +255,9 @@ int vamp_render_camera_prepare(const VampRenderDesc* d, const float* mats, const
 /* implementation selector: the float-atomic splat instead of the default cell-list gather
    (the independent cross-check of the tests; also what a caller-supplied geom tensor takes) */
 #define VAMP_CAMBWD_SPLAT 8
+/* the workspace holds the sample rows of vamp_render_camera_forward_ex(VAMP_CAMFWD_SAVE_SAMPLES)
+   for these same volumes / matrices and nothing has written to it since (cell-list path only) */
+#define VAMP_CAMBWD_SAMPLES_VALID 16
 int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, const float* mats,
                                     const float* us, const float* vs, const float* ds,
                                     const float* mids, const float* beta,

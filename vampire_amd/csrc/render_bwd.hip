@@ -23,7 +23,7 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
                       const float* beta, const float* packed, const float* g_rgb,
                       const float* g_seg, const float* g_depth, float* gdens, float* gsem,
                       float* grgb, float* grad_beta, void* scratch, int accumulate,
-                      hipEvent_t wait_event, bool cells_valid, hipStream_t s);
+                      hipEvent_t wait_event, bool cells_valid, const float* samples, hipStream_t s);
 int launch_cam_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                        const float* us, const float* vs, const float* ds, void* scratch,
                        hipStream_t s);
@@ -401,11 +401,19 @@ int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, 
   // Default: per-ray pass + cell-list gather (render_bwd_ray.hip, render_bwd_cell.hip), which
   // evaluates the frustum points itself from the matrices.  A caller-supplied geom tensor, or
   // VAMP_CAMBWD_SPLAT, takes the v1 float-atomic splat below (the independent cross-check).
-  if (!geom && mats && !(flags & VAMP_CAMBWD_SPLAT))
+  if (!geom && mats && !(flags & VAMP_CAMBWD_SPLAT)) {
+    const float* samples = nullptr;
+    if (flags & VAMP_CAMBWD_SAMPLES_VALID) {
+      VAMP_REQUIRE(flags & VAMP_CAMBWD_PACKED_VALID, "SAMPLES_VALID needs PACKED_VALID (the same forward wrote both)");
+      if (workspace_bytes < need + vamp_render_samples_bytes(d))
+        return fail(VAMP_ENOSPC, "%s: workspace %ld has no room for the sample rows", __func__, (long) workspace_bytes);
+      samples = reinterpret_cast<const float*>(static_cast<char*>(workspace) + need);
+    }
     return launch_cam_bwd_v2(d, P, mats, us, vs, ds, mids, beta, packed, g_rgb, g_seg, g_depth,
                              grad_density_feature, grad_semantic, grad_rgb, grad_beta, gpacked,
                              accumulate, static_cast<hipEvent_t>(wait_event),
-                             (flags & VAMP_CAMBWD_CELLS_VALID) != 0, s);
+                             (flags & VAMP_CAMBWD_CELLS_VALID) != 0, samples, s);
+  }
   VAMP_REQUIRE(!accumulate && !wait_event, "accumulate / wait_event need the cell-list path");
   {
     ProfScope sc;

@@ -25,7 +25,8 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
                    const float* __restrict__ packed, const float* __restrict__ g_rgb,
                    const float* __restrict__ g_seg, const float* __restrict__ g_depth,
                    const int* __restrict__ SLOT, float4* __restrict__ REC,
-                   float* __restrict__ Gcl, float* __restrict__ beta_part, int L) {
+                   float* __restrict__ Gcl, float* __restrict__ beta_part,
+                   const float* __restrict__ samples, int L) {
   constexpr int CP = CP4 * 4;
   extern __shared__ float lds[];              // [3][L][256]: s0, delta (sign = no-grad flag), q
   __shared__ float red[4];
@@ -87,7 +88,18 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
 #pragma unroll
     for (int c = 0; c < CP; ++c) s[c] = 0.f;
     if (tp.inside) {
-      gather_taps<CP4>(P, vol, tp, s);
+      if (samples) {
+        // the row the forward gathered for this sample (render_cam_fwd_plan_kernel<SAVE>): 96
+        // contiguous bytes per lane, neighbouring lanes = neighbouring pixels
+        const float4* row = reinterpret_cast<const float4*>(samples + ((((long) bn * S + i) * P.fH + h) * P.fW + w) * CP);
+#pragma unroll
+        for (int q = 0; q < CP4; ++q) {
+          const float4 f = row[q];
+          s[q * 4] = f.x; s[q * 4 + 1] = f.y; s[q * 4 + 2] = f.z; s[q * 4 + 3] = f.w;
+        }
+      } else {
+        gather_taps<CP4>(P, vol, tp, s);
+      }
     }
     const bool fin = (s[0] == s[0]) && (fabsf(s[0]) <= 3.402823466e+38f);
     const float s0 = nan_to_num(s[0]);
@@ -219,7 +231,7 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
                       const float* beta, const float* packed, const float* g_rgb,
                       const float* g_seg, const float* g_depth, float* gdens, float* gsem,
                       float* grgb, float* grad_beta, void* scratch, int accumulate,
-                      hipEvent_t wait_event, bool cells_valid, hipStream_t s) {
+                      hipEvent_t wait_event, bool cells_valid, const float* samples, hipStream_t s) {
   float* Gcl = static_cast<float*>(scratch);
   void* cell_scratch = static_cast<char*>(scratch) + gcl_bytes(d);
   // the sample -> slot table depends on the geometry only; the caller may have prepared it
@@ -244,7 +256,7 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
       return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);                           \
     VAMP_TIMED(kProfCamBwd, s, (kr<<<grid, 256, lds, s>>>(P, mats, us, vs, ds, mids, beta, packed, \
                                                            g_rgb, g_seg, g_depth, SLOT, R, Gcl,   \
-                                                           beta_part, L)));                       \
+                                                           beta_part, samples, L)));              \
   } while (0)
   if (P.CP == 12) VAMP_RAY(3); else if (P.CP == 24) VAMP_RAY(6); else VAMP_RAY(8);
 #undef VAMP_RAY

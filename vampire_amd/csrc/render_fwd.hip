@@ -170,13 +170,16 @@ render_cam_fwd_kernel(RenderParams P, const float* __restrict__ geom, const floa
 // ---------------------------------------------------------------------------
 // camera branch forward with a per-tile plan (geometry evaluated from the matrices)
 // ---------------------------------------------------------------------------
-template <int CP4>
+// SAVE: also store the gathered row of every inside sample at samples[((bn * S + i) * fH + h) * fW + w]
+// (CP floats, before the nan_to_num of bv2:421) for the backward's per-ray pass.
+template <int CP4, bool SAVE>
 __global__ void __launch_bounds__(256, 3)
 render_cam_fwd_plan_kernel(RenderParams P, const float* __restrict__ mats, const float* __restrict__ us,
                            const float* __restrict__ vs, const float* __restrict__ ds,
                            const float* __restrict__ mids, const float* __restrict__ beta_raw,
                            const float* __restrict__ packed, float* __restrict__ rgb_out,
-                           float* __restrict__ seg_out, float* __restrict__ depth_out) {
+                           float* __restrict__ seg_out, float* __restrict__ depth_out,
+                           float* __restrict__ samples) {
   constexpr int CP = CP4 * 4;
   __shared__ float xmerge[4 * (CP + 2) * 64];
   __shared__ int4 plan[kPlanMax];
@@ -247,6 +250,11 @@ render_cam_fwd_plan_kernel(RenderParams P, const float* __restrict__ mats, const
       for (int c = 0; c < CP; ++c) s[c] = 0.f;
       if (tp.inside) {
         gather_taps<CP4>(P, vol, tp, s);
+        if (SAVE && live) {
+          float4* row = reinterpret_cast<float4*>(samples + ((((long) bn * S + i) * P.fH + h) * P.fW + w) * CP);
+#pragma unroll
+          for (int q = 0; q < CP4; ++q) row[q] = make_float4(s[q * 4], s[q * 4 + 1], s[q * 4 + 2], s[q * 4 + 3]);
+        }
         // nan_to_num of the sampled features (bv2:421) only where something is not finite:
         // sum_c 0 * s_c is nan exactly then (two chains, so that they pack)
         float chk0 = 0.f, chk1 = 0.f;
@@ -400,31 +408,57 @@ size_t vamp_render_workspace_bytes(const VampRenderDesc* d) {
   return pb + (pb > v2 ? pb : v2);
 }
 
+size_t vamp_render_samples_bytes(const VampRenderDesc* d) {
+  if (!d) return 0;
+  const RenderParams P = to_params(d);
+  return align_up((size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW * P.CP * sizeof(float), 256);
+}
+
 int vamp_render_camera_forward(const VampRenderDesc* d, const float* geom, const float* mats,
                                const float* us, const float* vs, const float* ds,
                                const float* mids, const float* beta, const void* density_feature,
                                const void* semantic, const void* rgb, float* rgb_out,
                                float* seg_out, float* depth_out, void* workspace,
                                size_t workspace_bytes, void* stream) {
+  return vamp_render_camera_forward_ex(d, geom, mats, us, vs, ds, mids, beta, density_feature, semantic, rgb,
+                                       rgb_out, seg_out, depth_out, workspace, workspace_bytes, 0, stream);
+}
+
+int vamp_render_camera_forward_ex(const VampRenderDesc* d, const float* geom, const float* mats,
+                                  const float* us, const float* vs, const float* ds,
+                                  const float* mids, const float* beta, const void* density_feature,
+                                  const void* semantic, const void* rgb, float* rgb_out,
+                                  float* seg_out, float* depth_out, void* workspace,
+                                  size_t workspace_bytes, int flags, void* stream) {
   if (int e = validate(d)) return e;
   VAMP_REQUIRE(geom || (mats && us && vs && ds), "need geom or (mats, us, vs, ds)");
   VAMP_REQUIRE(mids && density_feature && semantic && rgb && rgb_out && seg_out && depth_out,
                "null pointer");
   VAMP_REQUIRE(beta || d->density_mode == VAMP_DENSITY_SIGMOID, "beta is NULL");
-  const size_t need = packed_bytes(d);
+  const bool planned = !geom && d->D - 1 <= kPlanMax;
+  const bool save = (flags & VAMP_CAMFWD_SAVE_SAMPLES) && planned;
+  const size_t need = save ? vamp_render_workspace_bytes(d) + vamp_render_samples_bytes(d) : packed_bytes(d);
   if (!workspace || workspace_bytes < need)
     return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) need);
   const RenderParams P = to_params(d);
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* packed = static_cast<float*>(workspace);
+  float* samples = save ? reinterpret_cast<float*>(static_cast<char*>(workspace) + vamp_render_workspace_bytes(d))
+                        : nullptr;
   if (int e = launch_pack(P, d->in_dtype, density_feature, semantic, rgb, packed, s)) return e;
   constexpr int LPR = 4;
   const unsigned grid = ray_grid<LPR>(P);
   // geometry from the matrices and at most kPlanMax samples per ray: the planned march
-  if (!geom && d->D - 1 <= kPlanMax) {
+  if (planned) {
 #define VAMP_CAMP(CP4)                                                                     \
-  VAMP_TIMED(kProfCamFwd, s, (render_cam_fwd_plan_kernel<CP4><<<grid, 256, 0, s>>>(         \
-      P, mats, us, vs, ds, mids, beta, packed, rgb_out, seg_out, depth_out)))
+  do {                                                                                     \
+    if (samples)                                                                           \
+      VAMP_TIMED(kProfCamFwd, s, (render_cam_fwd_plan_kernel<CP4, true><<<grid, 256, 0, s>>>(  \
+          P, mats, us, vs, ds, mids, beta, packed, rgb_out, seg_out, depth_out, samples)));    \
+    else                                                                                   \
+      VAMP_TIMED(kProfCamFwd, s, (render_cam_fwd_plan_kernel<CP4, false><<<grid, 256, 0, s>>>( \
+          P, mats, us, vs, ds, mids, beta, packed, rgb_out, seg_out, depth_out, nullptr)));    \
+  } while (0)
     if (P.CP == 12) VAMP_CAMP(3); else if (P.CP == 24) VAMP_CAMP(6); else VAMP_CAMP(8);
 #undef VAMP_CAMP
     return check_launch("render_cam_fwd_plan_kernel");

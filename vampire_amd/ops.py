@@ -88,6 +88,10 @@ class HotPath:
                      "bev_bwd": os.environ.get("VAMP_BEV_BWD", "cell"),
                      "lift_wpp": int(os.environ.get("VAMP_LIFT_WPP", "0")),
                      "overlap": os.environ.get("VAMP_OVERLAP", "1") != "0",
+                     # store the forward's sample rows for the backward's per-ray pass: measured
+                     # neutral at cfg-B (forward +50 us for the scattered row stores, backward -59 us),
+                     # so off unless asked for
+                     "save_samples": os.environ.get("VAMP_SAVE_SAMPLES", "0") == "1",
                      "prepare": os.environ.get("VAMP_PREPARE", "1") != "0"}
 
     # ---------------------------------------------------------------- descs
@@ -393,6 +397,12 @@ class _RenderFn(torch.autograd.Function):
         seg_p = torch.empty(B, N, K, c.fH, c.fW, dtype=f32, device=dev)
         dep_p = torch.empty(B, N, 1, c.fH, c.fW, dtype=f32, device=dev)
         nbytes = hp.lib.vamp_render_workspace_bytes(C.byref(d))
+        # training: the march also stores every inside sample's gathered row behind the base region,
+        # and the backward's per-ray pass reads it back instead of repeating the 8-tap gather
+        save = (any(ctx.needs_input_grad) and geom is None and hp.impl["cam_bwd"] != "v1"
+                and hp.impl["save_samples"])
+        if save:
+            nbytes += hp.lib.vamp_render_samples_bytes(C.byref(d))
         ws = hp._workspace("render", nbytes)
         CO = C_ + (K if c.cat_seg else 0)
         bev_rgb = torch.empty(B, 3, c.oY, c.oX, dtype=f32, device=dev)
@@ -416,10 +426,12 @@ class _RenderFn(torch.autograd.Function):
             C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
             _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
             _ptr(vdens), _ptr(vout), _stream(side)), "vamp_render_bev_forward")
-        _capi.check(hp.lib.vamp_render_camera_forward(
+        _capi.check(hp.lib.vamp_render_camera_forward_ex(
             C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
             _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
-            _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(), _stream(cur)), "vamp_render_camera_forward")
+            _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(),
+            _capi.VAMP_CAMFWD_SAVE_SAMPLES if save else 0, _stream(cur)), "vamp_render_camera_forward_ex")
+        ctx.samples = save
         if side is not None:
             cur.wait_stream(side)
         ctx.hp, ctx.desc = hp, d
@@ -441,6 +453,8 @@ class _RenderFn(torch.autograd.Function):
         g_rgb, g_seg, g_dep, g_brgb, g_bseg, g_bh, g_vd, g_vo = map(
             cont, (g_rgb, g_seg, g_dep, g_brgb, g_bseg, g_bh, g_vd, g_vo))
         nbytes = hp.lib.vamp_render_workspace_bytes(C.byref(d))
+        if ctx.samples:
+            nbytes += hp.lib.vamp_render_samples_bytes(C.byref(d))
         ws = hp._workspace("render", nbytes)
         ws_bev = hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d)))
         gb = torch.zeros(base.shape, dtype=f32, device=dens.device)
@@ -462,6 +476,8 @@ class _RenderFn(torch.autograd.Function):
         packed_valid = 2 if ctx.pack_key == (getattr(hp, "_pack_gen", 0), ws.data_ptr()) else 0
         if packed_valid and ctx.cells:
             packed_valid |= 4                                    # VAMP_CAMBWD_CELLS_VALID
+        if packed_valid and ctx.samples and default_impl:
+            packed_valid |= _capi.VAMP_CAMBWD_SAMPLES_VALID
         hp._pack_gen = getattr(hp, "_pack_gen", 0) + 1          # the backward scribbles after the copy only,
         ctx.pack_key = None                                     # but a second backward must not assume so
         if side is not None and geom is None and default_impl:
