@@ -203,6 +203,25 @@ int vamp_render_camera_forward(const VampRenderDesc* d, const float* geom, const
  * in-kernel geometry (geom == NULL); otherwise the flag is ignored and the backward gathers.
  */
 #define VAMP_CAMFWD_SAVE_SAMPLES 1
+/*
+ * Early ray termination (geom == NULL only).  A ray's samples behind the point where its
+ * transmittance has fallen below exp(-18) = 1.5e-8 are dropped: together they weigh less than
+ * that in every output and gradient (the compositing weights telescope), three orders below the
+ * 1e-4 the outputs are held to, and with the reference's sdf density they are most of the inside
+ * samples.  vamp_render_camera_terminate marches the density channel alone and leaves the number
+ * of kept samples per ray in a table inside `workspace` (needs vamp_render_workspace_bytes(d));
+ * forward, prepare and backward take the table from there:
+ *   VAMP_CAMFWD_NO_ERT       march every sample (bit-identical to the v1 results)
+ *   VAMP_CAMFWD_TERM_VALID   the table is already in `workspace` (vamp_render_camera_terminate has
+ *                            run for these volumes / matrices / beta); otherwise the forward
+ *                            builds it first
+ */
+#define VAMP_CAMFWD_NO_ERT 2
+#define VAMP_CAMFWD_TERM_VALID 4
+int vamp_render_camera_terminate(const VampRenderDesc* d, const float* mats, const float* us,
+                                 const float* vs, const float* ds, const float* beta,
+                                 const void* density_feature, void* workspace, size_t workspace_bytes,
+                                 void* stream);
 size_t vamp_render_samples_bytes(const VampRenderDesc* d);
 int vamp_render_camera_forward_ex(const VampRenderDesc* d, const float* geom, const float* mats,
                                   const float* us, const float* vs, const float* ds,
@@ -249,6 +268,12 @@ int vamp_render_camera_backward(const VampRenderDesc* d, const float* geom, cons
 int vamp_render_camera_prepare(const VampRenderDesc* d, const float* mats, const float* us,
                                const float* vs, const float* ds, void* workspace,
                                size_t workspace_bytes, void* stream);
+/* flags: VAMP_CAMPREP_TERM_VALID -- sort only the samples the early-termination table in
+   `workspace` keeps (the backward must then be given VAMP_CAMBWD_TERM_VALID too) */
+#define VAMP_CAMPREP_TERM_VALID 1
+int vamp_render_camera_prepare_ex(const VampRenderDesc* d, const float* mats, const float* us,
+                                  const float* vs, const float* ds, void* workspace,
+                                  size_t workspace_bytes, int flags, void* stream);
 #define VAMP_CAMBWD_ACCUMULATE 1
 #define VAMP_CAMBWD_PACKED_VALID 2
 #define VAMP_CAMBWD_CELLS_VALID 4
@@ -258,6 +283,10 @@ int vamp_render_camera_prepare(const VampRenderDesc* d, const float* mats, const
 /* the workspace holds the sample rows of vamp_render_camera_forward_ex(VAMP_CAMFWD_SAVE_SAMPLES)
    for these same volumes / matrices and nothing has written to it since (cell-list path only) */
 #define VAMP_CAMBWD_SAMPLES_VALID 16
+/* early ray termination in the cell-list path: TERM_VALID = the table of the forward is in
+   `workspace`; without it the backward builds the table itself; NO_ERT = every sample */
+#define VAMP_CAMBWD_TERM_VALID 32
+#define VAMP_CAMBWD_NO_ERT 64
 int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, const float* mats,
                                     const float* us, const float* vs, const float* ds,
                                     const float* mids, const float* beta,

@@ -56,8 +56,9 @@ VAMP_PAD_ZEROS, VAMP_PAD_BORDER = 0, 1
 VAMP_LIFTBWD_CELLS_VALID, VAMP_LIFTBWD_SPLAT = 1, 2
 VAMP_LIFTBWD_WPP1, VAMP_LIFTBWD_WPP4, VAMP_LIFTBWD_WPP16 = 4, 8, 16
 VAMP_CAMBWD_ACCUMULATE, VAMP_CAMBWD_PACKED_VALID, VAMP_CAMBWD_CELLS_VALID, VAMP_CAMBWD_SPLAT = 1, 2, 4, 8
-VAMP_CAMBWD_SAMPLES_VALID = 16
-VAMP_CAMFWD_SAVE_SAMPLES = 1
+VAMP_CAMBWD_SAMPLES_VALID, VAMP_CAMBWD_TERM_VALID, VAMP_CAMBWD_NO_ERT = 16, 32, 64
+VAMP_CAMFWD_SAVE_SAMPLES, VAMP_CAMFWD_NO_ERT, VAMP_CAMFWD_TERM_VALID = 1, 2, 4
+VAMP_CAMPREP_TERM_VALID = 1
 
 _P = C.c_void_p
 _LD = C.POINTER(VampLiftDesc)
@@ -85,6 +86,8 @@ SIGNATURES = {
     "vamp_render_workspace_bytes": (C.c_size_t, [_RD]),
     "vamp_render_camera_forward": (C.c_int, [_RD] + [_P] * 13 + [_P, C.c_size_t, _P]),
     "vamp_render_samples_bytes": (C.c_size_t, [_RD]),
+    "vamp_render_camera_terminate": (C.c_int, [_RD] + [_P] * 6 + [_P, C.c_size_t, _P]),
+    "vamp_render_camera_prepare_ex": (C.c_int, [_RD] + [_P] * 4 + [_P, C.c_size_t, C.c_int, _P]),
     "vamp_render_camera_forward_ex": (C.c_int, [_RD] + [_P] * 13 + [_P, C.c_size_t, C.c_int, _P]),
     "vamp_render_camera_backward": (C.c_int, [_RD] + [_P] * 17 + [_P, C.c_size_t, _P]),
     "vamp_render_camera_prepare": (C.c_int, [_RD] + [_P] * 4 + [_P, C.c_size_t, _P]),

@@ -110,6 +110,12 @@ __device__ __forceinline__ PlanMask plan_mask(const int4* __restrict__ plan) {
   return mk;
 }
 
+// drop the depth indices >= n (early ray termination: the tile is done there)
+__device__ __forceinline__ void mask_truncate(PlanMask& mk, int n) {
+  if (n < 64) { mk.lo &= (n <= 0) ? 0ull : (~0ull >> (64 - n)); mk.hi = 0ull; }
+  else if (n < 128) mk.hi &= (n == 64) ? 0ull : (~0ull >> (128 - n));
+}
+
 __device__ __forceinline__ bool mask_test(const PlanMask& mk, int j) {
   return (((j < 64) ? (mk.lo >> j) : (mk.hi >> (j - 64))) & 1ull) != 0;
 }

@@ -16,17 +16,16 @@ namespace vamp {
 
 int launch_pack(const RenderParams& P, int in_dtype, const void* dens, const void* sem,
                 const void* rgb, float* packed, hipStream_t s);
-size_t packed_bytes(const VampRenderDesc* d);
-size_t cam_bwd_v2_bytes(const VampRenderDesc* d);
 int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                       const float* us, const float* vs, const float* ds, const float* mids,
                       const float* beta, const float* packed, const float* g_rgb,
                       const float* g_seg, const float* g_depth, float* gdens, float* gsem,
                       float* grgb, float* grad_beta, void* scratch, int accumulate,
-                      hipEvent_t wait_event, bool cells_valid, const float* samples, hipStream_t s);
+                      hipEvent_t wait_event, bool cells_valid, const float* samples, const int* term,
+                      hipStream_t s);
 int launch_cam_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                        const float* us, const float* vs, const float* ds, void* scratch,
-                       hipStream_t s);
+                       const int* term, hipStream_t s);
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
   // wave reduce then 4-wave LDS reduce; result valid in thread 0
@@ -348,6 +347,12 @@ extern "C" {
 int vamp_render_camera_prepare(const VampRenderDesc* d, const float* mats, const float* us,
                                const float* vs, const float* ds, void* workspace,
                                size_t workspace_bytes, void* stream) {
+  return vamp_render_camera_prepare_ex(d, mats, us, vs, ds, workspace, workspace_bytes, 0, stream);
+}
+
+int vamp_render_camera_prepare_ex(const VampRenderDesc* d, const float* mats, const float* us,
+                                  const float* vs, const float* ds, void* workspace,
+                                  size_t workspace_bytes, int flags, void* stream) {
   if (int e = validate(d)) return e;
   VAMP_REQUIRE(mats && us && vs && ds, "null pointer");
   const size_t need = vamp_render_workspace_bytes(d);
@@ -355,6 +360,7 @@ int vamp_render_camera_prepare(const VampRenderDesc* d, const float* mats, const
     return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) need);
   const RenderParams P = to_params(d);
   return launch_cam_prepare(d, P, mats, us, vs, ds, static_cast<char*>(workspace) + packed_bytes(d),
+                            (flags & VAMP_CAMPREP_TERM_VALID) ? cam_term_ptr(d, workspace) : nullptr,
                             static_cast<hipStream_t>(stream));
 }
 
@@ -409,10 +415,20 @@ int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, 
         return fail(VAMP_ENOSPC, "%s: workspace %ld has no room for the sample rows", __func__, (long) workspace_bytes);
       samples = reinterpret_cast<const float*>(static_cast<char*>(workspace) + need);
     }
+    // early ray termination: the table of the forward (TERM_VALID), or computed here; the cell
+    // lists must have been prepared with the same table
+    int* term = nullptr;
+    if (!(flags & VAMP_CAMBWD_NO_ERT)) {
+      term = cam_term_ptr(d, workspace);
+      if (!(flags & VAMP_CAMBWD_TERM_VALID)) {
+        VAMP_REQUIRE(!(flags & VAMP_CAMBWD_CELLS_VALID), "CELLS_VALID with early termination needs TERM_VALID");
+        if (int e = launch_cam_term(d, P, mats, us, vs, ds, beta, density_feature, term, s)) return e;
+      }
+    }
     return launch_cam_bwd_v2(d, P, mats, us, vs, ds, mids, beta, packed, g_rgb, g_seg, g_depth,
                              grad_density_feature, grad_semantic, grad_rgb, grad_beta, gpacked,
                              accumulate, static_cast<hipEvent_t>(wait_event),
-                             (flags & VAMP_CAMBWD_CELLS_VALID) != 0, samples, s);
+                             (flags & VAMP_CAMBWD_CELLS_VALID) != 0, samples, term, s);
   }
   VAMP_REQUIRE(!accumulate && !wait_event, "accumulate / wait_event need the cell-list path");
   {

@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256)
 cam_cells_rank_kernel(RenderParams P, const float* __restrict__ mats, const float* __restrict__ us,
                       const float* __restrict__ vs, const float* __restrict__ ds,
                       int* __restrict__ cnt, int* __restrict__ KEY, int* __restrict__ RANK,
-                      unsigned samples, long ncell_b) {
+                      unsigned samples, long ncell_b, const int* __restrict__ term) {
   const unsigned sidx = blockIdx.x * 256u + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const unsigned HW = (unsigned) (P.fH * P.fW), S = (unsigned) (P.D - 1);
@@ -56,10 +56,19 @@ cam_cells_rank_kernel(RenderParams P, const float* __restrict__ mats, const floa
   const unsigned rem = sc % (S * HW);
   const unsigned i = rem / HW, pix = rem % HW;
   const unsigned h = pix / (unsigned) P.fW, w = pix % (unsigned) P.fW;
-  float x, y, z;
-  frustum_point(mats + (long) bn * 48, us[w], vs[h], ds[i], x, y, z);
-  const VolTap tp = volume_tap(P, nan_to_num_geom(x), nan_to_num_geom(y), nan_to_num_geom(z));
-  const bool valid = sidx < samples && tp.inside;
+  // early ray termination (render_common.hpp): samples from index term[ray] on carry no record;
+  // a wave (64 neighbouring pixels at one depth index) with none left skips the chain
+  const bool kept = sidx < samples && (!term || (int) i < term[bn * HW + pix]);
+  bool inside = false;
+  VolTap tp;
+  tp.ix0 = tp.iy0 = tp.iz0 = 0;
+  if (__ballot(kept) != 0ull) {
+    float x, y, z;
+    frustum_point(mats + (long) bn * 48, us[w], vs[h], ds[i], x, y, z);
+    tp = volume_tap(P, nan_to_num_geom(x), nan_to_num_geom(y), nan_to_num_geom(z));
+    inside = tp.inside;
+  }
+  const bool valid = kept && inside;
   const int key = valid ? pack_cell_key(tp.ix0, tp.iy0, tp.iz0) : 0;
   const long cell = sample_cell(P, key, bn / (unsigned) P.N, ncell_b);
   const LaneRun r = lane_run(valid, cell, lane);
@@ -299,7 +308,7 @@ float4* cam_cell_records(const VampRenderDesc* d, void* scratch) { return cell_w
 // rank -> scan -> slot.  Depends on (d, mats, us, vs, ds) only.
 int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                              const float* us, const float* vs, const float* ds, void* scratch,
-                             hipStream_t s) {
+                             const int* term, hipStream_t s) {
   const CellWs w = cell_ws(d, scratch);
   const long ncell = cell_count_padded(d->B, d->Z, d->Y, d->X);
   const size_t samples = (size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW;
@@ -311,7 +320,7 @@ int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, con
     return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
   const unsigned sgrid = (unsigned) ((samples + 255) / 256);
   VAMP_TIMED(kProfCamBwdCount, s, (cam_cells_rank_kernel<<<sgrid, 256, 0, s>>>(
-      P, mats, us, vs, ds, w.cnt, w.key, w.slot, (unsigned) samples, ncell_b)));
+      P, mats, us, vs, ds, w.cnt, w.key, w.slot, (unsigned) samples, ncell_b, term)));
   if (int e = check_launch("cam_cells_rank_kernel")) return e;
   if (int e = launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, ncell, s)) return e;
   VAMP_TIMED(kProfCamBwdFill, s, (cam_cells_slot_kernel<<<sgrid, 256, 0, s>>>(

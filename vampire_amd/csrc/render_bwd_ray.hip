@@ -26,7 +26,7 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
                    const float* __restrict__ g_seg, const float* __restrict__ g_depth,
                    const int* __restrict__ SLOT, float4* __restrict__ REC,
                    float* __restrict__ Gcl, float* __restrict__ beta_part,
-                   const float* __restrict__ samples, int L) {
+                   const float* __restrict__ samples, const int* __restrict__ term, int L) {
   constexpr int CP = CP4 * 4;
   extern __shared__ float lds[];              // [3][L][256]: s0, delta (sign = no-grad flag), q
   __shared__ float red[4];
@@ -45,7 +45,14 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
   const long ray = (bn * P.fH + h) * P.fW + w;
   const DensityParams dp = load_density(P.density_mode, beta_raw, P.beta_min, P.sdf_bias);
   const int S = P.D - 1;
-  const int i0 = min(S, sub * L), i1 = min(S, i0 + L);
+  // early ray termination: this ray's samples from index `keep` on are dropped (they have no
+  // record either: render_bwd_cell.hip), and the tile's four waves share its first Se indices
+  const int keep = term ? term[ray] : S;
+  int Se = keep;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) Se = max(Se, __shfl_xor(Se, o, 64));
+  const int Le = term ? (Se + LPR - 1) / LPR : L;
+  const int i0 = min(Se, sub * Le), i1 = min(Se, i0 + Le);
   const float* m = mats + bn * 48;
   const float u = us[w], v = vs[h];
   const long V = (long) P.Z * P.Y * P.X;
@@ -83,7 +90,8 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
     // ahead of the gather so that its latency hides behind it
     const int slot = SLOT[((bn * S + i) * P.fH + h) * P.fW + w];
     point(i + 1, qx, qy, qz);
-    const VolTap tp = volume_tap(P, px, py, pz);
+    VolTap tp = volume_tap(P, px, py, pz);
+    tp.inside = tp.inside && i < keep;
     float s[CP];
 #pragma unroll
     for (int c = 0; c < CP; ++c) s[c] = 0.f;
@@ -203,7 +211,7 @@ const int* cam_cell_slots(const VampRenderDesc* d, void* scratch);
 float4* cam_cell_records(const VampRenderDesc* d, void* scratch);
 int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                              const float* us, const float* vs, const float* ds, void* scratch,
-                             hipStream_t s);
+                             const int* term, hipStream_t s);
 int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const float* Gcl,
                         float* gdens, float* gsem, float* grgb, void* scratch, int accumulate,
                         hipEvent_t wait_event, hipStream_t s);
@@ -222,8 +230,8 @@ size_t cam_bwd_v2_bytes(const VampRenderDesc* d) { return gcl_bytes(d) + cam_bwd
 // scratch = workspace region after the packed volume: [Gcl | cell lists | beta partials]
 int launch_cam_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                        const float* us, const float* vs, const float* ds, void* scratch,
-                       hipStream_t s) {
-  return launch_cam_cells_prepare(d, P, mats, us, vs, ds, static_cast<char*>(scratch) + gcl_bytes(d), s);
+                       const int* term, hipStream_t s) {
+  return launch_cam_cells_prepare(d, P, mats, us, vs, ds, static_cast<char*>(scratch) + gcl_bytes(d), term, s);
 }
 
 int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const float* mats,
@@ -231,12 +239,13 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
                       const float* beta, const float* packed, const float* g_rgb,
                       const float* g_seg, const float* g_depth, float* gdens, float* gsem,
                       float* grgb, float* grad_beta, void* scratch, int accumulate,
-                      hipEvent_t wait_event, bool cells_valid, const float* samples, hipStream_t s) {
+                      hipEvent_t wait_event, bool cells_valid, const float* samples, const int* term,
+                      hipStream_t s) {
   float* Gcl = static_cast<float*>(scratch);
   void* cell_scratch = static_cast<char*>(scratch) + gcl_bytes(d);
   // the sample -> slot table depends on the geometry only; the caller may have prepared it
   if (!cells_valid)
-    if (int e = launch_cam_cells_prepare(d, P, mats, us, vs, ds, cell_scratch, s)) return e;
+    if (int e = launch_cam_cells_prepare(d, P, mats, us, vs, ds, cell_scratch, term, s)) return e;
   const int* SLOT = cam_cell_slots(d, cell_scratch);
   float4* R = cam_cell_records(d, cell_scratch);
   float* beta_part = reinterpret_cast<float*>(static_cast<char*>(cell_scratch) + cam_bwd_cell_bytes(d));
@@ -256,7 +265,7 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
       return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);                           \
     VAMP_TIMED(kProfCamBwd, s, (kr<<<grid, 256, lds, s>>>(P, mats, us, vs, ds, mids, beta, packed, \
                                                            g_rgb, g_seg, g_depth, SLOT, R, Gcl,   \
-                                                           beta_part, samples, L)));              \
+                                                           beta_part, samples, term, L)));        \
   } while (0)
   if (P.CP == 12) VAMP_RAY(3); else if (P.CP == 24) VAMP_RAY(6); else VAMP_RAY(8);
 #undef VAMP_RAY

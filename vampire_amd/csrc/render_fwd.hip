@@ -168,6 +168,85 @@ render_cam_fwd_kernel(RenderParams P, const float* __restrict__ geom, const floa
 
 
 // ---------------------------------------------------------------------------
+// early ray termination table (render_common.hpp): one wave per 8 x 8 ray tile marches the
+// density channel only -- 8 taps of 4 bytes from the channel-first density volume, 2.5 MB at
+// cfg-B, instead of 8 x 96 -- front to back and stops as soon as all 64 rays are saturated
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(64)
+cam_term_kernel(RenderParams P, const float* __restrict__ mats, const float* __restrict__ us,
+                const float* __restrict__ vs, const float* __restrict__ ds,
+                const float* __restrict__ beta_raw, const T* __restrict__ dens, int* __restrict__ term) {
+  const RayId id = decode_ray_wps(P);
+  const long bn = __builtin_amdgcn_readfirstlane((int) id.bn);
+  const int b = __builtin_amdgcn_readfirstlane(id.b);
+  const DensityParams dp = load_density(P.density_mode, beta_raw, P.beta_min, P.sdf_bias);
+  const int S = P.D - 1;
+  const float* m = mats + bn * 48;
+  const float u = us[id.w], v = vs[id.h];
+  const long V = (long) P.Z * P.Y * P.X;
+  const T* vol = dens + (long) b * V;
+  auto point = [&](int i, float& x, float& y, float& z) {
+    frustum_point(m, u, v, ds[i], x, y, z);
+    x = nan_to_num_geom(x); y = nan_to_num_geom(y); z = nan_to_num_geom(z);
+  };
+  float px, py, pz, qx, qy, qz;
+  point(0, px, py, pz);
+  float cum = 0.f;
+  int keep = S;
+  bool done = false, entered = false;
+  const float sigma_out = density_fwd(dp, 0.f);
+  for (int i = 0; i < S; ++i) {
+    point(i + 1, qx, qy, qz);
+    const VolTap tp = volume_tap(P, px, py, pz);
+    const float dx = qx - px, dy = qy - py, dz = qz - pz;
+    const float delta = sqrtf(dx * dx + dy * dy + dz * dz);
+    if (!done && entered && !tp.inside) {
+      // the ray has left the (convex) volume: every further sample is masked and adds the same
+      // density(0) * delta, so the index at which the ray saturates -- if ever -- is known
+      const float tau = sigma_out * delta;
+      const float k = (tau > 0.f) ? ceilf((kTermOpticalDepth - cum) / tau) : 3.0e9f;
+      keep = (k < (float) (S - i)) ? i + (int) k : S;
+      done = true;
+    }
+    entered = entered || tp.inside;
+    float s0 = 0.f;
+    if (tp.inside) {
+      const int x1 = min(tp.ix0 + 1, P.X - 1), y1 = min(tp.iy0 + 1, P.Y - 1), z1 = min(tp.iz0 + 1, P.Z - 1);
+      const float wx1 = (tp.ix0 + 1 < P.X) ? tp.wx1 : 0.f, wy1 = (tp.iy0 + 1 < P.Y) ? tp.wy1 : 0.f;
+      const float wz1 = (tp.iz0 + 1 < P.Z) ? tp.wz1 : 0.f;
+      const long r00 = ((long) tp.iz0 * P.Y + tp.iy0) * P.X, r01 = ((long) tp.iz0 * P.Y + y1) * P.X;
+      const long r10 = ((long) z1 * P.Y + tp.iy0) * P.X, r11 = ((long) z1 * P.Y + y1) * P.X;
+      const float a00 = tp.wx0 * ldf(vol, r00 + tp.ix0) + wx1 * ldf(vol, r00 + x1);
+      const float a01 = tp.wx0 * ldf(vol, r01 + tp.ix0) + wx1 * ldf(vol, r01 + x1);
+      const float a10 = tp.wx0 * ldf(vol, r10 + tp.ix0) + wx1 * ldf(vol, r10 + x1);
+      const float a11 = tp.wx0 * ldf(vol, r11 + tp.ix0) + wx1 * ldf(vol, r11 + x1);
+      s0 = nan_to_num(tp.wz0 * (tp.wy0 * a00 + wy1 * a01) + wz1 * (tp.wy0 * a10 + wy1 * a11));
+    }
+    cum += density_fwd(dp, s0) * delta;
+    // samples 0 .. i are kept; the optical depth in front of sample i + 1 is `cum`
+    if (!done && !(cum < kTermOpticalDepth)) { keep = i + 1; done = true; }
+    if (__ballot(!done) == 0ull) break;
+    px = qx; py = qy; pz = qz;
+  }
+  if (id.live) term[(bn * P.fH + id.h) * P.fW + id.w] = keep;
+}
+
+int launch_cam_term(const VampRenderDesc* d, const RenderParams& P, const float* mats, const float* us,
+                    const float* vs, const float* ds, const float* beta, const void* density_feature,
+                    int* term, hipStream_t s) {
+  const long tiles = (long) P.B * P.N * ((P.fH + 7) / 8) * ((P.fW + 7) / 8);
+  const unsigned grid = (unsigned) ((tiles + 7) / 8 * 8);
+  if (d->in_dtype == VAMP_F32)
+    VAMP_TIMED(kProfCamTerm, s, (cam_term_kernel<float><<<grid, 64, 0, s>>>(
+        P, mats, us, vs, ds, beta, static_cast<const float*>(density_feature), term)));
+  else
+    VAMP_TIMED(kProfCamTerm, s, (cam_term_kernel<__hip_bfloat16><<<grid, 64, 0, s>>>(
+        P, mats, us, vs, ds, beta, static_cast<const __hip_bfloat16*>(density_feature), term)));
+  return check_launch("cam_term_kernel");
+}
+
+// ---------------------------------------------------------------------------
 // camera branch forward with a per-tile plan (geometry evaluated from the matrices)
 // ---------------------------------------------------------------------------
 // SAVE: also store the gathered row of every inside sample at samples[((bn * S + i) * fH + h) * fW + w]
@@ -179,7 +258,7 @@ render_cam_fwd_plan_kernel(RenderParams P, const float* __restrict__ mats, const
                            const float* __restrict__ mids, const float* __restrict__ beta_raw,
                            const float* __restrict__ packed, float* __restrict__ rgb_out,
                            float* __restrict__ seg_out, float* __restrict__ depth_out,
-                           float* __restrict__ samples) {
+                           float* __restrict__ samples, const int* __restrict__ term) {
   constexpr int CP = CP4 * 4;
   __shared__ float xmerge[4 * (CP + 2) * 64];
   __shared__ int4 plan[kPlanMax];
@@ -202,9 +281,17 @@ render_cam_fwd_plan_kernel(RenderParams P, const float* __restrict__ mats, const
   plan_tile(P, m, us, vs, ds, __builtin_amdgcn_readlane(w, 0), __builtin_amdgcn_readlane(w, 63),
             __builtin_amdgcn_readlane(h, 0), __builtin_amdgcn_readlane(h, 63), sub, plan);
   __syncthreads();
-  const PlanMask mk = plan_mask(plan);
+  PlanMask mk = plan_mask(plan);
+  // early ray termination: this ray's samples from index `keep` on are dropped, and the tile is
+  // done at the largest `keep` of its 64 rays
+  const int keep = term ? term[(bn * P.fH + h) * P.fW + w] : S;
+  int Se = keep;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) Se = max(Se, __shfl_xor(Se, o, 64));
+  Se = __builtin_amdgcn_readfirstlane(Se);
+  mask_truncate(mk, Se);
   int i0, i1;
-  plan_share(mk, S, sub, i0, i1);
+  plan_share(mk, Se, sub, i0, i1);
 
   auto point = [&](int i, float& x, float& y, float& z) {
     frustum_point(m, u, v, ds[i], x, y, z);
@@ -244,7 +331,8 @@ render_cam_fwd_plan_kernel(RenderParams P, const float* __restrict__ mats, const
       jn = mask_next(mk, i + 1);
       if (!have_p) point(i, px, py, pz);
       point(i + 1, qx, qy, qz);
-      const VolTap tp = volume_tap(P, px, py, pz);
+      VolTap tp = volume_tap(P, px, py, pz);
+      tp.inside = tp.inside && i < keep;
       float s[CP];
 #pragma unroll
       for (int c = 0; c < CP; ++c) s[c] = 0.f;
@@ -391,7 +479,6 @@ int launch_pack(const RenderParams& P, int in_dtype, const void* dens, const voi
 using namespace vamp;
 
 namespace vamp {
-size_t cam_bwd_v2_bytes(const VampRenderDesc* d);
 size_t packed_bytes(const VampRenderDesc* d) {
   const RenderParams P = to_params(d);
   return align_up((size_t) d->B * d->Z * d->Y * d->X * P.CP * sizeof(float), 256);
@@ -403,9 +490,23 @@ extern "C" {
 
 size_t vamp_render_workspace_bytes(const VampRenderDesc* d) {
   if (!d) return 0;
-  // packed volume + backward scratch (v1: packed gradient volume; v2: per-sample buffers)
-  const size_t pb = packed_bytes(d), v2 = cam_bwd_v2_bytes(d);
-  return pb + (pb > v2 ? pb : v2);
+  // packed volume + backward scratch (v1: packed gradient volume; v2: per-sample buffers) + the
+  // per-ray early-termination table
+  return render_base_bytes(d) + cam_term_bytes(d);
+}
+
+int vamp_render_camera_terminate(const VampRenderDesc* d, const float* mats, const float* us,
+                                 const float* vs, const float* ds, const float* beta,
+                                 const void* density_feature, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  if (int e = validate(d)) return e;
+  VAMP_REQUIRE(mats && us && vs && ds && density_feature, "null pointer");
+  VAMP_REQUIRE(beta || d->density_mode == VAMP_DENSITY_SIGMOID, "beta is NULL");
+  const size_t need = vamp_render_workspace_bytes(d);
+  if (!workspace || workspace_bytes < need)
+    return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) need);
+  return launch_cam_term(d, to_params(d), mats, us, vs, ds, beta, density_feature, cam_term_ptr(d, workspace),
+                         static_cast<hipStream_t>(stream));
 }
 
 size_t vamp_render_samples_bytes(const VampRenderDesc* d) {
@@ -437,7 +538,9 @@ int vamp_render_camera_forward_ex(const VampRenderDesc* d, const float* geom, co
   VAMP_REQUIRE(beta || d->density_mode == VAMP_DENSITY_SIGMOID, "beta is NULL");
   const bool planned = !geom && d->D - 1 <= kPlanMax;
   const bool save = (flags & VAMP_CAMFWD_SAVE_SAMPLES) && planned;
-  const size_t need = save ? vamp_render_workspace_bytes(d) + vamp_render_samples_bytes(d) : packed_bytes(d);
+  const bool ert = planned && !(flags & VAMP_CAMFWD_NO_ERT);
+  const size_t need = save ? vamp_render_workspace_bytes(d) + vamp_render_samples_bytes(d)
+                           : (ert ? vamp_render_workspace_bytes(d) : packed_bytes(d));
   if (!workspace || workspace_bytes < need)
     return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) need);
   const RenderParams P = to_params(d);
@@ -445,6 +548,9 @@ int vamp_render_camera_forward_ex(const VampRenderDesc* d, const float* geom, co
   float* packed = static_cast<float*>(workspace);
   float* samples = save ? reinterpret_cast<float*>(static_cast<char*>(workspace) + vamp_render_workspace_bytes(d))
                         : nullptr;
+  int* term = ert ? cam_term_ptr(d, workspace) : nullptr;
+  if (ert && !(flags & VAMP_CAMFWD_TERM_VALID))
+    if (int e = launch_cam_term(d, P, mats, us, vs, ds, beta, density_feature, term, s)) return e;
   if (int e = launch_pack(P, d->in_dtype, density_feature, semantic, rgb, packed, s)) return e;
   constexpr int LPR = 4;
   const unsigned grid = ray_grid<LPR>(P);
@@ -454,10 +560,10 @@ int vamp_render_camera_forward_ex(const VampRenderDesc* d, const float* geom, co
   do {                                                                                     \
     if (samples)                                                                           \
       VAMP_TIMED(kProfCamFwd, s, (render_cam_fwd_plan_kernel<CP4, true><<<grid, 256, 0, s>>>(  \
-          P, mats, us, vs, ds, mids, beta, packed, rgb_out, seg_out, depth_out, samples)));    \
+          P, mats, us, vs, ds, mids, beta, packed, rgb_out, seg_out, depth_out, samples, term)));    \
     else                                                                                   \
       VAMP_TIMED(kProfCamFwd, s, (render_cam_fwd_plan_kernel<CP4, false><<<grid, 256, 0, s>>>( \
-          P, mats, us, vs, ds, mids, beta, packed, rgb_out, seg_out, depth_out, nullptr)));    \
+          P, mats, us, vs, ds, mids, beta, packed, rgb_out, seg_out, depth_out, nullptr, term)));    \
   } while (0)
     if (P.CP == 12) VAMP_CAMP(3); else if (P.CP == 24) VAMP_CAMP(6); else VAMP_CAMP(8);
 #undef VAMP_CAMP

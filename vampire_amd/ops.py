@@ -92,6 +92,8 @@ class HotPath:
                      # neutral at cfg-B (forward +50 us for the scattered row stores, backward -59 us),
                      # so off unless asked for
                      "save_samples": os.environ.get("VAMP_SAVE_SAMPLES", "0") == "1",
+                     # early ray termination in the camera branch (include/vampire_hip.h)
+                     "ert": os.environ.get("VAMP_ERT", "1") != "0",
                      "prepare": os.environ.get("VAMP_PREPARE", "1") != "0"}
 
     # ---------------------------------------------------------------- descs
@@ -413,14 +415,24 @@ class _RenderFn(torch.autograd.Function):
         # the two branches share only their inputs: BEV on the side stream, camera on this one
         cur, side = torch.cuda.current_stream(), hp._side_stream()
         ctx.cells = False
+        ert = geom is None and hp.impl["ert"]
+        fwd_flags = 0 if ert else _capi.VAMP_CAMFWD_NO_ERT
+        if ert:
+            # the per-ray termination table first: forward, the backward's sort and its per-ray pass
+            # all read it from the workspace
+            _capi.check(hp.lib.vamp_render_camera_terminate(
+                C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(beta), _ptr(dens), _ptr(ws),
+                ws.numel(), _stream(cur)), "vamp_render_camera_terminate")
+            fwd_flags |= _capi.VAMP_CAMFWD_TERM_VALID
+        ctx.ert = ert
         if side is not None:
             side.wait_stream(cur)
             if any(ctx.needs_input_grad) and geom is None and hp.impl["prepare"] and hp.impl["cam_bwd"] != "v1":
-                # the sample -> cell-slot table of the backward depends on the geometry only: it is
-                # built here, on the side stream, beside the forward kernels
-                _capi.check(hp.lib.vamp_render_camera_prepare(
+                # the sample -> cell-slot table of the backward depends on the geometry (and the
+                # termination table) only: it is built here, on the side stream, beside the forward
+                _capi.check(hp.lib.vamp_render_camera_prepare_ex(
                     C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(),
-                    _stream(side)), "vamp_render_camera_prepare")
+                    _capi.VAMP_CAMPREP_TERM_VALID if ert else 0, _stream(side)), "vamp_render_camera_prepare_ex")
                 ctx.cells = True
         _capi.check(hp.lib.vamp_render_bev_forward(
             C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
@@ -430,7 +442,8 @@ class _RenderFn(torch.autograd.Function):
             C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
             _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
             _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(),
-            _capi.VAMP_CAMFWD_SAVE_SAMPLES if save else 0, _stream(cur)), "vamp_render_camera_forward_ex")
+            fwd_flags | (_capi.VAMP_CAMFWD_SAVE_SAMPLES if save else 0), _stream(cur)),
+            "vamp_render_camera_forward_ex")
         ctx.samples = save
         if side is not None:
             cur.wait_stream(side)
@@ -478,6 +491,12 @@ class _RenderFn(torch.autograd.Function):
             packed_valid |= 4                                    # VAMP_CAMBWD_CELLS_VALID
         if packed_valid and ctx.samples and default_impl:
             packed_valid |= _capi.VAMP_CAMBWD_SAMPLES_VALID
+        if not ctx.ert:
+            packed_valid |= _capi.VAMP_CAMBWD_NO_ERT
+        elif packed_valid:
+            packed_valid |= _capi.VAMP_CAMBWD_TERM_VALID           # same validity as the packed copy
+        else:
+            packed_valid &= ~4                                      # no table: the cells are rebuilt with a fresh one
         hp._pack_gen = getattr(hp, "_pack_gen", 0) + 1          # the backward scribbles after the copy only,
         ctx.pack_key = None                                     # but a second backward must not assume so
         if side is not None and geom is None and default_impl:
