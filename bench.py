@@ -54,6 +54,7 @@ def kernel_algorithmic_bytes(cfg, B):
         "lift_bwd_gather": B * (4 * P * C + 4 * P * (D + C)),     # feat in, grad_depth / grad_feat out
         "pack_volume": B * (4 * cam * V),                         # the three volumes in
         "render_cam_fwd": B * (4 * cam * V + 4 * P * (K + 4)),
+        "render_cam_term": B * (4 * V + 4 * P),                   # density volume in, one int per ray out
         "render_bev_fwd": B * (4 * V * zf + 4 * YX * (oZ + 1)),
         "render_bev_fwd_channels": B * (4 * (K + 3 + C) * V * zf + 4 * YX * (K + 3) + 4 * oZ * YX * CO),
         "render_cam_bwd_ray": B * (4 * cam * V + 4 * P * (K + 4)),  # volumes + upstream gradients in
@@ -66,7 +67,7 @@ def kernel_algorithmic_bytes(cfg, B):
 
 STAGES = {   # SURVEY.md section 8(d) stage names -> kernels of this build
     "lift_fwd": ["feat_to_channel_last", "lift_fwd"],
-    "render_fwd": ["pack_volume", "render_cam_fwd", "render_bev_fwd", "render_bev_fwd_channels"],
+    "render_fwd": ["pack_volume", "render_cam_term", "render_cam_fwd", "render_bev_fwd", "render_bev_fwd_channels"],
     "lift_bwd": ["lift_bwd_count", "lift_bwd_fill", "lift_bwd_gather", "lift_bwd_v1", "feat_to_channel_first"],
     "render_bwd": ["render_cam_bwd_ray", "render_cam_bwd_rank", "render_cam_bwd_fill", "render_cam_bwd_gather",
                    "render_cam_bwd_heavy", "render_cam_bwd_v1", "render_bev_bwd_q", "render_bev_bwd_scan",
@@ -155,14 +156,21 @@ def forward_pair_us(model, batch, iters=100, warm=20):
     return ts[len(ts) // 2], ts[len(ts) // 10], ts[(9 * len(ts)) // 10]
 
 
-def extra_config(cfg_name, batch, dtype, steps=10, warm=3):
+def extra_config(cfg_name, batch, dtype, steps=10, warm=3, ert=True, density_mode=None):
     """A secondary configuration, measured the same way as the headline (fwd+bwd step time with a
-    barrier-free single-rank loop) plus its forward pair: driver-observed rather than README prose."""
+    barrier-free single-rank loop) plus its forward pair: driver-observed rather than README prose.
+    `ert=False` switches the camera branch's early ray termination off (every sample marched);
+    `density_mode="naive"` is the sigmoid density, under which no ray saturates on this data (the
+    worst case for that optimisation)."""
+    import dataclasses
     from vampire_amd.config import PRESETS
     from vampire_amd.step import LiftRenderStep, SyntheticBatch, train_step
     cfg = PRESETS[cfg_name]
+    if density_mode is not None:
+        cfg = dataclasses.replace(cfg, density_mode=density_mode)
     dev = torch.device("cuda", torch.cuda.current_device())
     model = LiftRenderStep(cfg, dev)
+    model.hp.impl["ert"] = ert
     data = SyntheticBatch(cfg, batch, dev, seed=1, dtype=dtype)
     for _ in range(warm):
         model.zero_grad(set_to_none=True); train_step(model, data)
@@ -174,7 +182,9 @@ def extra_config(cfg_name, batch, dtype, steps=10, warm=3):
     ms = (time.perf_counter() - t0) / steps * 1e3
     fwd_us, _, _ = forward_pair_us(model, data, iters=30, warm=5)
     ab = cfg.algorithmic_bytes(4 if dtype == torch.float32 else 2)
-    return {"workload": f"cfg-{cfg_name}, {batch} sample(s)/GPU/step, {'f32' if dtype == torch.float32 else 'bf16'} inputs",
+    return {"workload": f"cfg-{cfg_name}, {batch} sample(s)/GPU/step, {'f32' if dtype == torch.float32 else 'bf16'} inputs"
+                        + ("" if ert else ", early ray termination OFF")
+                        + ("" if density_mode is None else f", density_mode={density_mode}"),
             "samples_per_s": batch / (ms * 1e-3), "ms_per_step": ms, "fwd_us": fwd_us,
             "fwd_frac_of_hbm_peak": ab["fwd"] * batch / (fwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
@@ -266,11 +276,15 @@ def main():
     # the dominant kernel: measured over the timed region
     prof.update({k: (n, ms, a.steps) for k, (n, ms) in _capi.profile_read().items()})
     if rank == 0:
-        kern = {k: {"launches": n, "avg_us": ms / n * 1e3, "us_per_step": ms / st * 1e3}
+        kern = {k: {"launches": n, "avg_us": ms / n * 1e3, "us_per_step": ms / st * 1e3,
+                    "launches_per_step": n / st}
                 for k, (n, ms, st) in prof.items()}
         if dom is None:
-            dom = max((k for k in kern if k in alg), key=lambda k: kern[k]["avg_us"])
-        dom_gbs = alg[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e9
+            dom = max((k for k in kern if k in alg), key=lambda k: kern[k]["us_per_step"])
+        # `alg` holds the bytes of all launches of a kernel name in one step (the BEV gather runs
+        # once per channel kind): per launch = alg / launches per step, over the average launch
+        dom_alg_launch = alg[dom] / kern[dom]["launches_per_step"]
+        dom_gbs = dom_alg_launch / (kern[dom]["avg_us"] * 1e-6) / 1e9
         # stage view with SURVEY.md section 8(d)'s algorithmic bytes: kernel time per step, summed
         # (with the two render branches on two streams the stage's wall time is below this sum)
         sb = cfg.algorithmic_bytes(4 if a.dtype == "f32" else 2)
@@ -295,14 +309,17 @@ def main():
             "config": {"workload": f"cfg-{a.cfg}: 6x{cfg.final_dim[0]}x{cfg.final_dim[1]} images, "
                                    f"D={cfg.D} C={cfg.mid_channels} K={cfg.num_classes}, voxel grid "
                                    f"{cfg.vX}x{cfg.vY}x{cfg.vZ}, det grid {cfg.oX}x{cfg.oY}x{cfg.oZ}, "
-                                   f"{a.batch} sample(s)/GPU/step, lift+render fwd+bwd",
+                                   f"{a.batch} sample(s)/GPU/step, lift+render fwd+bwd, density_mode={cfg.density_mode} "
+                                   f"(the reference's default), camera-branch early ray termination "
+                                   f"{'on' if model.hp.impl['ert'] else 'off'} (T < 1.5e-8)",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"dp{world}"},
             "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": dom_gbs / HBM_PEAK_GBS,
                          "traffic": measured_traffic(a.cfg, dom, a.batch),
-                         "algorithmic_bytes_per_launch": alg[dom],
+                         "algorithmic_bytes_per_launch": dom_alg_launch,
+                         "launches_per_step": kern[dom]["launches_per_step"],
                          "avg_launch_us": kern[dom]["avg_us"]},
             "fwd_roofline": {"bound": "hbm", "achieved": fwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": fwd_gbs / HBM_PEAK_GBS, "fused_fwd_us": fwd_us,
@@ -316,7 +333,9 @@ def main():
         if world == 1 and not a.no_extra:
             # secondary configurations of BASELINE.json / SURVEY 8(d), measured in this same run
             line["extra_configs"] = [extra_config("A", 1, torch.float32), extra_config("B", 8, torch.float32),
-                                     extra_config("D", 1, torch.bfloat16)]
+                                     extra_config("D", 1, torch.bfloat16),
+                                     extra_config(a.cfg, a.batch, dtype, ert=False),
+                                     extra_config(a.cfg, a.batch, dtype, density_mode="naive")]
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, a.cfg)
         print(json.dumps(line), flush=True)

@@ -58,6 +58,8 @@ int launch_exclusive_scan(const int* cnt, int* off, int* fill, int n, int* total
 // afterwards the start offset of cell c is off[c] + boff[c / kScanTile]; bsum / boff / aux hold
 // ncell / kScanTile ints (aux two more) and aux[ncell / kScanTile] receives the grand total.
 // grad_beta[0] += sign(beta_raw[0]) * sum(part[0..n)), summed in a fixed order by one workgroup
+// zero `bytes` (multiple of 4) at ptr with a kernel (graph-safe, see runtime.hip)
+int launch_zero(void* ptr, size_t bytes, hipStream_t s);
 int launch_beta_reduce(const float* part, int n, const float* beta_raw, float* grad_beta, hipStream_t s);
 constexpr int kScanTile = 2048;
 int launch_cell_scan(const int* cnt, int* off, int* bsum, int* boff, int* aux, long ncell,

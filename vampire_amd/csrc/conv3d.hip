@@ -468,8 +468,7 @@ int vamp_conv3d_backward_weight(const VampConvDesc* d, const float* in, const fl
   const size_t lds = wgrad_lds(d);
   VAMP_REQUIRE(lds <= 160 * 1024, "row too long for the LDS images");
   float* part = static_cast<float*>(workspace);
-  if (hipMemsetAsync(grad_weight, 0, (size_t) d->cout * d->cin * 27 * sizeof(float), s) != hipSuccess)
-    return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
+  if (int ze = launch_zero(grad_weight, (size_t) d->cout * d->cin * 27 * sizeof(float), s)) return ze;
 #define VAMP_WGRAD_N(CI, CO, NP)                                                                    \
   do {                                                                                              \
     static bool attr_set = false;                                                                   \

@@ -504,11 +504,9 @@ int vamp_lift_backward_ex(const VampLiftDesc* d, const float* mats, const float*
   if (d->in_dtype == VAMP_F32) launch_to_cl<float>(feat, w.feat_cl, BN, d->C, HW, s);
   else launch_to_cl<__hip_bfloat16>(feat, w.feat_cl, BN, d->C, HW, s);
   if (int e = check_launch("feat_to_channel_last")) return e;
-  if (hipMemsetAsync(w.gfeat_cl, 0, (size_t) BN * HW * d->C * sizeof(float), s) != hipSuccess)
-    return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
-  if (d->use_depth &&
-      hipMemsetAsync(grad_depth, 0, (size_t) BN * d->D * HW * sizeof(float), s) != hipSuccess)
-    return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
+  if (int ze = launch_zero(w.gfeat_cl, (size_t) BN * HW * d->C * sizeof(float), s)) return ze;
+  if (d->use_depth)
+    if (int ze = launch_zero(grad_depth, (size_t) BN * d->D * HW * sizeof(float), s)) return ze;
   int e = (d->in_dtype == VAMP_F32)
               ? lift_backward_t<float>(d, P, mats, xs, ys, zs, depth, w.feat_cl, grad_out, hits, grad_depth, w.gfeat_cl, s)
               : lift_backward_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, w.feat_cl, grad_out, hits, grad_depth, w.gfeat_cl, s);

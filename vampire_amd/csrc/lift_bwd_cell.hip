@@ -327,8 +327,7 @@ int launch_lift_cell_prepare(const VampLiftDesc* d, const float* mats, const flo
   const LiftCellWs w = lift_cell_ws(d, scratch);
   const size_t cap = (size_t) d->B * d->N * d->Z * d->Y * d->X;
   VAMP_REQUIRE(cap < 0x7fffffffu && g.ncell < 0x7fffffffL, "pair / cell count exceeds 2^31");
-  if (hipMemsetAsync(w.cnt, 0, (size_t) g.ncell * sizeof(int), s) != hipSuccess)
-    return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
+  if (int ze = launch_zero(w.cnt, (size_t) g.ncell * sizeof(int), s)) return ze;
   dim3 grid((d->X + 63) / 64, (d->Y + 3) / 4, d->Z * d->B);
   VAMP_TIMED(kProfLiftBwdCount, s, (lift_bwd_cell_kernel<float, 16, false><<<grid, 256, 0, s>>>(
       P, g.cw, g.ch, mats, xs, ys, zs, nullptr, nullptr, nullptr, w.cnt, w.off, w.boff, w.entries)));
@@ -346,8 +345,7 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
   if (!cells_valid)
     if (int e = launch_lift_cell_prepare(d, mats, xs, ys, zs, scratch, s)) return e;
   // the counters become the fill cursors
-  if (hipMemsetAsync(w.cnt, 0, (size_t) g.ncell * sizeof(int), s) != hipSuccess)
-    return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
+  if (int ze = launch_zero(w.cnt, (size_t) g.ncell * sizeof(int), s)) return ze;
   dim3 grid((d->X + 63) / 64, (d->Y + 3) / 4, d->Z * d->B);
   const T* dp = static_cast<const T*>(depth);
 #define VAMP_CELL(CH)                                                                            \

@@ -107,55 +107,114 @@ bev_density_kernel(RenderParams P, const float* __restrict__ oxs, const float* _
   bev_height[(long) b * OYX + col] = height;
 }
 
-// channel index space of bev_channels: [0, K) semantic, [K, K+3) rgb, [K+3, K+3+C) base
-template <typename T>
+// channel index space of bev_channels: [0, K) semantic, [K, K+3) rgb, [K+3, K+3+C) base.
+// A thread owns one BEV column and NC consecutive channels: the column's compositing weights
+// (two exps per height) and the height taps are worked out once and shared by its channels --
+// with a thread per (channel, column) this kernel spent 80 % of its time in the vector ALU
+// redoing them 38 times -- and the 8 * NC plane loads of a height go out together.
+// cfg-B, us per launch: one thread per (channel, column) 55; NC = 1 / 2 / 4 / 8: 46 / 41.5 / 50 / 48
+// (fewer waves per CU hide less latency past NC = 2).
+#ifndef VAMP_BEV_NC
+#define VAMP_BEV_NC 2
+#endif
+constexpr int kBevNC = VAMP_BEV_NC;   // channels per thread
+constexpr int kBevMaxOZ = 64;         // heights whose taps fit the LDS table
+
+template <typename T, int NC>
 __global__ void __launch_bounds__(256)
 bev_channels_kernel(RenderParams P, const float* __restrict__ oxs, const float* __restrict__ oys,
                     const float* __restrict__ ozs, const T* __restrict__ sem,
                     const T* __restrict__ rgb, const T* __restrict__ base,
                     const float* __restrict__ voxel_density, float* __restrict__ bev_rgb,
                     float* __restrict__ bev_seg, float* __restrict__ voxel_output) {
+  __shared__ int tz_i0[kBevMaxOZ];
+  __shared__ float tz_w0[kBevMaxOZ], tz_w1[kBevMaxOZ];
+  if ((int) threadIdx.x < P.oZ) {
+    const AxisTap tz = axis_tap(ozs[P.oZ - 1 - threadIdx.x], P.lo[2], P.span[2], P.Z);   // flip (bv2:443)
+    tz_i0[threadIdx.x] = tz.i0; tz_w0[threadIdx.x] = tz.w0; tz_w1[threadIdx.x] = tz.w1;
+  }
+  __syncthreads();
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int nch = P.K + 3 + P.C;
-  const int b = blockIdx.z / nch, ch = blockIdx.z % nch;
+  const int ngrp = (nch + NC - 1) / NC;
+  const int b = blockIdx.z / ngrp, c0 = (blockIdx.z % ngrp) * NC;
   if (x >= P.oX || y >= P.oY) return;
   const long V = (long) P.Z * P.Y * P.X, OYX = (long) P.oY * P.oX, col = (long) y * P.oX + x;
   const int CO = P.C + (P.cat_seg ? P.K : 0);
   const AxisTap tx = axis_tap(oxs[x], P.lo[0], P.span[0], P.X);
   const AxisTap ty = axis_tap(oys[y], P.lo[1], P.span[1], P.Y);
-  const T* vol;
-  long cb;
-  if (ch < P.K) { vol = sem; cb = ((long) b * P.K + ch) * V; }
-  else if (ch < P.K + 3) { vol = rgb; cb = ((long) b * 3 + (ch - P.K)) * V; }
-  else { vol = base; cb = ((long) b * P.C + (ch - P.K - 3)) * V; }
-  const bool composite = ch < P.K + 3;
-  float cum = 0.f, acc = 0.f;
+  // the four (y, x) taps of the column: clamped offsets and weights (zero outside the volume)
+  long off4[4];
+  float w4[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int iy = ty.i0 + (k >> 1), ix = tx.i0 + (k & 1);
+    const bool in = iy >= 0 && iy < P.Y && ix >= 0 && ix < P.X;
+    w4[k] = in ? ((k & 1) ? tx.w1 : tx.w0) * ((k & 2) ? ty.w1 : ty.w0) : 0.f;
+    off4[k] = (long) min(max(iy, 0), P.Y - 1) * P.X + min(max(ix, 0), P.X - 1);
+  }
+  const T* vol[NC];
+  long cb[NC];
+  bool on[NC];
+#pragma unroll
+  for (int u = 0; u < NC; ++u) {
+    const int ch = min(c0 + u, nch - 1);
+    on[u] = c0 + u < nch;
+    if (ch < P.K) { vol[u] = sem; cb[u] = ((long) b * P.K + ch) * V; }
+    else if (ch < P.K + 3) { vol[u] = rgb; cb[u] = ((long) b * 3 + (ch - P.K)) * V; }
+    else { vol[u] = base; cb[u] = ((long) b * P.C + (ch - P.K - 3)) * V; }
+  }
+  auto plane = [&](int u, int iz) -> float {
+    const bool zin = iz >= 0 && iz < P.Z;
+    const long zo = cb[u] + (long) min(max(iz, 0), P.Z - 1) * P.Y * P.X;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s = __builtin_fmaf(zin ? w4[k] : 0.f, ldf(vol[u], zo + off4[k]), s);
+    return s;
+  };
+  float cum = 0.f, acc[NC], v_lo[NC], v_hi[NC];
+#pragma unroll
+  for (int u = 0; u < NC; ++u) acc[u] = v_lo[u] = v_hi[u] = 0.f;
   // consecutive heights share a volume plane (det and seg grids have equal spacing): keep the
   // two bilinear plane values and reload only what changed -> 4 loads per sample, not 8
   int p_lo = -0x7fffffff, p_hi = -0x7fffffff;
-  float v_lo = 0.f, v_hi = 0.f;
+  const bool any_comp = c0 < P.K + 3;
   for (int j = 0; j < P.oZ; ++j) {
-    const AxisTap tz = axis_tap(ozs[P.oZ - 1 - j], P.lo[2], P.span[2], P.Z);
-    float n_lo, n_hi;
-    if (tz.i0 == p_lo) n_lo = v_lo; else if (tz.i0 == p_hi) n_lo = v_hi;
-    else n_lo = bilinear_plane(P, vol, cb, tx, ty, tz.i0);
-    if (tz.i0 + 1 == p_lo) n_hi = v_lo; else if (tz.i0 + 1 == p_hi) n_hi = v_hi;
-    else n_hi = bilinear_plane(P, vol, cb, tx, ty, tz.i0 + 1);
-    p_lo = tz.i0; p_hi = tz.i0 + 1; v_lo = n_lo; v_hi = n_hi;
-    const float sv = __builtin_fmaf(tz.w1, n_hi, tz.w0 * n_lo);
-    if (composite) {
-      const float tau = voxel_density[((long) b * P.oZ + j) * OYX + col] * (1.0f * P.z_step);
-      acc = __builtin_fmaf((1.0f - expf(-tau)) * expf(-cum), sv, acc);
+    const int i0 = tz_i0[j];
+    const float wz0 = tz_w0[j], wz1 = tz_w1[j];
+    const bool lo_is_lo = i0 == p_lo, lo_is_hi = i0 == p_hi, hi_is_lo = i0 + 1 == p_lo, hi_is_hi = i0 + 1 == p_hi;
+    float wj = 0.f;
+    if (any_comp) {
+      const float tau = voxel_density[((long) b * P.oZ + j) * OYX + col] * (1.0f * P.z_step);   // bv2:451-458
+      wj = (1.0f - expf(-tau)) * expf(-cum);
       cum += tau;
-      if (ch < P.K && P.cat_seg)
-        voxel_output[(((long) b * CO + P.C + ch) * P.oZ + j) * OYX + col] = sv;     // bv2:449-450
-    } else {
-      voxel_output[(((long) b * CO + (ch - P.K - 3)) * P.oZ + j) * OYX + col] = sv;
     }
+#pragma unroll
+    for (int u = 0; u < NC; ++u) {
+      const float n_lo = lo_is_lo ? v_lo[u] : (lo_is_hi ? v_hi[u] : plane(u, i0));
+      const float n_hi = hi_is_lo ? v_lo[u] : (hi_is_hi ? v_hi[u] : plane(u, i0 + 1));
+      v_lo[u] = n_lo; v_hi[u] = n_hi;
+      const float sv = __builtin_fmaf(wz1, n_hi, wz0 * n_lo);
+      const int ch = c0 + u;
+      if (!on[u]) continue;
+      if (ch < P.K + 3) {
+        acc[u] = __builtin_fmaf(wj, sv, acc[u]);
+        if (ch < P.K && P.cat_seg)
+          voxel_output[(((long) b * CO + P.C + ch) * P.oZ + j) * OYX + col] = sv;     // bv2:449-450
+      } else {
+        voxel_output[(((long) b * CO + (ch - P.K - 3)) * P.oZ + j) * OYX + col] = sv;
+      }
+    }
+    p_lo = i0; p_hi = i0 + 1;
   }
-  if (ch < P.K) bev_seg[((long) b * P.K + ch) * OYX + col] = acc;
-  else if (ch < P.K + 3) bev_rgb[((long) b * 3 + (ch - P.K)) * OYX + col] = acc;
+#pragma unroll
+  for (int u = 0; u < NC; ++u) {
+    const int ch = c0 + u;
+    if (!on[u]) continue;
+    if (ch < P.K) bev_seg[((long) b * P.K + ch) * OYX + col] = acc[u];
+    else if (ch < P.K + 3) bev_rgb[((long) b * 3 + (ch - P.K)) * OYX + col] = acc[u];
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -598,13 +657,14 @@ int vamp_render_bev_forward(const VampRenderDesc* d, const float* oxs, const flo
   const RenderParams P = to_params(d);
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 g1((d->oX + 63) / 64, (d->oY + 3) / 4, d->B);
-  dim3 g2((d->oX + 63) / 64, (d->oY + 3) / 4, d->B * (d->K + 3 + d->C));
+  VAMP_REQUIRE(d->oZ <= kBevMaxOZ, "at most 64 det-grid heights");
+  dim3 g2((d->oX + 63) / 64, (d->oY + 3) / 4, d->B * ((d->K + 3 + d->C + kBevNC - 1) / kBevNC));
 #define VAMP_BEVF(T)                                                                              \
   do {                                                                                            \
     VAMP_TIMED(kProfBevFwd, s, (bev_density_kernel<T><<<g1, 256, 0, s>>>(                         \
         P, oxs, oys, ozs, bev_mids, beta, (const T*) density_feature, voxel_density, bev_height))); \
     if (int e = check_launch("bev_density_kernel")) return e;                                     \
-    VAMP_TIMED(kProfBevFwdCh, s, (bev_channels_kernel<T><<<g2, 256, 0, s>>>(                      \
+    VAMP_TIMED(kProfBevFwdCh, s, (bev_channels_kernel<T, kBevNC><<<g2, 256, 0, s>>>(              \
         P, oxs, oys, ozs, (const T*) semantic, (const T*) rgb, (const T*) base, voxel_density,    \
         bev_rgb, bev_seg, voxel_output)));                                                        \
   } while (0)

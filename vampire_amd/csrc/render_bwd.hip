@@ -431,13 +431,7 @@ int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, 
                              (flags & VAMP_CAMBWD_CELLS_VALID) != 0, samples, term, s);
   }
   VAMP_REQUIRE(!accumulate && !wait_event, "accumulate / wait_event need the cell-list path");
-  {
-    ProfScope sc;
-    prof_begin(kProfMemset, s, &sc);
-    const hipError_t me = hipMemsetAsync(gpacked, 0, pb, s);
-    prof_end(s, &sc);
-    if (me != hipSuccess) return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
-  }
+  if (int ze = launch_zero(gpacked, pb, s)) return ze;
   const long nrays = (long) d->B * d->N * d->fH * d->fW;
   const unsigned grid = (unsigned) ((nrays + 255) / 256);
   const long nvox = (long) d->B * d->Z * d->Y * d->X;

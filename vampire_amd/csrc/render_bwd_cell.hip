@@ -316,8 +316,7 @@ int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, con
   VAMP_REQUIRE(samples > 0 && samples < 0x7fffffffu && voxels < 0x7fffffffu && ncell < 0x7fffffffL,
                "sample / voxel / cell count exceeds 2^31");
   const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
-  if (hipMemsetAsync(w.cnt, 0, (size_t) ncell * sizeof(int), s) != hipSuccess)
-    return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
+  if (int ze = launch_zero(w.cnt, (size_t) ncell * sizeof(int), s)) return ze;
   const unsigned sgrid = (unsigned) ((samples + 255) / 256);
   VAMP_TIMED(kProfCamBwdCount, s, (cam_cells_rank_kernel<<<sgrid, 256, 0, s>>>(
       P, mats, us, vs, ds, w.cnt, w.key, w.slot, (unsigned) samples, ncell_b, term)));
@@ -338,8 +337,7 @@ int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const fl
   const size_t voxels = (size_t) d->B * d->Z * d->Y * d->X;
   const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
   int* nheavy = w.aux + ntile + 1;
-  if (hipMemsetAsync(nheavy, 0, sizeof(int), s) != hipSuccess)
-    return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
+  if (int ze = launch_zero(nheavy, sizeof(int), s)) return ze;
 
   // measured at cfg-B (gather + heavy, us): 8 lanes 145 + 56, 16 lanes 173 + 56, 32 lanes 249 + 56;
   // threshold 128 / 256 / 512 with 8 lanes: 131 + 107, 145 + 56, 159 + 40

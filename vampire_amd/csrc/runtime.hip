@@ -2,6 +2,7 @@
 // kernel timer used by bench.py's roofline leg.
 #include "common.hpp"
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -166,6 +167,39 @@ beta_reduce_kernel(const float* __restrict__ part, int n, const float* __restric
 int launch_beta_reduce(const float* part, int n, const float* beta_raw, float* grad_beta, hipStream_t s) {
   beta_reduce_kernel<<<1, 1024, 0, s>>>(part, n, beta_raw, grad_beta);
   return check_launch("beta_reduce_kernel");
+}
+
+// Zero fill as an ordinary kernel.  hipMemsetAsync is avoided on purpose: a captured step whose
+// single-stream graph held memset nodes faulted on replay once any eager kernel had run on the
+// null stream in between (ROCm 7.2, tools/debug/graph_abort.py); kernel nodes do not.
+__global__ void __launch_bounds__(256)
+zero_fill_kernel(uint4* __restrict__ p16, size_t n16, uint32_t* __restrict__ tail, int ntail) {
+  const size_t stride = (size_t) gridDim.x * 256;
+  for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n16; i += stride)
+    p16[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (blockIdx.x == 0 && (int) threadIdx.x < ntail) tail[threadIdx.x] = 0u;
+}
+
+int launch_zero(void* ptr, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return VAMP_OK;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+  if ((a & 3u) != 0 || (bytes & 3u) != 0) return fail(VAMP_EINVAL, "%s: buffer must be 4-byte granular", __func__);
+  // head words up to the first 16-byte boundary go with the tail words
+  char* p = static_cast<char*>(ptr);
+  const size_t head = std::min(bytes, (size_t) ((16 - (a & 15u)) & 15u));
+  if (head) {
+    zero_fill_kernel<<<1, 256, 0, s>>>(nullptr, 0, reinterpret_cast<uint32_t*>(p), (int) (head / 4));
+    if (int e = check_launch("zero_fill_kernel")) return e;
+    p += head;
+    bytes -= head;
+    if (bytes == 0) return VAMP_OK;
+  }
+  const size_t n16 = bytes / 16;
+  const int ntail = (int) ((bytes - n16 * 16) / 4);
+  const unsigned grid = (unsigned) std::min<size_t>(std::max<size_t>(1, (n16 + 1023) / 1024), 256 * 16);
+  VAMP_TIMED(kProfMemset, s, (zero_fill_kernel<<<grid, 256, 0, s>>>(
+      reinterpret_cast<uint4*>(p), n16, reinterpret_cast<uint32_t*>(p + n16 * 16), ntail)));
+  return check_launch("zero_fill_kernel");
 }
 
 int launch_exclusive_scan(const int* cnt, int* off, int* fill, int n, int* total, hipStream_t s) {

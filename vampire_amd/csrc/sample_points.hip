@@ -413,8 +413,7 @@ static int backward_t(const VampSampleDesc* d, const SampleParams& P, const void
   VAMP_REQUIRE(voxels < 0x7fffffffu && ncell < 0x7fffffffL, "voxel / cell count exceeds 2^31");
   const int CP = (d->C + 3) / 4 * 4, CP4 = CP / 4;
   const T* vol = static_cast<const T*>(volume);
-  if (hipMemsetAsync(w.cnt, 0, (size_t) ncell * sizeof(int), s) != hipSuccess)
-    return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
+  if (int ze = launch_zero(w.cnt, (size_t) ncell * sizeof(int), s)) return ze;
   int* nheavy = w.aux + ntile + 1;
   const unsigned pgrid = (unsigned) std::max<long>(1, (pts + 255) / 256);
   if (pts > 0) {
@@ -422,8 +421,7 @@ static int backward_t(const VampSampleDesc* d, const SampleParams& P, const void
     if (int e = check_launch("sample_points_rank_kernel")) return e;
   }
   if (int e = launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, ncell, s)) return e;
-  if (hipMemsetAsync(nheavy, 0, sizeof(int), s) != hipSuccess)
-    return fail(VAMP_EHIP, "%s: hipMemsetAsync failed", __func__);
+  if (int ze = launch_zero(nheavy, sizeof(int), s)) return ze;
   if (pts > 0) {
     sample_points_fill_kernel<<<pgrid, 256, 0, s>>>(P, w.key, w.rank, w.F, w.off, w.boff, w.R, ncell_b);
     if (int e = check_launch("sample_points_fill_kernel")) return e;

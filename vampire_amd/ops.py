@@ -87,7 +87,10 @@ class HotPath:
                      "lift_bwd": os.environ.get("VAMP_LIFT_BWD", "cell"),
                      "bev_bwd": os.environ.get("VAMP_BEV_BWD", "cell"),
                      "lift_wpp": int(os.environ.get("VAMP_LIFT_WPP", "0")),
-                     "overlap": os.environ.get("VAMP_OVERLAP", "1") != "0",
+                     # BEV branch on a second stream: worth 9 % of the step in round 1; since the
+                     # camera branch terminates rays early it costs more than it hides (forward pair 296 vs
+                     # 210 us, step 0.806 vs 0.804 ms), so off unless asked for
+                     "overlap": os.environ.get("VAMP_OVERLAP", "0") == "1",
                      # store the forward's sample rows for the backward's per-ray pass: measured
                      # neutral at cfg-B (forward +50 us for the scattered row stores, backward -59 us),
                      # so off unless asked for
