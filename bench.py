@@ -58,10 +58,11 @@ def kernel_algorithmic_bytes(cfg, B):
         "render_bev_fwd": B * (4 * V * zf + 4 * YX * (oZ + 1)),
         "render_bev_fwd_channels": B * (4 * (K + 3 + C) * V * zf + 4 * YX * (K + 3) + 4 * oZ * YX * CO),
         "render_cam_bwd_ray": B * (4 * cam * V + 4 * P * (K + 4)),  # volumes + upstream gradients in
-        "render_cam_bwd_gather": B * (4 * cam * V),               # the three volume gradients out
+        "render_cam_bwd_gather": B * (2 * 4 * cam * V),           # the three volume gradients: BEV part in, sum out
         "render_bev_bwd_q": B * (4 * (K + 3) * V * zf + 4 * YX * (K + 3)),
         "render_bev_bwd_scan": B * (4 * V * zf + 4 * YX * (oZ + 2)),
-        "render_bev_bwd_gather": B * (2 * 4 * (cam + C) * V * zf + 4 * oZ * YX * (1 + CO)),
+        # the four volume gradients out (every plane: it overwrites), upstream voxel_output + Wb/DS0 in
+        "render_bev_bwd_gather": B * (4 * (cam + C) * V + 4 * oZ * YX * (2 + CO) + 4 * YX * (K + 3)),
     }
 
 

@@ -333,6 +333,24 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
                              void* stream);
 
 /*
+ * The same with flags: an OVERWRITE bit makes the call write the named gradients instead of
+ * adding to them (voxel planes the det grid does not touch get zeros), which saves the zero fill
+ * and the read-modify-write; run it BEFORE vamp_render_camera_backward_acc(..ACCUMULATE) then.
+ */
+#define VAMP_BEVBWD_OVERWRITE_BASE 1   /* grad_base */
+#define VAMP_BEVBWD_OVERWRITE_CAM 2    /* grad_density_feature, grad_semantic, grad_rgb */
+int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const float* oys,
+                             const float* ozs, const float* bev_mids, const float* beta,
+                             const void* density_feature, const void* semantic,
+                             const void* rgb, const void* base, const float* g_bev_rgb,
+                             const float* g_bev_seg, const float* g_bev_height,
+                             const float* g_voxel_density, const float* g_voxel_output,
+                             float* grad_density_feature, float* grad_semantic,
+                             float* grad_rgb, float* grad_base, float* grad_beta,
+                             const float* ozs_host, void* workspace, size_t workspace_bytes,
+                             int flags, void* stream);
+
+/*
  * Diagnostics: inside-mask (bv2:405-407) and floor taps of the camera branch's
  * trilinear sample per (b, n, d < D-1, h, w); geometry as in the forward.
  */

@@ -10,9 +10,10 @@
 //                          voxel_density, or pass through (base -> voxel_output)
 //  backward  bev_q         thread per (channel-lane, column): q_j = sum_c G_c s_j[c]
 //            bev_scan      thread per column: weights, dL/dtau_j, dL/ds_j[0], d beta
-//            bev_gather    thread per (channel, voxel): sums w_tap * dL/ds over the <= 3^3
-//                          lattice samples whose taps include the voxel -- no atomics; adds
-//                          onto the camera-branch gradient already in the buffers
+//            bev_gather    thread per (voxel column, 4 channels): walks the lattice heights
+//                          upwards, one (y, x)-weighted plane sum per height, the two voxel
+//                          planes it feeds kept in registers -- no atomics; overwrites (the
+//                          camera gather then adds) or adds onto what the buffers hold
 #include "render_common.hpp"
 
 namespace vamp {
@@ -442,8 +443,6 @@ bev_gather_generic_kernel(RenderParams P, const float* __restrict__ oxs,
   }
 }
 
-constexpr int kPer = 4;                // channels per thread of bev_gather
-
 // Per-axis hit tables, built once per call: for every voxel index along an axis the (<= kMaxT)
 // lattice samples whose taps include it, and their weights, as one 32-byte record
 // {k0, k1, k2, count | w0, w1, w2, -} so that the gather needs a single round of loads per axis.
@@ -472,14 +471,6 @@ __device__ __forceinline__ AxisHits load_axis_hits(const int4* __restrict__ tab,
   return h;
 }
 
-// KIND 0 / 1 / 2 = semantic / rgb / base channels, kPer channels per thread, one launch per kind.
-//   KIND 0, 1: the sample gradient of a composited channel is Wb * gcol (gcol = g_bev_seg /
-//              g_bev_rgb, one value per BEV column, so the height taps fold into the weights)
-//   KIND 0 with cat_seg, KIND 2: the voxel_output gradient passes straight through
-// with_dens: group 0 of this launch also carries the density channel.
-// The first two hits per axis are handled without branches (unused slots: k = 0, w = 0), so all
-// loads of a thread are independent and in flight together; a third hit on some axis adds
-// its slot combinations at the end.  Offsets are 32-bit (the host checks the tensor sizes).
 __device__ __forceinline__ AxisHits uniform_hits(AxisHits h) {
 #pragma unroll
   for (int i = 0; i < kMaxT; ++i) {
@@ -490,139 +481,215 @@ __device__ __forceinline__ AxisHits uniform_hits(AxisHits h) {
   return h;
 }
 
-template <int KIND>
+// Column gather: a thread owns one voxel column (y, x) and G channels of one tensor and walks
+// the lattice heights in ascending order.  What a height gives to the column is one
+// (y, x)-weighted sum per channel -- the "plane sum" -- which goes to the two voxel planes of the
+// height's z taps; both running sums live in registers and a voxel plane is stored once, when
+// the heights have moved past it.  No per-voxel tap search, no second visit of a plane sum, and
+// the loads of the next height are issued before the current one is consumed.
+//   composited channels (semantic, rgb): dL/ds_j[c] = Wb_j * gcol[c]; gcol is one value per BEV
+//              column, loaded once per thread with the (y, x) weights folded in
+//   pass-through channels (base; semantic with cat_seg): dL/ds_j[c] = g_voxel_output[c, j]
+//   density (rides with group 0 of the rgb launch): dL/ds_j[0] = DS0_j
+// Taps per height: 2 (y) x 3 (x) slots without branches (the third x slot exists for about one
+// voxel in a hundred and otherwise has weight 0); a third y hit adds its three slots behind a
+// wave-level test.  Needs the heights ascending (the host checks) and oZ <= kBevMaxOZ.
+// The per-voxel formulation this replaces (thread per voxel and 4 channels, 8 tap loads per
+// output, read-modify-write of every output) took 26 + 55 + 54 us at cfg-B.
+// OW: overwrite the outputs (planes the lattice does not touch get zeros) instead of adding.
+#ifndef VAMP_COLG
+#define VAMP_COLG 4
+#endif
+constexpr int kColG = VAMP_COLG;       // channels per thread, pass-through launch
+#ifndef VAMP_COLGC
+#define VAMP_COLGC 4
+#endif
+constexpr int kColGC = VAMP_COLGC;     // channels per thread, composited launch
+
+template <int G, bool COL, bool VO, bool OW>
 __global__ void __launch_bounds__(256)
-bev_gather_kernel(RenderParams P, const int4* __restrict__ tab, const float* __restrict__ gcol,
-                  const float* __restrict__ g_vo, const float* __restrict__ Wb,
-                  const float* __restrict__ DS0, float* __restrict__ gdens,
-                  float* __restrict__ gout, int z_lo, int z_hi, int with_dens) {
-  const dim3 blk = xcd_block();      // neighbouring rows / planes share lattice lines: keep them in one L2
-  const int x = blk.x * 64 + (threadIdx.x & 63);
-  const int y = blk.y * 4 + (threadIdx.x >> 6);
-  const int nz = z_hi - z_lo + 1;
-  const int nchan = KIND == 0 ? P.K : (KIND == 1 ? 3 : P.C);
-  const int ngrp = (nchan + kPer - 1) / kPer;
-  // z fastest, then channel group: the two height taps of a voxel plane are shared with the
-  // plane above and below
-  const int z = z_lo + blk.z % nz;
-  const int cg = (blk.z / nz) % ngrp;
-  const int b = blk.z / (ngrp * nz);
-  if (x >= P.X || y >= P.Y) return;
-  // y and z are the same for the whole wave: their hits go to scalar registers, which turns the
-  // tap addresses into (scalar base) + (per-lane x offset) and most of the index arithmetic into
-  // scalar instructions
-  const AxisHits hx = load_axis_hits(tab, x), hy = uniform_hits(load_axis_hits(tab, P.X + y)),
-                 hz = uniform_hits(load_axis_hits(tab, P.X + P.Y + z));
-  if (hx.n == 0 || hy.n == 0 || hz.n == 0) return;
-  const unsigned V = (unsigned) (P.Z * P.Y * P.X), OYX = (unsigned) (P.oY * P.oX);
-  const unsigned vox = ((unsigned) z * P.Y + y) * P.X + x;
+bev_gather_col_kernel(RenderParams P, const int4* __restrict__ tab, const float* __restrict__ ozs,
+                      const float* __restrict__ gcol, const float* __restrict__ gcol2,
+                      const float* __restrict__ g_vo, int vo_c0, const float* __restrict__ Wb,
+                      const float* __restrict__ DS0, float* __restrict__ gdens,
+                      float* __restrict__ gout, float* __restrict__ gout2, int nchan, int nchan2,
+                      int zseg, int with_dens, int flags) {
+  __shared__ int tz_i0[kBevMaxOZ];
+  __shared__ float tz_w0[kBevMaxOZ], tz_w1[kBevMaxOZ];
+  if ((int) threadIdx.x < P.oZ) {
+    const AxisTap tz = axis_tap(ozs[threadIdx.x], P.lo[2], P.span[2], P.Z);
+    tz_i0[threadIdx.x] = tz.i0; tz_w0[threadIdx.x] = tz.w0; tz_w1[threadIdx.x] = tz.w1;
+  }
+  __syncthreads();
+  const unsigned YX = (unsigned) (P.Y * P.X);
+  const unsigned col = blockIdx.x * 256 + threadIdx.x;       // rows are contiguous: full waves
+  // channel space: [0, nchan) of (gcol, gout), then [0, nchan2) of (gcol2, gout2); the density
+  // channel rides with the last group
+  const int ngrp = (nchan + nchan2 + G - 1) / G;
+  const int nseg = (P.Z + zseg - 1) / zseg;
+  const int cg = blockIdx.y % ngrp;
+  const int sg = (blockIdx.y / ngrp) % nseg;
+  const int b = blockIdx.y / (ngrp * nseg);
+  if (col >= YX) return;
+  const int x = col % (unsigned) P.X, y = col / (unsigned) P.X;
+  constexpr bool ow = OW, ow_d = OW;
+  const bool dens = with_dens && cg == ngrp - 1;
+  const AxisHits hx = load_axis_hits(tab, x), hy = load_axis_hits(tab, P.X + y);
+  const bool y3 = __any(hy.n > 2);
+  const unsigned V = (unsigned) P.Z * YX, OYX = (unsigned) (P.oY * P.oX);
   const int CO = P.C + (P.cat_seg ? P.K : 0);
-  const bool use_col = KIND != 2 && gcol != nullptr;
-  const bool use_vo = g_vo != nullptr && (KIND == 2 || (KIND == 0 && P.cat_seg));
-  const int vo_c0 = KIND == 2 ? 0 : P.C;
-  const bool dens = with_dens && cg == 0;
-  const bool any = use_col || use_vo;
 
-  // The values accumulated onto are loaded first and everything is stored at the end: none of
-  // these loads depends on the taps, so their latency overlaps the taps' instead of following it.
-  bool on[kPer];
-  unsigned oo[kPer];
-  float prev[kPer], sum[kPer];
+  // the (y, x) taps of the column: lattice offsets and weights (absent slots: k = 0, w = 0)
+  unsigned cc[3][3];
+  float wyx[3][3];
 #pragma unroll
-  for (int u = 0; u < kPer; ++u) {
-    const int ch = cg * kPer + u;
-    on[u] = any && ch < nchan;
-    oo[u] = ((unsigned) b * nchan + (on[u] ? ch : 0)) * V + vox;
-    prev[u] = on[u] ? gout[oo[u]] : 0.f;
-    sum[u] = 0.f;
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      cc[c][e] = (unsigned) hy.k[c] * P.oX + hx.k[e];
+      wyx[c][e] = hy.w[c] * hx.w[e];
+    }
+  bool on[G];
+  unsigned vb[G];
+  float* op[G];                 // output plane 0 of the channel, at this column (wave-uniform base)
+  const float* gp[G];           // column gradient of the channel (null: none)
+  float gw[G][2][3];
+#pragma unroll
+  for (int u = 0; u < G; ++u) {
+    // a slot past the last channel repeats the last channel (same value to the same address from
+    // the same thread) when overwriting, which keeps the loop free of per-slot branches
+    const int ch = OW ? min(cg * G + u, nchan + nchan2 - 1) : cg * G + u;
+    on[u] = ch < nchan + nchan2;
+    const bool second = ch >= nchan;
+    const int chc = on[u] ? (second ? ch - nchan : ch) : 0;
+    const int nc = second ? nchan2 : nchan;
+    op[u] = (second ? gout2 : gout) + ((unsigned) b * nc + chc) * V + col;
+    const float* gc = second ? gcol2 : gcol;
+    gp[u] = (COL && on[u] && gc) ? gc + ((unsigned) b * nc + chc) * OYX : nullptr;
+    vb[u] = ((unsigned) b * CO + (VO ? vo_c0 : 0) + chc) * P.oZ * OYX;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 3; ++e) gw[u][c][e] = gp[u] ? wyx[c][e] * gp[u][cc[c][e]] : 0.f;
   }
-  const float prev_d = dens ? gdens[(unsigned) b * V + vox] : 0.f;
-  float s_dens = 0.f;
+  const unsigned od = (unsigned) b * V + col;
 
-  unsigned cc[4], jo[2];
-  float wyx[4], wz[2];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    cc[q] = (unsigned) hy.k[q >> 1] * P.oX + hx.k[q & 1];
-    wyx[q] = hy.w[q >> 1] * hx.w[q & 1];
+  // this segment's voxel planes [za, zb) and the heights whose taps reach them (ascending)
+  const int za = sg * zseg, zb = min(P.Z, za + zseg);
+  int k_a = P.oZ, k_b = -1;
+  for (int k = 0; k < P.oZ; ++k) {
+    const int i0 = tz_i0[k];
+    if (i0 + 1 >= za && i0 < zb) { k_a = min(k_a, k); k_b = max(k_b, k); }
   }
+
+  auto store_plane = [&](int z, const float (&v)[G], float vd, bool touched) __attribute__((always_inline)) {
+    if (z < za || z >= zb) return;
+    const unsigned zo = (unsigned) z * YX;
+    if (ow) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    jo[a] = ((unsigned) b * P.oZ + (P.oZ - 1 - hz.k[a])) * OYX;
-    wz[a] = hz.w[a];
-  }
-  float wcol[4] = {0.f, 0.f, 0.f, 0.f};
-  if (use_col) {
+      for (int u = 0; u < G; ++u) op[u][zo] = v[u];
+    } else if (touched) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) wcol[q] = __builtin_fmaf(wz[a] * wyx[q], Wb[jo[a] + cc[q]], wcol[q]);
-  }
-  if (dens) {
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) s_dens = __builtin_fmaf(wz[a] * wyx[q], DS0[jo[a] + cc[q]], s_dens);
-  }
-#pragma unroll
-  for (int u = 0; u < kPer; ++u) {
-    if (!on[u]) continue;                               // workgroup-uniform
-    const int ch = cg * kPer + u;
-    if (use_col) {
-      const unsigned cb = ((unsigned) b * nchan + ch) * OYX;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) sum[u] = __builtin_fmaf(wcol[q], gcol[cb + cc[q]], sum[u]);
+      for (int u = 0; u < G; ++u)
+        if (on[u]) op[u][zo] += v[u];
     }
-    if (use_vo) {
-      const unsigned vb = ((unsigned) b * CO + vo_c0 + ch) * P.oZ * OYX - (unsigned) b * P.oZ * OYX;
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) sum[u] = __builtin_fmaf(wz[a] * wyx[q], g_vo[vb + jo[a] + cc[q]], sum[u]);
-    }
-  }
-  // Third hit on an axis (the det lattice is slightly finer than the volume grid, so about one
-  // voxel index in a hundred has one): the extra (z, y, x) slot combinations, unrolled, each
-  // group behind a wave-level test.  A slot an axis does not have carries weight 0 and k = 0.
-  auto add_combo = [&](int kz, float wzv, int ky, float wyv, int kx, float wxv) {
-    const unsigned j0 = ((unsigned) b * P.oZ + (P.oZ - 1 - kz)) * OYX;
-    const unsigned c0 = (unsigned) ky * P.oX + kx;
-    const float wt = wzv * wyv * wxv;
-    const float wW = use_col ? wt * Wb[j0 + c0] : 0.f;
-    if (dens) s_dens = __builtin_fmaf(wt, DS0[j0 + c0], s_dens);
-#pragma unroll
-    for (int u = 0; u < kPer; ++u) {
-      if (!on[u]) continue;
-      const int ch = cg * kPer + u;
-      if (use_col) sum[u] = __builtin_fmaf(wW, gcol[((unsigned) b * nchan + ch) * OYX + c0], sum[u]);
-      if (use_vo)
-        sum[u] = __builtin_fmaf(
-            wt, g_vo[((unsigned) b * CO + vo_c0 + ch) * P.oZ * OYX - (unsigned) b * P.oZ * OYX + j0 + c0],
-            sum[u]);
+    if (dens) {
+      if (ow_d) gdens[od + zo] = vd;
+      else if (touched) gdens[od + zo] += vd;
     }
   };
-  if (hx.n > 2) {
+  float zero[G];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2) add_combo(hz.k[a], hz.w[a], hy.k[c2], hy.w[c2], hx.k[2], hx.w[2]);
+  for (int u = 0; u < G; ++u) zero[u] = 0.f;
+  if (k_b < k_a) {                               // nothing reaches this segment
+    for (int z = za; z < zb; ++z) store_plane(z, zero, 0.f, false);
+    return;
   }
-  if (hy.n > 2) {
+
+  // raw taps of one height: [G][2][3] pass-through values, [2][3] Wb and DS0
+  constexpr int GV = VO ? G : 1;
+  float nv[GV][2][3], nw[2][3], nd[2][3];
+  const float* __restrict__ dsp = dens ? DS0 : Wb;
+  auto fetch = [&](int k) __attribute__((always_inline)) {
+    const unsigned jv = (unsigned) (P.oZ - 1 - k) * OYX;                 // flip (bv2:443)
+    const unsigned jo = (unsigned) b * P.oZ * OYX + jv;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int e = 0; e < 3; ++e) add_combo(hz.k[a], hz.w[a], hy.k[2], hy.w[2], hx.k[e], hx.w[e]);
+      for (int e = 0; e < 3; ++e) {
+        // (a load behind a run-time test would push the tap arrays out of registers: groups
+        // without the density rider read Wb twice instead)
+        if (COL) nw[c][e] = Wb[jo + cc[c][e]];
+        if (COL) nd[c][e] = dsp[jo + cc[c][e]];
+        if (VO) {
+#pragma unroll
+          for (int u = 0; u < G; ++u) nv[u][c][e] = g_vo[vb[u] + jv + cc[c][e]];
+        }
+      }
+  };
+  fetch(k_a);
+  int cur = tz_i0[k_a];                           // voxel plane of lo[]
+  float lo[G], hi[G], lod = 0.f, hid = 0.f;
+#pragma unroll
+  for (int u = 0; u < G; ++u) lo[u] = hi[u] = 0.f;
+  bool lo_t = false, hi_t = false;                // does any height touch the plane?
+  for (int z = za; z < min(cur, zb); ++z) store_plane(z, zero, 0.f, false);
+
+  for (int k = k_a; k <= k_b; ++k) {
+    // plane sums of height k from the fetched taps
+    float S[G], Sd = 0.f;
+#pragma unroll
+    for (int u = 0; u < G; ++u) S[u] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        if (COL) Sd = __builtin_fmaf(wyx[c][e], nd[c][e], Sd);
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          if (COL) S[u] = __builtin_fmaf(nw[c][e], gw[u][c][e], S[u]);
+          if (VO) S[u] = __builtin_fmaf(wyx[c][e], nv[u][c][e], S[u]);
+        }
+      }
+    if (y3) {                                     // third y hit somewhere in the wave (about 1 row in 100)
+      const unsigned jv = (unsigned) (P.oZ - 1 - k) * OYX;
+      const unsigned jo = (unsigned) b * P.oZ * OYX + jv;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const float w = wyx[2][e];
+        if (dens) Sd = __builtin_fmaf(w, DS0[jo + cc[2][e]], Sd);
+        const float wbv = COL ? w * Wb[jo + cc[2][e]] : 0.f;
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          if (COL && gp[u]) S[u] = __builtin_fmaf(wbv, gp[u][cc[2][e]], S[u]);
+          if (VO) S[u] = __builtin_fmaf(w, g_vo[vb[u] + jv + cc[2][e]], S[u]);
+        }
+      }
+    }
+    const int i0 = tz_i0[k];
+    const float w0 = tz_w0[k], w1 = tz_w1[k];
+    if (k < k_b) fetch(k + 1);                    // in flight while this height is consumed
+    // the heights have moved past plane `cur`: store it, shift
+    while (cur < i0) {
+      store_plane(cur, lo, lod, lo_t);
+#pragma unroll
+      for (int u = 0; u < G; ++u) { lo[u] = hi[u]; hi[u] = 0.f; }
+      lod = hid; hid = 0.f;
+      lo_t = hi_t; hi_t = false;
+      ++cur;
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      lo[u] = __builtin_fmaf(w0, S[u], lo[u]);
+      hi[u] = __builtin_fmaf(w1, S[u], hi[u]);
+    }
+    lod = __builtin_fmaf(w0, Sd, lod);
+    hid = __builtin_fmaf(w1, Sd, hid);
+    lo_t = hi_t = true;
   }
-  if (hz.n > 2) {
-#pragma unroll
-    for (int c2 = 0; c2 < 3; ++c2)
-#pragma unroll
-      for (int e = 0; e < 3; ++e) add_combo(hz.k[2], hz.w[2], hy.k[c2], hy.w[c2], hx.k[e], hx.w[e]);
-  }
-  if (dens) gdens[(unsigned) b * V + vox] = prev_d + s_dens;
-#pragma unroll
-  for (int u = 0; u < kPer; ++u)
-    if (on[u]) gout[oo[u]] = prev[u] + sum[u];
+  store_plane(cur, lo, lod, lo_t);
+  store_plane(cur + 1, hi, hid, hi_t);
+  for (int z = max(cur + 2, za); z < zb; ++z) store_plane(z, zero, 0.f, false);
 }
 
 static size_t bev_scan_blocks(const VampRenderDesc* d) {
@@ -673,7 +740,20 @@ int vamp_render_bev_forward(const VampRenderDesc* d, const float* oxs, const flo
   return check_launch("bev_channels_kernel");
 }
 
-int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const float* oys,
+static int bev_zero_overwritten(const VampRenderDesc* d, int flags, float* gd, float* gs, float* gr,
+                                float* gb, hipStream_t s) {
+  const size_t vb = (size_t) d->B * d->Z * d->Y * d->X * sizeof(float);
+  if ((flags & VAMP_BEVBWD_OVERWRITE_BASE) && gb)
+    if (int ze = launch_zero(gb, vb * d->C, s)) return ze;
+  if (flags & VAMP_BEVBWD_OVERWRITE_CAM) {
+    if (int ze = launch_zero(gd, vb, s)) return ze;
+    if (int ze = launch_zero(gs, vb * d->K, s)) return ze;
+    if (int ze = launch_zero(gr, vb * 3, s)) return ze;
+  }
+  return VAMP_OK;
+}
+
+int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const float* oys,
                              const float* ozs, const float* bev_mids, const float* beta,
                              const void* density_feature, const void* semantic, const void* rgb,
                              const void* base, const float* g_bev_rgb, const float* g_bev_seg,
@@ -681,18 +761,22 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
                              const float* g_voxel_output, float* grad_density_feature,
                              float* grad_semantic, float* grad_rgb, float* grad_base,
                              float* grad_beta, const float* ozs_host, void* workspace,
-                             size_t workspace_bytes, void* stream) {
+                             size_t workspace_bytes, int flags, void* stream) {
   if (int e = validate(d)) return e;
   VAMP_REQUIRE(d->oZ > 0 && d->oY > 0 && d->oX > 0, "det grid must be non-empty");
   VAMP_REQUIRE(oxs && oys && ozs && bev_mids && density_feature && semantic && rgb, "null input");
   VAMP_REQUIRE(grad_density_feature && grad_semantic && grad_rgb, "null output");
   VAMP_REQUIRE(grad_base || d->C == 0 || !g_voxel_output, "grad_base is NULL");
   VAMP_REQUIRE((beta && grad_beta) || d->density_mode == VAMP_DENSITY_SIGMOID, "beta / grad_beta is NULL");
-  if (!ozs_host)
+  if (!ozs_host) {
+    // float-atomic formulation: adds, so zero what the caller asked to have overwritten
+    if (int e = bev_zero_overwritten(d, flags, grad_density_feature, grad_semantic, grad_rgb, grad_base,
+                                     static_cast<hipStream_t>(stream))) return e;
     return launch_bev_bwd_v1(d, oxs, oys, ozs, bev_mids, beta, density_feature, semantic, rgb, base,
                              g_bev_rgb, g_bev_seg, g_bev_height, g_voxel_density, g_voxel_output,
                              grad_density_feature, grad_semantic, grad_rgb, grad_base, grad_beta,
                              stream);
+  }
   const size_t need = bev_ws_bytes(d);
   if (!workspace || workspace_bytes < need)
     return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) need);
@@ -718,7 +802,9 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
   }
   z_lo = z_lo < 0 ? 0 : z_lo;
   z_hi = z_hi > d->Z - 1 ? d->Z - 1 : z_hi;
-  if (z_lo > z_hi) return VAMP_OK;
+  if (z_lo > z_hi)
+    return bev_zero_overwritten(d, flags, grad_density_feature, grad_semantic, grad_rgb, grad_base,
+                                static_cast<hipStream_t>(stream));
 
   dim3 gq((d->oX + 63) / 64, d->oY, d->B * d->oZ);
   dim3 gs((d->oX + 63) / 64, (d->oY + 3) / 4, d->B);
@@ -744,6 +830,10 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
     const float e = d->span[a] / (float) (nvox[a] - 1);
     if (!(d->det_step[a] > 0.f) || (int) floorf(2.0f * e / d->det_step[a]) + 1 > kMaxT) fits = false;
   }
+  // the column gather walks the heights upwards and keeps their z taps in an LDS table
+  if (d->oZ > kBevMaxOZ) fits = false;
+  for (int k = 1; k < d->oZ; ++k)
+    if (!(ozs_host[k] > ozs_host[k - 1])) fits = false;
   if (fits) {
     // 32-bit element offsets inside the gather
     const size_t lim = 0x7fffffffu;
@@ -753,25 +843,66 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
     VAMP_TIMED(kProfAux, s, (bev_axis_table_kernel<<<(tot_ax + 255) / 256, 256, 0, s>>>(P, oxs, oys, ozs, tab)));
     if (int e = check_launch("bev_axis_table_kernel")) return e;
     const bool vo_sem = g_voxel_output && d->cat_seg;
-    // rgb launch (one group) also carries the density channel
-    VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_kernel<1><<<gg, 256, 0, s>>>(
-        P, tab, g_bev_rgb, g_voxel_output, Wb, DS0, grad_density_feature, grad_rgb, z_lo, z_hi, 1)));
-    if (d->K > 0 && (g_bev_seg || vo_sem)) {
-      dim3 g0(gg.x, gg.y, gg.z * ((d->K + kPer - 1) / kPer));
-      VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_kernel<0><<<g0, 256, 0, s>>>(
-          P, tab, g_bev_seg, g_voxel_output, Wb, DS0, grad_density_feature, grad_semantic, z_lo, z_hi, 0)));
-    }
-    if (d->C > 0 && g_voxel_output) {
-      dim3 g2(gg.x, gg.y, gg.z * ((d->C + kPer - 1) / kPer));
-      VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_kernel<2><<<g2, 256, 0, s>>>(
-          P, tab, nullptr, g_voxel_output, Wb, DS0, grad_density_feature, grad_base, z_lo, z_hi, 0)));
-    }
+    const int ow = (flags & VAMP_BEVBWD_OVERWRITE_BASE) ? 1 : 0;
+    const int owc = (flags & VAMP_BEVBWD_OVERWRITE_CAM) ? 3 : 0;
+    // z-segments: a segment redoes the plane sums of the one or two heights that straddle its
+    // lower edge, so as few as fill the chip (cfg-B, composited + pass-through launch, us:
+    // 1 segment 40 + 29, 2 segments 40 + 25, 4 segments 43 + 25, 8 segments 73 + 29)
+    const long wgs = (((long) d->Y * d->X + 255) / 256) * d->B * ((d->C + kColG - 1) / kColG);
+    int nseg = (int) std::min<long>(std::max<long>(1, (1250 + wgs - 1) / std::max<long>(1, wgs)), std::max(1, d->Z / 4));
+    const int zseg = (d->Z + nseg - 1) / nseg;
+    nseg = (d->Z + zseg - 1) / zseg;
+    auto grid = [&](int nchan, int g = kColG) {
+      return dim3((unsigned) (((long) d->Y * d->X + 255) / 256), d->B * nseg * ((nchan + g - 1) / g));
+    };
+    // semantic + rgb + density in one launch (they share the Wb taps of a height)
+    if (owc) VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_col_kernel<kColGC, true, false, true><<<grid(d->K + 3, kColGC), 256, 0, s>>>(
+        P, tab, ozs, g_bev_seg, g_bev_rgb, nullptr, -1, Wb, DS0, grad_density_feature, grad_semantic, grad_rgb,
+        d->K, 3, zseg, 1, 0)));
+    else VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_col_kernel<kColGC, true, false, false><<<grid(d->K + 3, kColGC), 256, 0, s>>>(
+        P, tab, ozs, g_bev_seg, g_bev_rgb, nullptr, -1, Wb, DS0, grad_density_feature, grad_semantic, grad_rgb,
+        d->K, 3, zseg, 1, 0)));
+    if (int e = check_launch("bev_gather_col_kernel")) return e;
+    // pass-through gradients (voxel_output): the semantic part (cat_seg) adds, base is its own tensor
+    if (vo_sem)
+      VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_col_kernel<kColG, false, true, false><<<grid(d->K), 256, 0, s>>>(
+          P, tab, ozs, nullptr, nullptr, g_voxel_output, d->C, Wb, DS0, grad_density_feature, grad_semantic,
+          nullptr, d->K, 0, zseg, 0, 0)));
+    if (d->C > 0 && g_voxel_output && ow)
+      VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_col_kernel<kColG, false, true, true><<<grid(d->C), 256, 0, s>>>(
+          P, tab, ozs, nullptr, nullptr, g_voxel_output, 0, Wb, DS0, grad_density_feature, grad_base, nullptr,
+          d->C, 0, zseg, 0, 0)));
+    else if (d->C > 0 && g_voxel_output)
+      VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_col_kernel<kColG, false, true, false><<<grid(d->C), 256, 0, s>>>(
+          P, tab, ozs, nullptr, nullptr, g_voxel_output, 0, Wb, DS0, grad_density_feature, grad_base, nullptr,
+          d->C, 0, zseg, 0, 0)));
+    else if (d->C > 0 && ow)
+      if (int ze = launch_zero(grad_base, (size_t) d->B * d->C * d->Z * d->Y * d->X * sizeof(float), s)) return ze;
   }
-  else
+  else {
+    // the generic kernel adds: zero what the caller asked to have overwritten
+    if (int e = bev_zero_overwritten(d, flags, grad_density_feature, grad_semantic, grad_rgb, grad_base, s))
+      return e;
     VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_generic_kernel<<<gg, 256, 0, s>>>(
         P, oxs, oys, ozs, g_bev_rgb, g_bev_seg, g_voxel_output, Wb, DS0, grad_density_feature,
         grad_semantic, grad_rgb, grad_base, z_lo, z_hi)));
+  }
   return check_launch("bev_gather_kernel");
+}
+
+int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const float* oys,
+                             const float* ozs, const float* bev_mids, const float* beta,
+                             const void* density_feature, const void* semantic, const void* rgb,
+                             const void* base, const float* g_bev_rgb, const float* g_bev_seg,
+                             const float* g_bev_height, const float* g_voxel_density,
+                             const float* g_voxel_output, float* grad_density_feature,
+                             float* grad_semantic, float* grad_rgb, float* grad_base,
+                             float* grad_beta, const float* ozs_host, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  return vamp_render_bev_backward_ex(d, oxs, oys, ozs, bev_mids, beta, density_feature, semantic, rgb, base,
+                                     g_bev_rgb, g_bev_seg, g_bev_height, g_voxel_density, g_voxel_output,
+                                     grad_density_feature, grad_semantic, grad_rgb, grad_base, grad_beta,
+                                     ozs_host, workspace, workspace_bytes, 0, stream);
 }
 
 }  // extern "C"

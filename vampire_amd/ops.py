@@ -91,6 +91,9 @@ class HotPath:
                      # camera branch terminates rays early it costs more than it hides (forward pair 296 vs
                      # 210 us, step 0.806 vs 0.804 ms), so off unless asked for
                      "overlap": os.environ.get("VAMP_OVERLAP", "0") == "1",
+                     # single stream: BEV branch first (overwriting), camera gather adds -- or the
+                     # camera branch first and the BEV gather adds
+                     "bev_first": os.environ.get("VAMP_BEV_FIRST", "1") == "1",
                      # store the forward's sample rows for the backward's per-ray pass: measured
                      # neutral at cfg-B (forward +50 us for the scattered row stores, backward -59 us),
                      # so off unless asked for
@@ -473,16 +476,22 @@ class _RenderFn(torch.autograd.Function):
             nbytes += hp.lib.vamp_render_samples_bytes(C.byref(d))
         ws = hp._workspace("render", nbytes)
         ws_bev = hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d)))
-        gb = torch.zeros(base.shape, dtype=f32, device=dens.device)
+        # every gradient buffer is written in full by the calls below (the BEV branch overwrites,
+        # the camera branch adds, or the other way round): no zero fills
+        gb = torch.empty(base.shape, dtype=f32, device=dens.device)
+        gd = torch.empty(dens.shape, dtype=f32, device=dens.device)
+        gs = torch.empty(sem.shape, dtype=f32, device=dens.device)
+        gr = torch.empty(rgb.shape, dtype=f32, device=dens.device)
         gbeta = torch.zeros(1, dtype=f32, device=dens.device)
 
-        def bev_backward(stream):
-            _capi.check(hp.lib.vamp_render_bev_backward(
+        def bev_backward(stream, overwrite_cam):
+            flags = _capi.VAMP_BEVBWD_OVERWRITE_BASE | (_capi.VAMP_BEVBWD_OVERWRITE_CAM if overwrite_cam else 0)
+            _capi.check(hp.lib.vamp_render_bev_backward_ex(
                 C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
                 _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(g_brgb), _ptr(g_bseg), _ptr(g_bh),
                 _ptr(g_vd), _ptr(g_vo), _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gb), _ptr(gbeta),
                 None if hp.impl["bev_bwd"] == "v1" else hp.ozs_host, _ptr(ws_bev), ws_bev.numel(),
-                _stream(stream)), "vamp_render_bev_backward")
+                flags, _stream(stream)), "vamp_render_bev_backward_ex")
 
         cam_args = (C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
                     _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(g_rgb),
@@ -503,29 +512,28 @@ class _RenderFn(torch.autograd.Function):
         hp._pack_gen = getattr(hp, "_pack_gen", 0) + 1          # the backward scribbles after the copy only,
         ctx.pack_key = None                                     # but a second backward must not assume so
         if side is not None and geom is None and default_impl:
-            # Two streams: the BEV branch accumulates into zeroed buffers on the side stream while
-            # the camera branch marches its rays and sorts its samples on this one; the camera
-            # gather then waits for the BEV event and adds on top.
-            gd = torch.zeros(dens.shape, dtype=f32, device=dens.device)
-            gs = torch.zeros(sem.shape, dtype=f32, device=dens.device)
-            gr = torch.zeros(rgb.shape, dtype=f32, device=dens.device)
+            # Two streams: the BEV branch writes the buffers on the side stream while the camera
+            # branch marches its rays and sorts its samples on this one; the camera gather then
+            # waits for the BEV event and adds on top.
             side.wait_stream(cur)
-            bev_backward(side)
+            bev_backward(side, True)
             done = torch.cuda.Event()
             done.record(side)
             _capi.check(hp.lib.vamp_render_camera_backward_acc(
                 *cam_args, _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gbeta), _ptr(ws), ws.numel(), 1 | packed_valid,
                 C.c_void_p(done.cuda_event), _stream(cur)), "vamp_render_camera_backward_acc")
             cur.wait_stream(side)
+        elif hp.impl["bev_first"] and geom is None and default_impl:
+            bev_backward(cur, True)
+            _capi.check(hp.lib.vamp_render_camera_backward_acc(
+                *cam_args, _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gbeta), _ptr(ws), ws.numel(), 1 | packed_valid,
+                None, _stream(cur)), "vamp_render_camera_backward_acc")
         else:
-            gd = torch.empty(dens.shape, dtype=f32, device=dens.device)
-            gs = torch.empty(sem.shape, dtype=f32, device=dens.device)
-            gr = torch.empty(rgb.shape, dtype=f32, device=dens.device)
             _capi.check(hp.lib.vamp_render_camera_backward_acc(
                 *cam_args, _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gbeta), _ptr(ws), ws.numel(),
                 packed_valid | (0 if default_impl else _capi.VAMP_CAMBWD_SPLAT), None, _stream(cur)),
                 "vamp_render_camera_backward_acc")
-            bev_backward(cur)
+            bev_backward(cur, False)
         grad_beta = gbeta.reshape(ctx.beta_shape) if hp.cfg.density_mode == "sdf" else None
         dt = ctx.in_dtypes
         return (None, gd.to(dt[0]), gs.to(dt[1]), gb.to(dt[2]), gr.to(dt[3]), grad_beta, None, None)
