@@ -151,6 +151,30 @@ constexpr int reduce_dups() {
   else if constexpr (N % 2 == 0) return reduce_dups<N / 2, O / 2>();
   else return O | reduce_dups<N, O / 2>();
 }
+// The exchanges never touch the LDS crossbar (ds_bpermute, what __shfl_xor compiles to, made this
+// reduction 16 of the lift gather's 82 us): across 32 and 16 lanes gfx950's v_permlane32_swap /
+// v_permlane16_swap trade the two halves in one instruction; inside a row of 16 the partner comes
+// through DPP -- row_ror:8 (l ^ 8), row_half_mirror (l ^ 7: differs from l in bit 2, which is all
+// a pairing step needs, and the two steps that follow pair l ^ 2 and l ^ 1, so the eight lanes
+// are still covered), quad_perm (l ^ 2, l ^ 1).
+template <int O>
+__device__ __forceinline__ float lane_partner(float v) {
+  static_assert(O == 8 || O == 4 || O == 2 || O == 1, "DPP partner inside a row of 16");
+  constexpr int ctrl = O == 8 ? 0x128 : (O == 4 ? 0x141 : (O == 2 ? 0x4E : 0xB1));
+  return __builtin_amdgcn_update_dpp(0.f, v, ctrl, 0xf, 0xf, false);
+}
+// lanes whose bit O is clear get lo(l) + lo(l ^ O), the others hi(l) + hi(l ^ O)   (O = 32, 16)
+template <int O>
+__device__ __forceinline__ float swap_add(float lo, float hi) {
+  static_assert(O == 32 || O == 16, "row swaps");
+  if constexpr (O == 32) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  } else {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+}
 template <int N, int O, int W, int CP>
 __device__ __forceinline__ void reduce_halving(float (&a)[CP], int l, int& cbase) {
   if constexpr (O == 0) {
@@ -158,17 +182,25 @@ __device__ __forceinline__ void reduce_halving(float (&a)[CP], int l, int& cbase
   } else if constexpr (N % 2 == 0) {
     constexpr int H = N / 2;
     const bool up = (l & O) != 0;
+    if constexpr (O >= 16) {
 #pragma unroll
-    for (int c = 0; c < H; ++c) {
-      const float send = up ? a[c] : a[c + H];
-      const float keep = up ? a[c + H] : a[c];
-      a[c] = keep + __shfl_xor(send, O, W);
+      for (int c = 0; c < H; ++c) a[c] = swap_add<O>(a[c], a[c + H]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < H; ++c) {
+        const float send = up ? a[c] : a[c + H];
+        const float keep = up ? a[c + H] : a[c];
+        a[c] = keep + lane_partner<O>(send);
+      }
     }
     cbase += up ? H : 0;
     reduce_halving<H, O / 2, W, CP>(a, l, cbase);
   } else {
 #pragma unroll
-    for (int c = 0; c < N; ++c) a[c] += __shfl_xor(a[c], O, W);
+    for (int c = 0; c < N; ++c) {
+      if constexpr (O >= 16) a[c] = swap_add<O>(a[c], a[c]);
+      else a[c] += lane_partner<O>(a[c]);
+    }
     reduce_halving<N, O / 2, W, CP>(a, l, cbase);
   }
 }

@@ -5,9 +5,11 @@
 //           increments the counter of its cell = (camera, floor tap row + 1, floor tap column + 1),
 //           (fH + 1) x (fW + 1) cells per camera
 //   scan    two-level exclusive prefix sum of the counters -> cell start offsets (runtime.hip)
-//   fill    same walk; the pair's record {ix0, iy0, iz0, wz0, wz1 | w[4]*dep[4] | w[4] | gs[C]} --
+//   fill    same walk; the pair's record {iz0, wz0, wz1 | w[4]*dep[4] | w[4] | gs[C]} --
 //           tap weights, depth-interpolated values, grad_out / (hits + 1e-6) -- goes to the next
-//           slot of its cell (slots handed out by atomics on the cell cursor)
+//           slot of its cell (slots handed out by atomics on the cell cursor).  Records are
+//           stored field-major (one float4 array per 16-byte field, indexed by slot): the gather
+//           reads a field of 64 consecutive records as one contiguous kilobyte
 //   gather  one wave (or 4, or 16) per feature-map pixel: the pairs whose 2x2 pixel taps include
 //           pixel (x, y) are exactly those of the cells (x..x+1, y..y+1), two contiguous record
 //           ranges.  Lane = record: grad_feat partial sums in registers (folded over the lanes at
@@ -27,7 +29,7 @@ namespace vamp {
 
 constexpr int LGL = 16;              // lanes per record = channel lanes
 constexpr int kMinWaves = 4;         // waves per gather workgroup (more when a pixel takes more)
-constexpr int kRecHead = 16;         // floats before gs[] in a record
+constexpr int kRecHead4 = 3;         // float4 fields before gs[] in a record
 
 struct LiftCells {
   int cw, ch;                        // cells per row / column of one camera
@@ -53,7 +55,7 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
                      const float* __restrict__ zs, const T* __restrict__ depth,
                      const float* __restrict__ gout, const uint64_t* __restrict__ hits,
                      int* __restrict__ cnt, const int* __restrict__ off,
-                     const int* __restrict__ boff, float* __restrict__ entries) {
+                     const int* __restrict__ boff, float4* __restrict__ entries, long cap) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int x = blockIdx.x * 64 + lane;
   const int y = blockIdx.y * 4 + (tid >> 6);
@@ -64,7 +66,6 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
   const long V = (long) P.Z * P.Y * P.X;
   const long vox = ((long) z * P.Y + yc) * P.X + xc;
   const long HW = (long) P.fH * P.fW;
-  const int ES = kRecHead + P.C;
 
   constexpr int NB = 8;                          // cameras per batch: their atomics are in flight together
   const bool first_chunk_only = P.C == CH;
@@ -111,7 +112,7 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
       const LiftTap t = lift_project(P, mats + bn * 48, vx, vy, vz);
       const long cell = (bn * ch + (t.iy0 + 1)) * cw + (t.ix0 + 1);
       const long slot = (long) off[cell] + boff[cell / kScanTile] + rb + (lane - start[k]);
-      float* e = entries + slot * ES;
+      float4* e4 = entries + slot;               // field f of this record: e4[f * cap]
 
       const float wj[4] = {t.wy0 * t.wx0, t.wy0 * t.wx1, t.wy1 * t.wx0, t.wy1 * t.wx1};
       float dep[4] = {0.f, 0.f, 0.f, 0.f};
@@ -135,14 +136,12 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
         const float w = (t.iz0 == 0 ? t.wz0 : 0.f) + (t.iz0 == -1 ? t.wz1 : 0.f);
         dep[0] = dep[1] = dep[2] = dep[3] = w;
       }
-      float4* e4 = reinterpret_cast<float4*>(e);
-      e4[0] = make_float4(__int_as_float(t.ix0), __int_as_float(t.iy0), __int_as_float(t.iz0), 0.f);
-      e4[1] = make_float4(t.wz0, t.wz1, 0.f, 0.f);
-      e4[2] = make_float4(wj[0] * dep[0], wj[1] * dep[1], wj[2] * dep[2], wj[3] * dep[3]);
-      e4[3] = make_float4(wj[0], wj[1], wj[2], wj[3]);
+      e4[0] = make_float4(__int_as_float(t.iz0), t.wz0, t.wz1, 0.f);
+      e4[cap] = make_float4(wj[0] * dep[0], wj[1] * dep[1], wj[2] * dep[2], wj[3] * dep[3]);
+      e4[2 * cap] = make_float4(wj[0], wj[1], wj[2], wj[3]);
 #pragma unroll
       for (int c4 = 0; c4 < CH; c4 += 4)
-        *reinterpret_cast<float4*>(e + kRecHead + c4) = make_float4(gs0[c4], gs0[c4 + 1], gs0[c4 + 2], gs0[c4 + 3]);
+        e4[(kRecHead4 + c4 / 4) * cap] = make_float4(gs0[c4], gs0[c4 + 1], gs0[c4 + 2], gs0[c4 + 3]);
       if (!first_chunk_only)
         for (int chunk = 1; chunk < P.C / CH; ++chunk) {
           const uint64_t hw = hits[((long) b * V + vox) * (P.C / CH) + chunk];
@@ -153,7 +152,7 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
 #pragma unroll
             for (int q = 0; q < 4; ++q)
               v[q] = g[(long) (c4 + q) * V] / ((float) ((hw >> (4 * (c4 + q))) & 15) + 1e-6f);
-            *reinterpret_cast<float4*>(e + kRecHead + chunk * CH + c4) = make_float4(v[0], v[1], v[2], v[3]);
+            e4[(kRecHead4 + (chunk * CH + c4) / 4) * cap] = make_float4(v[0], v[1], v[2], v[3]);
           }
         }
     }
@@ -175,8 +174,8 @@ __global__ void __launch_bounds__(1024)
 lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
                             const T* __restrict__ feat,
                             const int* __restrict__ off, const int* __restrict__ boff,
-                            const float* __restrict__ entries, float* __restrict__ gdepth,
-                            float* __restrict__ gfeat) {
+                            const float4* __restrict__ entries, long cap,
+                            float* __restrict__ gdepth, float* __restrict__ gfeat) {
   extern __shared__ float smem[];                // [ppb][Dp] depth columns, then [waves][16]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int C = P.C, D = P.use_depth ? P.D : 0;
@@ -196,22 +195,25 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
   const long bn = pid / HW;
   const int pix = (int) (pid % HW);
   const int iy = pix / P.fW, ix = pix % P.fW;
-  const int ES = kRecHead + C;
 
   float* gcol = gd + pw * Dp;
   for (int dz = ws * 64 + lane; dz < D; dz += wpp * 64) gcol[dz] = 0.f;
   __syncthreads();
 
-  // record ranges of cell rows iy and iy + 1, columns ix .. ix + 1
-  int beg0, n0, beg1, tot;
+  // record ranges of cell rows iy and iy + 1, columns ix .. ix + 1 (mid = where column ix + 1
+  // starts).  The cell tells which tap of the record this pixel is: a record of cell
+  // (row, column) has iy0 = row - 1, ix0 = column - 1.
+  int beg0, mid0, n0, beg1, mid1, tot;
   {
-    const int r = (lane >> 1) & 1;
-    const long c = (bn * ch + iy + r) * cw + ix + 2 * (lane & 1);
+    const int l6 = min(lane, 5);
+    const long c = (bn * ch + iy + l6 / 3) * cw + ix + l6 % 3;
     const int sv = off[c] + boff[c / kScanTile];
     beg0 = __shfl(sv, 0, 64);
-    n0 = __shfl(sv, 1, 64) - beg0;
-    beg1 = __shfl(sv, 2, 64);
-    tot = n0 + __shfl(sv, 3, 64) - beg1;
+    mid0 = __shfl(sv, 1, 64);
+    n0 = __shfl(sv, 2, 64) - beg0;
+    beg1 = __shfl(sv, 3, 64);
+    mid1 = __shfl(sv, 4, 64);
+    tot = n0 + __shfl(sv, 5, 64) - beg1;
   }
   if (!pix_ok) tot = 0;
 
@@ -231,21 +233,26 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
       const int k = k0 + lane;
       const bool in = k < tot;
       const int kc = min(k, tot - 1);
-      const long pos = kc < n0 ? (long) beg0 + kc : (long) beg1 + (kc - n0);
-      const float* e = entries + pos * ES;
-      const float4 ha = *reinterpret_cast<const float4*>(e);
-      const float4 hb = *reinterpret_cast<const float4*>(e + 4);
-      const float4 pwv = *reinterpret_cast<const float4*>(e + 8);
-      const float4 ww = *reinterpret_cast<const float4*>(e + 12);
+      const bool row0 = kc < n0;
+      const long pos = row0 ? (long) beg0 + kc : (long) beg1 + (kc - n0);
+      const float4* e = entries + pos;
+      const float4 hb = e[0];
+      const float4 pwv = e[cap];
+      const float4 ww = e[2 * cap];
       float gs[16];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < nq) g4 = *reinterpret_cast<const float4*>(e + kRecHead + c0 + 4 * q);   // uniform branch
+#ifndef ABL_NOGS
+        if (q < nq) g4 = e[(kRecHead4 + c0 / 4 + q) * cap];   // uniform branch
+#else
+        g4 = make_float4(hb.y, hb.z, hb.y, hb.z);
+#endif
         gs[4 * q] = g4.x; gs[4 * q + 1] = g4.y; gs[4 * q + 2] = g4.z; gs[4 * q + 3] = g4.w;
       }
-      const int ix0 = __float_as_int(ha.x), iy0 = __float_as_int(ha.y), iz0 = __float_as_int(ha.z);
-      const int j = (iy - iy0) * 2 + (ix - ix0);         // which of the record's taps this pixel is
+      const int iz0 = __float_as_int(hb.x);
+      // which of the record's taps this pixel is: (iy - iy0) * 2 + (ix - ix0)
+      const int j = (row0 ? 2 : 0) + ((pos >= (row0 ? mid0 : mid1)) ? 0 : 1);
       const float pwj = in ? (j == 0 ? pwv.x : (j == 1 ? pwv.y : (j == 2 ? pwv.z : pwv.w))) : 0.f;
       const float wj = in ? (j == 0 ? ww.x : (j == 1 ? ww.y : (j == 2 ? ww.z : ww.w))) : 0.f;
       float dot = 0.f;
@@ -254,17 +261,31 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
         acc[c] = __builtin_fmaf(pwj, gs[c], acc[c]);
         dot = __builtin_fmaf(ft[c], gs[c], dot);
       }
+#ifdef ABL_NODEPTH
+      if (false) {
+#else
       if (D > 0 && in) {
+#endif
         const float wd = wj * dot;
         if (wd != 0.f) {
-          if (iz0 >= 0 && iz0 < D) atomicAdd(gcol + iz0, hb.x * wd);
-          if (iz0 + 1 >= 0 && iz0 + 1 < D) atomicAdd(gcol + iz0 + 1, hb.y * wd);
+#ifdef ABL_PLAINST
+          if (iz0 >= 0 && iz0 < D) gcol[iz0] = hb.y * wd;
+          if (iz0 + 1 >= 0 && iz0 + 1 < D) gcol[iz0 + 1] = hb.z * wd;
+#elif defined(ABL_NOBR)
+          atomicAdd(gcol + min(max(iz0, 0), D - 1), (iz0 >= 0 && iz0 < D) ? hb.y * wd : 0.f);
+          atomicAdd(gcol + min(max(iz0 + 1, 0), D - 1), (iz0 + 1 >= 0 && iz0 + 1 < D) ? hb.z * wd : 0.f);
+#else
+          if (iz0 >= 0 && iz0 < D) atomicAdd(gcol + iz0, hb.y * wd);
+          if (iz0 + 1 >= 0 && iz0 + 1 < D) atomicAdd(gcol + iz0 + 1, hb.z * wd);
+#endif
         }
       }
     }
     // fold the 64 lanes' partial sums: afterwards lane l holds channel c0 + (l >> 2)
     int cb = 0;
+#ifndef ABL_NORED
     reduce_halving<16, 32, 64, 16>(acc, lane, cb);
+#endif
     static_assert(reduce_left<16, 32>() == 1 && reduce_dups<16, 32>() == 3, "16 values over 64 lanes");
     if (wpp == 1) {
       if (pix_ok && (lane & 3) == 0 && c0 + cb < C) gfeat[(bn * C + c0 + cb) * HW + pix] = acc[0];
@@ -279,7 +300,11 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
       __syncthreads();
     }
   }
+#ifdef ABL_NOCOL
+  if (false) {
+#else
   if (D > 0 && gdepth) {
+#endif
     __syncthreads();
     // consecutive threads = consecutive pixels of one depth plane
     for (int e = tid; e < D * ppb; e += nw * 64) {
@@ -296,7 +321,7 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
 // ---------------------------------------------------------------------------
 struct LiftCellWs {
   int *cnt, *off, *bsum, *boff, *aux;
-  float* entries;
+  float4* entries;                   // [kRecHead4 + C / 4][cap]
   size_t bytes;
 };
 
@@ -312,7 +337,7 @@ static LiftCellWs lift_cell_ws(const VampLiftDesc* d, void* scratch) {
   w.bsum = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
   w.boff = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
   w.aux = reinterpret_cast<int*>(p); p += align_up((size_t) (ntile + 4) * sizeof(int), 256);
-  w.entries = reinterpret_cast<float*>(p); p += align_up(cap * (kRecHead + d->C) * sizeof(float), 256);
+  w.entries = reinterpret_cast<float4*>(p); p += align_up(cap * (kRecHead4 + (d->C + 3) / 4) * sizeof(float4), 256);
   w.bytes = (size_t) (p - static_cast<char*>(scratch));
   return w;
 }
@@ -330,7 +355,7 @@ int launch_lift_cell_prepare(const VampLiftDesc* d, const float* mats, const flo
   if (int ze = launch_zero(w.cnt, (size_t) g.ncell * sizeof(int), s)) return ze;
   dim3 grid((d->X + 63) / 64, (d->Y + 3) / 4, d->Z * d->B);
   VAMP_TIMED(kProfLiftBwdCount, s, (lift_bwd_cell_kernel<float, 16, false><<<grid, 256, 0, s>>>(
-      P, g.cw, g.ch, mats, xs, ys, zs, nullptr, nullptr, nullptr, w.cnt, w.off, w.boff, w.entries)));
+      P, g.cw, g.ch, mats, xs, ys, zs, nullptr, nullptr, nullptr, w.cnt, w.off, w.boff, w.entries, (long) cap)));
   if (int e = check_launch("lift_bwd_cell_kernel<count>")) return e;
   return launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, g.ncell, s);
 }
@@ -342,6 +367,7 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
                          float* gfeat, void* scratch, bool cells_valid, int wpp_force, hipStream_t s) {
   const LiftCells g = lift_cells(d);
   const LiftCellWs w = lift_cell_ws(d, scratch);
+  const size_t cap = (size_t) d->B * d->N * d->Z * d->Y * d->X;
   if (!cells_valid)
     if (int e = launch_lift_cell_prepare(d, mats, xs, ys, zs, scratch, s)) return e;
   // the counters become the fill cursors
@@ -350,7 +376,7 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
   const T* dp = static_cast<const T*>(depth);
 #define VAMP_CELL(CH)                                                                            \
   VAMP_TIMED(kProfLiftBwdFill, s, (lift_bwd_cell_kernel<T, CH, true><<<grid, 256, 0, s>>>(       \
-      P, g.cw, g.ch, mats, xs, ys, zs, dp, gout, hits, w.cnt, w.off, w.boff, w.entries)))
+      P, g.cw, g.ch, mats, xs, ys, zs, dp, gout, hits, w.cnt, w.off, w.boff, w.entries, (long) cap)))
   if (P.C == 4) VAMP_CELL(4); else if (P.C == 8) VAMP_CELL(8); else VAMP_CELL(16);
 #undef VAMP_CELL
   if (int e = check_launch("lift_bwd_cell_kernel<fill>")) return e;
@@ -374,7 +400,7 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
       return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);
     VAMP_TIMED(kProfLiftBwd, s, (k<<<ggrid, nw * 64, lds, s>>>(
         P, g.cw, g.ch, wpp, (d->fW % ppb == 0) ? d->fW / ppb : 0, static_cast<const T*>(feat), w.off,
-        w.boff, w.entries, gdepth, gfeat)));
+        w.boff, w.entries, (long) cap, gdepth, gfeat)));
   }
   return check_launch("lift_bwd_cell_gather_kernel");
 }
