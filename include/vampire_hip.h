@@ -312,6 +312,21 @@ int vamp_render_bev_forward(const VampRenderDesc* d, const float* oxs, const flo
                             float* voxel_output, void* stream);
 
 /*
+ * The same with flags.  VAMP_BEVFWD_SAVE (training): the density samples and the composited
+ * channels' samples of every det-grid point are kept in `workspace`
+ * (vamp_render_bev_workspace_bytes(d) bytes; +35 MB per sample at cfg-B); a backward call on the
+ * same workspace with VAMP_BEVBWD_SAVED_VALID reads them back instead of sampling again.
+ */
+#define VAMP_BEVFWD_SAVE 1
+int vamp_render_bev_forward_ex(const VampRenderDesc* d, const float* oxs, const float* oys,
+                            const float* ozs, const float* bev_mids, const float* beta,
+                            const void* density_feature, const void* semantic,
+                            const void* rgb, const void* base, float* bev_rgb,
+                            float* bev_seg, float* bev_height, float* voxel_density,
+                            float* voxel_output, void* workspace,
+                            size_t workspace_bytes, int flags, void* stream);
+
+/*
  * BEV branch, backward.  The four volume gradients are ACCUMULATED into (so that
  * the camera-branch backward can run first into the same buffers); grad_base is
  * written only by this call and must be zero-filled (or hold a running sum).
@@ -339,6 +354,7 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
  */
 #define VAMP_BEVBWD_OVERWRITE_BASE 1   /* grad_base */
 #define VAMP_BEVBWD_OVERWRITE_CAM 2    /* grad_density_feature, grad_semantic, grad_rgb */
+#define VAMP_BEVBWD_SAVED_VALID 4      /* the workspace holds what vamp_render_bev_forward_ex(.., VAMP_BEVFWD_SAVE) kept */
 int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const float* oys,
                              const float* ozs, const float* bev_mids, const float* beta,
                              const void* density_feature, const void* semantic,

@@ -59,7 +59,8 @@ VAMP_CAMBWD_ACCUMULATE, VAMP_CAMBWD_PACKED_VALID, VAMP_CAMBWD_CELLS_VALID, VAMP_
 VAMP_CAMBWD_SAMPLES_VALID, VAMP_CAMBWD_TERM_VALID, VAMP_CAMBWD_NO_ERT = 16, 32, 64
 VAMP_CAMFWD_SAVE_SAMPLES, VAMP_CAMFWD_NO_ERT, VAMP_CAMFWD_TERM_VALID = 1, 2, 4
 VAMP_CAMPREP_TERM_VALID = 1
-VAMP_BEVBWD_OVERWRITE_BASE, VAMP_BEVBWD_OVERWRITE_CAM = 1, 2
+VAMP_BEVBWD_OVERWRITE_BASE, VAMP_BEVBWD_OVERWRITE_CAM, VAMP_BEVBWD_SAVED_VALID = 1, 2, 4
+VAMP_BEVFWD_SAVE = 1
 
 _P = C.c_void_p
 _LD = C.POINTER(VampLiftDesc)
@@ -94,6 +95,7 @@ SIGNATURES = {
     "vamp_render_camera_prepare": (C.c_int, [_RD] + [_P] * 4 + [_P, C.c_size_t, _P]),
     "vamp_render_camera_backward_acc": (C.c_int, [_RD] + [_P] * 17 + [_P, C.c_size_t, C.c_int, _P, _P]),
     "vamp_render_bev_forward": (C.c_int, [_RD] + [_P] * 14 + [_P]),
+    "vamp_render_bev_forward_ex": (C.c_int, [_RD] + [_P] * 14 + [_P, C.c_size_t, C.c_int, _P]),
     "vamp_render_bev_workspace_bytes": (C.c_size_t, [_RD]),
     "vamp_render_bev_backward": (C.c_int, [_RD] + [_P] * 19 + [C.POINTER(C.c_float), _P, C.c_size_t, _P]),
     "vamp_render_bev_backward_ex": (C.c_int, [_RD] + [_P] * 19 + [C.POINTER(C.c_float), _P, C.c_size_t, C.c_int, _P]),

@@ -82,12 +82,18 @@ __device__ __forceinline__ float bilinear_plane(const RenderParams& P, const T* 
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
+// Heights are taken kHChunk at a time: a column is one thread and the grid is only oY * oX / 64
+// waves, so the loads of one height cannot hide behind other waves -- the taps of a whole chunk
+// are issued together instead of one round trip per height.
+constexpr int kHChunk = 5;
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 bev_density_kernel(RenderParams P, const float* __restrict__ oxs, const float* __restrict__ oys,
                    const float* __restrict__ ozs, const float* __restrict__ bev_mids,
                    const float* __restrict__ beta_raw, const T* __restrict__ dens,
-                   float* __restrict__ voxel_density, float* __restrict__ bev_height) {
+                   float* __restrict__ voxel_density, float* __restrict__ bev_height,
+                   float* __restrict__ s0_save) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int b = blockIdx.z;
@@ -97,13 +103,25 @@ bev_density_kernel(RenderParams P, const float* __restrict__ oxs, const float* _
   const AxisTap tx = axis_tap(oxs[x], P.lo[0], P.span[0], P.X);
   const AxisTap ty = axis_tap(oys[y], P.lo[1], P.span[1], P.Y);
   float cum = 0.f, height = 0.f;
-  for (int j = 0; j < P.oZ; ++j) {
-    const AxisTap tz = axis_tap(ozs[P.oZ - 1 - j], P.lo[2], P.span[2], P.Z);     // flip (bv2:443)
-    const float sigma = density_fwd(dp, sample8(P, dens, (long) b * V, tx, ty, tz));
-    voxel_density[((long) b * P.oZ + j) * OYX + col] = sigma;
-    const float tau = sigma * (1.0f * P.z_step);                                  // bv2:451-453
-    height = __builtin_fmaf((1.0f - expf(-tau)) * expf(-cum), bev_mids[j], height);
-    cum += tau;
+  for (int j0 = 0; j0 < P.oZ; j0 += kHChunk) {
+    float s0[kHChunk];
+#pragma unroll
+    for (int u = 0; u < kHChunk; ++u) {
+      const int j = min(j0 + u, P.oZ - 1);
+      const AxisTap tz = axis_tap(ozs[P.oZ - 1 - j], P.lo[2], P.span[2], P.Z);     // flip (bv2:443)
+      s0[u] = sample8(P, dens, (long) b * V, tx, ty, tz);
+    }
+#pragma unroll
+    for (int u = 0; u < kHChunk; ++u) {
+      const int j = j0 + u;
+      if (j >= P.oZ) break;
+      const float sigma = density_fwd(dp, s0[u]);
+      voxel_density[((long) b * P.oZ + j) * OYX + col] = sigma;
+      if (s0_save) s0_save[((long) b * P.oZ + j) * OYX + col] = s0[u];           // for the backward's scan
+      const float tau = sigma * (1.0f * P.z_step);                                  // bv2:451-453
+      height = __builtin_fmaf((1.0f - expf(-tau)) * expf(-cum), bev_mids[j], height);
+      cum += tau;
+    }
   }
   bev_height[(long) b * OYX + col] = height;
 }
@@ -127,7 +145,8 @@ bev_channels_kernel(RenderParams P, const float* __restrict__ oxs, const float* 
                     const float* __restrict__ ozs, const T* __restrict__ sem,
                     const T* __restrict__ rgb, const T* __restrict__ base,
                     const float* __restrict__ voxel_density, float* __restrict__ bev_rgb,
-                    float* __restrict__ bev_seg, float* __restrict__ voxel_output) {
+                    float* __restrict__ bev_seg, float* __restrict__ voxel_output,
+                    float* __restrict__ ss_save) {
   __shared__ int tz_i0[kBevMaxOZ];
   __shared__ float tz_w0[kBevMaxOZ], tz_w1[kBevMaxOZ];
   if ((int) threadIdx.x < P.oZ) {
@@ -201,6 +220,8 @@ bev_channels_kernel(RenderParams P, const float* __restrict__ oxs, const float* 
       if (!on[u]) continue;
       if (ch < P.K + 3) {
         acc[u] = __builtin_fmaf(wj, sv, acc[u]);
+        // training: the backward's q_j = sum_c G_c s_j[c] reads the samples back
+        if (ss_save) ss_save[(((long) b * (P.K + 3) + ch) * P.oZ + j) * OYX + col] = sv;
         if (ch < P.K && P.cat_seg)
           voxel_output[(((long) b * CO + P.C + ch) * P.oZ + j) * OYX + col] = sv;     // bv2:449-450
       } else {
@@ -326,14 +347,45 @@ bev_q_kernel(RenderParams P, const float* __restrict__ oxs, const float* __restr
                                              (qred[(j * 3 + 1) * 64 + lx] + qred[(j * 3 + 2) * 64 + lx]);
 }
 
+// the same from the samples the forward kept (VAMP_BEVFWD_SAVE): a streaming dot product
+__global__ void __launch_bounds__(256)
+bev_q_saved_kernel(RenderParams P, const float* __restrict__ ss, const float* __restrict__ g_brgb,
+                   const float* __restrict__ g_bseg, float* __restrict__ Q) {
+  const long OYX = (long) P.oY * P.oX;
+  const long col = (long) blockIdx.x * 256 + threadIdx.x;
+  const int j = blockIdx.y, b = blockIdx.z;
+  if (col >= OYX) return;
+  const int nch = P.K + 3;
+  float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+  constexpr int U = 7;                          // channels in flight (K + 3 = 21 = 3 x 7)
+  for (int c0 = 0; c0 < nch; c0 += U) {
+    float g[U], v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ch = min(c0 + u, nch - 1);
+      const bool is_sem = ch < P.K;
+      const float* gp = is_sem ? g_bseg : g_brgb;
+      g[u] = (gp && c0 + u < nch) ? gp[is_sem ? ((long) b * P.K + ch) * OYX + col : ((long) b * 3 + (ch - P.K)) * OYX + col] : 0.f;
+      v[u] = ss[(((long) b * nch + ch) * P.oZ + j) * OYX + col];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (u % 3 == 0) q0 = __builtin_fmaf(g[u], v[u], q0);
+      else if (u % 3 == 1) q1 = __builtin_fmaf(g[u], v[u], q1);
+      else q2 = __builtin_fmaf(g[u], v[u], q2);
+    }
+  }
+  Q[((long) b * P.oZ + j) * OYX + col] = (q0 + q1) + q2;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 bev_scan_kernel(RenderParams P, const float* __restrict__ oxs, const float* __restrict__ oys,
                 const float* __restrict__ ozs, const float* __restrict__ bev_mids,
                 const float* __restrict__ beta_raw, const T* __restrict__ dens,
-                const float* __restrict__ g_bh, const float* __restrict__ g_vd,
-                const float* __restrict__ Q, float* __restrict__ Wb, float* __restrict__ DS0,
-                float* __restrict__ beta_part) {
+                const float* __restrict__ s0_saved, const float* __restrict__ g_bh,
+                const float* __restrict__ g_vd, const float* __restrict__ Q, float* __restrict__ Wb,
+                float* __restrict__ DS0, float* __restrict__ beta_part) {
   __shared__ float red[4];
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -346,34 +398,59 @@ bev_scan_kernel(RenderParams P, const float* __restrict__ oxs, const float* __re
   const AxisTap ty = axis_tap(oys[yc], P.lo[1], P.span[1], P.Y);
   const float Gh = g_bh ? g_bh[(long) b * OYX + col] : 0.f;
   const float dz = 1.0f * P.z_step;
-  float total = 0.f, cum = 0.f;
-  for (int j = 0; j < P.oZ; ++j) {
+  // the density sample of height j: kept by the forward, or sampled again
+  auto sample = [&](int j) -> float {
+    if (s0_saved) return s0_saved[((long) b * P.oZ + j) * OYX + col];
     const AxisTap tz = axis_tap(ozs[P.oZ - 1 - j], P.lo[2], P.span[2], P.Z);
-    const float tau = density_fwd(dp, sample8(P, dens, (long) b * V, tx, ty, tz)) * dz;
-    const float qv = Q[((long) b * P.oZ + j) * OYX + col] + Gh * bev_mids[j];
-    total = __builtin_fmaf((1.0f - expf(-tau)) * expf(-cum), qv, total);
-    cum += tau;
+    return sample8(P, dens, (long) b * V, tx, ty, tz);
+  };
+  // heights kHChunk at a time (see bev_density): the loads of a chunk are in flight together
+  float total = 0.f, cum = 0.f;
+  for (int j0 = 0; j0 < P.oZ; j0 += kHChunk) {
+    float s0[kHChunk], qv[kHChunk];
+#pragma unroll
+    for (int u = 0; u < kHChunk; ++u) {
+      const int j = min(j0 + u, P.oZ - 1);
+      s0[u] = sample(j);
+      qv[u] = Q[((long) b * P.oZ + j) * OYX + col] + Gh * bev_mids[j];
+    }
+#pragma unroll
+    for (int u = 0; u < kHChunk; ++u) {
+      if (j0 + u >= P.oZ) break;
+      const float tau = density_fwd(dp, s0[u]) * dz;
+      total = __builtin_fmaf((1.0f - expf(-tau)) * expf(-cum), qv[u], total);
+      cum += tau;
+    }
   }
   float prefix = 0.f, dbeta = 0.f;
   cum = 0.f;
-  for (int j = 0; j < P.oZ; ++j) {
-    const AxisTap tz = axis_tap(ozs[P.oZ - 1 - j], P.lo[2], P.span[2], P.Z);
-    const float s0 = sample8(P, dens, (long) b * V, tx, ty, tz);
-    const float tau = density_fwd(dp, s0) * dz;
-    const float qv = Q[((long) b * P.oZ + j) * OYX + col] + Gh * bev_mids[j];
-    const float wgt = (1.0f - expf(-tau)) * expf(-cum);
-    const float Tn = expf(-(cum + tau));
-    cum += tau;
-    prefix = __builtin_fmaf(wgt, qv, prefix);
-    const float dtau = qv * Tn - (total - prefix);
-    float dsig_ds, dsig_db;
-    density_bwd(dp, s0, dsig_ds, dsig_db);
-    const float gvd = g_vd ? g_vd[((long) b * P.oZ + j) * OYX + col] : 0.f;
-    const float dsigma = dtau * dz + gvd;          // sigma feeds tau and voxel_density
-    dbeta = __builtin_fmaf(dsigma, dsig_db, dbeta);
-    if (live) {
-      Wb[((long) b * P.oZ + j) * OYX + col] = wgt;
-      DS0[((long) b * P.oZ + j) * OYX + col] = dsigma * dsig_ds;
+  for (int j0 = 0; j0 < P.oZ; j0 += kHChunk) {
+    float s0[kHChunk], qv[kHChunk], gvd[kHChunk];
+#pragma unroll
+    for (int u = 0; u < kHChunk; ++u) {
+      const int j = min(j0 + u, P.oZ - 1);
+      s0[u] = sample(j);
+      qv[u] = Q[((long) b * P.oZ + j) * OYX + col] + Gh * bev_mids[j];
+      gvd[u] = g_vd ? g_vd[((long) b * P.oZ + j) * OYX + col] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kHChunk; ++u) {
+      const int j = j0 + u;
+      if (j >= P.oZ) break;
+      const float tau = density_fwd(dp, s0[u]) * dz;
+      const float wgt = (1.0f - expf(-tau)) * expf(-cum);
+      const float Tn = expf(-(cum + tau));
+      cum += tau;
+      prefix = __builtin_fmaf(wgt, qv[u], prefix);
+      const float dtau = qv[u] * Tn - (total - prefix);
+      float dsig_ds, dsig_db;
+      density_bwd(dp, s0[u], dsig_ds, dsig_db);
+      const float dsigma = dtau * dz + gvd[u];       // sigma feeds tau and voxel_density
+      dbeta = __builtin_fmaf(dsigma, dsig_db, dbeta);
+      if (live) {
+        Wb[((long) b * P.oZ + j) * OYX + col] = wgt;
+        DS0[((long) b * P.oZ + j) * OYX + col] = dsigma * dsig_ds;
+      }
     }
   }
   if (P.density_mode == VAMP_DENSITY_SDF_LAPLACE) {
@@ -752,10 +829,18 @@ static size_t bev_scan_blocks(const VampRenderDesc* d) {
   return (size_t) ((d->oX + 63) / 64) * ((d->oY + 3) / 4) * d->B;
 }
 
-static size_t bev_ws_bytes(const VampRenderDesc* d) {
-  return 3 * align_up((size_t) d->B * d->oZ * d->oY * d->oX * sizeof(float), 256) +
-         align_up((size_t) 2 * (d->X + d->Y + d->Z) * sizeof(int4), 256) +
+// workspace: Q, Wb, DS0 [B, oZ, oY, oX] | axis tables | beta partials | what the forward keeps for
+// the backward (VAMP_BEVFWD_SAVE): density samples [B, oZ, oY, oX], composited channels' samples
+// [B, K + 3, oZ, oY, oX]
+static size_t bev_one(const VampRenderDesc* d) {
+  return align_up((size_t) d->B * d->oZ * d->oY * d->oX * sizeof(float), 256);
+}
+static size_t bev_saved_offset(const VampRenderDesc* d) {
+  return 3 * bev_one(d) + align_up((size_t) 2 * (d->X + d->Y + d->Z) * sizeof(int4), 256) +
          align_up(bev_scan_blocks(d) * sizeof(float), 256);
+}
+static size_t bev_ws_bytes(const VampRenderDesc* d) {
+  return bev_saved_offset(d) + (size_t) (1 + d->K + 3) * bev_one(d);
 }
 
 }  // namespace vamp
@@ -766,12 +851,20 @@ extern "C" {
 
 size_t vamp_render_bev_workspace_bytes(const VampRenderDesc* d) { return d ? bev_ws_bytes(d) : 0; }
 
-int vamp_render_bev_forward(const VampRenderDesc* d, const float* oxs, const float* oys,
-                            const float* ozs, const float* bev_mids, const float* beta,
-                            const void* density_feature, const void* semantic, const void* rgb,
-                            const void* base, float* bev_rgb, float* bev_seg, float* bev_height,
-                            float* voxel_density, float* voxel_output, void* stream) {
+int vamp_render_bev_forward_ex(const VampRenderDesc* d, const float* oxs, const float* oys,
+                               const float* ozs, const float* bev_mids, const float* beta,
+                               const void* density_feature, const void* semantic, const void* rgb,
+                               const void* base, float* bev_rgb, float* bev_seg, float* bev_height,
+                               float* voxel_density, float* voxel_output, void* workspace,
+                               size_t workspace_bytes, int flags, void* stream) {
   if (int e = validate(d)) return e;
+  float *s0_save = nullptr, *ss_save = nullptr;
+  if (flags & VAMP_BEVFWD_SAVE) {
+    if (!workspace || workspace_bytes < bev_ws_bytes(d))
+      return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) bev_ws_bytes(d));
+    s0_save = reinterpret_cast<float*>(static_cast<char*>(workspace) + bev_saved_offset(d));
+    ss_save = reinterpret_cast<float*>(static_cast<char*>(workspace) + bev_saved_offset(d) + bev_one(d));
+  }
   VAMP_REQUIRE(d->oZ > 0 && d->oY > 0 && d->oX > 0, "det grid must be non-empty");
   VAMP_REQUIRE(oxs && oys && ozs && bev_mids && density_feature && semantic && rgb, "null pointer");
   VAMP_REQUIRE(base || d->C == 0, "base is NULL");
@@ -785,11 +878,11 @@ int vamp_render_bev_forward(const VampRenderDesc* d, const float* oxs, const flo
 #define VAMP_BEVF(T)                                                                              \
   do {                                                                                            \
     VAMP_TIMED(kProfBevFwd, s, (bev_density_kernel<T><<<g1, 256, 0, s>>>(                         \
-        P, oxs, oys, ozs, bev_mids, beta, (const T*) density_feature, voxel_density, bev_height))); \
+        P, oxs, oys, ozs, bev_mids, beta, (const T*) density_feature, voxel_density, bev_height, s0_save))); \
     if (int e = check_launch("bev_density_kernel")) return e;                                     \
     VAMP_TIMED(kProfBevFwdCh, s, (bev_channels_kernel<T, kBevNC><<<g2, 256, 0, s>>>(              \
         P, oxs, oys, ozs, (const T*) semantic, (const T*) rgb, (const T*) base, voxel_density,    \
-        bev_rgb, bev_seg, voxel_output)));                                                        \
+        bev_rgb, bev_seg, voxel_output, ss_save)));                                               \
   } while (0)
   if (d->in_dtype == VAMP_F32) VAMP_BEVF(float); else VAMP_BEVF(__hip_bfloat16);
 #undef VAMP_BEVF
@@ -867,8 +960,16 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
   const size_t q_lds = (size_t) d->oZ * 4 * 64 * sizeof(float);
   dim3 gs((d->oX + 63) / 64, (d->oY + 3) / 4, d->B);
   dim3 gg((d->X + 63) / 64, (d->Y + 3) / 4, d->B * (z_hi - z_lo + 1));
+  const bool saved = (flags & VAMP_BEVBWD_SAVED_VALID) != 0;
+  const float* s0_saved = saved ? reinterpret_cast<const float*>(static_cast<char*>(workspace) + bev_saved_offset(d)) : nullptr;
+  const float* ss_saved = saved ? reinterpret_cast<const float*>(static_cast<char*>(workspace) + bev_saved_offset(d) + bev_one(d)) : nullptr;
+  dim3 gqs((unsigned) (((long) d->oY * d->oX + 255) / 256), d->oZ, d->B);
 #define VAMP_BEVB(T)                                                                              \
   do {                                                                                            \
+    if (saved) {                                                                                  \
+      VAMP_TIMED(kProfBevBwdQ, s, (bev_q_saved_kernel<<<gqs, 256, 0, s>>>(P, ss_saved, g_bev_rgb, g_bev_seg, Q))); \
+      if (int e = check_launch("bev_q_saved_kernel")) return e;                                   \
+    } else {                                                                                      \
     if (q_lds > 60 * 1024 &&                                                                      \
         hipFuncSetAttribute(reinterpret_cast<const void*>(&bev_q_kernel<T>),                     \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int) q_lds) != hipSuccess) \
@@ -876,8 +977,9 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
     VAMP_TIMED(kProfBevBwdQ, s, (bev_q_kernel<T><<<gq, 256, q_lds, s>>>(                              \
         P, oxs, oys, ozs, (const T*) semantic, (const T*) rgb, g_bev_rgb, g_bev_seg, Q)));        \
     if (int e = check_launch("bev_q_kernel")) return e;                                           \
+    }                                                                                             \
     VAMP_TIMED(kProfBevBwd, s, (bev_scan_kernel<T><<<gs, 256, 0, s>>>(                            \
-        P, oxs, oys, ozs, bev_mids, beta, (const T*) density_feature, g_bev_height,               \
+        P, oxs, oys, ozs, bev_mids, beta, (const T*) density_feature, s0_saved, g_bev_height,     \
         g_voxel_density, Q, Wb, DS0, beta_part)));                                                \
     if (int e = check_launch("bev_scan_kernel")) return e;                                        \
   } while (0)
@@ -965,6 +1067,16 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
                                      g_bev_rgb, g_bev_seg, g_bev_height, g_voxel_density, g_voxel_output,
                                      grad_density_feature, grad_semantic, grad_rgb, grad_base, grad_beta,
                                      ozs_host, workspace, workspace_bytes, 0, stream);
+}
+
+int vamp_render_bev_forward(const VampRenderDesc* d, const float* oxs, const float* oys,
+                            const float* ozs, const float* bev_mids, const float* beta,
+                            const void* density_feature, const void* semantic, const void* rgb,
+                            const void* base, float* bev_rgb, float* bev_seg, float* bev_height,
+                            float* voxel_density, float* voxel_output, void* stream) {
+  return vamp_render_bev_forward_ex(d, oxs, oys, ozs, bev_mids, beta, density_feature, semantic, rgb, base,
+                                    bev_rgb, bev_seg, bev_height, voxel_density, voxel_output, nullptr, 0, 0,
+                                    stream);
 }
 
 }  // extern "C"

@@ -94,6 +94,8 @@ class HotPath:
                      # single stream: BEV branch first (overwriting), camera gather adds -- or the
                      # camera branch first and the BEV gather adds
                      "bev_first": os.environ.get("VAMP_BEV_FIRST", "1") == "1",
+                     # the BEV forward keeps its samples for the backward (+35 MB per sample at cfg-B)
+                     "bev_save": os.environ.get("VAMP_BEV_SAVE", "1") == "1",
                      # store the forward's sample rows for the backward's per-ray pass: measured
                      # neutral at cfg-B (forward +50 us for the scattered row stores, backward -59 us),
                      # so off unless asked for
@@ -440,10 +442,16 @@ class _RenderFn(torch.autograd.Function):
                     C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(),
                     _capi.VAMP_CAMPREP_TERM_VALID if ert else 0, _stream(side)), "vamp_render_camera_prepare_ex")
                 ctx.cells = True
-        _capi.check(hp.lib.vamp_render_bev_forward(
+        # training: the BEV branch keeps its density / semantic / rgb samples for its backward
+        bev_save = any(ctx.needs_input_grad) and hp.impl["bev_save"] and hp.impl["bev_bwd"] != "v1"
+        ws_bev = (hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d))) if bev_save else None)
+        _capi.check(hp.lib.vamp_render_bev_forward_ex(
             C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
             _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
-            _ptr(vdens), _ptr(vout), _stream(side)), "vamp_render_bev_forward")
+            _ptr(vdens), _ptr(vout), _ptr(ws_bev), ws_bev.numel() if bev_save else 0,
+            _capi.VAMP_BEVFWD_SAVE if bev_save else 0, _stream(side)), "vamp_render_bev_forward_ex")
+        hp._bev_gen = getattr(hp, "_bev_gen", 0) + 1
+        ctx.bev_key = (hp._bev_gen, ws_bev.data_ptr()) if bev_save else None
         _capi.check(hp.lib.vamp_render_camera_forward_ex(
             C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
             _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
@@ -484,8 +492,13 @@ class _RenderFn(torch.autograd.Function):
         gr = torch.empty(rgb.shape, dtype=f32, device=dens.device)
         gbeta = torch.zeros(1, dtype=f32, device=dens.device)
 
+        bev_saved = (ctx.bev_key is not None and hp.impl["bev_bwd"] != "v1"
+                     and ctx.bev_key == (getattr(hp, "_bev_gen", 0), ws_bev.data_ptr()))
+
         def bev_backward(stream, overwrite_cam):
             flags = _capi.VAMP_BEVBWD_OVERWRITE_BASE | (_capi.VAMP_BEVBWD_OVERWRITE_CAM if overwrite_cam else 0)
+            if bev_saved:
+                flags |= _capi.VAMP_BEVBWD_SAVED_VALID
             _capi.check(hp.lib.vamp_render_bev_backward_ex(
                 C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
                 _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(g_brgb), _ptr(g_bseg), _ptr(g_bh),
