@@ -11,10 +11,9 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU" \
            "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" \
-           "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
-           "FETCH_SIZE" "WRITE_SIZE"; do
+           "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 $ROOT/tools/time_bwd.py $CFG $BATCH > /dev/null 2> $OUT/p$i.log
+  timeout 150 rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 $ROOT/tools/time_bwd.py $CFG $BATCH > /dev/null 2> $OUT/p$i.log
 done
 cd $ROOT
 python3 - "$OUT" <<'PY'

@@ -119,7 +119,7 @@ lift_fwd_kernel(LiftParams P, const float* __restrict__ mats, const float* __res
 
     for (int n = 0; n < P.N; ++n) {
       const long bn = (long) b * P.N + n;
-      const LiftTap t = lift_project(P, mats + bn * 48, vx, vy, vz);
+      const LiftTap t = lift_project<true>(P, mats + bn * 48, vx, vy, vz);
       if (!t.valid) continue;
       float dep[4];
       depth_taps<T>(P, depth + bn * P.D * HW, t, dep);

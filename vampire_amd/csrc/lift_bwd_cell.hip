@@ -77,7 +77,7 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
     const float* g = gout + (long) b * P.C * V + vox;
 #pragma unroll
     for (int k = 0; k < CH; ++k)
-      gs0[k] = (live ? g[(long) k * V] : 0.f) / ((float) ((hw >> (4 * k)) & 15) + 1e-6f);
+      gs0[k] = (live ? g[(long) k * V] : 0.f) * __builtin_amdgcn_rcpf((float) ((hw >> (4 * k)) & 15) + 1e-6f);   // 1 ulp: gradients are held to 1e-4
   }
 
   for (int n0 = 0; n0 < P.N; n0 += NB) {
@@ -90,7 +90,7 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
       start[k] = lane;
       if (n >= P.N) continue;                    // uniform
       const long bn = (long) b * P.N + n;
-      const LiftTap t = lift_project(P, mats + bn * 48, vx, vy, vz);
+      const LiftTap t = lift_project<true>(P, mats + bn * 48, vx, vy, vz);
       // at least one of the four pixel taps must exist
       const bool act = live && t.valid && t.ix0 >= -1 && t.ix0 < P.fW && t.iy0 >= -1 && t.iy0 < P.fH;
       const long cell = (bn * ch + (t.iy0 + 1)) * cw + (t.ix0 + 1);
@@ -151,7 +151,7 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
             float v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              v[q] = g[(long) (c4 + q) * V] / ((float) ((hw >> (4 * (c4 + q))) & 15) + 1e-6f);
+              v[q] = g[(long) (c4 + q) * V] * __builtin_amdgcn_rcpf((float) ((hw >> (4 * (c4 + q))) & 15) + 1e-6f);
             e4[(kRecHead4 + (chunk * CH + c4) / 4) * cap] = make_float4(v[0], v[1], v[2], v[3]);
           }
         }

@@ -31,11 +31,30 @@ struct LiftTap {
 // get_pixel (bv2:365-388) + validity / normalisation (bv2:493-505) + aten's
 // grid_sampler_unnormalize for align_corners=False.  Evaluation order is part of
 // the contract (bit-exact tap indices): do not reassociate, do not fuse.
+// WAVE_CULL (callers in wave-uniform control flow only): when the third row of `ida` is exactly
+// (0, 0, 1, 0) -- image-plane augmentations never touch depth -- the projected depth zz equals the
+// camera-space z bit for bit (or is NaN), so a camera that no lane of the wave has in front of it
+// (z > d_lo, resp. z > 0) is invalid for all 64 voxels and the divisions, the third matrix and
+// the normalisation are skipped: the same masks as the full chain, about half of the projections
+// (the cameras facing away) at a third of the instructions.
+template <bool WAVE_CULL = false>
 __device__ __forceinline__ LiftTap lift_project(const LiftParams& P, const float* __restrict__ m,
                                                 float x, float y, float z) {
   Vec4 p{x, y, z, 1.0f};
   p = matvec(m, p);        // inv(bda)
   p = matvec(m + 16, p);   // intrin @ inv(sensor2ego)
+  if (WAVE_CULL) {
+    const bool e3 = m[40] == 0.0f && m[41] == 0.0f && m[42] == 1.0f && m[43] == 0.0f;   // uniform
+    if (e3 && !__any(p.z > (P.use_depth ? P.d_lo : 0.0f))) {
+      LiftTap t;
+      t.valid = false;
+      t.ix0 = t.iy0 = t.iz0 = 0;
+      t.wx0 = t.wx1 = t.wy0 = t.wy1 = t.wz0 = t.wz1 = 0.f;
+      t.zz = p.z;
+      t.fx = t.fy = t.fz = 0.f;
+      return t;
+    }
+  }
   float zc = (p.z < 1e-6f) ? 1e-6f : p.z;   // clamp(min=eps); NaN stays NaN
   p.x = p.x / zc;
   p.y = p.y / zc;
