@@ -193,42 +193,63 @@ bev_channels_kernel(RenderParams P, const float* __restrict__ oxs, const float* 
     for (int k = 0; k < 4; ++k) s = __builtin_fmaf(zin ? w4[k] : 0.f, ldf(vol[u], zo + off4[k]), s);
     return s;
   };
-  float cum = 0.f, acc[NC], v_lo[NC], v_hi[NC];
+  float cum = 0.f, acc[NC];
 #pragma unroll
-  for (int u = 0; u < NC; ++u) acc[u] = v_lo[u] = v_hi[u] = 0.f;
-  // consecutive heights share a volume plane (det and seg grids have equal spacing): keep the
-  // two bilinear plane values and reload only what changed -> 4 loads per sample, not 8
-  int p_lo = -0x7fffffff, p_hi = -0x7fffffff;
+  for (int u = 0; u < NC; ++u) acc[u] = 0.f;
   const bool any_comp = c0 < P.K + 3;
-  for (int j = 0; j < P.oZ; ++j) {
-    const int i0 = tz_i0[j];
-    const float wz0 = tz_w0[j], wz1 = tz_w1[j];
-    const bool lo_is_lo = i0 == p_lo, lo_is_hi = i0 == p_hi, hi_is_lo = i0 + 1 == p_lo, hi_is_hi = i0 + 1 == p_hi;
-    float wj = 0.f;
-    if (any_comp) {
-      const float tau = voxel_density[((long) b * P.oZ + j) * OYX + col] * (1.0f * P.z_step);   // bv2:451-458
-      wj = (1.0f - expf(-tau)) * expf(-cum);
-      cum += tau;
-    }
+  // Heights kHChunk at a time.  A wave's life is (heights) x (memory round trip) -- 2.3 us per
+  // height under load -- so the volume planes of a whole chunk are fetched in one go: the chunk's
+  // heights step down the volume by at most one plane each (det and seg grids have about the same
+  // spacing), so its kHChunk + 1 planes below the first height's upper plane cover it; a height
+  // outside that window (other spacings) fetches its two planes itself.
+  for (int j0 = 0; j0 < P.oZ; j0 += kHChunk) {
+    const int top = tz_i0[j0] + 1;
+    float pl[NC][kHChunk + 1], tau[kHChunk];
 #pragma unroll
-    for (int u = 0; u < NC; ++u) {
-      const float n_lo = lo_is_lo ? v_lo[u] : (lo_is_hi ? v_hi[u] : plane(u, i0));
-      const float n_hi = hi_is_lo ? v_lo[u] : (hi_is_hi ? v_hi[u] : plane(u, i0 + 1));
-      v_lo[u] = n_lo; v_hi[u] = n_hi;
-      const float sv = __builtin_fmaf(wz1, n_hi, wz0 * n_lo);
-      const int ch = c0 + u;
-      if (!on[u]) continue;
-      if (ch < P.K + 3) {
-        acc[u] = __builtin_fmaf(wj, sv, acc[u]);
-        // training: the backward's q_j = sum_c G_c s_j[c] reads the samples back
-        if (ss_save) ss_save[(((long) b * (P.K + 3) + ch) * P.oZ + j) * OYX + col] = sv;
-        if (ch < P.K && P.cat_seg)
-          voxel_output[(((long) b * CO + P.C + ch) * P.oZ + j) * OYX + col] = sv;     // bv2:449-450
-      } else {
-        voxel_output[(((long) b * CO + (ch - P.K - 3)) * P.oZ + j) * OYX + col] = sv;
+    for (int t = 0; t <= kHChunk; ++t)
+#pragma unroll
+      for (int u = 0; u < NC; ++u) pl[u][t] = plane(u, top - t);
+#pragma unroll
+    for (int h = 0; h < kHChunk; ++h)
+      tau[h] = any_comp ? voxel_density[((long) b * P.oZ + min(j0 + h, P.oZ - 1)) * OYX + col] * (1.0f * P.z_step) : 0.f;   // bv2:451-458
+#pragma unroll
+    for (int h = 0; h < kHChunk; ++h) {
+      const int j = j0 + h;
+      if (j >= P.oZ) break;
+      const int i0 = tz_i0[j];
+      const float wz0 = tz_w0[j], wz1 = tz_w1[j];
+      const int d = top - 1 - i0;                  // planes below the chunk's first height (uniform)
+      float n_lo[NC], n_hi[NC];
+      bool found = false;
+#pragma unroll
+      for (int t = 0; t < kHChunk; ++t)
+        if (d == t) {
+#pragma unroll
+          for (int u = 0; u < NC; ++u) { n_hi[u] = pl[u][t]; n_lo[u] = pl[u][t + 1]; }
+          found = true;
+        }
+      if (!found) {
+#pragma unroll
+        for (int u = 0; u < NC; ++u) { n_hi[u] = plane(u, i0 + 1); n_lo[u] = plane(u, i0); }
+      }
+      const float wj = (1.0f - expf(-tau[h])) * expf(-cum);
+      cum += tau[h];
+#pragma unroll
+      for (int u = 0; u < NC; ++u) {
+        const float sv = __builtin_fmaf(wz1, n_hi[u], wz0 * n_lo[u]);
+        const int ch = c0 + u;
+        if (!on[u]) continue;
+        if (ch < P.K + 3) {
+          acc[u] = __builtin_fmaf(wj, sv, acc[u]);
+          // training: the backward's q_j = sum_c G_c s_j[c] reads the samples back
+          if (ss_save) ss_save[(((long) b * (P.K + 3) + ch) * P.oZ + j) * OYX + col] = sv;
+          if (ch < P.K && P.cat_seg)
+            voxel_output[(((long) b * CO + P.C + ch) * P.oZ + j) * OYX + col] = sv;     // bv2:449-450
+        } else {
+          voxel_output[(((long) b * CO + (ch - P.K - 3)) * P.oZ + j) * OYX + col] = sv;
+        }
       }
     }
-    p_lo = i0; p_hi = i0 + 1;
   }
 #pragma unroll
   for (int u = 0; u < NC; ++u) {
