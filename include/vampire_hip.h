@@ -118,6 +118,7 @@ int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs
 #define VAMP_LIFTBWD_WPP1 4
 #define VAMP_LIFTBWD_WPP4 8
 #define VAMP_LIFTBWD_WPP16 16
+#define VAMP_LIFTBWD_TILE 32     /* pixel-tile owners with LDS accumulators (lift_bwd_tile.hip); C <= 16 */
 int vamp_lift_prepare(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                       const float* zs, void* workspace, size_t workspace_bytes, void* stream);
 int vamp_lift_backward_ex(const VampLiftDesc* d, const float* mats, const float* xs,

@@ -84,7 +84,9 @@ class HotPath:
         # cross-checks for the tests; lift_wpp forces the lift gather's waves per pixel (0 = auto).
         # The environment gives the initial values only.
         self.impl = {"cam_bwd": os.environ.get("VAMP_CAM_BWD", "cell"),
-                     "lift_bwd": os.environ.get("VAMP_LIFT_BWD", "cell"),
+                     # lift backward: "tile" = pixel-tile owners with LDS accumulators (default),
+                     # "cell" = cell list + gather, "v1" = float-atomic splat
+                     "lift_bwd": os.environ.get("VAMP_LIFT_BWD", "tile"),
                      "bev_bwd": os.environ.get("VAMP_BEV_BWD", "cell"),
                      "lift_wpp": int(os.environ.get("VAMP_LIFT_WPP", "0")),
                      # BEV branch on a second stream: worth 9 % of the step in round 1; since the
@@ -297,7 +299,7 @@ class _LiftFn(torch.autograd.Function):
         nbytes = hp.lib.vamp_lift_workspace_bytes(C.byref(d))
         ws = hp._workspace("lift", nbytes)
         cur = torch.cuda.current_stream()
-        side = hp._side_stream() if (need_grad and hp.impl["prepare"] and hp.impl["lift_bwd"] != "v1") else None
+        side = hp._side_stream() if (need_grad and hp.impl["prepare"] and hp.impl["lift_bwd"] == "cell") else None
         hp._lift_gen = getattr(hp, "_lift_gen", 0) + 1
         ctx.cells_key = None
         if side is not None:
@@ -333,6 +335,8 @@ class _LiftFn(torch.autograd.Function):
         hp._lift_gen = getattr(hp, "_lift_gen", 0) + 1       # the backward consumes the prepared counters
         if hp.impl["lift_bwd"] == "v1":
             valid = _capi.VAMP_LIFTBWD_SPLAT
+        elif hp.impl["lift_bwd"] == "tile":
+            valid |= _capi.VAMP_LIFTBWD_TILE                 # falls through to the cell list where unsupported
         valid |= {1: _capi.VAMP_LIFTBWD_WPP1, 4: _capi.VAMP_LIFTBWD_WPP4,
                   16: _capi.VAMP_LIFTBWD_WPP16}.get(hp.impl["lift_wpp"], 0)
         _capi.check(hp.lib.vamp_lift_backward_ex(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys), _ptr(hp.zs),
