@@ -84,9 +84,9 @@ class HotPath:
         # cross-checks for the tests; lift_wpp forces the lift gather's waves per pixel (0 = auto).
         # The environment gives the initial values only.
         self.impl = {"cam_bwd": os.environ.get("VAMP_CAM_BWD", "cell"),
-                     # lift backward: "tile" = pixel-tile owners with LDS accumulators (default),
-                     # "cell" = cell list + gather, "v1" = float-atomic splat
-                     "lift_bwd": os.environ.get("VAMP_LIFT_BWD", "tile"),
+                     # lift backward: "cell" = cell list + gather (default), "tile" = pixel-tile owners with
+                     # fixed-point LDS accumulators (bit-reproducible, slower: DESIGN.md), "v1" = float-atomic splat
+                     "lift_bwd": os.environ.get("VAMP_LIFT_BWD", "cell"),
                      "bev_bwd": os.environ.get("VAMP_BEV_BWD", "cell"),
                      "lift_wpp": int(os.environ.get("VAMP_LIFT_WPP", "0")),
                      # BEV branch on a second stream: worth 9 % of the step in round 1; since the
