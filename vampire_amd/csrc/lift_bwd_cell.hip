@@ -243,11 +243,7 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifndef ABL_NOGS
         if (q < nq) g4 = e[(kRecHead4 + c0 / 4 + q) * cap];   // uniform branch
-#else
-        g4 = make_float4(hb.y, hb.z, hb.y, hb.z);
-#endif
         gs[4 * q] = g4.x; gs[4 * q + 1] = g4.y; gs[4 * q + 2] = g4.z; gs[4 * q + 3] = g4.w;
       }
       const int iz0 = __float_as_int(hb.x);
@@ -261,31 +257,20 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
         acc[c] = __builtin_fmaf(pwj, gs[c], acc[c]);
         dot = __builtin_fmaf(ft[c], gs[c], dot);
       }
-#ifdef ABL_NODEPTH
-      if (false) {
-#else
       if (D > 0 && in) {
-#endif
         const float wd = wj * dot;
+        // (ds_add_f32 is slow on gfx950 -- ~190 cycles per wave instruction against ~11 for
+        // ds_add_u32, tools/microbench/lds_atomic.hip -- but a fixed-point column with a per-pixel
+        // scale measured slower here, 80 vs 69 us: finding the scale costs a wave reduction per batch)
         if (wd != 0.f) {
-#ifdef ABL_PLAINST
-          if (iz0 >= 0 && iz0 < D) gcol[iz0] = hb.y * wd;
-          if (iz0 + 1 >= 0 && iz0 + 1 < D) gcol[iz0 + 1] = hb.z * wd;
-#elif defined(ABL_NOBR)
-          atomicAdd(gcol + min(max(iz0, 0), D - 1), (iz0 >= 0 && iz0 < D) ? hb.y * wd : 0.f);
-          atomicAdd(gcol + min(max(iz0 + 1, 0), D - 1), (iz0 + 1 >= 0 && iz0 + 1 < D) ? hb.z * wd : 0.f);
-#else
           if (iz0 >= 0 && iz0 < D) atomicAdd(gcol + iz0, hb.y * wd);
           if (iz0 + 1 >= 0 && iz0 + 1 < D) atomicAdd(gcol + iz0 + 1, hb.z * wd);
-#endif
         }
       }
     }
     // fold the 64 lanes' partial sums: afterwards lane l holds channel c0 + (l >> 2)
     int cb = 0;
-#ifndef ABL_NORED
     reduce_halving<16, 32, 64, 16>(acc, lane, cb);
-#endif
     static_assert(reduce_left<16, 32>() == 1 && reduce_dups<16, 32>() == 3, "16 values over 64 lanes");
     if (wpp == 1) {
       if (pix_ok && (lane & 3) == 0 && c0 + cb < C) gfeat[(bn * C + c0 + cb) * HW + pix] = acc[0];
@@ -300,11 +285,7 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
       __syncthreads();
     }
   }
-#ifdef ABL_NOCOL
-  if (false) {
-#else
   if (D > 0 && gdepth) {
-#endif
     __syncthreads();
     // consecutive threads = consecutive pixels of one depth plane
     for (int e = tid; e < D * ppb; e += nw * 64) {
