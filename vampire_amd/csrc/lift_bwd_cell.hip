@@ -55,7 +55,8 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
                      const float* __restrict__ zs, const T* __restrict__ depth,
                      const float* __restrict__ gout, const uint64_t* __restrict__ hits,
                      int* __restrict__ cnt, const int* __restrict__ off,
-                     const int* __restrict__ boff, float4* __restrict__ entries, long cap) {
+                     const int* __restrict__ boff, float4* __restrict__ entries, long cap,
+                     unsigned* __restrict__ amask) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int x = blockIdx.x * 64 + lane;
   const int y = blockIdx.y * 4 + (tid >> 6);
@@ -80,6 +81,11 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
       gs0[k] = (live ? g[(long) k * V] : 0.f) * __builtin_amdgcn_rcpf((float) ((hw >> (4 * k)) & 15) + 1e-6f);   // 1 ulp: gradients are held to 1e-4
   }
 
+  // camera mask of the voxel: written by the count pass, read by the fill pass, which then
+  // projects only the cameras some lane of the wave is valid for (1-3 of 6) instead of all
+  unsigned vmask = 0xffffffffu, wmask = 0;
+  if (FILL && amask) vmask = live ? amask[(long) b * V + vox] : 0u;
+
   for (int n0 = 0; n0 < P.N; n0 += NB) {
     int base[NB], start[NB];
     unsigned actm = 0;
@@ -89,10 +95,12 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
       base[k] = 0;
       start[k] = lane;
       if (n >= P.N) continue;                    // uniform
+      if (FILL && !__any((vmask >> (n & 31)) & 1u)) continue;   // uniform: nobody in this wave sees camera n
       const long bn = (long) b * P.N + n;
       const LiftTap t = lift_project<true>(P, mats + bn * 48, vx, vy, vz);
       // at least one of the four pixel taps must exist
       const bool act = live && t.valid && t.ix0 >= -1 && t.ix0 < P.fW && t.iy0 >= -1 && t.iy0 < P.fH;
+      if (act) wmask |= 1u << (n & 31);
       const long cell = (bn * ch + (t.iy0 + 1)) * cw + (t.ix0 + 1);
       const LaneRun r = lane_run(act, cell, lane);
       if (r.head) {
@@ -106,6 +114,7 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
     for (int k = 0; k < NB; ++k) {
       const int n = n0 + k;
       if (n >= P.N) continue;                    // uniform
+      if (!__any((actm >> k) & 1u)) continue;    // uniform
       const int rb = __shfl(base[k], start[k], 64);
       if (!((actm >> k) & 1u)) continue;
       const long bn = (long) b * P.N + n;
@@ -157,6 +166,7 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
         }
     }
   }
+  if (!FILL && amask && live) amask[(long) b * V + vox] = wmask;
 }
 
 // ---------------------------------------------------------------------------
@@ -302,6 +312,7 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
 // ---------------------------------------------------------------------------
 struct LiftCellWs {
   int *cnt, *off, *bsum, *boff, *aux;
+  unsigned* amask;                   // [B * V] cameras each voxel is valid for (N <= 32)
   float4* entries;                   // [kRecHead4 + C / 4][cap]
   size_t bytes;
 };
@@ -318,6 +329,7 @@ static LiftCellWs lift_cell_ws(const VampLiftDesc* d, void* scratch) {
   w.bsum = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
   w.boff = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
   w.aux = reinterpret_cast<int*>(p); p += align_up((size_t) (ntile + 4) * sizeof(int), 256);
+  w.amask = reinterpret_cast<unsigned*>(p); p += align_up((size_t) d->B * d->Z * d->Y * d->X * sizeof(unsigned), 256);
   w.entries = reinterpret_cast<float4*>(p); p += align_up(cap * (kRecHead4 + (d->C + 3) / 4) * sizeof(float4), 256);
   w.bytes = (size_t) (p - static_cast<char*>(scratch));
   return w;
@@ -336,7 +348,7 @@ int launch_lift_cell_prepare(const VampLiftDesc* d, const float* mats, const flo
   if (int ze = launch_zero(w.cnt, (size_t) g.ncell * sizeof(int), s)) return ze;
   dim3 grid((d->X + 63) / 64, (d->Y + 3) / 4, d->Z * d->B);
   VAMP_TIMED(kProfLiftBwdCount, s, (lift_bwd_cell_kernel<float, 16, false><<<grid, 256, 0, s>>>(
-      P, g.cw, g.ch, mats, xs, ys, zs, nullptr, nullptr, nullptr, w.cnt, w.off, w.boff, w.entries, (long) cap)));
+      P, g.cw, g.ch, mats, xs, ys, zs, nullptr, nullptr, nullptr, w.cnt, w.off, w.boff, w.entries, (long) cap, d->N <= 32 ? w.amask : nullptr)));
   if (int e = check_launch("lift_bwd_cell_kernel<count>")) return e;
   return launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, g.ncell, s);
 }
@@ -357,7 +369,8 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
   const T* dp = static_cast<const T*>(depth);
 #define VAMP_CELL(CH)                                                                            \
   VAMP_TIMED(kProfLiftBwdFill, s, (lift_bwd_cell_kernel<T, CH, true><<<grid, 256, 0, s>>>(       \
-      P, g.cw, g.ch, mats, xs, ys, zs, dp, gout, hits, w.cnt, w.off, w.boff, w.entries, (long) cap)))
+      P, g.cw, g.ch, mats, xs, ys, zs, dp, gout, hits, w.cnt, w.off, w.boff, w.entries, (long) cap,     \
+      d->N <= 32 ? w.amask : nullptr)))
   if (P.C == 4) VAMP_CELL(4); else if (P.C == 8) VAMP_CELL(8); else VAMP_CELL(16);
 #undef VAMP_CELL
   if (int e = check_launch("lift_bwd_cell_kernel<fill>")) return e;
