@@ -190,6 +190,35 @@ def extra_config(cfg_name, batch, dtype, steps=10, warm=3, ert=True, density_mod
             "fwd_frac_of_hbm_peak": ab["fwd"] * batch / (fwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
 
+def capture_step(model, batch, train_step):
+    """One training step (without the DDP wrapper) captured into a HIP graph; the replay must
+    reproduce the eager gradients."""
+    def raw_step():
+        model.zero_grad(set_to_none=True)
+        train_step(model, batch)
+
+    cur = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            raw_step()
+    cur.wait_stream(side)
+    torch.cuda.synchronize()
+    tensors = lambda: [batch.depth.grad, batch.feat.grad] + [v.grad for v in batch.vols] + [model.beta.grad]
+    ref = [t.detach().clone() for t in tensors()]
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        raw_step()
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    for got, want in zip(tensors(), ref):
+        if not (torch.equal(got, want) or float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())):
+            raise RuntimeError("graph replay does not reproduce the eager gradients")
+    return g
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -262,15 +291,53 @@ def main():
         dom = max((k for k in warm if k in alg), key=lambda k: warm[k][1])
         _capi.profile_select(dom)
     fence()
-    _capi.profile_enable(True)
+    # Timed region.  Default: the step replayed from a HIP graph (shapes are static; the capture holds
+    # both streams of the step, the zero fills and the workspaces -- tests/test_hip_parity.py::
+    # test_step_is_graph_capturable); the DDP all-reduce of the one parameter gradient stays outside
+    # the graph and is issued after every replay.  VAMP_BENCH_GRAPH=0, or a capture that fails or
+    # does not reproduce the eager gradients, times eager steps instead.  Either way the dominant
+    # kernel's launch duration comes from HIP events around it in K eager steps of this same run.
+    graph, launch_mode = None, "eager"
+    hook_sync = isinstance(step_model, vdist.GradSync)
+    if os.environ.get("VAMP_BENCH_GRAPH", "1") == "1" and (step_model is model or hook_sync):
+        try:
+            if hook_sync:
+                step_model.enabled = False          # the capture must not hold the collective
+            graph = capture_step(model, batch, train_step)
+            launch_mode = "hip_graph"
+        except Exception as e:                      # noqa: BLE001 -- any failure: measure eagerly
+            print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); timing eager steps", file=sys.stderr)
+            graph = None
+        if hook_sync:
+            step_model.enabled = True
+
+    def graph_step():
+        graph.replay()
+        if world > 1:
+            dist.all_reduce(model.beta.grad)        # sum (gloo has no AVG), then the mean
+            model.beta.grad.div_(world)
+
+    timed_step = graph_step if graph is not None else one_step
+    for _ in range(3):
+        timed_step()
+    fence()
+    if graph is None:
+        _capi.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        one_step()
+        timed_step()
     fence()
     elapsed = time.perf_counter() - t0
     _capi.profile_enable(False)
-    _capi.profile_select(None)
     elapsed = vdist.max_over_ranks(elapsed, dev)
+    if graph is not None:
+        # the dominant kernel's launches, timed with HIP events in K eager steps
+        _capi.profile_enable(True)
+        for _ in range(a.steps):
+            one_step()
+        fence()
+        _capi.profile_enable(False)
+    _capi.profile_select(None)
     fwd_med, fwd_p10, fwd_p90 = forward_pair_us(model, batch) if rank == 0 else (0.0, 0.0, 0.0)
 
     prof = dict(warm)
@@ -314,7 +381,10 @@ def main():
                                    f"(the reference's default), camera-branch early ray termination "
                                    f"{'on' if model.hp.impl['ert'] else 'off'} (T < 1.5e-8)",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}",
+                       "launch": ("the step replayed from a HIP graph (DDP all-reduce issued after each replay); "
+                                  "kernel timings from HIP events in eager steps of the same run"
+                                  if launch_mode == "hip_graph" else "eager launches")},
             "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": dom_gbs / HBM_PEAK_GBS,

@@ -52,6 +52,9 @@ class GradSync(torch.nn.Module):
         self.world = dist.get_world_size(group)
         self._pending = []
         self._joining = False
+        # False: the hooks do nothing (a caller that replays the step from a HIP graph captures it
+        # without the collective and averages the gradients itself after each replay)
+        self.enabled = True
         with torch.no_grad():
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
@@ -62,6 +65,8 @@ class GradSync(torch.nn.Module):
                 p.register_post_accumulate_grad_hook(self._launch)
 
     def _launch(self, p):
+        if not self.enabled:
+            return
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         if not self._joining:
             # join at the end of this backward pass, whoever called it

@@ -89,10 +89,9 @@ class HotPath:
                      "lift_bwd": os.environ.get("VAMP_LIFT_BWD", "cell"),
                      "bev_bwd": os.environ.get("VAMP_BEV_BWD", "cell"),
                      "lift_wpp": int(os.environ.get("VAMP_LIFT_WPP", "0")),
-                     # BEV branch on a second stream: worth 9 % of the step in round 1; since the
-                     # camera branch terminates rays early it costs more than it hides (forward pair 296 vs
-                     # 210 us, step 0.806 vs 0.804 ms), so off unless asked for
-                     "overlap": os.environ.get("VAMP_OVERLAP", "0") == "1",
+                     # BEV branch on a second stream in training steps (forward-only calls stay on one
+                     # stream): eager step 0.679 vs 0.699 ms, replayed from a HIP graph 0.629 vs 0.695 ms
+                     "overlap": os.environ.get("VAMP_OVERLAP", "1") == "1",
                      # single stream: BEV branch first (overwriting), camera gather adds -- or the
                      # camera branch first and the BEV gather adds
                      "bev_first": os.environ.get("VAMP_BEV_FIRST", "1") == "1",
@@ -164,7 +163,7 @@ class HotPath:
     # ----------------------------------------------------------------- lift
     def lift(self, depth, feat, lift_mats, use_depth=True):
         """depth [B,N,D,fH,fW], feat [B,N,C,fH,fW], lift_mats [B,N,3,4,4] -> [B,C,Z,Y,X]."""
-        return _LiftFn.apply(self, depth, feat, lift_mats, use_depth)
+        return _LiftFn.apply(self, depth, feat, lift_mats, use_depth, torch.is_grad_enabled())
 
     def lift_dense(self, frustum_feats, lift_mats):
         """frustum_feats [B,N,C,D,fH,fW] (materialised, fp32) -> [B,C,Z,Y,X]."""
@@ -221,7 +220,7 @@ class HotPath:
             if self.cfg.density_mode == "sdf":
                 raise ValueError("density_mode='sdf' needs the beta parameter")
         return _RenderFn.apply(self, density_feature, semantic_logits, base, rgb, beta, geom,
-                               render_mats)
+                               render_mats, torch.is_grad_enabled())
 
     # ------------------------------------------------------ point resampling
     def sample_points(self, volume, points, *, padding="zeros", mask_outside=False, activation=False,
@@ -272,7 +271,7 @@ class HotPath:
 # ===========================================================================
 class _LiftFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, hp: HotPath, depth, feat, mats, use_depth):
+    def forward(ctx, hp: HotPath, depth, feat, mats, use_depth, grad_mode=True):
         c = hp.cfg
         B, N, C_ = feat.shape[:3]
         ctx.in_dtypes = (depth.dtype if use_depth else None, feat.dtype)
@@ -290,9 +289,10 @@ class _LiftFn(torch.autograd.Function):
                 raise TypeError("depth and feat must share a dtype")
         mats = _chk(mats.float(), (B, N, 3, 4, 4), "lift_mats")
         out = torch.empty(B, C_, c.vZ, c.vY, c.vX, dtype=torch.float32, device=feat.device)
-        # (needs_input_grad, not requires_grad: under torch.no_grad() nothing is recorded and the
-        # backward's hit words / prepare pass would be wasted work)
-        need_grad = ctx.needs_input_grad[2] or (use_depth and ctx.needs_input_grad[1])
+        # (the caller's grad mode comes in as an argument: inside forward it is always off and
+        # needs_input_grad ignores torch.no_grad(), under which the backward's hit words / prepare
+        # pass would be wasted work)
+        need_grad = grad_mode and (ctx.needs_input_grad[2] or (use_depth and ctx.needs_input_grad[1]))
         nchunk = (C_ + 15) // 16
         hits = (torch.empty(B, c.vZ, c.vY, c.vX, nchunk, dtype=torch.int64, device=feat.device)
                 if need_grad else None)
@@ -344,7 +344,7 @@ class _LiftFn(torch.autograd.Function):
                                                  _ptr(hits), _ptr(gdepth), _ptr(gfeat), _ptr(ws),
                                                  ws.numel(), valid, _stream()), "vamp_lift_backward_ex")
         gd = gdepth.to(ctx.in_dtypes[0]) if use_depth else None
-        return None, gd, gfeat.to(ctx.in_dtypes[1]), None, None
+        return None, gd, gfeat.to(ctx.in_dtypes[1]), None, None, None
 
 
 class _LiftDenseFn(torch.autograd.Function):
@@ -383,8 +383,11 @@ class _LiftDenseFn(torch.autograd.Function):
 
 class _RenderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, hp: HotPath, dens, sem, base, rgb, beta, geom, mats):
+    def forward(ctx, hp: HotPath, dens, sem, base, rgb, beta, geom, mats, grad_mode=True):
         c = hp.cfg
+        # will a backward follow?  (grad_mode is the caller's: inside forward it is always off, and
+        # needs_input_grad ignores torch.no_grad())
+        train = grad_mode and any(ctx.needs_input_grad)
         B = dens.shape[0]
         N = (geom if geom is not None else mats).shape[1]
         C_ = base.shape[1]
@@ -413,7 +416,7 @@ class _RenderFn(torch.autograd.Function):
         nbytes = hp.lib.vamp_render_workspace_bytes(C.byref(d))
         # training: the march also stores every inside sample's gathered row behind the base region,
         # and the backward's per-ray pass reads it back instead of repeating the 8-tap gather
-        save = (any(ctx.needs_input_grad) and geom is None and hp.impl["cam_bwd"] != "v1"
+        save = (train and geom is None and hp.impl["cam_bwd"] != "v1"
                 and hp.impl["save_samples"])
         if save:
             nbytes += hp.lib.vamp_render_samples_bytes(C.byref(d))
@@ -424,8 +427,12 @@ class _RenderFn(torch.autograd.Function):
         bev_h = torch.empty(B, 1, c.oY, c.oX, dtype=f32, device=dev)
         vdens = torch.empty(B, 1, c.oZ, c.oY, c.oX, dtype=f32, device=dev)
         vout = torch.empty(B, CO, c.oZ, c.oY, c.oX, dtype=f32, device=dev)
-        # the two branches share only their inputs: BEV on the side stream, camera on this one
-        cur, side = torch.cuda.current_stream(), hp._side_stream()
+        # the two branches share only their inputs: in a training step the BEV branch (and the
+        # geometry-only prepare pass of the backward) runs on the side stream, the camera branch on
+        # this one.  Forward-only calls stay on one stream: the fork / join costs more than the short
+        # BEV forward hides (296 vs 210 us for the eager forward pair).
+        cur = torch.cuda.current_stream()
+        side = hp._side_stream() if train else None
         ctx.cells = False
         ert = geom is None and hp.impl["ert"]
         fwd_flags = 0 if ert else _capi.VAMP_CAMFWD_NO_ERT
@@ -439,7 +446,7 @@ class _RenderFn(torch.autograd.Function):
         ctx.ert = ert
         if side is not None:
             side.wait_stream(cur)
-            if any(ctx.needs_input_grad) and geom is None and hp.impl["prepare"] and hp.impl["cam_bwd"] != "v1":
+            if train and geom is None and hp.impl["prepare"] and hp.impl["cam_bwd"] != "v1":
                 # the sample -> cell-slot table of the backward depends on the geometry (and the
                 # termination table) only: it is built here, on the side stream, beside the forward
                 _capi.check(hp.lib.vamp_render_camera_prepare_ex(
@@ -447,7 +454,7 @@ class _RenderFn(torch.autograd.Function):
                     _capi.VAMP_CAMPREP_TERM_VALID if ert else 0, _stream(side)), "vamp_render_camera_prepare_ex")
                 ctx.cells = True
         # training: the BEV branch keeps its density / semantic / rgb samples for its backward
-        bev_save = any(ctx.needs_input_grad) and hp.impl["bev_save"] and hp.impl["bev_bwd"] != "v1"
+        bev_save = train and hp.impl["bev_save"] and hp.impl["bev_bwd"] != "v1"
         ws_bev = (hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d))) if bev_save else None)
         _capi.check(hp.lib.vamp_render_bev_forward_ex(
             C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
@@ -553,7 +560,7 @@ class _RenderFn(torch.autograd.Function):
             bev_backward(cur, False)
         grad_beta = gbeta.reshape(ctx.beta_shape) if hp.cfg.density_mode == "sdf" else None
         dt = ctx.in_dtypes
-        return (None, gd.to(dt[0]), gs.to(dt[1]), gb.to(dt[2]), gr.to(dt[3]), grad_beta, None, None)
+        return (None, gd.to(dt[0]), gs.to(dt[1]), gb.to(dt[2]), gr.to(dt[3]), grad_beta, None, None, None)
 
 
 class _SamplePointsFn(torch.autograd.Function):
