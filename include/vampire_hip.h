@@ -458,6 +458,9 @@ int vamp_upsample_trilinear_forward(int64_t planes, int32_t iz, int32_t iy, int3
                                     int32_t oy, int32_t ox, const float* in, float* out,
                                     void* stream);
 size_t vamp_upsample_trilinear_workspace_bytes(int32_t iz, int32_t iy, int32_t ix);
+/* 1 when the backward's gather table covers this scale (about out / in <= 6 per axis), else 0:
+ * callers fall back to F.interpolate then */
+int vamp_upsample_trilinear_supported(int32_t iz, int32_t iy, int32_t ix, int32_t oz, int32_t oy, int32_t ox);
 /* grad_in [planes, iz, iy, ix] is fully overwritten */
 int vamp_upsample_trilinear_backward(int64_t planes, int32_t iz, int32_t iy, int32_t ix, int32_t oz,
                                      int32_t oy, int32_t ox, const float* grad_out, float* grad_in,

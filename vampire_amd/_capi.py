@@ -110,6 +110,7 @@ SIGNATURES = {
     "vamp_density_gate_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, _P]),
     "vamp_upsample_trilinear_forward": (C.c_int, [C.c_int64] + [C.c_int32] * 6 + [_P, _P, _P]),
     "vamp_upsample_trilinear_workspace_bytes": (C.c_size_t, [C.c_int32] * 3),
+    "vamp_upsample_trilinear_supported": (C.c_int, [C.c_int32] * 6),
     "vamp_upsample_trilinear_backward": (C.c_int, [C.c_int64] + [C.c_int32] * 6 + [_P, _P, _P, C.c_size_t, _P]),
     "vamp_conv3d_supported": (C.c_int, [_CD]),
     "vamp_conv3d_forward": (C.c_int, [_CD, _P, _P, _P, _P]),

@@ -48,9 +48,12 @@ def _resize(x, size):
     """F.interpolate(x, size, mode='trilinear', align_corners=True) (bv2:66, 72): the HIP resize for
     device tensors (its backward is a gather; aten's atomic scatter is 8.8 ms of the module's
     backward at cfg-B), torch for CPU tensors like the other dense layers."""
-    if x.is_cuda:
+    if x.is_cuda and x.dim() == 5:
         from .ops import upsample_trilinear
-        return upsample_trilinear(x, size)
+        from . import _capi
+        # scale factors beyond the backward's gather table (about 6x per axis) go to aten
+        if _capi.load().vamp_upsample_trilinear_supported(*x.shape[2:], *[int(v) for v in size]):
+            return upsample_trilinear(x, size)
     return F.interpolate(x, tuple(size), mode="trilinear", align_corners=True)
 
 

@@ -34,7 +34,7 @@ inline int validate(const VampRenderDesc* d) {
   VAMP_REQUIRE(d->K > 0 && d->K <= 28, "1 <= K <= 28");
   VAMP_REQUIRE(d->C >= 0 && d->C <= 64, "0 <= C <= 64");
   VAMP_REQUIRE(d->Z > 1 && d->Y > 1 && d->X > 1, "Z, Y, X > 1");
-  VAMP_REQUIRE(d->X < 2047 && d->Y < 2047 && d->Z < 1023, "volume axes limited to 2046 x 2046 x 1022 (packed tap keys)");
+  VAMP_REQUIRE(d->X < 2047 && d->Y < 2047 && d->Z < 511, "volume axes limited to 2046 x 2046 x 510 (packed tap keys: 11 / 11 / 9 bits + sign)");
   VAMP_REQUIRE(d->density_mode == VAMP_DENSITY_SIGMOID ||
                d->density_mode == VAMP_DENSITY_SDF_LAPLACE, "density_mode");
   VAMP_REQUIRE(d->in_dtype == VAMP_F32 || d->in_dtype == VAMP_BF16, "in_dtype");

@@ -50,8 +50,8 @@ static SampleParams to_params(const VampSampleDesc* d, int points_per_sample) {
 static int validate(const VampSampleDesc* d, long n) {
   VAMP_REQUIRE(d != nullptr, "descriptor is NULL");
   VAMP_REQUIRE(d->B > 0 && d->C > 0 && d->C <= 32, "B > 0, 0 < C <= 32");
-  VAMP_REQUIRE(d->Z > 0 && d->Y > 0 && d->X > 0 && d->X < 2047 && d->Y < 2047 && d->Z < 1023,
-               "volume extents (X, Y < 2047, Z < 1023)");
+  VAMP_REQUIRE(d->Z > 0 && d->Y > 0 && d->X > 0 && d->X < 2047 && d->Y < 2047 && d->Z < 511,
+               "volume extents (X, Y < 2047, Z < 511: packed tap keys)");
   VAMP_REQUIRE(d->span[0] != 0.f && d->span[1] != 0.f && d->span[2] != 0.f, "zero span");
   VAMP_REQUIRE(d->padding == VAMP_PAD_ZEROS || d->padding == VAMP_PAD_BORDER, "padding mode");
   VAMP_REQUIRE(d->in_dtype == VAMP_F32 || d->in_dtype == VAMP_BF16, "in_dtype");

@@ -181,6 +181,11 @@ int vamp_upsample_trilinear_forward(int64_t planes, int32_t iz, int32_t iy, int3
   return check_launch("upsample_fwd_kernel");
 }
 
+int vamp_upsample_trilinear_supported(int32_t iz, int32_t iy, int32_t ix, int32_t oz, int32_t oy, int32_t ox) {
+  if (iz <= 0 || iy <= 0 || ix <= 0 || oz <= 0 || oy <= 0 || ox <= 0) return 0;
+  return (run_fits(iz, oz) && run_fits(iy, oy) && run_fits(ix, ox)) ? 1 : 0;
+}
+
 size_t vamp_upsample_trilinear_workspace_bytes(int32_t iz, int32_t iy, int32_t ix) {
   if (iz <= 0 || iy <= 0 || ix <= 0) return 0;
   return table_bytes(iz, iy, ix);

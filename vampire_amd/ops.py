@@ -163,7 +163,8 @@ class HotPath:
     # ----------------------------------------------------------------- lift
     def lift(self, depth, feat, lift_mats, use_depth=True):
         """depth [B,N,D,fH,fW], feat [B,N,C,fH,fW], lift_mats [B,N,3,4,4] -> [B,C,Z,Y,X]."""
-        return _LiftFn.apply(self, depth, feat, lift_mats, use_depth, torch.is_grad_enabled())
+        with torch.cuda.device(self.device):      # launches go to this object's device, whatever is current
+            return _LiftFn.apply(self, depth, feat, lift_mats, use_depth, torch.is_grad_enabled())
 
     def lift_dense(self, frustum_feats, lift_mats):
         """frustum_feats [B,N,C,D,fH,fW] (materialised, fp32) -> [B,C,Z,Y,X]."""
@@ -219,8 +220,9 @@ class HotPath:
             beta = torch.zeros((), device=self.device)
             if self.cfg.density_mode == "sdf":
                 raise ValueError("density_mode='sdf' needs the beta parameter")
-        return _RenderFn.apply(self, density_feature, semantic_logits, base, rgb, beta, geom,
-                               render_mats, torch.is_grad_enabled())
+        with torch.cuda.device(self.device):
+            return _RenderFn.apply(self, density_feature, semantic_logits, base, rgb, beta, geom,
+                                   render_mats, torch.is_grad_enabled())
 
     # ------------------------------------------------------ point resampling
     def sample_points(self, volume, points, *, padding="zeros", mask_outside=False, activation=False,
@@ -715,7 +717,7 @@ class _UpsampleTrilinearFn(torch.autograd.Function):
         if gin.numel() and g.numel():
             lib = ctx.lib
             nbytes = lib.vamp_upsample_trilinear_workspace_bytes(*ctx.dims[1:4])
-            key = (g.device, nbytes)
+            key = (g.device, torch.cuda.current_stream().cuda_stream, nbytes)   # one table per stream
             ws = _resize_ws.get(key)
             if ws is None:
                 ws = _resize_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
@@ -780,7 +782,7 @@ class _Conv3dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
             nbytes = lib.vamp_conv3d_workspace_bytes(C.byref(d))
-            key = (g.device, "conv", nbytes)
+            key = (g.device, torch.cuda.current_stream().cuda_stream, "conv", nbytes)
             ws = _resize_ws.get(key)
             if ws is None:
                 ws = _resize_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
