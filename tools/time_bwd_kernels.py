@@ -12,7 +12,8 @@ dev = torch.device("cuda:0")
 model = LiftRenderStep(cfg, dev)
 if os.environ.get("VAMP_OVERLAP", "1") == "0":
     model.hp.impl["overlap"] = False
-data = SyntheticBatch(cfg, B, dev)
+import torch as _t
+data = SyntheticBatch(cfg, B, dev, dtype=(_t.bfloat16 if os.environ.get("VAMP_DTYPE") == "bf16" else _t.float32))
 for _ in range(5):
     model.zero_grad(set_to_none=True); train_step(model, data)
 torch.cuda.synchronize()
