@@ -278,12 +278,19 @@ def main():
     for _ in range(a.warmup - n_prof):
         one_step()
     fence()
+    # (per-kernel timings are taken with both render branches on ONE stream: side by side on two
+    # streams the kernels stretch each other and an event pair no longer times one kernel)
+    overlap = model.hp.impl["overlap"]
+    model.hp.impl["overlap"] = False
+    one_step()
+    fence()
     _capi.profile_select(None)
     _capi.profile_enable(True)
     for _ in range(n_prof):
         one_step()
     fence()
     _capi.profile_enable(False)
+    model.hp.impl["overlap"] = overlap
     warm = {k: (n, ms, n_prof) for k, (n, ms) in _capi.profile_read().items()}
     alg = kernel_algorithmic_bytes(cfg, a.batch)
     dom = None
@@ -331,12 +338,16 @@ def main():
     _capi.profile_enable(False)
     elapsed = vdist.max_over_ranks(elapsed, dev)
     if graph is not None:
-        # the dominant kernel's launches, timed with HIP events in K eager steps
+        # the dominant kernel's launches, timed with HIP events in K eager one-stream steps
+        model.hp.impl["overlap"] = False
+        one_step()
+        fence()
         _capi.profile_enable(True)
         for _ in range(a.steps):
             one_step()
         fence()
         _capi.profile_enable(False)
+        model.hp.impl["overlap"] = overlap
     _capi.profile_select(None)
     fwd_med, fwd_p10, fwd_p90 = forward_pair_us(model, batch) if rank == 0 else (0.0, 0.0, 0.0)
 
@@ -383,7 +394,7 @@ def main():
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"dp{world}",
                        "launch": ("the step replayed from a HIP graph (DDP all-reduce issued after each replay); "
-                                  "kernel timings from HIP events in eager steps of the same run"
+                                  "kernel timings from HIP events in eager one-stream steps of the same run"
                                   if launch_mode == "hip_graph" else "eager launches")},
             "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS,
