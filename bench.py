@@ -208,7 +208,8 @@ def capture_step(model, batch, train_step):
     tensors = lambda: [batch.depth.grad, batch.feat.grad] + [v.grad for v in batch.vols] + [model.beta.grad]
     ref = [t.detach().clone() for t in tensors()]
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=side):
+    # thread_local: calls of other threads (the RCCL watchdog polls its events) must not fail the capture
+    with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
         raw_step()
     torch.cuda.synchronize()
     g.replay()
@@ -317,6 +318,13 @@ def main():
             graph = None
         if hook_sync:
             step_model.enabled = True
+    if world > 1:
+        # all ranks replay, or all launch eagerly: one rank falling back alone would pair its averaging
+        # all-reduce with the others' sums
+        ok = torch.tensor([1.0 if graph is not None else 0.0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) == 0.0:
+            graph, launch_mode = None, "eager"
 
     def graph_step():
         graph.replay()
