@@ -5,7 +5,7 @@ set -e
 ROOT=$(cd $(dirname $0)/.. && pwd)
 SRC=$1; shift
 BASE=$(basename $SRC .hip)
-OBJS=$(ls $ROOT/vampire_amd/_lib/*.o | grep -v "/$BASE.o" | grep -v abl_ | grep -v -E "lift_bwd_bin|lift_bwd_tile|render_bwd_bin|render_bwd_brick")
+OBJS=$(ls $ROOT/vampire_amd/_lib/*.o | grep -v "/$BASE.o" | grep -v abl_)
 for spec in "$@"; do
   name=${spec%%=*}; flags=${spec#*=}
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -std=c++17 $flags -c $ROOT/vampire_amd/csrc/$BASE.hip -o $ROOT/vampire_amd/_lib/abl_${name}_$BASE.o

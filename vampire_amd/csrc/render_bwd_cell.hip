@@ -27,7 +27,10 @@
 
 namespace vamp {
 
-constexpr int kHeavy = 256;          // records per voxel beyond which the whole-workgroup kernel runs
+#ifndef VAMP_HEAVY
+#define VAMP_HEAVY 256
+#endif
+constexpr int kHeavy = VAMP_HEAVY;       // records per voxel beyond which the whole-workgroup kernel runs
 
 __device__ __forceinline__ long sample_cell(const RenderParams& P, int key, unsigned b, long ncell_b) {
   return key_to_cell(key, P.Y, P.X, b, ncell_b);
