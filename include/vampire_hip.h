@@ -355,6 +355,8 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
  */
 #define VAMP_BEVBWD_OVERWRITE_BASE 1   /* grad_base */
 #define VAMP_BEVBWD_OVERWRITE_CAM 2    /* grad_density_feature, grad_semantic, grad_rgb */
+#define VAMP_BEVBWD_ONLY_BASE 8         /* only the pass-through (grad_base) gather: it needs neither q nor the scan and nobody waits for it, so it can be a call of its own ... */
+#define VAMP_BEVBWD_SKIP_BASE 16        /* ... behind (or beside) the call that does everything else; give both calls the same OVERWRITE flags */
 #define VAMP_BEVBWD_SAVED_VALID 4      /* the workspace holds what vamp_render_bev_forward_ex(.., VAMP_BEVFWD_SAVE) kept */
 int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const float* oys,
                              const float* ozs, const float* bev_mids, const float* beta,

@@ -857,7 +857,7 @@ static size_t bev_one(const VampRenderDesc* d) {
   return align_up((size_t) d->B * d->oZ * d->oY * d->oX * sizeof(float), 256);
 }
 static size_t bev_saved_offset(const VampRenderDesc* d) {
-  return 3 * bev_one(d) + align_up((size_t) 2 * (d->X + d->Y + d->Z) * sizeof(int4), 256) +
+  return 3 * bev_one(d) + 2 * align_up((size_t) 2 * (d->X + d->Y + d->Z) * sizeof(int4), 256) +
          align_up(bev_scan_blocks(d) * sizeof(float), 256);
 }
 static size_t bev_ws_bytes(const VampRenderDesc* d) {
@@ -938,6 +938,7 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
   VAMP_REQUIRE(grad_density_feature && grad_semantic && grad_rgb, "null output");
   VAMP_REQUIRE(grad_base || d->C == 0 || !g_voxel_output, "grad_base is NULL");
   VAMP_REQUIRE((beta && grad_beta) || d->density_mode == VAMP_DENSITY_SIGMOID, "beta / grad_beta is NULL");
+  if (!ozs_host && (flags & VAMP_BEVBWD_ONLY_BASE)) return VAMP_OK;   // the SKIP_BASE call of the pair does it all
   if (!ozs_host) {
     // float-atomic formulation: adds, so zero what the caller asked to have overwritten
     if (int e = bev_zero_overwritten(d, flags, grad_density_feature, grad_semantic, grad_rgb, grad_base,
@@ -955,12 +956,17 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t one = align_up((size_t) d->B * d->oZ * d->oY * d->oX * sizeof(float), 256);
   const int tot_ax = d->X + d->Y + d->Z;
-  int4* tab = reinterpret_cast<int4*>(static_cast<char*>(workspace) + 3 * one);
+  // VAMP_BEVBWD_ONLY_BASE / _SKIP_BASE: the pass-through (base) gather needs neither q nor the
+  // scan and nobody waits for grad_base, so a caller may issue it as a call of its own -- behind
+  // the event the camera gather waits for, or on another stream; that call has its own axis table
+  const bool only_base = (flags & VAMP_BEVBWD_ONLY_BASE) != 0, skip_base = (flags & VAMP_BEVBWD_SKIP_BASE) != 0;
+  VAMP_REQUIRE(!(only_base && skip_base), "ONLY_BASE and SKIP_BASE exclude each other");
+  const size_t tab_bytes = align_up((size_t) 2 * (d->X + d->Y + d->Z) * sizeof(int4), 256);
+  int4* tab = reinterpret_cast<int4*>(static_cast<char*>(workspace) + 3 * one + (only_base ? tab_bytes : 0));
   float* Q = static_cast<float*>(workspace);
   float* Wb = reinterpret_cast<float*>(static_cast<char*>(workspace) + one);
   float* DS0 = reinterpret_cast<float*>(static_cast<char*>(workspace) + 2 * one);
-  float* beta_part = reinterpret_cast<float*>(static_cast<char*>(workspace) + 3 * one +
-                                              align_up((size_t) 2 * (d->X + d->Y + d->Z) * sizeof(int4), 256));
+  float* beta_part = reinterpret_cast<float*>(static_cast<char*>(workspace) + 3 * one + 2 * tab_bytes);
 
   // z-range of volume planes the lattice touches (host copy of the det-grid heights)
   int z_lo = d->Z, z_hi = -1;
@@ -1004,9 +1010,11 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
         g_voxel_density, Q, Wb, DS0, beta_part)));                                                \
     if (int e = check_launch("bev_scan_kernel")) return e;                                        \
   } while (0)
-  if (d->in_dtype == VAMP_F32) VAMP_BEVB(float); else VAMP_BEVB(__hip_bfloat16);
+  if (!only_base) {
+    if (d->in_dtype == VAMP_F32) VAMP_BEVB(float); else VAMP_BEVB(__hip_bfloat16);
+  }
 #undef VAMP_BEVB
-  if (d->density_mode == VAMP_DENSITY_SDF_LAPLACE)
+  if (!only_base && d->density_mode == VAMP_DENSITY_SDF_LAPLACE)
     if (int e = launch_beta_reduce(beta_part, (int) bev_scan_blocks(d), beta, grad_beta, s)) return e;
   // lattice points within one voxel's trilinear support, per axis
   bool fits = true;
@@ -1041,7 +1049,8 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
       return dim3((unsigned) (((long) d->Y * d->X + 255) / 256), d->B * nseg * ((nchan + g - 1) / g));
     };
     // semantic + rgb + density in one launch (they share the Wb taps of a height)
-    if (owc) VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_col_kernel<kColGC, true, false, true><<<grid(d->K + 3, kColGC), 256, 0, s>>>(
+    if (only_base) {}
+    else if (owc) VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_col_kernel<kColGC, true, false, true><<<grid(d->K + 3, kColGC), 256, 0, s>>>(
         P, tab, ozs, g_bev_seg, g_bev_rgb, nullptr, -1, Wb, DS0, grad_density_feature, grad_semantic, grad_rgb,
         d->K, 3, zseg, 1, 0)));
     else VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_col_kernel<kColGC, true, false, false><<<grid(d->K + 3, kColGC), 256, 0, s>>>(
@@ -1049,11 +1058,12 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
         d->K, 3, zseg, 1, 0)));
     if (int e = check_launch("bev_gather_col_kernel")) return e;
     // pass-through gradients (voxel_output): the semantic part (cat_seg) adds, base is its own tensor
-    if (vo_sem)
+    if (vo_sem && !only_base)
       VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_col_kernel<kColG, false, true, false><<<grid(d->K), 256, 0, s>>>(
           P, tab, ozs, nullptr, nullptr, g_voxel_output, d->C, Wb, DS0, grad_density_feature, grad_semantic,
           nullptr, d->K, 0, zseg, 0, 0)));
-    if (d->C > 0 && g_voxel_output && ow)
+    if (skip_base) {}
+    else if (d->C > 0 && g_voxel_output && ow)
       VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_col_kernel<kColG, false, true, true><<<grid(d->C), 256, 0, s>>>(
           P, tab, ozs, nullptr, nullptr, g_voxel_output, 0, Wb, DS0, grad_density_feature, grad_base, nullptr,
           d->C, 0, zseg, 0, 0)));
@@ -1064,7 +1074,9 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
     else if (d->C > 0 && ow)
       if (int ze = launch_zero(grad_base, (size_t) d->B * d->C * d->Z * d->Y * d->X * sizeof(float), s)) return ze;
   }
-  else {
+  else if (!only_base) {
+    // (the generic kernel does all four tensors at once: of a split pair of calls the SKIP_BASE one
+    // does the whole job and the ONLY_BASE one nothing)
     // the generic kernel adds: zero what the caller asked to have overwritten
     if (int e = bev_zero_overwritten(d, flags, grad_density_feature, grad_semantic, grad_rgb, grad_base, s))
       return e;

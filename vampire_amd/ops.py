@@ -508,8 +508,8 @@ class _RenderFn(torch.autograd.Function):
         bev_saved = (ctx.bev_key is not None and hp.impl["bev_bwd"] != "v1"
                      and ctx.bev_key == (getattr(hp, "_bev_gen", 0), ws_bev.data_ptr()))
 
-        def bev_backward(stream, overwrite_cam):
-            flags = _capi.VAMP_BEVBWD_OVERWRITE_BASE | (_capi.VAMP_BEVBWD_OVERWRITE_CAM if overwrite_cam else 0)
+        def bev_backward(stream, overwrite_cam, part=0):
+            flags = _capi.VAMP_BEVBWD_OVERWRITE_BASE | (_capi.VAMP_BEVBWD_OVERWRITE_CAM if overwrite_cam else 0) | part
             if bev_saved:
                 flags |= _capi.VAMP_BEVBWD_SAVED_VALID
             _capi.check(hp.lib.vamp_render_bev_backward_ex(
@@ -541,10 +541,13 @@ class _RenderFn(torch.autograd.Function):
             # Two streams: the BEV branch writes the buffers on the side stream while the camera
             # branch marches its rays and sorts its samples on this one; the camera gather then
             # waits for the BEV event and adds on top.
+            # The pass-through (grad_base) gather of the BEV branch is issued behind the event: nobody
+            # waits for grad_base, so it runs beside the camera gather instead of in front of it.
             side.wait_stream(cur)
-            bev_backward(side, True)
+            bev_backward(side, True, _capi.VAMP_BEVBWD_SKIP_BASE)
             done = torch.cuda.Event()
             done.record(side)
+            bev_backward(side, True, _capi.VAMP_BEVBWD_ONLY_BASE)
             _capi.check(hp.lib.vamp_render_camera_backward_acc(
                 *cam_args, _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gbeta), _ptr(ws), ws.numel(), 1 | packed_valid,
                 C.c_void_p(done.cuda_event), _stream(cur)), "vamp_render_camera_backward_acc")
