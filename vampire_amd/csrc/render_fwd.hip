@@ -17,28 +17,44 @@
 namespace vamp {
 
 // ---------------------------------------------------------------------------
-// pack: thread per voxel, CP/4 float4 stores (lanes contiguous -> coalesced)
+// pack: thread per voxel on the load side, rows transposed through LDS on the store side
 // ---------------------------------------------------------------------------
 template <typename T, int CP4>
 __global__ void __launch_bounds__(256)
 pack_volume_kernel(RenderParams P, const T* __restrict__ dens, const T* __restrict__ sem,
                    const T* __restrict__ rgb, float* __restrict__ packed) {
-  const long V = (long) P.Z * P.Y * P.X;
-  const long gid = (long) blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= V * P.B) return;
-  const long b = gid / V, vox = gid % V;
-  float v[CP4 * 4];
+  // The channel-first volumes are read coalesced along x (a thread per voxel) and the 96-byte
+  // channel-last rows leave through LDS, so that a workgroup's 256 rows go out as one contiguous
+  // 24 KB run of aligned float4 stores (a thread storing its own row puts 16 bytes into each of
+  // 64 lines per instruction).
+  constexpr int CP = CP4 * 4, ST = CP + 1;       // odd row stride: conflict-free both ways
+  __shared__ float rows[256 * ST];
+  const long V = (long) P.Z * P.Y * P.X, total = V * P.B;
+  const long gid0 = (long) blockIdx.x * 256;
+  const long gid = gid0 + threadIdx.x;
+  if (gid < total) {
+    const long b = gid / V, vox = gid % V;
 #pragma unroll
-  for (int c = 0; c < CP4 * 4; ++c) {
-    float val = 0.f;
-    if (c == 0) val = ldf(dens, b * V + vox);
-    else if (c <= P.K) val = ldf(sem, (b * P.K + (c - 1)) * V + vox);
-    else if (c <= P.K + 3) val = ldf(rgb, (b * 3 + (c - 1 - P.K)) * V + vox);
-    v[c] = val;
+    for (int c = 0; c < CP; ++c) {
+      float val = 0.f;
+      if (c == 0) val = ldf(dens, b * V + vox);
+      else if (c <= P.K) val = ldf(sem, (b * P.K + (c - 1)) * V + vox);
+      else if (c <= P.K + 3) val = ldf(rgb, (b * 3 + (c - 1 - P.K)) * V + vox);
+      rows[threadIdx.x * ST + c] = val;
+    }
   }
-  float4* dst = reinterpret_cast<float4*>(packed + gid * (CP4 * 4));
+  __syncthreads();
+  const long nrow = min((long) 256, total - gid0);
+  float4* dst = reinterpret_cast<float4*>(packed + gid0 * CP);
 #pragma unroll
-  for (int q = 0; q < CP4; ++q) dst[q] = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
+  for (int i = 0; i < CP4; ++i) {
+    const int q = i * 256 + threadIdx.x;         // float4 index inside the workgroup's run
+    const int r = q / CP4, c4 = q % CP4;
+    if (r < nrow) {
+      const float* src = rows + r * ST + c4 * 4;
+      dst[q] = make_float4(src[0], src[1], src[2], src[3]);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
