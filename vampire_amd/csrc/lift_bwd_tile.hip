@@ -154,9 +154,6 @@ lift_bwd_tile_kernel(LiftParams P, const float* __restrict__ mats, const float* 
          q[12] == 0.f && q[13] == 0.f && q[14] == 0.f && q[15] == 1.f;
     const double det = (double) q[0] * q[5] - (double) q[1] * q[4];
     ok = ok && fabs(det) > 1e-300 && P.X > 1 && P.Y > 1 && P.Z > 1;
-#ifdef TILE_FULL_GRID
-    ok = false;
-#endif
     if (ok) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) s_inv[i] = (float) ai[i];
@@ -250,22 +247,8 @@ lift_bwd_tile_kernel(LiftParams P, const float* __restrict__ mats, const float* 
 
   const float S = s_scale[0];
   // ---- drain: lane = queued pair ------------------------------------------------------------------
-#ifdef VAMP_TILE_DEBUG
-  int dbg_pairs = 0, dbg_drains = 0;
-  long long dbg_tdrain = 0, dbg_s1 = 0, dbg_s2 = 0, dbg_s3 = 0;
-  float dbg_sink = 0.f;
-  const long long dbg_t0 = __builtin_amdgcn_s_memtime();
-#endif
   auto drain = [&]() {
-#ifdef VAMP_TILE_DEBUG
-    dbg_pairs += s_qn; dbg_drains += 1;
-    const long long dbg_ta = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef TILE_NO_DRAIN
-    const int qn = 0;
-#else
     const int qn = s_qn;
-#endif
     // Queue order is box order: neighbours in the queue are neighbours in space and tend to land
     // on the same pixel, and ds_add_f32 lanes that share an address are served one after the
     // other at ~100 cycles each (measured: a 1 000-pair drain took 600 k cycles).  The lanes of a
@@ -284,24 +267,12 @@ lift_bwd_tile_kernel(LiftParams P, const float* __restrict__ mats, const float* 
       const float wy1 = fy - fly, wy0 = (fly + 1.0f) - fy;
       const float wz1 = fz - flz, wz0 = (flz + 1.0f) - fz;
       // grad_out / (hit count + 1e-6), the camera-mean factor of bv2:512-514
-#ifdef TILE_NO_GLOAD
-      float gs[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) gs[c] = fx * (float) c;
-#else
       const uint64_t hw = hits[(long) b * V + vox];
       const float* g = gout + (long) b * C * V + vox;
       float gs[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c)
         gs[c] = c < C ? g[(long) c * V] * __builtin_amdgcn_rcpf((float) ((hw >> (4 * c)) & 15) + 1e-6f) : 0.f;
-#endif
-#ifdef VAMP_TILE_DEBUG
-      const long long dbg_a = __builtin_amdgcn_s_memtime();
-      { float t = 0.f; for (int c = 0; c < 16; ++c) t += gs[c]; dbg_sink += t; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
-      const long long dbg_b = __builtin_amdgcn_s_memtime();
-      dbg_s1 += dbg_b - dbg_a;
-#endif
       const float wj[4] = {wy0 * wx0, wy0 * wx1, wy1 * wx0, wy1 * wx1};
       float dep[4] = {0.f, 0.f, 0.f, 0.f};
       if (P.use_depth) {
@@ -324,12 +295,6 @@ lift_bwd_tile_kernel(LiftParams P, const float* __restrict__ mats, const float* 
         const float w = (iz0 == 0 ? wz0 : 0.f) + (iz0 == -1 ? wz1 : 0.f);
         dep[0] = dep[1] = dep[2] = dep[3] = w;
       }
-#ifdef VAMP_TILE_DEBUG
-      dbg_sink += dep[0] + dep[1] + dep[2] + dep[3];
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      const long long dbg_c = __builtin_amdgcn_s_memtime();
-      dbg_s2 += dbg_c - dbg_b;
-#endif
       // the pair's grad_feat part belongs to the range its floor tap lies in (tap -1: range 0)
       const bool own_feat = !P.use_depth || (iz0 >= (rng == 0 ? -1 : b0) && iz0 < b1);
       // neighbouring lanes are neighbouring voxels and often share their floor pixel: starting
@@ -358,29 +323,14 @@ lift_bwd_tile_kernel(LiftParams P, const float* __restrict__ mats, const float* 
           }
         }
       }
-#ifdef VAMP_TILE_DEBUG
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      dbg_s3 += __builtin_amdgcn_s_memtime() - dbg_c;
-#endif
     }
     __syncthreads();
     if (tid == 0) s_qn = 0;
     __syncthreads();
-#ifdef VAMP_TILE_DEBUG
-    dbg_tdrain += __builtin_amdgcn_s_memtime() - dbg_ta;
-#endif
   };
 
   // ---- walk the boxes -----------------------------------------------------------------------------
   const int nbox = s_nbox;
-#ifdef VAMP_TILE_DEBUG
-  if (tid == 0 && (blockIdx.x % 97) == 0) {
-    long cells = 0;
-    for (int i = 0; i < nbox; ++i) cells += (long) s_box[i].nx * s_box[i].ny * s_box[i].nz;
-    printf("tile %d bn %d X0 %d Y0 %d nbox %d cells %ld box0 %d %d %d  n %d %d %d\n", tile, bn, X0, Y0, nbox, cells,
-           s_box[0].x0, s_box[0].y0, s_box[0].z0, s_box[0].nx, s_box[0].ny, s_box[0].nz);
-  }
-#endif
   for (int bi = 0; bi < nbox; ++bi) {
     const TileBox bx = s_box[bi];
     const int plane = bx.nx * bx.ny, cells = plane * bx.nz;
@@ -398,11 +348,7 @@ lift_bwd_tile_kernel(LiftParams P, const float* __restrict__ mats, const float* 
         cy -= (cy * bx.nx > r); cy += ((cy + 1) * bx.nx <= r);
         const int cx = r - cy * bx.nx;
         const int vx = bx.x0 + cx, vy = bx.y0 + cy, vz = bx.z0 + cz;
-#ifdef TILE_NO_PROJECT
-        LiftTap t; t.valid = (ci & 7) == 0; t.ix0 = X0; t.iy0 = Y0; t.iz0 = bx.s_lo; t.fx = X0 + 0.5f; t.fy = Y0 + 0.5f; t.fz = bx.s_lo + 0.5f;
-#else
         const LiftTap t = lift_project(P, m, xs[vx], ys[vy], zs[vz]);
-#endif
         hit = t.valid && t.ix0 >= X0 - 1 && t.ix0 <= X1 && t.iy0 >= Y0 - 1 && t.iy0 <= Y1 &&
               (!P.use_depth || (t.iz0 >= bx.s_lo && t.iz0 <= bx.s_hi));
         ent = make_float4(__int_as_float((vz * P.Y + vy) * P.X + vx), t.fx, t.fy, t.fz);
@@ -422,11 +368,6 @@ lift_bwd_tile_kernel(LiftParams P, const float* __restrict__ mats, const float* 
   __syncthreads();
   if (s_qn > 0) drain();
 
-#ifdef VAMP_TILE_DEBUG
-  if (tid == 0 && (blockIdx.x % 197) == 0)
-    printf("blk %d tile %d pairs %d drains %d  cycles total %lld drain %lld | gs %lld dep %lld taps %lld (%f)\n", blockIdx.x, tile, dbg_pairs, dbg_drains,
-           (long long) (__builtin_amdgcn_s_memtime() - dbg_t0), dbg_tdrain, dbg_s1, dbg_s2, dbg_s3, dbg_sink);
-#endif
   // ---- store the tile: every element once (grad_feat: this range's partial) ---------------------
   const long gf_elems = (long) P.B * P.N * C * HW;
   for (int i = tid; i < C * kTP; i += kTileThreads) {
