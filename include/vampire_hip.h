@@ -219,6 +219,8 @@ int vamp_render_camera_forward(const VampRenderDesc* d, const float* geom, const
  */
 #define VAMP_CAMFWD_NO_ERT 2
 #define VAMP_CAMFWD_TERM_VALID 4
+#define VAMP_CAMFWD_PACK_ONLY 8      /* only the channel-last copy of (density, semantic, rgb) into the workspace */
+#define VAMP_CAMFWD_PACKED_VALID 16   /* the workspace already holds that copy: march only */
 int vamp_render_camera_terminate(const VampRenderDesc* d, const float* mats, const float* us,
                                  const float* vs, const float* ds, const float* beta,
                                  const void* density_feature, void* workspace, size_t workspace_bytes,

@@ -62,6 +62,7 @@ VAMP_CAMFWD_SAVE_SAMPLES, VAMP_CAMFWD_NO_ERT, VAMP_CAMFWD_TERM_VALID = 1, 2, 4
 VAMP_CAMPREP_TERM_VALID = 1
 VAMP_BEVBWD_OVERWRITE_BASE, VAMP_BEVBWD_OVERWRITE_CAM, VAMP_BEVBWD_SAVED_VALID = 1, 2, 4
 VAMP_BEVFWD_SAVE = 1
+VAMP_CAMFWD_PACK_ONLY, VAMP_CAMFWD_PACKED_VALID = 8, 16
 VAMP_BEVBWD_ONLY_BASE, VAMP_BEVBWD_SKIP_BASE = 8, 16
 
 _P = C.c_void_p

@@ -567,7 +567,11 @@ int vamp_render_camera_forward_ex(const VampRenderDesc* d, const float* geom, co
   int* term = ert ? cam_term_ptr(d, workspace) : nullptr;
   if (ert && !(flags & VAMP_CAMFWD_TERM_VALID))
     if (int e = launch_cam_term(d, P, mats, us, vs, ds, beta, density_feature, term, s)) return e;
-  if (int e = launch_pack(P, d->in_dtype, density_feature, semantic, rgb, packed, s)) return e;
+  // VAMP_CAMFWD_PACK_ONLY / _PACKED_VALID: the channel-last copy as a call of its own (a caller
+  // with two streams packs beside its other work and marches when both are there)
+  if (!(flags & VAMP_CAMFWD_PACKED_VALID))
+    if (int e = launch_pack(P, d->in_dtype, density_feature, semantic, rgb, packed, s)) return e;
+  if (flags & VAMP_CAMFWD_PACK_ONLY) return VAMP_OK;
   constexpr int LPR = 4;
   const unsigned grid = ray_grid<LPR>(P);
   // geometry from the matrices and at most kPlanMax samples per ray: the planned march

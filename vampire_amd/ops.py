@@ -95,6 +95,10 @@ class HotPath:
                      # single stream: BEV branch first (overwriting), camera gather adds -- or the
                      # camera branch first and the BEV gather adds
                      "bev_first": os.environ.get("VAMP_BEV_FIRST", "1") == "1",
+                     # stream schedule of the render forward in a training step: "default" = BEV branch
+                     # and prepare pass on the side stream; "split" = table, copy and prepare pass on the
+                     # side stream, BEV branch and march on the caller's
+                     "sched": os.environ.get("VAMP_SCHED", "split"),
                      # the BEV forward keeps its samples for the backward (+35 MB per sample at cfg-B)
                      "bev_save": os.environ.get("VAMP_BEV_SAVE", "1") == "1",
                      # store the forward's sample rows for the backward's per-ray pass: measured
@@ -438,39 +442,81 @@ class _RenderFn(torch.autograd.Function):
         ctx.cells = False
         ert = geom is None and hp.impl["ert"]
         fwd_flags = 0 if ert else _capi.VAMP_CAMFWD_NO_ERT
-        if ert:
-            # the per-ray termination table first: forward, the backward's sort and its per-ray pass
-            # all read it from the workspace
+        split = (side is not None and ert and hp.impl["sched"] == "split" and geom is None
+                 and hp.impl["prepare"] and hp.impl["cam_bwd"] != "v1")
+        if split:
+            # Schedule "split": the side stream takes what only the camera branch needs later --
+            # termination table, channel-last copy, then the backward's prepare pass -- and this
+            # stream the BEV branch, then the march once table and copy are there.  The critical
+            # chain of the default schedule (table -> prepare -> BEV forward on the side stream,
+            # 158 us) becomes max(BEV + march, table + copy + prepare) = 129 us.
+            side.wait_stream(cur)
             _capi.check(hp.lib.vamp_render_camera_terminate(
                 C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(beta), _ptr(dens), _ptr(ws),
-                ws.numel(), _stream(cur)), "vamp_render_camera_terminate")
+                ws.numel(), _stream(side)), "vamp_render_camera_terminate")
             fwd_flags |= _capi.VAMP_CAMFWD_TERM_VALID
-        ctx.ert = ert
-        if side is not None:
-            side.wait_stream(cur)
-            if train and geom is None and hp.impl["prepare"] and hp.impl["cam_bwd"] != "v1":
-                # the sample -> cell-slot table of the backward depends on the geometry (and the
-                # termination table) only: it is built here, on the side stream, beside the forward
-                _capi.check(hp.lib.vamp_render_camera_prepare_ex(
-                    C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(),
-                    _capi.VAMP_CAMPREP_TERM_VALID if ert else 0, _stream(side)), "vamp_render_camera_prepare_ex")
-                ctx.cells = True
-        # training: the BEV branch keeps its density / semantic / rgb samples for its backward
-        bev_save = train and hp.impl["bev_save"] and hp.impl["bev_bwd"] != "v1"
-        ws_bev = (hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d))) if bev_save else None)
-        _capi.check(hp.lib.vamp_render_bev_forward_ex(
-            C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
-            _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
-            _ptr(vdens), _ptr(vout), _ptr(ws_bev), ws_bev.numel() if bev_save else 0,
-            _capi.VAMP_BEVFWD_SAVE if bev_save else 0, _stream(side)), "vamp_render_bev_forward_ex")
-        hp._bev_gen = getattr(hp, "_bev_gen", 0) + 1
-        ctx.bev_key = (hp._bev_gen, ws_bev.data_ptr()) if bev_save else None
-        _capi.check(hp.lib.vamp_render_camera_forward_ex(
-            C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
-            _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
-            _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(),
-            fwd_flags | (_capi.VAMP_CAMFWD_SAVE_SAMPLES if save else 0), _stream(cur)),
-            "vamp_render_camera_forward_ex")
+            ctx.ert = ert
+            _capi.check(hp.lib.vamp_render_camera_forward_ex(
+                C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
+                _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
+                _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(),
+                fwd_flags | _capi.VAMP_CAMFWD_PACK_ONLY, _stream(side)), "vamp_render_camera_forward_ex")
+            packed_done = torch.cuda.Event()
+            packed_done.record(side)
+            _capi.check(hp.lib.vamp_render_camera_prepare_ex(
+                C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(),
+                _capi.VAMP_CAMPREP_TERM_VALID, _stream(side)), "vamp_render_camera_prepare_ex")
+            ctx.cells = True
+            bev_save = train and hp.impl["bev_save"] and hp.impl["bev_bwd"] != "v1"
+            ws_bev = (hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d))) if bev_save else None)
+            _capi.check(hp.lib.vamp_render_bev_forward_ex(
+                C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
+                _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
+                _ptr(vdens), _ptr(vout), _ptr(ws_bev), ws_bev.numel() if bev_save else 0,
+                _capi.VAMP_BEVFWD_SAVE if bev_save else 0, _stream(cur)), "vamp_render_bev_forward_ex")
+            hp._bev_gen = getattr(hp, "_bev_gen", 0) + 1
+            ctx.bev_key = (hp._bev_gen, ws_bev.data_ptr()) if bev_save else None
+            cur.wait_event(packed_done)
+            _capi.check(hp.lib.vamp_render_camera_forward_ex(
+                C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
+                _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
+                _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(),
+                fwd_flags | _capi.VAMP_CAMFWD_PACKED_VALID | (_capi.VAMP_CAMFWD_SAVE_SAMPLES if save else 0),
+                _stream(cur)), "vamp_render_camera_forward_ex")
+        else:
+            if ert:
+                # the per-ray termination table first: forward, the backward's sort and its per-ray pass
+                # all read it from the workspace
+                _capi.check(hp.lib.vamp_render_camera_terminate(
+                    C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(beta), _ptr(dens), _ptr(ws),
+                    ws.numel(), _stream(cur)), "vamp_render_camera_terminate")
+                fwd_flags |= _capi.VAMP_CAMFWD_TERM_VALID
+            ctx.ert = ert
+            if side is not None:
+                side.wait_stream(cur)
+                if train and geom is None and hp.impl["prepare"] and hp.impl["cam_bwd"] != "v1":
+                    # the sample -> cell-slot table of the backward depends on the geometry (and the
+                    # termination table) only: it is built here, on the side stream, beside the forward
+                    _capi.check(hp.lib.vamp_render_camera_prepare_ex(
+                        C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(),
+                        _capi.VAMP_CAMPREP_TERM_VALID if ert else 0, _stream(side)), "vamp_render_camera_prepare_ex")
+                    ctx.cells = True
+            # training: the BEV branch keeps its density / semantic / rgb samples for its backward
+            bev_save = train and hp.impl["bev_save"] and hp.impl["bev_bwd"] != "v1"
+            ws_bev = (hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d))) if bev_save else None)
+            _capi.check(hp.lib.vamp_render_bev_forward_ex(
+                C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
+                _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
+                _ptr(vdens), _ptr(vout), _ptr(ws_bev), ws_bev.numel() if bev_save else 0,
+                _capi.VAMP_BEVFWD_SAVE if bev_save else 0, _stream(side)), "vamp_render_bev_forward_ex")
+            hp._bev_gen = getattr(hp, "_bev_gen", 0) + 1
+            ctx.bev_key = (hp._bev_gen, ws_bev.data_ptr()) if bev_save else None
+            _capi.check(hp.lib.vamp_render_camera_forward_ex(
+                C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
+                _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
+                _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(),
+                fwd_flags | (_capi.VAMP_CAMFWD_SAVE_SAMPLES if save else 0), _stream(cur)),
+                "vamp_render_camera_forward_ex")
         ctx.samples = save
         if side is not None:
             cur.wait_stream(side)
