@@ -357,8 +357,9 @@ int vamp_render_bev_backward(const VampRenderDesc* d, const float* oxs, const fl
  */
 #define VAMP_BEVBWD_OVERWRITE_BASE 1   /* grad_base */
 #define VAMP_BEVBWD_OVERWRITE_CAM 2    /* grad_density_feature, grad_semantic, grad_rgb */
-#define VAMP_BEVBWD_ONLY_BASE 8         /* only the pass-through (grad_base) gather: it needs neither q nor the scan and nobody waits for it, so it can be a call of its own ... */
-#define VAMP_BEVBWD_SKIP_BASE 16        /* ... behind (or beside) the call that does everything else; give both calls the same OVERWRITE flags */
+#define VAMP_BEVBWD_SKIP_BASE 16        /* first half of a split pair: q, scan, the composited channels' gather (what the camera gather waits for) ... */
+#define VAMP_BEVBWD_ONLY_BASE 8         /* ... second half: the beta reduction and the pass-through (grad_base) gather, which nobody waits for; give both calls the same OVERWRITE flags, and issue both */
+#define VAMP_BEVBWD_TABLE_VALID 32      /* the workspace still holds the axis tables of an earlier call with the same grids (both halves write their own) */
 #define VAMP_BEVBWD_SAVED_VALID 4      /* the workspace holds what vamp_render_bev_forward_ex(.., VAMP_BEVFWD_SAVE) kept */
 int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const float* oys,
                              const float* ozs, const float* bev_mids, const float* beta,

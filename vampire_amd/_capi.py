@@ -63,7 +63,7 @@ VAMP_CAMPREP_TERM_VALID = 1
 VAMP_BEVBWD_OVERWRITE_BASE, VAMP_BEVBWD_OVERWRITE_CAM, VAMP_BEVBWD_SAVED_VALID = 1, 2, 4
 VAMP_BEVFWD_SAVE = 1
 VAMP_CAMFWD_PACK_ONLY, VAMP_CAMFWD_PACKED_VALID = 8, 16
-VAMP_BEVBWD_ONLY_BASE, VAMP_BEVBWD_SKIP_BASE = 8, 16
+VAMP_BEVBWD_ONLY_BASE, VAMP_BEVBWD_SKIP_BASE, VAMP_BEVBWD_TABLE_VALID = 8, 16, 32
 
 _P = C.c_void_p
 _LD = C.POINTER(VampLiftDesc)

@@ -1014,7 +1014,9 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
     if (d->in_dtype == VAMP_F32) VAMP_BEVB(float); else VAMP_BEVB(__hip_bfloat16);
   }
 #undef VAMP_BEVB
-  if (!only_base && d->density_mode == VAMP_DENSITY_SDF_LAPLACE)
+  // the beta partial sums of the scan are added up where nobody waits: in the second call of a split
+  // pair (ONLY_BASE; the first, SKIP_BASE, leaves them in the workspace), else right here
+  if (!skip_base && d->density_mode == VAMP_DENSITY_SDF_LAPLACE)
     if (int e = launch_beta_reduce(beta_part, (int) bev_scan_blocks(d), beta, grad_beta, s)) return e;
   // lattice points within one voxel's trilinear support, per axis
   bool fits = true;
@@ -1033,8 +1035,11 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
     VAMP_REQUIRE((size_t) d->B * (d->K > d->C ? d->K : d->C) * d->Z * d->Y * d->X < lim &&
                  (size_t) d->B * (d->C + d->K) * d->oZ * d->oY * d->oX < lim,
                  "tensor too large for the 32-bit offsets of the BEV gather");
-    VAMP_TIMED(kProfAux, s, (bev_axis_table_kernel<<<(tot_ax + 255) / 256, 256, 0, s>>>(P, oxs, oys, ozs, tab)));
-    if (int e = check_launch("bev_axis_table_kernel")) return e;
+    // the axis table depends on the grids only: a caller that kept the workspace says so
+    if (!(flags & VAMP_BEVBWD_TABLE_VALID)) {
+      VAMP_TIMED(kProfAux, s, (bev_axis_table_kernel<<<(tot_ax + 255) / 256, 256, 0, s>>>(P, oxs, oys, ozs, tab)));
+      if (int e = check_launch("bev_axis_table_kernel")) return e;
+    }
     const bool vo_sem = g_voxel_output && d->cat_seg;
     const int ow = (flags & VAMP_BEVBWD_OVERWRITE_BASE) ? 1 : 0;
     const int owc = (flags & VAMP_BEVBWD_OVERWRITE_CAM) ? 3 : 0;

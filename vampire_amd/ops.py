@@ -554,8 +554,15 @@ class _RenderFn(torch.autograd.Function):
         bev_saved = (ctx.bev_key is not None and hp.impl["bev_bwd"] != "v1"
                      and ctx.bev_key == (getattr(hp, "_bev_gen", 0), ws_bev.data_ptr()))
 
+        # the axis tables in the BEV workspace depend on the grids only (constants of this object):
+        # valid once both halves of a split pair have written theirs into this very buffer
+        tab_key = (ws_bev.data_ptr(), d.B)
+        tab_valid = hp.impl["bev_bwd"] != "v1" and getattr(hp, "_bev_tab_key", None) == tab_key
+
         def bev_backward(stream, overwrite_cam, part=0):
             flags = _capi.VAMP_BEVBWD_OVERWRITE_BASE | (_capi.VAMP_BEVBWD_OVERWRITE_CAM if overwrite_cam else 0) | part
+            if tab_valid and part:
+                flags |= _capi.VAMP_BEVBWD_TABLE_VALID
             if bev_saved:
                 flags |= _capi.VAMP_BEVBWD_SAVED_VALID
             _capi.check(hp.lib.vamp_render_bev_backward_ex(
@@ -594,6 +601,7 @@ class _RenderFn(torch.autograd.Function):
             done = torch.cuda.Event()
             done.record(side)
             bev_backward(side, True, _capi.VAMP_BEVBWD_ONLY_BASE)
+            hp._bev_tab_key = tab_key
             _capi.check(hp.lib.vamp_render_camera_backward_acc(
                 *cam_args, _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gbeta), _ptr(ws), ws.numel(), 1 | packed_valid,
                 C.c_void_p(done.cuda_event), _stream(cur)), "vamp_render_camera_backward_acc")
