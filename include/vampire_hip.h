@@ -290,6 +290,16 @@ int vamp_render_camera_prepare_ex(const VampRenderDesc* d, const float* mats, co
    `workspace`; without it the backward builds the table itself; NO_ERT = every sample */
 #define VAMP_CAMBWD_TERM_VALID 32
 #define VAMP_CAMBWD_NO_ERT 64
+/* Parts of the call, for a caller with two streams (none set = all three, in this order):
+ *   PART_RAY     the per-ray pass (and the channel-last copy / termination table / cell lists and
+ *                heavy list where the VALID flags do not promise them), d loss / d beta
+ *   PART_GATHER  the per-voxel gather (waits for wait_event first)
+ *   PART_HEAVY   the kernel that drains the heavy-voxel list; it owns other voxels than the gather,
+ *                so the two may run side by side once the ray pass is done
+ * Give every part the same VALID / ACCUMULATE flags. */
+#define VAMP_CAMBWD_PART_RAY 128
+#define VAMP_CAMBWD_PART_GATHER 256
+#define VAMP_CAMBWD_PART_HEAVY 512
 int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, const float* mats,
                                     const float* us, const float* vs, const float* ds,
                                     const float* mids, const float* beta,

@@ -22,7 +22,7 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
                       const float* g_seg, const float* g_depth, float* gdens, float* gsem,
                       float* grgb, float* grad_beta, void* scratch, int accumulate,
                       hipEvent_t wait_event, bool cells_valid, const float* samples, const int* term,
-                      hipStream_t s);
+                      int parts, hipStream_t s);
 int launch_cam_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                        const float* us, const float* vs, const float* ds, void* scratch,
                        const int* term, hipStream_t s);
@@ -402,11 +402,15 @@ int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, 
   float* packed = static_cast<float*>(workspace);
   float* gpacked = reinterpret_cast<float*>(static_cast<char*>(workspace) + pb);
   // the channel-last copy of the three volumes: the forward left it at the head of the workspace
-  if (!(flags & VAMP_CAMBWD_PACKED_VALID))
+  const bool part_ray = !(flags & (VAMP_CAMBWD_PART_GATHER | VAMP_CAMBWD_PART_HEAVY)) || (flags & VAMP_CAMBWD_PART_RAY);
+  if (!(flags & VAMP_CAMBWD_PACKED_VALID) && part_ray)
     if (int e = launch_pack(P, d->in_dtype, density_feature, semantic, rgb, packed, s)) return e;
   // Default: per-ray pass + cell-list gather (render_bwd_ray.hip, render_bwd_cell.hip), which
   // evaluates the frustum points itself from the matrices.  A caller-supplied geom tensor, or
   // VAMP_CAMBWD_SPLAT, takes the v1 float-atomic splat below (the independent cross-check).
+  int parts = ((flags & VAMP_CAMBWD_PART_RAY) ? kCamPartRay : 0) | ((flags & VAMP_CAMBWD_PART_GATHER) ? kCamPartGather : 0) |
+              ((flags & VAMP_CAMBWD_PART_HEAVY) ? kCamPartHeavy : 0);
+  if (parts == 0) parts = kCamPartAll;
   if (!geom && mats && !(flags & VAMP_CAMBWD_SPLAT)) {
     const float* samples = nullptr;
     if (flags & VAMP_CAMBWD_SAMPLES_VALID) {
@@ -420,7 +424,7 @@ int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, 
     int* term = nullptr;
     if (!(flags & VAMP_CAMBWD_NO_ERT)) {
       term = cam_term_ptr(d, workspace);
-      if (!(flags & VAMP_CAMBWD_TERM_VALID)) {
+      if (!(flags & VAMP_CAMBWD_TERM_VALID) && part_ray) {
         VAMP_REQUIRE(!(flags & VAMP_CAMBWD_CELLS_VALID), "CELLS_VALID with early termination needs TERM_VALID");
         if (int e = launch_cam_term(d, P, mats, us, vs, ds, beta, density_feature, term, s)) return e;
       }
@@ -428,7 +432,7 @@ int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, 
     return launch_cam_bwd_v2(d, P, mats, us, vs, ds, mids, beta, packed, g_rgb, g_seg, g_depth,
                              grad_density_feature, grad_semantic, grad_rgb, grad_beta, gpacked,
                              accumulate, static_cast<hipEvent_t>(wait_event),
-                             (flags & VAMP_CAMBWD_CELLS_VALID) != 0, samples, term, s);
+                             (flags & VAMP_CAMBWD_CELLS_VALID) != 0, samples, term, parts, s);
   }
   VAMP_REQUIRE(!accumulate && !wait_event, "accumulate / wait_event need the cell-list path");
   if (int ze = launch_zero(gpacked, pb, s)) return ze;

@@ -143,12 +143,12 @@ __global__ void __launch_bounds__(256)
 cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const int* __restrict__ boff,
                            const float4* __restrict__ R, const float* __restrict__ Gcl,
                            float* __restrict__ gdens, float* __restrict__ gsem,
-                           float* __restrict__ grgb, int* __restrict__ heavy,
-                           int* __restrict__ nheavy, long ncell_b, int runs_x, int heavy_thresh,
+                           float* __restrict__ grgb, long ncell_b, int runs_x, int heavy_thresh,
                            int accumulate) {
   constexpr int CP = CP4 * 4;
   constexpr int CVPB = 256 / CGL;
   __shared__ float outs[CP][CVPB + 1];
+  __shared__ int skip[CVPB];            // the voxel is on the heavy list: its outputs are not ours
   const int tid = threadIdx.x;
   const int g = tid / CGL, l = tid % CGL;
   // (giving each XCD a contiguous slab of x-runs instead of the round-robin deal measured 12 %
@@ -181,17 +181,15 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
     optr[i] = (e < nch * CVPB && bx * CVPB + gx < P.X) ? o + vox0 + gx : nullptr;
     prevv[i] = (accumulate && optr[i]) ? *optr[i] : 0.f;
   }
+  if (l == 0) skip[g] = vox_ok && cr.tot > heavy_thresh;
 
   float acc[CP];
 #pragma unroll
   for (int c = 0; c < CP; ++c) acc[c] = 0.f;
 
-  if (vox_ok && cr.tot > heavy_thresh) {
-    if (l == 0) {
-      const int q = atomicAdd(nheavy, 1);
-      heavy[q] = ((b * P.Z + iz) * P.Y + iy) * P.X + ix;
-    }
-  } else if (vox_ok) {
+  // (voxels with more records than the threshold are on the heavy list, built with the cell lists:
+  // cam_heavy_list_kernel; the whole-workgroup kernel owns their outputs and may run beside this one)
+  if (vox_ok && cr.tot <= heavy_thresh) {
     const float fix = (float) ix, fiy = (float) iy, fiz = (float) iz;
     constexpr int U = 1;              // U = 2 costs a wave of occupancy and measured slower
     for (int k = l; k < cr.tot; k += U * CGL)
@@ -212,7 +210,7 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
 #pragma unroll
   for (int i = 0; i < PE; ++i) {
     const int e = tid + i * 256;
-    if (optr[i]) *optr[i] = prevv[i] + outs[e / CVPB][e % CVPB];
+    if (optr[i] && !skip[e % CVPB]) *optr[i] = prevv[i] + outs[e / CVPB][e % CVPB];
   }
 }
 
@@ -309,6 +307,8 @@ const int* cam_cell_slots(const VampRenderDesc* d, void* scratch) { return cell_
 float4* cam_cell_records(const VampRenderDesc* d, void* scratch) { return cell_ws(d, scratch).R; }
 
 // rank -> scan -> slot.  Depends on (d, mats, us, vs, ds) only.
+static int launch_cam_heavy_list(const VampRenderDesc* d, const RenderParams& P, const CellWs& w, hipStream_t s);
+
 int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                              const float* us, const float* vs, const float* ds, void* scratch,
                              const int* term, hipStream_t s) {
@@ -327,23 +327,56 @@ int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, con
   if (int e = launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, ncell, s)) return e;
   VAMP_TIMED(kProfCamBwdFill, s, (cam_cells_slot_kernel<<<sgrid, 256, 0, s>>>(
       P, w.key, w.slot, w.off, w.boff, (unsigned) samples, ncell_b)));
-  return check_launch("cam_cells_slot_kernel");
+  if (int e = check_launch("cam_cells_slot_kernel")) return e;
+  return launch_cam_heavy_list(d, P, w, s);
+}
+
+// Heavy list: the voxels whose eight cells hold more than kHeavy records, known as soon as the
+// cells are scanned -- so the list belongs to the prepare pass, and the kernel that drains it can
+// run beside the gather instead of behind it.
+__global__ void __launch_bounds__(256)
+cam_heavy_list_kernel(RenderParams P, const int* __restrict__ off, const int* __restrict__ boff,
+                      int* __restrict__ heavy, int* __restrict__ nheavy, long ncell_b, long voxels,
+                      int thresh) {
+  const long v = (long) blockIdx.x * 256 + threadIdx.x;
+  if (v >= voxels) return;
+  const int ix = (int) (v % P.X), iy = (int) ((v / P.X) % P.Y), iz = (int) ((v / ((long) P.X * P.Y)) % P.Z);
+  const long b = v / ((long) P.X * P.Y * P.Z);
+  int tot = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long c = b * ncell_b + ((long) (iz + (r >> 1)) * (P.Y + 1) + (iy + (r & 1))) * (P.X + 1) + ix;
+    tot += (off[c + 2] + boff[(c + 2) / kScanTile]) - (off[c] + boff[c / kScanTile]);
+  }
+  if (tot > thresh) heavy[atomicAdd(nheavy, 1)] = (int) v;
+}
+
+static int launch_cam_heavy_list(const VampRenderDesc* d, const RenderParams& P, const CellWs& w, hipStream_t s) {
+  const long ncell = cell_count_padded(d->B, d->Z, d->Y, d->X);
+  const long ntile = ncell / kScanTile;
+  const long voxels = (long) d->B * d->Z * d->Y * d->X;
+  const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
+  int* nheavy = w.aux + ntile + 1;
+  if (int ze = launch_zero(nheavy, sizeof(int), s)) return ze;
+  VAMP_TIMED(kProfAux, s, (cam_heavy_list_kernel<<<(unsigned) ((voxels + 255) / 256), 256, 0, s>>>(
+      P, w.off, w.boff, w.heavy, nheavy, ncell_b, voxels, kHeavy)));
+  return check_launch("cam_heavy_list_kernel");
 }
 
 // per-voxel gather of the records the per-ray pass has written in cell order
 int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const float* Gcl,
                         float* gdens, float* gsem, float* grgb, void* scratch, int accumulate,
-                        hipEvent_t wait_event, hipStream_t s) {
+                        hipEvent_t wait_event, int parts, hipStream_t s) {
   const CellWs w = cell_ws(d, scratch);
   const long ncell = cell_count_padded(d->B, d->Z, d->Y, d->X);
   const long ntile = ncell / kScanTile;
   const size_t voxels = (size_t) d->B * d->Z * d->Y * d->X;
   const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
-  int* nheavy = w.aux + ntile + 1;
-  if (int ze = launch_zero(nheavy, sizeof(int), s)) return ze;
+  const int* nheavy = w.aux + ntile + 1;
 
   // measured at cfg-B (gather + heavy, us): 8 lanes 145 + 56, 16 lanes 173 + 56, 32 lanes 249 + 56;
-  // threshold 128 / 256 / 512 with 8 lanes: 131 + 107, 145 + 56, 159 + 40
+  // threshold 128 / 256 / 512 with 8 lanes: 131 + 107, 145 + 56, 159 + 40 (round 1); after early ray
+  // termination 68 + 37, 68 + 34, 91 + 33
   constexpr int gl = 8;
   const int heavy_thresh = kHeavy;
   const int vpb = 256 / gl;
@@ -356,19 +389,19 @@ int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const fl
   VAMP_REQUIRE(nblk < 0x7fffffffL, "too many x-runs");
   const unsigned grid = (unsigned) nblk;
   const unsigned hgrid = (unsigned) std::min<size_t>(voxels, 8192);
-#define VAMP_CELL_G(CP4, GLV)                                                                       \
-  VAMP_TIMED(kProfCamBwdBrick, s, (cam_bwd_cell_gather_kernel<CP4, GLV><<<grid, 256, 0, s>>>(       \
-      P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, w.heavy, nheavy, ncell_b, runs_x, heavy_thresh, \
-      accumulate)))
+  // the two kernels own disjoint voxels (the heavy list was built with the cell lists), so the
+  // caller may run them on two streams: parts selects
 #define VAMP_CELL(CP4)                                                                              \
   do {                                                                                              \
-    VAMP_CELL_G(CP4, gl);                                                                           \
-    VAMP_TIMED(kProfCamBwdOwn, s, (cam_bwd_cell_heavy_kernel<CP4><<<hgrid, 256, 0, s>>>(            \
-        P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, w.heavy, nheavy, ncell_b, accumulate)));     \
+    if (parts & kCamPartGather)                                                                     \
+      VAMP_TIMED(kProfCamBwdBrick, s, (cam_bwd_cell_gather_kernel<CP4, gl><<<grid, 256, 0, s>>>(    \
+          P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, ncell_b, runs_x, heavy_thresh, accumulate))); \
+    if (parts & kCamPartHeavy)                                                                      \
+      VAMP_TIMED(kProfCamBwdOwn, s, (cam_bwd_cell_heavy_kernel<CP4><<<hgrid, 256, 0, s>>>(          \
+          P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, w.heavy, nheavy, ncell_b, accumulate)));   \
   } while (0)
   if (P.CP == 12) VAMP_CELL(3); else if (P.CP == 24) VAMP_CELL(6); else VAMP_CELL(8);
 #undef VAMP_CELL
-#undef VAMP_CELL_G
   return check_launch("cam_bwd_cell_gather_kernel");
 }
 

@@ -214,7 +214,7 @@ int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, con
                              const int* term, hipStream_t s);
 int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const float* Gcl,
                         float* gdens, float* gsem, float* grgb, void* scratch, int accumulate,
-                        hipEvent_t wait_event, hipStream_t s);
+                        hipEvent_t wait_event, int parts, hipStream_t s);
 
 static size_t gcl_bytes(const VampRenderDesc* d) {
   const RenderParams P = to_params(d);
@@ -240,9 +240,11 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
                       const float* g_seg, const float* g_depth, float* gdens, float* gsem,
                       float* grgb, float* grad_beta, void* scratch, int accumulate,
                       hipEvent_t wait_event, bool cells_valid, const float* samples, const int* term,
-                      hipStream_t s) {
+                      int parts, hipStream_t s) {
   float* Gcl = static_cast<float*>(scratch);
   void* cell_scratch = static_cast<char*>(scratch) + gcl_bytes(d);
+  if (!(parts & kCamPartRay))
+    return launch_cam_bwd_cell(d, P, Gcl, gdens, gsem, grgb, cell_scratch, accumulate, wait_event, parts, s);
   // the sample -> slot table depends on the geometry only; the caller may have prepared it
   if (!cells_valid)
     if (int e = launch_cam_cells_prepare(d, P, mats, us, vs, ds, cell_scratch, term, s)) return e;
@@ -272,7 +274,8 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
   if (int e = check_launch("cam_bwd_ray_kernel")) return e;
   if (P.density_mode == VAMP_DENSITY_SDF_LAPLACE)
     if (int e = launch_beta_reduce(beta_part, (int) grid, beta, grad_beta, s)) return e;
-  return launch_cam_bwd_cell(d, P, Gcl, gdens, gsem, grgb, cell_scratch, accumulate, wait_event, s);
+  if (!(parts & (kCamPartGather | kCamPartHeavy))) return VAMP_OK;
+  return launch_cam_bwd_cell(d, P, Gcl, gdens, gsem, grgb, cell_scratch, accumulate, wait_event, parts, s);
 }
 
 }  // namespace vamp

@@ -261,4 +261,8 @@ __device__ __forceinline__ void gather_taps(const RenderParams& P, const float* 
   }
 }
 
+// parts of the camera backward a caller may issue separately (VAMP_CAMBWD_PART_*): the per-ray pass
+// (with the cell lists if they are not prepared), the per-voxel gather, the heavy-voxel kernel
+constexpr int kCamPartRay = 1, kCamPartGather = 2, kCamPartHeavy = 4, kCamPartAll = 7;
+
 }  // namespace vamp

@@ -99,6 +99,8 @@ class HotPath:
                      # and prepare pass on the side stream; "split" = table, copy and prepare pass on the
                      # side stream, BEV branch and march on the caller's
                      "sched": os.environ.get("VAMP_SCHED", "split"),
+                     # the heavy-voxel kernel of the camera backward on the side stream beside the gather
+                     "heavy_side": os.environ.get("VAMP_HEAVY_SIDE", "1") == "1",
                      # the BEV forward keeps its samples for the backward (+35 MB per sample at cfg-B)
                      "bev_save": os.environ.get("VAMP_BEV_SAVE", "1") == "1",
                      # store the forward's sample rows for the backward's per-ray pass: measured
@@ -602,9 +604,25 @@ class _RenderFn(torch.autograd.Function):
             done.record(side)
             bev_backward(side, True, _capi.VAMP_BEVBWD_ONLY_BASE)
             hp._bev_tab_key = tab_key
-            _capi.check(hp.lib.vamp_render_camera_backward_acc(
-                *cam_args, _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gbeta), _ptr(ws), ws.numel(), 1 | packed_valid,
-                C.c_void_p(done.cuda_event), _stream(cur)), "vamp_render_camera_backward_acc")
+            # The camera backward in three parts: ray pass here; then the gather here (after the BEV
+            # event) and, beside it on the side stream, the kernel that drains the heavy-voxel list --
+            # the two own different voxels (the list is built with the cell lists).
+            cam_flags = 1 | packed_valid
+
+            def cam_part(part, stream, event=None):
+                _capi.check(hp.lib.vamp_render_camera_backward_acc(
+                    *cam_args, _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gbeta), _ptr(ws), ws.numel(), cam_flags | part,
+                    event, _stream(stream)), "vamp_render_camera_backward_acc")
+
+            if hp.impl["heavy_side"]:
+                cam_part(_capi.VAMP_CAMBWD_PART_RAY, cur)
+                ray_done = torch.cuda.Event()
+                ray_done.record(cur)
+                side.wait_event(ray_done)
+                cam_part(_capi.VAMP_CAMBWD_PART_HEAVY, side)
+                cam_part(_capi.VAMP_CAMBWD_PART_GATHER, cur, C.c_void_p(done.cuda_event))
+            else:
+                cam_part(0, cur, C.c_void_p(done.cuda_event))
             cur.wait_stream(side)
         elif hp.impl["bev_first"] and geom is None and default_impl:
             bev_backward(cur, True)
