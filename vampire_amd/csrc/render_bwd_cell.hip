@@ -356,8 +356,7 @@ static int launch_cam_heavy_list(const VampRenderDesc* d, const RenderParams& P,
   const long ntile = ncell / kScanTile;
   const long voxels = (long) d->B * d->Z * d->Y * d->X;
   const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
-  int* nheavy = w.aux + ntile + 1;
-  if (int ze = launch_zero(nheavy, sizeof(int), s)) return ze;
+  int* nheavy = w.aux + ntile + 1;              // zeroed by the scan that just ran (runtime.hip)
   VAMP_TIMED(kProfAux, s, (cam_heavy_list_kernel<<<(unsigned) ((voxels + 255) / 256), 256, 0, s>>>(
       P, w.off, w.boff, w.heavy, nheavy, ncell_b, voxels, kHeavy)));
   return check_launch("cam_heavy_list_kernel");

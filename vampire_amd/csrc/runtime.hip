@@ -91,7 +91,9 @@ exclusive_scan_kernel(const int* __restrict__ cnt, int* __restrict__ off, int* _
     if (tid == 1023) carry = c0 + wbase + incl;
     __syncthreads();
   }
-  if (tid == 0) *total = carry;
+  // total[1] is the heavy-list counter of the cell-list users (aux[ntile + 1]): the list is built
+  // right after this scan, so it is zeroed here instead of by a launch of its own
+  if (tid == 0) { total[0] = carry; total[1] = 0; }
 }
 
 // Level 1 of the cell-list scan: exclusive scan inside each kScanTile-cell tile (256 threads x 8
