@@ -118,6 +118,8 @@ int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs
 #define VAMP_LIFTBWD_WPP1 4
 #define VAMP_LIFTBWD_WPP4 8
 #define VAMP_LIFTBWD_WPP16 16
+#define VAMP_LIFTBWD_HALF_LO 64   /* only the lower half of the flattened (sample, camera) images: with CELLS_VALID, ... */
+#define VAMP_LIFTBWD_HALF_HI 128  /* ... the two halves touch disjoint records and outputs and may run on two streams */
 #define VAMP_LIFTBWD_TILE 32     /* pixel-tile owners with LDS accumulators (lift_bwd_tile.hip); C <= 16 */
 int vamp_lift_prepare(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                       const float* zs, void* workspace, size_t workspace_bytes, void* stream);

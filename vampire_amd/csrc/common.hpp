@@ -62,7 +62,7 @@ int launch_exclusive_scan(const int* cnt, int* off, int* fill, int n, int* total
 int launch_zero(void* ptr, size_t bytes, hipStream_t s);
 int launch_beta_reduce(const float* part, int n, const float* beta_raw, float* grad_beta, hipStream_t s);
 constexpr int kScanTile = 2048;
-int launch_cell_scan(const int* cnt, int* off, int* bsum, int* boff, int* aux, long ncell,
+int launch_cell_scan(int* cnt, int* off, int* bsum, int* boff, int* aux, long ncell,
                      hipStream_t s);
 // usage: VAMP_TIMED(slot, stream, kernel<<<...>>>(...));
 #define VAMP_TIMED(slot, stream, launch)              \

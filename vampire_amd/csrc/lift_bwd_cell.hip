@@ -56,7 +56,7 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
                      const float* __restrict__ gout, const uint64_t* __restrict__ hits,
                      int* __restrict__ cnt, const int* __restrict__ off,
                      const int* __restrict__ boff, float4* __restrict__ entries, long cap,
-                     unsigned* __restrict__ amask) {
+                     unsigned* __restrict__ amask, int bn_lo, int bn_hi) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int x = blockIdx.x * 64 + lane;
   const int y = blockIdx.y * 4 + (tid >> 6);
@@ -86,7 +86,11 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
   unsigned vmask = 0xffffffffu, wmask = 0;
   if (FILL && amask) vmask = live ? amask[(long) b * V + vox] : 0u;
 
-  for (int n0 = 0; n0 < P.N; n0 += NB) {
+  // images [bn_lo, bn_hi) of the flattened (sample, camera) index: all of them, or one half when
+  // the caller runs two halves of the lift backward side by side (an image's records only meet
+  // that image's pixels)
+  const int n_lo = max(0, bn_lo - b * P.N), n_hi = min(P.N, bn_hi - b * P.N);
+  for (int n0 = n_lo; n0 < n_hi; n0 += NB) {
     int base[NB], start[NB];
     unsigned actm = 0;
 #pragma unroll
@@ -94,7 +98,7 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
       const int n = n0 + k;
       base[k] = 0;
       start[k] = lane;
-      if (n >= P.N) continue;                    // uniform
+      if (n >= n_hi) continue;                   // uniform
       if (FILL && !__any((vmask >> (n & 31)) & 1u)) continue;   // uniform: nobody in this wave sees camera n
       const long bn = (long) b * P.N + n;
       const LiftTap t = lift_project<true>(P, mats + bn * 48, vx, vy, vz);
@@ -113,7 +117,7 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
       const int n = n0 + k;
-      if (n >= P.N) continue;                    // uniform
+      if (n >= n_hi) continue;                   // uniform
       if (!__any((actm >> k) & 1u)) continue;    // uniform
       const int rb = __shfl(base[k], start[k], 64);
       if (!((actm >> k) & 1u)) continue;
@@ -185,7 +189,7 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
                             const T* __restrict__ feat,
                             const int* __restrict__ off, const int* __restrict__ boff,
                             const float4* __restrict__ entries, long cap,
-                            float* __restrict__ gdepth, float* __restrict__ gfeat) {
+                            float* __restrict__ gdepth, float* __restrict__ gfeat, long pix_lo, long pix_hi) {
   extern __shared__ float smem[];                // [ppb][Dp] depth columns, then [waves][16]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int C = P.C, D = P.use_depth ? P.D : 0;
@@ -196,10 +200,10 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
   float* gd = smem;
   float* accbuf = smem + ppb * Dp;
   const long HW = (long) P.fH * P.fW;
-  const long npix = (long) P.B * P.N * HW;
+  const long npix = pix_hi;                      // this launch owns pixels [pix_lo, pix_hi)
   // the workgroups of one image row run on one XCD: their 16-byte pieces of a depth plane's row
   // merge into whole lines in that L2
-  const long pid0 = (long) xcd_grouped(blockIdx.x, gridDim.x, xgroup) * ppb;
+  const long pid0 = pix_lo + (long) xcd_grouped(blockIdx.x, gridDim.x, xgroup) * ppb;
   const long pid = min(pid0 + pw, npix - 1);
   const bool pix_ok = pid0 + pw < npix;
   const long bn = pid / HW;
@@ -348,7 +352,7 @@ int launch_lift_cell_prepare(const VampLiftDesc* d, const float* mats, const flo
   if (int ze = launch_zero(w.cnt, (size_t) g.ncell * sizeof(int), s)) return ze;
   dim3 grid((d->X + 63) / 64, (d->Y + 3) / 4, d->Z * d->B);
   VAMP_TIMED(kProfLiftBwdCount, s, (lift_bwd_cell_kernel<float, 16, false><<<grid, 256, 0, s>>>(
-      P, g.cw, g.ch, mats, xs, ys, zs, nullptr, nullptr, nullptr, w.cnt, w.off, w.boff, w.entries, (long) cap, d->N <= 32 ? w.amask : nullptr)));
+      P, g.cw, g.ch, mats, xs, ys, zs, nullptr, nullptr, nullptr, w.cnt, w.off, w.boff, w.entries, (long) cap, d->N <= 32 ? w.amask : nullptr, 0, d->B * d->N)));
   if (int e = check_launch("lift_bwd_cell_kernel<count>")) return e;
   return launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, g.ncell, s);
 }
@@ -357,27 +361,33 @@ template <typename T>
 static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float* mats,
                          const float* xs, const float* ys, const float* zs, const void* depth,
                          const void* feat, const float* gout, const uint64_t* hits, float* gdepth,
-                         float* gfeat, void* scratch, bool cells_valid, int wpp_force, hipStream_t s) {
+                         float* gfeat, void* scratch, bool cells_valid, int wpp_force, int half,
+                         hipStream_t s) {
   const LiftCells g = lift_cells(d);
   const LiftCellWs w = lift_cell_ws(d, scratch);
   const size_t cap = (size_t) d->B * d->N * d->Z * d->Y * d->X;
   if (!cells_valid)
     if (int e = launch_lift_cell_prepare(d, mats, xs, ys, zs, scratch, s)) return e;
-  // the counters become the fill cursors
-  if (int ze = launch_zero(w.cnt, (size_t) g.ncell * sizeof(int), s)) return ze;
+  // (the counters are the fill cursors: the scan left them at zero)
+  // half 0: all images; 1 / 2: the lower / upper half of the flattened (sample, camera) index
+  const int BN = d->B * d->N;
+  const int bn_lo = half == 2 ? BN / 2 : 0, bn_hi = half == 1 ? BN / 2 : BN;
   dim3 grid((d->X + 63) / 64, (d->Y + 3) / 4, d->Z * d->B);
   const T* dp = static_cast<const T*>(depth);
 #define VAMP_CELL(CH)                                                                            \
   VAMP_TIMED(kProfLiftBwdFill, s, (lift_bwd_cell_kernel<T, CH, true><<<grid, 256, 0, s>>>(       \
       P, g.cw, g.ch, mats, xs, ys, zs, dp, gout, hits, w.cnt, w.off, w.boff, w.entries, (long) cap,     \
-      d->N <= 32 ? w.amask : nullptr)))
+      d->N <= 32 ? w.amask : nullptr, bn_lo, bn_hi)))
   if (P.C == 4) VAMP_CELL(4); else if (P.C == 8) VAMP_CELL(8); else VAMP_CELL(16);
 #undef VAMP_CELL
   if (int e = check_launch("lift_bwd_cell_kernel<fill>")) return e;
 
   // waves per pixel from the expected records per pixel (4 taps x voxels per camera pixel)
-  const long npix = (long) d->B * d->N * d->fH * d->fW;
-  const double per_pix = 4.0 * (double) d->B * d->Z * d->Y * d->X / (double) npix;
+  const long npix_all = (long) d->B * d->N * d->fH * d->fW;
+  const long pix_lo = (long) bn_lo * d->fH * d->fW, pix_hi = (long) bn_hi * d->fH * d->fW;
+  const long npix = pix_hi - pix_lo;
+  if (npix <= 0) return VAMP_OK;
+  const double per_pix = 4.0 * (double) d->B * d->Z * d->Y * d->X / (double) npix_all;
   int wpp = per_pix <= 96.0 ? 1 : (per_pix <= 768.0 ? 4 : 16);
   if (wpp_force == 1 || wpp_force == 4 || wpp_force == 16) wpp = wpp_force;
   const int nw = std::max(kMinWaves, wpp);
@@ -394,7 +404,7 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
       return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);
     VAMP_TIMED(kProfLiftBwd, s, (k<<<ggrid, nw * 64, lds, s>>>(
         P, g.cw, g.ch, wpp, (d->fW % ppb == 0) ? d->fW / ppb : 0, static_cast<const T*>(feat), w.off,
-        w.boff, w.entries, (long) cap, gdepth, gfeat)));
+        w.boff, w.entries, (long) cap, gdepth, gfeat, pix_lo, pix_hi)));
   }
   return check_launch("lift_bwd_cell_gather_kernel");
 }
@@ -402,13 +412,13 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
 int launch_lift_bwd_cell(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                          const float* zs, const void* depth, const void* feat, const float* gout,
                          const uint64_t* hits, float* gdepth, float* gfeat, void* scratch,
-                         bool cells_valid, int wpp_force, hipStream_t s) {
+                         bool cells_valid, int wpp_force, int half, hipStream_t s) {
   const LiftParams P = to_params(d);
   if (d->in_dtype == VAMP_F32)
     return launch_cell_t<float>(d, P, mats, xs, ys, zs, depth, feat, gout, hits, gdepth, gfeat, scratch,
-                                cells_valid, wpp_force, s);
+                                cells_valid, wpp_force, half, s);
   return launch_cell_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, feat, gout, hits, gdepth, gfeat,
-                                       scratch, cells_valid, wpp_force, s);
+                                       scratch, cells_valid, wpp_force, half, s);
 }
 
 }  // namespace vamp

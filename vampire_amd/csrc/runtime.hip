@@ -99,12 +99,16 @@ exclusive_scan_kernel(const int* __restrict__ cnt, int* __restrict__ off, int* _
 // Level 1 of the cell-list scan: exclusive scan inside each kScanTile-cell tile (256 threads x 8
 // cells), tile totals to bsum.
 __global__ void __launch_bounds__(256)
-cell_scan_tile_kernel(const int* __restrict__ cnt, int* __restrict__ off, int* __restrict__ bsum) {
+cell_scan_tile_kernel(int* __restrict__ cnt, int* __restrict__ off, int* __restrict__ bsum) {
   __shared__ int wsum[4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const long base = (long) blockIdx.x * kScanTile + tid * 8;
-  const int4* c4 = reinterpret_cast<const int4*>(cnt + base);
+  int4* c4 = reinterpret_cast<int4*>(cnt + base);
   const int4 a = c4[0], b = c4[1];
+  // the counters are spent: left at zero they are the fill cursors of the list's user (the lift
+  // backward hands out record slots with them), without a zero fill of their own
+  c4[0] = make_int4(0, 0, 0, 0);
+  c4[1] = make_int4(0, 0, 0, 0);
   const int v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
   int tsum = 0;
 #pragma unroll
@@ -134,7 +138,7 @@ cell_scan_tile_kernel(const int* __restrict__ cnt, int* __restrict__ off, int* _
   if (tid == 255) bsum[blockIdx.x] = run;
 }
 
-int launch_cell_scan(const int* cnt, int* off, int* bsum, int* boff, int* aux, long ncell,
+int launch_cell_scan(int* cnt, int* off, int* bsum, int* boff, int* aux, long ncell,
                      hipStream_t s) {
   const long ntile = ncell / kScanTile;
   if (ncell % kScanTile != 0 || ntile > 0x7fffffffL)

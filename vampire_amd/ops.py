@@ -101,6 +101,9 @@ class HotPath:
                      "sched": os.environ.get("VAMP_SCHED", "split"),
                      # the heavy-voxel kernel of the camera backward on the side stream beside the gather
                      "heavy_side": os.environ.get("VAMP_HEAVY_SIDE", "1") == "1",
+                     # the lift backward as two halves of the images on two streams: measured slower
+                     # (graph step 0.613 vs 0.582 ms: each half's fill still walks every voxel), so off
+                     "lift_halves": os.environ.get("VAMP_LIFT_HALVES", "0") == "1",
                      # the BEV forward keeps its samples for the backward (+35 MB per sample at cfg-B)
                      "bev_save": os.environ.get("VAMP_BEV_SAVE", "1") == "1",
                      # store the forward's sample rows for the backward's per-ray pass: measured
@@ -347,10 +350,23 @@ class _LiftFn(torch.autograd.Function):
             valid |= _capi.VAMP_LIFTBWD_TILE                 # falls through to the cell list where unsupported
         valid |= {1: _capi.VAMP_LIFTBWD_WPP1, 4: _capi.VAMP_LIFTBWD_WPP4,
                   16: _capi.VAMP_LIFTBWD_WPP16}.get(hp.impl["lift_wpp"], 0)
-        _capi.check(hp.lib.vamp_lift_backward_ex(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys), _ptr(hp.zs),
-                                                 _ptr(depth if use_depth else None), _ptr(feat), _ptr(g),
-                                                 _ptr(hits), _ptr(gdepth), _ptr(gfeat), _ptr(ws),
-                                                 ws.numel(), valid, _stream()), "vamp_lift_backward_ex")
+        def call(flags, stream):
+            _capi.check(hp.lib.vamp_lift_backward_ex(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys), _ptr(hp.zs),
+                                                     _ptr(depth if use_depth else None), _ptr(feat), _ptr(g),
+                                                     _ptr(hits), _ptr(gdepth), _ptr(gfeat), _ptr(ws),
+                                                     ws.numel(), flags, _stream(stream)), "vamp_lift_backward_ex")
+
+        side = hp._side_stream()
+        if side is not None and hp.impl["lift_bwd"] == "cell" and (valid & 1) and hp.impl["lift_halves"]:
+            # The two halves of the images (cameras 0-2 / 3-5 at batch 1) touch disjoint records and
+            # outputs: fill + gather of one half on the side stream beside the other half's.
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            call(valid | _capi.VAMP_LIFTBWD_HALF_HI, side)
+            call(valid | _capi.VAMP_LIFTBWD_HALF_LO, cur)
+            cur.wait_stream(side)
+        else:
+            call(valid, None)
         gd = gdepth.to(ctx.in_dtypes[0]) if use_depth else None
         return None, gd, gfeat.to(ctx.in_dtypes[1]), None, None, None
 
