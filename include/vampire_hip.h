@@ -276,6 +276,7 @@ int vamp_render_camera_prepare(const VampRenderDesc* d, const float* mats, const
 /* flags: VAMP_CAMPREP_TERM_VALID -- sort only the samples the early-termination table in
    `workspace` keeps (the backward must then be given VAMP_CAMBWD_TERM_VALID too) */
 #define VAMP_CAMPREP_TERM_VALID 1
+#define VAMP_CAMPREP_RANK_ONLY 2   /* stop after ranking and scanning the cells (what needs the termination table); the backward finishes (VAMP_CAMBWD_SLOTS_PENDING) */
 int vamp_render_camera_prepare_ex(const VampRenderDesc* d, const float* mats, const float* us,
                                   const float* vs, const float* ds, void* workspace,
                                   size_t workspace_bytes, int flags, void* stream);
@@ -299,6 +300,7 @@ int vamp_render_camera_prepare_ex(const VampRenderDesc* d, const float* mats, co
  *   PART_HEAVY   the kernel that drains the heavy-voxel list; it owns other voxels than the gather,
  *                so the two may run side by side once the ray pass is done
  * Give every part the same VALID / ACCUMULATE flags. */
+#define VAMP_CAMBWD_SLOTS_PENDING 1024  /* with CELLS_VALID: vamp_render_camera_prepare_ex ran with VAMP_CAMPREP_RANK_ONLY; the slot table and the heavy list are built here, in front of the ray pass */
 #define VAMP_CAMBWD_PART_RAY 128
 #define VAMP_CAMBWD_PART_GATHER 256
 #define VAMP_CAMBWD_PART_HEAVY 512

@@ -21,11 +21,11 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
                       const float* beta, const float* packed, const float* g_rgb,
                       const float* g_seg, const float* g_depth, float* gdens, float* gsem,
                       float* grgb, float* grad_beta, void* scratch, int accumulate,
-                      hipEvent_t wait_event, bool cells_valid, const float* samples, const int* term,
+                      hipEvent_t wait_event, int cells_valid, const float* samples, const int* term,
                       int parts, hipStream_t s);
 int launch_cam_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                        const float* us, const float* vs, const float* ds, void* scratch,
-                       const int* term, hipStream_t s);
+                       const int* term, int phase, hipStream_t s);
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
   // wave reduce then 4-wave LDS reduce; result valid in thread 0
@@ -361,7 +361,7 @@ int vamp_render_camera_prepare_ex(const VampRenderDesc* d, const float* mats, co
   const RenderParams P = to_params(d);
   return launch_cam_prepare(d, P, mats, us, vs, ds, static_cast<char*>(workspace) + packed_bytes(d),
                             (flags & VAMP_CAMPREP_TERM_VALID) ? cam_term_ptr(d, workspace) : nullptr,
-                            static_cast<hipStream_t>(stream));
+                            (flags & VAMP_CAMPREP_RANK_ONLY) ? 1 : 0, static_cast<hipStream_t>(stream));
 }
 
 int vamp_render_camera_backward(const VampRenderDesc* d, const float* geom, const float* mats,
@@ -432,7 +432,8 @@ int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, 
     return launch_cam_bwd_v2(d, P, mats, us, vs, ds, mids, beta, packed, g_rgb, g_seg, g_depth,
                              grad_density_feature, grad_semantic, grad_rgb, grad_beta, gpacked,
                              accumulate, static_cast<hipEvent_t>(wait_event),
-                             (flags & VAMP_CAMBWD_CELLS_VALID) != 0, samples, term, parts, s);
+                             (flags & VAMP_CAMBWD_CELLS_VALID) ? ((flags & VAMP_CAMBWD_SLOTS_PENDING) ? 2 : 1) : 0,
+                             samples, term, parts, s);
   }
   VAMP_REQUIRE(!accumulate && !wait_event, "accumulate / wait_event need the cell-list path");
   if (int ze = launch_zero(gpacked, pb, s)) return ze;

@@ -309,9 +309,11 @@ float4* cam_cell_records(const VampRenderDesc* d, void* scratch) { return cell_w
 // rank -> scan -> slot.  Depends on (d, mats, us, vs, ds) only.
 static int launch_cam_heavy_list(const VampRenderDesc* d, const RenderParams& P, const CellWs& w, hipStream_t s);
 
+// phase 0: everything; 1: rank + scan (what needs the geometry and the termination table);
+// 2: slots + heavy list (needs the scan only) -- a caller may leave phase 2 to the backward
 int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                              const float* us, const float* vs, const float* ds, void* scratch,
-                             const int* term, hipStream_t s) {
+                             const int* term, int phase, hipStream_t s) {
   const CellWs w = cell_ws(d, scratch);
   const long ncell = cell_count_padded(d->B, d->Z, d->Y, d->X);
   const size_t samples = (size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW;
@@ -319,12 +321,15 @@ int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, con
   VAMP_REQUIRE(samples > 0 && samples < 0x7fffffffu && voxels < 0x7fffffffu && ncell < 0x7fffffffL,
                "sample / voxel / cell count exceeds 2^31");
   const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
-  if (int ze = launch_zero(w.cnt, (size_t) ncell * sizeof(int), s)) return ze;
   const unsigned sgrid = (unsigned) ((samples + 255) / 256);
-  VAMP_TIMED(kProfCamBwdCount, s, (cam_cells_rank_kernel<<<sgrid, 256, 0, s>>>(
-      P, mats, us, vs, ds, w.cnt, w.key, w.slot, (unsigned) samples, ncell_b, term)));
-  if (int e = check_launch("cam_cells_rank_kernel")) return e;
-  if (int e = launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, ncell, s)) return e;
+  if (phase != 2) {
+    if (int ze = launch_zero(w.cnt, (size_t) ncell * sizeof(int), s)) return ze;
+    VAMP_TIMED(kProfCamBwdCount, s, (cam_cells_rank_kernel<<<sgrid, 256, 0, s>>>(
+        P, mats, us, vs, ds, w.cnt, w.key, w.slot, (unsigned) samples, ncell_b, term)));
+    if (int e = check_launch("cam_cells_rank_kernel")) return e;
+    if (int e = launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, ncell, s)) return e;
+  }
+  if (phase == 1) return VAMP_OK;
   VAMP_TIMED(kProfCamBwdFill, s, (cam_cells_slot_kernel<<<sgrid, 256, 0, s>>>(
       P, w.key, w.slot, w.off, w.boff, (unsigned) samples, ncell_b)));
   if (int e = check_launch("cam_cells_slot_kernel")) return e;

@@ -211,7 +211,7 @@ const int* cam_cell_slots(const VampRenderDesc* d, void* scratch);
 float4* cam_cell_records(const VampRenderDesc* d, void* scratch);
 int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                              const float* us, const float* vs, const float* ds, void* scratch,
-                             const int* term, hipStream_t s);
+                             const int* term, int phase, hipStream_t s);
 int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const float* Gcl,
                         float* gdens, float* gsem, float* grgb, void* scratch, int accumulate,
                         hipEvent_t wait_event, int parts, hipStream_t s);
@@ -230,8 +230,8 @@ size_t cam_bwd_v2_bytes(const VampRenderDesc* d) { return gcl_bytes(d) + cam_bwd
 // scratch = workspace region after the packed volume: [Gcl | cell lists | beta partials]
 int launch_cam_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                        const float* us, const float* vs, const float* ds, void* scratch,
-                       const int* term, hipStream_t s) {
-  return launch_cam_cells_prepare(d, P, mats, us, vs, ds, static_cast<char*>(scratch) + gcl_bytes(d), term, s);
+                       const int* term, int phase, hipStream_t s) {
+  return launch_cam_cells_prepare(d, P, mats, us, vs, ds, static_cast<char*>(scratch) + gcl_bytes(d), term, phase, s);
 }
 
 int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const float* mats,
@@ -239,15 +239,16 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
                       const float* beta, const float* packed, const float* g_rgb,
                       const float* g_seg, const float* g_depth, float* gdens, float* gsem,
                       float* grgb, float* grad_beta, void* scratch, int accumulate,
-                      hipEvent_t wait_event, bool cells_valid, const float* samples, const int* term,
+                      hipEvent_t wait_event, int cells_valid, const float* samples, const int* term,
                       int parts, hipStream_t s) {
   float* Gcl = static_cast<float*>(scratch);
   void* cell_scratch = static_cast<char*>(scratch) + gcl_bytes(d);
   if (!(parts & kCamPartRay))
     return launch_cam_bwd_cell(d, P, Gcl, gdens, gsem, grgb, cell_scratch, accumulate, wait_event, parts, s);
   // the sample -> slot table depends on the geometry only; the caller may have prepared it
-  if (!cells_valid)
-    if (int e = launch_cam_cells_prepare(d, P, mats, us, vs, ds, cell_scratch, term, s)) return e;
+  // (cells_valid 1), or its rank + scan half (2: the slots and the heavy list follow here)
+  if (cells_valid != 1)
+    if (int e = launch_cam_cells_prepare(d, P, mats, us, vs, ds, cell_scratch, term, cells_valid == 2 ? 2 : 0, s)) return e;
   const int* SLOT = cam_cell_slots(d, cell_scratch);
   float4* R = cam_cell_records(d, cell_scratch);
   float* beta_part = reinterpret_cast<float*>(static_cast<char*>(cell_scratch) + cam_bwd_cell_bytes(d));

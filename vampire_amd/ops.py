@@ -101,6 +101,10 @@ class HotPath:
                      "sched": os.environ.get("VAMP_SCHED", "split"),
                      # the heavy-voxel kernel of the camera backward on the side stream beside the gather
                      "heavy_side": os.environ.get("VAMP_HEAVY_SIDE", "1") == "1",
+                     # the slot table and heavy list of the camera backward in front of its ray pass
+                     # instead of at the end of the forward's prepare pass: measured slower (graph step
+                     # 0.588 vs 0.570 ms: the backward's chain is the tighter one), so off
+                     "slots_late": os.environ.get("VAMP_SLOTS_LATE", "0") == "1",
                      # the lift backward as two halves of the images on two streams: measured slower
                      # (graph step 0.613 vs 0.582 ms: each half's fill still walks every voxel), so off
                      "lift_halves": os.environ.get("VAMP_LIFT_HALVES", "0") == "1",
@@ -481,10 +485,15 @@ class _RenderFn(torch.autograd.Function):
                 fwd_flags | _capi.VAMP_CAMFWD_PACK_ONLY, _stream(side)), "vamp_render_camera_forward_ex")
             packed_done = torch.cuda.Event()
             packed_done.record(side)
+            # (only the rank + scan half of the prepare pass: the slot table and the heavy list need
+            # nothing but the scan and are built in front of the backward's ray pass, which has the
+            # slack; here they would lengthen the side stream's chain, the longer one of the forward)
+            late = hp.impl["slots_late"] and hp.impl["heavy_side"]
             _capi.check(hp.lib.vamp_render_camera_prepare_ex(
                 C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(),
-                _capi.VAMP_CAMPREP_TERM_VALID, _stream(side)), "vamp_render_camera_prepare_ex")
-            ctx.cells = True
+                _capi.VAMP_CAMPREP_TERM_VALID | (_capi.VAMP_CAMPREP_RANK_ONLY if late else 0), _stream(side)),
+                "vamp_render_camera_prepare_ex")
+            ctx.cells = 2 if late else True
             bev_save = train and hp.impl["bev_save"] and hp.impl["bev_bwd"] != "v1"
             ws_bev = (hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d))) if bev_save else None)
             _capi.check(hp.lib.vamp_render_bev_forward_ex(
@@ -598,6 +607,8 @@ class _RenderFn(torch.autograd.Function):
         packed_valid = 2 if ctx.pack_key == (getattr(hp, "_pack_gen", 0), ws.data_ptr()) else 0
         if packed_valid and ctx.cells:
             packed_valid |= 4                                    # VAMP_CAMBWD_CELLS_VALID
+            if ctx.cells == 2:
+                packed_valid |= _capi.VAMP_CAMBWD_SLOTS_PENDING
         if packed_valid and ctx.samples and default_impl:
             packed_valid |= _capi.VAMP_CAMBWD_SAMPLES_VALID
         if not ctx.ert:
@@ -605,7 +616,7 @@ class _RenderFn(torch.autograd.Function):
         elif packed_valid:
             packed_valid |= _capi.VAMP_CAMBWD_TERM_VALID           # same validity as the packed copy
         else:
-            packed_valid &= ~4                                      # no table: the cells are rebuilt with a fresh one
+            packed_valid &= ~(4 | _capi.VAMP_CAMBWD_SLOTS_PENDING)  # no table: the cells are rebuilt with a fresh one
         hp._pack_gen = getattr(hp, "_pack_gen", 0) + 1          # the backward scribbles after the copy only,
         ctx.pack_key = None                                     # but a second backward must not assume so
         if side is not None and geom is None and default_impl:
