@@ -163,6 +163,10 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
   const int nch = 1 + P.K + 3;
   const int ixc = min(ix, P.X - 1);
   const CellRanges cr = cell_ranges<CGL>(P.Y, P.X, off, boff, ncell_b, b, ixc, iy, iz, l);
+  // An x-run none of whose voxels has a record for this kernel (nothing sampled there: behind a
+  // terminated ray, outside every frustum -- or all on the heavy list) has nothing to add: when the
+  // buffers already hold the BEV branch's gradient the workgroup is done before it touches them.
+  if (accumulate && !__syncthreads_or(vox_ok && cr.tot > 0 && cr.tot <= heavy_thresh)) return;
 
   // output elements this thread stores at the end; with accumulate their current values (the
   // BEV branch's gradient) are fetched now, so that the load overlaps the record streaming
