@@ -68,6 +68,17 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
   const long vox = ((long) z * P.Y + yc) * P.X + xc;
   const long HW = (long) P.fH * P.fW;
 
+  // camera mask of the voxel: written by the count pass, read by the fill pass, which then
+  // projects only the cameras some lane of the wave is valid for (1-3 of 6) instead of all -- and
+  // leaves at once when no voxel of the wave is seen by any camera (the half-split's images)
+  unsigned vmask = 0xffffffffu, wmask = 0;
+  if (FILL && amask) {
+    vmask = live ? amask[(long) b * V + vox] : 0u;
+    const int lo = max(0, bn_lo - b * P.N), hi = min(P.N, bn_hi - b * P.N);
+    const unsigned range = hi > lo ? ((hi - lo >= 32 ? 0xffffffffu : ((1u << (hi - lo)) - 1u)) << lo) : 0u;
+    if (!__any((vmask & range) != 0u)) return;
+  }
+
   constexpr int NB = 8;                          // cameras per batch: their atomics are in flight together
   const bool first_chunk_only = P.C == CH;
   // grad_out / (hit count + 1e-6), the camera-mean factor of bv2:512-514: the same for every
@@ -80,11 +91,6 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
     for (int k = 0; k < CH; ++k)
       gs0[k] = (live ? g[(long) k * V] : 0.f) * __builtin_amdgcn_rcpf((float) ((hw >> (4 * k)) & 15) + 1e-6f);   // 1 ulp: gradients are held to 1e-4
   }
-
-  // camera mask of the voxel: written by the count pass, read by the fill pass, which then
-  // projects only the cameras some lane of the wave is valid for (1-3 of 6) instead of all
-  unsigned vmask = 0xffffffffu, wmask = 0;
-  if (FILL && amask) vmask = live ? amask[(long) b * V + vox] : 0u;
 
   // images [bn_lo, bn_hi) of the flattened (sample, camera) index: all of them, or one half when
   // the caller runs two halves of the lift backward side by side (an image's records only meet
