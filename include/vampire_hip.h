@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VAMP_ABI_VERSION 1
+#define VAMP_ABI_VERSION 3   /* bumped whenever entry points or flags are added (round 2: 2, round 3: 3) */
 
 enum {
   VAMP_OK = 0,
@@ -228,6 +228,10 @@ int vamp_render_camera_terminate(const VampRenderDesc* d, const float* mats, con
                                  const void* density_feature, void* workspace, size_t workspace_bytes,
                                  void* stream);
 size_t vamp_render_samples_bytes(const VampRenderDesc* d);
+/* Byte offset of that table inside `workspace`: int32 [B, N, fH, fW], the number of leading
+ * samples each ray keeps (D - 1 = nothing dropped).  For callers that report how much of the
+ * march early ray termination removed (bench.py). */
+size_t vamp_render_term_offset(const VampRenderDesc* d);
 int vamp_render_camera_forward_ex(const VampRenderDesc* d, const float* geom, const float* mats,
                                   const float* us, const float* vs, const float* ds,
                                   const float* mids, const float* beta,

@@ -38,6 +38,15 @@ Fixtures
   cfgd_checksums.json  cfg-D (512x1408 image, 400x400x32 grid) with bf16-rounded inputs: sha256
                        of the lift / render tap indices and masks, forward statistics, block
                        sums and probes of the lift output and the eight render outputs
+  regime_checksums.json
+                       the renderer at cfg-B in the two density regimes the sdf / synthetic
+                       fixtures do not reach (`make_regimes`): density_mode="naive" (sigmoid;
+                       out-of-volume samples carry density(0) = 0.5, so rays saturate BEHIND the
+                       volume -- the analytic exit of the early-ray-termination table), the
+                       reference's INITIAL regime (density_conv.bias = sdf_bias - 10, bv2:241:
+                       density_feature ~ -11, sigma = 1 / beta: every ray saturates at once) and an
+                       EMPTY scene (density_feature ~ +2: nothing terminates); forward block statistics of
+                       the eight outputs and, with autograd, of the four volume gradients + grad_beta
 """
 import hashlib
 import json
@@ -396,6 +405,49 @@ def make_cfg_d(BaseVAMPIRE2):
     print("cfg D done: valid", entry["lift_valid_count"], "inside", entry["render_inside_count"])
 
 
+def make_regimes(BaseVAMPIRE2):
+    """cfg-B, B=1, the reference's renderer with autograd in two more density regimes:
+      "naive"  density_mode="naive" on the synthetic volumes (bv2:191-194; Q6: masked samples carry
+               sigmoid(0) = 0.5, so the optical depth keeps growing behind the volume),
+      "init"   density_mode="sdf" with density_feature = 0.5 * randn + (sdf_bias - 10), the value
+               range density_conv produces at initialisation (bv2:241): s - bias ~ -10, so sigma
+               = 1 / beta = 10 everywhere and every ray saturates within its first three inside
+               samples (the regime in which termination cuts the most),
+      "empty"  density_mode="sdf" with density_feature = 0.5 * randn + (sdf_bias + 3): s - bias ~ +3,
+               sigma ~ 5 exp(-30): free space everywhere, no ray ever saturates and every sample
+               is marched (the regime in which termination cuts nothing)."""
+    from vampire_amd.config import CFG_B as cfg
+    from vampire_amd import synthetic
+    res = {}
+    s2e, K, ida = synthetic.camera_rig(cfg, 1)
+    bda = synthetic.bda_matrix(1)
+    for regime, mode in (("naive", "naive"), ("init", "sdf"), ("empty", "sdf")):
+        m = ref_module(BaseVAMPIRE2, cfg, mode, False)
+        vols = list(synthetic.render_inputs(cfg, 1, seed=0))
+        entry = {"density_mode": mode, "seed_render": 4545, "density_shift": 0.0}
+        if regime in ("init", "empty"):
+            entry["density_shift"] = -10.0 if regime == "init" else 3.0
+            vols[0] = vols[0] + entry["density_shift"]                      # init: -1 - 10 = sdf_bias - 10
+        with torch.no_grad():
+            geom = torch.nan_to_num(m.get_geometry(s2e, K, ida, bda), -1e3)        # bv2:612
+        v_ = [t.clone().requires_grad_(True) for t in vols]
+        r = m.volume_rendering_from_multiple_views(geom, *v_)
+        for n_, t in zip(RENDER_NAMES, r):
+            entry[n_] = block_stat(t)
+        g_r = upstream_grads([t.shape for t in r], entry["seed_render"])
+        torch.autograd.backward(r, g_r)
+        for n_, t in zip(["density_feature", "semantic_logits", "base", "rgb"], v_):
+            entry["grad_" + n_] = block_stat(t.grad)
+        if mode == "sdf":
+            entry["beta"] = float(m.density.beta.detach())
+            entry["grad_beta"] = float(m.density.beta.grad)
+        res[regime] = entry
+        print("regime", regime, "done; depth mean", float(r[2].mean()), flush=True)
+        del r, v_, g_r, geom
+    with open(os.path.join(HERE, "regime_checksums.json"), "w") as f:
+        json.dump(res, f)
+
+
 def make_points(BaseVAMPIRE2):
     """SURVEY 8f N1.  bv2:576-609 is inline in _forward_single_sweep; the statements are replayed
     on the reference module's own state (occ_coords, density, bounds)."""
@@ -532,6 +584,9 @@ if __name__ == "__main__":
     if "--cfgd-only" in sys.argv:
         make_cfg_d(V2)
         sys.exit(0)
+    if "--regimes-only" in sys.argv:
+        make_regimes(V2)
+        sys.exit(0)
     make_tiny(V2, BL)
     make_glue(V2)
     make_hourglass(V2)
@@ -540,3 +595,4 @@ if __name__ == "__main__":
         make_full(V2)
         make_full_grads(V2)
         make_cfg_d(V2)
+        make_regimes(V2)

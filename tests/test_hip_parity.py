@@ -1223,3 +1223,75 @@ def test_saved_sample_rows_equal_regather(tiny_common, dev, cfg, batch):
     if bool(torch.isfinite(b0)):      # (the BEV branch has no nan_to_num: with nan voxels its d beta is nan either way)
         close(b1.reshape(1), b0.reshape(1), atol=1e-6, rtol=1e-5, what="saved rows vs re-gather: grad_beta")
     hp.impl["save_samples"] = False
+
+
+# --------------------------------------------------------------------------- round-3 parity pins: early ray termination
+def _regime_inputs(cfg, regime, dev, with_grad=True):
+    """The render inputs of tests/golden/make_golden.py: make_regimes ("sdf" = the bench workload)."""
+    mode = "naive" if regime == "naive" else "sdf"
+    cfg = dataclasses.replace(cfg, density_mode=mode)
+    vols = list(synthetic.render_inputs(cfg, 1, seed=0, device=dev))
+    if regime in ("init", "empty"):
+        # init: sdf_bias - 10 = density_conv's initial bias (bv2:241), sigma = 1 / beta everywhere;
+        # empty: s - bias ~ +3, sigma ~ 0, no ray ever saturates
+        vols[0] = vols[0] + (-10.0 if regime == "init" else 3.0)
+    if with_grad:
+        vols = [v.detach().requires_grad_(True) for v in vols]
+    return cfg, vols
+
+
+def _render_fwd_bwd(cfg, vols, rm, dev, ert, seed, beta_value=0.1):
+    hp = hot(cfg, dev)
+    hp.impl["ert"] = ert
+    for v in vols:
+        v.grad = None
+    beta = torch.tensor(beta_value, device=dev, requires_grad=(cfg.density_mode == "sdf"))
+    outs = hp.render(*vols, beta if cfg.density_mode == "sdf" else None, render_mats=rm)
+    torch.autograd.backward(outs, _upstream([o.shape for o in outs], seed, dev))
+    grads = [v.grad.clone() for v in vols]
+    return [o.detach().clone() for o in outs], grads, (beta.grad.clone() if beta.grad is not None else None)
+
+
+@pytest.mark.parametrize("regime", ["sdf", "naive", "init", "empty"])
+def test_ert_on_equals_off_full_size(dev, regime):
+    """Early ray termination (render_common.hpp) against the same kernels with it switched off, on
+    identical cfg-B inputs, in the three density regimes: the synthetic sdf workload (64 % of the
+    inside samples dropped), density_mode="naive" (rays saturate behind the volume: the analytic
+    exit of cam_term_kernel), the reference's initial regime (sigma = 1 / beta: every ray saturates
+    within three samples) and an empty scene (nothing terminates).  All 8
+    outputs within 1e-6, all gradients within 1e-5 of the tensor's largest magnitude."""
+    with open(os.path.join(GOLDEN, "full_checksums.json")) as f:
+        rm = torch.tensor(json.load(f)["B"]["render_mats"], dtype=torch.float32, device=dev)
+    cfg, vols = _regime_inputs(CFG_B, regime, dev)
+    on = _render_fwd_bwd(cfg, vols, rm, dev, True, 4545)
+    off = _render_fwd_bwd(cfg, vols, rm, dev, False, 4545)
+    for nm, a, b in zip(NAMES, on[0], off[0]):
+        close(a, b, atol=1e-6, rtol=1e-6, what=f"{regime} ERT on/off {nm}")
+    for nm, a, b in zip(("density_feature", "semantic_logits", "base", "rgb"), on[1], off[1]):
+        close(a, b, atol=1e-12, rtol=1e-5, scale="max", what=f"{regime} ERT on/off grad_{nm}")
+    if on[2] is not None:
+        assert abs(float(on[2]) - float(off[2])) <= 1e-5 * abs(float(off[2])) + 1e-9, (float(on[2]), float(off[2]))
+
+
+@pytest.mark.parametrize("ert", [True, False], ids=["ert", "no-ert"])
+@pytest.mark.parametrize("regime", ["naive", "init", "empty"])
+def test_density_regimes_match_reference(dev, regime, ert):
+    """cfg-B in the regimes of tests/golden/regime_checksums.json (the REFERENCE run with autograd):
+    sigmoid density -- where the analytic exit of the termination table fires --, the reference's
+    initial density regime (everything saturates) and an empty scene (nothing does), with early ray
+    termination on and off: block statistics of
+    the eight outputs, of the four volume gradients and grad_beta."""
+    with open(os.path.join(GOLDEN, "regime_checksums.json")) as f:
+        ref = json.load(f)[regime]
+    with open(os.path.join(GOLDEN, "full_checksums.json")) as f:
+        rm = torch.tensor(json.load(f)["B"]["render_mats"], dtype=torch.float32, device=dev)
+    cfg, vols = _regime_inputs(CFG_B, regime, dev)
+    assert cfg.density_mode == ref["density_mode"]
+    outs, grads, gbeta = _render_fwd_bwd(cfg, vols, rm, dev, ert, ref["seed_render"],
+                                         beta_value=ref.get("beta", 0.1))
+    for nm, o in zip(NAMES, outs):
+        _block_check(o, ref[nm], f"{regime} {nm}", rtol=5e-5)
+    for k, g in zip(("density_feature", "semantic_logits", "base", "rgb"), grads):
+        _block_check(g, ref["grad_" + k], f"{regime} grad_{k}", rtol=5e-5)
+    if "grad_beta" in ref:
+        assert abs(float(gbeta) - ref["grad_beta"]) <= 2e-3 * abs(ref["grad_beta"]) + 1e-4, (float(gbeta), ref["grad_beta"])

@@ -185,3 +185,37 @@ def test_hourglass_and_resize_oracle():
         torch.testing.assert_close(r, g[f"rs{i}_out"], rtol=0, atol=0)
         r.backward(g[f"rs{i}_g"])
         torch.testing.assert_close(a.grad, g[f"rs{i}_grad"], rtol=1e-6, atol=1e-6)
+
+
+def test_oracle_density_regimes_full_size():
+    """The oracle's renderer at cfg-B against the REFERENCE's outputs in the regimes of
+    tests/golden/regime_checksums.json (make_golden.py: make_regimes), forward only (the backward of
+    one regime takes a minute on 8 cores): whole-tensor statistics of the eight outputs for the
+    sigmoid density and for the reference's initial sdf regime."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from vampire_amd.config import CFG_B
+    from vampire_amd import synthetic
+    with open(os.path.join(GOLDEN, "regime_checksums.json")) as f:
+        ref = json.load(f)
+    with open(os.path.join(GOLDEN, "full_checksums.json")) as f:
+        rm = torch.tensor(json.load(f)["B"]["render_mats"], dtype=torch.float32)
+    for regime in ("naive", "init"):
+        cfg = dataclasses.replace(CFG_B, density_mode=ref[regime]["density_mode"])
+        geo = PathGeometry(cfg)
+        vols = list(synthetic.render_inputs(cfg, 1, seed=0))
+        vols[0] = vols[0] + ref[regime]["density_shift"]
+        with torch.no_grad():
+            geom = torch.nan_to_num(O.frustum_to_ego(geo.frustum, None, None, None, None, rm), -1e3)
+            outs = O.render(geom, *vols, seg_bounds=(cfg.x_bound_seg, cfg.y_bound_seg, cfg.z_bound_seg),
+                            output_coords=geo.output_coords, camera_mids=geo.camera_mids, bev_mids=geo.bev_mids,
+                            d_far=cfg.d_bound[1], z_step_det=cfg.z_bound_det[2], num_classes=cfg.num_classes,
+                            density_mode=cfg.density_mode, beta_param=torch.tensor(ref[regime].get("beta", 0.1)),
+                            sdf_bias=cfg.sdf_bias, cat_seg=False)
+        for name, o in zip(NAMES, outs):
+            st = ref[regime][name]
+            assert list(o.shape) == st["shape"], (regime, name)
+            tot = float(o.double().abs().sum())
+            assert abs(tot - st["abs_sum"]) <= 1e-6 * st["abs_sum"] + 1e-6, (regime, name, tot, st["abs_sum"])
+            assert abs(float(o.max()) - st["max"]) <= 1e-6 * max(1.0, abs(st["max"])), (regime, name)

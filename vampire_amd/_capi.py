@@ -9,7 +9,7 @@ import os
 
 from .build import lib_path
 
-ABI_VERSION = 1
+ABI_VERSION = 3
 
 VAMP_F32, VAMP_BF16 = 0, 1
 VAMP_DENSITY_SIGMOID, VAMP_DENSITY_SDF_LAPLACE = 0, 1
@@ -94,6 +94,7 @@ SIGNATURES = {
     "vamp_render_workspace_bytes": (C.c_size_t, [_RD]),
     "vamp_render_camera_forward": (C.c_int, [_RD] + [_P] * 13 + [_P, C.c_size_t, _P]),
     "vamp_render_samples_bytes": (C.c_size_t, [_RD]),
+    "vamp_render_term_offset": (C.c_size_t, [_RD]),
     "vamp_render_camera_terminate": (C.c_int, [_RD] + [_P] * 6 + [_P, C.c_size_t, _P]),
     "vamp_render_camera_prepare_ex": (C.c_int, [_RD] + [_P] * 4 + [_P, C.c_size_t, C.c_int, _P]),
     "vamp_render_camera_forward_ex": (C.c_int, [_RD] + [_P] * 13 + [_P, C.c_size_t, C.c_int, _P]),

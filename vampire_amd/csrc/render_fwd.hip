@@ -525,6 +525,8 @@ int vamp_render_camera_terminate(const VampRenderDesc* d, const float* mats, con
                          static_cast<hipStream_t>(stream));
 }
 
+size_t vamp_render_term_offset(const VampRenderDesc* d) { return d ? render_base_bytes(d) : 0; }
+
 size_t vamp_render_samples_bytes(const VampRenderDesc* d) {
   if (!d) return 0;
   const RenderParams P = to_params(d);

@@ -237,6 +237,28 @@ class HotPath:
             return _RenderFn.apply(self, density_feature, semantic_logits, base, rgb, beta, geom,
                                    render_mats, torch.is_grad_enabled())
 
+    def ert_statistics(self, density_feature, beta, render_mats):
+        """What early ray termination removes on these inputs: (inside samples, inside samples the
+        per-ray table keeps).  Diagnostic for bench.py (the gain is data-dependent); one termination
+        pre-pass + the index kernel, a host sync."""
+        c = self.cfg
+        B, N = render_mats.shape[:2]
+        dens = _chk(_accept(density_feature), (B, 1, c.vZ, c.vY, c.vX), "density_feature")
+        d = self.render_desc(B, N, _dtype_code(dens))
+        mats = _chk(render_mats.float(), (B, N, 3, 4, 4), "render_mats")
+        beta = (torch.zeros(1, device=self.device) if beta is None else beta.detach().reshape(1).float().contiguous())
+        ws = self._workspace("render", self.lib.vamp_render_workspace_bytes(C.byref(d)))
+        with torch.cuda.device(self.device):
+            _capi.check(self.lib.vamp_render_camera_terminate(
+                C.byref(d), _ptr(mats), _ptr(self.us), _ptr(self.vs), _ptr(self.ds), _ptr(beta), _ptr(dens),
+                _ptr(ws), ws.numel(), _stream()), "vamp_render_camera_terminate")
+            off = self.lib.vamp_render_term_offset(C.byref(d))
+            term = ws[off:off + 4 * B * N * c.fH * c.fW].view(torch.int32).reshape(B, N, 1, c.fH, c.fW).clone()
+            inside = self.render_indices(render_mats=mats)[0].bool()
+        idx = torch.arange(c.D - 1, device=self.device).reshape(1, 1, -1, 1, 1)
+        self._pack_gen = getattr(self, "_pack_gen", 0) + 1      # the workspace no longer matches a saved forward
+        return int(inside.sum()), int((inside & (idx < term)).sum())
+
     # ------------------------------------------------------ point resampling
     def sample_points(self, volume, points, *, padding="zeros", mask_outside=False, activation=False,
                       beta=None, channel_last=False, lattice=None):
