@@ -413,9 +413,12 @@ def make_regimes(BaseVAMPIRE2):
                range density_conv produces at initialisation (bv2:241): s - bias ~ -10, so sigma
                = 1 / beta = 10 everywhere and every ray saturates within its first three inside
                samples (the regime in which termination cuts the most),
-      "empty"  density_mode="sdf" with density_feature = 0.5 * randn + (sdf_bias + 3): s - bias ~ +3,
-               sigma ~ 5 exp(-30): free space everywhere, no ray ever saturates and every sample
-               is marched (the regime in which termination cuts nothing)."""
+      "empty"  density_mode="sdf" with density_feature = 0.4 * (0.5 * randn - 1) = 0.2 * randn - 0.4:
+               s - bias ~ +0.6, sigma ~ 5 exp(-6) = 0.012 per metre: thin haze everywhere, a ray
+               collects an optical depth of ~0.5, none ever saturates and every sample is marched
+               (the regime in which termination cuts nothing; chosen so that 1 + expm1(-|t| / beta)
+               stays well above the rounding of expm1 -- with s - bias = 3 the reference's sigma is
+               the last bit of expm1f and CPU / GPU libm disagree by factors of two)."""
     from vampire_amd.config import CFG_B as cfg
     from vampire_amd import synthetic
     res = {}
@@ -424,10 +427,12 @@ def make_regimes(BaseVAMPIRE2):
     for regime, mode in (("naive", "naive"), ("init", "sdf"), ("empty", "sdf")):
         m = ref_module(BaseVAMPIRE2, cfg, mode, False)
         vols = list(synthetic.render_inputs(cfg, 1, seed=0))
-        entry = {"density_mode": mode, "seed_render": 4545, "density_shift": 0.0}
-        if regime in ("init", "empty"):
-            entry["density_shift"] = -10.0 if regime == "init" else 3.0
-            vols[0] = vols[0] + entry["density_shift"]                      # init: -1 - 10 = sdf_bias - 10
+        entry = {"density_mode": mode, "seed_render": 4545, "density_shift": 0.0, "density_scale": 1.0}
+        if regime == "init":
+            entry["density_shift"] = -10.0                                  # -1 - 10 = sdf_bias - 10
+        elif regime == "empty":
+            entry["density_scale"] = 0.4
+        vols[0] = vols[0] * entry["density_scale"] + entry["density_shift"]
         with torch.no_grad():
             geom = torch.nan_to_num(m.get_geometry(s2e, K, ida, bda), -1e3)        # bv2:612
         v_ = [t.clone().requires_grad_(True) for t in vols]

@@ -205,7 +205,7 @@ def test_oracle_density_regimes_full_size():
         cfg = dataclasses.replace(CFG_B, density_mode=ref[regime]["density_mode"])
         geo = PathGeometry(cfg)
         vols = list(synthetic.render_inputs(cfg, 1, seed=0))
-        vols[0] = vols[0] + ref[regime]["density_shift"]
+        vols[0] = vols[0] * ref[regime]["density_scale"] + ref[regime]["density_shift"]
         with torch.no_grad():
             geom = torch.nan_to_num(O.frustum_to_ego(geo.frustum, None, None, None, None, rm), -1e3)
             outs = O.render(geom, *vols, seg_bounds=(cfg.x_bound_seg, cfg.y_bound_seg, cfg.z_bound_seg),
