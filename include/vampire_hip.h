@@ -223,6 +223,11 @@ int vamp_render_camera_forward(const VampRenderDesc* d, const float* geom, const
 #define VAMP_CAMFWD_TERM_VALID 4
 #define VAMP_CAMFWD_PACK_ONLY 8      /* only the channel-last copy of (density, semantic, rgb) into the workspace */
 #define VAMP_CAMFWD_PACKED_VALID 16   /* the workspace already holds that copy: march only */
+/* geom == NULL only: the whole camera branch as ONE kernel that reads the channel-first volumes
+ * directly (render_cam_direct.hip) -- no channel-last copy, no separate termination pass; the
+ * per-ray table is written into `workspace` as a by-product when workspace_bytes >=
+ * vamp_render_workspace_bytes(d) (workspace may be NULL otherwise).  Combines with NO_ERT. */
+#define VAMP_CAMFWD_DIRECT 32
 int vamp_render_camera_terminate(const VampRenderDesc* d, const float* mats, const float* us,
                                  const float* vs, const float* ds, const float* beta,
                                  const void* density_feature, void* workspace, size_t workspace_bytes,

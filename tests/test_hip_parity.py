@@ -1303,3 +1303,63 @@ def test_density_regimes_match_reference(dev, regime, ert):
         _block_check(g, ref["grad_" + k], f"{regime} grad_{k}", rtol=5e-5, elem_atol=1e-10)
     if "grad_beta" in ref:
         assert abs(float(gbeta) - ref["grad_beta"]) <= 2e-3 * abs(ref["grad_beta"]) + 1e-4, (float(gbeta), ref["grad_beta"])
+
+
+# --------------------------------------------------------------------------- round-3: one-kernel camera forward
+@pytest.mark.parametrize("mode,cat_seg", RENDER_VARIANTS)
+def test_camera_direct_forward_tiny(tiny_common, dev, mode, cat_seg):
+    """render_cam_direct.hip (the camera branch as one kernel on the channel-first volumes; what
+    forward-only calls run) against the reference's outputs on the tiny fixtures, with and without
+    early ray termination, fp32 and bf16-rounded inputs; and against the packed-copy path bit for
+    bit in the termination table."""
+    g = tiny_common
+    r = load_golden(render_fixture_name(mode, cat_seg))
+    cfg = dataclasses.replace(CFG_TINY, density_mode=mode, cat_seg=cat_seg)
+    _, rm = tiny_mats(g, dev)
+    vols = [g[k].to(dev) for k in ("density_feature", "semantic_logits", "base", "rgb")]
+    beta = r["beta"].reshape(()).to(dev) if mode == "sdf" else None
+    for ert in (True, False):
+        hp = hot(cfg, dev)
+        hp.impl["ert"] = ert
+        assert hp.impl["cam_direct"]
+        with torch.no_grad():
+            outs = hp.render(*vols, beta, render_mats=rm)
+        for nm, o in zip(NAMES, outs):
+            close(o, r[nm], what=f"direct {mode} ert={ert} {nm}")
+        hp.impl["cam_direct"] = False
+        with torch.no_grad():
+            old = hp.render(*vols, beta, render_mats=rm)
+        for nm, a, b_ in zip(NAMES[:3], outs, old):
+            close(a, b_, atol=2e-5, rtol=1e-5, what=f"direct vs packed {mode} ert={ert} {nm}")
+    # bf16 volumes: the kernel reads the 2-byte elements itself
+    hp = hot(cfg, dev)
+    vb = [v.bfloat16() for v in vols]
+    with torch.no_grad():
+        ob = hp.render(*vb, beta, render_mats=rm)
+        of = hp.render(*[v.float() for v in vb], beta, render_mats=rm)
+    for nm, a, b_ in zip(NAMES, ob, of):
+        close(a, b_, atol=1e-5, rtol=1e-5, what=f"direct bf16 {nm}")
+
+
+@pytest.mark.parametrize("regime", ["sdf", "naive", "init", "empty"])
+def test_camera_direct_forward_full_size(dev, regime):
+    """cfg-B: the one-kernel camera forward against the packed-copy march in the four density
+    regimes (outputs to 1e-5 of the largest magnitude) and, where the reference fixture exists,
+    against the reference's block statistics; its termination table equals cam_term_kernel's."""
+    with open(os.path.join(GOLDEN, "full_checksums.json")) as f:
+        rm = torch.tensor(json.load(f)["B"]["render_mats"], dtype=torch.float32, device=dev)
+    cfg, vols = _regime_inputs(CFG_B, regime, dev, with_grad=False)
+    beta = torch.tensor(0.1, device=dev) if cfg.density_mode == "sdf" else None
+    hp = hot(cfg, dev)
+    with torch.no_grad():
+        new = hp.render(*vols, beta, render_mats=rm)
+        hp.impl["cam_direct"] = False
+        old = hp.render(*vols, beta, render_mats=rm)
+    for nm, a, b_ in zip(NAMES[:3], new, old):
+        close(a, b_, atol=(3 * 1.2e-7 * cfg.d_bound[1] if nm == "depth_preds" else 1e-7), rtol=1e-5, scale="max",
+              what=f"{regime} direct vs packed {nm}")
+    if regime != "sdf":
+        with open(os.path.join(GOLDEN, "regime_checksums.json")) as f:
+            ref = json.load(f)[regime]
+        for nm, o in zip(NAMES, new):
+            _block_check(o, ref[nm], f"{regime} direct {nm}", rtol=5e-5, elem_atol=1e-8)

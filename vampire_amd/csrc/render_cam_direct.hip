@@ -1,0 +1,456 @@
+// Camera branch of the renderer, forward, as ONE kernel that reads the reference-layout
+// (channel-first) volumes directly: volume_rendering_from_multiple_views, bv2:396-440.
+//
+// It replaces three launches of render_fwd.hip -- pack_volume (a 117 MB re-layout), cam_term (the
+// density-only pre-pass of early ray termination) and the planned march -- for callers that hand
+// over [B,c,Z,Y,X] volumes and want the three camera maps:
+//
+//   plan     (ray_plan.hpp) which depth indices of the 8 x 8 ray tile can hold inside samples
+//   density  the four waves share those depth indices; every inside sample takes its density
+//            feature (4 x-pair loads from the 2.5 MB density volume) -> tau_i = sigma_i delta_i
+//            into LDS, [depth index][ray]
+//   scan     lanes = (ray, quarter of the depth range): exclusive prefix of tau along each ray,
+//            compositing weights w_i = (1 - exp(-tau_i)) exp(-prefix) back into LDS, sum of
+//            weights / expected depth, and the early-termination index keep[ray] (first sample in
+//            front of which the optical depth has reached kTermOpticalDepth)
+//   gather   the depth indices below the tile's largest keep are dealt to the four waves again;
+//            every kept inside sample gathers its K + 3 composited channels -- per channel four
+//            8-byte loads of the x-neighbour pair at (z, y), (z, y+1), (z+1, y), (z+1, y+1) -- and
+//            adds w_i * s.  The weights are absolute, so there is no serial dependence between
+//            samples and no exp() rescaling at the merge.
+//   merge    partial sums of the four waves meet in LDS; coalesced stores of the maps
+//
+// Why channel-first works here although a lone ray would touch 22 x 8 lines per sample: the 64
+// lanes of a wave are the 64 rays of the tile at ONE depth index, so for a fixed channel and
+// (z, y) tap the wave's 64 pairs lie in a handful of rows of that channel's plane -- no more
+// cache lines per wave instruction than the packed 96-byte rows cost, and the packed copy
+// (24 us, 117 MB of traffic at cfg-B) disappears.  HBM/L2-bound gather + a short scan: no MFMA.
+#include "render_common.hpp"
+#include "ray_plan.hpp"
+
+namespace vamp {
+
+// x-neighbour pair through a buffer descriptor: the address is descriptor base + per-lane byte offset
+// (VGPR) + per-channel byte offset (SGPR) -- no vector address arithmetic per channel, and hipcc issues
+// a whole batch of such loads back to back (with 64-bit global addresses it waited after every
+// second channel: eleven round trips per sample).  fp32: one 8-byte load at a 4-byte-aligned
+// address; bf16: two 2-byte loads.
+typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+struct PairRaw {
+  unsigned x, y;       // fp32: the two floats' bits; bf16: the two elements' 16 bits, zero-extended
+};
+template <typename T>
+__device__ __forceinline__ PairRaw ld_pair(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  PairRaw r;
+  if constexpr (sizeof(T) == 4) {
+    const v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    r.x = v.x; r.y = v.y;
+  } else {
+    r.x = __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0);
+    r.y = __builtin_amdgcn_raw_buffer_load_b16(rs, voff + 2u, soff, 0);
+  }
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ float pair_lo(const PairRaw& p) { return __uint_as_float(sizeof(T) == 4 ? p.x : p.x << 16); }
+template <typename T>
+__device__ __forceinline__ float pair_hi(const PairRaw& p) { return __uint_as_float(sizeof(T) == 4 ? p.y : p.y << 16); }
+
+// descriptor over `bytes` bytes at p (wave-uniform values only: the block's batch index)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int) (bytes > 0x7fffffffull ? 0x7fffffffull : bytes), 0x00020000);
+}
+
+// the four row offsets and six weights of an INSIDE sample's 2 x 2 x 2 taps, x taken as a pair
+struct PairTap {
+  unsigned o00, o01, o10, o11;      // (z0,y0) (z0,y1) (z1,y0) (z1,y1): BYTE offset of the pair in a channel
+  float w00, w01, w10, w11;         // wz * wy
+  float wa, wb;                     // weights of the pair's two elements
+};
+
+template <typename T>
+__device__ __forceinline__ PairTap pair_tap(const RenderParams& P, const VolTap& tp) {
+  // inside => 0 <= ix0 <= X - 1 etc.; a "+1" tap beyond the volume has weight exactly zero
+  // (the coordinate is the last index itself): clamp its address, zero its weight
+  PairTap t;
+  const int xa = min(tp.ix0, P.X - 2);
+  const bool last = tp.ix0 != xa;                   // ix0 == X - 1: the pair is (X - 2, X - 1)
+  t.wa = last ? 0.f : tp.wx0;
+  t.wb = last ? tp.wx0 : tp.wx1;
+  const int y1 = min(tp.iy0 + 1, P.Y - 1), z1 = min(tp.iz0 + 1, P.Z - 1);
+  const float wy1 = (tp.iy0 + 1 < P.Y) ? tp.wy1 : 0.f, wz1 = (tp.iz0 + 1 < P.Z) ? tp.wz1 : 0.f;
+  const unsigned r0 = (unsigned) (tp.iz0 * P.Y), r1 = (unsigned) (z1 * P.Y);
+  constexpr unsigned es = sizeof(T);
+  t.o00 = ((r0 + tp.iy0) * P.X + xa) * es; t.o01 = ((r0 + y1) * P.X + xa) * es;
+  t.o10 = ((r1 + tp.iy0) * P.X + xa) * es; t.o11 = ((r1 + y1) * P.X + xa) * es;
+  t.w00 = tp.wz0 * tp.wy0; t.w01 = tp.wz0 * wy1; t.w10 = wz1 * tp.wy0; t.w11 = wz1 * wy1;
+  return t;
+}
+
+template <typename T>
+__device__ __forceinline__ float pair_combine(const PairTap& t, const PairRaw (&v)[4]) {
+  const float r0 = __builtin_fmaf(t.wb, pair_hi<T>(v[0]), t.wa * pair_lo<T>(v[0]));
+  const float r1 = __builtin_fmaf(t.wb, pair_hi<T>(v[1]), t.wa * pair_lo<T>(v[1]));
+  const float r2 = __builtin_fmaf(t.wb, pair_hi<T>(v[2]), t.wa * pair_lo<T>(v[2]));
+  const float r3 = __builtin_fmaf(t.wb, pair_hi<T>(v[3]), t.wa * pair_lo<T>(v[3]));
+  return __builtin_fmaf(t.w11, r3, __builtin_fmaf(t.w10, r2, __builtin_fmaf(t.w01, r1, t.w00 * r0)));
+}
+
+// depth index of the first active index at or after `from`, skipping `skip` active ones (uniform)
+__device__ __forceinline__ int mask_skip(const PlanMask& mk, int from, int skip) {
+  int j = mask_next(mk, from);
+  for (int k = 0; k < skip && j < kPlanMax; ++k) j = mask_next(mk, j + 1);
+  return j;
+}
+
+// wave `sub` of NW: contiguous range [j0, j1) of the S depth indices, equal shares of the active ones
+template <int NW>
+__device__ __forceinline__ void plan_share_n(const PlanMask& mk, int S, int sub, int& j0, int& j1) {
+  const int A = __builtin_popcountll(mk.lo) + __builtin_popcountll(mk.hi);
+  if (A < NW) {
+    const int L = (S + NW - 1) / NW;
+    j0 = min(S, sub * L); j1 = min(S, j0 + L);
+    return;
+  }
+  j0 = sub == 0 ? 0 : mask_select(mk, (sub * A) / NW);
+  j1 = sub == NW - 1 ? S : mask_select(mk, ((sub + 1) * A) / NW);
+}
+
+// Per-ray constants of get_geometry's first product (bv2:334-336): inv(ida) @ (u, v, d, 1) evaluated as
+// ((m0 u + m1 v) + m2 d) + m3 -- the first sum does not depend on the depth index, and m3 * 1 is m3.
+struct RayBase {
+  float c[4];
+};
+__device__ __forceinline__ RayBase ray_base(const float* __restrict__ m, float u, float v) {
+  RayBase r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r.c[k] = m[4 * k] * u + m[4 * k + 1] * v;
+  return r;
+}
+// frustum_point (render_common.hpp) with that sum taken from `rb`: the same roundings, bit for bit
+__device__ __forceinline__ void frustum_point_rb(const float* __restrict__ m, const RayBase& rb, float dd,
+                                                 float& x, float& y, float& z) {
+  Vec4 p;
+  p.x = (rb.c[0] + m[2] * dd) + m[3] * 1.0f;
+  p.y = (rb.c[1] + m[6] * dd) + m[7] * 1.0f;
+  p.z = (rb.c[2] + m[10] * dd) + m[11] * 1.0f;
+  p.w = (rb.c[3] + m[14] * dd) + m[15] * 1.0f;
+  p.x = p.x * p.z;
+  p.y = p.y * p.z;
+  p = matvec(m + 16, p);
+  p = matvec(m + 32, p);
+  x = nan_to_num_geom(p.x); y = nan_to_num_geom(p.y); z = nan_to_num_geom(p.z);
+}
+
+// sigma(s) with one v_exp_f32: for t = s - bias > 0 the reference's 0.5 + 0.5 sign(t) expm1(-|t| / beta) is
+// 0.5 e, for t < 0 it is 1 - 0.5 e (e = exp(-|t| / beta)); neither form cancels, so the fast exponential's
+// 1e-6 relative error is all there is (the outputs are held to 1e-4)
+__device__ __forceinline__ float density_fast(const DensityParams& dp, float s) {
+  if (dp.mode == VAMP_DENSITY_SIGMOID) return __builtin_amdgcn_rcpf(1.f + __expf(-s));
+  const float t = s - dp.bias;
+  const float e = 0.5f * __expf(-fabsf(t) * dp.ib);
+  return dp.ib * (t > 0.f ? e : (t < 0.f ? 1.0f - e : 0.5f));
+}
+
+constexpr int kDirectG = 4;               // depth indices a wave takes per round of the density phase
+#ifndef VAMP_DIRECT_CB
+#define VAMP_DIRECT_CB 4
+#endif
+constexpr int kDirectCB = VAMP_DIRECT_CB; // channels whose loads are in flight together in the gather
+
+// NCH = composited channels (K + 3), rounded up by the launcher; channels >= K + 3 are skipped.
+// NW = waves per 8 x 8 ray tile.  LDS: plan (2 KB) + round sums + dyn = max(S, NW * NCH) * 64 floats
+// (tau / weights, then the merge buffer).
+template <typename T, int NCH, bool ERT, int NW>
+__global__ void __launch_bounds__(NW * 64)
+cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const float* __restrict__ us,
+                      const float* __restrict__ vs, const float* __restrict__ ds,
+                      const float* __restrict__ mids, const float* __restrict__ beta_raw,
+                      const T* __restrict__ dens, const T* __restrict__ sem, const T* __restrict__ rgb,
+                      float* __restrict__ rgb_out, float* __restrict__ seg_out,
+                      float* __restrict__ depth_out, int* __restrict__ term_out) {
+  extern __shared__ __align__(16) float dyn[];
+  __shared__ int4 plan[kPlanMax];
+  __shared__ int keep_s[64];
+  __shared__ float accw_s[64], accd_s[64];
+  __shared__ float part_s[2][NW][64];
+  float* wbuf = dyn;                                                // [S][64]
+  const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const RayId id = decode_ray_wps(P);
+  const int w = id.w, h = id.h;
+  const long bn = __builtin_amdgcn_readfirstlane((int) id.bn);
+  const int b = __builtin_amdgcn_readfirstlane(id.b);
+  const DensityParams dp = load_density(P.density_mode, beta_raw, P.beta_min, P.sdf_bias);
+  const int S = P.D - 1;
+  const float* m = mats + bn * 48;
+  const float u = us[w], v = vs[h];
+  const long V = (long) P.Z * P.Y * P.X;
+  const int nch = P.K + 3;
+  const RayBase rb = ray_base(m, u, v);
+
+  auto point = [&](int i, float& x, float& y, float& z) { frustum_point_rb(m, rb, ds[i], x, y, z); };
+
+  // ---- plan: depth indices of the tile that can hold inside samples (waves 0..3 plan 32 each)
+  if (sub < 4)
+    plan_tile(P, m, us, vs, ds, __builtin_amdgcn_readlane(w, 0), __builtin_amdgcn_readlane(w, 63),
+              __builtin_amdgcn_readlane(h, 0), __builtin_amdgcn_readlane(h, 63), sub, plan);
+  __syncthreads();
+  const PlanMask mk_all = plan_mask(plan);
+  const int A = __builtin_popcountll(mk_all.lo) + __builtin_popcountll(mk_all.hi);
+#if defined(VAMP_DIRECT_STOP) && VAMP_DIRECT_STOP == 1
+  if (mk_all.lo != 0x1234567ull) return;
+#endif
+
+  // ---- density: tau_i = sigma_i delta_i of every depth index into LDS
+  int S_eff = S;                      // depth indices the scan covers (early exit: the tile is saturated there)
+  {
+    // (the frustum points of a ray are affine in the depth: one bin length per unit of depth)
+    float tau_unit;
+    {
+      float px, py, pz, qx, qy, qz;
+      point(0, px, py, pz);
+      point(1, qx, qy, qz);
+      const float dx = qx - px, dy = qy - py, dz = qz - pz;
+      tau_unit = density_fast(dp, 0.f) * (sqrtf(dx * dx + dy * dy + dz * dz) / (ds[1] - ds[0]));   // masked sample -> density(0) (Q6)
+    }
+    // depth indices at which no ray of the tile is inside the volume: s = 0 (bv2:426 for samples the
+    // mask zeroes; equal to the exact norm up to rounding)
+    for (int i = sub; i < S; i += NW)
+      if (!mask_test(mk_all, i)) wbuf[i * 64 + lane] = tau_unit * (ds[i + 1] - ds[i]);
+    // the others in rounds of NW * G: a wave takes G consecutive active indices, all its taps in
+    // flight together; after each round every wave knows every ray's optical depth so far, and the
+    // tile stops once all 64 rays are saturated
+    const __amdgpu_buffer_rsrc_t rs_d = make_rsrc(dens + (long) b * V, (size_t) V * sizeof(T));
+    constexpr int G = kDirectG, R = NW * G;
+    float carry = 0.f;                // sum of the active indices' tau so far (per ray)
+    float d_inact = 0.f;              // sum of the skipped bins' depth extents so far (uniform)
+    int cursor = 0;                   // depth index where the current round starts
+    for (int r0 = 0, rd = 0; r0 < A; r0 += R, ++rd) {
+      int idx[G];
+      idx[0] = mask_skip(mk_all, cursor, sub * G);
+#pragma unroll
+      for (int g = 1; g < G; ++g) idx[g] = idx[g - 1] < kPlanMax ? mask_next(mk_all, idx[g - 1] + 1) : kPlanMax;
+      float s0[G], delta[G];
+      bool in[G];
+      PairTap pt[G];
+      PairRaw raw[G][4];
+      float px, py, pz, qx = 0.f, qy = 0.f, qz = 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        in[g] = false; delta[g] = 0.f;
+        if (idx[g] < S) {
+          // (consecutive depth indices share a frustum point)
+          if (g > 0 && idx[g] == idx[g - 1] + 1) { px = qx; py = qy; pz = qz; }
+          else point(idx[g], px, py, pz);
+          point(idx[g] + 1, qx, qy, qz);
+          const VolTap tp = volume_tap(P, px, py, pz);
+          const float dx = qx - px, dy = qy - py, dz = qz - pz;
+          delta[g] = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);               // bv2:426
+          in[g] = tp.inside;
+          if (tp.inside) {
+            pt[g] = pair_tap<T>(P, tp);
+            raw[g][0] = ld_pair<T>(rs_d, pt[g].o00, 0u);
+            raw[g][1] = ld_pair<T>(rs_d, pt[g].o01, 0u);
+            raw[g][2] = ld_pair<T>(rs_d, pt[g].o10, 0u);
+            raw[g][3] = ld_pair<T>(rs_d, pt[g].o11, 0u);
+          }
+        }
+      }
+      float psum = 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (idx[g] < S) {
+          float sv = 0.f;
+          if (in[g]) sv = nan_to_num(pair_combine<T>(pt[g], raw[g]));
+          const float tau = density_fast(dp, sv) * delta[g];
+          wbuf[idx[g] * 64 + lane] = tau;
+          psum += tau;
+        }
+      }
+      part_s[rd & 1][sub][lane] = psum;
+      // where the next round starts, and the skipped bins in front of it
+      const int nxt = (r0 + R >= A) ? S : mask_skip(mk_all, cursor, R);
+      for (int i = cursor; i < nxt; ++i)
+        if (!mask_test(mk_all, i)) d_inact += ds[i + 1] - ds[i];
+      cursor = nxt;
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NW; ++k) carry += part_s[rd & 1][k][lane];
+      if (ERT) {
+        // (the margin covers the different summation order of the scan below)
+        const bool done = carry + tau_unit * d_inact >= kTermOpticalDepth * 1.001f;
+        if (__ballot(!done) == 0ull) { S_eff = nxt; break; }
+      }
+    }
+  }
+  __syncthreads();
+#if defined(VAMP_DIRECT_STOP) && VAMP_DIRECT_STOP == 2
+  if (wbuf[lane] != 12345.f) return;
+#endif
+
+  // ---- scan: lanes = (ray of this wave's 64 / NW, segment of the depth range)
+  {
+    constexpr int RPW = 64 / NW, SEG = NW;
+    const int r = sub * RPW + (lane % RPW), q = lane / RPW;
+    const int L = (S_eff + SEG - 1) / SEG;
+    const int a0 = min(S_eff, q * L), a1 = min(S_eff, a0 + L);
+    float part = 0.f;
+    for (int i = a0; i < a1; ++i) part += wbuf[i * 64 + r];
+    // exclusive prefix over the segments of the ray (bv2:431-433: exclusive cumsum)
+    float incl = part;
+#pragma unroll
+    for (int o = 1; o < SEG; o <<= 1) {
+      const float up = __shfl_up(incl, o * RPW, 64);
+      if (q >= o) incl += up;
+    }
+    float cum = incl - part;
+    int keep = S;
+    float aw = 0.f, ad = 0.f;
+    for (int i = a0; i < a1; ++i) {
+      const float tau = wbuf[i * 64 + r];
+      const float wgt = (1.0f - __expf(-tau)) * __expf(-cum);      // bv2:430-434
+      wbuf[i * 64 + r] = wgt;
+      aw += wgt;
+      ad = __builtin_fmaf(wgt, mids[i], ad);
+      cum += tau;
+      // samples 0 .. i are kept; the optical depth in front of sample i + 1 is `cum`
+      if (ERT && keep == S && !(cum < kTermOpticalDepth)) keep = i + 1;
+    }
+#pragma unroll
+    for (int o = RPW; o < 64; o <<= 1) {
+      aw += __shfl_xor(aw, o, 64);
+      ad += __shfl_xor(ad, o, 64);
+      keep = min(keep, __shfl_xor(keep, o, 64));
+    }
+    if (q == 0) { keep_s[r] = min(keep, S_eff < S ? S_eff : S); accw_s[r] = aw; accd_s[r] = ad; }
+  }
+  __syncthreads();
+#if defined(VAMP_DIRECT_STOP) && VAMP_DIRECT_STOP == 3
+  if (keep_s[lane] != 12345) return;
+#endif
+
+  // ---- gather: the kept inside samples' K + 3 composited channels
+  const int keep = keep_s[lane];
+  int Se = keep;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) Se = max(Se, __shfl_xor(Se, o, 64));
+  Se = __builtin_amdgcn_readfirstlane(Se);
+  PlanMask mk = mk_all;
+  mask_truncate(mk, Se);
+  float acc[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) acc[c] = 0.f;
+  {
+    int i0, i1;
+    plan_share_n<NW>(mk, Se, sub, i0, i1);
+    const __amdgpu_buffer_rsrc_t rs_s = make_rsrc(sem + (long) b * P.K * V, (size_t) P.K * V * sizeof(T));
+    const __amdgpu_buffer_rsrc_t rs_r = make_rsrc(rgb + (long) b * 3 * V, (size_t) 3 * V * sizeof(T));
+    const unsigned vbytes = (unsigned) V * (unsigned) sizeof(T);     // one channel, bytes (launcher: K * V * es < 2 GB)
+    for (int i = mask_next(mk, i0); i < i1; i = mask_next(mk, i + 1)) {
+      float px, py, pz;
+      point(i, px, py, pz);
+      const VolTap tp = volume_tap(P, px, py, pz);
+      if (tp.inside && i < keep) {
+        const PairTap pt = pair_tap<T>(P, tp);
+        const float wgt = wbuf[i * 64 + lane];
+        float s[NCH];
+        // channels in batches of kDirectCB: all 4 * CB pair loads of a batch are issued back to back
+#pragma unroll
+        for (int c0 = 0; c0 < NCH; c0 += kDirectCB) {
+          PairRaw raw[kDirectCB][4];
+#pragma unroll
+          for (int u = 0; u < kDirectCB; ++u) {
+            if (c0 + u < NCH) {
+              const int cc = min(c0 + u, nch - 1);
+              const bool is_sem = cc < P.K;
+              const __amdgpu_buffer_rsrc_t rs = is_sem ? rs_s : rs_r;
+              const unsigned so = (unsigned) (is_sem ? cc : cc - P.K) * vbytes;
+              raw[u][0] = ld_pair<T>(rs, pt.o00, so);
+              raw[u][1] = ld_pair<T>(rs, pt.o01, so);
+              raw[u][2] = ld_pair<T>(rs, pt.o10, so);
+              raw[u][3] = ld_pair<T>(rs, pt.o11, so);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < kDirectCB; ++u)
+            if (c0 + u < NCH) s[c0 + u] = pair_combine<T>(pt, raw[u]);
+        }
+        // nan_to_num of the sampled features (bv2:421) only where something is not finite:
+        // sum_c 0 * s_c is nan exactly then
+        float chk = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) chk = __builtin_fmaf(s[c], 0.f, chk);
+        if (chk != chk) {
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) s[c] = nan_to_num(s[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc[c] = __builtin_fmaf(wgt, s[c], acc[c]);
+      }
+    }
+  }
+  __syncthreads();                                                   // all reads of wbuf are done
+
+  // ---- merge the waves' partial sums; stores
+  float* xa = dyn;                                                   // [NW][NCH][64]
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) xa[(sub * NCH + c) * 64 + lane] = acc[c];
+  __syncthreads();
+  const long HW = (long) P.fH * P.fW;
+  const long pix = (long) h * P.fW + w;
+  if (id.live) {
+    for (int c = sub; c < nch; c += NW) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) t += xa[(k * NCH + c) * 64 + lane];
+      if (c < P.K) seg_out[(bn * P.K + c) * HW + pix] = t;
+      else rgb_out[(bn * 3 + (c - P.K)) * HW + pix] = t;
+    }
+    if (sub == 0) {
+      depth_out[bn * HW + pix] = accd_s[lane] + (1.0f - accw_s[lane]) * P.d_far;   // bv2:436,440
+      if (term_out) term_out[bn * HW + pix] = keep;
+    }
+  }
+}
+
+#ifndef VAMP_DIRECT_NW
+#define VAMP_DIRECT_NW 4
+#endif
+
+int launch_cam_fwd_direct(const VampRenderDesc* d, const RenderParams& P, const float* mats, const float* us,
+                          const float* vs, const float* ds, const float* mids, const float* beta,
+                          const void* dens, const void* sem, const void* rgb, float* rgb_out,
+                          float* seg_out, float* depth_out, int* term_out, bool ert, hipStream_t s) {
+  const int S = P.D - 1, nch = P.K + 3;
+  const long tiles = (long) P.B * P.N * ((P.fH + 7) / 8) * ((P.fW + 7) / 8);
+  const unsigned grid = (unsigned) ((tiles + 7) / 8 * 8);
+#define VAMP_CAMD(T, NCH)                                                                               \
+  do {                                                                                                  \
+    constexpr int NW = VAMP_DIRECT_NW;                                                                  \
+    const size_t dyn = sizeof(float) * 64 * (size_t) (S > NW * NCH ? S : NW * NCH);                     \
+    if (ert)                                                                                            \
+      VAMP_TIMED(kProfCamFwd, s, (cam_fwd_direct_kernel<T, NCH, true, NW><<<grid, NW * 64, dyn, s>>>(   \
+          P, mats, us, vs, ds, mids, beta, static_cast<const T*>(dens), static_cast<const T*>(sem),     \
+          static_cast<const T*>(rgb), rgb_out, seg_out, depth_out, term_out)));                         \
+    else                                                                                                \
+      VAMP_TIMED(kProfCamFwd, s, (cam_fwd_direct_kernel<T, NCH, false, NW><<<grid, NW * 64, dyn, s>>>(  \
+          P, mats, us, vs, ds, mids, beta, static_cast<const T*>(dens), static_cast<const T*>(sem),     \
+          static_cast<const T*>(rgb), rgb_out, seg_out, depth_out, term_out)));                         \
+  } while (0)
+#define VAMP_CAMD_T(T)                                                                                  \
+  do {                                                                                                  \
+    if (nch <= 8) VAMP_CAMD(T, 8);                                                                      \
+    else if (nch <= 12) VAMP_CAMD(T, 12);                                                               \
+    else if (nch == 21) VAMP_CAMD(T, 21);                                                               \
+    else if (nch <= 24) VAMP_CAMD(T, 24);                                                               \
+    else VAMP_CAMD(T, 32);                                                                              \
+  } while (0)
+  if (d->in_dtype == VAMP_F32) VAMP_CAMD_T(float);
+  else VAMP_CAMD_T(__hip_bfloat16);
+#undef VAMP_CAMD_T
+#undef VAMP_CAMD
+  return check_launch("cam_fwd_direct_kernel");
+}
+
+}  // namespace vamp

@@ -230,6 +230,13 @@ int launch_cam_term(const VampRenderDesc* d, const RenderParams& P, const float*
                     const float* vs, const float* ds, const float* beta, const void* density_feature,
                     int* term, hipStream_t s);
 
+// render_cam_direct.hip: plan + density march + scan + channel gather in one kernel, on the
+// channel-first volumes; term_out (may be NULL) receives the per-ray table
+int launch_cam_fwd_direct(const VampRenderDesc* d, const RenderParams& P, const float* mats, const float* us,
+                          const float* vs, const float* ds, const float* mids, const float* beta,
+                          const void* dens, const void* sem, const void* rgb, float* rgb_out,
+                          float* seg_out, float* depth_out, int* term_out, bool ert, hipStream_t s);
+
 // 8-tap trilinear gather of CP4*4 packed channels for an INSIDE sample, branch-free: all
 // 8 * CP4 16-byte loads are independent and can be in flight together (a per-tap bounds
 // branch would serialise eight memory round trips).  Inside => tap indices >= 0; a "+1" tap

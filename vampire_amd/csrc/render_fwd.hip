@@ -555,6 +555,14 @@ int vamp_render_camera_forward_ex(const VampRenderDesc* d, const float* geom, co
                "null pointer");
   VAMP_REQUIRE(beta || d->density_mode == VAMP_DENSITY_SIGMOID, "beta is NULL");
   const bool planned = !geom && d->D - 1 <= kPlanMax;
+  if ((flags & VAMP_CAMFWD_DIRECT) && planned && !(flags & VAMP_CAMFWD_SAVE_SAMPLES)) {
+    // one kernel on the channel-first volumes (render_cam_direct.hip): no packed copy, the
+    // termination table is a by-product (written when the workspace can hold it)
+    const bool ert = !(flags & VAMP_CAMFWD_NO_ERT);
+    int* term = (workspace && workspace_bytes >= vamp_render_workspace_bytes(d)) ? cam_term_ptr(d, workspace) : nullptr;
+    return launch_cam_fwd_direct(d, to_params(d), mats, us, vs, ds, mids, beta, density_feature, semantic, rgb,
+                                 rgb_out, seg_out, depth_out, term, ert, static_cast<hipStream_t>(stream));
+  }
   const bool save = (flags & VAMP_CAMFWD_SAVE_SAMPLES) && planned;
   const bool ert = planned && !(flags & VAMP_CAMFWD_NO_ERT);
   const size_t need = save ? vamp_render_workspace_bytes(d) + vamp_render_samples_bytes(d)

@@ -116,6 +116,13 @@ class HotPath:
                      "save_samples": os.environ.get("VAMP_SAVE_SAMPLES", "0") == "1",
                      # early ray termination in the camera branch (include/vampire_hip.h)
                      "ert": os.environ.get("VAMP_ERT", "1") != "0",
+                     # the camera branch as ONE kernel on the channel-first volumes (no packed copy, no
+                     # separate termination pass; render_cam_direct.hip)
+                     "cam_direct": os.environ.get("VAMP_CAM_DIRECT", "1") != "0",
+                     # forward-only calls: BEV branch on the side stream beside the camera branch.  Off for
+                     # eager launches (the fork / join costs more than it hides); a caller that captures the
+                     # forward into a HIP graph switches it on (bench.py)
+                     "fwd_overlap": os.environ.get("VAMP_FWD_OVERLAP", "0") == "1",
                      "prepare": os.environ.get("VAMP_PREPARE", "1") != "0"}
 
     # ---------------------------------------------------------------- descs
@@ -482,9 +489,10 @@ class _RenderFn(torch.autograd.Function):
         # this one.  Forward-only calls stay on one stream: the fork / join costs more than the short
         # BEV forward hides (296 vs 210 us for the eager forward pair).
         cur = torch.cuda.current_stream()
-        side = hp._side_stream() if train else None
+        side = hp._side_stream() if (train or hp.impl["fwd_overlap"]) else None
         ctx.cells = False
         ert = geom is None and hp.impl["ert"]
+        direct = geom is None and hp.impl["cam_direct"] and not save and (c.D - 1) <= 128
         fwd_flags = 0 if ert else _capi.VAMP_CAMFWD_NO_ERT
         split = (side is not None and ert and hp.impl["sched"] == "split" and geom is None
                  and hp.impl["prepare"] and hp.impl["cam_bwd"] != "v1")
@@ -532,6 +540,24 @@ class _RenderFn(torch.autograd.Function):
                 _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(),
                 fwd_flags | _capi.VAMP_CAMFWD_PACKED_VALID | (_capi.VAMP_CAMFWD_SAVE_SAMPLES if save else 0),
                 _stream(cur)), "vamp_render_camera_forward_ex")
+        elif direct and not train:
+            # forward only: the camera branch is one kernel on the volumes as they are; with
+            # fwd_overlap the BEV branch runs beside it on the side stream
+            ctx.ert = ert
+            bstream = cur
+            if side is not None:
+                side.wait_stream(cur)
+                bstream = side
+            _capi.check(hp.lib.vamp_render_bev_forward_ex(
+                C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
+                _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
+                _ptr(vdens), _ptr(vout), None, 0, 0, _stream(bstream)), "vamp_render_bev_forward_ex")
+            ctx.bev_key = None
+            _capi.check(hp.lib.vamp_render_camera_forward_ex(
+                C.byref(d), None, _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
+                _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
+                _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(),
+                fwd_flags | _capi.VAMP_CAMFWD_DIRECT, _stream(cur)), "vamp_render_camera_forward_ex")
         else:
             if ert:
                 # the per-ray termination table first: forward, the backward's sort and its per-ray pass
@@ -573,7 +599,7 @@ class _RenderFn(torch.autograd.Function):
         # the workspace now starts with the channel-last copy of (dens, sem, rgb); the backward
         # reuses it if no other render call has touched the workspace in between
         hp._pack_gen = getattr(hp, "_pack_gen", 0) + 1
-        ctx.pack_key = (hp._pack_gen, ws.data_ptr())
+        ctx.pack_key = None if (direct and not train) else (hp._pack_gen, ws.data_ptr())   # (the direct kernel packs nothing)
         ctx.has_geom = geom is not None
         ctx.save_for_backward(dens, sem, base, rgb, beta, geom if geom is not None else mats)
         return rgb_p, seg_p, dep_p, bev_rgb, bev_seg, bev_h, vdens, vout
