@@ -344,6 +344,7 @@ int vamp_render_bev_forward(const VampRenderDesc* d, const float* oxs, const flo
  * same workspace with VAMP_BEVBWD_SAVED_VALID reads them back instead of sampling again.
  */
 #define VAMP_BEVFWD_SAVE 1
+#define VAMP_BEVFWD_TWO_KERNELS 2   /* the first implementation (density pass + channel-pair pass) instead of the one-kernel forward of render_bev_fused.hip: kept as the cross-check of the tests */
 int vamp_render_bev_forward_ex(const VampRenderDesc* d, const float* oxs, const float* oys,
                             const float* ozs, const float* bev_mids, const float* beta,
                             const void* density_feature, const void* semantic,

@@ -619,10 +619,18 @@ def test_edge_cases(tiny_common, dev):
     for v in vols:
         assert float(v.grad.abs().max()) == 0.0
     assert float(beta.grad.abs()) == 0.0
-    # --- forward is deterministic bit for bit
+    # --- forward is deterministic bit for bit (calls of the same kind: a forward-only call runs the
+    # one-kernel camera branch, a call that keeps state for a backward the packed-copy march; the
+    # two agree to rounding)
     outs2 = hp.render(*[v.detach() for v in vols], beta.detach(), render_mats=rm)
-    for x, y in zip(outs, outs2):
+    outs3 = hp.render(*[v.detach() for v in vols], beta.detach(), render_mats=rm)
+    for x, y in zip(outs2, outs3):
         assert torch.equal(x, y)
+    outs4 = hp.render(*vols, beta, render_mats=rm)
+    for x, y in zip(outs, outs4):
+        assert torch.equal(x, y)
+    for nm, x, y in zip(NAMES, outs, outs2):
+        close(x, y, atol=2e-5, rtol=1e-5, what=f"training-mode vs forward-only {nm}")
     # --- empty point list
     sem = g["semantic_logits"].to(dev).requires_grad_(True)
     empty = hp.sample_points(sem, torch.zeros(sem.shape[0], 0, 3, device=dev), padding="border")

@@ -64,7 +64,7 @@ VAMP_CAMFWD_SAVE_SAMPLES, VAMP_CAMFWD_NO_ERT, VAMP_CAMFWD_TERM_VALID = 1, 2, 4
 VAMP_CAMPREP_TERM_VALID, VAMP_CAMPREP_RANK_ONLY = 1, 2
 VAMP_CAMBWD_SLOTS_PENDING = 1024
 VAMP_BEVBWD_OVERWRITE_BASE, VAMP_BEVBWD_OVERWRITE_CAM, VAMP_BEVBWD_SAVED_VALID = 1, 2, 4
-VAMP_BEVFWD_SAVE = 1
+VAMP_BEVFWD_SAVE, VAMP_BEVFWD_TWO_KERNELS = 1, 2
 VAMP_CAMFWD_PACK_ONLY, VAMP_CAMFWD_PACKED_VALID, VAMP_CAMFWD_DIRECT = 8, 16, 32
 VAMP_BEVBWD_ONLY_BASE, VAMP_BEVBWD_SKIP_BASE, VAMP_BEVBWD_TABLE_VALID = 8, 16, 32
 

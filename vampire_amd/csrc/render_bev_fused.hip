@@ -1,0 +1,278 @@
+// BEV (top-down) branch of the renderer, forward, as ONE kernel: base_vampire2.py:408-418, 442-461.
+//
+// render_bev.hip's forward is two launches -- bev_density (a thread per column: 625 waves on 1024
+// SIMDs, pure latency) and bev_channels (a thread per column and channel pair, which reads
+// voxel_density back and redoes the weights per pair).  Here a workgroup owns 64 consecutive
+// columns of the flattened (y, x) det lattice and NWV waves:
+//
+//   density   the waves split the oZ heights: trilinear density sample, sigma_j -> LDS,
+//             voxel_density (and the raw sample for the backward)
+//   weights   every wave turns the column's sigma_j into compositing weights w_j in LDS
+//             (identical values from every wave: no second barrier) -- wave 0 also the height map
+//   channels  wave g owns channels g, g + NWV, ...: per batch of CB channels and chunk of heights
+//             the x-pair loads of all needed volume planes are issued together through buffer
+//             descriptors (channel and plane offsets are scalars); consecutive heights share a
+//             plane; semantic / rgb are composited, base passes through to voxel_output
+//
+// Every global access is coalesced along x (lanes = consecutive columns).  HBM-bound streaming
+// with a short per-column scan: no MFMA.
+#include "render_common.hpp"
+
+namespace vamp {
+
+typedef unsigned bev_v2u32 __attribute__((ext_vector_type(2)));
+
+struct BevAxis {
+  int i0;
+  float w0, w1;
+};
+__device__ __forceinline__ BevAxis bev_axis(float pos, float lo, float span, int n) {
+  const float g = ((pos - lo) / span) * 2.0f - 1.0f;
+  const float f = ((g + 1.0f) / 2.0f) * (float) (n - 1);
+  const float fl = floorf(f);
+  BevAxis t;
+  t.i0 = (int) fl;
+  t.w1 = f - fl;
+  t.w0 = (fl + 1.0f) - f;
+  return t;
+}
+
+template <typename T>
+__device__ __forceinline__ void bev_ld_pair(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, float& a, float& b) {
+  if constexpr (sizeof(T) == 4) {
+    const bev_v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    a = __uint_as_float(v.x); b = __uint_as_float(v.y);
+  } else {
+    a = __uint_as_float(((unsigned) __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0)) << 16);
+    b = __uint_as_float(((unsigned) __builtin_amdgcn_raw_buffer_load_b16(rs, voff + 2u, soff, 0)) << 16);
+  }
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bev_rsrc(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int) (bytes > 0x7fffffffull ? 0x7fffffffull : bytes), 0x00020000);
+}
+
+// a column's (y, x) taps: byte offsets of the x-pair in rows y0 / y1 of a plane, and the weights
+// (zero padding: a tap outside the volume keeps a legal address and gets weight zero)
+struct ColTap {
+  unsigned o0, o1;
+  float wy0, wy1, wa, wb;
+};
+template <typename T>
+__device__ __forceinline__ ColTap col_tap(const RenderParams& P, const BevAxis& tx, const BevAxis& ty) {
+  ColTap c;
+  const int xa = min(max(tx.i0, 0), P.X - 2);                 // the pair is (xa, xa + 1)
+  const float w0 = (tx.i0 >= 0 && tx.i0 < P.X) ? tx.w0 : 0.f;
+  const float w1 = (tx.i0 + 1 >= 0 && tx.i0 + 1 < P.X) ? tx.w1 : 0.f;
+  c.wa = (tx.i0 == xa ? w0 : 0.f) + (tx.i0 + 1 == xa ? w1 : 0.f);
+  c.wb = (tx.i0 == xa + 1 ? w0 : 0.f) + (tx.i0 + 1 == xa + 1 ? w1 : 0.f);
+  const int y0 = min(max(ty.i0, 0), P.Y - 1), y1 = min(max(ty.i0 + 1, 0), P.Y - 1);
+  c.wy0 = (ty.i0 >= 0 && ty.i0 < P.Y) ? ty.w0 : 0.f;
+  c.wy1 = (ty.i0 + 1 >= 0 && ty.i0 + 1 < P.Y) ? ty.w1 : 0.f;
+  c.o0 = (unsigned) (y0 * P.X + xa) * (unsigned) sizeof(T);
+  c.o1 = (unsigned) (y1 * P.X + xa) * (unsigned) sizeof(T);
+  return c;
+}
+
+constexpr int kFusedMaxOZ = 64;       // heights whose taps / weights fit the LDS tables
+#ifndef VAMP_BEVF_PC
+#define VAMP_BEVF_PC 6
+#endif
+constexpr int kFusedPC = VAMP_BEVF_PC; // volume planes fetched together (2 x-pair loads each)
+constexpr int kFusedMaxNP = 40;       // distinct volume planes the det heights may touch
+
+#ifndef VAMP_BEVF_NWV
+#define VAMP_BEVF_NWV 8
+#endif
+#ifndef VAMP_BEVF_XCD
+#define VAMP_BEVF_XCD 1
+#endif
+
+__device__ __forceinline__ void bev_store(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, 0);
+}
+
+// dynamic LDS: sigma [oZ][64] | weights [oZ][64] | per wave: bilinear plane values [NP][64]
+template <typename T, int NWV>
+__global__ void __launch_bounds__(NWV * 64)
+bev_fwd_fused_kernel(RenderParams P, int NPA, const float* __restrict__ oxs, const float* __restrict__ oys,
+                     const float* __restrict__ ozs, const float* __restrict__ bev_mids,
+                     const float* __restrict__ beta_raw, const T* __restrict__ dens,
+                     const T* __restrict__ sem, const T* __restrict__ rgb, const T* __restrict__ base,
+                     float* __restrict__ bev_rgb, float* __restrict__ bev_seg, float* __restrict__ bev_height,
+                     float* __restrict__ voxel_density, float* __restrict__ voxel_output,
+                     float* __restrict__ s0_save, float* __restrict__ ss_save) {
+  __shared__ int tz_i0[kFusedMaxOZ];
+  __shared__ float tz_w0[kFusedMaxOZ], tz_w1[kFusedMaxOZ];
+  extern __shared__ __align__(16) float sig[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* wgt = sig + P.oZ * 64;
+  float* bl = wgt + P.oZ * 64 + wave * NPA * 64;                 // this wave's plane values (NPA planes allocated)
+  const int b = blockIdx.y;
+  const int OYX = P.oY * P.oX;
+  // XCD k (workgroups with blockIdx % 8 == k) walks a contiguous band of the lattice: y-neighbours,
+  // which read the same volume rows, share that XCD's L2 (the grid is rounded up to a multiple of 8)
+  const int nwg = (OYX + 63) / 64, per_xcd = (nwg + 7) / 8;
+  const int wg = VAMP_BEVF_XCD ? (int) (blockIdx.x & 7) * per_xcd + (int) (blockIdx.x >> 3) : (int) blockIdx.x;
+  if (wg >= nwg || (VAMP_BEVF_XCD && (int) (blockIdx.x >> 3) >= per_xcd)) return;
+  const int col_raw = wg * 64 + lane;
+  const bool live = col_raw < OYX;
+  const int col = live ? col_raw : OYX - 1;
+  const int y = col / P.oX, x = col - y * P.oX;
+  if ((int) threadIdx.x < P.oZ) {
+    const BevAxis tz = bev_axis(ozs[P.oZ - 1 - threadIdx.x], P.lo[2], P.span[2], P.Z);   // flip (bv2:443)
+    tz_i0[threadIdx.x] = tz.i0; tz_w0[threadIdx.x] = tz.w0; tz_w1[threadIdx.x] = tz.w1;
+  }
+  const DensityParams dp = load_density(P.density_mode, beta_raw, P.beta_min, P.sdf_bias);
+  const unsigned V = (unsigned) (P.Z * P.Y * P.X);
+  const unsigned plane_b = (unsigned) (P.Y * P.X) * (unsigned) sizeof(T);
+  const unsigned vol_b = V * (unsigned) sizeof(T);
+  const unsigned oplane_b = (unsigned) OYX * 4u, ovol_b = oplane_b * (unsigned) P.oZ;   // one height / one channel of the outputs
+  const ColTap ct = col_tap<T>(P, bev_axis(oxs[x], P.lo[0], P.span[0], P.X), bev_axis(oys[y], P.lo[1], P.span[1], P.Y));
+  // a lane outside the lattice stores beyond every descriptor's range: the hardware drops it
+  const unsigned ocol = live ? (unsigned) col * 4u : 0x7ffffff0u;
+  __syncthreads();
+  // the volume planes the heights touch: [pmin, pmin + NP) (uniform; the launcher sized the slabs for a
+  // lattice of heights with the descriptor's spacing, NPA planes)
+  int pmin = tz_i0[0], pmax = tz_i0[0] + 1;
+  for (int j = 1; j < P.oZ; ++j) { pmin = min(pmin, tz_i0[j]); pmax = max(pmax, tz_i0[j] + 1); }
+  pmin = __builtin_amdgcn_readfirstlane(pmin);
+  const int NP = min(__builtin_amdgcn_readfirstlane(pmax) - pmin + 1, NPA);
+
+  // All NP planes [pmin, pmin + NP) of the channel at scalar byte offset `cso`: bilinear (y, x) samples
+  // into this wave's LDS slab, kFusedPC planes (2 * kFusedPC x-pair loads in flight) at a time.  A plane
+  // outside the volume is zero padding; the last chunk repeats its last plane (branch-free).
+  auto fetch_planes = [&](__amdgpu_buffer_rsrc_t rs, unsigned cso) {
+    for (int p0 = 0; p0 < NP; p0 += kFusedPC) {
+      float a0[kFusedPC], b0[kFusedPC], a1[kFusedPC], b1[kFusedPC];
+      bool zin[kFusedPC];
+#pragma unroll
+      for (int t = 0; t < kFusedPC; ++t) {
+        const int p = pmin + min(p0 + t, NP - 1);
+        const int pc = min(max(p, 0), P.Z - 1);
+        zin[t] = p == pc;
+        const unsigned so = cso + (unsigned) pc * plane_b;
+        bev_ld_pair<T>(rs, ct.o0, so, a0[t], b0[t]);
+        bev_ld_pair<T>(rs, ct.o1, so, a1[t], b1[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < kFusedPC; ++t) {
+        const float r0 = __builtin_fmaf(ct.wb, b0[t], ct.wa * a0[t]), r1 = __builtin_fmaf(ct.wb, b1[t], ct.wa * a1[t]);
+        const float r = __builtin_fmaf(ct.wy1, r1, ct.wy0 * r0);
+        if (p0 + t < NP) bl[(p0 + t) * 64 + lane] = zin[t] ? r : 0.f;
+      }
+    }
+  };
+  // trilinear sample at height j from the slab (aten: z-interpolation of the two bilinear plane values)
+  auto sample = [&](int j) -> float {
+    const int k = min(tz_i0[j] - pmin, NP - 2);                    // 0 <= k, k + 1 < NP
+    return __builtin_fmaf(tz_w1[j], bl[(k + 1) * 64 + lane], tz_w0[j] * bl[k * 64 + lane]);
+  };
+
+  // ---- density: wave 0 .. samples every height; sigma_j -> LDS, voxel_density (+ the raw sample)
+  {
+    const __amdgpu_buffer_rsrc_t rs_vd = bev_rsrc(voxel_density + (long) b * P.oZ * OYX, (size_t) ovol_b);
+    const __amdgpu_buffer_rsrc_t rs_s0 = bev_rsrc(s0_save ? s0_save + (long) b * P.oZ * OYX : voxel_density, s0_save ? (size_t) ovol_b : 0);
+    if (wave == 0) {
+      fetch_planes(bev_rsrc(dens + (long) b * V, (size_t) vol_b), 0u);
+      for (int j = 0; j < P.oZ; ++j) {
+        const float s0 = sample(j);
+        const float sigma = density_fwd(dp, s0);
+        sig[j * 64 + lane] = sigma;
+        bev_store(rs_vd, ocol, (unsigned) j * oplane_b, sigma);
+        bev_store(rs_s0, ocol, (unsigned) j * oplane_b, s0);        // for the backward's scan (zero-size descriptor: dropped)
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- weights (every wave writes the same values: a wave reads back only what it wrote itself)
+  {
+    float cum = 0.f, height = 0.f;
+    for (int j = 0; j < P.oZ; ++j) {
+      const float tau = sig[j * 64 + lane] * (1.0f * P.z_step);                   // bv2:451-453
+      const float wj = (1.0f - expf(-tau)) * expf(-cum);
+      cum += tau;
+      height = __builtin_fmaf(wj, bev_mids[j], height);
+      wgt[j * 64 + lane] = wj;
+    }
+    if (wave == 0 && live) bev_height[(long) b * OYX + col] = height;
+  }
+
+  // ---- channels: [0, K) semantic, [K, K + 3) rgb, [K + 3, K + 3 + C) base; wave g owns g, g + NWV, ...
+  const int nch = P.K + 3 + P.C;
+  const int CO = P.C + (P.cat_seg ? P.K : 0);
+  const __amdgpu_buffer_rsrc_t rs_s = bev_rsrc(sem + (long) b * P.K * V, (size_t) P.K * vol_b);
+  const __amdgpu_buffer_rsrc_t rs_r = bev_rsrc(rgb + (long) b * 3 * V, (size_t) 3 * vol_b);
+  const __amdgpu_buffer_rsrc_t rs_b = bev_rsrc(base + (long) b * P.C * V, (size_t) P.C * vol_b);
+  const __amdgpu_buffer_rsrc_t rs_vo = bev_rsrc(voxel_output + (long) b * CO * P.oZ * OYX, (size_t) CO * ovol_b);
+  const __amdgpu_buffer_rsrc_t rs_ss = bev_rsrc(ss_save ? ss_save + (long) b * (P.K + 3) * P.oZ * OYX : voxel_output,
+                                                ss_save ? (size_t) (P.K + 3) * ovol_b : 0);
+  for (int c = wave; c < nch; c += NWV) {
+    if (c < P.K + 3) {
+      // composited channel (semantic / rgb)
+      if (c < P.K) fetch_planes(rs_s, (unsigned) c * vol_b);
+      else fetch_planes(rs_r, (unsigned) (c - P.K) * vol_b);
+      const bool cat = c < P.K && P.cat_seg;
+      float acc = 0.f;
+      for (int j = 0; j < P.oZ; ++j) {
+        const float sv = sample(j);
+        acc = __builtin_fmaf(wgt[j * 64 + lane], sv, acc);
+        // training: the backward's q_j = sum_c G_c s_j[c] reads the samples back (zero-size descriptor otherwise)
+        bev_store(rs_ss, ocol, (unsigned) c * ovol_b + (unsigned) j * oplane_b, sv);
+        if (cat) bev_store(rs_vo, ocol, (unsigned) (P.C + c) * ovol_b + (unsigned) j * oplane_b, sv);   // bv2:449-450
+      }
+      if (live) {
+        if (c < P.K) bev_seg[((long) b * P.K + c) * OYX + col] = acc;
+        else bev_rgb[((long) b * 3 + (c - P.K)) * OYX + col] = acc;
+      }
+    } else {
+      // pass-through channel (base -> voxel_output)
+      const int cb = c - P.K - 3;
+      fetch_planes(rs_b, (unsigned) cb * vol_b);
+      for (int j = 0; j < P.oZ; ++j)
+        bev_store(rs_vo, ocol, (unsigned) cb * ovol_b + (unsigned) j * oplane_b, sample(j));
+    }
+  }
+}
+
+// Planes a lattice of oZ heights with spacing det_step[2] can touch (+ slack).  Heights that are not
+// such a lattice (the API takes any array) belong to the two-kernel path (VAMP_BEVFWD_TWO_KERNELS).
+static int bev_planes_alloc(const VampRenderDesc* d) {
+  const float per = fabsf(d->det_step[2]) * (float) (d->Z - 1) / d->span[2];       // volume planes per height step
+  return (int) ceilf((float) (d->oZ - 1) * per) + 4;
+}
+
+bool bev_fwd_fused_supported(const VampRenderDesc* d) {
+  const size_t V = (size_t) d->Z * d->Y * d->X;
+  const size_t es = d->in_dtype == VAMP_F32 ? 4 : 2;
+  const size_t cmax = (size_t) (d->K > d->C ? d->K : d->C);
+  const size_t CO = (size_t) d->C + (d->cat_seg ? d->K : 0);
+  const size_t omax = (CO > (size_t) d->K + 3 ? CO : (size_t) d->K + 3) * d->oZ * d->oY * d->oX * 4;
+  return d->oZ <= kFusedMaxOZ && d->X >= 2 && (cmax > 3 ? cmax : 3) * V * es < 0x7fffffffull && omax < 0x7fffffffull &&
+         bev_planes_alloc(d) <= kFusedMaxNP;
+}
+
+int launch_bev_fwd_fused(const VampRenderDesc* d, const RenderParams& P, const float* oxs, const float* oys,
+                         const float* ozs, const float* bev_mids, const float* beta, const void* dens,
+                         const void* sem, const void* rgb, const void* base, float* bev_rgb, float* bev_seg,
+                         float* bev_height, float* voxel_density, float* voxel_output, float* s0_save,
+                         float* ss_save, hipStream_t s) {
+  constexpr int NWV = VAMP_BEVF_NWV;
+  const int np = bev_planes_alloc(d);
+  const long cols = (long) P.oY * P.oX;
+  const dim3 grid((unsigned) (((cols + 63) / 64 + 7) / 8 * 8), (unsigned) P.B);
+  const size_t dyn = sizeof(float) * 64 * (2 * (size_t) P.oZ + (size_t) NWV * np);
+#define VAMP_BEVFU(T)                                                                                     \
+  VAMP_TIMED(kProfBevFwdCh, s, (bev_fwd_fused_kernel<T, NWV><<<grid, NWV * 64, dyn, s>>>(                 \
+      P, np, oxs, oys, ozs, bev_mids, beta, static_cast<const T*>(dens), static_cast<const T*>(sem), \
+      static_cast<const T*>(rgb), static_cast<const T*>(base), bev_rgb, bev_seg, bev_height,              \
+      voxel_density, voxel_output, s0_save, ss_save)))
+  if (d->in_dtype == VAMP_F32) VAMP_BEVFU(float);
+  else VAMP_BEVFU(__hip_bfloat16);
+#undef VAMP_BEVFU
+  return check_launch("bev_fwd_fused_kernel");
+}
+
+}  // namespace vamp

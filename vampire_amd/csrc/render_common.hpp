@@ -237,6 +237,14 @@ int launch_cam_fwd_direct(const VampRenderDesc* d, const RenderParams& P, const 
                           const void* dens, const void* sem, const void* rgb, float* rgb_out,
                           float* seg_out, float* depth_out, int* term_out, bool ert, hipStream_t s);
 
+// render_bev_fused.hip: the BEV forward (density, weights, all channels) as one kernel
+bool bev_fwd_fused_supported(const VampRenderDesc* d);
+int launch_bev_fwd_fused(const VampRenderDesc* d, const RenderParams& P, const float* oxs, const float* oys,
+                         const float* ozs, const float* bev_mids, const float* beta, const void* dens,
+                         const void* sem, const void* rgb, const void* base, float* bev_rgb, float* bev_seg,
+                         float* bev_height, float* voxel_density, float* voxel_output, float* s0_save,
+                         float* ss_save, hipStream_t s);
+
 // 8-tap trilinear gather of CP4*4 packed channels for an INSIDE sample, branch-free: all
 // 8 * CP4 16-byte loads are independent and can be in flight together (a per-tap bounds
 // branch would serialise eight memory round trips).  Inside => tap indices >= 0; a "+1" tap

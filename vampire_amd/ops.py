@@ -119,6 +119,9 @@ class HotPath:
                      # the camera branch as ONE kernel on the channel-first volumes (no packed copy, no
                      # separate termination pass; render_cam_direct.hip)
                      "cam_direct": os.environ.get("VAMP_CAM_DIRECT", "1") != "0",
+                     # the BEV forward as one kernel (render_bev_fused.hip); "0" = the two-kernel first
+                     # implementation, the cross-check of the tests
+                     "bev_fused": os.environ.get("VAMP_BEV_FUSED", "1") != "0",
                      # forward-only calls: BEV branch on the side stream beside the camera branch.  Off for
                      # eager launches (the fork / join costs more than it hides); a caller that captures the
                      # forward into a HIP graph switches it on (bench.py)
@@ -493,6 +496,7 @@ class _RenderFn(torch.autograd.Function):
         ctx.cells = False
         ert = geom is None and hp.impl["ert"]
         direct = geom is None and hp.impl["cam_direct"] and not save and (c.D - 1) <= 128
+        bev_flags = 0 if hp.impl["bev_fused"] else _capi.VAMP_BEVFWD_TWO_KERNELS
         fwd_flags = 0 if ert else _capi.VAMP_CAMFWD_NO_ERT
         split = (side is not None and ert and hp.impl["sched"] == "split" and geom is None
                  and hp.impl["prepare"] and hp.impl["cam_bwd"] != "v1")
@@ -530,7 +534,7 @@ class _RenderFn(torch.autograd.Function):
                 C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
                 _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
                 _ptr(vdens), _ptr(vout), _ptr(ws_bev), ws_bev.numel() if bev_save else 0,
-                _capi.VAMP_BEVFWD_SAVE if bev_save else 0, _stream(cur)), "vamp_render_bev_forward_ex")
+                (_capi.VAMP_BEVFWD_SAVE if bev_save else 0) | bev_flags, _stream(cur)), "vamp_render_bev_forward_ex")
             hp._bev_gen = getattr(hp, "_bev_gen", 0) + 1
             ctx.bev_key = (hp._bev_gen, ws_bev.data_ptr()) if bev_save else None
             cur.wait_event(packed_done)
@@ -551,7 +555,7 @@ class _RenderFn(torch.autograd.Function):
             _capi.check(hp.lib.vamp_render_bev_forward_ex(
                 C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
                 _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
-                _ptr(vdens), _ptr(vout), None, 0, 0, _stream(bstream)), "vamp_render_bev_forward_ex")
+                _ptr(vdens), _ptr(vout), None, 0, bev_flags, _stream(bstream)), "vamp_render_bev_forward_ex")
             ctx.bev_key = None
             _capi.check(hp.lib.vamp_render_camera_forward_ex(
                 C.byref(d), None, _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
@@ -583,7 +587,7 @@ class _RenderFn(torch.autograd.Function):
                 C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
                 _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
                 _ptr(vdens), _ptr(vout), _ptr(ws_bev), ws_bev.numel() if bev_save else 0,
-                _capi.VAMP_BEVFWD_SAVE if bev_save else 0, _stream(side)), "vamp_render_bev_forward_ex")
+                (_capi.VAMP_BEVFWD_SAVE if bev_save else 0) | bev_flags, _stream(side)), "vamp_render_bev_forward_ex")
             hp._bev_gen = getattr(hp, "_bev_gen", 0) + 1
             ctx.bev_key = (hp._bev_gen, ws_bev.data_ptr()) if bev_save else None
             _capi.check(hp.lib.vamp_render_camera_forward_ex(
