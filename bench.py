@@ -157,6 +157,56 @@ def forward_pair_us(model, batch, iters=100, warm=20):
     return ts[len(ts) // 2], ts[len(ts) // 10], ts[(9 * len(ts)) // 10]
 
 
+def forward_pair_graph_us(model, batch, iters=100, warm=20):
+    """The same forward pair replayed from a HIP graph: inside the graph the camera and the BEV
+    branch of the renderer -- which share only their inputs -- run side by side on two streams
+    (HotPath.impl["fwd_overlap"]; the lift is NOT overlapped with the renderer: in the model the 3-D
+    UNet sits between them), and the launches cost no host time.  One HIP-event pair around each
+    replay, median.  Returns None when the capture fails or does not reproduce the eager outputs."""
+    hp = model.hp
+    keep = hp.impl["fwd_overlap"]
+    try:
+        with torch.no_grad():
+            def fwd():
+                return model(batch.depth, batch.feat, batch.vols, batch.lift_mats, batch.render_mats)
+            vox0, outs0 = fwd()
+            ref = [vox0.clone()] + [o.clone() for o in outs0]
+            hp.impl["fwd_overlap"] = True
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    fwd()
+            cur.wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                vox, outs = fwd()
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            for got, want in zip([vox] + list(outs), ref):
+                if not (torch.equal(got, want) or float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())):
+                    raise RuntimeError("graph replay does not reproduce the eager forward")
+            for _ in range(warm):
+                g.replay()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(iters):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); g.replay(); b.record()
+                b.synchronize()
+                ts.append(a.elapsed_time(b) * 1e3)
+        ts.sort()
+        return ts[len(ts) // 2], ts[len(ts) // 10], ts[(9 * len(ts)) // 10]
+    except Exception as e:                          # noqa: BLE001 -- report the eager number only
+        print(f"[bench] forward graph unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+        return None
+    finally:
+        hp.impl["fwd_overlap"] = keep
+
+
 def extra_config(cfg_name, batch, dtype, steps=10, warm=3, ert=True, density_mode=None):
     """A secondary configuration, measured the same way as the headline (fwd+bwd step time with a
     barrier-free single-rank loop) plus its forward pair: driver-observed rather than README prose.
@@ -358,6 +408,43 @@ def main():
         model.hp.impl["overlap"] = overlap
     _capi.profile_select(None)
     fwd_med, fwd_p10, fwd_p90 = forward_pair_us(model, batch) if rank == 0 else (0.0, 0.0, 0.0)
+    fwd_graph = forward_pair_graph_us(model, batch) if (rank == 0 and os.environ.get("VAMP_BENCH_GRAPH", "1") == "1") else None
+
+    # {HIP graph, eager launches} x {early ray termination on, off}: the headline is the best case on
+    # both axes (the termination gain is data-dependent), so the line carries all four (N = 1 only:
+    # no collective inside)
+    step_matrix, ert_stats = None, None
+    if world == 1:
+        def time_loop(fn, n):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n * 1e3
+        step_matrix = {}
+        ert_default = model.hp.impl["ert"]
+        for ert in (True, False):
+            model.hp.impl["ert"] = ert
+            tag = "ert_on" if ert else "ert_off"
+            step_matrix["eager_" + tag + "_ms"] = round(time_loop(one_step, a.steps), 4)
+            if ert == ert_default and graph is not None:
+                step_matrix["graph_" + tag + "_ms"] = round(elapsed / a.steps * 1e3, 4)     # the headline itself
+            elif os.environ.get("VAMP_BENCH_GRAPH", "1") == "1":
+                try:
+                    g2 = capture_step(model, batch, train_step)
+                    step_matrix["graph_" + tag + "_ms"] = round(time_loop(g2.replay, a.steps), 4)
+                    del g2
+                except Exception as e:              # noqa: BLE001
+                    step_matrix["graph_" + tag + "_ms"] = None
+                    print(f"[bench] graph capture ({tag}) unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+        model.hp.impl["ert"] = ert_default
+        inside, kept = model.hp.ert_statistics(batch.vols[0].detach(), model.beta if cfg.density_mode == "sdf" else None,
+                                               batch.render_mats)
+        ert_stats = {"inside_samples": inside, "kept_samples": kept,
+                     "terminated_fraction": round(1.0 - kept / max(1, inside), 4)}
 
     prof = dict(warm)
     # the dominant kernel: measured over the timed region
@@ -382,7 +469,9 @@ def main():
                           "frac_of_hbm_peak": round(sb[st] * a.batch / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                           if us > 0 else None}
         fwd_kernel_sum_us = stages["lift_fwd"]["us"] + stages["render_fwd"]["us"]
-        fwd_us = fwd_med                                 # the pair timed as one unit (forward_pair_us)
+        # the pair timed as one unit: replayed from a HIP graph (camera and BEV branch side by side) when
+        # the capture works, else the eager one-stream launches; both are reported
+        fwd_us = fwd_graph[0] if fwd_graph else fwd_med
         fwd_bytes = sb["fwd"] * a.batch
         fwd_gbs = fwd_bytes / (fwd_us * 1e-6) / 1e9
         line = {
@@ -398,7 +487,10 @@ def main():
                                    f"{cfg.vX}x{cfg.vY}x{cfg.vZ}, det grid {cfg.oX}x{cfg.oY}x{cfg.oZ}, "
                                    f"{a.batch} sample(s)/GPU/step, lift+render fwd+bwd, density_mode={cfg.density_mode} "
                                    f"(the reference's default), camera-branch early ray termination "
-                                   f"{'on' if model.hp.impl['ert'] else 'off'} (T < 1.5e-8)",
+                                   f"{'on' if model.hp.impl['ert'] else 'off'} (T < 1.5e-8)"
+                                   + (f": on this synthetic density (0.5 randn - 1) {100 * ert_stats['terminated_fraction']:.0f} % of the "
+                                      f"inside samples lie behind a saturated ray and are skipped -- data-dependent, see step_matrix "
+                                      f"for the same step with termination off" if ert_stats else ""),
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"dp{world}",
                        "launch": ("the step replayed from a HIP graph (DDP all-reduce issued after each replay); "
@@ -413,10 +505,17 @@ def main():
                          "avg_launch_us": kern[dom]["avg_us"]},
             "fwd_roofline": {"bound": "hbm", "achieved": fwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": fwd_gbs / HBM_PEAK_GBS, "fused_fwd_us": fwd_us,
-                             "p10_us": fwd_p10, "p90_us": fwd_p90, "iters": 100, "warmup": 20,
-                             "timing": "one HIP-event pair around lift + render per iteration, median",
+                             "p10_us": fwd_graph[1] if fwd_graph else fwd_p10, "p90_us": fwd_graph[2] if fwd_graph else fwd_p90,
+                             "iters": 100, "warmup": 20,
+                             "timing": ("one HIP-event pair around each replay of the captured forward (lift, then camera "
+                                        "and BEV branch of the renderer side by side on two streams), median"
+                                        if fwd_graph else "one HIP-event pair around lift + render per iteration, median"),
+                             "eager_one_stream_us": fwd_med, "eager_p10_us": fwd_p10, "eager_p90_us": fwd_p90,
+                             "eager_frac": fwd_bytes / (fwd_med * 1e-6) / 1e9 / HBM_PEAK_GBS,
                              "kernel_sum_us": fwd_kernel_sum_us, "algorithmic_bytes": fwd_bytes},
             "stages": stages,
+            "step_matrix": step_matrix,
+            "early_ray_termination": ert_stats,
             "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in sorted(kern.items())},
             "kernels_us_per_step": {k: round(v["us_per_step"], 2) for k, v in sorted(kern.items())},
         }

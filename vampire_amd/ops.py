@@ -498,7 +498,7 @@ class _RenderFn(torch.autograd.Function):
         direct = geom is None and hp.impl["cam_direct"] and not save and (c.D - 1) <= 128
         bev_flags = 0 if hp.impl["bev_fused"] else _capi.VAMP_BEVFWD_TWO_KERNELS
         fwd_flags = 0 if ert else _capi.VAMP_CAMFWD_NO_ERT
-        split = (side is not None and ert and hp.impl["sched"] == "split" and geom is None
+        split = (train and side is not None and ert and hp.impl["sched"] == "split" and geom is None
                  and hp.impl["prepare"] and hp.impl["cam_bwd"] != "v1")
         if split:
             # Schedule "split": the side stream takes what only the camera branch needs later --
@@ -550,8 +550,10 @@ class _RenderFn(torch.autograd.Function):
             ctx.ert = ert
             bstream = cur
             if side is not None:
-                side.wait_stream(cur)
+                side.wait_stream(cur)                 # fork: the BEV branch waits for what precedes the renderer only
                 bstream = side
+            # (BEV first: issued second it starts ~5 us behind the camera kernel, finds the CUs taken and
+            # takes twice as long -- 129 vs 123 us for the replayed pair at cfg-B)
             _capi.check(hp.lib.vamp_render_bev_forward_ex(
                 C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
                 _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
