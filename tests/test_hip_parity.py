@@ -1338,7 +1338,7 @@ def test_camera_direct_forward_tiny(tiny_common, dev, mode, cat_seg):
         with torch.no_grad():
             old = hp.render(*vols, beta, render_mats=rm)
         for nm, a, b_ in zip(NAMES[:3], outs, old):
-            close(a, b_, atol=2e-5, rtol=1e-5, what=f"direct vs packed {mode} ert={ert} {nm}")
+            close(a, b_, atol=5e-5, rtol=2e-5, what=f"direct vs packed {mode} ert={ert} {nm}")
     # bf16 volumes: the kernel reads the 2-byte elements itself
     hp = hot(cfg, dev)
     vb = [v.bfloat16() for v in vols]
@@ -1363,8 +1363,12 @@ def test_camera_direct_forward_full_size(dev, regime):
         new = hp.render(*vols, beta, render_mats=rm)
         hp.impl["cam_direct"] = False
         old = hp.render(*vols, beta, render_mats=rm)
+    # (the one-kernel forward evaluates the sample positions from a per-ray line set up in fp64 -- the
+    # correctly rounded tap coordinates -- where the packed march repeats the reference's fp32 chain bit
+    # for bit: the two differ by the reference's own rounding, ~1e-5 voxel, which on these white-noise
+    # volumes, the worst case, moves a composited value by up to 3e-5; the bar is 1e-4)
     for nm, a, b_ in zip(NAMES[:3], new, old):
-        close(a, b_, atol=(3 * 1.2e-7 * cfg.d_bound[1] if nm == "depth_preds" else 1e-7), rtol=1e-5, scale="max",
+        close(a, b_, atol=(3 * 1.2e-7 * cfg.d_bound[1] if nm == "depth_preds" else 1e-7), rtol=5e-5, scale="max",
               what=f"{regime} direct vs packed {nm}")
     if regime != "sdf":
         with open(os.path.join(GOLDEN, "regime_checksums.json")) as f:

@@ -20,6 +20,11 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"] + os.environ.get("VAMP_EXTRA_FLAGS", "").split()
 
 
+# per-file flags.  -fno-slp-vectorize: hipcc pairs the per-channel fma chains of the gathers into
+# v_pk_* instructions and spends as many v_mov on building the register pairs as it saves
+FILE_FLAGS = {}
+
+
 def lib_path() -> str:
     return os.path.join(LIBDIR, LIBNAME)
 
@@ -42,7 +47,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + FILE_FLAGS.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

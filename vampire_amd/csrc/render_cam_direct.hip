@@ -152,11 +152,117 @@ __device__ __forceinline__ float density_fast(const DensityParams& dp, float s) 
   return dp.ib * (t > 0.f ? e : (t < 0.f ? 1.0f - e : 0.5f));
 }
 
+#ifdef VAMP_DIRECT_STAMPS
+// diagnostic build only (tools/debug/cam_stamps.py): per-tile phase stamps of wave 0
+__device__ long long g_direct_stamps[4096 * 8];
+#define VAMP_STAMP(k)                                                                 \
+  do {                                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_direct_stamps[blockIdx.x * 8 + (k)] = (long long) __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define VAMP_STAMP(k) do { } while (0)
+#endif
+
 constexpr int kDirectG = 4;               // depth indices a wave takes per round of the density phase
 #ifndef VAMP_DIRECT_CB
 #define VAMP_DIRECT_CB 4
 #endif
 constexpr int kDirectCB = VAMP_DIRECT_CB; // channels whose loads are in flight together in the gather
+
+// ---------------------------------------------------------------------------
+// The sample points of one ray as a line in tap coordinates.
+//
+// get_geometry (bv2:328-349) maps (u, v, d, 1) through inv(ida), multiplies x and y by z, then
+// through two more matrices.  When inv(ida)'s x and y rows do not depend on the depth (entries
+// [0][2] and [1][2] are zero: image-plane augmentations never touch depth) the result is AFFINE in
+// d, and so are the continuous tap coordinates f = (p - lo) / span * (size - 1) of bv2:397-404 /
+// aten's align_corners=True rule.  The line f(d) = A + d B is set up once per ray in fp64 (the exact
+// chain at the first and the last depth plane) and evaluated per sample with three fp64 fma: ~25
+// vector instructions instead of the ~160 of the fp32 chain with its three IEEE divisions, which is
+// what this kernel was bound by.  f(d) is the correctly rounded value of the exact map; the
+// reference's own fp32 chain deviates from that by its accumulated rounding (a few ulp of f, 1e-5
+// voxel), which moves a trilinear sample by < 3e-5 on white-noise volumes (bar: 1e-4).  The one thing
+// that is NOT continuous in f is the inclusive inside mask (bv2:405-407): whenever a lane of the wave
+// is within 1e-3 voxel of a face of the volume, the wave evaluates the reference's fp32 chain for that
+// depth index, so the mask is the reference's bit for bit.
+// ---------------------------------------------------------------------------
+struct RayLine {
+  double ax, bx, ay, by, az, bz;      // tap coordinates: f = a + d * b
+  float len;                          // ego-space length of the ray per unit of depth (bv2:426)
+};
+
+__device__ __forceinline__ void chain_f64(const float* __restrict__ m, const RenderParams& P, double u, double v,
+                                          double d, double& ex, double& ey, double& ez) {
+  double p[4], q[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) p[r] = (double) m[4 * r] * u + (double) m[4 * r + 1] * v + (double) m[4 * r + 2] * d + (double) m[4 * r + 3];
+  p[0] *= p[2]; p[1] *= p[2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) q[r] = (double) m[16 + 4 * r] * p[0] + (double) m[17 + 4 * r] * p[1] + (double) m[18 + 4 * r] * p[2] + (double) m[19 + 4 * r] * p[3];
+  ex = (double) m[32] * q[0] + (double) m[33] * q[1] + (double) m[34] * q[2] + (double) m[35] * q[3];
+  ey = (double) m[36] * q[0] + (double) m[37] * q[1] + (double) m[38] * q[2] + (double) m[39] * q[3];
+  ez = (double) m[40] * q[0] + (double) m[41] * q[1] + (double) m[42] * q[2] + (double) m[43] * q[3];
+}
+
+__device__ __forceinline__ RayLine ray_line(const float* __restrict__ m, const RenderParams& P, float u, float v,
+                                            float d0, float d1) {
+  double x0, y0, z0, x1, y1, z1;
+  chain_f64(m, P, u, v, d0, x0, y0, z0);
+  chain_f64(m, P, u, v, d1, x1, y1, z1);
+  const double inv = 1.0 / ((double) d1 - (double) d0);
+  const double sx = (double) (P.X - 1) / (double) P.span[0], sy = (double) (P.Y - 1) / (double) P.span[1],
+               sz = (double) (P.Z - 1) / (double) P.span[2];
+  RayLine L;
+  const double dx = (x1 - x0) * inv, dy = (y1 - y0) * inv, dz = (z1 - z0) * inv;
+  L.bx = dx * sx; L.by = dy * sy; L.bz = dz * sz;
+  L.ax = (x0 - (double) P.lo[0]) * sx - (double) d0 * L.bx;
+  L.ay = (y0 - (double) P.lo[1]) * sy - (double) d0 * L.by;
+  L.az = (z0 - (double) P.lo[2]) * sz - (double) d0 * L.bz;
+  L.len = (float) sqrt(dx * dx + dy * dy + dz * dz);
+  return L;
+}
+
+// tap of the sample at depth d: from the line, or -- `exact`, wave-uniform -- from the fp32 chain
+__device__ __forceinline__ VolTap line_tap(const RenderParams& P, const RayLine& L, float d, bool& near_face) {
+  const float fx = (float) __builtin_fma((double) d, L.bx, L.ax);
+  const float fy = (float) __builtin_fma((double) d, L.by, L.ay);
+  const float fz = (float) __builtin_fma((double) d, L.bz, L.az);
+  const float X1 = (float) (P.X - 1), Y1 = (float) (P.Y - 1), Z1 = (float) (P.Z - 1);
+  VolTap t;
+  t.inside = fx >= 0.f && fx <= X1 && fy >= 0.f && fy <= Y1 && fz >= 0.f && fz <= Z1;
+  const float e = fminf(fminf(fminf(fabsf(fx), fabsf(fx - X1)), fminf(fabsf(fy), fabsf(fy - Y1))),
+                        fminf(fabsf(fz), fabsf(fz - Z1)));
+  near_face = !(e > 1e-3f);                         // (also true for a NaN coordinate)
+  const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+  t.ix0 = (int) flx; t.iy0 = (int) fly; t.iz0 = (int) flz;
+  t.wx1 = fx - flx; t.wx0 = (flx + 1.0f) - fx;
+  t.wy1 = fy - fly; t.wy0 = (fly + 1.0f) - fy;
+  t.wz1 = fz - flz; t.wz0 = (flz + 1.0f) - fz;
+  t.fx = fx; t.fy = fy; t.fz = fz;
+  return t;
+}
+
+// tile -> ray with 32-bit arithmetic (decode_ray_wps of render_common.hpp divides 64-bit values)
+__device__ __forceinline__ RayId decode_tile(const RenderParams& P) {
+  const int tiles_w = (P.fW + 7) >> 3, tiles_h = (P.fH + 7) >> 3;
+  const int per_cam = tiles_h * tiles_w, tiles = P.B * P.N * per_cam;
+  const int per_xcd = (tiles + 7) >> 3;
+  const int t = (int) (blockIdx.x & 7u) * per_xcd + (int) (blockIdx.x >> 3);
+  const int r = threadIdx.x & 63;
+  RayId id;
+  id.sub = threadIdx.x >> 6;
+  const int tc = t < tiles ? t : tiles - 1;
+  const int bn = tc / per_cam, tt = tc - bn * per_cam;
+  const int ty = tt / tiles_w, tx = tt - ty * tiles_w;
+  id.bn = bn;
+  id.h = ty * 8 + (r >> 3);
+  id.w = tx * 8 + (r & 7);
+  id.live = t < tiles && id.h < P.fH && id.w < P.fW;
+  if (id.h >= P.fH) id.h = P.fH - 1;
+  if (id.w >= P.fW) id.w = P.fW - 1;
+  id.b = bn / P.N;
+  return id;
+}
 
 // NCH = composited channels (K + 3), rounded up by the launcher; channels >= K + 3 are skipped.
 // NW = waves per 8 x 8 ray tile.  LDS: plan (2 KB) + round sums + dyn = max(S, NW * NCH) * 64 floats
@@ -172,24 +278,42 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
   extern __shared__ __align__(16) float dyn[];
   __shared__ int4 plan[kPlanMax];
   __shared__ int keep_s[64];
-  __shared__ float accw_s[64], accd_s[64];
+  __shared__ float accw_s[64], accd_s[64], tunit_s[64];
   __shared__ float part_s[2][NW][64];
+  __shared__ unsigned char act_s[kPlanMax + 8];                  // the active depth indices, in order (then S)
+  __shared__ unsigned char actf_s[kPlanMax];                     // 1 = active depth index
   float* wbuf = dyn;                                                // [S][64]
   const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const RayId id = decode_ray_wps(P);
+  const RayId id = decode_tile(P);
   const int w = id.w, h = id.h;
-  const long bn = __builtin_amdgcn_readfirstlane((int) id.bn);
+  const int bn = __builtin_amdgcn_readfirstlane((int) id.bn);
   const int b = __builtin_amdgcn_readfirstlane(id.b);
   const DensityParams dp = load_density(P.density_mode, beta_raw, P.beta_min, P.sdf_bias);
   const int S = P.D - 1;
-  const float* m = mats + bn * 48;
+  const float* m = mats + (long) bn * 48;
   const float u = us[w], v = vs[h];
-  const long V = (long) P.Z * P.Y * P.X;
+  const unsigned V = (unsigned) (P.Z * P.Y * P.X);
   const int nch = P.K + 3;
-  const RayBase rb = ray_base(m, u, v);
-
-  auto point = [&](int i, float& x, float& y, float& z) { frustum_point_rb(m, rb, ds[i], x, y, z); };
+  VAMP_STAMP(0);
+  // the ray as a line in tap coordinates; `affine`: the chain is affine in the depth (see RayLine)
+  const bool affine = m[2] == 0.0f && m[6] == 0.0f;               // uniform
+  const RayLine L = ray_line(m, P, u, v, ds[0], ds[S]);
+  // tap of depth index i: the line, or the reference's fp32 chain where the inside mask is decided
+  auto tap_at = [&](int i) -> VolTap {
+    bool near_face;
+    VolTap tp = line_tap(P, L, ds[i], near_face);
+    if (!affine || __any(near_face)) {
+      // (rare: the matrices are read again here instead of living in 36 scalar registers -- which the
+      // allocator does not have: they came back through v_readlane -- across the whole kernel)
+      const float* mm = m;
+      asm volatile("" : "+s"(mm));
+      float x, y, z;
+      frustum_point(mm, u, v, ds[i], x, y, z);
+      tp = volume_tap(P, nan_to_num_geom(x), nan_to_num_geom(y), nan_to_num_geom(z));
+    }
+    return tp;
+  };
 
   // ---- plan: depth indices of the tile that can hold inside samples (waves 0..3 plan 32 each)
   if (sub < 4)
@@ -198,29 +322,29 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
   __syncthreads();
   const PlanMask mk_all = plan_mask(plan);
   const int A = __builtin_popcountll(mk_all.lo) + __builtin_popcountll(mk_all.hi);
-#if defined(VAMP_DIRECT_STOP) && VAMP_DIRECT_STOP == 1
-  if (mk_all.lo != 0x1234567ull) return;
-#endif
+  // the active indices as a list (rank -> depth index) and as flags, so that the loops below index
+  // LDS instead of walking the bit masks (75 scalar instructions per index)
+  if (sub == 0) {
+    const bool a_lo = (mk_all.lo >> lane) & 1ull, a_hi = (mk_all.hi >> lane) & 1ull;
+    const int r_lo = __builtin_popcountll(mk_all.lo & ((1ull << lane) - 1ull));
+    const int r_hi = __builtin_popcountll(mk_all.lo) + __builtin_popcountll(mk_all.hi & ((1ull << lane) - 1ull));
+    if (a_lo) act_s[r_lo] = (unsigned char) lane;
+    if (a_hi) act_s[r_hi] = (unsigned char) (64 + lane);
+    if (lane < 8) act_s[A + lane] = (unsigned char) S;           // ranks past the end read S ("none")
+    actf_s[lane] = a_lo ? 1 : 0;
+    actf_s[64 + lane] = a_hi ? 1 : 0;
+    // masked samples carry density(0) (Q6): optical depth per unit of depth of the skipped bins
+    tunit_s[lane] = density_fast(dp, 0.f) * L.len;
+  }
+  __syncthreads();
+  VAMP_STAMP(1);
 
-  // ---- density: tau_i = sigma_i delta_i of every depth index into LDS
+  // ---- density: tau_i = sigma_i delta_i of the active depth indices into LDS, in rounds of NW * G: a
+  // wave takes G consecutive active indices, all its taps in flight together; after each round every
+  // wave knows every ray's optical depth so far, and the tile stops once all 64 rays are saturated
   int S_eff = S;                      // depth indices the scan covers (early exit: the tile is saturated there)
   {
-    // (the frustum points of a ray are affine in the depth: one bin length per unit of depth)
-    float tau_unit;
-    {
-      float px, py, pz, qx, qy, qz;
-      point(0, px, py, pz);
-      point(1, qx, qy, qz);
-      const float dx = qx - px, dy = qy - py, dz = qz - pz;
-      tau_unit = density_fast(dp, 0.f) * (sqrtf(dx * dx + dy * dy + dz * dz) / (ds[1] - ds[0]));   // masked sample -> density(0) (Q6)
-    }
-    // depth indices at which no ray of the tile is inside the volume: s = 0 (bv2:426 for samples the
-    // mask zeroes; equal to the exact norm up to rounding)
-    for (int i = sub; i < S; i += NW)
-      if (!mask_test(mk_all, i)) wbuf[i * 64 + lane] = tau_unit * (ds[i + 1] - ds[i]);
-    // the others in rounds of NW * G: a wave takes G consecutive active indices, all its taps in
-    // flight together; after each round every wave knows every ray's optical depth so far, and the
-    // tile stops once all 64 rays are saturated
+    const float tau_unit = tunit_s[lane];
     const __amdgpu_buffer_rsrc_t rs_d = make_rsrc(dens + (long) b * V, (size_t) V * sizeof(T));
     constexpr int G = kDirectG, R = NW * G;
     float carry = 0.f;                // sum of the active indices' tau so far (per ray)
@@ -228,25 +352,19 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
     int cursor = 0;                   // depth index where the current round starts
     for (int r0 = 0, rd = 0; r0 < A; r0 += R, ++rd) {
       int idx[G];
-      idx[0] = mask_skip(mk_all, cursor, sub * G);
 #pragma unroll
-      for (int g = 1; g < G; ++g) idx[g] = idx[g - 1] < kPlanMax ? mask_next(mk_all, idx[g - 1] + 1) : kPlanMax;
-      float s0[G], delta[G];
+      for (int g = 0; g < G; ++g)
+        idx[g] = __builtin_amdgcn_readfirstlane((int) act_s[min(r0 + sub * G + g, A)]);
+      float delta[G];
       bool in[G];
       PairTap pt[G];
       PairRaw raw[G][4];
-      float px, py, pz, qx = 0.f, qy = 0.f, qz = 0.f;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         in[g] = false; delta[g] = 0.f;
         if (idx[g] < S) {
-          // (consecutive depth indices share a frustum point)
-          if (g > 0 && idx[g] == idx[g - 1] + 1) { px = qx; py = qy; pz = qz; }
-          else point(idx[g], px, py, pz);
-          point(idx[g] + 1, qx, qy, qz);
-          const VolTap tp = volume_tap(P, px, py, pz);
-          const float dx = qx - px, dy = qy - py, dz = qz - pz;
-          delta[g] = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);               // bv2:426
+          const VolTap tp = tap_at(idx[g]);
+          delta[g] = L.len * (ds[idx[g] + 1] - ds[idx[g]]);                            // bv2:426
           in[g] = tp.inside;
           if (tp.inside) {
             pt[g] = pair_tap<T>(P, tp);
@@ -270,14 +388,21 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
       }
       part_s[rd & 1][sub][lane] = psum;
       // where the next round starts, and the skipped bins in front of it
-      const int nxt = (r0 + R >= A) ? S : mask_skip(mk_all, cursor, R);
-      for (int i = cursor; i < nxt; ++i)
-        if (!mask_test(mk_all, i)) d_inact += ds[i + 1] - ds[i];
+      const int nxt = (r0 + R >= A) ? S : __builtin_amdgcn_readfirstlane((int) act_s[r0 + R]);
+      if (ERT) {
+        // (ds is the depth-plane lattice: the skipped extent is the whole extent minus the active bins')
+        float act_ext = 0.f;
+        for (int k = r0; k < min(r0 + R, A); ++k) {
+          const int i = __builtin_amdgcn_readfirstlane((int) act_s[k]);
+          act_ext += ds[i + 1] - ds[i];
+        }
+        d_inact += (ds[nxt] - ds[cursor]) - act_ext;
+      }
       cursor = nxt;
       __syncthreads();
-#pragma unroll
-      for (int k = 0; k < NW; ++k) carry += part_s[rd & 1][k][lane];
       if (ERT) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) carry += part_s[rd & 1][k][lane];
         // (the margin covers the different summation order of the scan below)
         const bool done = carry + tau_unit * d_inact >= kTermOpticalDepth * 1.001f;
         if (__ballot(!done) == 0ull) { S_eff = nxt; break; }
@@ -285,18 +410,25 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
     }
   }
   __syncthreads();
+  VAMP_STAMP(2);
 #if defined(VAMP_DIRECT_STOP) && VAMP_DIRECT_STOP == 2
   if (wbuf[lane] != 12345.f) return;
 #endif
 
-  // ---- scan: lanes = (ray of this wave's 64 / NW, segment of the depth range)
+  // ---- scan: lanes = (ray of this wave's 64 / NW, segment of the depth range); the bins of inactive
+  // depth indices are all-masked samples: tau = density(0) * bin length
   {
     constexpr int RPW = 64 / NW, SEG = NW;
     const int r = sub * RPW + (lane % RPW), q = lane / RPW;
-    const int L = (S_eff + SEG - 1) / SEG;
-    const int a0 = min(S_eff, q * L), a1 = min(S_eff, a0 + L);
+    const int L_ = (S_eff + SEG - 1) / SEG;
+    const int a0 = min(S_eff, q * L_), a1 = min(S_eff, a0 + L_);
+    const float tu = tunit_s[r];
     float part = 0.f;
-    for (int i = a0; i < a1; ++i) part += wbuf[i * 64 + r];
+    for (int i = a0; i < a1; ++i) {
+      const float tau = actf_s[i] ? wbuf[i * 64 + r] : tu * (ds[i + 1] - ds[i]);
+      wbuf[i * 64 + r] = tau;
+      part += tau;
+    }
     // exclusive prefix over the segments of the ray (bv2:431-433: exclusive cumsum)
     float incl = part;
 #pragma unroll
@@ -326,6 +458,7 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
     if (q == 0) { keep_s[r] = min(keep, S_eff < S ? S_eff : S); accw_s[r] = aw; accd_s[r] = ad; }
   }
   __syncthreads();
+  VAMP_STAMP(3);
 #if defined(VAMP_DIRECT_STOP) && VAMP_DIRECT_STOP == 3
   if (keep_s[lane] != 12345) return;
 #endif
@@ -336,52 +469,57 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) Se = max(Se, __shfl_xor(Se, o, 64));
   Se = __builtin_amdgcn_readfirstlane(Se);
-  PlanMask mk = mk_all;
-  mask_truncate(mk, Se);
   float acc[NCH];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) acc[c] = 0.f;
   {
-    int i0, i1;
-    plan_share_n<NW>(mk, Se, sub, i0, i1);
+    // the active indices below Se, dealt to the waves by rank
+    PlanMask mk = mk_all;
+    mask_truncate(mk, Se);
+    const int Ae = __builtin_popcountll(mk.lo) + __builtin_popcountll(mk.hi);
+    const int k0 = (sub * Ae) / NW, k1 = ((sub + 1) * Ae) / NW;
     const __amdgpu_buffer_rsrc_t rs_s = make_rsrc(sem + (long) b * P.K * V, (size_t) P.K * V * sizeof(T));
     const __amdgpu_buffer_rsrc_t rs_r = make_rsrc(rgb + (long) b * 3 * V, (size_t) 3 * V * sizeof(T));
-    const unsigned vbytes = (unsigned) V * (unsigned) sizeof(T);     // one channel, bytes (launcher: K * V * es < 2 GB)
-    for (int i = mask_next(mk, i0); i < i1; i = mask_next(mk, i + 1)) {
-      float px, py, pz;
-      point(i, px, py, pz);
-      const VolTap tp = volume_tap(P, px, py, pz);
+    const unsigned vbytes = V * (unsigned) sizeof(T);               // one channel, bytes (launcher: K * V * es < 2 GB)
+    for (int k = k0; k < k1; ++k) {
+      const int i = __builtin_amdgcn_readfirstlane((int) act_s[k]);
+      const VolTap tp = tap_at(i);
       if (tp.inside && i < keep) {
         const PairTap pt = pair_tap<T>(P, tp);
         const float wgt = wbuf[i * 64 + lane];
         float s[NCH];
+        // (the per-channel byte offsets are recomputed here, one s_mul each: hoisted out of the loop they
+        // were 21 more live scalars than the register file has, and came back through v_readlane)
+        unsigned vb = vbytes;
+        asm volatile("" : "+s"(vb));
         // channels in batches of kDirectCB: all 4 * CB pair loads of a batch are issued back to back
 #pragma unroll
         for (int c0 = 0; c0 < NCH; c0 += kDirectCB) {
           PairRaw raw[kDirectCB][4];
 #pragma unroll
-          for (int u = 0; u < kDirectCB; ++u) {
-            if (c0 + u < NCH) {
-              const int cc = min(c0 + u, nch - 1);
+          for (int uu = 0; uu < kDirectCB; ++uu) {
+            if (c0 + uu < NCH) {
+              const int cc = min(c0 + uu, nch - 1);
               const bool is_sem = cc < P.K;
               const __amdgpu_buffer_rsrc_t rs = is_sem ? rs_s : rs_r;
-              const unsigned so = (unsigned) (is_sem ? cc : cc - P.K) * vbytes;
-              raw[u][0] = ld_pair<T>(rs, pt.o00, so);
-              raw[u][1] = ld_pair<T>(rs, pt.o01, so);
-              raw[u][2] = ld_pair<T>(rs, pt.o10, so);
-              raw[u][3] = ld_pair<T>(rs, pt.o11, so);
+              const unsigned so = (unsigned) (is_sem ? cc : cc - P.K) * vb;
+              raw[uu][0] = ld_pair<T>(rs, pt.o00, so);
+              raw[uu][1] = ld_pair<T>(rs, pt.o01, so);
+              raw[uu][2] = ld_pair<T>(rs, pt.o10, so);
+              raw[uu][3] = ld_pair<T>(rs, pt.o11, so);
             }
           }
 #pragma unroll
-          for (int u = 0; u < kDirectCB; ++u)
-            if (c0 + u < NCH) s[c0 + u] = pair_combine<T>(pt, raw[u]);
+          for (int uu = 0; uu < kDirectCB; ++uu)
+            if (c0 + uu < NCH) s[c0 + uu] = pair_combine<T>(pt, raw[uu]);
         }
         // nan_to_num of the sampled features (bv2:421) only where something is not finite:
         // sum_c 0 * s_c is nan exactly then
         float chk = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) chk = __builtin_fmaf(s[c], 0.f, chk);
-        if (chk != chk) {
+        if (__builtin_expect(chk != chk, 0)) {
+          asm volatile("" ::: "memory");                     // (keeps the rare path a branch: if-converted it is ~95 instructions per sample)
 #pragma unroll
           for (int c = 0; c < NCH; ++c) s[c] = nan_to_num(s[c]);
         }
@@ -391,28 +529,40 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
     }
   }
   __syncthreads();                                                   // all reads of wbuf are done
+  VAMP_STAMP(4);
+#ifdef VAMP_DIRECT_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 4096)
+    g_direct_stamps[blockIdx.x * 8 + 6] = ((long long) A << 32) | ((long long) S_eff << 16) | (long long) Se;
+#endif
 
   // ---- merge the waves' partial sums; stores
   float* xa = dyn;                                                   // [NW][NCH][64]
 #pragma unroll
   for (int c = 0; c < NCH; ++c) xa[(sub * NCH + c) * 64 + lane] = acc[c];
   __syncthreads();
-  const long HW = (long) P.fH * P.fW;
-  const long pix = (long) h * P.fW + w;
+  const int HW = P.fH * P.fW;
+  const int pix = h * P.fW + w;
   if (id.live) {
     for (int c = sub; c < nch; c += NW) {
       float t = 0.f;
 #pragma unroll
       for (int k = 0; k < NW; ++k) t += xa[(k * NCH + c) * 64 + lane];
-      if (c < P.K) seg_out[(bn * P.K + c) * HW + pix] = t;
-      else rgb_out[(bn * 3 + (c - P.K)) * HW + pix] = t;
+      if (c < P.K) seg_out[((long) bn * P.K + c) * HW + pix] = t;
+      else rgb_out[((long) bn * 3 + (c - P.K)) * HW + pix] = t;
     }
     if (sub == 0) {
-      depth_out[bn * HW + pix] = accd_s[lane] + (1.0f - accw_s[lane]) * P.d_far;   // bv2:436,440
-      if (term_out) term_out[bn * HW + pix] = keep;
+      depth_out[(long) bn * HW + pix] = accd_s[lane] + (1.0f - accw_s[lane]) * P.d_far;   // bv2:436,440
+      if (term_out) term_out[(long) bn * HW + pix] = keep;
     }
   }
+  VAMP_STAMP(5);
 }
+
+#ifdef VAMP_DIRECT_STAMPS
+extern "C" int vamp_debug_direct_stamps(long long* host, size_t n) {
+  return (int) hipMemcpyFromSymbol(host, HIP_SYMBOL(g_direct_stamps), n * sizeof(long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 #ifndef VAMP_DIRECT_NW
 #define VAMP_DIRECT_NW 4
