@@ -498,9 +498,47 @@ class _RenderFn(torch.autograd.Function):
         direct = geom is None and hp.impl["cam_direct"] and not save and (c.D - 1) <= 128
         bev_flags = 0 if hp.impl["bev_fused"] else _capi.VAMP_BEVFWD_TWO_KERNELS
         fwd_flags = 0 if ert else _capi.VAMP_CAMFWD_NO_ERT
-        split = (train and side is not None and ert and hp.impl["sched"] == "split" and geom is None
+        split = (train and side is not None and (ert or direct) and hp.impl["sched"] == "split" and geom is None
                  and hp.impl["prepare"] and hp.impl["cam_bwd"] != "v1")
-        if split:
+        if split and direct:
+            # Training step, one-kernel camera forward: this stream runs the camera kernel (which leaves
+            # the per-ray termination table in the workspace) and then the BEV forward; the side stream
+            # makes the channel-last copy the backward's per-ray pass gathers from and, once the table
+            # is there, the backward's geometry-only prepare pass.  Critical chains at cfg-B: 45 + 38 us
+            # here, max(copy 37, camera 45) + prepare 58 there (was: table 19 + copy 37 + prepare 58
+            # beside BEV 55 + march 40).
+            side.wait_stream(cur)
+            ctx.ert = ert
+            _capi.check(hp.lib.vamp_render_camera_forward_ex(
+                C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
+                _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
+                _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(),
+                fwd_flags | _capi.VAMP_CAMFWD_TERM_VALID | _capi.VAMP_CAMFWD_PACK_ONLY, _stream(side)),
+                "vamp_render_camera_forward_ex")
+            _capi.check(hp.lib.vamp_render_camera_forward_ex(
+                C.byref(d), None, _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
+                _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
+                _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(),
+                fwd_flags | _capi.VAMP_CAMFWD_DIRECT, _stream(cur)), "vamp_render_camera_forward_ex")
+            term_done = torch.cuda.Event()
+            term_done.record(cur)
+            side.wait_event(term_done)
+            late = hp.impl["slots_late"] and hp.impl["heavy_side"]
+            _capi.check(hp.lib.vamp_render_camera_prepare_ex(
+                C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(),
+                _capi.VAMP_CAMPREP_TERM_VALID | (_capi.VAMP_CAMPREP_RANK_ONLY if late else 0), _stream(side)),
+                "vamp_render_camera_prepare_ex")
+            ctx.cells = 2 if late else True
+            bev_save = train and hp.impl["bev_save"] and hp.impl["bev_bwd"] != "v1"
+            ws_bev = (hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d))) if bev_save else None)
+            _capi.check(hp.lib.vamp_render_bev_forward_ex(
+                C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
+                _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
+                _ptr(vdens), _ptr(vout), _ptr(ws_bev), ws_bev.numel() if bev_save else 0,
+                (_capi.VAMP_BEVFWD_SAVE if bev_save else 0) | bev_flags, _stream(cur)), "vamp_render_bev_forward_ex")
+            hp._bev_gen = getattr(hp, "_bev_gen", 0) + 1
+            ctx.bev_key = (hp._bev_gen, ws_bev.data_ptr()) if bev_save else None
+        elif split and ert:
             # Schedule "split": the side stream takes what only the camera branch needs later --
             # termination table, channel-last copy, then the backward's prepare pass -- and this
             # stream the BEV branch, then the march once table and copy are there.  The critical
