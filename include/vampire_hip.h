@@ -120,7 +120,6 @@ int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs
 #define VAMP_LIFTBWD_WPP16 16
 #define VAMP_LIFTBWD_HALF_LO 64   /* only the lower half of the flattened (sample, camera) images: with CELLS_VALID, ... */
 #define VAMP_LIFTBWD_HALF_HI 128  /* ... the two halves touch disjoint records and outputs and may run on two streams */
-#define VAMP_LIFTBWD_TILE 32     /* pixel-tile owners with LDS accumulators (lift_bwd_tile.hip); C <= 16 */
 int vamp_lift_prepare(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                       const float* zs, void* workspace, size_t workspace_bytes, void* stream);
 int vamp_lift_backward_ex(const VampLiftDesc* d, const float* mats, const float* xs,

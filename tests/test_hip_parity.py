@@ -770,9 +770,8 @@ def test_lift_backward_cell_matches_atomic_splat_full_size(dev, monkeypatch, cfg
     d6, f6 = run("cell")
     hp.impl["lift_wpp"] = 0
     d1, f1 = run("v1")          # per-voxel float-atomic splat
-    d7, f7 = run("tile")        # pixel-tile owners, fixed-point LDS accumulators
     assert float(d1.abs().max()) > 0 and float(f1.abs().max()) > 0
-    for tag, dd, ff in (("cell", d4, f4), ("cell wpp4", d5, f5), ("cell wpp16", d6, f6), ("tile", d7, f7)):
+    for tag, dd, ff in (("cell", d4, f4), ("cell wpp4", d5, f5), ("cell wpp16", d6, f6)):
         close(dd, d1, atol=1e-6, rtol=2e-5, scale="max", what=tag + " vs splat grad_depth")
         close(ff, f1, atol=1e-6, rtol=2e-5, scale="max", chan_dim=2, what=tag + " vs splat grad_feat")
 
@@ -887,11 +886,11 @@ def _upstream(shapes, seed, dev):
     return [(torch.randn(s, generator=g) * 1e-3).to(dev) for s in shapes]
 
 
-@pytest.mark.parametrize("impl", ["default", "tile", "v1"])
+@pytest.mark.parametrize("impl", ["default", "v1"])
 @pytest.mark.parametrize("name,cfg", [("A", CFG_A), ("B", CFG_B)])
 def test_full_size_gradients_match_reference(dev, name, cfg, impl):
-    """cfg-A / cfg-B at B=1: every gradient of the HIP backward -- the default cell-list path, the
-    pixel-tile lift backward AND the v1 float-atomic cross-check path -- against the REFERENCE run
+    """cfg-A / cfg-B at B=1: every gradient of the HIP backward -- the default cell-list path AND the
+    v1 float-atomic cross-check path -- against the REFERENCE run
     with autograd on the same seeded inputs and upstream gradients
     (tests/golden/full_grad_checksums.json)."""
     with open(os.path.join(GOLDEN, "full_grad_checksums.json")) as f:
@@ -899,9 +898,7 @@ def test_full_size_gradients_match_reference(dev, name, cfg, impl):
     with open(os.path.join(GOLDEN, "full_checksums.json")) as f:
         mats = json.load(f)[name]
     hp = hot(cfg, dev)
-    if impl == "tile":
-        hp.impl["lift_bwd"] = "tile"
-    elif impl != "default":
+    if impl != "default":
         hp.impl["cam_bwd"] = hp.impl["lift_bwd"] = hp.impl["bev_bwd"] = impl
     lm = torch.tensor(mats["lift_mats"], dtype=torch.float32, device=dev)
     rm = torch.tensor(mats["render_mats"], dtype=torch.float32, device=dev)

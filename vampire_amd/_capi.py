@@ -55,7 +55,6 @@ VAMP_PAD_ZEROS, VAMP_PAD_BORDER = 0, 1
 # flag bits of vamp_lift_backward_ex / vamp_render_camera_backward_acc (include/vampire_hip.h)
 VAMP_LIFTBWD_CELLS_VALID, VAMP_LIFTBWD_SPLAT = 1, 2
 VAMP_LIFTBWD_WPP1, VAMP_LIFTBWD_WPP4, VAMP_LIFTBWD_WPP16 = 4, 8, 16
-VAMP_LIFTBWD_TILE = 32
 VAMP_LIFTBWD_HALF_LO, VAMP_LIFTBWD_HALF_HI = 64, 128
 VAMP_CAMBWD_ACCUMULATE, VAMP_CAMBWD_PACKED_VALID, VAMP_CAMBWD_CELLS_VALID, VAMP_CAMBWD_SPLAT = 1, 2, 4, 8
 VAMP_CAMBWD_SAMPLES_VALID, VAMP_CAMBWD_TERM_VALID, VAMP_CAMBWD_NO_ERT = 16, 32, 64

@@ -503,11 +503,6 @@ int vamp_lift_backward_ex(const VampLiftDesc* d, const float* mats, const float*
   const int BN = d->B * d->N, HW = d->fH * d->fW;
   // default: cell list + one wave per pixel (lift_bwd_cell.hip), no float atomics.
   // VAMP_LIFTBWD_SPLAT selects the per-voxel atomic splat below, kept as an independent cross-check.
-  // VAMP_LIFTBWD_TILE: pixel-tile owners pull the voxels of their viewing pyramid (lift_bwd_tile.hip);
-  // configurations it does not cover fall through to the cell list
-  if ((flags & VAMP_LIFTBWD_TILE) && !(flags & VAMP_LIFTBWD_SPLAT) && lift_bwd_tile_supported(d))
-    return launch_lift_bwd_tile(d, mats, xs, ys, zs, depth, feat, grad_out, hits, grad_depth, grad_feat,
-                                w.cells, lift_bwd_cell_ws_bytes(d), s);   // the cell lists' space is free here
   if (!(flags & VAMP_LIFTBWD_SPLAT)) {
     const int wpp = (flags & VAMP_LIFTBWD_WPP1) ? 1 : (flags & VAMP_LIFTBWD_WPP4) ? 4
                     : (flags & VAMP_LIFTBWD_WPP16) ? 16 : 0;

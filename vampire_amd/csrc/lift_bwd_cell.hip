@@ -5,16 +5,24 @@
 //           increments the counter of its cell = (camera, floor tap row + 1, floor tap column + 1),
 //           (fH + 1) x (fW + 1) cells per camera
 //   scan    two-level exclusive prefix sum of the counters -> cell start offsets (runtime.hip)
-//   fill    same walk; the pair's record {iz0, wz0, wz1 | w[4]*dep[4] | w[4] | gs[C]} --
-//           tap weights, depth-interpolated values, grad_out / (hits + 1e-6) -- goes to the next
-//           slot of its cell (slots handed out by atomics on the cell cursor).  Records are
-//           stored field-major (one float4 array per 16-byte field, indexed by slot): the gather
-//           reads a field of 64 consecutive records as one contiguous kilobyte
+//   fill    same walk: the voxel's row grad_out / (hits + 1e-6) goes into a channel-last table
+//           [B V, C] (consecutive lanes = consecutive 64-byte rows: streaming stores), and every
+//           valid pair puts its voxel index and {wx1, wy1, wz1, iz0} -- 20 bytes -- into the next slot
+//           of its cell (slots handed out by atomics on the cell cursor)
 //   gather  one wave (or 4, or 16) per feature-map pixel: the pairs whose 2x2 pixel taps include
-//           pixel (x, y) are exactly those of the cells (x..x+1, y..y+1), two contiguous record
-//           ranges.  Lane = record: grad_feat partial sums in registers (folded over the lanes at
-//           the end), the channel dot product feeds the two depth bins of the pixel's private
-//           LDS column.  Every output element is stored once.
+//           pixel (x, y) are exactly those of the cells (x..x+1, y..y+1), two contiguous ranges of
+//           pairs.  Lane = pair: it reads the pair's 20 bytes, the voxel's 64-byte row of the table
+//           and the two depth bins of the pixel's own column (staged in LDS); grad_feat partial
+//           sums in registers (folded over the lanes at the end), the channel dot product feeds the
+//           two depth bins of the pixel's private LDS column.  Every output element is stored once.
+//
+// (Until round 3 the fill wrote a 112-byte record per pair -- tap weights, depth-interpolated values
+// and a copy of the voxel's row -- scattered in cell order as 16-byte pieces: 122 MB of HBM writes
+// for 71 MB of records, and the pass was half of the lift backward.  A pair is now 20 bytes: the
+// depth-interpolated values come from the consuming pixel's own depth column, the lower-tap weights
+// are 1 - w1, and the voxel's row is shared by the pairs of a voxel.  Recomputing the projection in
+// the gather instead (4-byte pairs) was measured too: fill 40 us, gather 120 -- every pair is visited
+// by four pixels, and the chain with its coordinate loads sits behind the index load.)
 //
 // Both atomic passes aggregate runs of equal cells across the lanes of a wave (x-neighbouring
 // voxels share a cell in the far field), one atomic per run: device-scope atomics are served at
@@ -29,7 +37,6 @@ namespace vamp {
 
 constexpr int LGL = 16;              // lanes per record = channel lanes
 constexpr int kMinWaves = 4;         // waves per gather workgroup (more when a pixel takes more)
-constexpr int kRecHead4 = 3;         // float4 fields before gs[] in a record
 
 struct LiftCells {
   int cw, ch;                        // cells per row / column of one camera
@@ -55,8 +62,8 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
                      const float* __restrict__ zs, const T* __restrict__ depth,
                      const float* __restrict__ gout, const uint64_t* __restrict__ hits,
                      int* __restrict__ cnt, const int* __restrict__ off,
-                     const int* __restrict__ boff, float4* __restrict__ entries, long cap,
-                     unsigned* __restrict__ amask, int bn_lo, int bn_hi) {
+                     const int* __restrict__ boff, int* __restrict__ ids, float4* __restrict__ recs,
+                     float4* __restrict__ table, unsigned* __restrict__ amask, int bn_lo, int bn_hi) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int x = blockIdx.x * 64 + lane;
   const int y = blockIdx.y * 4 + (tid >> 6);
@@ -80,16 +87,22 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
   }
 
   constexpr int NB = 8;                          // cameras per batch: their atomics are in flight together
-  const bool first_chunk_only = P.C == CH;
   // grad_out / (hit count + 1e-6), the camera-mean factor of bv2:512-514: the same for every
-  // camera of the voxel, loaded before the atomics so that both latencies overlap
-  float gs0[CH];
-  if (FILL) {
-    const uint64_t hw = live ? hits[((long) b * V + vox) * (P.C / CH)] : 0;
-    const float* g = gout + (long) b * P.C * V + vox;
+  // camera of the voxel -- one channel-last row of the table per voxel (lanes = consecutive voxels
+  // = consecutive rows)
+  if (FILL && live) {
+    const int nchunk = P.C / CH;
+    float4* row = table + ((long) b * V + vox) * (P.C / 4);
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+      const uint64_t hw = hits[((long) b * V + vox) * nchunk + chunk];
+      const float* g = gout + ((long) b * P.C + chunk * CH) * V + vox;
+      float v[CH];
 #pragma unroll
-    for (int k = 0; k < CH; ++k)
-      gs0[k] = (live ? g[(long) k * V] : 0.f) * __builtin_amdgcn_rcpf((float) ((hw >> (4 * k)) & 15) + 1e-6f);   // 1 ulp: gradients are held to 1e-4
+      for (int k = 0; k < CH; ++k)
+        v[k] = g[(long) k * V] * __builtin_amdgcn_rcpf((float) ((hw >> (4 * k)) & 15) + 1e-6f);   // 1 ulp: gradients are held to 1e-4
+#pragma unroll
+      for (int c4 = 0; c4 < CH; c4 += 4) row[(chunk * CH + c4) / 4] = make_float4(v[c4], v[c4 + 1], v[c4 + 2], v[c4 + 3]);
+    }
   }
 
   // images [bn_lo, bn_hi) of the flattened (sample, camera) index: all of them, or one half when
@@ -98,12 +111,16 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
   const int n_lo = max(0, bn_lo - b * P.N), n_hi = min(P.N, bn_hi - b * P.N);
   for (int n0 = n_lo; n0 < n_hi; n0 += NB) {
     int base[NB], start[NB];
+    long cellk[NB];
+    float4 tapk[NB];                             // the pair's fractional tap coordinates and depth plane
     unsigned actm = 0;
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
       const int n = n0 + k;
       base[k] = 0;
       start[k] = lane;
+      cellk[k] = 0;
+      tapk[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (n >= n_hi) continue;                   // uniform
       if (FILL && !__any((vmask >> (n & 31)) & 1u)) continue;   // uniform: nobody in this wave sees camera n
       const long bn = (long) b * P.N + n;
@@ -112,6 +129,8 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
       const bool act = live && t.valid && t.ix0 >= -1 && t.ix0 < P.fW && t.iy0 >= -1 && t.iy0 < P.fH;
       if (act) wmask |= 1u << (n & 31);
       const long cell = (bn * ch + (t.iy0 + 1)) * cw + (t.ix0 + 1);
+      cellk[k] = cell;
+      tapk[k] = make_float4(t.wx1, t.wy1, t.wz1, __int_as_float(t.iz0));
       const LaneRun r = lane_run(act, cell, lane);
       if (r.head) {
         if (FILL) base[k] = atomicAdd(cnt + cell, r.len);
@@ -127,53 +146,9 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
       if (!__any((actm >> k) & 1u)) continue;    // uniform
       const int rb = __shfl(base[k], start[k], 64);
       if (!((actm >> k) & 1u)) continue;
-      const long bn = (long) b * P.N + n;
-      const LiftTap t = lift_project(P, mats + bn * 48, vx, vy, vz);
-      const long cell = (bn * ch + (t.iy0 + 1)) * cw + (t.ix0 + 1);
-      const long slot = (long) off[cell] + boff[cell / kScanTile] + rb + (lane - start[k]);
-      float4* e4 = entries + slot;               // field f of this record: e4[f * cap]
-
-      const float wj[4] = {t.wy0 * t.wx0, t.wy0 * t.wx1, t.wy1 * t.wx0, t.wy1 * t.wx1};
-      float dep[4] = {0.f, 0.f, 0.f, 0.f};
-      if (P.use_depth) {
-        const T* dptr = depth + bn * P.D * HW;
-#pragma unroll
-        for (int kz = 0; kz < 2; ++kz) {
-          const int iz = t.iz0 + kz;
-          const bool zin = iz >= 0 && iz < P.D;
-          const float wz = zin ? (kz ? t.wz1 : t.wz0) : 0.f;
-          const long zo = (long) min(max(iz, 0), P.D - 1) * HW;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int iy = t.iy0 + (j >> 1), ix = t.ix0 + (j & 1);
-            const bool in = iy >= 0 && iy < P.fH && ix >= 0 && ix < P.fW;
-            dep[j] += (in ? wz : 0.f) *
-                      ldf(dptr, zo + (long) min(max(iy, 0), P.fH - 1) * P.fW + min(max(ix, 0), P.fW - 1));
-          }
-        }
-      } else {
-        const float w = (t.iz0 == 0 ? t.wz0 : 0.f) + (t.iz0 == -1 ? t.wz1 : 0.f);
-        dep[0] = dep[1] = dep[2] = dep[3] = w;
-      }
-      e4[0] = make_float4(__int_as_float(t.iz0), t.wz0, t.wz1, 0.f);
-      e4[cap] = make_float4(wj[0] * dep[0], wj[1] * dep[1], wj[2] * dep[2], wj[3] * dep[3]);
-      e4[2 * cap] = make_float4(wj[0], wj[1], wj[2], wj[3]);
-#pragma unroll
-      for (int c4 = 0; c4 < CH; c4 += 4)
-        e4[(kRecHead4 + c4 / 4) * cap] = make_float4(gs0[c4], gs0[c4 + 1], gs0[c4 + 2], gs0[c4 + 3]);
-      if (!first_chunk_only)
-        for (int chunk = 1; chunk < P.C / CH; ++chunk) {
-          const uint64_t hw = hits[((long) b * V + vox) * (P.C / CH) + chunk];
-          const float* g = gout + ((long) b * P.C + chunk * CH) * V + vox;
-#pragma unroll
-          for (int c4 = 0; c4 < CH; c4 += 4) {
-            float v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              v[q] = g[(long) (c4 + q) * V] * __builtin_amdgcn_rcpf((float) ((hw >> (4 * (c4 + q))) & 15) + 1e-6f);
-            e4[(kRecHead4 + (chunk * CH + c4) / 4) * cap] = make_float4(v[0], v[1], v[2], v[3]);
-          }
-        }
+      const long slot = (long) off[cellk[k]] + boff[cellk[k] / kScanTile] + rb + (lane - start[k]);
+      ids[slot] = (int) vox;
+      recs[slot] = tapk[k];
     }
   }
   if (!FILL && amask && live) amask[(long) b * V + vox] = wmask;
@@ -181,22 +156,27 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
 
 // ---------------------------------------------------------------------------
 // gather: one wave per feature-map pixel (or wpp = 4 / 16 waves for dense configurations, chosen
-// on the host from the expected records per pixel), lane = RECORD: every lane loads one record
-// (64-byte head + its 16 channel gradients -- all of it data only that lane needs, which is what
-// the L1 -> register path is paid for), keeps 16 grad_feat partial sums in registers and adds its
-// two depth-plane terms to the pixel's LDS column.  The 16 x 64 partial sums are folded with a
-// recursive-halving reduction at the end.  C > 16 runs in chunks of 16 channels.
+// on the host from the expected pairs per pixel), lane = PAIR: every lane takes one pair (voxel
+// index + fractional taps), loads the voxel's row of the table (64 bytes at C = 16), keeps 16
+// grad_feat partial sums in registers and
+// adds its two depth-plane terms to the pixel's LDS column.  The depth values a pair needs -- the
+// two planes around its projected depth at THIS pixel -- come from the pixel's own depth column,
+// staged in LDS once.  The 16 x 64 partial sums are folded with a recursive-halving reduction at
+// the end.  C > 16 runs in chunks of 16 channels.
 // max(kMinWaves, wpp) waves per workgroup: small workgroups, because a workgroup lives as long
 // as its slowest pixel.
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(1024)
 lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
-                            const T* __restrict__ feat,
+                            const float* __restrict__ mats, const float* __restrict__ xs,
+                            const float* __restrict__ ys, const float* __restrict__ zs,
+                            const T* __restrict__ depth, const T* __restrict__ feat,
                             const int* __restrict__ off, const int* __restrict__ boff,
-                            const float4* __restrict__ entries, long cap,
+                            const int* __restrict__ ids, const float4* __restrict__ recs,
+                            const float4* __restrict__ table,
                             float* __restrict__ gdepth, float* __restrict__ gfeat, long pix_lo, long pix_hi) {
-  extern __shared__ float smem[];                // [ppb][Dp] depth columns, then [waves][16]
+  extern __shared__ float smem[];                // [ppb][Dp] grad columns, [ppb][Dp] depth columns, [waves][16]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int C = P.C, D = P.use_depth ? P.D : 0;
   const int Dp = D | 1;
@@ -204,25 +184,33 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
   const int ppb = nw / wpp;                      // pixels per workgroup
   const int pw = wv / wpp, ws = wv % wpp;        // pixel of this wave, wave index inside the pixel
   float* gd = smem;
-  float* accbuf = smem + ppb * Dp;
+  float* dcolumns = smem + ppb * Dp;
+  float* accbuf = smem + 2 * ppb * Dp;
   const long HW = (long) P.fH * P.fW;
+  const long V = (long) P.Z * P.Y * P.X;
   const long npix = pix_hi;                      // this launch owns pixels [pix_lo, pix_hi)
   // the workgroups of one image row run on one XCD: their 16-byte pieces of a depth plane's row
   // merge into whole lines in that L2
   const long pid0 = pix_lo + (long) xcd_grouped(blockIdx.x, gridDim.x, xgroup) * ppb;
   const long pid = min(pid0 + pw, npix - 1);
   const bool pix_ok = pid0 + pw < npix;
-  const long bn = pid / HW;
-  const int pix = (int) (pid % HW);
+  const long bn = __builtin_amdgcn_readfirstlane((int) (pid / HW));      // wave-uniform: the pixel
+  const int pix = __builtin_amdgcn_readfirstlane((int) (pid % HW));
+  const int b = (int) (bn / P.N);
   const int iy = pix / P.fW, ix = pix % P.fW;
+  const float* m = mats + bn * 48;
 
   float* gcol = gd + pw * Dp;
-  for (int dz = ws * 64 + lane; dz < D; dz += wpp * 64) gcol[dz] = 0.f;
+  float* dcol = dcolumns + pw * Dp;
+  for (int dz = ws * 64 + lane; dz < D; dz += wpp * 64) {
+    gcol[dz] = 0.f;
+    dcol[dz] = ldf(depth, (bn * P.D + dz) * HW + pix);
+  }
   __syncthreads();
 
-  // record ranges of cell rows iy and iy + 1, columns ix .. ix + 1 (mid = where column ix + 1
-  // starts).  The cell tells which tap of the record this pixel is: a record of cell
-  // (row, column) has iy0 = row - 1, ix0 = column - 1.
+  // index ranges of cell rows iy and iy + 1, columns ix .. ix + 1 (mid = where column ix + 1
+  // starts).  The cell tells which tap of the pair this pixel is: a pair of cell (row, column)
+  // has iy0 = row - 1, ix0 = column - 1.
   int beg0, mid0, n0, beg1, mid1, tot;
   {
     const int l6 = min(lane, 5);
@@ -255,22 +243,31 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
       const int kc = min(k, tot - 1);
       const bool row0 = kc < n0;
       const long pos = row0 ? (long) beg0 + kc : (long) beg1 + (kc - n0);
-      const float4* e = entries + pos;
-      const float4 hb = e[0];
-      const float4 pwv = e[cap];
-      const float4 ww = e[2 * cap];
+      const int vox = ids[pos];
+      // the voxel's row of grad_out / (hits + 1e-6)
+      const float4* e = table + ((long) b * V + vox) * (C / 4) + c0 / 4;
       float gs[16];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < nq) g4 = e[(kRecHead4 + c0 / 4 + q) * cap];   // uniform branch
+        if (q < nq) g4 = e[q];                    // uniform branch
         gs[4 * q] = g4.x; gs[4 * q + 1] = g4.y; gs[4 * q + 2] = g4.z; gs[4 * q + 3] = g4.w;
       }
-      const int iz0 = __float_as_int(hb.x);
-      // which of the record's taps this pixel is: (iy - iy0) * 2 + (ix - ix0)
+      // the pair's taps: fractional coordinates (w1 of each axis) and the lower depth plane; the weights
+      // of the lower taps are taken as 1 - w1 (the forward's (floor + 1) - f up to an ulp: gradients are
+      // held to 1e-4)
+      const float4 rc = recs[pos];
+      const int iz0 = __float_as_int(rc.w);
+      const float wz1v = rc.z, wz0v = 1.0f - rc.z;
+      // which of the pair's taps this pixel is: (iy - iy0) * 2 + (ix - ix0)
       const int j = (row0 ? 2 : 0) + ((pos >= (row0 ? mid0 : mid1)) ? 0 : 1);
-      const float pwj = in ? (j == 0 ? pwv.x : (j == 1 ? pwv.y : (j == 2 ? pwv.z : pwv.w))) : 0.f;
-      const float wj = in ? (j == 0 ? ww.x : (j == 1 ? ww.y : (j == 2 ? ww.z : ww.w))) : 0.f;
+      const float wj = in ? (((j & 2) ? rc.y : 1.0f - rc.y) * ((j & 1) ? rc.x : 1.0f - rc.x)) : 0.f;
+      // depth interpolated at this pixel: the two planes around the projected depth (zero padding)
+      const bool z0in = iz0 >= 0 && iz0 < D, z1in = iz0 + 1 >= 0 && iz0 + 1 < D;
+      float dep;
+      if (D > 0) dep = (z0in ? wz0v * dcol[min(max(iz0, 0), D - 1)] : 0.f) + (z1in ? wz1v * dcol[min(max(iz0 + 1, 0), D - 1)] : 0.f);
+      else dep = (iz0 == 0 ? wz0v : 0.f) + (iz0 == -1 ? wz1v : 0.f);      // D == 1: the single plane
+      const float pwj = wj * dep;
       float dot = 0.f;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
@@ -283,8 +280,8 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
         // ds_add_u32, tools/microbench/lds_atomic.hip -- but a fixed-point column with a per-pixel
         // scale measured slower here, 80 vs 69 us: finding the scale costs a wave reduction per batch)
         if (wd != 0.f) {
-          if (iz0 >= 0 && iz0 < D) atomicAdd(gcol + iz0, hb.y * wd);
-          if (iz0 + 1 >= 0 && iz0 + 1 < D) atomicAdd(gcol + iz0 + 1, hb.z * wd);
+          if (z0in) atomicAdd(gcol + iz0, wz0v * wd);
+          if (z1in) atomicAdd(gcol + iz0 + 1, wz1v * wd);
         }
       }
     }
@@ -323,7 +320,9 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
 struct LiftCellWs {
   int *cnt, *off, *bsum, *boff, *aux;
   unsigned* amask;                   // [B * V] cameras each voxel is valid for (N <= 32)
-  float4* entries;                   // [kRecHead4 + C / 4][cap]
+  int* ids;                          // [cap] voxel index (within its sample) of every pair, in cell order
+  float4* recs;                      // [cap] {wx1, wy1, wz1, iz0} of every pair
+  float4* table;                     // [B * V, C] grad_out / (hits + 1e-6), channel-last
   size_t bytes;
 };
 
@@ -340,7 +339,9 @@ static LiftCellWs lift_cell_ws(const VampLiftDesc* d, void* scratch) {
   w.boff = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
   w.aux = reinterpret_cast<int*>(p); p += align_up((size_t) (ntile + 4) * sizeof(int), 256);
   w.amask = reinterpret_cast<unsigned*>(p); p += align_up((size_t) d->B * d->Z * d->Y * d->X * sizeof(unsigned), 256);
-  w.entries = reinterpret_cast<float4*>(p); p += align_up(cap * (kRecHead4 + (d->C + 3) / 4) * sizeof(float4), 256);
+  w.ids = reinterpret_cast<int*>(p); p += align_up(cap * sizeof(int), 256);
+  w.recs = reinterpret_cast<float4*>(p); p += align_up(cap * sizeof(float4), 256);
+  w.table = reinterpret_cast<float4*>(p); p += align_up((size_t) d->B * d->Z * d->Y * d->X * d->C * sizeof(float), 256);
   w.bytes = (size_t) (p - static_cast<char*>(scratch));
   return w;
 }
@@ -355,10 +356,11 @@ int launch_lift_cell_prepare(const VampLiftDesc* d, const float* mats, const flo
   const LiftCellWs w = lift_cell_ws(d, scratch);
   const size_t cap = (size_t) d->B * d->N * d->Z * d->Y * d->X;
   VAMP_REQUIRE(cap < 0x7fffffffu && g.ncell < 0x7fffffffL, "pair / cell count exceeds 2^31");
+  VAMP_REQUIRE(d->C % 4 == 0, "C must be a multiple of 4");
   if (int ze = launch_zero(w.cnt, (size_t) g.ncell * sizeof(int), s)) return ze;
   dim3 grid((d->X + 63) / 64, (d->Y + 3) / 4, d->Z * d->B);
   VAMP_TIMED(kProfLiftBwdCount, s, (lift_bwd_cell_kernel<float, 16, false><<<grid, 256, 0, s>>>(
-      P, g.cw, g.ch, mats, xs, ys, zs, nullptr, nullptr, nullptr, w.cnt, w.off, w.boff, w.entries, (long) cap, d->N <= 32 ? w.amask : nullptr, 0, d->B * d->N)));
+      P, g.cw, g.ch, mats, xs, ys, zs, nullptr, nullptr, nullptr, w.cnt, w.off, w.boff, w.ids, w.recs, w.table, d->N <= 32 ? w.amask : nullptr, 0, d->B * d->N)));
   if (int e = check_launch("lift_bwd_cell_kernel<count>")) return e;
   return launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, g.ncell, s);
 }
@@ -382,7 +384,7 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
   const T* dp = static_cast<const T*>(depth);
 #define VAMP_CELL(CH)                                                                            \
   VAMP_TIMED(kProfLiftBwdFill, s, (lift_bwd_cell_kernel<T, CH, true><<<grid, 256, 0, s>>>(       \
-      P, g.cw, g.ch, mats, xs, ys, zs, dp, gout, hits, w.cnt, w.off, w.boff, w.entries, (long) cap,     \
+      P, g.cw, g.ch, mats, xs, ys, zs, dp, gout, hits, w.cnt, w.off, w.boff, w.ids, w.recs, w.table,     \
       d->N <= 32 ? w.amask : nullptr, bn_lo, bn_hi)))
   if (P.C == 4) VAMP_CELL(4); else if (P.C == 8) VAMP_CELL(8); else VAMP_CELL(16);
 #undef VAMP_CELL
@@ -399,7 +401,7 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
   const int nw = std::max(kMinWaves, wpp);
   const int ppb = nw / wpp;
   const int Dd = d->use_depth ? d->D : 0;
-  const size_t lds = ((size_t) ppb * (Dd | 1) + (size_t) nw * 16) * sizeof(float);
+  const size_t lds = ((size_t) 2 * ppb * (Dd | 1) + (size_t) nw * 16) * sizeof(float);
   if (lds > 150 * 1024) return fail(VAMP_EINVAL, "%s: D too large for the LDS depth columns", __func__);
   const unsigned ggrid = (unsigned) ((npix + ppb - 1) / ppb);
   {
@@ -409,8 +411,8 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess)
       return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);
     VAMP_TIMED(kProfLiftBwd, s, (k<<<ggrid, nw * 64, lds, s>>>(
-        P, g.cw, g.ch, wpp, (d->fW % ppb == 0) ? d->fW / ppb : 0, static_cast<const T*>(feat), w.off,
-        w.boff, w.entries, (long) cap, gdepth, gfeat, pix_lo, pix_hi)));
+        P, g.cw, g.ch, wpp, (d->fW % ppb == 0) ? d->fW / ppb : 0, mats, xs, ys, zs, dp, static_cast<const T*>(feat),
+        w.off, w.boff, w.ids, w.recs, w.table, gdepth, gfeat, pix_lo, pix_hi)));
   }
   return check_launch("lift_bwd_cell_gather_kernel");
 }

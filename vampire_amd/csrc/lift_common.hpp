@@ -94,12 +94,4 @@ int launch_lift_bwd_cell(const VampLiftDesc* d, const float* mats, const float* 
 int launch_lift_cell_prepare(const VampLiftDesc* d, const float* mats, const float* xs,
                              const float* ys, const float* zs, void* scratch, hipStream_t s);
 
-// lift_bwd_tile.hip
-bool lift_bwd_tile_supported(const VampLiftDesc* d);
-int launch_lift_bwd_tile(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
-                         const float* zs, const void* depth, const void* feat, const float* gout,
-                         const uint64_t* hits, float* gdepth, float* gfeat, void* scratch,
-                         size_t scratch_bytes, hipStream_t s);
-size_t lift_bwd_tile_scratch_bytes(const VampLiftDesc* d);
-
 }  // namespace vamp

@@ -84,8 +84,7 @@ class HotPath:
         # cross-checks for the tests; lift_wpp forces the lift gather's waves per pixel (0 = auto).
         # The environment gives the initial values only.
         self.impl = {"cam_bwd": os.environ.get("VAMP_CAM_BWD", "cell"),
-                     # lift backward: "cell" = cell list + gather (default), "tile" = pixel-tile owners with
-                     # fixed-point LDS accumulators (bit-reproducible, slower: DESIGN.md), "v1" = float-atomic splat
+                     # lift backward: "cell" = cell list + gather (default), "v1" = float-atomic splat
                      "lift_bwd": os.environ.get("VAMP_LIFT_BWD", "cell"),
                      "bev_bwd": os.environ.get("VAMP_BEV_BWD", "cell"),
                      "lift_wpp": int(os.environ.get("VAMP_LIFT_WPP", "0")),
@@ -382,8 +381,6 @@ class _LiftFn(torch.autograd.Function):
         hp._lift_gen = getattr(hp, "_lift_gen", 0) + 1       # the backward consumes the prepared counters
         if hp.impl["lift_bwd"] == "v1":
             valid = _capi.VAMP_LIFTBWD_SPLAT
-        elif hp.impl["lift_bwd"] == "tile":
-            valid |= _capi.VAMP_LIFTBWD_TILE                 # falls through to the cell list where unsupported
         valid |= {1: _capi.VAMP_LIFTBWD_WPP1, 4: _capi.VAMP_LIFTBWD_WPP4,
                   16: _capi.VAMP_LIFTBWD_WPP16}.get(hp.impl["lift_wpp"], 0)
         def call(flags, stream):
