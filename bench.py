@@ -76,17 +76,24 @@ STAGES = {   # SURVEY.md section 8(d) stage names -> kernels of this build
 }
 
 
-def measured_traffic(cfg_name, kernel, batch):
+def measured_traffic(cfg_name, kernel, batch, run_kernels):
     """HBM bytes per launch from a committed rocprofv3 PMC run (profiles/traffic_*.json, made on
-    the GPU box by tools/collect_profiles.sh + tools/summarize_profiles.py), or None when no run matches."""
+    the GPU box by tools/collect_profiles.sh + tools/summarize_profiles.py), or None when no run matches.
+    Only the NEWEST file is considered, and only if its kernel list is this run's (the profiler slots of
+    the eager one-stream step): a profile made before a kernel was added, removed or renamed is stale
+    and is refused rather than quoted."""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")), reverse=True):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")), key=os.path.getmtime, reverse=True)
+    for f in files[:1]:
         try:
             with open(f) as fh:
                 t = json.load(fh)
         except (OSError, ValueError):
             continue
-        if t.get("cfg") == cfg_name and t.get("batch") == batch and kernel in t.get("kernels", {}):
+        ks = set(t.get("kernels", {}))
+        ignore = {"aux", "memset", "scan", "cell_scan"}
+        if (t.get("cfg") == cfg_name and t.get("batch") == batch and kernel in ks
+                and (set(run_kernels) - ignore) == (ks - ignore)):
             return t["kernels"][kernel]["hbm_bytes_per_launch"]
     return None
 
@@ -499,7 +506,7 @@ def main():
             "rccl_ranks": (dist.get_world_size() if dist.is_initialized() else 1),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": dom_gbs / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(a.cfg, dom, a.batch),
+                         "traffic": measured_traffic(a.cfg, dom, a.batch, list(kern)),
                          "algorithmic_bytes_per_launch": dom_alg_launch,
                          "launches_per_step": kern[dom]["launches_per_step"],
                          "avg_launch_us": kern[dom]["avg_us"]},

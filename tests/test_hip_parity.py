@@ -407,8 +407,8 @@ def test_module_conv_routing_matches_miopen(dev, monkeypatch):
     """The module mirror's routing of its 3-D convolutions (Unet3D stride-1 layers, the three heads
     fused into one 16 -> 32 conv) through the HIP kernels against the same modules on MIOpen:
     outputs, input gradient and every parameter gradient."""
-    from vampire_amd.backbone import BaseVAMPIRE2, Unet3D
-    monkeypatch.setenv("VAMP_CONV3D_MIN_VOXELS", "0")
+    from vampire_amd.backbone import BaseVAMPIRE2, Unet3D, SWITCHES
+    monkeypatch.setattr(SWITCHES, "conv3d_min_voxels", 0)
     torch.manual_seed(3)
     net = Unet3D(16, 16).to(dev)
     c = CFG_TINY
@@ -423,7 +423,7 @@ def test_module_conv_routing_matches_miopen(dev, monkeypatch):
     heads = [mod.density_conv, mod.seg_conv, mod.rgb_conv]
 
     def run(flag):
-        monkeypatch.setenv("VAMP_CONV3D", flag)
+        monkeypatch.setattr(SWITCHES, "conv3d", flag == "1")
         for m in [net] + heads:
             m.zero_grad(set_to_none=True)
         a = x.clone().requires_grad_(True)

@@ -57,6 +57,19 @@ def _resize(x, size):
     return F.interpolate(x, tuple(size), mode="trilinear", align_corners=True)
 
 
+# Switches of the module path, read ONCE at import (not on every forward): VAMP_CONV3D=0 keeps MIOpen for
+# every 3-D convolution, VAMP_CONV3D_MIN_VOXELS is the volume size from which the HIP convolution is
+# used, VAMP_GLUE=hip routes the depth softmax / density gate through the HIP kernels.  Tests and
+# tools flip the attributes of `SWITCHES`.
+class _Switches:
+    conv3d = os.environ.get("VAMP_CONV3D", "1") != "0"
+    conv3d_min_voxels = int(os.environ.get("VAMP_CONV3D_MIN_VOXELS", "50000"))
+    hip_glue = os.environ.get("VAMP_GLUE", "aten") == "hip"
+
+
+SWITCHES = _Switches()
+
+
 class _Conv3(nn.Conv3d):
     """nn.Conv3d(cin, cout, 3, stride, 1, bias=False) (same parameter name and shape).  The
     stride-1 layers with 16 / 32 channels run on the HIP fp32 matrix-core kernels for fp32 device
@@ -65,9 +78,9 @@ class _Conv3(nn.Conv3d):
     MIOpen); `VAMP_CONV3D=0` keeps MIOpen everywhere."""
 
     def forward(self, x):
-        if os.environ.get("VAMP_CONV3D", "1") != "0" and x.dim() == 5:
+        if SWITCHES.conv3d and x.dim() == 5:
             from .ops import conv3d_3x3x3, conv3d_supported
-            if (x[0, 0].numel() >= int(os.environ.get("VAMP_CONV3D_MIN_VOXELS", "50000"))
+            if (x[0, 0].numel() >= SWITCHES.conv3d_min_voxels
                     and conv3d_supported(x, self.weight, self.stride, self.padding, self.bias)):
                 return conv3d_3x3x3(x, self.weight)
         return super().forward(x)
@@ -213,7 +226,9 @@ class BaseVAMPIRE2(nn.Module):
             span = torch.as_tensor([x_bound_seg[1] - x_bound_seg[0], y_bound_seg[1] - y_bound_seg[0],
                                     z_bound_seg[1] - z_bound_seg[0]])
             self.register_buffer("norm_occ_coords", ((occ - lo) / span) * 2.0 - 1.0)
-            self._occ_points = occ                                   # plain attribute: the kernels normalise themselves
+            # the raw grid for the kernels (they normalise themselves): a non-persistent buffer, so that it
+            # follows module.to() / .cuda() and the state-dict keys stay the reference's
+            self.register_buffer("_occ_points", occ, persistent=False)
         if cat_pos:
             self.register_buffer("norm_voxel_coords",
                                  G.make_voxel_coords(x_bound_seg, y_bound_seg, z_bound_seg, norm=True))
@@ -355,11 +370,11 @@ class BaseVAMPIRE2(nn.Module):
         weights -- the volume is read once and MIOpen's three forward / data / weight-gradient
         launches become one each; biases and the rgb sigmoid follow.  Parameters are untouched."""
         nout = 1 + self.num_classes + 3
-        if os.environ.get("VAMP_CONV3D", "1") != "0" and nout <= 32 and base.dim() == 5:
+        if SWITCHES.conv3d and nout <= 32 and base.dim() == 5:
             from .ops import conv3d_3x3x3, conv3d_supported
             wd, ws, wr = self.density_conv.weight, self.seg_conv.weight, self.rgb_conv[0].weight
             w = torch.cat([wd, ws, wr, wd.new_zeros((32 - nout,) + tuple(wd.shape[1:]))], 0)
-            if (base[0, 0].numel() >= int(os.environ.get("VAMP_CONV3D_MIN_VOXELS", "50000"))
+            if (base[0, 0].numel() >= SWITCHES.conv3d_min_voxels
                     and conv3d_supported(base, w, (1, 1, 1), (1, 1, 1), None)):
                 y = conv3d_3x3x3(base, w)
                 K = self.num_classes
@@ -379,7 +394,7 @@ class BaseVAMPIRE2(nn.Module):
         # costs what they save (156 vs 149 us and 167 vs 104 us end to end, profiles/widening_rows_r01f.txt),
         # so the module runs the reference's aten expressions unless VAMP_GLUE=hip asks for the kernels
         # (they stay available and tested: HotPath.depth_softmax / density_gate).
-        hip_glue = os.environ.get("VAMP_GLUE", "aten") == "hip"
+        hip_glue = SWITCHES.hip_glue
         if self._USE_DEPTH:
             logits = self.mapping_along_depth(src)
             depth = hp.depth_softmax(logits) if hip_glue else logits.float().softmax(dim=1)   # bv2:550
@@ -417,7 +432,7 @@ class BaseVAMPIRE2(nn.Module):
         else:
             # static grid (base_lss_impaintor.py:611-616): the same queries without the bda rotation
             occ_logits, occ_density = hp.occupancy_queries(semantic_logits.float(), density_feature.float(),
-                                                           self._occ_points.to(semantic_logits.device), None, beta)
+                                                           self._occ_points, None, beta)
 
         (rgb_p, seg_p, depth_p, bev_rgb, bev_seg, bev_height, bev_density, voxel_output) = \
             self.render(mats_dict, sweep_index, density_feature, semantic_logits, base, rgb)

@@ -982,9 +982,16 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
   }
   z_lo = z_lo < 0 ? 0 : z_lo;
   z_hi = z_hi > d->Z - 1 ? d->Z - 1 : z_hi;
-  if (z_lo > z_hi)
-    return bev_zero_overwritten(d, flags, grad_density_feature, grad_semantic, grad_rgb, grad_base,
+  if (z_lo > z_hi) {
+    // the det lattice misses the volume: only zeros to write.  A split pair zeroes each buffer in the
+    // half that owns it (ONLY_BASE is issued behind the event the camera gather waits for: zeroing the
+    // three camera tensors again there would race with, or wipe, that gather's sums)
+    int zf = flags;
+    if (flags & VAMP_BEVBWD_ONLY_BASE) zf &= ~VAMP_BEVBWD_OVERWRITE_CAM;
+    if (flags & VAMP_BEVBWD_SKIP_BASE) zf &= ~VAMP_BEVBWD_OVERWRITE_BASE;
+    return bev_zero_overwritten(d, zf, grad_density_feature, grad_semantic, grad_rgb, grad_base,
                                 static_cast<hipStream_t>(stream));
+  }
 
   dim3 gq((d->oX + 63) / 64, d->oY, d->B);
   const size_t q_lds = (size_t) d->oZ * 4 * 64 * sizeof(float);

@@ -75,6 +75,13 @@ class GradSync(torch.nn.Module):
         self._pending.append((dist.all_reduce(p.grad, op=op, group=self.group, async_op=True), p))
 
     def forward(self, *a, **kw):
+        # a backward pass that raised after its first hook leaves stale handles and the flag behind (the
+        # engine drops its callbacks): start every step clean
+        if self._pending or self._joining:
+            for work, _ in self._pending:
+                work.wait()
+            self._pending.clear()
+            self._joining = False
         return self.module(*a, **kw)
 
     def finish(self):
