@@ -247,6 +247,41 @@ def extra_config(cfg_name, batch, dtype, steps=10, warm=3, ert=True, density_mod
             "fwd_frac_of_hbm_peak": ab["fwd"] * batch / (fwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
 
+def layered_measure(cfg, dev, batch_per_gpu, rank, world, steps=6, warm=3):
+    """the operators between the reference backbone's own layers (step.LayeredStep: 777 111
+    parameters, a 3.1 MB gradient bucket) under the bucketed GradSync (VAMP_GRAD_SYNC=ddp:
+    DistributedDataParallel), so that a multi-GPU run exercises a real all-reduce overlapped with the
+    backward.  Reported beside the headline (whose only parameter is the density beta); the step is
+    dominated by the 3-D UNet's convolutions, which are not part of the hot path."""
+    from vampire_amd import dist as vdist
+    from vampire_amd.step import LayeredStep, LayeredBatch, layered_step
+    torch.backends.cudnn.benchmark = True      # MIOpen find mode for the UNet's remaining layers (immediate mode: 10x slower)
+    model = LayeredStep(cfg, dev)
+    wrapped = vdist.wrap_ddp(model, dev)
+    data = LayeredBatch(cfg, batch_per_gpu, dev, seed=vdist.shard_seed(0, rank))
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        layered_step(wrapped, data)
+
+    for _ in range(warm):
+        step()
+    vdist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    vdist.barrier(); torch.cuda.synchronize()
+    el = vdist.max_over_ranks(time.perf_counter() - t0, dev)
+    nparam = sum(p.numel() for p in model.parameters())
+    sync = ("none (1 rank)" if wrapped is model else
+            ("GradSync, %d buckets of <= 1 MiB, all-reduce launched as each bucket completes" % len(wrapped._buckets)
+             if isinstance(wrapped, vdist.GradSync) else "DistributedDataParallel"))
+    return {"ms_per_step": el / steps * 1e3, "samples_per_s": batch_per_gpu * world * steps / el,
+            "parameters": nparam, "gradient_bytes": 4 * nparam, "grad_sync": sync, "steps": steps,
+            "what": "mapping_along_depth, channel_lower, depth softmax, lift, Unet3D, heads, render, occupancy queries, "
+                    "voxel_output: forward + backward from synthetic neck features"}
+
+
 def capture_step(model, batch, train_step):
     """One training step (without the DDP wrapper) captured into a HIP graph; the replay must
     reproduce the eager gradients."""
@@ -287,6 +322,8 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations (extra_configs)")
+    ap.add_argument("--layers", action="store_true",
+                    help="also time the step wrapped with the backbone's own layers (always done when --gpus > 1)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -453,6 +490,9 @@ def main():
         ert_stats = {"inside_samples": inside, "kept_samples": kept,
                      "terminated_fraction": round(1.0 - kept / max(1, inside), 4)}
 
+    # with more than one rank (or --layers) also the step with a real gradient bucket
+    layered = layered_measure(cfg, dev, a.batch, rank, world) if (world > 1 or a.layers) else None
+
     prof = dict(warm)
     # the dominant kernel: measured over the timed region
     prof.update({k: (n, ms, a.steps) for k, (n, ms) in _capi.profile_read().items()})
@@ -522,6 +562,7 @@ def main():
                              "kernel_sum_us": fwd_kernel_sum_us, "algorithmic_bytes": fwd_bytes},
             "stages": stages,
             "step_matrix": step_matrix,
+            "layered_step": layered,
             "early_ray_termination": ert_stats,
             "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in sorted(kern.items())},
             "kernels_us_per_step": {k: round(v["us_per_step"], 2) for k, v in sorted(kern.items())},

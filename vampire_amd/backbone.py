@@ -384,8 +384,13 @@ class BaseVAMPIRE2(nn.Module):
         return self.density_conv(base), self.seg_conv(base), self.rgb_conv(base)
 
     def _forward_single_sweep(self, sweep_index, sweep_imgs, mats_dict, inrange_pts=None):
-        B, S, N = sweep_imgs.shape[:3]
-        img_feats = self.get_cam_feats(sweep_imgs)
+        return self._sweep_from_feats(sweep_index, self.get_cam_feats(sweep_imgs), mats_dict, inrange_pts)
+
+    def _sweep_from_feats(self, sweep_index, img_feats, mats_dict, inrange_pts=None, occupancy=True):
+        """bv2:548-649 from the neck features [B, S, N, c, fH, fW] on (everything behind get_cam_feats);
+        `occupancy=False` leaves the Occ3D resampling out (the last two outputs are None): the
+        data-parallel harness of step.py uses it on CPU, where the oracle stands in for the kernels."""
+        B, S, N = img_feats.shape[:3]
         src = img_feats[:, 0].reshape(B * N, -1, img_feats.shape[-2], img_feats.shape[-1])
         hp = self.hot_path()
         feat = self.channel_lower(src).reshape(B, N, -1, *src.shape[-2:])
@@ -426,7 +431,9 @@ class BaseVAMPIRE2(nn.Module):
                 if self.density_mode == "sdf":
                     pts_sdf_batch.append(hp.sample_points(density_feature[[i]].float(), pts,
                                                           mask_outside=True)[0, 0])
-        if self._ROTATE_OCC:
+        if not occupancy:
+            occ_logits = occ_density = None
+        elif self._ROTATE_OCC:
             occ_logits, occ_density = hp.occupancy_queries(semantic_logits.float(), density_feature.float(),
                                                            self.occ_coords, mats_dict.get("bda_mat", None), beta)
         else:
@@ -447,7 +454,8 @@ class BaseVAMPIRE2(nn.Module):
         bev_feat = self.voxel_output(voxel_output.reshape(B, -1, *voxel_output.shape[-2:])).float()
         return (bev_feat.contiguous(), rgb_p, seg_p, depth_p, bev_rgb, bev_seg, bev_height,
                 bev_density, pts_logits_batch, pts_sdf_batch,
-                occ_logits.permute(0, 2, 3, 4, 1), occ_density.permute(0, 2, 3, 4, 1).tanh())
+                None if occ_logits is None else occ_logits.permute(0, 2, 3, 4, 1),
+                None if occ_density is None else occ_density.permute(0, 2, 3, 4, 1).tanh())
 
     def forward(self, sweep_imgs, mats_dict, inrange_pts=None, timestamps=None):
         if sweep_imgs.shape[1] != 1:

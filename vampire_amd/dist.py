@@ -31,13 +31,17 @@ def shard_seed(base_seed: int, rank: int) -> int:
 
 
 class GradSync(torch.nn.Module):
-    """Minimal overlapped data-parallel gradient averaging for a module with a handful of
-    parameters (the path owns one scalar): a post-accumulate hook launches an asynchronous
-    all-reduce the moment a parameter's gradient is complete -- for `beta` that is the end of the
-    render backward, so the collective runs under the lift backward -- and `finish()` (called by
-    `train_step` after backward) makes the compute stream wait for it.  Same result as
-    DistributedDataParallel (mean over ranks) without its per-step bookkeeping, which costs 45 us
-    of a 1.07 ms step on one MI355X (tools/ddp_overhead.py).  `VAMP_GRAD_SYNC=ddp` selects DDP.
+    """Minimal overlapped data-parallel gradient averaging: the parameters are grouped, in reverse
+    registration order (about the order in which backward completes them), into buckets of at most
+    `bucket_bytes`; a post-accumulate hook counts the gradients of a bucket and, when the last one is
+    there, flattens the bucket and launches ONE asynchronous all-reduce for it -- for the hot path's
+    own parameter (`beta`, a bucket of one) that is the end of the render backward, so the collective
+    runs under the lift backward; for the layered step (step.LayeredStep, 777 111 parameters) three
+    1 MiB buckets go out while the backward is still running.  `finish()` (called by `train_step`
+    after backward) makes the compute stream wait for the collectives and scatters the averaged
+    buckets back.  Same result as DistributedDataParallel (mean over ranks) without its per-step
+    bookkeeping, which costs 45 us of a 1.07 ms step on one MI355X (tools/ddp_overhead.py).
+    `VAMP_GRAD_SYNC=ddp` selects DDP.
 
     Like DDP it broadcasts parameters and buffers from rank 0 at construction, and it joins its
     collectives by itself at the end of every backward pass (an autograd-engine callback queued by
@@ -45,7 +49,7 @@ class GradSync(torch.nn.Module):
     `finish()` stays as an explicit, idempotent join.  Every rank must produce a gradient for every
     parameter in every step (as with DDP's find_unused_parameters=False, base_cli.py:72)."""
 
-    def __init__(self, module, group=None):
+    def __init__(self, module, group=None, bucket_bytes: int = 1 << 20):
         super().__init__()
         self.module = module
         self.group = group
@@ -60,38 +64,70 @@ class GradSync(torch.nn.Module):
                 dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         # NCCL / RCCL has a native average; gloo (CPU tests) sums and the division follows
         self._avg = dist.get_backend(group) == "nccl"
-        for p in module.parameters():
-            if p.requires_grad:
-                p.register_post_accumulate_grad_hook(self._launch)
+        params = [p for p in module.parameters() if p.requires_grad][::-1]
+        self._buckets, cur, size = [], [], 0
+        for p in params:
+            nb = p.numel() * p.element_size()
+            if cur and (size + nb > bucket_bytes or p.dtype != cur[0].dtype or p.device != cur[0].device):
+                self._buckets.append(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += nb
+        if cur:
+            self._buckets.append(cur)
+        self._bucket_of = {p: i for i, b in enumerate(self._buckets) for p in b}
+        self._ready = [0] * len(self._buckets)
+        for p in params:
+            p.register_post_accumulate_grad_hook(self._launch)
 
     def _launch(self, p):
         if not self.enabled:
             return
-        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         if not self._joining:
             # join at the end of this backward pass, whoever called it
             torch.autograd.Variable._execution_engine.queue_callback(self.finish)
             self._joining = True
-        self._pending.append((dist.all_reduce(p.grad, op=op, group=self.group, async_op=True), p))
+        i = self._bucket_of[p]
+        self._ready[i] += 1
+        if self._ready[i] == len(self._buckets[i]):
+            self._reduce(i)
+
+    def _reduce(self, i):
+        bucket = self._buckets[i]
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        flat = bucket[0].grad if len(bucket) == 1 else torch.cat([q.grad.reshape(-1) for q in bucket])
+        self._pending.append((dist.all_reduce(flat, op=op, group=self.group, async_op=True), flat, bucket))
+        self._ready[i] = 0
 
     def forward(self, *a, **kw):
         # a backward pass that raised after its first hook leaves stale handles and the flag behind (the
         # engine drops its callbacks): start every step clean
-        if self._pending or self._joining:
-            for work, _ in self._pending:
+        if self._pending or self._joining or any(self._ready):
+            for work, _, _ in self._pending:
                 work.wait()
             self._pending.clear()
             self._joining = False
+            self._ready = [0] * len(self._buckets)
         return self.module(*a, **kw)
 
     def finish(self):
-        """Order the caller's stream after the collectives launched during backward."""
-        for work, p in self._pending:
+        """Order the caller's stream after the collectives launched during backward and scatter the
+        averaged buckets back into the gradients."""
+        for i, n in enumerate(self._ready):          # (a bucket a hook never completed: reduce what is there)
+            if n and self.enabled and all(q.grad is not None for q in self._buckets[i]):
+                self._reduce(i)
+        for work, flat, bucket in self._pending:
             work.wait()
             if not self._avg:
-                p.grad.div_(self.world)
+                flat.div_(self.world)
+            if len(bucket) > 1:
+                off = 0
+                for q in bucket:
+                    q.grad.copy_(flat[off:off + q.numel()].view_as(q.grad))
+                    off += q.numel()
         self._pending.clear()
         self._joining = False
+        self._ready = [0] * len(self._buckets)
 
 
 def wrap_ddp(module, device=None, force: bool = False):
