@@ -62,8 +62,42 @@ int launch_exclusive_scan(const int* cnt, int* off, int* fill, int n, int* total
 int launch_zero(void* ptr, size_t bytes, hipStream_t s);
 int launch_beta_reduce(const float* part, int n, const float* beta_raw, float* grad_beta, hipStream_t s);
 constexpr int kScanTile = 2048;
+// `cnt` holds ncell + kScanPad ints, all zeroed by the caller before the count pass: cnt[ncell] is the
+// scan's arrival ticket (the workgroup that takes the last ticket scans the tile totals, so the whole
+// scan is one launch)
+constexpr int kScanPad = 64;
 int launch_cell_scan(int* cnt, int* off, int* bsum, int* boff, int* aux, long ncell,
                      hipStream_t s);
+// A duty a consumer kernel takes over from a launch of its own: the first workgroup adds up, in a
+// fixed order, the per-workgroup partial sums of d loss / d beta_eff that an EARLIER kernel of the same
+// stream left in `part` (kernel boundary: visible), and adds sign(beta_raw) * sum to grad_beta with one
+// atomic (the camera and BEV branches add to the same word from two streams; two addends commute, so
+// the sum has the same bits every run).  part == nullptr: nothing to do.
+struct BetaTail {
+  const float* part;
+  int n;
+  const float* beta_raw;
+  float* grad_beta;
+};
+__device__ __forceinline__ void beta_tail(const BetaTail& t) {
+  if (!t.part || blockIdx.x != 0 || blockIdx.y != 0 || blockIdx.z != 0) return;     // uniform per workgroup
+  __shared__ float beta_red[16];
+  const int nthr = blockDim.x * blockDim.y * blockDim.z;
+  float v = 0.f;
+  for (int i = threadIdx.x; i < t.n; i += nthr) v += t.part[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) beta_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < (nthr + 63) / 64; ++i) tot += beta_red[i];
+    const float b = t.beta_raw[0];
+    atomicAdd(t.grad_beta, ((b > 0.f) ? 1.f : ((b < 0.f) ? -1.f : 0.f)) * tot);
+  }
+  __syncthreads();
+}
+
 // usage: VAMP_TIMED(slot, stream, kernel<<<...>>>(...));
 #define VAMP_TIMED(slot, stream, launch)              \
   do {                                                \

@@ -333,7 +333,7 @@ static LiftCellWs lift_cell_ws(const VampLiftDesc* d, void* scratch) {
   const size_t cap = (size_t) d->B * d->N * d->Z * d->Y * d->X;
   char* p = static_cast<char*>(scratch);
   LiftCellWs w;
-  w.cnt = reinterpret_cast<int*>(p); p += align_up((size_t) g.ncell * sizeof(int), 256);
+  w.cnt = reinterpret_cast<int*>(p); p += align_up((size_t) (g.ncell + kScanPad) * sizeof(int), 256);   // + the scan's ticket word
   w.off = reinterpret_cast<int*>(p); p += align_up((size_t) g.ncell * sizeof(int), 256);
   w.bsum = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
   w.boff = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
@@ -357,7 +357,7 @@ int launch_lift_cell_prepare(const VampLiftDesc* d, const float* mats, const flo
   const size_t cap = (size_t) d->B * d->N * d->Z * d->Y * d->X;
   VAMP_REQUIRE(cap < 0x7fffffffu && g.ncell < 0x7fffffffL, "pair / cell count exceeds 2^31");
   VAMP_REQUIRE(d->C % 4 == 0, "C must be a multiple of 4");
-  if (int ze = launch_zero(w.cnt, (size_t) g.ncell * sizeof(int), s)) return ze;
+  if (int ze = launch_zero(w.cnt, (size_t) (g.ncell + kScanPad) * sizeof(int), s)) return ze;
   dim3 grid((d->X + 63) / 64, (d->Y + 3) / 4, d->Z * d->B);
   VAMP_TIMED(kProfLiftBwdCount, s, (lift_bwd_cell_kernel<float, 16, false><<<grid, 256, 0, s>>>(
       P, g.cw, g.ch, mats, xs, ys, zs, nullptr, nullptr, nullptr, w.cnt, w.off, w.boff, w.ids, w.recs, w.table, d->N <= 32 ? w.amask : nullptr, 0, d->B * d->N)));

@@ -667,7 +667,8 @@ bev_gather_col_kernel(RenderParams P, const int4* __restrict__ tab, const float*
                       const float* __restrict__ g_vo, int vo_c0, const float* __restrict__ Wb,
                       const float* __restrict__ DS0, float* __restrict__ gdens,
                       float* __restrict__ gout, float* __restrict__ gout2, int nchan, int nchan2,
-                      int zseg, int with_dens, int flags) {
+                      int zseg, int with_dens, int flags, BetaTail btail) {
+  beta_tail(btail);                     // the scan's d beta partials (a launch of its own before round 3)
   __shared__ int tz_i0[kBevMaxOZ];
   __shared__ float tz_w0[kBevMaxOZ], tz_w1[kBevMaxOZ];
   if ((int) threadIdx.x < P.oZ) {
@@ -1026,8 +1027,13 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
 #undef VAMP_BEVB
   // the beta partial sums of the scan are added up where nobody waits: in the second call of a split
   // pair (ONLY_BASE; the first, SKIP_BASE, leaves them in the workspace), else right here
+  // ... by the first workgroup of the first column-gather launch of that call (beta_tail), or, where no
+  // such launch follows, by a launch of its own
+  BetaTail btail{nullptr, 0, nullptr, nullptr};
   if (!skip_base && d->density_mode == VAMP_DENSITY_SDF_LAPLACE)
-    if (int e = launch_beta_reduce(beta_part, (int) bev_scan_blocks(d), beta, grad_beta, s)) return e;
+    btail = BetaTail{beta_part, (int) bev_scan_blocks(d), beta, grad_beta};
+  const BetaTail no_tail{nullptr, 0, nullptr, nullptr};
+  auto take_tail = [&]() { const BetaTail t = btail; btail = no_tail; return t; };
   // lattice points within one voxel's trilinear support, per axis
   bool fits = true;
   const int nvox[3] = {d->X, d->Y, d->Z};
@@ -1067,25 +1073,25 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
     if (only_base) {}
     else if (owc) VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_col_kernel<kColGC, true, false, true><<<grid(d->K + 3, kColGC), 256, 0, s>>>(
         P, tab, ozs, g_bev_seg, g_bev_rgb, nullptr, -1, Wb, DS0, grad_density_feature, grad_semantic, grad_rgb,
-        d->K, 3, zseg, 1, 0)));
+        d->K, 3, zseg, 1, 0, take_tail())));
     else VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_col_kernel<kColGC, true, false, false><<<grid(d->K + 3, kColGC), 256, 0, s>>>(
         P, tab, ozs, g_bev_seg, g_bev_rgb, nullptr, -1, Wb, DS0, grad_density_feature, grad_semantic, grad_rgb,
-        d->K, 3, zseg, 1, 0)));
+        d->K, 3, zseg, 1, 0, take_tail())));
     if (int e = check_launch("bev_gather_col_kernel")) return e;
     // pass-through gradients (voxel_output): the semantic part (cat_seg) adds, base is its own tensor
     if (vo_sem && !only_base)
       VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_col_kernel<kColG, false, true, false><<<grid(d->K), 256, 0, s>>>(
           P, tab, ozs, nullptr, nullptr, g_voxel_output, d->C, Wb, DS0, grad_density_feature, grad_semantic,
-          nullptr, d->K, 0, zseg, 0, 0)));
+          nullptr, d->K, 0, zseg, 0, 0, take_tail())));
     if (skip_base) {}
     else if (d->C > 0 && g_voxel_output && ow)
       VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_col_kernel<kColG, false, true, true><<<grid(d->C), 256, 0, s>>>(
           P, tab, ozs, nullptr, nullptr, g_voxel_output, 0, Wb, DS0, grad_density_feature, grad_base, nullptr,
-          d->C, 0, zseg, 0, 0)));
+          d->C, 0, zseg, 0, 0, take_tail())));
     else if (d->C > 0 && g_voxel_output)
       VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_col_kernel<kColG, false, true, false><<<grid(d->C), 256, 0, s>>>(
           P, tab, ozs, nullptr, nullptr, g_voxel_output, 0, Wb, DS0, grad_density_feature, grad_base, nullptr,
-          d->C, 0, zseg, 0, 0)));
+          d->C, 0, zseg, 0, 0, take_tail())));
     else if (d->C > 0 && ow)
       if (int ze = launch_zero(grad_base, (size_t) d->B * d->C * d->Z * d->Y * d->X * sizeof(float), s)) return ze;
   }
@@ -1099,6 +1105,8 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
         P, oxs, oys, ozs, g_bev_rgb, g_bev_seg, g_voxel_output, Wb, DS0, grad_density_feature,
         grad_semantic, grad_rgb, grad_base, z_lo, z_hi)));
   }
+  if (btail.part)          // no column-gather launch took the partial sums over
+    if (int e = launch_beta_reduce(btail.part, btail.n, btail.beta_raw, btail.grad_beta, s)) return e;
   return check_launch("bev_gather_kernel");
 }
 

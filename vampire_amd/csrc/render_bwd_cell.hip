@@ -144,9 +144,10 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
                            const float4* __restrict__ R, const float* __restrict__ Gcl,
                            float* __restrict__ gdens, float* __restrict__ gsem,
                            float* __restrict__ grgb, long ncell_b, int runs_x, int heavy_thresh,
-                           int accumulate) {
+                           int accumulate, BetaTail btail) {
   constexpr int CP = CP4 * 4;
   constexpr int CVPB = 256 / CGL;
+  beta_tail(btail);                     // the ray pass's d beta partials (a launch of its own before round 3)
   __shared__ float outs[CP][CVPB + 1];
   __shared__ int skip[CVPB];            // the voxel is on the heavy list: its outputs are not ours
   const int tid = threadIdx.x;
@@ -291,7 +292,7 @@ static CellWs cell_ws(const VampRenderDesc* d, void* scratch) {
   const size_t voxels = (size_t) d->B * d->Z * d->Y * d->X;
   char* p = static_cast<char*>(scratch);
   CellWs w;
-  w.cnt = reinterpret_cast<int*>(p); p += align_up((size_t) ncell * sizeof(int), 256);
+  w.cnt = reinterpret_cast<int*>(p); p += align_up((size_t) (ncell + kScanPad) * sizeof(int), 256);   // + the scan's ticket word
   w.off = reinterpret_cast<int*>(p); p += align_up((size_t) ncell * sizeof(int), 256);
   w.bsum = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
   w.boff = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
@@ -327,7 +328,7 @@ int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, con
   const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
   const unsigned sgrid = (unsigned) ((samples + 255) / 256);
   if (phase != 2) {
-    if (int ze = launch_zero(w.cnt, (size_t) ncell * sizeof(int), s)) return ze;
+    if (int ze = launch_zero(w.cnt, (size_t) (ncell + kScanPad) * sizeof(int), s)) return ze;
     VAMP_TIMED(kProfCamBwdCount, s, (cam_cells_rank_kernel<<<sgrid, 256, 0, s>>>(
         P, mats, us, vs, ds, w.cnt, w.key, w.slot, (unsigned) samples, ncell_b, term)));
     if (int e = check_launch("cam_cells_rank_kernel")) return e;
@@ -374,7 +375,7 @@ static int launch_cam_heavy_list(const VampRenderDesc* d, const RenderParams& P,
 // per-voxel gather of the records the per-ray pass has written in cell order
 int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const float* Gcl,
                         float* gdens, float* gsem, float* grgb, void* scratch, int accumulate,
-                        hipEvent_t wait_event, int parts, hipStream_t s) {
+                        hipEvent_t wait_event, int parts, BetaTail btail, hipStream_t s) {
   const CellWs w = cell_ws(d, scratch);
   const long ncell = cell_count_padded(d->B, d->Z, d->Y, d->X);
   const long ntile = ncell / kScanTile;
@@ -403,7 +404,7 @@ int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const fl
   do {                                                                                              \
     if (parts & kCamPartGather)                                                                     \
       VAMP_TIMED(kProfCamBwdBrick, s, (cam_bwd_cell_gather_kernel<CP4, gl><<<grid, 256, 0, s>>>(    \
-          P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, ncell_b, runs_x, heavy_thresh, accumulate))); \
+          P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, ncell_b, runs_x, heavy_thresh, accumulate, btail))); \
     if (parts & kCamPartHeavy)                                                                      \
       VAMP_TIMED(kProfCamBwdOwn, s, (cam_bwd_cell_heavy_kernel<CP4><<<hgrid, 256, 0, s>>>(          \
           P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, w.heavy, nheavy, ncell_b, accumulate)));   \

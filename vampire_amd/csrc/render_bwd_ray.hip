@@ -214,7 +214,7 @@ int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, con
                              const int* term, int phase, hipStream_t s);
 int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const float* Gcl,
                         float* gdens, float* gsem, float* grgb, void* scratch, int accumulate,
-                        hipEvent_t wait_event, int parts, hipStream_t s);
+                        hipEvent_t wait_event, int parts, BetaTail btail, hipStream_t s);
 
 static size_t gcl_bytes(const VampRenderDesc* d) {
   const RenderParams P = to_params(d);
@@ -243,8 +243,13 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
                       int parts, hipStream_t s) {
   float* Gcl = static_cast<float*>(scratch);
   void* cell_scratch = static_cast<char*>(scratch) + gcl_bytes(d);
+  // the ray pass leaves one d beta partial per workgroup; the gather's first workgroup adds them up
+  BetaTail btail{nullptr, 0, nullptr, nullptr};
+  if (P.density_mode == VAMP_DENSITY_SDF_LAPLACE && (parts & kCamPartGather))
+    btail = BetaTail{reinterpret_cast<const float*>(static_cast<char*>(cell_scratch) + cam_bwd_cell_bytes(d)),
+                     (int) ray_grid<4>(P), beta, grad_beta};
   if (!(parts & kCamPartRay))
-    return launch_cam_bwd_cell(d, P, Gcl, gdens, gsem, grgb, cell_scratch, accumulate, wait_event, parts, s);
+    return launch_cam_bwd_cell(d, P, Gcl, gdens, gsem, grgb, cell_scratch, accumulate, wait_event, parts, btail, s);
   // the sample -> slot table depends on the geometry only; the caller may have prepared it
   // (cells_valid 1), or its rank + scan half (2: the slots and the heavy list follow here)
   if (cells_valid != 1)
@@ -273,10 +278,8 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
   if (P.CP == 12) VAMP_RAY(3); else if (P.CP == 24) VAMP_RAY(6); else VAMP_RAY(8);
 #undef VAMP_RAY
   if (int e = check_launch("cam_bwd_ray_kernel")) return e;
-  if (P.density_mode == VAMP_DENSITY_SDF_LAPLACE)
-    if (int e = launch_beta_reduce(beta_part, (int) grid, beta, grad_beta, s)) return e;
   if (!(parts & (kCamPartGather | kCamPartHeavy))) return VAMP_OK;
-  return launch_cam_bwd_cell(d, P, Gcl, gdens, gsem, grgb, cell_scratch, accumulate, wait_event, parts, s);
+  return launch_cam_bwd_cell(d, P, Gcl, gdens, gsem, grgb, cell_scratch, accumulate, wait_event, parts, btail, s);
 }
 
 }  // namespace vamp

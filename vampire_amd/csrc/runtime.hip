@@ -96,11 +96,18 @@ exclusive_scan_kernel(const int* __restrict__ cnt, int* __restrict__ off, int* _
   if (tid == 0) { total[0] = carry; total[1] = 0; }
 }
 
-// Level 1 of the cell-list scan: exclusive scan inside each kScanTile-cell tile (256 threads x 8
-// cells), tile totals to bsum.
+// The cell-list scan in ONE launch.  Level 1: every workgroup scans its kScanTile-cell tile (256
+// threads x 8 cells) exclusively and publishes the tile total.  Level 2: the workgroup that takes the
+// last arrival ticket scans the tile totals (a few hundred values) -- consumers add off[c] +
+// boff[c / kScanTile].  The hand-off goes through agent-scope atomics on both sides (see below).
+// (Two launches before round 3: the second one, a single workgroup, cost a dependent kernel boundary
+// four times per step.)
 __global__ void __launch_bounds__(256)
-cell_scan_tile_kernel(int* __restrict__ cnt, int* __restrict__ off, int* __restrict__ bsum) {
+cell_scan_kernel(int* __restrict__ cnt, int* __restrict__ off, int* __restrict__ bsum, int* __restrict__ boff,
+                 int* __restrict__ fill, int* __restrict__ total, int* __restrict__ ticket, int ntile) {
   __shared__ int wsum[4];
+  __shared__ int is_last;
+  __shared__ int carry;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const long base = (long) blockIdx.x * kScanTile + tid * 8;
   int4* c4 = reinterpret_cast<int4*>(cnt + base);
@@ -135,7 +142,53 @@ cell_scan_tile_kernel(int* __restrict__ cnt, int* __restrict__ off, int* __restr
   int4* o4 = reinterpret_cast<int4*>(off + base);
   o4[0] = make_int4(o8[0], o8[1], o8[2], o8[3]);
   o4[1] = make_int4(o8[4], o8[5], o8[6], o8[7]);
-  if (tid == 255) bsum[blockIdx.x] = run;
+  if (tid == 255) {
+    // Publish the tile total, then take a ticket.  Both, and the last workgroup's reads of the totals,
+    // are agent-scope read-modify-write atomics: they execute at the memory side, past every cache, so
+    // the hand-off needs no release / acquire fence (a release fence here writes back the 16 KB of
+    // offsets the workgroup has just dirtied: measured slower than the second launch it was to
+    // replace).  The exchange has returned before the ticket is taken.
+    const int old = __hip_atomic_exchange(bsum + blockIdx.x, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(old) : "memory");
+    const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == ntile - 1) ? 1 : 0;
+  }
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  if (!is_last) return;
+  // ---- level 2, last workgroup only: exclusive scan of the ntile totals
+  for (int b0 = 0; b0 < ntile; b0 += 256) {
+    const int i = b0 + tid;
+    const int vv = i < ntile ? __hip_atomic_fetch_add(bsum + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    int inc2 = vv;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(inc2, o, 64);
+      if (lane >= o) inc2 += up;
+    }
+    __syncthreads();                                  // wsum of the previous round is consumed
+    if (lane == 63) wsum[wv] = inc2;
+    __syncthreads();
+    int wb = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < wv) wb += wsum[k];
+    const int c0 = carry;
+    if (i < ntile) {
+      boff[i] = c0 + wb + inc2 - vv;
+      fill[i] = 0;
+    }
+    __syncthreads();
+    if (tid == 255) carry = c0 + wb + inc2;
+    __syncthreads();
+  }
+  // total[1] is the heavy-list counter of the cell-list users (aux[ntile + 1]): the list is built
+  // right after this scan, so it is zeroed here instead of by a launch of its own
+  if (tid == 0) {
+    total[0] = carry;
+    total[1] = 0;
+    *ticket = 0;                                      // ready for the next scan without a zero fill
+  }
 }
 
 int launch_cell_scan(int* cnt, int* off, int* bsum, int* boff, int* aux, long ncell,
@@ -143,9 +196,9 @@ int launch_cell_scan(int* cnt, int* off, int* bsum, int* boff, int* aux, long nc
   const long ntile = ncell / kScanTile;
   if (ncell % kScanTile != 0 || ntile > 0x7fffffffL)
     return fail(VAMP_EINVAL, "%s: cell count must be a multiple of the scan tile", __func__);
-  VAMP_TIMED(kProfAux, s, (cell_scan_tile_kernel<<<(unsigned) ntile, 256, 0, s>>>(cnt, off, bsum)));
-  if (int e = check_launch("cell_scan_tile_kernel")) return e;
-  return launch_exclusive_scan(bsum, boff, aux, (int) ntile, aux + ntile, s);
+  VAMP_TIMED(kProfAux, s, (cell_scan_kernel<<<(unsigned) ntile, 256, 0, s>>>(
+      cnt, off, bsum, boff, aux, aux + ntile, cnt + ncell, (int) ntile)));
+  return check_launch("cell_scan_kernel");
 }
 
 // grad_beta += sign(beta_raw) * sum(part[0..n)): the per-workgroup partial sums of d loss / d beta_eff

@@ -383,7 +383,7 @@ static PtsWs pts_ws(const VampSampleDesc* d, long n, void* scratch) {
   const int CP = (d->C + 3) / 4 * 4;
   char* p = static_cast<char*>(scratch);
   PtsWs w;
-  w.cnt = reinterpret_cast<int*>(p); p += align_up((size_t) ncell * sizeof(int), 256);
+  w.cnt = reinterpret_cast<int*>(p); p += align_up((size_t) (ncell + kScanPad) * sizeof(int), 256);   // + the scan's ticket word
   w.off = reinterpret_cast<int*>(p); p += align_up((size_t) ncell * sizeof(int), 256);
   w.bsum = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
   w.boff = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
@@ -413,7 +413,7 @@ static int backward_t(const VampSampleDesc* d, const SampleParams& P, const void
   VAMP_REQUIRE(voxels < 0x7fffffffu && ncell < 0x7fffffffL, "voxel / cell count exceeds 2^31");
   const int CP = (d->C + 3) / 4 * 4, CP4 = CP / 4;
   const T* vol = static_cast<const T*>(volume);
-  if (int ze = launch_zero(w.cnt, (size_t) ncell * sizeof(int), s)) return ze;
+  if (int ze = launch_zero(w.cnt, (size_t) (ncell + kScanPad) * sizeof(int), s)) return ze;
   int* nheavy = w.aux + ntile + 1;
   const unsigned pgrid = (unsigned) std::max<long>(1, (pts + 255) / 256);
   if (pts > 0) {
