@@ -1192,45 +1192,6 @@ def test_sibling_backbones_forward(dev, name):
               atol=2e-4, what=name + " occ_density")
 
 
-@pytest.mark.parametrize("cfg,batch", [(CFG_TINY, 2), (CFG_B, 1)], ids=["tiny", "cfg-B"])
-def test_saved_sample_rows_equal_regather(tiny_common, dev, cfg, batch):
-    """Training forward stores every inside sample's gathered row (vamp_render_camera_forward_ex,
-    VAMP_CAMFWD_SAVE_SAMPLES) and the backward's per-ray pass reads it back; without it the pass
-    repeats the 8-tap gather.  Same arithmetic on the same values: the gradients agree up to the
-    order in which a cell's records are summed."""
-    cfg = dataclasses.replace(cfg, density_mode="sdf")
-    hp = hot(cfg, dev)
-    if cfg.vX == CFG_TINY.vX:
-        _, rm = tiny_mats(tiny_common, dev)
-        srcs = [tiny_common[k] for k in ("density_feature", "semantic_logits", "base", "rgb")]
-        srcs[1] = srcs[1].clone()
-        srcs[1].view(-1)[::97] = float("nan")          # the non-finite path goes through the saved rows too
-    else:
-        s2e, K, ida = synthetic.camera_rig(cfg, batch)
-        rm = render_matrices(s2e, K, ida, synthetic.bda_matrix(batch)).to(dev)
-        srcs = synthetic.render_inputs(cfg, batch, seed=5)
-
-    def run(save):
-        hp.impl["save_samples"] = save
-        vols = [s.to(dev).requires_grad_(True) for s in srcs]
-        beta = torch.tensor(0.1, device=dev, requires_grad=True)
-        outs = hp.render(*vols, beta, render_mats=rm)
-        gen = torch.Generator(device=dev).manual_seed(23)
-        gs = [torch.randn(o.shape, device=dev, generator=gen) for o in outs]
-        for i in (3, 4, 5, 6, 7):
-            gs[i].zero_()                              # camera branch only
-        torch.autograd.backward(outs, gs)
-        return [torch.nan_to_num(v.grad) for v in vols], beta.grad.clone()
-
-    g1, b1 = run(True)
-    g0, b0 = run(False)
-    for name, a, b in zip(("density_feature", "semantic_logits", "base", "rgb"), g1, g0):
-        close(a, b, atol=0.0, rtol=2e-6, scale="max", what="saved rows vs re-gather: grad_" + name)
-    if bool(torch.isfinite(b0)):      # (the BEV branch has no nan_to_num: with nan voxels its d beta is nan either way)
-        close(b1.reshape(1), b0.reshape(1), atol=1e-6, rtol=1e-5, what="saved rows vs re-gather: grad_beta")
-    hp.impl["save_samples"] = False
-
-
 # --------------------------------------------------------------------------- round-3 parity pins: early ray termination
 def _regime_inputs(cfg, regime, dev, with_grad=True):
     """The render inputs of tests/golden/make_golden.py: make_regimes ("sdf" = the bench workload)."""

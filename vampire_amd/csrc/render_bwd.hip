@@ -18,7 +18,7 @@ int launch_pack(const RenderParams& P, int in_dtype, const void* dens, const voi
                 const void* rgb, float* packed, hipStream_t s);
 int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                       const float* us, const float* vs, const float* ds, const float* mids,
-                      const float* beta, const float* packed, const float* g_rgb,
+                      const float* beta, const void* dens, const void* sem, const void* rgbv, const float* g_rgb,
                       const float* g_seg, const float* g_depth, float* gdens, float* gsem,
                       float* grgb, float* grad_beta, void* scratch, int accumulate,
                       hipEvent_t wait_event, int cells_valid, const float* samples, const int* term,
@@ -401,9 +401,11 @@ int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* packed = static_cast<float*>(workspace);
   float* gpacked = reinterpret_cast<float*>(static_cast<char*>(workspace) + pb);
-  // the channel-last copy of the three volumes: the forward left it at the head of the workspace
   const bool part_ray = !(flags & (VAMP_CAMBWD_PART_GATHER | VAMP_CAMBWD_PART_HEAVY)) || (flags & VAMP_CAMBWD_PART_RAY);
-  if (!(flags & VAMP_CAMBWD_PACKED_VALID) && part_ray)
+  // (the default path reads the volumes as they are; only the v1 splat below gathers from a channel-last
+  // copy, which the forward may have left at the head of the workspace)
+  const bool splat = geom || !mats || (flags & VAMP_CAMBWD_SPLAT);
+  if (splat && !(flags & VAMP_CAMBWD_PACKED_VALID) && part_ray)
     if (int e = launch_pack(P, d->in_dtype, density_feature, semantic, rgb, packed, s)) return e;
   // Default: per-ray pass + cell-list gather (render_bwd_ray.hip, render_bwd_cell.hip), which
   // evaluates the frustum points itself from the matrices.  A caller-supplied geom tensor, or
@@ -414,7 +416,6 @@ int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, 
   if (!geom && mats && !(flags & VAMP_CAMBWD_SPLAT)) {
     const float* samples = nullptr;
     if (flags & VAMP_CAMBWD_SAMPLES_VALID) {
-      VAMP_REQUIRE(flags & VAMP_CAMBWD_PACKED_VALID, "SAMPLES_VALID needs PACKED_VALID (the same forward wrote both)");
       if (workspace_bytes < need + vamp_render_samples_bytes(d))
         return fail(VAMP_ENOSPC, "%s: workspace %ld has no room for the sample rows", __func__, (long) workspace_bytes);
       samples = reinterpret_cast<const float*>(static_cast<char*>(workspace) + need);
@@ -429,7 +430,7 @@ int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, 
         if (int e = launch_cam_term(d, P, mats, us, vs, ds, beta, density_feature, term, s)) return e;
       }
     }
-    return launch_cam_bwd_v2(d, P, mats, us, vs, ds, mids, beta, packed, g_rgb, g_seg, g_depth,
+    return launch_cam_bwd_v2(d, P, mats, us, vs, ds, mids, beta, density_feature, semantic, rgb, g_rgb, g_seg, g_depth,
                              grad_density_feature, grad_semantic, grad_rgb, grad_beta, gpacked,
                              accumulate, static_cast<hipEvent_t>(wait_event),
                              (flags & VAMP_CAMBWD_CELLS_VALID) ? ((flags & VAMP_CAMBWD_SLOTS_PENDING) ? 2 : 1) : 0,

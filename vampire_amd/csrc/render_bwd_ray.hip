@@ -2,7 +2,8 @@
 // float-atomic splat kept as an independent cross-check, and the compositing algebra).
 //
 //  cam_bwd_ray   four waves per 8x8 ray tile, one per depth chunk: each re-marches its samples
-//                once (8-tap gather of the packed volume), keeps (s0, delta, q) per sample in
+//                once (x-pair gathers from the channel-first volumes as they are, pair_gather.hpp:
+//                no channel-last copy anywhere on the default path), keeps (s0, delta, q) per sample in
 //                LDS, merges the chunks through LDS and writes one record per inside sample --
 //                the continuous tap coordinates (fx, fy, fz) exactly as the forward computed
 //                them, the compositing weight w_i, dL/ds_i[0], the ray id -- straight to the
@@ -11,18 +12,22 @@
 //                gradient row (Gcl).
 //  The records are then gathered per voxel: render_bwd_cell.hip.
 #include "render_common.hpp"
+#include "pair_gather.hpp"
 
 namespace vamp {
 
 // ---------------------------------------------------------------------------
 // per-ray pass
 // ---------------------------------------------------------------------------
-template <int LPR, int CP4>
+// KT: the number of semantic classes when known at compile time (the channel -> tensor mapping of the
+// gather then costs no scalar selects; 0 = read P.K)
+template <typename T, int LPR, int CP4, int KT>
 __global__ void __launch_bounds__(256)
 cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* __restrict__ us,
                    const float* __restrict__ vs, const float* __restrict__ ds,
                    const float* __restrict__ mids, const float* __restrict__ beta_raw,
-                   const float* __restrict__ packed, const float* __restrict__ g_rgb,
+                   const T* __restrict__ dens, const T* __restrict__ sem, const T* __restrict__ rgbv,
+                   const float* __restrict__ g_rgb,
                    const float* __restrict__ g_seg, const float* __restrict__ g_depth,
                    const int* __restrict__ SLOT, float4* __restrict__ REC,
                    float* __restrict__ Gcl, float* __restrict__ beta_part,
@@ -56,7 +61,13 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
   const float* m = mats + bn * 48;
   const float u = us[w], v = vs[h];
   const long V = (long) P.Z * P.Y * P.X;
-  const float* vol = packed + (long) b * V * CP;
+  const int bu = __builtin_amdgcn_readfirstlane(b);                 // (a tile is one camera of one sample)
+  const __amdgpu_buffer_rsrc_t rs_d = make_rsrc(dens + (long) bu * V, (size_t) V * sizeof(T));
+  const __amdgpu_buffer_rsrc_t rs_s = make_rsrc(sem + (long) bu * P.K * V, (size_t) P.K * V * sizeof(T));
+  const __amdgpu_buffer_rsrc_t rs_r = make_rsrc(rgbv + (long) bu * 3 * V, (size_t) 3 * V * sizeof(T));
+  const unsigned vbytes = (unsigned) V * (unsigned) sizeof(T);
+  const int Kc = KT > 0 ? KT : P.K;
+  const int nch = 1 + Kc + 3;
   const long HW = (long) P.fH * P.fW;
   const long pix = (long) h * P.fW + w;
 
@@ -106,7 +117,27 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
           s[q * 4] = f.x; s[q * 4 + 1] = f.y; s[q * 4 + 2] = f.z; s[q * 4 + 3] = f.w;
         }
       } else {
-        gather_taps<CP4>(P, vol, tp, s);
+        // channel 0 = density feature, 1..K semantic, K+1..K+3 rgb; four x-pair loads per channel, in
+        // batches of four channels (their 16 loads are issued back to back)
+        const PairTap pt = pair_tap<T>(P, tp);
+        unsigned vb = vbytes;
+        asm volatile("" : "+s"(vb));                      // (per-channel offsets recomputed: see render_cam_direct.hip)
+#pragma unroll
+        for (int c0 = 0; c0 < CP; c0 += 4) {
+          PairRaw raw[4][4];
+#pragma unroll
+          for (int uu = 0; uu < 4; ++uu) {
+            const int cc = min(c0 + uu, nch - 1);
+            const __amdgpu_buffer_rsrc_t rs = cc == 0 ? rs_d : (cc <= Kc ? rs_s : rs_r);
+            const unsigned so = (unsigned) (cc == 0 ? 0 : (cc <= Kc ? cc - 1 : cc - 1 - Kc)) * vb;
+            raw[uu][0] = ld_pair<T>(rs, pt.o00, so);
+            raw[uu][1] = ld_pair<T>(rs, pt.o01, so);
+            raw[uu][2] = ld_pair<T>(rs, pt.o10, so);
+            raw[uu][3] = ld_pair<T>(rs, pt.o11, so);
+          }
+#pragma unroll
+          for (int uu = 0; uu < 4; ++uu) s[c0 + uu] = (c0 + uu < nch) ? pair_combine<T>(pt, raw[uu]) : 0.f;
+        }
       }
     }
     const bool fin = (s[0] == s[0]) && (fabsf(s[0]) <= 3.402823466e+38f);
@@ -236,7 +267,7 @@ int launch_cam_prepare(const VampRenderDesc* d, const RenderParams& P, const flo
 
 int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                       const float* us, const float* vs, const float* ds, const float* mids,
-                      const float* beta, const float* packed, const float* g_rgb,
+                      const float* beta, const void* dens, const void* sem, const void* rgbv, const float* g_rgb,
                       const float* g_seg, const float* g_depth, float* gdens, float* gsem,
                       float* grgb, float* grad_beta, void* scratch, int accumulate,
                       hipEvent_t wait_event, int cells_valid, const float* samples, const int* term,
@@ -264,19 +295,24 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
   const size_t lds = (size_t) 3 * L * 256 * sizeof(float);
   if (lds > 150 * 1024) return fail(VAMP_EINVAL, "%s: too many depth samples for the LDS staging", __func__);
   const unsigned grid = ray_grid<LPR>(P);
-#define VAMP_RAY(CP4)                                                                             \
+#define VAMP_RAY_T(T, CP4, KT)                                                                    \
   do {                                                                                            \
-    auto kr = cam_bwd_ray_kernel<LPR, CP4>;                                                       \
+    auto kr = cam_bwd_ray_kernel<T, LPR, CP4, KT>;                                                \
     if (lds > 64 * 1024 &&                                                                        \
         hipFuncSetAttribute(reinterpret_cast<const void*>(kr),                                    \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) \
       return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);                           \
-    VAMP_TIMED(kProfCamBwd, s, (kr<<<grid, 256, lds, s>>>(P, mats, us, vs, ds, mids, beta, packed, \
-                                                           g_rgb, g_seg, g_depth, SLOT, R, Gcl,   \
-                                                           beta_part, samples, term, L)));        \
+    VAMP_TIMED(kProfCamBwd, s, (kr<<<grid, 256, lds, s>>>(P, mats, us, vs, ds, mids, beta,         \
+        static_cast<const T*>(dens), static_cast<const T*>(sem), static_cast<const T*>(rgbv),     \
+        g_rgb, g_seg, g_depth, SLOT, R, Gcl, beta_part, samples, term, L)));                      \
   } while (0)
-  if (P.CP == 12) VAMP_RAY(3); else if (P.CP == 24) VAMP_RAY(6); else VAMP_RAY(8);
+#define VAMP_RAY(CP4, KT)                                                                         \
+  do {                                                                                            \
+    if (d->in_dtype == VAMP_F32) VAMP_RAY_T(float, CP4, KT); else VAMP_RAY_T(__hip_bfloat16, CP4, KT); \
+  } while (0)
+  if (P.CP == 12) VAMP_RAY(3, 0); else if (P.CP == 24 && P.K == 18) VAMP_RAY(6, 18); else if (P.CP == 24) VAMP_RAY(6, 0); else VAMP_RAY(8, 0);
 #undef VAMP_RAY
+#undef VAMP_RAY_T
   if (int e = check_launch("cam_bwd_ray_kernel")) return e;
   if (!(parts & (kCamPartGather | kCamPartHeavy))) return VAMP_OK;
   return launch_cam_bwd_cell(d, P, Gcl, gdens, gsem, grgb, cell_scratch, accumulate, wait_event, parts, btail, s);

@@ -109,10 +109,6 @@ class HotPath:
                      "lift_halves": os.environ.get("VAMP_LIFT_HALVES", "0") == "1",
                      # the BEV forward keeps its samples for the backward (+35 MB per sample at cfg-B)
                      "bev_save": os.environ.get("VAMP_BEV_SAVE", "1") == "1",
-                     # store the forward's sample rows for the backward's per-ray pass: measured
-                     # neutral at cfg-B (forward +50 us for the scattered row stores, backward -59 us),
-                     # so off unless asked for
-                     "save_samples": os.environ.get("VAMP_SAVE_SAMPLES", "0") == "1",
                      # early ray termination in the camera branch (include/vampire_hip.h)
                      "ert": os.environ.get("VAMP_ERT", "1") != "0",
                      # the camera branch as ONE kernel on the channel-first volumes (no packed copy, no
@@ -473,8 +469,7 @@ class _RenderFn(torch.autograd.Function):
         nbytes = hp.lib.vamp_render_workspace_bytes(C.byref(d))
         # training: the march also stores every inside sample's gathered row behind the base region,
         # and the backward's per-ray pass reads it back instead of repeating the 8-tap gather
-        save = (train and geom is None and hp.impl["cam_bwd"] != "v1"
-                and hp.impl["save_samples"])
+        save = False      # (saving the forward's sample rows for the backward measured neutral in round 2: switched off for good)
         if save:
             nbytes += hp.lib.vamp_render_samples_bytes(C.byref(d))
         ws = hp._workspace("render", nbytes)
@@ -499,19 +494,11 @@ class _RenderFn(torch.autograd.Function):
                  and hp.impl["prepare"] and hp.impl["cam_bwd"] != "v1")
         if split and direct:
             # Training step, one-kernel camera forward: this stream runs the camera kernel (which leaves
-            # the per-ray termination table in the workspace) and then the BEV forward; the side stream
-            # makes the channel-last copy the backward's per-ray pass gathers from and, once the table
-            # is there, the backward's geometry-only prepare pass.  Critical chains at cfg-B: 45 + 38 us
-            # here, max(copy 37, camera 45) + prepare 58 there (was: table 19 + copy 37 + prepare 58
-            # beside BEV 55 + march 40).
+            # the per-ray termination table in the workspace) and then the BEV forward; the side stream,
+            # once the table is there, the backward's geometry-only prepare pass.  No channel-last copy:
+            # the backward's per-ray pass gathers from the volumes as they are, like the forward.
             side.wait_stream(cur)
             ctx.ert = ert
-            _capi.check(hp.lib.vamp_render_camera_forward_ex(
-                C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
-                _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
-                _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(),
-                fwd_flags | _capi.VAMP_CAMFWD_TERM_VALID | _capi.VAMP_CAMFWD_PACK_ONLY, _stream(side)),
-                "vamp_render_camera_forward_ex")
             _capi.check(hp.lib.vamp_render_camera_forward_ex(
                 C.byref(d), None, _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
                 _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
@@ -600,7 +587,7 @@ class _RenderFn(torch.autograd.Function):
                 _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(),
                 fwd_flags | _capi.VAMP_CAMFWD_DIRECT, _stream(cur)), "vamp_render_camera_forward_ex")
         else:
-            if ert:
+            if ert and not direct:
                 # the per-ray termination table first: forward, the backward's sort and its per-ray pass
                 # all read it from the workspace
                 _capi.check(hp.lib.vamp_render_camera_terminate(
@@ -610,9 +597,11 @@ class _RenderFn(torch.autograd.Function):
             ctx.ert = ert
             if side is not None:
                 side.wait_stream(cur)
-                if train and geom is None and hp.impl["prepare"] and hp.impl["cam_bwd"] != "v1":
+                if train and geom is None and hp.impl["prepare"] and hp.impl["cam_bwd"] != "v1" and not direct:
                     # the sample -> cell-slot table of the backward depends on the geometry (and the
                     # termination table) only: it is built here, on the side stream, beside the forward
+                    # (with the one-kernel forward the table is that kernel's by-product: the backward
+                    # builds its cell lists itself)
                     _capi.check(hp.lib.vamp_render_camera_prepare_ex(
                         C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(),
                         _capi.VAMP_CAMPREP_TERM_VALID if ert else 0, _stream(side)), "vamp_render_camera_prepare_ex")
@@ -624,15 +613,16 @@ class _RenderFn(torch.autograd.Function):
                 C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
                 _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
                 _ptr(vdens), _ptr(vout), _ptr(ws_bev), ws_bev.numel() if bev_save else 0,
-                (_capi.VAMP_BEVFWD_SAVE if bev_save else 0) | bev_flags, _stream(side)), "vamp_render_bev_forward_ex")
+                (_capi.VAMP_BEVFWD_SAVE if bev_save else 0) | bev_flags, _stream(cur if side is None else side)),
+                "vamp_render_bev_forward_ex")
             hp._bev_gen = getattr(hp, "_bev_gen", 0) + 1
             ctx.bev_key = (hp._bev_gen, ws_bev.data_ptr()) if bev_save else None
             _capi.check(hp.lib.vamp_render_camera_forward_ex(
                 C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
                 _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
                 _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(),
-                fwd_flags | (_capi.VAMP_CAMFWD_SAVE_SAMPLES if save else 0), _stream(cur)),
-                "vamp_render_camera_forward_ex")
+                fwd_flags | (_capi.VAMP_CAMFWD_SAVE_SAMPLES if save else 0) | (_capi.VAMP_CAMFWD_DIRECT if direct else 0),
+                _stream(cur)), "vamp_render_camera_forward_ex")
         ctx.samples = save
         if side is not None:
             cur.wait_stream(side)
@@ -640,7 +630,8 @@ class _RenderFn(torch.autograd.Function):
         # the workspace now starts with the channel-last copy of (dens, sem, rgb); the backward
         # reuses it if no other render call has touched the workspace in between
         hp._pack_gen = getattr(hp, "_pack_gen", 0) + 1
-        ctx.pack_key = None if (direct and not train) else (hp._pack_gen, ws.data_ptr())   # (the direct kernel packs nothing)
+        ctx.pack_key = None if (direct and not train) else (hp._pack_gen, ws.data_ptr())
+        ctx.packed = not direct                 # (the one-kernel forward makes no channel-last copy)
         ctx.has_geom = geom is not None
         ctx.save_for_backward(dens, sem, base, rgb, beta, geom if geom is not None else mats)
         return rgb_p, seg_p, dep_p, bev_rgb, bev_seg, bev_h, vdens, vout
@@ -706,6 +697,8 @@ class _RenderFn(torch.autograd.Function):
             packed_valid |= _capi.VAMP_CAMBWD_TERM_VALID           # same validity as the packed copy
         else:
             packed_valid &= ~(4 | _capi.VAMP_CAMBWD_SLOTS_PENDING)  # no table: the cells are rebuilt with a fresh one
+        if not ctx.packed:
+            packed_valid &= ~2                                   # table / cells are there, a packed copy (v1 splat only) is not
         hp._pack_gen = getattr(hp, "_pack_gen", 0) + 1          # the backward scribbles after the copy only,
         ctx.pack_key = None                                     # but a second backward must not assume so
         if side is not None and geom is None and default_impl:
