@@ -56,7 +56,9 @@ def kernel_algorithmic_bytes(cfg, B):
         "render_cam_fwd": B * (4 * cam * V + 4 * P * (K + 4)),
         "render_cam_term": B * (4 * V + 4 * P),                   # density volume in, one int per ray out
         "render_bev_fwd": B * (4 * V * zf + 4 * YX * (oZ + 1)),
-        "render_bev_fwd_channels": B * (4 * (K + 3 + C) * V * zf + 4 * YX * (K + 3) + 4 * oZ * YX * CO),
+        # (since round 3 one kernel: density, weights and all channels -- the density planes and voxel_density /
+        # bev_height are its traffic too)
+        "render_bev_fwd_channels": B * (4 * (1 + K + 3 + C) * V * zf + 4 * YX * (K + 3) + 4 * oZ * YX * CO + 4 * YX * (oZ + 1)),
         "render_cam_bwd_ray": B * (4 * cam * V + 4 * P * (K + 4)),  # volumes + upstream gradients in
         "render_cam_bwd_gather": B * (2 * 4 * cam * V),           # the three volume gradients: BEV part in, sum out
         "render_bev_bwd_q": B * (4 * (K + 3) * V * zf + 4 * YX * (K + 3)),

@@ -14,6 +14,7 @@ SLOTS = [("lift_fwd_kernel", "lift_fwd"), ("lift_bwd_cell_gather_kernel", "lift_
          ("lift_bwd_cell_kernel", None), ("lift_bwd_kernel", "lift_bwd_v1"),
          ("feat_to_channel_last", "feat_to_channel_last"), ("pack_volume_kernel", "pack_volume"),
          ("render_cam_fwd_kernel", "render_cam_fwd"), ("render_cam_fwd_plan_kernel", "render_cam_fwd"),
+         ("cam_fwd_direct_kernel", "render_cam_fwd"), ("bev_fwd_fused_kernel", "render_bev_fwd_channels"),
          ("cam_term_kernel", "render_cam_term"), ("bev_density_kernel", "render_bev_fwd"),
          ("bev_channels_kernel", "render_bev_fwd_channels"), ("cam_bwd_ray_kernel", "render_cam_bwd_ray"),
          ("cam_bwd_cell_gather_kernel", "render_cam_bwd_gather"), ("cam_bwd_cell_heavy_kernel", "render_cam_bwd_heavy"),
