@@ -93,6 +93,19 @@ int vamp_lift_forward(const VampLiftDesc* d, const float* mats, const float* xs,
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Producer fusion (bv2:550 `mapping_along_depth(src).softmax(dim=1)` feeding bv2:553):
+ * `logits` [B, N, D, fH, fW] (logits_dtype VAMP_F32 | VAMP_BF16) are the raw depth logits.  ONE launch
+ * makes both lift operands -- the softmax over D into `depth_out` (fp32 [B, N, D, fH, fW]; keep it for
+ * the backward, where it is the `depth` argument) and the channel-last feature copy -- and the lift
+ * follows.  d->in_dtype must be VAMP_F32 (feat fp32), d->use_depth 1.  Everything else as
+ * vamp_lift_forward.
+ */
+int vamp_lift_forward_logits(const VampLiftDesc* d, const float* mats, const float* xs,
+                             const float* ys, const float* zs, const void* logits,
+                             int32_t logits_dtype, const float* feat, float* depth_out, float* out,
+                             uint64_t* hits, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Backward of vamp_lift_forward w.r.t. depth and feat (autograd of bv2:507-514,
  * i.e. grid_sampler_3d_backward + the mean).  grad_depth / grad_feat are fp32 and
  * fully overwritten.  grad_depth may be NULL when use_depth == 0.
@@ -120,6 +133,10 @@ int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs
 #define VAMP_LIFTBWD_WPP16 16
 #define VAMP_LIFTBWD_HALF_LO 64   /* only the lower half of the flattened (sample, camera) images: with CELLS_VALID, ... */
 #define VAMP_LIFTBWD_HALF_HI 128  /* ... the two halves touch disjoint records and outputs and may run on two streams */
+/* LOGITS: `depth` is softmax(logits) over D as written by vamp_lift_forward_logits, and grad_depth receives
+   the gradient w.r.t. the LOGITS, p * (g - sum_d p g) (autograd of bv2:550): applied to the pixel's column
+   while it sits in LDS, no extra pass.  Default (cell-list) backward only. */
+#define VAMP_LIFTBWD_LOGITS 256
 int vamp_lift_prepare(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                       const float* zs, void* workspace, size_t workspace_bytes, void* stream);
 int vamp_lift_backward_ex(const VampLiftDesc* d, const float* mats, const float* xs,

@@ -122,6 +122,64 @@ def test_lift_bf16_inputs(tiny_common, dev):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("ldtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_lift_logits_tiny(tiny_common, dev, ldtype):
+    """N2 producer fusion (bv2:550 + 553): the lift fed with depth LOGITS -- softmax inside the operand
+    launch, softmax backward inside the gather -- against torch.softmax -> lift through autograd, and
+    against the golden lift at the logits whose softmax is the fixture's depth."""
+    g = tiny_common
+    hp = hot(CFG_TINY, dev)
+    lm, _ = tiny_mats(g, dev)
+    lg0 = g["depth"].to(dev).clamp_min(1e-30).log()              # softmax(log p) = p for a normalised p
+    if ldtype == torch.float32:
+        close(hp.lift_logits(lg0, g["feat"].to(dev), lm), g["lift"], atol=1e-5, what="lift_logits vs golden")
+    gen = torch.Generator(device=dev).manual_seed(3)
+    lg = (torch.randn(lg0.shape, device=dev, generator=gen) * 2).to(ldtype)
+    a_l = lg.clone().requires_grad_(True); a_f = g["feat"].to(dev).requires_grad_(True)
+    b_l = lg.clone().requires_grad_(True); b_f = g["feat"].to(dev).requires_grad_(True)
+    out_a = hp.lift_logits(a_l, a_f, lm)
+    out_b = hp.lift(b_l.float().softmax(dim=2), b_f, lm)
+    close(out_a, out_b, atol=1e-6, rtol=1e-5, what="lift_logits forward")
+    out_a.backward(g["g_lift"].to(dev)); out_b.backward(g["g_lift"].to(dev))
+    assert a_l.grad.dtype == ldtype
+    tol = dict(atol=1e-5, rtol=1e-5) if ldtype == torch.float32 else dict(atol=1e-5, rtol=1e-2)
+    close(a_l.grad, b_l.grad, scale="max", what="grad logits", **tol)
+    close(a_f.grad, b_f.grad, atol=1e-5, rtol=1e-5, scale="max", chan_dim=2, what="grad feat")
+    # the atomic-splat cross-check implementation behind the same entry
+    hp.impl["lift_bwd"] = "v1"
+    c_l = lg.clone().requires_grad_(True); c_f = g["feat"].to(dev).requires_grad_(True)
+    hp.lift_logits(c_l, c_f, lm).backward(g["g_lift"].to(dev))
+    close(c_l.grad, b_l.grad, scale="max", what="v1 grad logits", **tol)
+    # no-grad call: no hit words, same values
+    with torch.no_grad():
+        assert torch.equal(hp.lift_logits(lg, g["feat"].to(dev), lm), out_a)
+
+
+@pytest.mark.parametrize("wpp", [0, 4], ids=["wpp1", "wpp4"])
+def test_lift_logits_full_size(dev, wpp):
+    """Same at cfg-B, B=2 (jittered rigs + bda), halves on two streams as in the training step."""
+    cfg = CFG_B
+    hp = hot(cfg, dev)
+    hp.impl["lift_wpp"] = wpp
+    s2e, K, ida = synthetic.camera_rig(cfg, 2, jitter=2.0, seed=11)
+    lm = lift_matrices(s2e, K, ida, synthetic.bda_matrix(2, rot_deg=-6.0, scale=1.02)).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(8)
+    _, feat = synthetic.lift_inputs(cfg, 2, seed=6, device=dev)
+    lg = torch.randn(2, feat.shape[1], cfg.D, cfg.fH, cfg.fW, device=dev, generator=gen) * 3
+    a_l = lg.clone().requires_grad_(True); a_f = feat.clone().requires_grad_(True)
+    b_l = lg.clone().requires_grad_(True); b_f = feat.clone().requires_grad_(True)
+    out_a = hp.lift_logits(a_l, a_f, lm)
+    out_b = hp.lift(b_l.softmax(dim=2), b_f, lm)
+    close(out_a, out_b, atol=1e-6, rtol=1e-5, what="forward")
+    go = torch.randn(out_a.shape, device=dev, generator=gen)
+    out_a.backward(go); out_b.backward(go)
+    assert float(b_l.grad.abs().max()) > 0
+    close(a_l.grad, b_l.grad, atol=1e-7, rtol=2e-5, scale="max", what="grad logits")
+    close(a_f.grad, b_f.grad, atol=1e-6, rtol=2e-5, scale="max", chan_dim=2, what="grad feat")
+    # softmax rows: the gradient of the logits sums to zero over D
+    assert float(a_l.grad.sum(2).abs().max()) <= 1e-4 * float(a_l.grad.abs().max()) * cfg.D ** 0.5 + 1e-7
+
+
 # --------------------------------------------------------------------------- render
 def test_frustum_geometry_bitexact(tiny_common, dev):
     g = tiny_common

@@ -56,6 +56,7 @@ VAMP_PAD_ZEROS, VAMP_PAD_BORDER = 0, 1
 VAMP_LIFTBWD_CELLS_VALID, VAMP_LIFTBWD_SPLAT = 1, 2
 VAMP_LIFTBWD_WPP1, VAMP_LIFTBWD_WPP4, VAMP_LIFTBWD_WPP16 = 4, 8, 16
 VAMP_LIFTBWD_HALF_LO, VAMP_LIFTBWD_HALF_HI = 64, 128
+VAMP_LIFTBWD_LOGITS = 256
 VAMP_CAMBWD_ACCUMULATE, VAMP_CAMBWD_PACKED_VALID, VAMP_CAMBWD_CELLS_VALID, VAMP_CAMBWD_SPLAT = 1, 2, 4, 8
 VAMP_CAMBWD_SAMPLES_VALID, VAMP_CAMBWD_TERM_VALID, VAMP_CAMBWD_NO_ERT = 16, 32, 64
 VAMP_CAMBWD_PART_RAY, VAMP_CAMBWD_PART_GATHER, VAMP_CAMBWD_PART_HEAVY = 128, 256, 512
@@ -84,6 +85,7 @@ SIGNATURES = {
                                     C.POINTER(C.c_double)]),
     "vamp_lift_workspace_bytes": (C.c_size_t, [_LD]),
     "vamp_lift_forward": (C.c_int, [_LD] + [_P] * 8 + [_P, C.c_size_t, _P]),
+    "vamp_lift_forward_logits": (C.c_int, [_LD] + [_P] * 5 + [C.c_int32] + [_P] * 4 + [_P, C.c_size_t, _P]),
     "vamp_lift_backward": (C.c_int, [_LD] + [_P] * 10 + [_P, C.c_size_t, _P]),
     "vamp_lift_backward_ex": (C.c_int, [_LD] + [_P] * 10 + [_P, C.c_size_t, C.c_int, _P]),
     "vamp_lift_prepare": (C.c_int, [_LD] + [_P] * 4 + [_P, C.c_size_t, _P]),

@@ -59,12 +59,16 @@ def _resize(x, size):
 
 # Switches of the module path, read ONCE at import (not on every forward): VAMP_CONV3D=0 keeps MIOpen for
 # every 3-D convolution, VAMP_CONV3D_MIN_VOXELS is the volume size from which the HIP convolution is
-# used, VAMP_GLUE=hip routes the depth softmax / density gate through the HIP kernels.  Tests and
+# used, VAMP_GLUE=hip routes the depth softmax / density gate through the standalone HIP kernels,
+# VAMP_FUSE=0 turns the fused producer / consumer forms off.  Tests and
 # tools flip the attributes of `SWITCHES`.
 class _Switches:
     conv3d = os.environ.get("VAMP_CONV3D", "1") != "0"
     conv3d_min_voxels = int(os.environ.get("VAMP_CONV3D_MIN_VOXELS", "50000"))
     hip_glue = os.environ.get("VAMP_GLUE", "aten") == "hip"
+    # SURVEY 8f N2, the fused forms (default on): the depth softmax runs inside the lift's operand launch
+    # and its backward inside the lift backward's gather; VAMP_FUSE=0 restores softmax -> lift
+    fuse = os.environ.get("VAMP_FUSE", "1") != "0"
 
 
 SWITCHES = _Switches()
@@ -328,12 +332,14 @@ class BaseVAMPIRE2(nn.Module):
             return self.hot_path().lift(None, frustum_feats.float(), mats, use_depth=False)
         return self.hot_path().lift_dense(frustum_feats.float(), mats)
 
-    def lift(self, depth, feat, sweep_index, mats_dict):
-        """Fused lift: depth [B,N,D,fH,fW] and feat [B,N,C,fH,fW]; no outer product."""
-        mats = G.lift_matrices(mats_dict["sensor2ego_mats"][:, sweep_index],
+    def _lift_mats(self, sweep_index, mats_dict):
+        return G.lift_matrices(mats_dict["sensor2ego_mats"][:, sweep_index],
                                mats_dict["intrin_mats"][:, sweep_index],
                                mats_dict["ida_mats"][:, sweep_index], mats_dict.get("bda_mat", None))
-        return self.hot_path().lift(depth, feat, mats)
+
+    def lift(self, depth, feat, sweep_index, mats_dict):
+        """Fused lift: depth [B,N,D,fH,fW] and feat [B,N,C,fH,fW]; no outer product."""
+        return self.hot_path().lift(depth, feat, self._lift_mats(sweep_index, mats_dict))
 
     # -- RENDER (bv2:391-467) -----------------------------------------------
     def volume_rendering_from_multiple_views(self, geom_xyz, density_feature, semantic_logits,
@@ -402,9 +408,15 @@ class BaseVAMPIRE2(nn.Module):
         hip_glue = SWITCHES.hip_glue
         if self._USE_DEPTH:
             logits = self.mapping_along_depth(src)
-            depth = hp.depth_softmax(logits) if hip_glue else logits.float().softmax(dim=1)   # bv2:550
-            depth = depth.reshape(B, N, -1, *src.shape[-2:])
-            voxel_features = self.lift(depth, feat.float(), sweep_index, mats_dict)
+            if SWITCHES.fuse and hasattr(hp, "lift_logits"):
+                # bv2:550 + 553 fused: the lift takes the logits (softmax in its operand launch, softmax
+                # backward in its gather); no depth tensor in the autograd graph
+                voxel_features = hp.lift_logits(logits.reshape(B, N, -1, *src.shape[-2:]), feat.float(),
+                                                self._lift_mats(sweep_index, mats_dict))
+            else:
+                depth = hp.depth_softmax(logits) if hip_glue else logits.float().softmax(dim=1)   # bv2:550
+                depth = depth.reshape(B, N, -1, *src.shape[-2:])
+                voxel_features = self.lift(depth, feat.float(), sweep_index, mats_dict)
         else:
             voxel_features = self.get_voxel_feats(feat, sweep_index, mats_dict)     # base_bilinear.py:566
         if self.cat_pos:

@@ -10,74 +10,17 @@
 //                  (naive), base_vampire2.py:627-630, in front of the `voxel_output` 1x1 conv.  The
 //                  backward produces both gradients in one pass over (grad, voxel_output).
 // Elementwise / short reductions, HBM-bound: no MFMA.
-#include "common.hpp"
+#include "depth_softmax.hpp"
 
 namespace vamp {
 namespace {
 
-constexpr int kPix = 64;     // pixels per workgroup (= lanes of a wave)
-constexpr int kSplit = 4;    // waves per workgroup = chunks of the depth axis
-
-constexpr int kRegBins = 32; // depth bins a lane keeps in registers (D <= kSplit * kRegBins)
-
-// REG: the wave's chunk of the depth axis lives in registers, so the logits are read once and all
-// loads of a lane are in flight together; otherwise (D > 128) the chunk is streamed twice.
 template <typename T, bool REG>
 __global__ void __launch_bounds__(256)
 depth_softmax_fwd_kernel(const T* __restrict__ logits, float* __restrict__ out, int D, long HW,
                          int tiles) {
-  __shared__ float sm[kSplit][kPix], ss[kSplit][kPix];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const long img = blockIdx.x / tiles;
-  const long pix = (long) (blockIdx.x % tiles) * kPix + lane;
-  const bool live = pix < HW;
-  const int L = (D + kSplit - 1) / kSplit;
-  const int d0 = wv * L, d1 = min(D, d0 + L);
-  const long base = img * D * HW + (live ? pix : HW - 1);
-  // local (max, sum of exp) of this wave's depth chunk
-  float m = -INFINITY, s = 0.f;
-  float x[REG ? kRegBins : 1];
-  if (REG) {
-#pragma unroll
-    for (int k = 0; k < kRegBins; ++k)
-      x[k] = (d0 + k < d1) ? ldf(logits, base + (long) (d0 + k) * HW) : -INFINITY;
-#pragma unroll
-    for (int k = 0; k < kRegBins; ++k) m = fmaxf(m, x[k]);
-    if (m > -INFINITY) {
-#pragma unroll
-      for (int k = 0; k < kRegBins; ++k) s += expf(x[k] - m);
-    }
-  } else {
-    for (int d = d0; d < d1; ++d) {
-      const float v = ldf(logits, base + (long) d * HW);
-      const float mn = fmaxf(m, v);
-      if (mn > -INFINITY) s = s * expf(m - mn) + expf(v - mn);
-      m = mn;
-    }
-  }
-  sm[wv][lane] = m;
-  ss[wv][lane] = s;
-  __syncthreads();
-  float M = sm[0][lane];
-#pragma unroll
-  for (int k = 1; k < kSplit; ++k) M = fmaxf(M, sm[k][lane]);
-  float S = 0.f;
-#pragma unroll
-  for (int k = 0; k < kSplit; ++k) {
-    const float mk = sm[k][lane];
-    S += (mk == -INFINITY) ? 0.f : ss[k][lane] * expf(mk - M);
-  }
-  if (!live) return;
-  if (REG) {
-#pragma unroll
-    for (int k = 0; k < kRegBins; ++k)
-      if (d0 + k < d1) out[base + (long) (d0 + k) * HW] = expf(x[k] - M) / S;
-  } else {
-    for (int d = d0; d < d1; ++d) {
-      const float v = ldf(logits, base + (long) d * HW);
-      out[base + (long) d * HW] = expf(v - M) / S;
-    }
-  }
+  __shared__ SoftmaxLds L;
+  depth_softmax_tile<T, REG>(logits, out, D, HW, blockIdx.x / tiles, blockIdx.x % tiles, L);
 }
 
 // grad_logits = p * (g - sum_d p g)

@@ -10,6 +10,7 @@
 // [B,C,Z,Y,X] stores coalesce; features are read channel-last (one 64-byte run
 // per tap for C = 16) from a transposed copy made by a tiny pre-pass.
 #include "lift_common.hpp"
+#include "depth_softmax.hpp"
 
 namespace vamp {
 
@@ -17,11 +18,9 @@ namespace vamp {
 // feat [BN, C, HW] (f32 or bf16) -> channel-last fp32 [BN, HW, C]
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) feat_to_channel_last(const T* __restrict__ feat,
-                                                            float* __restrict__ out, int C, int HW) {
-  __shared__ float tile[64][65];
-  const long bn = blockIdx.z;
-  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+__device__ __forceinline__ void feat_to_channel_last_tile(const T* __restrict__ feat, float* __restrict__ out,
+                                                          int C, int HW, long bn, int p0, int c0,
+                                                          float (&tile)[64][65]) {
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int j = ty; j < 64; j += 4) {
     int c = c0 + j, p = p0 + tx;
@@ -31,6 +30,39 @@ __global__ void __launch_bounds__(256) feat_to_channel_last(const T* __restrict_
   for (int j = ty; j < 64; j += 4) {
     int p = p0 + j, c = c0 + tx;
     if (p < HW && c < C) out[(bn * HW + p) * C + c] = tile[tx][j];
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) feat_to_channel_last(const T* __restrict__ feat,
+                                                            float* __restrict__ out, int C, int HW) {
+  __shared__ float tile[64][65];
+  feat_to_channel_last_tile<T>(feat, out, C, HW, blockIdx.z, blockIdx.x * 64, blockIdx.y * 64, tile);
+}
+
+// ---------------------------------------------------------------------------
+// Both lift operands in one launch (the producer side): workgroups [0, n_sm) turn
+// the raw `mapping_along_depth` logits into the depth distribution (softmax over D,
+// base_vampire2.py:550), the rest make the channel-last copy of the features.  The two jobs are
+// independent, so the 6 600 softmax tiles and the 1 100 transpose tiles of cfg-B share one grid.
+// ---------------------------------------------------------------------------
+template <typename TL, bool REG>
+__global__ void __launch_bounds__(256)
+lift_operands_kernel(const TL* __restrict__ logits, float* __restrict__ depth, int D, long HW, int sm_tiles,
+                     unsigned n_sm, const float* __restrict__ feat, float* __restrict__ feat_cl, int C,
+                     int ptiles, int ctiles) {
+  __shared__ union {
+    SoftmaxLds sm;
+    float tile[64][65];
+  } L;
+  if (blockIdx.x < n_sm) {
+    depth_softmax_tile<TL, REG>(logits, depth, D, HW, blockIdx.x / sm_tiles, blockIdx.x % sm_tiles, L.sm);
+  } else {
+    unsigned r = blockIdx.x - n_sm;
+    const int px = r % ptiles;
+    r /= ptiles;
+    const int ct = r % ctiles;
+    feat_to_channel_last_tile<float>(feat, feat_cl, C, (int) HW, (long) (r / ctiles), px * 64, ct * 64, L.tile);
   }
 }
 
@@ -468,6 +500,42 @@ int vamp_lift_forward(const VampLiftDesc* d, const float* mats, const float* xs,
   return lift_forward_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, s);
 }
 
+int vamp_lift_forward_logits(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
+                             const float* zs, const void* logits, int32_t logits_dtype, const float* feat,
+                             float* depth_out, float* out, uint64_t* hits, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  VAMP_REQUIRE(mats && xs && ys && zs && logits && feat && depth_out && out, "null pointer");
+  VAMP_REQUIRE(d->use_depth == 1, "the logits entry is the depth-distribution lift");
+  VAMP_REQUIRE(d->in_dtype == VAMP_F32, "feat (and the depth distribution written here) are fp32");
+  VAMP_REQUIRE(logits_dtype == VAMP_F32 || logits_dtype == VAMP_BF16, "logits_dtype");
+  VAMP_REQUIRE(fused_channels_ok(d->C), "C must be 4, 8 or a multiple of 16 (<= 64)");
+  const LiftWs w = carve(d, workspace);
+  if (!workspace || workspace_bytes < w.bytes)
+    return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) w.bytes);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const LiftParams P = to_params(d);
+  const long BN = (long) d->B * d->N, HW = (long) d->fH * d->fW;
+  const long sm_tiles = (HW + kPix - 1) / kPix;
+  const int ptiles = (int) ((HW + 63) / 64), ctiles = (d->C + 63) / 64;
+  const long n_sm = BN * sm_tiles, n_cl = BN * ptiles * ctiles;
+  VAMP_REQUIRE(n_sm + n_cl < 0x7fffffffL, "too many tiles");
+  const unsigned grid = (unsigned) (n_sm + n_cl);
+#define VAMP_OPERANDS(TL, REG)                                                                           \
+  VAMP_TIMED(kProfFeatCL, s, (lift_operands_kernel<TL, REG><<<grid, 256, 0, s>>>(                        \
+      static_cast<const TL*>(logits), depth_out, d->D, HW, (int) sm_tiles, (unsigned) n_sm, feat,        \
+      w.feat_cl, d->C, ptiles, ctiles)))
+  const bool reg = d->D <= kSplit * kRegBins;
+  if (logits_dtype == VAMP_F32) {
+    if (reg) VAMP_OPERANDS(float, true); else VAMP_OPERANDS(float, false);
+  } else {
+    if (reg) VAMP_OPERANDS(__hip_bfloat16, true); else VAMP_OPERANDS(__hip_bfloat16, false);
+  }
+#undef VAMP_OPERANDS
+  if (int e = check_launch("lift_operands_kernel")) return e;
+  return lift_forward_t<float>(d, P, mats, xs, ys, zs, depth_out, w.feat_cl, out, hits, s);
+}
+
 int vamp_lift_prepare(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                       const float* zs, void* workspace, size_t workspace_bytes, void* stream) {
   if (int e = validate(d)) return e;
@@ -511,8 +579,10 @@ int vamp_lift_backward_ex(const VampLiftDesc* d, const float* mats, const float*
     const int half = (flags & VAMP_LIFTBWD_HALF_LO) ? 1 : ((flags & VAMP_LIFTBWD_HALF_HI) ? 2 : 0);
     VAMP_REQUIRE(half == 0 || (flags & VAMP_LIFTBWD_CELLS_VALID), "HALF_LO / HALF_HI need CELLS_VALID");
     return launch_lift_bwd_cell(d, mats, xs, ys, zs, depth, feat, grad_out, hits, grad_depth,
-                                grad_feat, w.cells, (flags & VAMP_LIFTBWD_CELLS_VALID) != 0, wpp, half, s);
+                                grad_feat, w.cells, (flags & VAMP_LIFTBWD_CELLS_VALID) != 0, wpp, half,
+                                (flags & VAMP_LIFTBWD_LOGITS) != 0, s);
   }
+  VAMP_REQUIRE(!(flags & VAMP_LIFTBWD_LOGITS), "VAMP_LIFTBWD_LOGITS is a feature of the default (cell-list) backward");
   if (d->in_dtype == VAMP_F32) launch_to_cl<float>(feat, w.feat_cl, BN, d->C, HW, s);
   else launch_to_cl<__hip_bfloat16>(feat, w.feat_cl, BN, d->C, HW, s);
   if (int e = check_launch("feat_to_channel_last")) return e;

@@ -175,7 +175,8 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
                             const int* __restrict__ off, const int* __restrict__ boff,
                             const int* __restrict__ ids, const float4* __restrict__ recs,
                             const float4* __restrict__ table,
-                            float* __restrict__ gdepth, float* __restrict__ gfeat, long pix_lo, long pix_hi) {
+                            float* __restrict__ gdepth, float* __restrict__ gfeat, long pix_lo, long pix_hi,
+                            int softmax_bwd) {
   extern __shared__ float smem[];                // [ppb][Dp] grad columns, [ppb][Dp] depth columns, [waves][16]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int C = P.C, D = P.use_depth ? P.D : 0;
@@ -304,12 +305,27 @@ lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
   }
   if (D > 0 && gdepth) {
     __syncthreads();
+    if (softmax_bwd) {
+      // VAMP_LIFTBWD_LOGITS: the depth column is softmax(logits) (base_vampire2.py:550) and the caller
+      // wants the gradient of the logits, p * (g - sum_d p g): both columns sit in LDS, so the
+      // softmax backward costs one wave reduction per pixel and no pass over HBM
+      if (ws == 0) {
+        float dot = 0.f;
+        for (int dz = lane; dz < D; dz += 64) dot = __builtin_fmaf(dcol[dz], gcol[dz], dot);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+        if (lane == 0) accbuf[pw] = dot;
+      }
+      __syncthreads();
+    }
     // consecutive threads = consecutive pixels of one depth plane
     for (int e = tid; e < D * ppb; e += nw * 64) {
       const int dz = e / ppb, p = e % ppb;
       const long pp = pid0 + p;
       if (pp >= npix) continue;
-      gdepth[((pp / HW) * P.D + dz) * HW + pp % HW] = gd[p * Dp + dz];
+      float v = gd[p * Dp + dz];
+      if (softmax_bwd) v = dcolumns[p * Dp + dz] * (v - accbuf[p]);
+      gdepth[((pp / HW) * P.D + dz) * HW + pp % HW] = v;
     }
   }
 }
@@ -369,7 +385,7 @@ template <typename T>
 static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float* mats,
                          const float* xs, const float* ys, const float* zs, const void* depth,
                          const void* feat, const float* gout, const uint64_t* hits, float* gdepth,
-                         float* gfeat, void* scratch, bool cells_valid, int wpp_force, int half,
+                         float* gfeat, void* scratch, bool cells_valid, int wpp_force, int half, bool softmax_bwd,
                          hipStream_t s) {
   const LiftCells g = lift_cells(d);
   const LiftCellWs w = lift_cell_ws(d, scratch);
@@ -412,7 +428,7 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
       return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);
     VAMP_TIMED(kProfLiftBwd, s, (k<<<ggrid, nw * 64, lds, s>>>(
         P, g.cw, g.ch, wpp, (d->fW % ppb == 0) ? d->fW / ppb : 0, mats, xs, ys, zs, dp, static_cast<const T*>(feat),
-        w.off, w.boff, w.ids, w.recs, w.table, gdepth, gfeat, pix_lo, pix_hi)));
+        w.off, w.boff, w.ids, w.recs, w.table, gdepth, gfeat, pix_lo, pix_hi, softmax_bwd ? 1 : 0)));
   }
   return check_launch("lift_bwd_cell_gather_kernel");
 }
@@ -420,13 +436,13 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
 int launch_lift_bwd_cell(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                          const float* zs, const void* depth, const void* feat, const float* gout,
                          const uint64_t* hits, float* gdepth, float* gfeat, void* scratch,
-                         bool cells_valid, int wpp_force, int half, hipStream_t s) {
+                         bool cells_valid, int wpp_force, int half, bool softmax_bwd, hipStream_t s) {
   const LiftParams P = to_params(d);
   if (d->in_dtype == VAMP_F32)
     return launch_cell_t<float>(d, P, mats, xs, ys, zs, depth, feat, gout, hits, gdepth, gfeat, scratch,
-                                cells_valid, wpp_force, half, s);
+                                cells_valid, wpp_force, half, softmax_bwd, s);
   return launch_cell_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, feat, gout, hits, gdepth, gfeat,
-                                       scratch, cells_valid, wpp_force, half, s);
+                                       scratch, cells_valid, wpp_force, half, softmax_bwd, s);
 }
 
 }  // namespace vamp

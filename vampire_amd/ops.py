@@ -184,6 +184,13 @@ class HotPath:
         with torch.cuda.device(self.device):      # launches go to this object's device, whatever is current
             return _LiftFn.apply(self, depth, feat, lift_mats, use_depth, torch.is_grad_enabled())
 
+    def lift_logits(self, logits, feat, lift_mats):
+        """The lift fed with the raw depth LOGITS [B,N,D,fH,fW] (fp32 | bf16): the softmax of bv2:550 runs
+        in the launch that prepares the lift's operands and its backward inside the lift backward's
+        gather (producer side) -- same values as ``lift(logits.softmax(2), feat, mats)``."""
+        with torch.cuda.device(self.device):
+            return _LiftFn.apply(self, logits, feat, lift_mats, True, torch.is_grad_enabled(), True)
+
     def lift_dense(self, frustum_feats, lift_mats):
         """frustum_feats [B,N,C,D,fH,fW] (materialised, fp32) -> [B,C,Z,Y,X]."""
         return _LiftDenseFn.apply(self, frustum_feats, lift_mats)
@@ -313,12 +320,18 @@ class HotPath:
 # ===========================================================================
 class _LiftFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, hp: HotPath, depth, feat, mats, use_depth, grad_mode=True):
+    def forward(ctx, hp: HotPath, depth, feat, mats, use_depth, grad_mode=True, logits=False):
         c = hp.cfg
         B, N, C_ = feat.shape[:3]
+        ctx.logits = logits
         ctx.in_dtypes = (depth.dtype if use_depth else None, feat.dtype)
         feat = _accept(feat)
-        if use_depth:
+        if logits:
+            # `depth` holds the logits (their own dtype); the kernel writes the fp32 distribution
+            lg = _chk(_accept(depth), (B, N, c.D, c.fH, c.fW), "depth logits")
+            feat = feat.float()
+            depth = torch.empty(lg.shape, dtype=torch.float32, device=lg.device)
+        elif use_depth:
             depth = _accept(depth)
             if depth.dtype != feat.dtype:               # mixed inputs (e.g. fp32 softmax output + half features)
                 depth, feat = depth.float(), feat.float()
@@ -352,10 +365,16 @@ class _LiftFn(torch.autograd.Function):
                                                  _ptr(hp.zs), _ptr(ws), ws.numel(), _stream(side)),
                         "vamp_lift_prepare")
             ctx.cells_key = (hp._lift_gen, ws.data_ptr())
-        _capi.check(hp.lib.vamp_lift_forward(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys), _ptr(hp.zs),
-                                             _ptr(depth if use_depth else None), _ptr(feat), _ptr(out),
-                                             _ptr(hits), _ptr(ws), ws.numel(), _stream(cur)),
-                    "vamp_lift_forward")
+        if logits:
+            _capi.check(hp.lib.vamp_lift_forward_logits(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys), _ptr(hp.zs),
+                                                        _ptr(lg), _dtype_code(lg), _ptr(feat), _ptr(depth), _ptr(out),
+                                                        _ptr(hits), _ptr(ws), ws.numel(), _stream(cur)),
+                        "vamp_lift_forward_logits")
+        else:
+            _capi.check(hp.lib.vamp_lift_forward(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys), _ptr(hp.zs),
+                                                 _ptr(depth if use_depth else None), _ptr(feat), _ptr(out),
+                                                 _ptr(hits), _ptr(ws), ws.numel(), _stream(cur)),
+                        "vamp_lift_forward")
         if side is not None:
             cur.wait_stream(side)
         if need_grad:
@@ -377,6 +396,8 @@ class _LiftFn(torch.autograd.Function):
         hp._lift_gen = getattr(hp, "_lift_gen", 0) + 1       # the backward consumes the prepared counters
         if hp.impl["lift_bwd"] == "v1":
             valid = _capi.VAMP_LIFTBWD_SPLAT
+        elif ctx.logits:
+            valid |= _capi.VAMP_LIFTBWD_LOGITS
         valid |= {1: _capi.VAMP_LIFTBWD_WPP1, 4: _capi.VAMP_LIFTBWD_WPP4,
                   16: _capi.VAMP_LIFTBWD_WPP16}.get(hp.impl["lift_wpp"], 0)
         def call(flags, stream):
@@ -396,8 +417,11 @@ class _LiftFn(torch.autograd.Function):
             cur.wait_stream(side)
         else:
             call(valid, None)
+        if ctx.logits and hp.impl["lift_bwd"] == "v1":
+            # (the cross-check implementation returns the gradient of the distribution)
+            gdepth = depth * (gdepth - (depth * gdepth).sum(2, keepdim=True))
         gd = gdepth.to(ctx.in_dtypes[0]) if use_depth else None
-        return None, gd, gfeat.to(ctx.in_dtypes[1]), None, None, None
+        return None, gd, gfeat.to(ctx.in_dtypes[1]), None, None, None, None
 
 
 class _LiftDenseFn(torch.autograd.Function):
