@@ -492,6 +492,30 @@ int vamp_density_gate_backward(int64_t B, int32_t C, int64_t cells, int32_t dens
                                const float* voxel_density, float* grad_voxel_output,
                                float* grad_voxel_density, void* stream);
 
+/*
+ * Consumer fusion (base_vampire2.py:627-632 with the conv of :203-209): the density gate and
+ * the `voxel_output` 1x1 convolution in one kernel each way, on the fp32 matrix cores --
+ *   out[b, o, cell] = bias[o] + sum_ci weight[o, ci] * voxel_output[b, ci, cell] * gate(voxel_density[b, ci % oZ, cell])
+ * with ci = c * oZ + z (the reference's reshape(B, C * oZ, oY, oX)), cell = oY * oX positions of the BEV
+ * plane, gate = tanh (sdf density) or identity (naive).  voxel_output [B, C, oZ, cells], voxel_density
+ * [B, 1, oZ, cells] (outputs of vamp_render_forward), weight [Cout, C * oZ] (= Conv2d.weight), bias [Cout] or
+ * NULL, out [B, Cout, cells]; fp32, contiguous.  The gated tensor is never materialised.
+ * Shapes: C * oZ <= 160, Cout <= 80, oZ <= 32 (vamp_gate_conv1x1_supported; else callers keep aten).
+ */
+int vamp_gate_conv1x1_supported(int32_t C, int32_t oZ, int32_t Cout);
+size_t vamp_gate_conv1x1_workspace_bytes(int32_t C, int32_t oZ, int32_t Cout);
+int vamp_gate_conv1x1_forward(int64_t B, int32_t C, int32_t oZ, int64_t cells, int32_t Cout,
+                              int32_t density_mode, const float* voxel_output,
+                              const float* voxel_density, const float* weight, const float* bias,
+                              float* out, void* stream);
+/* grad_voxel_output [B, C, oZ, cells], grad_voxel_density [B, 1, oZ, cells], grad_weight [Cout, C * oZ] and
+ * grad_bias [Cout] (may be NULL) are fully overwritten; deterministic (no float atomics). */
+int vamp_gate_conv1x1_backward(int64_t B, int32_t C, int32_t oZ, int64_t cells, int32_t Cout,
+                               int32_t density_mode, const float* grad_out, const float* voxel_output,
+                               const float* voxel_density, const float* weight,
+                               float* grad_voxel_output, float* grad_voxel_density, float* grad_weight,
+                               float* grad_bias, void* workspace, size_t workspace_bytes, void* stream);
+
 /* --------------------------------------------------------------------------
  * Trilinear resize inside the 3-D UNet between lift and render (first piece):
  * F.interpolate(x, size, mode='trilinear', align_corners=True), base_vampire2.py:66, 72.

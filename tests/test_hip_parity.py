@@ -345,6 +345,42 @@ def test_density_gate_full_size(dev):
 
 
 # --------------------------------------------------------------------------- HIP graph capture
+@pytest.mark.parametrize("mode", ["sdf", "naive"])
+@pytest.mark.parametrize("shape", [(2, 16, 10, 37, 41, 80), (1, 9, 6, 16, 16, 8), (1, 16, 10, 256, 256, 80)],
+                         ids=["ragged", "tiny", "ref-grid"])
+def test_gate_conv1x1(dev, mode, shape):
+    import torch.nn.functional as F
+    """N2 consumer fusion (bv2:627-632): gate + `voxel_output` 1x1 conv in one matrix-core kernel each way
+    against the reference's aten expression, all five gradients; ragged sizes exercise the cell / channel
+    padding, `ref-grid` is the reference's 256 x 256 x 10 det grid with 16 -> 80 channels."""
+    import dataclasses
+    B, C_, oZ, oY, oX, cout = shape
+    hp = hot(dataclasses.replace(CFG_TINY, density_mode=mode), dev)
+    assert hp.gate_conv1x1_supported(C_, oZ, cout)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    rnd = lambda *s_: torch.randn(*s_, device=dev, generator=gen)
+    vo, vd = rnd(B, C_, oZ, oY, oX), rnd(B, 1, oZ, oY, oX)
+    w, bs = rnd(cout, C_ * oZ, 1, 1) * 0.1, rnd(cout)
+    go = rnd(B, cout, oY, oX)
+    leaves_a = [t.clone().requires_grad_(True) for t in (vo, vd, w, bs)]
+    leaves_b = [t.clone().double().requires_grad_(True) for t in (vo, vd, w, bs)]
+    out = hp.gate_conv1x1(*leaves_a)
+    gate = leaves_b[1].tanh() if mode == "sdf" else leaves_b[1]
+    ref = F.conv2d((leaves_b[0] * gate).reshape(B, C_ * oZ, oY, oX), leaves_b[2], leaves_b[3])
+    close(out, ref, atol=1e-5, rtol=1e-5, scale="max", what="gate_conv forward")
+    out.backward(go); ref.backward(go.double())
+    for a, b_, name in zip(leaves_a, leaves_b, ("voxel_output", "voxel_density", "weight", "bias")):
+        close(a.grad, b_.grad, atol=1e-6, rtol=2e-5, scale="max", what="grad " + name)
+    # deterministic: same bits on a second run
+    leaves_c = [t.clone().requires_grad_(True) for t in (vo, vd, w, bs)]
+    hp.gate_conv1x1(*leaves_c).backward(go)
+    assert all(torch.equal(a.grad, c.grad) for a, c in zip(leaves_a, leaves_c))
+    # no bias
+    o2 = hp.gate_conv1x1(vo, vd, w, None)
+    close(o2, ref - leaves_b[3].view(1, -1, 1, 1), atol=1e-5, rtol=1e-5, scale="max", what="no bias")
+    assert not hp.gate_conv1x1_supported(34, 10, 80)      # cat_seg at the reference sizes: aten path
+
+
 @pytest.mark.parametrize("cfg,batch", [(CFG_TINY, 2), (CFG_B, 1)], ids=["tiny", "cfg-B"])
 def test_step_is_graph_capturable(dev, cfg, batch):
     """The whole step (both streams, the prepare passes, workspaces, memsets) captures into one

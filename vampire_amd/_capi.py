@@ -126,6 +126,12 @@ SIGNATURES = {
     "vamp_conv3d_backward_weight": (C.c_int, [_CD, _P, _P, _P, _P, C.c_size_t, _P]),
     "vamp_density_gate_backward": (C.c_int, [C.c_int64, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, _P, _P,
                                              _P]),
+    "vamp_gate_conv1x1_supported": (C.c_int, [C.c_int32] * 3),
+    "vamp_gate_conv1x1_workspace_bytes": (C.c_size_t, [C.c_int32] * 3),
+    "vamp_gate_conv1x1_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32]
+                                  + [_P] * 6),
+    "vamp_gate_conv1x1_backward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32]
+                                   + [_P] * 9 + [C.c_size_t, _P]),
 }
 
 _lib = None

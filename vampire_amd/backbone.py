@@ -459,11 +459,19 @@ class BaseVAMPIRE2(nn.Module):
         up = lambda t: self.upsample2d(t.reshape(B * N, -1, self.fH, self.fW)).reshape(
             B, N, -1, self.fH * self.upsample_factor, self.fW * self.upsample_factor)
         rgb_p, seg_p, depth_p = up(rgb_p), up(seg_p), up(depth_p)
-        if hip_glue:
-            voxel_output = hp.density_gate(voxel_output, bev_density)  # bv2:627-630, HIP consumer kernel
+        conv = self.voxel_output[0] if isinstance(self.voxel_output, nn.Sequential) else self.voxel_output
+        if (SWITCHES.fuse and hasattr(hp, "gate_conv1x1")
+                and hp.gate_conv1x1_supported(voxel_output.shape[1], voxel_output.shape[2], conv.out_channels)):
+            # bv2:627-632 fused: gate and 1x1 conv in one matrix-core kernel, the gated tensor never exists
+            bev_feat = hp.gate_conv1x1(voxel_output, bev_density, conv.weight, conv.bias)
+            if conv is not self.voxel_output:
+                bev_feat = self.voxel_output[1](bev_feat)          # the 256-cell grid's 0.5x bilinear resize (bv2:205)
         else:
-            voxel_output = voxel_output * (bev_density.tanh() if self.density_mode == "sdf" else bev_density)
-        bev_feat = self.voxel_output(voxel_output.reshape(B, -1, *voxel_output.shape[-2:])).float()
+            if hip_glue:
+                voxel_output = hp.density_gate(voxel_output, bev_density)  # bv2:627-630, HIP consumer kernel
+            else:
+                voxel_output = voxel_output * (bev_density.tanh() if self.density_mode == "sdf" else bev_density)
+            bev_feat = self.voxel_output(voxel_output.reshape(B, -1, *voxel_output.shape[-2:])).float()
         return (bev_feat.contiguous(), rgb_p, seg_p, depth_p, bev_rgb, bev_seg, bev_height,
                 bev_density, pts_logits_batch, pts_sdf_batch,
                 None if occ_logits is None else occ_logits.permute(0, 2, 3, 4, 1),

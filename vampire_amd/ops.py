@@ -12,9 +12,11 @@ All heavy work happens in hand-written HIP kernels reached through ctypes
 (`_capi`); torch supplies device memory and the current stream only.
 """
 import ctypes as C
+import math
 import os
 
 import numpy as np
+
 import torch
 
 from . import _capi
@@ -313,6 +315,17 @@ class HotPath:
         """`voxel_output * bev_density.tanh()` (sdf) / `voxel_output * bev_density` (naive),
         bv2:627-630: [B,C,oZ,oY,oX] x [B,1,oZ,oY,oX] -> [B,C,oZ,oY,oX]."""
         return _DensityGateFn.apply(self, voxel_output, voxel_density)
+
+
+    def gate_conv1x1_supported(self, C_, oZ, cout):
+        return bool(self.lib.vamp_gate_conv1x1_supported(int(C_), int(oZ), int(cout)))
+
+    def gate_conv1x1(self, voxel_output, voxel_density, weight, bias=None):
+        """The density gate and the `voxel_output` 1x1 conv in one kernel (bv2:627-632; SURVEY 8f N2, consumer
+        side): voxel_output [B,C,oZ,oY,oX], voxel_density [B,1,oZ,oY,oX], weight [Cout, C*oZ(,1,1)], bias
+        [Cout] | None -> [B,Cout,oY,oX] = conv1x1((voxel_output * gate(voxel_density)).reshape(B, C*oZ, oY, oX))."""
+        with torch.cuda.device(self.device):
+            return _GateConvFn.apply(self, voxel_output, voxel_density, weight, bias)
 
 
 # ===========================================================================
@@ -884,6 +897,45 @@ class _DensityGateFn(torch.autograd.Function):
             _capi.check(ctx.hp.lib.vamp_density_gate_backward(*ctx.dims, _ptr(g), _ptr(vo), _ptr(vd), _ptr(gvo),
                                                               _ptr(gvd), _stream()), "vamp_density_gate_backward")
         return None, gvo, gvd
+
+
+class _GateConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hp: HotPath, vo, vd, weight, bias):
+        if not (vo.is_cuda and vd.is_cuda and weight.is_cuda):
+            raise _capi.VampireHipError("gate_conv1x1 needs device tensors (no CPU fallback)")
+        B, C_, oZ = vo.shape[:3]
+        plane = tuple(vo.shape[3:])
+        cells = int(math.prod(plane))
+        cout = weight.shape[0]
+        vd = _chk(vd.float(), (B, 1, oZ) + plane, "voxel_density")
+        vo = vo.float().contiguous()
+        w = _chk(weight.float().reshape(cout, -1), (cout, C_ * oZ), "weight")
+        bs = None if bias is None else _chk(bias.float(), (cout,), "bias")
+        mode = (_capi.VAMP_DENSITY_SDF_LAPLACE if hp.cfg.density_mode == "sdf" else _capi.VAMP_DENSITY_SIGMOID)
+        out = torch.empty((B, cout) + plane, dtype=torch.float32, device=vo.device)
+        dims = (B, C_, oZ, cells, cout, mode)
+        _capi.check(hp.lib.vamp_gate_conv1x1_forward(*dims, _ptr(vo), _ptr(vd), _ptr(w), _ptr(bs), _ptr(out),
+                                                     _stream()), "vamp_gate_conv1x1_forward")
+        ctx.hp, ctx.dims, ctx.wshape, ctx.has_bias = hp, dims, tuple(weight.shape), bias is not None
+        ctx.dtypes = (weight.dtype, None if bias is None else bias.dtype)
+        ctx.save_for_backward(vo, vd, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        hp = ctx.hp
+        vo, vd, w = ctx.saved_tensors
+        g = g.contiguous().float()
+        gvo, gvd, gw = torch.empty_like(vo), torch.empty_like(vd), torch.empty_like(w)
+        gb = torch.empty(w.shape[0], dtype=torch.float32, device=w.device) if ctx.has_bias else None
+        B, C_, oZ, cells, cout, mode = ctx.dims
+        ws = hp._workspace("gate_conv", hp.lib.vamp_gate_conv1x1_workspace_bytes(C_, oZ, cout))
+        _capi.check(hp.lib.vamp_gate_conv1x1_backward(*ctx.dims, _ptr(g), _ptr(vo), _ptr(vd), _ptr(w), _ptr(gvo),
+                                                      _ptr(gvd), _ptr(gw), _ptr(gb), _ptr(ws), ws.numel(), _stream()),
+                    "vamp_gate_conv1x1_backward")
+        return (None, gvo, gvd, gw.reshape(ctx.wshape).to(ctx.dtypes[0]),
+                None if gb is None else gb.to(ctx.dtypes[1]))
 
 
 # ===========================================================================
