@@ -284,6 +284,43 @@ def layered_measure(cfg, dev, batch_per_gpu, rank, world, steps=6, warm=3):
                     "voxel_output: forward + backward from synthetic neck features"}
 
 
+def multitask_measure(dev, batch_per_gpu, rank, world, steps=4, warm=2):
+    """BASELINE.json configs[4]: the full multi-task model -- ResNet-50 + SECOND FPN image encoder, the
+    backbone with the HIP lift / render / query / gate operators, the CenterPoint-style BEV head -- on the
+    reference's own configuration (cfg-A: 256 x 704 images, 256 x 256 x 20 seg grid, base_exp.py:40-252),
+    a collate_fn-shaped synthetic batch, the nine losses, AdamW step, under bf16 autocast; data-parallel
+    over the ranks (gradient all-reduce as in layered_measure).  Encoders / head / losses are this
+    build's own stand-ins for the absent mmdet / mmdet3d / torchmetrics (vampire_amd/multitask.py)."""
+    from vampire_amd import dist as vdist
+    from vampire_amd import multitask as M
+    from vampire_amd.config import CFG_A
+    torch.backends.cudnn.benchmark = True
+    torch.manual_seed(0)
+    bb, hd = M.reference_confs(CFG_A)
+    model = M.VAMPIRE2(bb, hd).to(dev)
+    with torch.no_grad():
+        model.backbone.density_conv.bias.fill_(CFG_A.sdf_bias)     # informative densities (the init value saturates every ray)
+    wrapped = vdist.wrap_ddp(model, dev)
+    loss_fn = M.MultiTaskLoss(model, downsample_factor=4, upsample_factor=4, sdf_bias=CFG_A.sdf_bias)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    data = M.synthetic_batch(CFG_A, batch_per_gpu, seed=vdist.shard_seed(0, rank), device=dev, num_points=30000, num_boxes=30)
+    loss = None
+    for _ in range(warm):
+        loss = M.multitask_step(wrapped, loss_fn, data, optimizer=opt)
+    vdist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = M.multitask_step(wrapped, loss_fn, data, optimizer=opt)
+    vdist.barrier(); torch.cuda.synchronize()
+    el = vdist.max_over_ranks(time.perf_counter() - t0, dev)
+    nparam = sum(p.numel() for p in model.parameters())
+    return {"ms_per_step": el / steps * 1e3, "samples_per_s": batch_per_gpu * world * steps / el, "steps": steps,
+            "parameters": nparam, "loss": float(loss), "amp": "bf16", "batch_per_gpu": batch_per_gpu,
+            "loss_terms": {k: float(v) for k, v in loss_fn.last.items()},
+            "what": "configs[4]: R50 + SECONDFPN + BaseVAMPIRE2 (HIP operators) + BEVDepthHead stand-ins, 9 losses, "
+                    "AdamW; cfg-A, synthetic collate_fn-shaped batch; forward + backward + optimizer step"}
+
+
 def capture_step(model, batch, train_step):
     """One training step (without the DDP wrapper) captured into a HIP graph; the replay must
     reproduce the eager gradients."""
@@ -324,6 +361,8 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations (extra_configs)")
+    ap.add_argument("--multitask", action="store_true",
+                    help="also time the full multi-task step of BASELINE configs[4] (R50 encoder, BEV head, 9 losses; bf16 autocast)")
     ap.add_argument("--layers", action="store_true",
                     help="also time the step wrapped with the backbone's own layers (always done when --gpus > 1)")
     a = ap.parse_args()
@@ -494,6 +533,7 @@ def main():
 
     # with more than one rank (or --layers) also the step with a real gradient bucket
     layered = layered_measure(cfg, dev, a.batch, rank, world) if (world > 1 or a.layers) else None
+    multitask = multitask_measure(dev, a.batch, rank, world) if a.multitask else None
 
     prof = dict(warm)
     # the dominant kernel: measured over the timed region
@@ -565,6 +605,7 @@ def main():
             "stages": stages,
             "step_matrix": step_matrix,
             "layered_step": layered,
+            "multitask_step": multitask,
             "early_ray_termination": ert_stats,
             "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in sorted(kern.items())},
             "kernels_us_per_step": {k: round(v["us_per_step"], 2) for k, v in sorted(kern.items())},

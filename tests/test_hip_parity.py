@@ -1427,3 +1427,56 @@ def test_camera_direct_forward_full_size(dev, regime):
             ref = json.load(f)[regime]
         for nm, o in zip(NAMES, new):
             _block_check(o, ref[nm], f"{regime} direct {nm}", rtol=5e-5, elem_atol=1e-8)
+
+
+# --------------------------------------------------------------------------- N4: configs[4] end to end
+def test_multitask_step_matches_oracle_operators(dev):
+    """The full multi-task model (R18 encoder, backbone, BEV head, nine losses) with the HIP operators on the
+    GPU against the same weights and batch with the oracle operators on CPU: every loss term."""
+    import copy
+    import dataclasses
+    from vampire_amd import multitask as M
+    from tests.test_multitask import OracleOps
+    cfg = dataclasses.replace(CFG_TINY, density_mode="sdf", final_dim=(192, 224), num_classes=6)
+    torch.manual_seed(0)
+    bb, hd = M.reference_confs(cfg, output_channels=8, small_encoder=True)
+    ref = M.VAMPIRE2(bb, hd)
+    with torch.no_grad():
+        ref.backbone.density_conv.bias.fill_(cfg.sdf_bias)
+    mod = copy.deepcopy(ref).to(dev)
+    ref.backbone._hot = OracleOps(cfg)
+    batch = M.synthetic_batch(cfg, 2, seed=5, num_points=40, num_boxes=6)
+    batch_d = M.synthetic_batch(cfg, 2, seed=5, num_points=40, num_boxes=6, device=dev)
+    lf_r, lf_d = M.MultiTaskLoss(ref, sdf_bias=cfg.sdf_bias), M.MultiTaskLoss(mod, sdf_bias=cfg.sdf_bias)
+    loss_r = M.multitask_step(ref, lf_r, batch, amp_dtype=None)
+    loss_d = M.multitask_step(mod, lf_d, batch_d, amp_dtype=None)
+    for k in lf_r.last:
+        a, b = float(lf_d.last[k]), float(lf_r.last[k])
+        assert abs(a - b) <= 2e-3 * abs(b) + 1e-4, (k, a, b)
+    assert abs(float(loss_d) - float(loss_r)) <= 2e-3 * abs(float(loss_r))
+    # gradients of a few representative parameters (encoder stem, depth head, 3-D stem, BEV head)
+    pr, pd = dict(ref.named_parameters()), dict(mod.named_parameters())
+    for name in ("backbone.img_backbone.conv1.weight", "backbone.mapping_along_depth.0.weight",
+                 "backbone.base_conv.init_dres.weight", "backbone.voxel_output.weight", "head.shared_conv.0.weight"):
+        close(pd[name].grad, pr[name].grad, atol=1e-6, rtol=2e-2, scale="max", what="grad " + name)
+
+
+def test_multitask_step_reference_config_bf16(dev):
+    """configs[4] at the reference's own configuration (cfg-A, ResNet-50, 256 x 704, bf16 autocast), one
+    sample: finite losses, a gradient on every parameter, stride-8 neck features feeding the lift."""
+    from vampire_amd import multitask as M
+    from vampire_amd.config import CFG_A
+    torch.manual_seed(0)
+    bb, hd = M.reference_confs(CFG_A)
+    model = M.VAMPIRE2(bb, hd).to(dev)
+    with torch.no_grad():
+        model.backbone.density_conv.bias.fill_(CFG_A.sdf_bias)
+    feats = model.backbone.get_cam_feats(torch.zeros(1, 1, 6, 3, 256, 704, device=dev))
+    assert feats.shape == (1, 1, 6, 512, 32, 88)
+    batch = M.synthetic_batch(CFG_A, 1, seed=2, device=dev, num_points=5000, num_boxes=20)
+    lf = M.MultiTaskLoss(model, sdf_bias=CFG_A.sdf_bias)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    loss = M.multitask_step(model, lf, batch, optimizer=opt)
+    assert torch.isfinite(loss)
+    assert all(torch.isfinite(torch.as_tensor(v)) for v in lf.last.values())
+    assert not [n for n, p in model.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]

@@ -172,6 +172,10 @@ def _build_image_encoder(img_backbone_conf, img_neck_conf, downsample):
         from mmdet3d.models import build_neck
         return build_backbone(img_backbone_conf), build_neck(img_neck_conf)
     except ImportError:
+        if img_backbone_conf.get("type") == "ResNet" and img_neck_conf.get("type") == "SECONDFPN":
+            # mmdet / mmdet3d absent: this build's own ResNet + SECOND FPN (vampire_amd/encoders.py)
+            from .encoders import build_backbone, build_neck
+            return build_backbone(img_backbone_conf), build_neck(img_neck_conf)
         return _StandInEncoder(sum(img_neck_conf["out_channels"]), downsample), _Identity()
 
 

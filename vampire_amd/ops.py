@@ -126,11 +126,16 @@ class HotPath:
                      "prepare": os.environ.get("VAMP_PREPARE", "1") != "0"}
 
     # ---------------------------------------------------------------- descs
-    def lift_desc(self, B, N, C_, dtype_code, use_depth=True) -> _capi.VampLiftDesc:
+    def lift_desc(self, B, N, C_, dtype_code, use_depth=True, fhw=None) -> _capi.VampLiftDesc:
+        """`fhw`: size of the image feature map when it is not final_dim / downsample_factor -- the lift
+        samples it in normalised coordinates (bv2:499-507), so any resolution works: the reference's own
+        ResNet-50 + SECONDFPN(upsample_strides=[0.5, 1, 2, 4]) delivers stride-8 maps (32 x 88) beside
+        the stride-4 frustum of the renderer."""
         c = self.cfg
         d = _capi.VampLiftDesc()
         d.B, d.N, d.C = B, N, C_
-        d.D, d.fH, d.fW = (c.D if use_depth else 1), c.fH, c.fW
+        d.D = c.D if use_depth else 1
+        d.fH, d.fW = (c.fH, c.fW) if fhw is None else (int(fhw[0]), int(fhw[1]))
         d.Z, d.Y, d.X = c.vZ, c.vY, c.vX
         d.u_max, d.v_max = float(c.final_dim[1] - 0.5), float(c.final_dim[0] - 0.5)
         d.u_div, d.v_div = float(c.final_dim[1] - 1), float(c.final_dim[0] - 1)
@@ -341,7 +346,7 @@ class _LiftFn(torch.autograd.Function):
         feat = _accept(feat)
         if logits:
             # `depth` holds the logits (their own dtype); the kernel writes the fp32 distribution
-            lg = _chk(_accept(depth), (B, N, c.D, c.fH, c.fW), "depth logits")
+            lg = _chk(_accept(depth), (B, N, c.D) + tuple(feat.shape[-2:]), "depth logits")
             feat = feat.float()
             depth = torch.empty(lg.shape, dtype=torch.float32, device=lg.device)
         elif use_depth:
@@ -349,10 +354,11 @@ class _LiftFn(torch.autograd.Function):
             if depth.dtype != feat.dtype:               # mixed inputs (e.g. fp32 softmax output + half features)
                 depth, feat = depth.float(), feat.float()
         code = _dtype_code(feat)
-        d = hp.lift_desc(B, N, C_, code, use_depth)
-        feat = _chk(feat, (B, N, C_, c.fH, c.fW), "feat")
+        fhw = tuple(feat.shape[-2:])
+        d = hp.lift_desc(B, N, C_, code, use_depth, fhw=fhw)
+        feat = _chk(feat, (B, N, C_) + fhw, "feat")
         if use_depth:
-            depth = _chk(depth, (B, N, c.D, c.fH, c.fW), "depth")
+            depth = _chk(depth, (B, N, c.D) + fhw, "depth")
             if depth.dtype != feat.dtype:
                 raise TypeError("depth and feat must share a dtype")
         mats = _chk(mats.float(), (B, N, 3, 4, 4), "lift_mats")
@@ -443,9 +449,9 @@ class _LiftDenseFn(torch.autograd.Function):
         c = hp.cfg
         B, N, C_, D = ff.shape[:4]
         use_depth = D > 1
-        d = hp.lift_desc(B, N, C_, _capi.VAMP_F32, use_depth)
+        d = hp.lift_desc(B, N, C_, _capi.VAMP_F32, use_depth, fhw=tuple(ff.shape[-2:]))
         d.D = D
-        ff = _chk(ff.float(), (B, N, C_, D, c.fH, c.fW), "frustum_feats")
+        ff = _chk(ff.float(), (B, N, C_, D) + tuple(ff.shape[-2:]), "frustum_feats")
         mats = _chk(mats.float(), (B, N, 3, 4, 4), "lift_mats")
         out = torch.empty(B, C_, c.vZ, c.vY, c.vX, dtype=torch.float32, device=ff.device)
         nchunk = (C_ + 15) // 16
