@@ -172,7 +172,8 @@ def _build_image_encoder(img_backbone_conf, img_neck_conf, downsample):
         from mmdet3d.models import build_neck
         return build_backbone(img_backbone_conf), build_neck(img_neck_conf)
     except ImportError:
-        if img_backbone_conf.get("type") == "ResNet" and img_neck_conf.get("type") == "SECONDFPN":
+        if (img_backbone_conf.get("type") == "ResNet" and img_neck_conf.get("type") == "SECONDFPN"
+                and "depth" in img_backbone_conf and "upsample_strides" in img_neck_conf):
             # mmdet / mmdet3d absent: this build's own ResNet + SECOND FPN (vampire_amd/encoders.py)
             from .encoders import build_backbone, build_neck
             return build_backbone(img_backbone_conf), build_neck(img_neck_conf)
