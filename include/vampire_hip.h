@@ -517,6 +517,29 @@ int vamp_gate_conv1x1_backward(int64_t B, int32_t C, int32_t oZ, int64_t cells, 
                                float* grad_bias, void* workspace, size_t workspace_bytes, void* stream);
 
 /* --------------------------------------------------------------------------
+ * BEVDepth-style voxel pooling (north_star's "LSS frustum-to-voxel pooling op").
+ * NOT in /root/reference at the pinned commit (its backbones lift with grid_sample = vamp_lift_*); this
+ * follows the published BEVDepth operator `voxel_pooling(geom_xyz, input_features, voxel_num)`:
+ *   out[b, y, x, :] = sum of feat[b, p, :] over the points p with 0 <= geom[b, p] = (x, y, z) < (nx, ny, nz).
+ * geom_xyz [B, P, 3] int32 voxel indices (P = N * D * H * W frustum points), feat [B, P, C] (in_dtype),
+ * out [B, ny, nx, C] fp32, fully overwritten (the caller permutes to [B, C, ny, nx] as upstream does).
+ * Sort-then-own instead of upstream's float atomics; sums run in list order (last-bit run-to-run
+ * variation, like upstream).  Parity unpinned: checked against a numpy scatter-add of the definition.
+ * -------------------------------------------------------------------------- */
+typedef struct VampPoolDesc {
+  int32_t B, C;          /* samples, channels                                   */
+  int64_t P;             /* frustum points per sample                           */
+  int32_t nx, ny, nz;    /* voxel_num                                           */
+  int32_t in_dtype;      /* VAMP_F32 | VAMP_BF16 for feat                       */
+} VampPoolDesc;
+size_t vamp_voxel_pooling_workspace_bytes(const VampPoolDesc* d);
+int vamp_voxel_pooling_forward(const VampPoolDesc* d, const int32_t* geom_xyz, const void* feat, float* out,
+                               void* workspace, size_t workspace_bytes, void* stream);
+/* grad_feat [B, P, C] fp32 is fully overwritten: the row of the point's cell, zeros outside the grid */
+int vamp_voxel_pooling_backward(const VampPoolDesc* d, const int32_t* geom_xyz, const float* grad_out,
+                                float* grad_feat, void* stream);
+
+/* --------------------------------------------------------------------------
  * Trilinear resize inside the 3-D UNet between lift and render (first piece):
  * F.interpolate(x, size, mode='trilinear', align_corners=True), base_vampire2.py:66, 72.
  * in [planes, iz, iy, ix] -> out [planes, oz, oy, ox], planes = batch * channels, fp32 contiguous.

@@ -1480,3 +1480,36 @@ def test_multitask_step_reference_config_bf16(dev):
     assert torch.isfinite(loss)
     assert all(torch.isfinite(torch.as_tensor(v)) for v in lf.last.values())
     assert not [n for n, p in model.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+
+
+# --------------------------------------------------------------------------- a11: BEVDepth-style voxel pooling
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 6, 7, 4, 5, 9, (16, 12, 1)), (1, 6, 112, 16, 44, 80, (128, 128, 1))],
+                         ids=["tiny", "bevdepth"])
+def test_voxel_pooling_against_numpy_definition(dev, shape, dtype):
+    """north_star's pooling op (absent from the reference: parity UNPINNED) against a numpy scatter-add of the
+    published definition: forward sums, backward rows; points outside the grid (incl. z) are dropped."""
+    from oracle import voxel_pooling_oracle as VO
+    from vampire_amd.ops import voxel_pooling
+    B, N, D, H, W, C_, vn = shape
+    gen = torch.Generator().manual_seed(11)
+    geom = torch.stack([torch.randint(-3, vn[0] + 3, (B, N, D, H, W), generator=gen),
+                        torch.randint(-3, vn[1] + 3, (B, N, D, H, W), generator=gen),
+                        torch.randint(-1, vn[2] + 1, (B, N, D, H, W), generator=gen)], -1)
+    geom[0, 0, 0] = torch.tensor([2, 3, 0])                       # one crowded cell
+    feat = torch.randn(B, N, D, H, W, C_, generator=gen).to(dtype)
+    f_d = feat.to(dev).requires_grad_(True)
+    out = voxel_pooling(geom.to(dev), f_d, vn)
+    assert out.shape == (B, C_, vn[1], vn[0])
+    want = VO.voxel_pooling(geom.reshape(B, -1, 3).numpy(), feat.float().reshape(B, -1, C_).numpy(), vn)
+    close(out, torch.from_numpy(want).float(), atol=1e-5, rtol=1e-5, scale="max", what="voxel_pooling")
+    go = torch.randn(out.shape, generator=gen)
+    out.backward(go.to(dev))
+    gw = VO.voxel_pooling_backward(geom.reshape(B, -1, 3).numpy(), go.numpy(), vn)
+    assert f_d.grad.dtype == dtype
+    got = f_d.grad.float().cpu().reshape(B, -1, C_)
+    ref = torch.from_numpy(gw).to(dtype).float()
+    assert torch.equal(got, ref)
+    # every point outside: an all-zero output (no zero fill needed by the caller)
+    far = torch.full_like(geom, -5).to(dev)
+    assert float(voxel_pooling(far, f_d.detach(), vn).abs().max()) == 0.0

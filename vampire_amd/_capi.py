@@ -25,6 +25,11 @@ class VampLiftDesc(C.Structure):
                 ("use_depth", C.c_int32), ("in_dtype", C.c_int32)]
 
 
+class VampPoolDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("C", C.c_int32), ("P", C.c_int64),
+                ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("in_dtype", C.c_int32)]
+
+
 class VampRenderDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32),
                 ("D", C.c_int32), ("fH", C.c_int32), ("fW", C.c_int32),
@@ -126,6 +131,9 @@ SIGNATURES = {
     "vamp_conv3d_backward_weight": (C.c_int, [_CD, _P, _P, _P, _P, C.c_size_t, _P]),
     "vamp_density_gate_backward": (C.c_int, [C.c_int64, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, _P, _P,
                                              _P]),
+    "vamp_voxel_pooling_workspace_bytes": (C.c_size_t, [_P]),
+    "vamp_voxel_pooling_forward": (C.c_int, [_P] * 4 + [_P, C.c_size_t, _P]),
+    "vamp_voxel_pooling_backward": (C.c_int, [_P] * 5),
     "vamp_gate_conv1x1_supported": (C.c_int, [C.c_int32] * 3),
     "vamp_gate_conv1x1_workspace_bytes": (C.c_size_t, [C.c_int32] * 3),
     "vamp_gate_conv1x1_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32]

@@ -945,6 +945,57 @@ class _GateConvFn(torch.autograd.Function):
 
 
 # ===========================================================================
+# BEVDepth-style voxel pooling (north_star; SURVEY 8 row a11 -- not in the reference tree, parity unpinned)
+# ===========================================================================
+_pool_ws = {}
+
+
+def voxel_pooling(geom_xyz, input_features, voxel_num):
+    """The published BEVDepth operator `voxel_pooling(geom_xyz, input_features, voxel_num)`:
+    geom_xyz [B, N, D, H, W, 3] integer voxel indices (x, y, z), input_features [B, N, D, H, W, C]
+    (fp32 | bf16), voxel_num (nx, ny, nz) -> [B, C, ny, nx] fp32, the sum of the features of the points
+    falling into each BEV cell (points outside the grid are dropped).  HIP kernels, no CPU fallback."""
+    return _VoxelPoolingFn.apply(geom_xyz, input_features, tuple(int(v) for v in voxel_num))
+
+
+class _VoxelPoolingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, geom, feat, voxel_num):
+        if not (geom.is_cuda and feat.is_cuda):
+            raise _capi.VampireHipError("voxel_pooling needs device tensors (no CPU fallback)")
+        lib = _capi.load()
+        B, C_ = feat.shape[0], feat.shape[-1]
+        P = feat[0].numel() // C_
+        ctx.in_dtype, ctx.fshape = feat.dtype, tuple(feat.shape)
+        feat = _accept(feat).reshape(B, P, C_).contiguous()
+        geom = _chk(geom.reshape(B, P, 3).to(torch.int32), (B, P, 3), "geom_xyz")
+        d = _capi.VampPoolDesc(B, C_, P, voxel_num[0], voxel_num[1], voxel_num[2], _dtype_code(feat))
+        out = torch.empty(B, voxel_num[1], voxel_num[0], C_, dtype=torch.float32, device=feat.device)
+        nbytes = lib.vamp_voxel_pooling_workspace_bytes(C.byref(d))
+        key = (feat.device, torch.cuda.current_stream().cuda_stream)
+        ws = _pool_ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = _pool_ws[key] = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=feat.device)
+        with torch.cuda.device(feat.device):
+            _capi.check(lib.vamp_voxel_pooling_forward(C.byref(d), _ptr(geom), _ptr(feat), _ptr(out), _ptr(ws),
+                                                       ws.numel(), _stream()), "vamp_voxel_pooling_forward")
+        ctx.desc = d
+        ctx.save_for_backward(geom)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        (geom,) = ctx.saved_tensors
+        d = ctx.desc
+        g = g.permute(0, 2, 3, 1).contiguous().float()
+        gfeat = torch.empty(d.B, d.P, d.C, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _capi.check(_capi.load().vamp_voxel_pooling_backward(C.byref(d), _ptr(geom), _ptr(g), _ptr(gfeat), _stream()),
+                        "vamp_voxel_pooling_backward")
+        return None, gfeat.reshape(ctx.fshape).to(ctx.in_dtype), None
+
+
+# ===========================================================================
 # trilinear resize of the 3-D UNet (SURVEY 8f N3, first piece)
 # ===========================================================================
 _resize_ws = {}
