@@ -1513,3 +1513,32 @@ def test_voxel_pooling_against_numpy_definition(dev, shape, dtype):
     # every point outside: an all-zero output (no zero fill needed by the caller)
     far = torch.full_like(geom, -5).to(dev)
     assert float(voxel_pooling(far, f_d.detach(), vn).abs().max()) == 0.0
+
+
+# --------------------------------------------------------------------------- N3 in bf16 (the reference's precision=16)
+@pytest.mark.parametrize("cin,cout,vol,batch", [(16, 16, (6, 12, 40), 2), (16, 32, (4, 8, 72), 1), (32, 16, (5, 8, 24), 1),
+                                                (32, 32, (3, 4, 136), 1), (16, 16, (16, 200, 200), 1)])
+def test_conv3d_bf16_matches_torch(dev, cin, cout, vol, batch):
+    """bf16 3x3x3 conv on the bf16 matrix cores (fp32 accumulate) against torch's conv3d evaluated in fp64 on the
+    same bf16-rounded operands: forward (bf16 output rounding), data gradient, weight gradient."""
+    import torch.nn.functional as F
+    from vampire_amd.ops import conv3d_bf16, conv3d_bf16_supported
+    gen = torch.Generator(device=dev).manual_seed(4)
+    x = torch.randn(batch, cin, *vol, device=dev, generator=gen).bfloat16()
+    w = (torch.randn(cout, cin, 3, 3, 3, device=dev, generator=gen) * 0.05).bfloat16()
+    go = torch.randn(batch, cout, *vol, device=dev, generator=gen).bfloat16()
+    assert conv3d_bf16_supported(x, w, (1, 1, 1), (1, 1, 1), None)
+    a, wa = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = conv3d_bf16(a, wa)
+    assert y.dtype == torch.bfloat16
+    y.backward(go)
+    big = vol[0] * vol[1] * vol[2] > 100000
+    rd = torch.float32 if big else torch.float64           # (fp64 conv3d on 640 k voxels is slow; fp32 reference there)
+    b, wb = x.to(rd).requires_grad_(True), w.to(rd).requires_grad_(True)
+    yr = F.conv3d(b, wb, padding=1)
+    yr.backward(go.to(rd))
+    # one bf16 rounding of the output (2^-9 relative) on top of fp32 accumulation
+    close(y, yr, atol=1e-3, rtol=2.0 ** -8, what="conv3d_bf16 forward")
+    close(a.grad, b.grad, atol=1e-3, rtol=2.0 ** -8, what="conv3d_bf16 grad_in")
+    # the weight gradient is accumulated in fp32 and rounded once to bf16
+    close(wa.grad, wb.grad, atol=1e-6, rtol=2.0 ** -7, scale="max", what="conv3d_bf16 grad_w")

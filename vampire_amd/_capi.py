@@ -129,6 +129,11 @@ SIGNATURES = {
     "vamp_conv3d_backward_data": (C.c_int, [_CD, _P, _P, _P, _P]),
     "vamp_conv3d_workspace_bytes": (C.c_size_t, [_CD]),
     "vamp_conv3d_backward_weight": (C.c_int, [_CD, _P, _P, _P, _P, C.c_size_t, _P]),
+    "vamp_conv3d_bf16_supported": (C.c_int, [_CD]),
+    "vamp_conv3d_bf16_forward": (C.c_int, [_CD, _P, _P, _P, _P]),
+    "vamp_conv3d_bf16_backward_data": (C.c_int, [_CD, _P, _P, _P, _P]),
+    "vamp_conv3d_bf16_workspace_bytes": (C.c_size_t, [_CD]),
+    "vamp_conv3d_bf16_backward_weight": (C.c_int, [_CD, _P, _P, _P, _P, C.c_size_t, _P]),
     "vamp_density_gate_backward": (C.c_int, [C.c_int64, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, _P, _P,
                                              _P]),
     "vamp_voxel_pooling_workspace_bytes": (C.c_size_t, [_P]),

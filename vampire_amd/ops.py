@@ -1054,6 +1054,67 @@ def conv3d_3x3x3(x, weight):
     return _Conv3dFn.apply(x, weight)
 
 
+def conv3d_bf16(x, weight):
+    """The same layer in bf16 (what the reference's `precision=16` training hands it): x bf16 [B,cin,Z,Y,X],
+    weight bf16 [cout,cin,3,3,3] -> bf16 [B,cout,Z,Y,X]; fp32 accumulation on the bf16 matrix cores."""
+    return _Conv3dBf16Fn.apply(x, weight)
+
+
+def conv3d_bf16_supported(x, weight, stride, padding, bias):
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and bias is None and tuple(stride) == (1, 1, 1)
+            and tuple(padding) == (1, 1, 1) and tuple(weight.shape[2:]) == (3, 3, 3) and x.dim() == 5
+            and weight.shape[1] == x.shape[1]):
+        return False
+    d = _capi.VampConvDesc()
+    d.B, d.cin, d.Z, d.Y, d.X = x.shape
+    d.cout = weight.shape[0]
+    return bool(_capi.load().vamp_conv3d_bf16_supported(C.byref(d)))
+
+
+class _Conv3dBf16Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        if not (x.is_cuda and w.is_cuda):
+            raise _capi.VampireHipError("x / weight must be device tensors (no CPU fallback)")
+        if x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or x.dim() != 5 or w.dim() != 5:
+            raise TypeError("conv3d_bf16 takes bf16 [B,cin,Z,Y,X] and [cout,cin,3,3,3] tensors")
+        lib = _capi.load()
+        x, w = x.contiguous(), w.contiguous()
+        d = _capi.VampConvDesc()
+        d.B, d.cin, d.Z, d.Y, d.X = x.shape
+        d.cout = w.shape[0]
+        if w.shape[1] != d.cin:
+            raise ValueError("weight / input channel mismatch")
+        out = torch.empty((d.B, d.cout, d.Z, d.Y, d.X), dtype=torch.bfloat16, device=x.device)
+        _capi.check(lib.vamp_conv3d_bf16_forward(C.byref(d), _ptr(x), _ptr(w), _ptr(out), _stream()),
+                    "vamp_conv3d_bf16_forward")
+        ctx.lib, ctx.desc = lib, d
+        ctx.save_for_backward(x, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        lib, d = ctx.lib, ctx.desc
+        g = g.contiguous().to(torch.bfloat16)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _capi.check(lib.vamp_conv3d_bf16_backward_data(C.byref(d), _ptr(g), _ptr(w), _ptr(gx), _stream()),
+                        "vamp_conv3d_bf16_backward_data")
+        if ctx.needs_input_grad[1]:
+            gw32 = torch.empty(w.shape, dtype=torch.float32, device=w.device)
+            nbytes = lib.vamp_conv3d_bf16_workspace_bytes(C.byref(d))
+            key = (g.device, torch.cuda.current_stream().cuda_stream, "conv16", nbytes)
+            ws = _resize_ws.get(key)
+            if ws is None:
+                ws = _resize_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
+            _capi.check(lib.vamp_conv3d_bf16_backward_weight(C.byref(d), _ptr(x), _ptr(g), _ptr(gw32), _ptr(ws),
+                                                             ws.numel(), _stream()), "vamp_conv3d_bf16_backward_weight")
+            gw = gw32.to(torch.bfloat16)          # the gradient of the bf16 copy autocast made of the fp32 parameter
+        return gx, gw
+
+
 def conv3d_supported(x, weight, stride, padding, bias):
     if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and bias is None
             and tuple(stride) == (1, 1, 1) and tuple(padding) == (1, 1, 1) and tuple(weight.shape[2:]) == (3, 3, 3)
