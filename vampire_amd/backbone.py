@@ -74,6 +74,10 @@ class _Switches:
 SWITCHES = _Switches()
 
 
+def _autocast_bf16(x):
+    return x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+
+
 class _Conv3(nn.Conv3d):
     """nn.Conv3d(cin, cout, 3, stride, 1, bias=False) (same parameter name and shape).  The
     stride-1 layers with 16 / 32 channels run on the HIP fp32 matrix-core kernels for fp32 device
@@ -82,9 +86,14 @@ class _Conv3(nn.Conv3d):
     MIOpen); `VAMP_CONV3D=0` keeps MIOpen everywhere."""
 
     def forward(self, x):
-        if SWITCHES.conv3d and x.dim() == 5:
-            from .ops import conv3d_3x3x3, conv3d_supported
-            if (x[0, 0].numel() >= SWITCHES.conv3d_min_voxels
+        if SWITCHES.conv3d and x.dim() == 5 and x.is_cuda:
+            from .ops import conv3d_3x3x3, conv3d_supported, conv3d_bf16, conv3d_bf16_supported
+            if _autocast_bf16(x):
+                # the reference's mixed-precision training: bf16 operands, as autocast would hand them to MIOpen
+                xb = x.to(torch.bfloat16)
+                if conv3d_bf16_supported(xb, self.weight, self.stride, self.padding, self.bias):
+                    return conv3d_bf16(xb, self.weight.to(torch.bfloat16))
+            elif (x[0, 0].numel() >= SWITCHES.conv3d_min_voxels
                     and conv3d_supported(x, self.weight, self.stride, self.padding, self.bias)):
                 return conv3d_3x3x3(x, self.weight)
         return super().forward(x)
@@ -381,13 +390,19 @@ class BaseVAMPIRE2(nn.Module):
         weights -- the volume is read once and MIOpen's three forward / data / weight-gradient
         launches become one each; biases and the rgb sigmoid follow.  Parameters are untouched."""
         nout = 1 + self.num_classes + 3
-        if SWITCHES.conv3d and nout <= 32 and base.dim() == 5:
-            from .ops import conv3d_3x3x3, conv3d_supported
+        if SWITCHES.conv3d and nout <= 32 and base.dim() == 5 and base.is_cuda:
+            from .ops import conv3d_3x3x3, conv3d_supported, conv3d_bf16, conv3d_bf16_supported
             wd, ws, wr = self.density_conv.weight, self.seg_conv.weight, self.rgb_conv[0].weight
             w = torch.cat([wd, ws, wr, wd.new_zeros((32 - nout,) + tuple(wd.shape[1:]))], 0)
-            if (base[0, 0].numel() >= SWITCHES.conv3d_min_voxels
+            y = None
+            if _autocast_bf16(base):
+                bb = base.to(torch.bfloat16)
+                if conv3d_bf16_supported(bb, w, (1, 1, 1), (1, 1, 1), None):
+                    y = conv3d_bf16(bb, w.to(torch.bfloat16))
+            elif (base[0, 0].numel() >= SWITCHES.conv3d_min_voxels
                     and conv3d_supported(base, w, (1, 1, 1), (1, 1, 1), None)):
                 y = conv3d_3x3x3(base, w)
+            if y is not None:
                 K = self.num_classes
                 bias = lambda b: b.view(1, -1, 1, 1, 1)
                 return (y[:, :1] + bias(self.density_conv.bias), y[:, 1:1 + K] + bias(self.seg_conv.bias),

@@ -29,6 +29,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef u32x4 __attribute__((aligned(2))) u32x4_u;     // a 16-byte global load at 2-byte alignment
 typedef bf16x8 __attribute__((aligned(2))) bf16x8_u;
 
@@ -200,7 +201,7 @@ conv3d_bf16_fwd_kernel(CvP P, const unsigned short* __restrict__ in, const unsig
 // w + 4, ...: 7 accumulator sets) and walks the rows its workgroup is given; per-workgroup partial
 // sums [27][cout][cin] are added by a second kernel.
 // ---------------------------------------------------------------------------
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool X8>       // X8: X % 8 == 0, every window is one aligned 16-byte load; else X % 4 == 0, two 8-byte halves
 __global__ void __launch_bounds__(192)
 conv3d_bf16_wgrad_kernel(CvP P, const unsigned short* __restrict__ in, const unsigned short* __restrict__ dout,
                          float* __restrict__ part, long nrows) {
@@ -235,19 +236,34 @@ conv3d_bf16_wgrad_kernel(CvP P, const unsigned short* __restrict__ in, const uns
     S.z = (int) ((row / P.Y) % P.Z);
     const int b = (int) (row / ((long) P.Y * P.Z));
     S.xb = ks * 32 + 8 * kg;
-    const int xc = min(S.xb, P.X - 8);
     const unsigned short* gb = dout + (long) b * COUT * plane + ((long) S.z * P.Y + S.y) * P.X;
     const unsigned short* ib = in + (long) b * CIN * plane;
     const int zz = min(max(S.z + wv - 1, 0), P.Z - 1);
+    // the window [xb, xb + 8): one 16-byte load, or (rows that are only 8-byte aligned, last window half
+    // outside) its two halves from starts clamped into the row -- the compute step zeroes what lies outside
+    const int xc = min(S.xb, P.X - (X8 ? 8 : 4)), xh = min(S.xb + 4, P.X - 4);
+    auto window = [&](const unsigned short* rowp) {
+      if (X8) return *reinterpret_cast<const u32x4*>(rowp + xc);
+      const u32x2 lo = *reinterpret_cast<const u32x2*>(rowp + xc), hi = *reinterpret_cast<const u32x2*>(rowp + xh);
+      return u32x4{lo[0], lo[1], hi[0], hi[1]};
+    };
 #pragma unroll
-    for (int m = 0; m < MT; ++m) S.a[m] = *reinterpret_cast<const bf16x8*>(gb + (long) (m * 16 + li) * plane + xc);
+    for (int m = 0; m < MT; ++m) {
+      const u32x4 t = window(gb + (long) (m * 16 + li) * plane);
+      __builtin_memcpy(&S.a[m], &t, 16);
+    }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const int yy = min(max(S.y + r - 1, 0), P.Y - 1);
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
-        S.v[r][n] = *reinterpret_cast<const u32x4*>(ib + (((long) (n * 16 + li) * P.Z + zz) * P.Y + yy) * P.X + xc);
+      for (int n = 0; n < NT; ++n) S.v[r][n] = window(ib + (((long) (n * 16 + li) * P.Z + zz) * P.Y + yy) * P.X);
     }
+  };
+  // zero the part of a window that lies beyond the row end (whole window, or its upper half when X % 8 == 4)
+  auto clip = [&](const u32x4& v, int xb) {
+    u32x4 r = xb < P.X ? v : u32x4{0u, 0u, 0u, 0u};
+    if (!X8 && xb + 4 >= P.X) { r[2] = 0u; r[3] = 0u; }
+    return r;
   };
   auto as_frag = [](const u32x4& v) {
     bf16x8 f;
@@ -265,7 +281,12 @@ conv3d_bf16_wgrad_kernel(CvP P, const unsigned short* __restrict__ in, const uns
     const bool in_row = S.xb < P.X;
     bf16x8 a[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) a[m] = in_row ? S.a[m] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int m = 0; m < MT; ++m) {
+      u32x4 t;
+      __builtin_memcpy(&t, &S.a[m], 16);
+      t = clip(t, S.xb);
+      __builtin_memcpy(&a[m], &t, 16);
+    }
     const int zz = S.z + wv - 1;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -273,7 +294,7 @@ conv3d_bf16_wgrad_kernel(CvP P, const unsigned short* __restrict__ in, const uns
       const bool row_ok = zz >= 0 && zz < P.Z && yy >= 0 && yy < P.Y;       // wave-uniform
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const u32x4 v = (row_ok && in_row) ? S.v[r][n] : zero4;
+        const u32x4 v = row_ok ? clip(S.v[r][n], S.xb) : zero4;
         // the dword left of this lane's window: lane group kg - 1 (same step), or the previous step's group 3
         const unsigned lsend = kg == 3 ? prev3[r][n] : v[3];
         unsigned left = (unsigned) __shfl((int) lsend, (lane + 48) & 63, 64);
@@ -351,7 +372,7 @@ constexpr int kWgradWgs = 512;       // two workgroups per CU
 
 bool bf16_shape_ok(const VampConvDesc* d) {
   return d && (d->cin == 16 || d->cin == 32) && (d->cout == 16 || d->cout == 32) && d->B > 0 && d->Z > 0 &&
-         d->Y > 0 && d->X > 0 && d->Y % kTY == 0 && d->X % 8 == 0 &&
+         d->Y > 0 && d->X >= 8 && d->Y % kTY == 0 && d->X % 4 == 0 &&
          (long) d->Z * d->Y * d->X * 32 * 2 < 0x7fffffffL;
 }
 
@@ -376,8 +397,12 @@ int launch_wgrad(const VampConvDesc* d, const void* in, const void* dout, float*
   const CvP P{d->B, d->Z, d->Y, d->X};
   const long nrows = (long) d->B * d->Z * d->Y;
   const int nwg = (int) std::min<long>(nrows, kWgradWgs);
-  VAMP_TIMED(kProfConvWgrad, s, (conv3d_bf16_wgrad_kernel<CIN, COUT><<<nwg, 192, 0, s>>>(
-      P, static_cast<const unsigned short*>(in), static_cast<const unsigned short*>(dout), ws, nrows)));
+  if (d->X % 8 == 0)
+    VAMP_TIMED(kProfConvWgrad, s, (conv3d_bf16_wgrad_kernel<CIN, COUT, true><<<nwg, 192, 0, s>>>(
+        P, static_cast<const unsigned short*>(in), static_cast<const unsigned short*>(dout), ws, nrows)));
+  else
+    VAMP_TIMED(kProfConvWgrad, s, (conv3d_bf16_wgrad_kernel<CIN, COUT, false><<<nwg, 192, 0, s>>>(
+        P, static_cast<const unsigned short*>(in), static_cast<const unsigned short*>(dout), ws, nrows)));
   if (int e = check_launch("conv3d_bf16_wgrad_kernel")) return e;
   const int n = 27 * CIN * COUT;
   VAMP_TIMED(kProfConvWgrad, s, (conv3d_bf16_wreduce_kernel<<<(n + 63) / 64, 256, 0, s>>>(ws, dw, CIN, COUT, nwg)));
