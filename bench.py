@@ -361,6 +361,8 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations (extra_configs)")
+    ap.add_argument("--no-matrix", action="store_true",
+                    help="skip the {eager, graph} x {early termination on, off} step matrix (profile runs: only default-path kernels)")
     ap.add_argument("--multitask", action="store_true",
                     help="also time the full multi-task step of BASELINE configs[4] (R50 encoder, BEV head, 9 losses; bf16 autocast)")
     ap.add_argument("--layers", action="store_true",
@@ -499,7 +501,7 @@ def main():
     # both axes (the termination gain is data-dependent), so the line carries all four (N = 1 only:
     # no collective inside)
     step_matrix, ert_stats = None, None
-    if world == 1:
+    if world == 1 and not a.no_matrix:
         def time_loop(fn, n):
             for _ in range(3):
                 fn()

@@ -10,7 +10,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --cfg $CFG --batch $BATCH --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --cfg $CFG --batch $BATCH --steps 20 --warmup 5 --no-cpu-baseline --no-extra --no-matrix > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/tools/time_bwd.py $CFG $BATCH > /dev/null 2> $OUT/pmc_fetch.log
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/tools/time_bwd.py $CFG $BATCH > /dev/null 2> $OUT/pmc_write.log
 cd $ROOT

@@ -75,7 +75,7 @@ SWITCHES = _Switches()
 
 
 def _autocast_bf16(x):
-    return x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+    return x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
 
 
 class _Conv3(nn.Conv3d):
