@@ -19,7 +19,7 @@ SLOTS = [("lift_fwd_kernel", "lift_fwd"), ("lift_bwd_cell_gather_kernel", "lift_
          ("bev_channels_kernel", "render_bev_fwd_channels"), ("cam_bwd_ray_kernel", "render_cam_bwd_ray"),
          ("cam_bwd_cell_gather_kernel", "render_cam_bwd_gather"), ("cam_bwd_cell_heavy_kernel", "render_cam_bwd_heavy"),
          ("cam_cells_rank_kernel", "render_cam_bwd_rank"), ("cam_cells_slot_kernel", "render_cam_bwd_fill"),
-         ("bev_q_kernel", "render_bev_bwd_q"), ("bev_scan_kernel", "render_bev_bwd_scan"),
+         ("bev_q_kernel", "render_bev_bwd_q"), ("bev_q_saved_kernel", "render_bev_bwd_q"), ("bev_scan_kernel", "render_bev_bwd_scan"),
          ("bev_gather_kernel", "render_bev_bwd_gather"), ("bev_gather_col_kernel", "render_bev_bwd_gather"),
          ("zero_fill_kernel", "memset"), ("cell_scan_kernel", "cell_scan"),
          ("exclusive_scan_kernel", "scan")]
