@@ -240,12 +240,30 @@ def extra_config(cfg_name, batch, dtype, steps=10, warm=3, ert=True, density_mod
         model.zero_grad(set_to_none=True); train_step(model, data)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
+    # the same step replayed from a HIP graph, as the headline is timed (None when capture is unavailable)
+    graph_ms = None
+    if os.environ.get("VAMP_BENCH_GRAPH", "1") == "1":
+        try:
+            g = capture_step(model, data, train_step)
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                g.replay()
+            torch.cuda.synchronize()
+            graph_ms = (time.perf_counter() - t0) / steps * 1e3
+            del g
+        except Exception as e:                      # noqa: BLE001
+            print(f"[bench] extra config graph capture unavailable ({type(e).__name__}: {e})", file=sys.stderr)
     fwd_us, _, _ = forward_pair_us(model, data, iters=30, warm=5)
     ab = cfg.algorithmic_bytes(4 if dtype == torch.float32 else 2)
     return {"workload": f"cfg-{cfg_name}, {batch} sample(s)/GPU/step, {'f32' if dtype == torch.float32 else 'bf16'} inputs"
                         + ("" if ert else ", early ray termination OFF")
                         + ("" if density_mode is None else f", density_mode={density_mode}"),
-            "samples_per_s": batch / (ms * 1e-3), "ms_per_step": ms, "fwd_us": fwd_us,
+            "samples_per_s": batch / (ms * 1e-3), "ms_per_step": ms, "launch": "eager (samples_per_s, ms_per_step); graph_* = HIP-graph replay like the headline",
+            "graph_ms_per_step": graph_ms, "graph_samples_per_s": None if graph_ms is None else batch / (graph_ms * 1e-3),
+            "fwd_us": fwd_us,
             "fwd_frac_of_hbm_peak": ab["fwd"] * batch / (fwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
 
@@ -336,7 +354,8 @@ def capture_step(model, batch, train_step):
             raw_step()
     cur.wait_stream(side)
     torch.cuda.synchronize()
-    tensors = lambda: [batch.depth.grad, batch.feat.grad] + [v.grad for v in batch.vols] + [model.beta.grad]
+    tensors = lambda: [t for t in [batch.depth.grad, batch.feat.grad] + [v.grad for v in batch.vols] + [model.beta.grad]
+                       if t is not None]                    # (no beta gradient under density_mode="naive")
     ref = [t.detach().clone() for t in tensors()]
     g = torch.cuda.CUDAGraph()
     # thread_local: calls of other threads (the RCCL watchdog polls its events) must not fail the capture
@@ -346,7 +365,10 @@ def capture_step(model, batch, train_step):
     g.replay()
     torch.cuda.synchronize()
     for got, want in zip(tensors(), ref):
-        if not (torch.equal(got, want) or float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())):
+        # fp32 sums with LDS float atomics differ in the last bits from run to run; a gradient handed back in
+        # bf16 (bf16 inputs) can flip one rounding step on such a difference
+        tol = 1e-5 if got.dtype == torch.float32 else 2.0 ** -7
+        if not (torch.equal(got, want) or float((got.float() - want.float()).abs().max()) <= tol * float(want.float().abs().max())):
             raise RuntimeError("graph replay does not reproduce the eager gradients")
     return g
 
