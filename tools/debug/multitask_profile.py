@@ -1,0 +1,48 @@
+"""Where the full multi-task step (BASELINE configs[4], cfg-A, bf16 autocast) spends its time: torch profiler, top ops."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from vampire_amd import multitask as M
+from vampire_amd.config import CFG_A
+dev = torch.device("cuda:0")
+torch.backends.cudnn.benchmark = True
+torch.manual_seed(0)
+bb, hd = M.reference_confs(CFG_A)
+model = M.VAMPIRE2(bb, hd).to(dev)
+with torch.no_grad():
+    model.backbone.density_conv.bias.fill_(CFG_A.sdf_bias)
+lf = M.MultiTaskLoss(model, sdf_bias=CFG_A.sdf_bias)
+opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+batch = M.synthetic_batch(CFG_A, 1, seed=0, device=dev, num_points=30000, num_boxes=30)
+for _ in range(3):
+    M.multitask_step(model, lf, batch, optimizer=opt)
+torch.cuda.synchronize()
+# coarse phases with events
+def phase_times():
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        feats = model.backbone.get_cam_feats(batch[0])
+        ev[1].record()
+        out_b = model.backbone._sweep_from_feats(0, feats, batch[1], batch[11])
+        ev[2].record()
+        preds = model.head(out_b[0])
+        ev[3].record()
+        loss = lf((preds,) + tuple(out_b[1:]), batch)
+    ev[4].record()
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    opt.step()
+    ev[5].record()
+    torch.cuda.synchronize()
+    host = time.perf_counter() - t0
+    names = ["image encoder fwd", "backbone fwd (lift, UNet, heads, render, queries)", "BEV head fwd", "losses fwd (incl. targets)", "backward + AdamW"]
+    for i, n in enumerate(names):
+        print("%-52s %8.2f ms" % (n, ev[i].elapsed_time(ev[i + 1])))
+    print("%-52s %8.2f ms (host wall %.2f ms)" % ("total", ev[0].elapsed_time(ev[5]), host * 1e3))
+phase_times(); phase_times()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    M.multitask_step(model, lf, batch, optimizer=opt)
+    torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=60))

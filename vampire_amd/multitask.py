@@ -345,16 +345,18 @@ def lovasz_softmax(probas, labels):
     if probas.numel() == 0:
         return probas.sum() * 0.0
     P, C = probas.shape
-    fg = F.one_hot(labels, C).to(probas.dtype)                    # [P, C]
-    present = fg.sum(0) > 0
-    err, perm = (fg - probas).abs().sort(0, descending=True)
-    fgs = fg.gather(0, perm)
-    gts = fgs.sum(0, keepdim=True)
-    inter = gts - fgs.cumsum(0)
-    union = gts + (1 - fgs).cumsum(0)
+    # class-major [C, P]: the sort and the two cumulative sums run along the contiguous axis (a cumsum over
+    # the OUTER axis of [P, C] takes 19 ms per call at 1.3 M x 18 on this ROCm build, 150 ms of a 215 ms step)
+    fg = F.one_hot(labels, C).to(probas.dtype).t().contiguous()   # [C, P]
+    present = fg.sum(1) > 0
+    err, perm = (fg - probas.t()).abs().sort(1, descending=True)
+    fgs = fg.gather(1, perm)
+    gts = fgs.sum(1, keepdim=True)
+    inter = gts - fgs.cumsum(1)
+    union = gts + (1 - fgs).cumsum(1)
     jac = 1.0 - inter / union
-    jac = torch.cat([jac[:1], jac[1:] - jac[:-1]], 0)
-    per_class = (err * jac).sum(0)
+    jac = torch.cat([jac[:, :1], jac[:, 1:] - jac[:, :-1]], 1)
+    per_class = (err * jac).sum(1)
     return (per_class * present).sum() / present.sum().clamp(min=1)
 
 
