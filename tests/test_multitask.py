@@ -182,8 +182,11 @@ class OracleOps:
         self.cfg, self.geo = cfg, PathGeometry(cfg)
         self.bounds = (cfg.x_bound_seg, cfg.y_bound_seg, cfg.z_bound_seg)
 
-    def lift(self, depth, feat, lift_mats):
+    def lift(self, depth, feat, lift_mats, use_depth=True):
         from oracle import aten_oracle as O
+        if not use_depth:                               # base_bilinear.py:471-519: the D = 1 bilinear lift
+            pix = O.ego_to_pixel(self.geo.voxel_coords, None, None, None, None, prepared=lift_mats)
+            return O.lift_from_frustum_feats(feat.unsqueeze(3), pix, self.cfg.final_dim, self.cfg.d_bound, use_depth=False)
         return O.lift(depth, feat, self.geo.voxel_coords, None, None, None, None, self.cfg.final_dim, self.cfg.d_bound,
                       prepared=lift_mats)
 
@@ -203,6 +206,8 @@ class OracleOps:
 
     def occupancy_queries(self, sem, dens, occ_coords, bda_mat, beta=None):
         from oracle import aten_oracle as O
+        if bda_mat is None:                             # the static grid of the sibling backbones
+            bda_mat = torch.eye(4).expand(sem.shape[0], 4, 4)
         return O.occupancy_queries(sem, dens, occ_coords, bda_mat, self.bounds, self.cfg.density_mode, beta, self.cfg.sdf_bias)
 
 
