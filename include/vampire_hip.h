@@ -36,7 +36,7 @@ enum {
   VAMP_EHIP = -3     /* a HIP runtime call failed (launch error) */
 };
 
-enum { VAMP_F32 = 0, VAMP_BF16 = 1 };
+enum { VAMP_F32 = 0, VAMP_BF16 = 1, VAMP_F16 = 2 };   /* VAMP_F16: only the vamp_conv3d_half_* entry points take it */
 enum { VAMP_DENSITY_SIGMOID = 0, VAMP_DENSITY_SDF_LAPLACE = 1 };
 
 int vamp_abi_version(void);
@@ -594,6 +594,14 @@ int vamp_conv3d_bf16_backward_data(const VampConvDesc* d, const void* grad_out, 
 size_t vamp_conv3d_bf16_workspace_bytes(const VampConvDesc* d);
 int vamp_conv3d_bf16_backward_weight(const VampConvDesc* d, const void* in, const void* grad_out, float* grad_weight,
                                      void* workspace, size_t workspace_bytes, void* stream);
+/* the same three with the 16-bit type as an argument: dtype = VAMP_BF16 or VAMP_F16 (IEEE half, what Lightning's
+   `precision=16` autocasts to: v_mfma_f32_16x16x32_f16); shapes / workspace as the bf16 entry points */
+int vamp_conv3d_half_forward(const VampConvDesc* d, int32_t dtype, const void* in, const void* weight, void* out,
+                             void* stream);
+int vamp_conv3d_half_backward_data(const VampConvDesc* d, int32_t dtype, const void* grad_out, const void* weight,
+                                   void* grad_in, void* stream);
+int vamp_conv3d_half_backward_weight(const VampConvDesc* d, int32_t dtype, const void* in, const void* grad_out,
+                                     float* grad_weight, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

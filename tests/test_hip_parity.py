@@ -1562,19 +1562,20 @@ def test_voxel_pooling_against_numpy_definition(dev, shape, dtype):
 # --------------------------------------------------------------------------- N3 in bf16 (the reference's precision=16)
 @pytest.mark.parametrize("cin,cout,vol,batch", [(16, 16, (6, 12, 40), 2), (16, 32, (4, 8, 72), 1), (32, 16, (5, 8, 24), 1),
                                                 (32, 32, (3, 4, 136), 1), (32, 32, (8, 100, 100), 1), (16, 16, (2, 4, 12), 1), (16, 16, (16, 200, 200), 1)])
-def test_conv3d_bf16_matches_torch(dev, cin, cout, vol, batch):
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_conv3d_bf16_matches_torch(dev, cin, cout, vol, batch, dt):
     """bf16 3x3x3 conv on the bf16 matrix cores (fp32 accumulate) against torch's conv3d evaluated in fp64 on the
     same bf16-rounded operands: forward (bf16 output rounding), data gradient, weight gradient."""
     import torch.nn.functional as F
     from vampire_amd.ops import conv3d_bf16, conv3d_bf16_supported
     gen = torch.Generator(device=dev).manual_seed(4)
-    x = torch.randn(batch, cin, *vol, device=dev, generator=gen).bfloat16()
-    w = (torch.randn(cout, cin, 3, 3, 3, device=dev, generator=gen) * 0.05).bfloat16()
-    go = torch.randn(batch, cout, *vol, device=dev, generator=gen).bfloat16()
+    x = torch.randn(batch, cin, *vol, device=dev, generator=gen).to(dt)
+    w = (torch.randn(cout, cin, 3, 3, 3, device=dev, generator=gen) * 0.05).to(dt)
+    go = torch.randn(batch, cout, *vol, device=dev, generator=gen).to(dt)
     assert conv3d_bf16_supported(x, w, (1, 1, 1), (1, 1, 1), None)
     a, wa = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     y = conv3d_bf16(a, wa)
-    assert y.dtype == torch.bfloat16
+    assert y.dtype == dt
     y.backward(go)
     big = vol[0] * vol[1] * vol[2] > 100000
     rd = torch.float32 if big else torch.float64           # (fp64 conv3d on 640 k voxels is slow; fp32 reference there)

@@ -11,7 +11,7 @@ from .build import lib_path
 
 ABI_VERSION = 3
 
-VAMP_F32, VAMP_BF16 = 0, 1
+VAMP_F32, VAMP_BF16, VAMP_F16 = 0, 1, 2
 VAMP_DENSITY_SIGMOID, VAMP_DENSITY_SDF_LAPLACE = 0, 1
 
 
@@ -134,6 +134,9 @@ SIGNATURES = {
     "vamp_conv3d_bf16_backward_data": (C.c_int, [_CD, _P, _P, _P, _P]),
     "vamp_conv3d_bf16_workspace_bytes": (C.c_size_t, [_CD]),
     "vamp_conv3d_bf16_backward_weight": (C.c_int, [_CD, _P, _P, _P, _P, C.c_size_t, _P]),
+    "vamp_conv3d_half_forward": (C.c_int, [_CD, C.c_int32, _P, _P, _P, _P]),
+    "vamp_conv3d_half_backward_data": (C.c_int, [_CD, C.c_int32, _P, _P, _P, _P]),
+    "vamp_conv3d_half_backward_weight": (C.c_int, [_CD, C.c_int32, _P, _P, _P, _P, C.c_size_t, _P]),
     "vamp_density_gate_backward": (C.c_int, [C.c_int64, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, _P, _P,
                                              _P]),
     "vamp_voxel_pooling_workspace_bytes": (C.c_size_t, [_P]),

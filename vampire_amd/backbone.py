@@ -74,8 +74,13 @@ class _Switches:
 SWITCHES = _Switches()
 
 
-def _autocast_bf16(x):
-    return x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+def _autocast_16(x):
+    """bf16 or fp16 when a 16-bit CUDA autocast is on (the reference trains with Lightning's `precision=16`), else None."""
+    if x.is_cuda and torch.is_autocast_enabled():
+        dt = torch.get_autocast_dtype("cuda")
+        if dt in (torch.bfloat16, torch.float16):
+            return dt
+    return None
 
 
 class _Conv3(nn.Conv3d):
@@ -88,11 +93,12 @@ class _Conv3(nn.Conv3d):
     def forward(self, x):
         if SWITCHES.conv3d and x.dim() == 5 and x.is_cuda:
             from .ops import conv3d_3x3x3, conv3d_supported, conv3d_bf16, conv3d_bf16_supported
-            if _autocast_bf16(x):
-                # the reference's mixed-precision training: bf16 operands, as autocast would hand them to MIOpen
-                xb = x.to(torch.bfloat16)
+            dt16 = _autocast_16(x)
+            if dt16 is not None:
+                # the reference's mixed-precision training: 16-bit operands, as autocast would hand them to MIOpen
+                xb = x.to(dt16)
                 if conv3d_bf16_supported(xb, self.weight, self.stride, self.padding, self.bias):
-                    return conv3d_bf16(xb, self.weight.to(torch.bfloat16))
+                    return conv3d_bf16(xb, self.weight.to(dt16))
             elif (x[0, 0].numel() >= SWITCHES.conv3d_min_voxels
                     and conv3d_supported(x, self.weight, self.stride, self.padding, self.bias)):
                 return conv3d_3x3x3(x, self.weight)
@@ -395,10 +401,11 @@ class BaseVAMPIRE2(nn.Module):
             wd, ws, wr = self.density_conv.weight, self.seg_conv.weight, self.rgb_conv[0].weight
             w = torch.cat([wd, ws, wr, wd.new_zeros((32 - nout,) + tuple(wd.shape[1:]))], 0)
             y = None
-            if _autocast_bf16(base):
-                bb = base.to(torch.bfloat16)
+            dt16 = _autocast_16(base)
+            if dt16 is not None:
+                bb = base.to(dt16)
                 if conv3d_bf16_supported(bb, w, (1, 1, 1), (1, 1, 1), None):
-                    y = conv3d_bf16(bb, w.to(torch.bfloat16))
+                    y = conv3d_bf16(bb, w.to(dt16))
             elif (base[0, 0].numel() >= SWITCHES.conv3d_min_voxels
                     and conv3d_supported(base, w, (1, 1, 1), (1, 1, 1), None)):
                 y = conv3d_3x3x3(base, w)

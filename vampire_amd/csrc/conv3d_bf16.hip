@@ -42,11 +42,38 @@ constexpr int kTX = 64;       // output x per tile (four 16-voxel N tiles per wa
 constexpr int kHX = 68;       // staged x: x0 - 2 .. x0 + 65 (pairs at even x)
 constexpr int kRows = 3 * (kTY + 2);
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// the 16-bit matrix-core product: bf16 or (F16) IEEE half operands, fp32 accumulate; same fragment maps
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  if constexpr (F16) {
+    f16x8 ha, hb;
+    __builtin_memcpy(&ha, &a, 16);
+    __builtin_memcpy(&hb, &b, 16);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+}
+
 __device__ __forceinline__ unsigned short f2bf(float f) {          // round to nearest even (NaN kept quiet)
   unsigned u = __float_as_uint(f);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short) ((u >> 16) | 0x40);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short) (u >> 16);
+}
+
+template <bool F16>
+__device__ __forceinline__ unsigned short f2e(float f) {              // fp32 -> the 16-bit element type, round to nearest even
+  if constexpr (F16) {
+    const _Float16 h = (_Float16) f;
+    unsigned short u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
+  } else {
+    return f2bf(f);
+  }
 }
 
 template <int CIN, int COUT>
@@ -58,7 +85,7 @@ struct CvLds {
   static constexpr size_t bytes = w_bytes + in_bytes;
 };
 
-template <int CIN, int COUT, bool FLIP>
+template <int CIN, int COUT, bool FLIP, bool F16>
 __global__ void __launch_bounds__(256)
 conv3d_bf16_fwd_kernel(CvP P, const unsigned short* __restrict__ in, const unsigned short* __restrict__ w,
                        unsigned short* __restrict__ out, int tiles_x, long ntiles) {
@@ -170,7 +197,7 @@ conv3d_bf16_fwd_kernel(CvP P, const unsigned short* __restrict__ in, const unsig
 #pragma unroll
         for (int n = 0; n < NN; ++n)
 #pragma unroll
-          for (int m = 0; m < MT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], bv[n], acc[m][n], 0, 0, 0);
+          for (int m = 0; m < MT; ++m) acc[m][n] = mfma16<F16>(a[m], bv[n], acc[m][n]);
       }
     };
     if (nnt == 4) run(std::integral_constant<int, 4>());
@@ -186,7 +213,7 @@ conv3d_bf16_fwd_kernel(CvP P, const unsigned short* __restrict__ in, const unsig
           const int x = x0 + n * 16 + li;
           if (x < P.X) {
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) ob[(long) (m * 16 + 4 * kg + rg) * plane + x] = f2bf(acc[m][n][rg]);
+            for (int rg = 0; rg < 4; ++rg) ob[(long) (m * 16 + 4 * kg + rg) * plane + x] = f2e<F16>(acc[m][n][rg]);
           }
         }
     }
@@ -201,7 +228,7 @@ conv3d_bf16_fwd_kernel(CvP P, const unsigned short* __restrict__ in, const unsig
 // w + 4, ...: 7 accumulator sets) and walks the rows its workgroup is given; per-workgroup partial
 // sums [27][cout][cin] are added by a second kernel.
 // ---------------------------------------------------------------------------
-template <int CIN, int COUT, bool X8>       // X8: X % 8 == 0, every window is one aligned 16-byte load; else X % 4 == 0, two 8-byte halves
+template <int CIN, int COUT, bool X8, bool F16>       // X8: X % 8 == 0, every window is one aligned 16-byte load; else X % 4 == 0, two 8-byte halves
 __global__ void __launch_bounds__(192)
 conv3d_bf16_wgrad_kernel(CvP P, const unsigned short* __restrict__ in, const unsigned short* __restrict__ dout,
                          float* __restrict__ part, long nrows) {
@@ -310,9 +337,9 @@ conv3d_bf16_wgrad_kernel(CvP P, const unsigned short* __restrict__ in, const uns
         const bf16x8 b0 = as_frag(in_row ? vl : zero4), b1 = as_frag(v), b2 = as_frag(in_row ? vr : zero4);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          acc[r * 3 + 0][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b0, acc[r * 3 + 0][m][n], 0, 0, 0);
-          acc[r * 3 + 1][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b1, acc[r * 3 + 1][m][n], 0, 0, 0);
-          acc[r * 3 + 2][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b2, acc[r * 3 + 2][m][n], 0, 0, 0);
+          acc[r * 3 + 0][m][n] = mfma16<F16>(a[m], b0, acc[r * 3 + 0][m][n]);
+          acc[r * 3 + 1][m][n] = mfma16<F16>(a[m], b1, acc[r * 3 + 1][m][n]);
+          acc[r * 3 + 2][m][n] = mfma16<F16>(a[m], b2, acc[r * 3 + 2][m][n]);
         }
         prev3[r][n] = v[3];
       }
@@ -376,10 +403,10 @@ bool bf16_shape_ok(const VampConvDesc* d) {
          (long) d->Z * d->Y * d->X * 32 * 2 < 0x7fffffffL;
 }
 
-template <int CIN, int COUT, bool FLIP>
+template <int CIN, int COUT, bool FLIP, bool F16>
 int launch_fwd(const VampConvDesc* d, const void* in, const void* w, void* out, hipStream_t s) {
   using L = CvLds<CIN, COUT>;
-  auto k = conv3d_bf16_fwd_kernel<CIN, COUT, FLIP>;
+  auto k = conv3d_bf16_fwd_kernel<CIN, COUT, FLIP, F16>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int) L::bytes) != hipSuccess)
     return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);
   const CvP P{d->B, d->Z, d->Y, d->X};
@@ -392,16 +419,16 @@ int launch_fwd(const VampConvDesc* d, const void* in, const void* w, void* out, 
   return check_launch("conv3d_bf16_fwd_kernel");
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool F16>
 int launch_wgrad(const VampConvDesc* d, const void* in, const void* dout, float* dw, float* ws, hipStream_t s) {
   const CvP P{d->B, d->Z, d->Y, d->X};
   const long nrows = (long) d->B * d->Z * d->Y;
   const int nwg = (int) std::min<long>(nrows, kWgradWgs);
   if (d->X % 8 == 0)
-    VAMP_TIMED(kProfConvWgrad, s, (conv3d_bf16_wgrad_kernel<CIN, COUT, true><<<nwg, 192, 0, s>>>(
+    VAMP_TIMED(kProfConvWgrad, s, (conv3d_bf16_wgrad_kernel<CIN, COUT, true, F16><<<nwg, 192, 0, s>>>(
         P, static_cast<const unsigned short*>(in), static_cast<const unsigned short*>(dout), ws, nrows)));
   else
-    VAMP_TIMED(kProfConvWgrad, s, (conv3d_bf16_wgrad_kernel<CIN, COUT, false><<<nwg, 192, 0, s>>>(
+    VAMP_TIMED(kProfConvWgrad, s, (conv3d_bf16_wgrad_kernel<CIN, COUT, false, F16><<<nwg, 192, 0, s>>>(
         P, static_cast<const unsigned short*>(in), static_cast<const unsigned short*>(dout), ws, nrows)));
   if (int e = check_launch("conv3d_bf16_wgrad_kernel")) return e;
   const int n = 27 * CIN * COUT;
@@ -423,41 +450,70 @@ size_t vamp_conv3d_bf16_workspace_bytes(const VampConvDesc* d) {
   return (size_t) kWgradWgs * 27 * d->cin * d->cout * sizeof(float);
 }
 
-int vamp_conv3d_bf16_forward(const VampConvDesc* d, const void* in, const void* weight, void* out, void* stream) {
+// dtype: VAMP_BF16 or VAMP_F16 (the reference's `precision=16` is IEEE half)
+int vamp_conv3d_half_forward(const VampConvDesc* d, int32_t dtype, const void* in, const void* weight, void* out,
+                             void* stream) {
   VAMP_REQUIRE(bf16_shape_ok(d), "unsupported shape: see vamp_conv3d_bf16_supported");
   VAMP_REQUIRE(in && weight && out, "NULL tensor");
+  VAMP_REQUIRE(dtype == VAMP_BF16 || dtype == VAMP_F16, "dtype must be VAMP_BF16 or VAMP_F16");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (d->cin == 16) return d->cout == 16 ? launch_fwd<16, 16, false>(d, in, weight, out, s)
-                                         : launch_fwd<16, 32, false>(d, in, weight, out, s);
-  return d->cout == 16 ? launch_fwd<32, 16, false>(d, in, weight, out, s)
-                       : launch_fwd<32, 32, false>(d, in, weight, out, s);
+#define VAMP_CV(F16)                                                                                       \
+  if (d->cin == 16) return d->cout == 16 ? launch_fwd<16, 16, false, F16>(d, in, weight, out, s)           \
+                                         : launch_fwd<16, 32, false, F16>(d, in, weight, out, s);          \
+  return d->cout == 16 ? launch_fwd<32, 16, false, F16>(d, in, weight, out, s)                             \
+                       : launch_fwd<32, 32, false, F16>(d, in, weight, out, s);
+  if (dtype == VAMP_F16) { VAMP_CV(true) }
+  VAMP_CV(false)
+#undef VAMP_CV
 }
 
-int vamp_conv3d_bf16_backward_data(const VampConvDesc* d, const void* grad_out, const void* weight, void* grad_in,
-                                   void* stream) {
+int vamp_conv3d_half_backward_data(const VampConvDesc* d, int32_t dtype, const void* grad_out, const void* weight,
+                                   void* grad_in, void* stream) {
   VAMP_REQUIRE(bf16_shape_ok(d), "unsupported shape: see vamp_conv3d_bf16_supported");
   VAMP_REQUIRE(grad_out && weight && grad_in, "NULL tensor");
+  VAMP_REQUIRE(dtype == VAMP_BF16 || dtype == VAMP_F16, "dtype must be VAMP_BF16 or VAMP_F16");
   hipStream_t s = static_cast<hipStream_t>(stream);
   // the kernel's input tensor is grad_out (cout channels), its output grad_in (cin channels)
-  if (d->cout == 16) return d->cin == 16 ? launch_fwd<16, 16, true>(d, grad_out, weight, grad_in, s)
-                                         : launch_fwd<16, 32, true>(d, grad_out, weight, grad_in, s);
-  return d->cin == 16 ? launch_fwd<32, 16, true>(d, grad_out, weight, grad_in, s)
-                      : launch_fwd<32, 32, true>(d, grad_out, weight, grad_in, s);
+#define VAMP_CV(F16)                                                                                       \
+  if (d->cout == 16) return d->cin == 16 ? launch_fwd<16, 16, true, F16>(d, grad_out, weight, grad_in, s)  \
+                                         : launch_fwd<16, 32, true, F16>(d, grad_out, weight, grad_in, s); \
+  return d->cin == 16 ? launch_fwd<32, 16, true, F16>(d, grad_out, weight, grad_in, s)                     \
+                      : launch_fwd<32, 32, true, F16>(d, grad_out, weight, grad_in, s);
+  if (dtype == VAMP_F16) { VAMP_CV(true) }
+  VAMP_CV(false)
+#undef VAMP_CV
 }
 
-int vamp_conv3d_bf16_backward_weight(const VampConvDesc* d, const void* in, const void* grad_out, float* grad_weight,
-                                     void* workspace, size_t workspace_bytes, void* stream) {
+int vamp_conv3d_half_backward_weight(const VampConvDesc* d, int32_t dtype, const void* in, const void* grad_out,
+                                     float* grad_weight, void* workspace, size_t workspace_bytes, void* stream) {
   VAMP_REQUIRE(bf16_shape_ok(d), "unsupported shape: see vamp_conv3d_bf16_supported");
   VAMP_REQUIRE(in && grad_out && grad_weight, "NULL tensor");
+  VAMP_REQUIRE(dtype == VAMP_BF16 || dtype == VAMP_F16, "dtype must be VAMP_BF16 or VAMP_F16");
   const size_t need = vamp_conv3d_bf16_workspace_bytes(d);
   if (!workspace || workspace_bytes < need)
     return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) need);
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* ws = static_cast<float*>(workspace);
-  if (d->cin == 16) return d->cout == 16 ? launch_wgrad<16, 16>(d, in, grad_out, grad_weight, ws, s)
-                                         : launch_wgrad<16, 32>(d, in, grad_out, grad_weight, ws, s);
-  return d->cout == 16 ? launch_wgrad<32, 16>(d, in, grad_out, grad_weight, ws, s)
-                       : launch_wgrad<32, 32>(d, in, grad_out, grad_weight, ws, s);
+#define VAMP_CV(F16)                                                                                       \
+  if (d->cin == 16) return d->cout == 16 ? launch_wgrad<16, 16, F16>(d, in, grad_out, grad_weight, ws, s)  \
+                                         : launch_wgrad<16, 32, F16>(d, in, grad_out, grad_weight, ws, s); \
+  return d->cout == 16 ? launch_wgrad<32, 16, F16>(d, in, grad_out, grad_weight, ws, s)                    \
+                       : launch_wgrad<32, 32, F16>(d, in, grad_out, grad_weight, ws, s);
+  if (dtype == VAMP_F16) { VAMP_CV(true) }
+  VAMP_CV(false)
+#undef VAMP_CV
+}
+
+int vamp_conv3d_bf16_forward(const VampConvDesc* d, const void* in, const void* weight, void* out, void* stream) {
+  return vamp_conv3d_half_forward(d, VAMP_BF16, in, weight, out, stream);
+}
+int vamp_conv3d_bf16_backward_data(const VampConvDesc* d, const void* grad_out, const void* weight, void* grad_in,
+                                   void* stream) {
+  return vamp_conv3d_half_backward_data(d, VAMP_BF16, grad_out, weight, grad_in, stream);
+}
+int vamp_conv3d_bf16_backward_weight(const VampConvDesc* d, const void* in, const void* grad_out, float* grad_weight,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  return vamp_conv3d_half_backward_weight(d, VAMP_BF16, in, grad_out, grad_weight, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

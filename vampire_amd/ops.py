@@ -1061,7 +1061,7 @@ def conv3d_bf16(x, weight):
 
 
 def conv3d_bf16_supported(x, weight, stride, padding, bias):
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and bias is None and tuple(stride) == (1, 1, 1)
+    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and bias is None and tuple(stride) == (1, 1, 1)
             and tuple(padding) == (1, 1, 1) and tuple(weight.shape[2:]) == (3, 3, 3) and x.dim() == 5
             and weight.shape[1] == x.shape[1]):
         return False
@@ -1076,8 +1076,9 @@ class _Conv3dBf16Fn(torch.autograd.Function):
     def forward(ctx, x, w):
         if not (x.is_cuda and w.is_cuda):
             raise _capi.VampireHipError("x / weight must be device tensors (no CPU fallback)")
-        if x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or x.dim() != 5 or w.dim() != 5:
-            raise TypeError("conv3d_bf16 takes bf16 [B,cin,Z,Y,X] and [cout,cin,3,3,3] tensors")
+        if x.dtype not in (torch.bfloat16, torch.float16) or w.dtype != x.dtype or x.dim() != 5 or w.dim() != 5:
+            raise TypeError("conv3d_bf16 takes bf16 (or fp16) [B,cin,Z,Y,X] and [cout,cin,3,3,3] tensors of one dtype")
+        code = _capi.VAMP_BF16 if x.dtype == torch.bfloat16 else _capi.VAMP_F16
         lib = _capi.load()
         x, w = x.contiguous(), w.contiguous()
         d = _capi.VampConvDesc()
@@ -1085,10 +1086,10 @@ class _Conv3dBf16Fn(torch.autograd.Function):
         d.cout = w.shape[0]
         if w.shape[1] != d.cin:
             raise ValueError("weight / input channel mismatch")
-        out = torch.empty((d.B, d.cout, d.Z, d.Y, d.X), dtype=torch.bfloat16, device=x.device)
-        _capi.check(lib.vamp_conv3d_bf16_forward(C.byref(d), _ptr(x), _ptr(w), _ptr(out), _stream()),
-                    "vamp_conv3d_bf16_forward")
-        ctx.lib, ctx.desc = lib, d
+        out = torch.empty((d.B, d.cout, d.Z, d.Y, d.X), dtype=x.dtype, device=x.device)
+        _capi.check(lib.vamp_conv3d_half_forward(C.byref(d), code, _ptr(x), _ptr(w), _ptr(out), _stream()),
+                    "vamp_conv3d_half_forward")
+        ctx.lib, ctx.desc, ctx.code = lib, d, code
         ctx.save_for_backward(x, w)
         return out
 
@@ -1096,12 +1097,12 @@ class _Conv3dBf16Fn(torch.autograd.Function):
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         lib, d = ctx.lib, ctx.desc
-        g = g.contiguous().to(torch.bfloat16)
+        g = g.contiguous().to(x.dtype)
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            _capi.check(lib.vamp_conv3d_bf16_backward_data(C.byref(d), _ptr(g), _ptr(w), _ptr(gx), _stream()),
-                        "vamp_conv3d_bf16_backward_data")
+            _capi.check(lib.vamp_conv3d_half_backward_data(C.byref(d), ctx.code, _ptr(g), _ptr(w), _ptr(gx), _stream()),
+                        "vamp_conv3d_half_backward_data")
         if ctx.needs_input_grad[1]:
             gw32 = torch.empty(w.shape, dtype=torch.float32, device=w.device)
             nbytes = lib.vamp_conv3d_bf16_workspace_bytes(C.byref(d))
@@ -1109,9 +1110,9 @@ class _Conv3dBf16Fn(torch.autograd.Function):
             ws = _resize_ws.get(key)
             if ws is None:
                 ws = _resize_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
-            _capi.check(lib.vamp_conv3d_bf16_backward_weight(C.byref(d), _ptr(x), _ptr(g), _ptr(gw32), _ptr(ws),
-                                                             ws.numel(), _stream()), "vamp_conv3d_bf16_backward_weight")
-            gw = gw32.to(torch.bfloat16)          # the gradient of the bf16 copy autocast made of the fp32 parameter
+            _capi.check(lib.vamp_conv3d_half_backward_weight(C.byref(d), ctx.code, _ptr(x), _ptr(g), _ptr(gw32), _ptr(ws),
+                                                             ws.numel(), _stream()), "vamp_conv3d_half_backward_weight")
+            gw = gw32.to(w.dtype)                 # the gradient of the 16-bit copy autocast made of the fp32 parameter
         return gx, gw
 
 
