@@ -333,7 +333,7 @@ def multitask_measure(dev, batch_per_gpu, rank, world, steps=4, warm=2):
     el = vdist.max_over_ranks(time.perf_counter() - t0, dev)
     nparam = sum(p.numel() for p in model.parameters())
     return {"ms_per_step": el / steps * 1e3, "samples_per_s": batch_per_gpu * world * steps / el, "steps": steps,
-            "parameters": nparam, "loss": float(loss), "amp": "bf16", "batch_per_gpu": batch_per_gpu,
+            "parameters": nparam, "loss": float(loss.detach()), "amp": "bf16", "batch_per_gpu": batch_per_gpu,
             "loss_terms": {k: float(v) for k, v in loss_fn.last.items()},
             "what": "configs[4]: R50 + SECONDFPN + BaseVAMPIRE2 (HIP operators) + BEVDepthHead stand-ins, 9 losses, "
                     "AdamW; cfg-A, synthetic collate_fn-shaped batch; forward + backward + optimizer step"}

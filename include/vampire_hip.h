@@ -550,6 +550,14 @@ int vamp_upsample_trilinear_forward(int64_t planes, int32_t iz, int32_t iy, int3
                                     int32_t oy, int32_t ox, const float* in, float* out,
                                     void* stream);
 size_t vamp_upsample_trilinear_workspace_bytes(int32_t iz, int32_t iy, int32_t ix);
+/* the same with 16-bit tensors (a mixed-precision UNet): dtype = VAMP_F32 | VAMP_BF16 | VAMP_F16 for in / out
+   (and grad_out / grad_in below); fp32 arithmetic */
+int vamp_upsample_trilinear_forward_ex(int64_t planes, int32_t iz, int32_t iy, int32_t ix, int32_t oz,
+                                       int32_t oy, int32_t ox, int32_t dtype, const void* in, void* out,
+                                       void* stream);
+int vamp_upsample_trilinear_backward_ex(int64_t planes, int32_t iz, int32_t iy, int32_t ix, int32_t oz,
+                                        int32_t oy, int32_t ox, int32_t dtype, const void* grad_out, void* grad_in,
+                                        void* workspace, size_t workspace_bytes, void* stream);
 /* 1 when the backward's gather table covers this scale (about out / in <= 6 per axis), else 0:
  * callers fall back to F.interpolate then */
 int vamp_upsample_trilinear_supported(int32_t iz, int32_t iy, int32_t ix, int32_t oz, int32_t oy, int32_t ox);

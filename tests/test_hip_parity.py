@@ -1587,3 +1587,25 @@ def test_conv3d_bf16_matches_torch(dev, cin, cout, vol, batch, dt):
     close(a.grad, b.grad, atol=1e-3, rtol=2.0 ** -8, what="conv3d_bf16 grad_in")
     # the weight gradient is accumulated in fp32 and rounded once to bf16
     close(wa.grad, wb.grad, atol=1e-6, rtol=2.0 ** -7, scale="max", what="conv3d_bf16 grad_w")
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_resize_16bit(dev, dt):
+    """The UNet's trilinear resize with 16-bit tensors (mixed precision): same taps and fp32 arithmetic as the
+    fp32 kernel, one rounding at the output; forward and the gather backward."""
+    import torch.nn.functional as F
+    from vampire_amd.ops import upsample_trilinear
+    gen = torch.Generator(device=dev).manual_seed(2)
+    x = torch.randn(2, 5, 4, 9, 13, device=dev, generator=gen).to(dt)
+    size = (8, 17, 26)
+    a = x.clone().requires_grad_(True)
+    y = upsample_trilinear(a, size)
+    assert y.dtype == dt and y.shape == (2, 5) + size
+    b = x.double().requires_grad_(True)
+    yr = F.interpolate(b, size, mode="trilinear", align_corners=True)
+    rel = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -10
+    close(y, yr, atol=1e-3, rtol=rel, what="resize 16-bit forward")
+    go = torch.randn(y.shape, device=dev, generator=gen).to(dt)
+    y.backward(go); yr.backward(go.double())
+    assert a.grad.dtype == dt
+    close(a.grad, b.grad, atol=1e-2, rtol=4 * rel, what="resize 16-bit backward")

@@ -121,6 +121,8 @@ SIGNATURES = {
     "vamp_depth_softmax_backward": (C.c_int, [C.c_int64, C.c_int32, C.c_int64, _P, _P, _P, _P]),
     "vamp_density_gate_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_int64, C.c_int32, _P, _P, _P, _P]),
     "vamp_upsample_trilinear_forward": (C.c_int, [C.c_int64] + [C.c_int32] * 6 + [_P, _P, _P]),
+    "vamp_upsample_trilinear_forward_ex": (C.c_int, [C.c_int64] + [C.c_int32] * 7 + [_P, _P, _P]),
+    "vamp_upsample_trilinear_backward_ex": (C.c_int, [C.c_int64] + [C.c_int32] * 7 + [_P, _P, _P, C.c_size_t, _P]),
     "vamp_upsample_trilinear_workspace_bytes": (C.c_size_t, [C.c_int32] * 3),
     "vamp_upsample_trilinear_supported": (C.c_int, [C.c_int32] * 6),
     "vamp_upsample_trilinear_backward": (C.c_int, [C.c_int64] + [C.c_int32] * 6 + [_P, _P, _P, C.c_size_t, _P]),

@@ -30,6 +30,27 @@ __device__ __forceinline__ float axis_scale(int in, int out) {
   return out > 1 ? (float) (in - 1) / (float) (out - 1) : 0.f;
 }
 
+// element types of the tensors: fp32, or the 16-bit types a mixed-precision UNet hands over (compute stays fp32)
+struct Bf16 { unsigned short u; };
+struct F16 { unsigned short u; };
+__device__ __forceinline__ float lde(const float* p, long i) { return p[i]; }
+__device__ __forceinline__ float lde(const Bf16* p, long i) { return __uint_as_float((unsigned) p[i].u << 16); }
+__device__ __forceinline__ float lde(const F16* p, long i) {
+  _Float16 h;
+  __builtin_memcpy(&h, &p[i].u, 2);
+  return (float) h;
+}
+__device__ __forceinline__ void ste(float* p, long i, float v) { p[i] = v; }
+__device__ __forceinline__ void ste(Bf16* p, long i, float v) {
+  unsigned u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) u |= 0x400000u; else u += 0x7fffu + ((u >> 16) & 1u);
+  p[i].u = (unsigned short) (u >> 16);
+}
+__device__ __forceinline__ void ste(F16* p, long i, float v) {
+  const _Float16 h = (_Float16) v;
+  __builtin_memcpy(&p[i].u, &h, 2);
+}
+
 struct Tap {
   int i0, i1;
   float l0, l1;
@@ -80,8 +101,9 @@ constexpr int kPlanesPerBlock = 8;     // (batch, channel) planes a thread walks
 constexpr int kBwdPlanes = 1;          // the backward has 64 loads per plane already: parallelism wins
 
 // thread per output voxel, kPlanesPerBlock planes per thread (the taps are computed once)
+template <typename T>
 __global__ void __launch_bounds__(256)
-upsample_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int iz, int iy, int ix,
+upsample_fwd_kernel(const T* __restrict__ in, T* __restrict__ out, int iz, int iy, int ix,
                     int oz, int oy, int ox, int planes) {
   const unsigned ovox = (unsigned) oz * oy * ox, ivox = (unsigned) iz * iy * ix;
   const unsigned o = blockIdx.x * 256u + threadIdx.x;
@@ -95,13 +117,13 @@ upsample_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int i
   const unsigned r10 = ((unsigned) tz.i1 * iy + ty.i0) * ix, r11 = ((unsigned) tz.i1 * iy + ty.i1) * ix;
   const int p0 = blockIdx.y * kPlanesPerBlock, p1 = min(planes, p0 + kPlanesPerBlock);
   for (int pl = p0; pl < p1; ++pl) {
-    const float* p = in + (long) pl * ivox;
-    const float v000 = p[r00 + tx.i0], v001 = p[r00 + tx.i1], v010 = p[r01 + tx.i0], v011 = p[r01 + tx.i1];
-    const float v100 = p[r10 + tx.i0], v101 = p[r10 + tx.i1], v110 = p[r11 + tx.i0], v111 = p[r11 + tx.i1];
+    const T* p = in + (long) pl * ivox;
+    const float v000 = lde(p, r00 + tx.i0), v001 = lde(p, r00 + tx.i1), v010 = lde(p, r01 + tx.i0), v011 = lde(p, r01 + tx.i1);
+    const float v100 = lde(p, r10 + tx.i0), v101 = lde(p, r10 + tx.i1), v110 = lde(p, r11 + tx.i0), v111 = lde(p, r11 + tx.i1);
     // aten's nesting (UpSampleTrilinear3d.cu)
-    out[(long) pl * ovox + o] =
+    ste(out, (long) pl * ovox + o,
         tz.l0 * (ty.l0 * (tx.l0 * v000 + tx.l1 * v001) + ty.l1 * (tx.l0 * v010 + tx.l1 * v011)) +
-        tz.l1 * (ty.l0 * (tx.l0 * v100 + tx.l1 * v101) + ty.l1 * (tx.l0 * v110 + tx.l1 * v111));
+        tz.l1 * (ty.l0 * (tx.l0 * v100 + tx.l1 * v101) + ty.l1 * (tx.l0 * v110 + tx.l1 * v111)));
   }
 }
 
@@ -116,9 +138,9 @@ __device__ __forceinline__ float hit_weight(const AxisHit& h, int k) {
 
 // thread per source voxel: sum of the (at most nz * ny * nx) output gradients, kBwdPlanes
 // planes per thread; MH = hits per axis the x-loop is unrolled for
-template <int MH>
+template <int MH, typename T>
 __global__ void __launch_bounds__(256)
-upsample_bwd_kernel(const float* __restrict__ g, float* __restrict__ gin, const AxisHit* __restrict__ tab,
+upsample_bwd_kernel(const T* __restrict__ g, T* __restrict__ gin, const AxisHit* __restrict__ tab,
                     int iz, int iy, int ix, int oz, int oy, int ox, int planes) {
   const unsigned ivox = (unsigned) iz * iy * ix;
   const unsigned i = blockIdx.x * 256u + threadIdx.x;
@@ -129,19 +151,19 @@ upsample_bwd_kernel(const float* __restrict__ g, float* __restrict__ gin, const 
   const long ovox = (long) oz * oy * ox;
   const int p0 = blockIdx.y * kBwdPlanes, p1 = min(planes, p0 + kBwdPlanes);
   for (int pl = p0; pl < p1; ++pl) {
-    const float* gp = g + (long) pl * ovox;
+    const T* gp = g + (long) pl * ovox;
     float acc = 0.f;
     for (int a = 0; a < hz.n; ++a) {
       const float wz = hit_weight<MH>(hz, a);
       for (int b = 0; b < hy.n; ++b) {
         const float wzy = wz * hit_weight<MH>(hy, b);
-        const float* row = gp + ((unsigned) (hz.begin + a) * oy + (hy.begin + b)) * (unsigned) ox + hx.begin;
+        const T* row = gp + ((unsigned) (hz.begin + a) * oy + (hy.begin + b)) * (unsigned) ox + hx.begin;
 #pragma unroll
         for (int c = 0; c < MH; ++c)
-          if (c < hx.n) acc += wzy * hx.w[c] * row[c];
+          if (c < hx.n) acc += wzy * hx.w[c] * lde(row, c);
       }
     }
-    gin[(long) pl * ivox + i] = acc;
+    ste(gin, (long) pl * ivox + i, acc);
   }
 }
 
@@ -168,17 +190,36 @@ using namespace vamp;
 
 extern "C" {
 
+}  // extern "C"
+
+template <typename T>
+static int up_forward(int64_t planes, int iz, int iy, int ix, int oz, int oy, int ox, const void* in, void* out, hipStream_t s) {
+  const long ovox = (long) oz * oy * ox;
+  const dim3 grid((unsigned) ((ovox + 255) / 256), (unsigned) ((planes + kPlanesPerBlock - 1) / kPlanesPerBlock));
+  VAMP_TIMED(kProfUpsample, s, (upsample_fwd_kernel<T><<<grid, 256, 0, s>>>(static_cast<const T*>(in), static_cast<T*>(out),
+                                                                           iz, iy, ix, oz, oy, ox, (int) planes)));
+  return check_launch("upsample_fwd_kernel");
+}
+
+extern "C" {
+
+/* dtype: VAMP_F32, VAMP_BF16 or VAMP_F16 for `in` and `out` alike (fp32 arithmetic) */
+int vamp_upsample_trilinear_forward_ex(int64_t planes, int32_t iz, int32_t iy, int32_t ix, int32_t oz,
+                                       int32_t oy, int32_t ox, int32_t dtype, const void* in, void* out,
+                                       void* stream) {
+  if (int e = check_dims(planes, iz, iy, ix, oz, oy, ox)) return e;
+  VAMP_REQUIRE(in && out, "NULL tensor");
+  VAMP_REQUIRE(dtype == VAMP_F32 || dtype == VAMP_BF16 || dtype == VAMP_F16, "dtype");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == VAMP_F32) return up_forward<float>(planes, iz, iy, ix, oz, oy, ox, in, out, s);
+  if (dtype == VAMP_BF16) return up_forward<Bf16>(planes, iz, iy, ix, oz, oy, ox, in, out, s);
+  return up_forward<F16>(planes, iz, iy, ix, oz, oy, ox, in, out, s);
+}
+
 int vamp_upsample_trilinear_forward(int64_t planes, int32_t iz, int32_t iy, int32_t ix, int32_t oz,
                                     int32_t oy, int32_t ox, const float* in, float* out,
                                     void* stream) {
-  if (int e = check_dims(planes, iz, iy, ix, oz, oy, ox)) return e;
-  VAMP_REQUIRE(in && out, "NULL tensor");
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const long ovox = (long) oz * oy * ox;
-  const dim3 grid((unsigned) ((ovox + 255) / 256), (unsigned) ((planes + kPlanesPerBlock - 1) / kPlanesPerBlock));
-  VAMP_TIMED(kProfUpsample, s, (upsample_fwd_kernel<<<grid, 256, 0, s>>>(in, out, iz, iy, ix, oz, oy, ox,
-                                                                        (int) planes)));
-  return check_launch("upsample_fwd_kernel");
+  return vamp_upsample_trilinear_forward_ex(planes, iz, iy, ix, oz, oy, ox, VAMP_F32, in, out, stream);
 }
 
 int vamp_upsample_trilinear_supported(int32_t iz, int32_t iy, int32_t ix, int32_t oz, int32_t oy, int32_t ox) {
@@ -191,11 +232,31 @@ size_t vamp_upsample_trilinear_workspace_bytes(int32_t iz, int32_t iy, int32_t i
   return table_bytes(iz, iy, ix);
 }
 
-int vamp_upsample_trilinear_backward(int64_t planes, int32_t iz, int32_t iy, int32_t ix, int32_t oz,
-                                     int32_t oy, int32_t ox, const float* grad_out, float* grad_in,
-                                     void* workspace, size_t workspace_bytes, void* stream) {
+}  // extern "C"
+
+template <typename T>
+static int up_backward(int64_t planes, int iz, int iy, int ix, int oz, int oy, int ox, const void* grad_out, void* grad_in,
+                       AxisHit* tab, hipStream_t s) {
+  const long ivox = (long) iz * iy * ix;
+  const dim3 grid((unsigned) ((ivox + 255) / 256), (unsigned) ((planes + kBwdPlanes - 1) / kBwdPlanes));
+  const T* g = static_cast<const T*>(grad_out);
+  T* gi = static_cast<T*>(grad_in);
+  if (run_fits(ix, ox, 6) && run_fits(iy, oy, 6) && run_fits(iz, oz, 6)) {
+    VAMP_TIMED(kProfUpsample, s, (upsample_bwd_kernel<6, T><<<grid, 256, 0, s>>>(g, gi, tab, iz, iy, ix, oz, oy, ox, (int) planes)));
+  } else {
+    VAMP_TIMED(kProfUpsample, s, (upsample_bwd_kernel<kMaxHits, T><<<grid, 256, 0, s>>>(g, gi, tab, iz, iy, ix, oz, oy, ox, (int) planes)));
+  }
+  return check_launch("upsample_bwd_kernel");
+}
+
+extern "C" {
+
+int vamp_upsample_trilinear_backward_ex(int64_t planes, int32_t iz, int32_t iy, int32_t ix, int32_t oz,
+                                        int32_t oy, int32_t ox, int32_t dtype, const void* grad_out, void* grad_in,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
   if (int e = check_dims(planes, iz, iy, ix, oz, oy, ox)) return e;
   VAMP_REQUIRE(grad_out && grad_in && workspace, "NULL tensor");
+  VAMP_REQUIRE(dtype == VAMP_F32 || dtype == VAMP_BF16 || dtype == VAMP_F16, "dtype");
   VAMP_REQUIRE(workspace_bytes >= table_bytes(iz, iy, ix), "workspace too small");
   // outputs whose source coordinate lies in [i - 1, i + 1): at most floor(2 (out-1)/(in-1)) + 1
   VAMP_REQUIRE(run_fits(iz, oz) && run_fits(iy, oy) && run_fits(ix, ox),
@@ -205,16 +266,16 @@ int vamp_upsample_trilinear_backward(int64_t planes, int32_t iz, int32_t iy, int
   const int n = iz + iy + ix;
   upsample_axis_table_kernel<<<(n + 255) / 256, 256, 0, s>>>(tab, iz, iy, ix, oz, oy, ox);
   if (int e = check_launch("upsample_axis_table_kernel")) return e;
-  const long ivox = (long) iz * iy * ix;
-  const dim3 grid((unsigned) ((ivox + 255) / 256), (unsigned) ((planes + kBwdPlanes - 1) / kBwdPlanes));
-  if (run_fits(ix, ox, 6) && run_fits(iy, oy, 6) && run_fits(iz, oz, 6)) {
-    VAMP_TIMED(kProfUpsample, s, (upsample_bwd_kernel<6><<<grid, 256, 0, s>>>(grad_out, grad_in, tab, iz, iy, ix,
-                                                                             oz, oy, ox, (int) planes)));
-  } else {
-    VAMP_TIMED(kProfUpsample, s, (upsample_bwd_kernel<kMaxHits><<<grid, 256, 0, s>>>(
-        grad_out, grad_in, tab, iz, iy, ix, oz, oy, ox, (int) planes)));
-  }
-  return check_launch("upsample_bwd_kernel");
+  if (dtype == VAMP_F32) return up_backward<float>(planes, iz, iy, ix, oz, oy, ox, grad_out, grad_in, tab, s);
+  if (dtype == VAMP_BF16) return up_backward<Bf16>(planes, iz, iy, ix, oz, oy, ox, grad_out, grad_in, tab, s);
+  return up_backward<F16>(planes, iz, iy, ix, oz, oy, ox, grad_out, grad_in, tab, s);
+}
+
+int vamp_upsample_trilinear_backward(int64_t planes, int32_t iz, int32_t iy, int32_t ix, int32_t oz,
+                                     int32_t oy, int32_t ox, const float* grad_out, float* grad_in,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  return vamp_upsample_trilinear_backward_ex(planes, iz, iy, ix, oz, oy, ox, VAMP_F32, grad_out, grad_in, workspace,
+                                             workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -1017,20 +1017,25 @@ class _UpsampleTrilinearFn(torch.autograd.Function):
             raise ValueError("expected a [B,C,z,y,x] tensor and a 3-tuple size")
         lib = _capi.load()
         ctx.in_dtype = x.dtype
-        x = x.float().contiguous()
+        codes = {torch.float32: _capi.VAMP_F32, torch.bfloat16: _capi.VAMP_BF16, torch.float16: _capi.VAMP_F16}
+        if x.dtype not in codes:
+            x = x.float()
+        x = x.contiguous()
+        ctx.code = codes[x.dtype]
         B, C_ = x.shape[:2]
-        out = torch.empty((B, C_) + size, dtype=torch.float32, device=x.device)
+        out = torch.empty((B, C_) + size, dtype=x.dtype, device=x.device)
         if out.numel() and x.numel():
-            _capi.check(lib.vamp_upsample_trilinear_forward(B * C_, *x.shape[2:], *size, _ptr(x), _ptr(out),
-                                                            _stream()), "vamp_upsample_trilinear_forward")
+            _capi.check(lib.vamp_upsample_trilinear_forward_ex(B * C_, *x.shape[2:], *size, ctx.code, _ptr(x), _ptr(out),
+                                                               _stream()), "vamp_upsample_trilinear_forward_ex")
         ctx.lib, ctx.dims = lib, (B * C_,) + tuple(x.shape[2:]) + size
         ctx.in_shape = tuple(x.shape)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        g = g.contiguous().float()
-        gin = torch.empty(ctx.in_shape, dtype=torch.float32, device=g.device)
+        dt = {_capi.VAMP_F32: torch.float32, _capi.VAMP_BF16: torch.bfloat16, _capi.VAMP_F16: torch.float16}[ctx.code]
+        g = g.contiguous().to(dt)
+        gin = torch.empty(ctx.in_shape, dtype=dt, device=g.device)
         if gin.numel() and g.numel():
             lib = ctx.lib
             nbytes = lib.vamp_upsample_trilinear_workspace_bytes(*ctx.dims[1:4])
@@ -1038,8 +1043,8 @@ class _UpsampleTrilinearFn(torch.autograd.Function):
             ws = _resize_ws.get(key)
             if ws is None:
                 ws = _resize_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
-            _capi.check(lib.vamp_upsample_trilinear_backward(*ctx.dims, _ptr(g), _ptr(gin), _ptr(ws), ws.numel(),
-                                                             _stream()), "vamp_upsample_trilinear_backward")
+            _capi.check(lib.vamp_upsample_trilinear_backward_ex(*ctx.dims, ctx.code, _ptr(g), _ptr(gin), _ptr(ws), ws.numel(),
+                                                                _stream()), "vamp_upsample_trilinear_backward_ex")
         else:
             gin.zero_()
         return gin.to(ctx.in_dtype), None
