@@ -43,8 +43,19 @@ pool_cells_kernel(PoolParams q, const int* __restrict__ geom, int* __restrict__ 
   else ids[off[cell] + boff[cell / kScanTile] + rank[gp]] = (int) (gp % q.P);
 }
 
-// one wave per cell, lanes over channels (C > 64: several passes); four rows in flight
-template <typename T>
+// four channels of one point per lane
+__device__ __forceinline__ float4 ld4(const float* p, long i) { return *reinterpret_cast<const float4*>(p + i); }
+__device__ __forceinline__ float4 ld4(const __hip_bfloat16* p, long i) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p + i);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u));
+}
+
+// One wave per cell.  C % 4 == 0 and C <= 256 (VEC): a lane holds four channels, so a feature row takes
+// Q = C / 4 lanes and R = 64 / Q points of the cell's list are added side by side (C = 80: 20 lanes x 3
+// points; with a lane per channel the second pass of 64 covered 16 channels); the R partial rows are
+// folded with shuffles at the end.  Otherwise lanes over channels, several passes.
+template <typename T, bool VEC>
 __global__ void __launch_bounds__(256)
 pool_gather_kernel(PoolParams q, const T* __restrict__ feat, const int* __restrict__ off,
                    const int* __restrict__ boff, const int* __restrict__ ids, float* __restrict__ out,
@@ -56,6 +67,29 @@ pool_gather_kernel(PoolParams q, const T* __restrict__ feat, const int* __restri
   const int beg = off[cell] + boff[cell / kScanTile];
   const int end = off[cell + 1] + boff[(cell + 1) / kScanTile];
   const T* fb = feat + (long) b * q.P * q.C;
+  if (VEC) {
+    const int Q = q.C >> 2, R = 64 / Q;
+    const int cq = lane % Q, r = lane / Q;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < R) {
+      int k = beg + r;
+      for (; k + R < end; k += 2 * R) {           // two rows in flight per lane
+        const float4 v0 = ld4(fb, (long) ids[k] * q.C + 4 * cq), v1 = ld4(fb, (long) ids[k + R] * q.C + 4 * cq);
+        acc.x += v0.x + v1.x; acc.y += v0.y + v1.y; acc.z += v0.z + v1.z; acc.w += v0.w + v1.w;
+      }
+      if (k < end) {
+        const float4 v0 = ld4(fb, (long) ids[k] * q.C + 4 * cq);
+        acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+      }
+    }
+    for (int j = 1; j < R; ++j) {                 // fold the point slots into slot 0 (wave-uniform trip count)
+      const int src = min(cq + j * Q, 63);
+      const float x = __shfl(acc.x, src, 64), y = __shfl(acc.y, src, 64), z = __shfl(acc.z, src, 64), w = __shfl(acc.w, src, 64);
+      if (r == 0) { acc.x += x; acc.y += y; acc.z += z; acc.w += w; }
+    }
+    if (r == 0) *reinterpret_cast<float4*>(out + cell * q.C + 4 * cq) = acc;
+    return;
+  }
   for (int c0 = 0; c0 < q.C; c0 += 64) {
     const int c = c0 + lane;
     const bool live = c < q.C;
@@ -75,11 +109,24 @@ pool_gather_kernel(PoolParams q, const T* __restrict__ feat, const int* __restri
 }
 
 // grad_feat[b, p, :] = grad_out[cell(p), :] (0 for points outside the grid)
+template <bool VEC>
 __global__ void __launch_bounds__(256)
 pool_bwd_kernel(PoolParams q, const int* __restrict__ geom, const float* __restrict__ gout,
-                float* __restrict__ gfeat) {
+                float* __restrict__ gfeat, int ppw) {
   const int lane = threadIdx.x & 63;
-  const long gp = (long) blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long wave = (long) blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (VEC) {
+    // ppw = 64 / (C / 4) points per wave, a lane copies four channels of one point's row
+    const int Q = q.C >> 2, cq = lane % Q, r = lane / Q;
+    const long gp = wave * ppw + r;
+    if (r >= ppw || gp >= q.B * q.P) return;
+    const long cell = pool_cell(q, geom, gp, (int) (gp / q.P));
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cell >= 0) v = *reinterpret_cast<const float4*>(gout + cell * q.C + 4 * cq);
+    *reinterpret_cast<float4*>(gfeat + gp * q.C + 4 * cq) = v;
+    return;
+  }
+  const long gp = wave;
   if (gp >= q.B * q.P) return;
   const long cell = pool_cell(q, geom, gp, (int) (gp / q.P));
   for (int c = lane; c < q.C; c += 64) gfeat[gp * q.C + c] = cell >= 0 ? gout[cell * q.C + c] : 0.f;
@@ -149,10 +196,11 @@ int vamp_voxel_pooling_forward(const VampPoolDesc* d, const int32_t* geom_xyz, c
   VAMP_TIMED(kProfAux, s, (pool_cells_kernel<true><<<pgrid, 256, 0, s>>>(q, geom_xyz, w.cnt, w.rank, w.off, w.boff, w.ids)));
   if (int e = check_launch("pool_cells_kernel<fill>")) return e;
   const unsigned ggrid = (unsigned) ((cells + 3) / 4);
-  if (d->in_dtype == VAMP_F32)
-    VAMP_TIMED(kProfAux, s, (pool_gather_kernel<float><<<ggrid, 256, 0, s>>>(q, static_cast<const float*>(feat), w.off, w.boff, w.ids, out, cells)));
-  else
-    VAMP_TIMED(kProfAux, s, (pool_gather_kernel<__hip_bfloat16><<<ggrid, 256, 0, s>>>(q, static_cast<const __hip_bfloat16*>(feat), w.off, w.boff, w.ids, out, cells)));
+  const bool vec = d->C % 4 == 0 && d->C <= 256;
+#define VAMP_POOL(T, V) VAMP_TIMED(kProfAux, s, (pool_gather_kernel<T, V><<<ggrid, 256, 0, s>>>(q, static_cast<const T*>(feat), w.off, w.boff, w.ids, out, cells)))
+  if (d->in_dtype == VAMP_F32) { if (vec) VAMP_POOL(float, true); else VAMP_POOL(float, false); }
+  else { if (vec) VAMP_POOL(__hip_bfloat16, true); else VAMP_POOL(__hip_bfloat16, false); }
+#undef VAMP_POOL
   return check_launch("pool_gather_kernel");
 }
 
@@ -163,7 +211,13 @@ int vamp_voxel_pooling_backward(const VampPoolDesc* d, const int32_t* geom_xyz, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const PoolParams q{d->B, d->C, d->nx, d->ny, d->nz, d->P};
   const long npts = (long) d->B * d->P;
-  VAMP_TIMED(kProfAux, s, (pool_bwd_kernel<<<(unsigned) ((npts + 3) / 4), 256, 0, s>>>(q, geom_xyz, grad_out, grad_feat)));
+  if (d->C % 4 == 0 && d->C <= 256) {
+    const int ppw = 64 / (d->C / 4);
+    const long waves = (npts + ppw - 1) / ppw;
+    VAMP_TIMED(kProfAux, s, (pool_bwd_kernel<true><<<(unsigned) ((waves + 3) / 4), 256, 0, s>>>(q, geom_xyz, grad_out, grad_feat, ppw)));
+  } else {
+    VAMP_TIMED(kProfAux, s, (pool_bwd_kernel<false><<<(unsigned) ((npts + 3) / 4), 256, 0, s>>>(q, geom_xyz, grad_out, grad_feat, 1)));
+  }
   return check_launch("pool_bwd_kernel");
 }
 
