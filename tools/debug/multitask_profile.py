@@ -20,6 +20,7 @@ torch.cuda.synchronize()
 def phase_times():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
     t0 = time.perf_counter()
+    tg = lf.targets(batch)
     ev[0].record()
     with torch.autocast("cuda", dtype=torch.bfloat16):
         feats = model.backbone.get_cam_feats(batch[0])
@@ -28,7 +29,7 @@ def phase_times():
         ev[2].record()
         preds = model.head(out_b[0])
         ev[3].record()
-        loss = lf((preds,) + tuple(out_b[1:]), batch)
+        loss = lf((preds,) + tuple(out_b[1:]), batch, tg)
     ev[4].record()
     opt.zero_grad(set_to_none=True)
     loss.backward()
@@ -45,4 +46,10 @@ from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     M.multitask_step(model, lf, batch, optimizer=opt)
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=60))
+ka = prof.key_averages()
+print("top by device time")
+for e in sorted(ka, key=lambda e: -e.self_device_time_total)[:16]:
+    print("  %-80s %5d %9.1f us" % (e.key[:80], e.count, e.self_device_time_total))
+print("top by host (self CPU) time")
+for e in sorted(ka, key=lambda e: -e.self_cpu_time_total)[:12]:
+    print("  %-80s %5d %9.1f us" % (e.key[:80], e.count, e.self_cpu_time_total))

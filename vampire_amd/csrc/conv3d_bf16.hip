@@ -35,6 +35,7 @@ typedef bf16x8 __attribute__((aligned(2))) bf16x8_u;
 
 struct CvP {
   int B, Z, Y, X;
+  int cin, cout;        // real channel counts of the kernel's input / output tensors (<= the template tile sizes)
 };
 
 constexpr int kTY = 4;        // output rows per tile = waves per workgroup
@@ -105,7 +106,8 @@ conv3d_bf16_fwd_kernel(CvP P, const unsigned short* __restrict__ in, const unsig
     const int k = e & 31, co = (e >> 5) % COUT, tp = e / (32 * COUT);
     const int tap = CIN == 16 ? 2 * tp + (k >> 4) : tp, ci = CIN == 16 ? (k & 15) : k;
     unsigned short v = 0;
-    if (tap < 27) v = FLIP ? w[((long) ci * COUT + co) * 27 + (26 - tap)] : w[((long) co * CIN + ci) * 27 + tap];
+    if (tap < 27 && ci < P.cin && co < P.cout)       // channels beyond the real counts: zero weights
+      v = FLIP ? w[((long) ci * P.cout + co) * 27 + (26 - tap)] : w[((long) co * P.cin + ci) * 27 + tap];
     reinterpret_cast<unsigned short*>(w_s)[e] = v;
   }
 
@@ -118,7 +120,7 @@ conv3d_bf16_fwd_kernel(CvP P, const unsigned short* __restrict__ in, const unsig
     r /= (P.Y / kTY);
     const int z = (int) (r % P.Z), b = (int) (r / P.Z);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned short*>(in + (long) b * CIN * plane), 0, (int) ((size_t) CIN * plane * 2), 0x00020000);
+        const_cast<unsigned short*>(in + (long) b * P.cin * plane), 0, (int) ((size_t) P.cin * plane * 2), 0x00020000);   // planes >= cin read 0
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int it = tid + i * 256;
@@ -205,7 +207,7 @@ conv3d_bf16_fwd_kernel(CvP P, const unsigned short* __restrict__ in, const unsig
     else if (nnt == 2) run(std::integral_constant<int, 2>());
     else run(std::integral_constant<int, 1>());
     if (y < P.Y) {
-      unsigned short* ob = out + (long) b * COUT * plane + ((long) z * P.Y + y) * P.X;
+      unsigned short* ob = out + (long) b * P.cout * plane + ((long) z * P.Y + y) * P.X;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -213,7 +215,8 @@ conv3d_bf16_fwd_kernel(CvP P, const unsigned short* __restrict__ in, const unsig
           const int x = x0 + n * 16 + li;
           if (x < P.X) {
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) ob[(long) (m * 16 + 4 * kg + rg) * plane + x] = f2e<F16>(acc[m][n][rg]);
+            for (int rg = 0; rg < 4; ++rg)
+              if (m * 16 + 4 * kg + rg < P.cout) ob[(long) (m * 16 + 4 * kg + rg) * plane + x] = f2e<F16>(acc[m][n][rg]);
           }
         }
     }
@@ -263,8 +266,8 @@ conv3d_bf16_wgrad_kernel(CvP P, const unsigned short* __restrict__ in, const uns
     S.z = (int) ((row / P.Y) % P.Z);
     const int b = (int) (row / ((long) P.Y * P.Z));
     S.xb = ks * 32 + 8 * kg;
-    const unsigned short* gb = dout + (long) b * COUT * plane + ((long) S.z * P.Y + S.y) * P.X;
-    const unsigned short* ib = in + (long) b * CIN * plane;
+    const unsigned short* gb = dout + (long) b * P.cout * plane + ((long) S.z * P.Y + S.y) * P.X;
+    const unsigned short* ib = in + (long) b * P.cin * plane;
     const int zz = min(max(S.z + wv - 1, 0), P.Z - 1);
     // the window [xb, xb + 8): one 16-byte load, or (rows that are only 8-byte aligned, last window half
     // outside) its two halves from starts clamped into the row -- the compute step zeroes what lies outside
@@ -276,14 +279,14 @@ conv3d_bf16_wgrad_kernel(CvP P, const unsigned short* __restrict__ in, const uns
     };
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const u32x4 t = window(gb + (long) (m * 16 + li) * plane);
+      const u32x4 t = window(gb + (long) min(m * 16 + li, P.cout - 1) * plane);      // rows beyond cout: clamped here, zeroed in compute
       __builtin_memcpy(&S.a[m], &t, 16);
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const int yy = min(max(S.y + r - 1, 0), P.Y - 1);
 #pragma unroll
-      for (int n = 0; n < NT; ++n) S.v[r][n] = window(ib + (((long) (n * 16 + li) * P.Z + zz) * P.Y + yy) * P.X);
+      for (int n = 0; n < NT; ++n) S.v[r][n] = window(ib + (((long) min(n * 16 + li, P.cin - 1) * P.Z + zz) * P.Y + yy) * P.X);
     }
   };
   // zero the part of a window that lies beyond the row end (whole window, or its upper half when X % 8 == 4)
@@ -312,6 +315,7 @@ conv3d_bf16_wgrad_kernel(CvP P, const unsigned short* __restrict__ in, const uns
       u32x4 t;
       __builtin_memcpy(&t, &S.a[m], 16);
       t = clip(t, S.xb);
+      if (m * 16 + li >= P.cout) t = zero4;
       __builtin_memcpy(&a[m], &t, 16);
     }
     const int zz = S.z + wv - 1;
@@ -321,7 +325,7 @@ conv3d_bf16_wgrad_kernel(CvP P, const unsigned short* __restrict__ in, const uns
       const bool row_ok = zz >= 0 && zz < P.Z && yy >= 0 && yy < P.Y;       // wave-uniform
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const u32x4 v = row_ok ? clip(S.v[r][n], S.xb) : zero4;
+        const u32x4 v = (row_ok && n * 16 + li < P.cin) ? clip(S.v[r][n], S.xb) : zero4;
         // the dword left of this lane's window: lane group kg - 1 (same step), or the previous step's group 3
         const unsigned lsend = kg == 3 ? prev3[r][n] : v[3];
         unsigned left = (unsigned) __shfl((int) lsend, (lane + 48) & 63, 64);
@@ -370,7 +374,8 @@ conv3d_bf16_wgrad_kernel(CvP P, const unsigned short* __restrict__ in, const uns
 
 // dw[co][ci][tap] (bf16 or fp32 out) = sum over workgroups of part[wg][tap][co][ci]
 __global__ void __launch_bounds__(256)
-conv3d_bf16_wreduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int cin, int cout, int nwg) {
+conv3d_bf16_wreduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int cin, int cout, int nwg,
+                           int cin_r, int cout_r) {
   const int e = blockIdx.x * 64 + (threadIdx.x & 63), wv = threadIdx.x >> 6;
   __shared__ float red[4][64];
   const int n = 27 * cout * cin;
@@ -391,14 +396,16 @@ conv3d_bf16_wreduce_kernel(const float* __restrict__ part, float* __restrict__ d
   if (wv == 0 && e < n) {
     s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     const int ci = e % cin, co = (e / cin) % cout, tap = e / (cin * cout);
-    dw[((size_t) co * cin + ci) * 27 + tap] = s;
+    if (co < cout_r && ci < cin_r) dw[((size_t) co * cin_r + ci) * 27 + tap] = s;
   }
 }
 
 constexpr int kWgradWgs = 512;       // two workgroups per CU
 
+int tile_ch(int c) { return c <= 16 ? 16 : 32; }       // channel tile a real channel count runs under
+
 bool bf16_shape_ok(const VampConvDesc* d) {
-  return d && (d->cin == 16 || d->cin == 32) && (d->cout == 16 || d->cout == 32) && d->B > 0 && d->Z > 0 &&
+  return d && d->cin >= 1 && d->cin <= 32 && d->cout >= 1 && d->cout <= 32 && d->B > 0 && d->Z > 0 &&
          d->Y > 0 && d->X >= 8 && d->Y % kTY == 0 && d->X % 4 == 0 &&
          (long) d->Z * d->Y * d->X * 32 * 2 < 0x7fffffffL;
 }
@@ -409,7 +416,7 @@ int launch_fwd(const VampConvDesc* d, const void* in, const void* w, void* out, 
   auto k = conv3d_bf16_fwd_kernel<CIN, COUT, FLIP, F16>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int) L::bytes) != hipSuccess)
     return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);
-  const CvP P{d->B, d->Z, d->Y, d->X};
+  const CvP P{d->B, d->Z, d->Y, d->X, FLIP ? d->cout : d->cin, FLIP ? d->cin : d->cout};
   const int tiles_x = (d->X + kTX - 1) / kTX;
   const long ntiles = (long) d->B * d->Z * (d->Y / kTY) * tiles_x;
   const int per_cu = L::bytes <= 78 * 1024 ? 2 : 1;
@@ -421,7 +428,7 @@ int launch_fwd(const VampConvDesc* d, const void* in, const void* w, void* out, 
 
 template <int CIN, int COUT, bool F16>
 int launch_wgrad(const VampConvDesc* d, const void* in, const void* dout, float* dw, float* ws, hipStream_t s) {
-  const CvP P{d->B, d->Z, d->Y, d->X};
+  const CvP P{d->B, d->Z, d->Y, d->X, d->cin, d->cout};
   const long nrows = (long) d->B * d->Z * d->Y;
   const int nwg = (int) std::min<long>(nrows, kWgradWgs);
   if (d->X % 8 == 0)
@@ -432,7 +439,7 @@ int launch_wgrad(const VampConvDesc* d, const void* in, const void* dout, float*
         P, static_cast<const unsigned short*>(in), static_cast<const unsigned short*>(dout), ws, nrows)));
   if (int e = check_launch("conv3d_bf16_wgrad_kernel")) return e;
   const int n = 27 * CIN * COUT;
-  VAMP_TIMED(kProfConvWgrad, s, (conv3d_bf16_wreduce_kernel<<<(n + 63) / 64, 256, 0, s>>>(ws, dw, CIN, COUT, nwg)));
+  VAMP_TIMED(kProfConvWgrad, s, (conv3d_bf16_wreduce_kernel<<<(n + 63) / 64, 256, 0, s>>>(ws, dw, CIN, COUT, nwg, d->cin, d->cout)));
   return check_launch("conv3d_bf16_wreduce_kernel");
 }
 
@@ -447,7 +454,7 @@ int vamp_conv3d_bf16_supported(const VampConvDesc* d) { return bf16_shape_ok(d) 
 
 size_t vamp_conv3d_bf16_workspace_bytes(const VampConvDesc* d) {
   if (!bf16_shape_ok(d)) return 0;
-  return (size_t) kWgradWgs * 27 * d->cin * d->cout * sizeof(float);
+  return (size_t) kWgradWgs * 27 * tile_ch(d->cin) * tile_ch(d->cout) * sizeof(float);
 }
 
 // dtype: VAMP_BF16 or VAMP_F16 (the reference's `precision=16` is IEEE half)
@@ -458,9 +465,9 @@ int vamp_conv3d_half_forward(const VampConvDesc* d, int32_t dtype, const void* i
   VAMP_REQUIRE(dtype == VAMP_BF16 || dtype == VAMP_F16, "dtype must be VAMP_BF16 or VAMP_F16");
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define VAMP_CV(F16)                                                                                       \
-  if (d->cin == 16) return d->cout == 16 ? launch_fwd<16, 16, false, F16>(d, in, weight, out, s)           \
+  if (tile_ch(d->cin) == 16) return tile_ch(d->cout) == 16 ? launch_fwd<16, 16, false, F16>(d, in, weight, out, s)           \
                                          : launch_fwd<16, 32, false, F16>(d, in, weight, out, s);          \
-  return d->cout == 16 ? launch_fwd<32, 16, false, F16>(d, in, weight, out, s)                             \
+  return tile_ch(d->cout) == 16 ? launch_fwd<32, 16, false, F16>(d, in, weight, out, s)                             \
                        : launch_fwd<32, 32, false, F16>(d, in, weight, out, s);
   if (dtype == VAMP_F16) { VAMP_CV(true) }
   VAMP_CV(false)
@@ -475,9 +482,9 @@ int vamp_conv3d_half_backward_data(const VampConvDesc* d, int32_t dtype, const v
   hipStream_t s = static_cast<hipStream_t>(stream);
   // the kernel's input tensor is grad_out (cout channels), its output grad_in (cin channels)
 #define VAMP_CV(F16)                                                                                       \
-  if (d->cout == 16) return d->cin == 16 ? launch_fwd<16, 16, true, F16>(d, grad_out, weight, grad_in, s)  \
+  if (tile_ch(d->cout) == 16) return tile_ch(d->cin) == 16 ? launch_fwd<16, 16, true, F16>(d, grad_out, weight, grad_in, s)  \
                                          : launch_fwd<16, 32, true, F16>(d, grad_out, weight, grad_in, s); \
-  return d->cin == 16 ? launch_fwd<32, 16, true, F16>(d, grad_out, weight, grad_in, s)                     \
+  return tile_ch(d->cin) == 16 ? launch_fwd<32, 16, true, F16>(d, grad_out, weight, grad_in, s)                     \
                       : launch_fwd<32, 32, true, F16>(d, grad_out, weight, grad_in, s);
   if (dtype == VAMP_F16) { VAMP_CV(true) }
   VAMP_CV(false)
@@ -495,9 +502,9 @@ int vamp_conv3d_half_backward_weight(const VampConvDesc* d, int32_t dtype, const
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* ws = static_cast<float*>(workspace);
 #define VAMP_CV(F16)                                                                                       \
-  if (d->cin == 16) return d->cout == 16 ? launch_wgrad<16, 16, F16>(d, in, grad_out, grad_weight, ws, s)  \
+  if (tile_ch(d->cin) == 16) return tile_ch(d->cout) == 16 ? launch_wgrad<16, 16, F16>(d, in, grad_out, grad_weight, ws, s)  \
                                          : launch_wgrad<16, 32, F16>(d, in, grad_out, grad_weight, ws, s); \
-  return d->cout == 16 ? launch_wgrad<32, 16, F16>(d, in, grad_out, grad_weight, ws, s)                    \
+  return tile_ch(d->cout) == 16 ? launch_wgrad<32, 16, F16>(d, in, grad_out, grad_weight, ws, s)                    \
                        : launch_wgrad<32, 32, F16>(d, in, grad_out, grad_weight, ws, s);
   if (dtype == VAMP_F16) { VAMP_CV(true) }
   VAMP_CV(false)

@@ -253,8 +253,12 @@ class BEVDepthHead(nn.Module):
                 if tb.shape[1] > 7:
                     row.append(tb[k, 7:9])
                 anno[k] = torch.cat(row)
-            heatmaps.append(heat.to(dev)); anno_boxes.append(anno.to(dev)); inds.append(ind.to(dev)); masks.append(mask.to(dev))
-        return heatmaps, anno_boxes, inds, masks
+            heatmaps.append(heat); anno_boxes.append(anno); inds.append(ind); masks.append(mask)
+        # four uploads per sample instead of four per task (pageable host copies synchronise)
+        ncls = [h.shape[0] for h in heatmaps]
+        heat_d = torch.cat(heatmaps, 0).to(dev)
+        anno_d, ind_d, mask_d = torch.stack(anno_boxes).to(dev), torch.stack(inds).to(dev), torch.stack(masks).to(dev)
+        return list(heat_d.split(ncls, 0)), list(anno_d.unbind(0)), list(ind_d.unbind(0)), list(mask_d.unbind(0))
 
     # ---- loss (bev_depth_head.py:318-375) ----
     def loss(self, targets, preds_dicts, **_):
@@ -263,9 +267,11 @@ class BEVDepthHead(nn.Module):
         for t, pd in enumerate(preds_dicts):
             p = pd[0]
             p["heatmap"] = clip_sigmoid(p["heatmap"])
+            # (the averaging factors stay device tensors: the reference's `.item()` would stall the stream
+            # twice per task)
             num_pos = heatmaps[t].eq(1).float().sum()
             total = total + gaussian_focal_loss(p["heatmap"], heatmaps[t],
-                                                avg_factor=float(torch.clamp(reduce_mean(num_pos), min=1)))
+                                                avg_factor=torch.clamp(reduce_mean(num_pos), min=1))
             keys = ["reg", "height", "dim", "rot"] + (["vel"] if "vel" in p else [])
             p["anno_box"] = torch.cat([p[k] for k in keys], dim=1)
             pred = p["anno_box"].permute(0, 2, 3, 1).reshape(p["anno_box"].shape[0], -1, p["anno_box"].shape[1])
@@ -273,7 +279,7 @@ class BEVDepthHead(nn.Module):
             tgt = anno_boxes[t]
             m = masks[t][..., None].expand_as(tgt).float() * (~torch.isnan(tgt)).float()
             w = m * m.new_tensor(self.train_cfg["code_weights"])
-            num = float(torch.clamp(reduce_mean(masks[t].float().sum()), min=1e-4))
+            num = torch.clamp(reduce_mean(masks[t].float().sum()), min=1e-4)
             total = total + self.loss_bbox_weight * ((pred - torch.nan_to_num(tgt)).abs() * w).sum() / num
         return total
 
@@ -419,13 +425,19 @@ class MultiTaskLoss:
         depths, segs = depths[..., ::s, ::s].contiguous(), segs[..., ::s, ::s].contiguous()
         return imgs, depths, segs, depths > 0
 
-    def __call__(self, outputs, batch):
+    def targets(self, batch):
+        """The detection targets depend on the labels only: made BEFORE the forward is launched, their host
+        round trip (boxes to the CPU, heatmaps back) does not wait for the GPU to drain the forward."""
+        head = self.model.module if hasattr(self.model, "module") else self.model
+        return head.get_targets(batch[4], batch[5])
+
+    def __call__(self, outputs, batch, targets=None):
         (sweep_imgs, mats, _, _, gt_boxes, gt_labels, depth_labels, seg_labels, bev_seg, bev_height, bev_mask,
          inrange_pts, inrange_labels, _, _, _, occ_sem, occ_dens_lab, mask_lidar, mask_camera) = batch
         (preds, rgb_p, seg_p, depth_p, bev_rgb_p, bev_seg_p, bev_h_p, bev_density, pts_logits, pts_sdf,
          occ_logits, occ_density) = outputs
         head = self.model.module if hasattr(self.model, "module") else self.model
-        det = head.loss(head.get_targets(gt_boxes, gt_labels), preds)
+        det = head.loss(head.get_targets(gt_boxes, gt_labels) if targets is None else targets, preds)
         if depth_labels.dim() == 5:                      # only the key frame carries camera labels
             sweep_imgs, depth_labels, seg_labels = sweep_imgs[:, 0], depth_labels[:, 0], seg_labels[:, 0]
         depth_p = depth_p[:, :, 0]
@@ -556,9 +568,10 @@ def multitask_step(model, loss_fn, batch, optimizer=None, amp_dtype=torch.bfloat
     """One end-to-end training step of BASELINE configs[4]: forward under autocast (the reference trains
     with `precision=16`, base_cli.py:77), the nine losses, backward, optional optimizer step."""
     dev = batch[0].device
+    tg = loss_fn.targets(batch) if hasattr(loss_fn, "targets") else None
     with torch.autocast(device_type=dev.type, dtype=amp_dtype, enabled=amp_dtype is not None and dev.type == "cuda"):
         out = model(batch[0], batch[1], inrange_pts=batch[11], lidar_seg=False)
-        loss = loss_fn(out, batch)
+        loss = loss_fn(out, batch, tg) if tg is not None else loss_fn(out, batch)
     if optimizer is not None:
         optimizer.zero_grad(set_to_none=True)
     loss.backward()
