@@ -593,7 +593,7 @@ int vamp_conv3d_backward_weight(const VampConvDesc* d, const float* in, const fl
  * The same layers under the reference's `precision=16` (base_cli.py:77; autocast hands the layers of
  * base_vampire2.py:20, 40-60 bf16 activations and weights): bf16 NCDHW in, fp32 accumulate on the bf16
  * matrix cores (v_mfma_f32_16x16x32_bf16), bf16 NCDHW out; weight [cout, cin, 3, 3, 3] bf16; 1 <= cin, cout
- * <= 32, Y % 4 == 0, X % 4 == 0 (vamp_conv3d_bf16_supported).  grad_weight is fp32 [cout, cin, 3, 3, 3].
+ * <= 32, X % 4 == 0 (vamp_conv3d_bf16_supported).  grad_weight is fp32 [cout, cin, 3, 3, 3].
  */
 int vamp_conv3d_bf16_supported(const VampConvDesc* d);
 int vamp_conv3d_bf16_forward(const VampConvDesc* d, const void* in, const void* weight, void* out, void* stream);

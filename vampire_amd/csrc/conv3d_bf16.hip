@@ -116,8 +116,8 @@ conv3d_bf16_fwd_kernel(CvP P, const unsigned short* __restrict__ in, const unsig
   auto fetch = [&](long tile) {
     const int tx = (int) (tile % tiles_x);
     long r = tile / tiles_x;
-    const int ty = (int) (r % (P.Y / kTY));
-    r /= (P.Y / kTY);
+    const int ty = (int) (r % ((P.Y + kTY - 1) / kTY));
+    r /= ((P.Y + kTY - 1) / kTY);
     const int z = (int) (r % P.Z), b = (int) (r / P.Z);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned short*>(in + (long) b * P.cin * plane), 0, (int) ((size_t) P.cin * plane * 2), 0x00020000);   // planes >= cin read 0
@@ -161,8 +161,8 @@ conv3d_bf16_fwd_kernel(CvP P, const unsigned short* __restrict__ in, const unsig
 
     const int tx = (int) (tile % tiles_x);
     long r = tile / tiles_x;
-    const int ty = (int) (r % (P.Y / kTY));
-    r /= (P.Y / kTY);
+    const int ty = (int) (r % ((P.Y + kTY - 1) / kTY));
+    r /= ((P.Y + kTY - 1) / kTY);
     const int z = (int) (r % P.Z), b = (int) (r / P.Z);
     const int y = ty * kTY + wv, x0 = tx * kTX;
     const int nnt = min(4, (P.X - x0 + 15) / 16);       // N tiles of this wave inside the volume (uniform)
@@ -406,7 +406,7 @@ int tile_ch(int c) { return c <= 16 ? 16 : 32; }       // channel tile a real ch
 
 bool bf16_shape_ok(const VampConvDesc* d) {
   return d && d->cin >= 1 && d->cin <= 32 && d->cout >= 1 && d->cout <= 32 && d->B > 0 && d->Z > 0 &&
-         d->Y > 0 && d->X >= 8 && d->Y % kTY == 0 && d->X % 4 == 0 &&
+         d->Y > 0 && d->X >= 8 && d->X % 4 == 0 &&
          (long) d->Z * d->Y * d->X * 32 * 2 < 0x7fffffffL;
 }
 
@@ -418,7 +418,7 @@ int launch_fwd(const VampConvDesc* d, const void* in, const void* w, void* out, 
     return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);
   const CvP P{d->B, d->Z, d->Y, d->X, FLIP ? d->cout : d->cin, FLIP ? d->cin : d->cout};
   const int tiles_x = (d->X + kTX - 1) / kTX;
-  const long ntiles = (long) d->B * d->Z * (d->Y / kTY) * tiles_x;
+  const long ntiles = (long) d->B * d->Z * ((d->Y + kTY - 1) / kTY) * tiles_x;
   const int per_cu = L::bytes <= 78 * 1024 ? 2 : 1;
   const unsigned grid = (unsigned) std::min<long>(ntiles, 256 * per_cu);
   VAMP_TIMED(FLIP ? kProfConvDgrad : kProfConvFwd, s, (k<<<grid, 256, L::bytes, s>>>(
