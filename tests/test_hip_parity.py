@@ -1609,3 +1609,43 @@ def test_resize_16bit(dev, dt):
     y.backward(go); yr.backward(go.double())
     assert a.grad.dtype == dt
     close(a.grad, b.grad, atol=1e-2, rtol=4 * rel, what="resize 16-bit backward")
+
+
+def test_round3_entry_points_reject_bad_arguments(dev):
+    """Error behaviour of the round-3 entry points: a bad descriptor / dtype / workspace comes back as a negative
+    code with a message (no launch, no crash); the Python host raises VampireHipError."""
+    import ctypes as C
+    from vampire_amd import _capi
+    from vampire_amd.ops import HotPath, voxel_pooling, conv3d_bf16
+    lib = _capi.load()
+    hp = HotPath(CFG_TINY, dev)
+    x = torch.zeros(64, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    # gate + conv: unsupported channel counts, NULL tensors, missing workspace
+    assert lib.vamp_gate_conv1x1_supported(34, 10, 80) == 0 and lib.vamp_gate_conv1x1_supported(16, 10, 80) == 1
+    assert lib.vamp_gate_conv1x1_forward(1, 34, 10, 16, 80, _capi.VAMP_DENSITY_SDF_LAPLACE, p(x), p(x), p(x), None, p(x), None) < 0
+    assert b"not supported" in lib.vamp_last_error()
+    assert lib.vamp_gate_conv1x1_forward(1, 4, 2, 16, 8, 7, p(x), p(x), p(x), None, p(x), None) < 0          # density_mode
+    assert lib.vamp_gate_conv1x1_backward(1, 4, 2, 16, 8, _capi.VAMP_DENSITY_SIGMOID, p(x), p(x), p(x), p(x), p(x), p(x), p(x),
+                                          None, None, 0, None) < 0                                             # no workspace
+    # 16-bit conv: dtype must be bf16 or fp16; shape outside the tiles
+    d = _capi.VampConvDesc()
+    d.B, d.cin, d.cout, d.Z, d.Y, d.X = 1, 16, 16, 2, 4, 8
+    assert lib.vamp_conv3d_half_forward(C.byref(d), _capi.VAMP_F32, p(x), p(x), p(x), None) < 0
+    d.cin = 40
+    assert lib.vamp_conv3d_bf16_supported(C.byref(d)) == 0 and lib.vamp_conv3d_bf16_forward(C.byref(d), p(x), p(x), p(x), None) < 0
+    with pytest.raises(TypeError):
+        conv3d_bf16(torch.zeros(1, 16, 2, 4, 8, device=dev), torch.zeros(16, 16, 3, 3, 3, device=dev))            # fp32 tensors
+    # logits lift: the features must be fp32
+    ld = hp.lift_desc(1, 6, 4, _capi.VAMP_BF16)
+    assert lib.vamp_lift_forward_logits(C.byref(ld), p(x), p(x), p(x), p(x), p(x), _capi.VAMP_F32, p(x), p(x), p(x), None,
+                                        p(x), 64, None) < 0
+    # voxel pooling: empty grid, CPU tensors
+    pd = _capi.VampPoolDesc(1, 4, 16, 0, 4, 1, _capi.VAMP_F32)
+    assert lib.vamp_voxel_pooling_workspace_bytes(C.byref(pd)) == 0
+    assert lib.vamp_voxel_pooling_forward(C.byref(pd), p(x), p(x), p(x), p(x), 64, None) < 0
+    with pytest.raises(_capi.VampireHipError):
+        voxel_pooling(torch.zeros(1, 1, 1, 2, 2, 3, dtype=torch.int32), torch.zeros(1, 1, 1, 2, 2, 4), (4, 4, 1))
+    # the library is still usable afterwards
+    out = voxel_pooling(torch.zeros(1, 1, 1, 2, 2, 3, dtype=torch.int32, device=dev), torch.ones(1, 1, 1, 2, 2, 4, device=dev), (4, 4, 1))
+    assert float(out[0, :, 0, 0].sum()) == 16.0
