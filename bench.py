@@ -615,7 +615,13 @@ def main():
                          "traffic": measured_traffic(a.cfg, dom, a.batch, list(kern)),
                          "algorithmic_bytes_per_launch": dom_alg_launch,
                          "launches_per_step": kern[dom]["launches_per_step"],
-                         "avg_launch_us": kern[dom]["avg_us"]},
+                         "avg_launch_us": kern[dom]["avg_us"],
+                         # the same figure for every kernel that has compulsory bytes of its own (the kernel the
+                         # round-2 review named, lift_bwd_fill, is in here)
+                         "per_kernel": {k: {"avg_launch_us": round(kern[k]["avg_us"], 2),
+                                            "frac": round(alg[k] / kern[k]["launches_per_step"] / (kern[k]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                            "traffic": measured_traffic(a.cfg, k, a.batch, list(kern))}
+                                        for k in sorted(kern) if k in alg and kern[k]["avg_us"] > 0}},
             "fwd_roofline": {"bound": "hbm", "achieved": fwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": fwd_gbs / HBM_PEAK_GBS, "fused_fwd_us": fwd_us,
                              "p10_us": fwd_graph[1] if fwd_graph else fwd_p10, "p90_us": fwd_graph[2] if fwd_graph else fwd_p90,
