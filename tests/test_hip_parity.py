@@ -1425,7 +1425,7 @@ def test_camera_direct_forward_tiny(tiny_common, dev, mode, cat_seg):
     for ert in (True, False):
         hp = hot(cfg, dev)
         hp.impl["ert"] = ert
-        assert hp.impl["cam_direct"]
+        hp.impl["cam_direct"] = True          # (the default; explicit so that VAMP_CAM_DIRECT=0 runs of the suite still test this kernel)
         with torch.no_grad():
             outs = hp.render(*vols, beta, render_mats=rm)
         for nm, o in zip(NAMES, outs):
