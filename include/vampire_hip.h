@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VAMP_ABI_VERSION 3   /* bumped whenever entry points or flags are added (round 2: 2, round 3: 3) */
+#define VAMP_ABI_VERSION 4   /* bumped whenever entry points or flags are added (round 2: 2, round 3: 3, round 4: 4) */
 
 enum {
   VAMP_OK = 0,
@@ -93,6 +93,20 @@ int vamp_lift_forward(const VampLiftDesc* d, const float* mats, const float* xs,
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * flags = VAMP_LIFTFWD_EMIT_PAIRS (a backward will follow): the forward kernel -- which projects every
+ * voxel into every camera anyway -- also does the counting half of the backward's pixel sort and leaves
+ * every valid (voxel, camera) pair's taps in `workspace`.  Afterwards the workspace is in the state
+ * vamp_lift_prepare leaves (VAMP_LIFTBWD_CELLS_VALID), and no kernel of the backward projects a voxel
+ * again (the backward's prepare pass and half of its fill pass were that projection).  flags == 0 is
+ * vamp_lift_forward.
+ */
+#define VAMP_LIFTFWD_EMIT_PAIRS 1
+int vamp_lift_forward_ex(const VampLiftDesc* d, const float* mats, const float* xs,
+                         const float* ys, const float* zs, const void* depth,
+                         const void* feat, float* out, uint64_t* hits,
+                         void* workspace, size_t workspace_bytes, int flags, void* stream);
+
+/*
  * Producer fusion (bv2:550 `mapping_along_depth(src).softmax(dim=1)` feeding bv2:553):
  * `logits` [B, N, D, fH, fW] (logits_dtype VAMP_F32 | VAMP_BF16) are the raw depth logits.  ONE launch
  * makes both lift operands -- the softmax over D into `depth_out` (fp32 [B, N, D, fH, fW]; keep it for
@@ -104,6 +118,12 @@ int vamp_lift_forward_logits(const VampLiftDesc* d, const float* mats, const flo
                              const float* ys, const float* zs, const void* logits,
                              int32_t logits_dtype, const float* feat, float* depth_out, float* out,
                              uint64_t* hits, void* workspace, size_t workspace_bytes, void* stream);
+/* the same with the flags of vamp_lift_forward_ex */
+int vamp_lift_forward_logits_ex(const VampLiftDesc* d, const float* mats, const float* xs,
+                                const float* ys, const float* zs, const void* logits,
+                                int32_t logits_dtype, const float* feat, float* depth_out, float* out,
+                                uint64_t* hits, void* workspace, size_t workspace_bytes, int flags,
+                                void* stream);
 
 /*
  * Backward of vamp_lift_forward w.r.t. depth and feat (autograd of bv2:507-514,
@@ -118,15 +138,17 @@ int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs
 
 /*
  * The backward first sorts the valid (voxel, camera) pairs by feature-map pixel; the counting
- * half of that depends on the geometry only.  vamp_lift_prepare runs it ahead of time into
- * `workspace` (e.g. on a second stream beside vamp_lift_forward, which leaves that part of the
- * workspace alone), and vamp_lift_backward_ex with VAMP_LIFTBWD_CELLS_VALID then skips it: the
- * caller asserts that `workspace` is the same buffer, d / mats / xs / ys / zs are unchanged and
- * no other lift backward has run on it since.  flags == 0 is vamp_lift_backward.
+ * half of that depends on the geometry only.  A forward with VAMP_LIFTFWD_EMIT_PAIRS has done it;
+ * vamp_lift_prepare does it alone (a projection-only kernel) into `workspace`; and
+ * vamp_lift_backward_ex with VAMP_LIFTBWD_CELLS_VALID then skips it: the caller asserts that
+ * `workspace` is the same buffer, d / mats / xs / ys / zs are unchanged and no other lift
+ * backward has run on it since.  flags == 0 is vamp_lift_backward.
  */
 #define VAMP_LIFTBWD_CELLS_VALID 1
 /* implementation selectors (tests cross-check them; 0 = the default cell-list gather):
-   SPLAT = the per-voxel float-atomic splat; WPP1 / WPP4 / WPP16 force the gather's waves per pixel */
+   SPLAT = the per-voxel float-atomic splat; WPP4 / WPP16 (names from round 3's wave-per-pixel gather) make
+   the strip gather stage its pairs in chunks of 64 / 32 instead of 256, so that small inputs cross chunk
+   boundaries too; WPP1 = default */
 #define VAMP_LIFTBWD_SPLAT 2
 #define VAMP_LIFTBWD_WPP1 4
 #define VAMP_LIFTBWD_WPP4 8

@@ -9,7 +9,7 @@ import os
 
 from .build import lib_path
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 VAMP_F32, VAMP_BF16, VAMP_F16 = 0, 1, 2
 VAMP_DENSITY_SIGMOID, VAMP_DENSITY_SDF_LAPLACE = 0, 1
@@ -58,6 +58,7 @@ class VampSampleDesc(C.Structure):
 
 VAMP_PAD_ZEROS, VAMP_PAD_BORDER = 0, 1
 # flag bits of vamp_lift_backward_ex / vamp_render_camera_backward_acc (include/vampire_hip.h)
+VAMP_LIFTFWD_EMIT_PAIRS = 1
 VAMP_LIFTBWD_CELLS_VALID, VAMP_LIFTBWD_SPLAT = 1, 2
 VAMP_LIFTBWD_WPP1, VAMP_LIFTBWD_WPP4, VAMP_LIFTBWD_WPP16 = 4, 8, 16
 VAMP_LIFTBWD_HALF_LO, VAMP_LIFTBWD_HALF_HI = 64, 128
@@ -91,6 +92,8 @@ SIGNATURES = {
     "vamp_lift_workspace_bytes": (C.c_size_t, [_LD]),
     "vamp_lift_forward": (C.c_int, [_LD] + [_P] * 8 + [_P, C.c_size_t, _P]),
     "vamp_lift_forward_logits": (C.c_int, [_LD] + [_P] * 5 + [C.c_int32] + [_P] * 4 + [_P, C.c_size_t, _P]),
+    "vamp_lift_forward_ex": (C.c_int, [_LD] + [_P] * 8 + [_P, C.c_size_t, C.c_int, _P]),
+    "vamp_lift_forward_logits_ex": (C.c_int, [_LD] + [_P] * 5 + [C.c_int32] + [_P] * 4 + [_P, C.c_size_t, C.c_int, _P]),
     "vamp_lift_backward": (C.c_int, [_LD] + [_P] * 10 + [_P, C.c_size_t, _P]),
     "vamp_lift_backward_ex": (C.c_int, [_LD] + [_P] * 10 + [_P, C.c_size_t, C.c_int, _P]),
     "vamp_lift_prepare": (C.c_int, [_LD] + [_P] * 4 + [_P, C.c_size_t, _P]),

@@ -123,12 +123,15 @@ __device__ __forceinline__ void depth_taps(const LiftParams& P, const T* __restr
 // ---------------------------------------------------------------------------
 // LIFT forward.  Block = TX*TY*TZ (= 256) voxels; CH channels per pass.
 // ---------------------------------------------------------------------------
-template <typename T, int CH, int TX, int TY, int TZ>
+// EMIT (a backward will follow): the kernel also does the counting half of the backward's pixel
+// sort -- every valid (voxel, camera) pair is counted in its cell and its taps are left in the
+// workspace (lift_emit_pair), so nothing on the backward projects a voxel again.
+template <typename T, int CH, int TX, int TY, int TZ, bool EMIT>
 __global__ void __launch_bounds__(TX* TY* TZ)
 lift_fwd_kernel(LiftParams P, const float* __restrict__ mats, const float* __restrict__ xs,
                 const float* __restrict__ ys, const float* __restrict__ zs,
                 const T* __restrict__ depth, const float* __restrict__ feat_cl,
-                float* __restrict__ out, uint64_t* __restrict__ hits) {
+                float* __restrict__ out, uint64_t* __restrict__ hits, LiftEmit E) {
   const int tid = threadIdx.x;
   const int x = blockIdx.x * TX + (tid % TX);
   const int y = blockIdx.y * TY + ((tid / TX) % TY);
@@ -143,6 +146,7 @@ lift_fwd_kernel(LiftParams P, const float* __restrict__ mats, const float* __res
   const long HW = (long) P.fH * P.fW;
   const int nchunk = P.C / CH;
 
+  unsigned wmask = 0;
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     float sum[CH];
     uint64_t cnt = 0;
@@ -152,6 +156,8 @@ lift_fwd_kernel(LiftParams P, const float* __restrict__ mats, const float* __res
     for (int n = 0; n < P.N; ++n) {
       const long bn = (long) b * P.N + n;
       const LiftTap t = lift_project<true>(P, mats + bn * 48, vx, vy, vz);
+      if (EMIT && chunk == 0)        // (wave-uniform here: the lanes part ways at the next line)
+        if (lift_emit_pair(P, E, t, true, bn, V, vox, tid & 63)) wmask |= 1u << (n & 31);
       if (!t.valid) continue;
       float dep[4];
       depth_taps<T>(P, depth + bn * P.D * HW, t, dep);
@@ -190,6 +196,30 @@ lift_fwd_kernel(LiftParams P, const float* __restrict__ mats, const float* __res
     }
     if (hits) hits[((long) b * V + vox) * nchunk + chunk] = cnt;
   }
+  if (EMIT && E.amask) E.amask[(long) b * V + vox] = wmask;
+}
+
+// The same walk without the samples: counts and emits the pairs for a backward whose forward did
+// not (vamp_lift_prepare; vamp_lift_backward without VAMP_LIFTBWD_CELLS_VALID).
+template <int TX, int TY>
+__global__ void __launch_bounds__(TX* TY)
+lift_pairs_kernel(LiftParams P, const float* __restrict__ mats, const float* __restrict__ xs,
+                  const float* __restrict__ ys, const float* __restrict__ zs, LiftEmit E) {
+  const int tid = threadIdx.x;
+  const int x = blockIdx.x * TX + (tid % TX);
+  const int y = blockIdx.y * TY + (tid / TX);
+  const int b = blockIdx.z / P.Z, z = blockIdx.z % P.Z;
+  if (x >= P.X || y >= P.Y) return;
+  const float vx = xs[x], vy = ys[y], vz = zs[z];
+  const long V = (long) P.Z * P.Y * P.X;
+  const long vox = ((long) z * P.Y + y) * P.X + x;
+  unsigned wmask = 0;
+  for (int n = 0; n < P.N; ++n) {
+    const long bn = (long) b * P.N + n;
+    const LiftTap t = lift_project<true>(P, mats + bn * 48, vx, vy, vz);
+    if (lift_emit_pair(P, E, t, true, bn, V, vox, tid & 63)) wmask |= 1u << (n & 31);
+  }
+  if (E.amask) E.amask[(long) b * V + vox] = wmask;
 }
 
 // ---------------------------------------------------------------------------
@@ -435,20 +465,44 @@ static LiftWs carve(const VampLiftDesc* d, void* ws) {
 #endif
 #define VAMP_LIFT_TILE VAMP_LIFT_TX, VAMP_LIFT_TY, 1
 
+// `cells` != nullptr: the kernel emits the backward's pairs into that part of the workspace, between
+// the zero fill of the cell counters and their scan (afterwards the workspace is what
+// vamp_lift_prepare leaves: VAMP_LIFTBWD_CELLS_VALID)
 template <typename T>
 static int lift_forward_t(const VampLiftDesc* d, const LiftParams& P, const float* mats,
                           const float* xs, const float* ys, const float* zs, const void* depth,
-                          const float* feat_cl, float* out, uint64_t* hits, hipStream_t s) {
+                          const float* feat_cl, float* out, uint64_t* hits, void* cells, hipStream_t s) {
   constexpr int TX = VAMP_LIFT_TX, TY = VAMP_LIFT_TY, TZ = 1;
   dim3 grid((P.X + TX - 1) / TX, (P.Y + TY - 1) / TY, ((P.Z + TZ - 1) / TZ) * P.B);
   const T* dp = static_cast<const T*>(depth);
-  if (P.C == 4)
-    VAMP_TIMED(kProfLiftFwd, s, (lift_fwd_kernel<T, 4, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, out, hits)));
-  else if (P.C == 8)
-    VAMP_TIMED(kProfLiftFwd, s, (lift_fwd_kernel<T, 8, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, out, hits)));
-  else
-    VAMP_TIMED(kProfLiftFwd, s, (lift_fwd_kernel<T, 16, VAMP_LIFT_TILE><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, out, hits)));
-  return check_launch("lift_fwd_kernel");
+  LiftEmit E{};
+  if (cells) {
+    VAMP_REQUIRE(d->N <= 15, "at most 15 cameras");
+    if (int e = launch_lift_cells_begin(d, cells, s)) return e;
+    E = lift_emit_of(d, cells);
+  }
+#define VAMP_FWD(CH, EM)                                                                               \
+  VAMP_TIMED(kProfLiftFwd, s, (lift_fwd_kernel<T, CH, VAMP_LIFT_TILE, EM><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, out, hits, E)))
+  if (cells) {
+    if (P.C == 4) VAMP_FWD(4, true); else if (P.C == 8) VAMP_FWD(8, true); else VAMP_FWD(16, true);
+  } else {
+    if (P.C == 4) VAMP_FWD(4, false); else if (P.C == 8) VAMP_FWD(8, false); else VAMP_FWD(16, false);
+  }
+#undef VAMP_FWD
+  if (int e = check_launch("lift_fwd_kernel")) return e;
+  return cells ? launch_lift_cells_end(d, cells, s) : VAMP_OK;
+}
+
+int launch_lift_cell_prepare(const VampLiftDesc* d, const float* mats, const float* xs,
+                             const float* ys, const float* zs, void* scratch, hipStream_t s) {
+  const LiftParams P = to_params(d);
+  if (int e = launch_lift_cells_begin(d, scratch, s)) return e;
+  const LiftEmit E = lift_emit_of(d, scratch);
+  constexpr int TX = VAMP_LIFT_TX, TY = VAMP_LIFT_TY;
+  dim3 grid((P.X + TX - 1) / TX, (P.Y + TY - 1) / TY, P.Z * P.B);
+  VAMP_TIMED(kProfLiftBwdCount, s, (lift_pairs_kernel<TX, TY><<<grid, TX * TY, 0, s>>>(P, mats, xs, ys, zs, E)));
+  if (int e = check_launch("lift_pairs_kernel")) return e;
+  return launch_lift_cells_end(d, scratch, s);
 }
 
 template <typename T>
@@ -482,6 +536,12 @@ size_t vamp_lift_workspace_bytes(const VampLiftDesc* d) {
 int vamp_lift_forward(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                       const float* zs, const void* depth, const void* feat, float* out,
                       uint64_t* hits, void* workspace, size_t workspace_bytes, void* stream) {
+  return vamp_lift_forward_ex(d, mats, xs, ys, zs, depth, feat, out, hits, workspace, workspace_bytes, 0, stream);
+}
+
+int vamp_lift_forward_ex(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
+                         const float* zs, const void* depth, const void* feat, float* out,
+                         uint64_t* hits, void* workspace, size_t workspace_bytes, int flags, void* stream) {
   if (int e = validate(d)) return e;
   VAMP_REQUIRE(mats && xs && ys && zs && feat && out, "null pointer");
   VAMP_REQUIRE(depth || !d->use_depth, "depth is NULL");
@@ -495,15 +555,24 @@ int vamp_lift_forward(const VampLiftDesc* d, const float* mats, const float* xs,
   if (d->in_dtype == VAMP_F32) launch_to_cl<float>(feat, w.feat_cl, BN, d->C, HW, s);
   else launch_to_cl<__hip_bfloat16>(feat, w.feat_cl, BN, d->C, HW, s);
   if (int e = check_launch("feat_to_channel_last")) return e;
+  void* cells = (flags & VAMP_LIFTFWD_EMIT_PAIRS) ? w.cells : nullptr;
   if (d->in_dtype == VAMP_F32)
-    return lift_forward_t<float>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, s);
-  return lift_forward_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, s);
+    return lift_forward_t<float>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, cells, s);
+  return lift_forward_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, cells, s);
 }
 
 int vamp_lift_forward_logits(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                              const float* zs, const void* logits, int32_t logits_dtype, const float* feat,
                              float* depth_out, float* out, uint64_t* hits, void* workspace,
                              size_t workspace_bytes, void* stream) {
+  return vamp_lift_forward_logits_ex(d, mats, xs, ys, zs, logits, logits_dtype, feat, depth_out, out, hits,
+                                     workspace, workspace_bytes, 0, stream);
+}
+
+int vamp_lift_forward_logits_ex(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
+                                const float* zs, const void* logits, int32_t logits_dtype, const float* feat,
+                                float* depth_out, float* out, uint64_t* hits, void* workspace,
+                                size_t workspace_bytes, int flags, void* stream) {
   if (int e = validate(d)) return e;
   VAMP_REQUIRE(mats && xs && ys && zs && logits && feat && depth_out && out, "null pointer");
   VAMP_REQUIRE(d->use_depth == 1, "the logits entry is the depth-distribution lift");
@@ -533,7 +602,8 @@ int vamp_lift_forward_logits(const VampLiftDesc* d, const float* mats, const flo
   }
 #undef VAMP_OPERANDS
   if (int e = check_launch("lift_operands_kernel")) return e;
-  return lift_forward_t<float>(d, P, mats, xs, ys, zs, depth_out, w.feat_cl, out, hits, s);
+  return lift_forward_t<float>(d, P, mats, xs, ys, zs, depth_out, w.feat_cl, out, hits,
+                               (flags & VAMP_LIFTFWD_EMIT_PAIRS) ? w.cells : nullptr, s);
 }
 
 int vamp_lift_prepare(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
@@ -572,6 +642,8 @@ int vamp_lift_backward_ex(const VampLiftDesc* d, const float* mats, const float*
   // default: cell list + one wave per pixel (lift_bwd_cell.hip), no float atomics.
   // VAMP_LIFTBWD_SPLAT selects the per-voxel atomic splat below, kept as an independent cross-check.
   if (!(flags & VAMP_LIFTBWD_SPLAT)) {
+    // gather variants (same kernel, smaller record chunks: the tests run them to cross the chunk
+    // boundaries at every size)
     const int wpp = (flags & VAMP_LIFTBWD_WPP1) ? 1 : (flags & VAMP_LIFTBWD_WPP4) ? 4
                     : (flags & VAMP_LIFTBWD_WPP16) ? 16 : 0;
     // VAMP_LIFTBWD_HALF_LO / _HI: one half of the images (needs prepared cell lists: both halves

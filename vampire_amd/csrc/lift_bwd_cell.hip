@@ -1,96 +1,90 @@
 // LIFT backward as a cell list ("sort, then own").  Autograd of base_vampire2.py:507-514
 // (grid_sampler_3d backward + the camera mean):
 //
-//   count   thread per voxel, forward's bit-exact projection: every valid (voxel, camera) pair
-//           increments the counter of its cell = (camera, floor tap row + 1, floor tap column + 1),
-//           (fH + 1) x (fW + 1) cells per camera
-//   scan    two-level exclusive prefix sum of the counters -> cell start offsets (runtime.hip)
-//   fill    same walk: the voxel's row grad_out / (hits + 1e-6) goes into a channel-last table
-//           [B V, C] (consecutive lanes = consecutive 64-byte rows: streaming stores), and every
-//           valid pair puts its voxel index and {wx1, wy1, wz1, iz0} -- 20 bytes -- into the next slot
-//           of its cell (slots handed out by atomics on the cell cursor)
-//   gather  one wave (or 4, or 16) per feature-map pixel: the pairs whose 2x2 pixel taps include
-//           pixel (x, y) are exactly those of the cells (x..x+1, y..y+1), two contiguous ranges of
-//           pairs.  Lane = pair: it reads the pair's 20 bytes, the voxel's 64-byte row of the table
-//           and the two depth bins of the pixel's own column (staged in LDS); grad_feat partial
-//           sums in registers (folded over the lanes at the end), the channel dot product feeds the
-//           two depth bins of the pixel's private LDS column.  Every output element is stored once.
+//   count   done by the FORWARD kernel in grad mode (lift.hip, lift_emit_pair; lift_pairs_kernel for a
+//           backward whose forward did not): every valid (voxel, camera) pair increments the counter of
+//           its cell = (camera, floor tap row + 1, floor tap column + 1), (fH + 1) x (fW + 1) cells per
+//           camera, and leaves its taps {wx1, wy1, wz1, iz0} at (image, voxel)
+//   scan    exclusive prefix sum of the counters -> cell start offsets (runtime.hip)
+//   fill    thread per voxel, NO projection: the voxel's row grad_out / (hits + 1e-6) goes into a
+//           channel-last table [B V, C] (consecutive lanes = consecutive 64-byte rows), and every pair of
+//           the voxel (camera mask + taps from the forward) moves its voxel index and taps -- 20 bytes --
+//           to the next slot of its cell (slots handed out by atomics on the cell cursor)
+//   gather  one workgroup per STRIP of 16 consecutive pixels of a feature-map row.  The pairs that touch
+//           the strip are those of the cell rows iy, iy + 1, columns x0 .. x0 + 16: two contiguous ranges
+//           of the cell-ordered list.  The workgroup stages them in LDS lane = pair (ids -> table row:
+//           every load of a chunk is in flight at once), then consumes them lane = (pixel, channel
+//           quad): a pixel's pairs are one contiguous sub-range (its two cells are adjacent), the four
+//           waves take every fourth pair of it, the channel dot product is a 4-lane DPP sum, the depth
+//           terms go to the wave's own LDS tile with plain read-add-write (a pixel's column belongs to
+//           one lane pair).  No atomics of any kind, no cross-lane folds; depth planes enter and leave
+//           as 64-byte runs.
 //
-// (Until round 3 the fill wrote a 112-byte record per pair -- tap weights, depth-interpolated values
-// and a copy of the voxel's row -- scattered in cell order as 16-byte pieces: 122 MB of HBM writes
-// for 71 MB of records, and the pass was half of the lift backward.  A pair is now 20 bytes: the
-// depth-interpolated values come from the consuming pixel's own depth column, the lower-tap weights
-// are 1 - w1, and the voxel's row is shared by the pairs of a voxel.  Recomputing the projection in
-// the gather instead (4-byte pairs) was measured too: fill 40 us, gather 120 -- every pair is visited
-// by four pixels, and the chain with its coordinate loads sits behind the index load.)
+// (Round 3 ran one WAVE per pixel with lane = pair: 67 584 waves at cfg-B of which half held fewer
+// than ten pairs, each paying the column staging, the range loads, a 64-lane fold of 16 channels and
+// 16-byte pieces of 86 depth planes -- 5.85 M L2 requests and 92 us for 2.4 M pair visits; every pair
+// was read by four pixels.  A strip reads a pair 2.1 times and has 16x fewer, 16x fuller units of work.)
 //
-// Both atomic passes aggregate runs of equal cells across the lanes of a wave (x-neighbouring
-// voxels share a cell in the far field), one atomic per run: device-scope atomics are served at
-// the memory side on this part and cost ~1 us each.
 // No float atomics on global memory, no memset of the outputs, no layout transposes.
 #include "lift_common.hpp"
-#include "cell_list.hpp"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace vamp {
 
-constexpr int LGL = 16;              // lanes per record = channel lanes
-constexpr int kMinWaves = 4;         // waves per gather workgroup (more when a pixel takes more)
-
-struct LiftCells {
-  int cw, ch;                        // cells per row / column of one camera
-  long ncell;                        // padded to the scan tile, + 2 for the range ends
-};
-
-static LiftCells lift_cells(const VampLiftDesc* d) {
-  LiftCells g;
-  g.cw = d->fW + 1;
-  g.ch = d->fH + 1;
-  const long nc = (long) d->B * d->N * g.cw * g.ch + 2;
-  g.ncell = (nc + kScanTile - 1) / kScanTile * kScanTile;
-  return g;
-}
-
 // ---------------------------------------------------------------------------
-// count / fill: thread per voxel, the 64 lanes of a wave are 64 x-consecutive voxels
+// fill: thread per voxel, the 64 lanes of a wave are 64 x-consecutive voxels
 // ---------------------------------------------------------------------------
-template <typename T, int CH, bool FILL>
+template <int CH>
 __global__ void __launch_bounds__(256)
-lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mats,
-                     const float* __restrict__ xs, const float* __restrict__ ys,
-                     const float* __restrict__ zs, const T* __restrict__ depth,
-                     const float* __restrict__ gout, const uint64_t* __restrict__ hits,
-                     int* __restrict__ cnt, const int* __restrict__ off,
-                     const int* __restrict__ boff, int* __restrict__ ids, float4* __restrict__ recs,
-                     float4* __restrict__ table, unsigned* __restrict__ amask, int bn_lo, int bn_hi) {
+lift_bwd_fill_kernel(LiftParams P, int cw, int ch, const float* __restrict__ gout,
+                     const uint64_t* __restrict__ hits, const unsigned* __restrict__ amask,
+                     const float4* __restrict__ ptaps, const int* __restrict__ pcell,
+                     int* __restrict__ cnt, const int* __restrict__ off, const int* __restrict__ boff,
+                     int* __restrict__ ids, float4* __restrict__ recs, float4* __restrict__ table,
+                     int* __restrict__ rowq, int bn_lo, int bn_hi) {
   const int tid = threadIdx.x, lane = tid & 63;
+  // A duty of the first workgroup, beside its voxels: the order in which the gather takes the image
+  // rows -- those with the most pairs first (counting sort by the bit length of a row's pair count), so
+  // that its long-running workgroups start early and the light ones fill the tail.
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    __shared__ int cls[34];
+    if (tid < 34) cls[tid] = 0;
+    __syncthreads();
+    const int nrow = (bn_hi - bn_lo) * P.fH;
+    auto row_class = [&](int r) {
+      const long c0 = ((long) bn_lo * ch + (long) (r / P.fH) * ch + r % P.fH) * cw, c1 = c0 + 2 * cw;
+      const int w = (off[c1] + boff[c1 / kScanTile]) - (off[c0] + boff[c0 / kScanTile]);
+      return 32 - __clz(max(w, 0));                  // 0 .. 32, heavy rows get high classes
+    };
+    for (int r = tid; r < nrow; r += 256) atomicAdd(cls + row_class(r), 1);
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0;
+      for (int k = 32; k >= 0; --k) { const int n = cls[k]; cls[k] = run; run += n; }
+    }
+    __syncthreads();
+    for (int r = tid; r < nrow; r += 256) rowq[(long) bn_lo * P.fH + atomicAdd(cls + row_class(r), 1)] = bn_lo * P.fH + r;
+  }
   const int x = blockIdx.x * 64 + lane;
   const int y = blockIdx.y * 4 + (tid >> 6);
   const int z = blockIdx.z % P.Z, b = blockIdx.z / P.Z;
   const bool live = x < P.X && y < P.Y;
   const int xc = min(x, P.X - 1), yc = min(y, P.Y - 1);
-  const float vx = xs[xc], vy = ys[yc], vz = zs[z];
   const long V = (long) P.Z * P.Y * P.X;
   const long vox = ((long) z * P.Y + yc) * P.X + xc;
-  const long HW = (long) P.fH * P.fW;
 
-  // camera mask of the voxel: written by the count pass, read by the fill pass, which then
-  // projects only the cameras some lane of the wave is valid for (1-3 of 6) instead of all -- and
-  // leaves at once when no voxel of the wave is seen by any camera (the half-split's images)
-  unsigned vmask = 0xffffffffu, wmask = 0;
-  if (FILL && amask) {
-    vmask = live ? amask[(long) b * V + vox] : 0u;
-    const int lo = max(0, bn_lo - b * P.N), hi = min(P.N, bn_hi - b * P.N);
-    const unsigned range = hi > lo ? ((hi - lo >= 32 ? 0xffffffffu : ((1u << (hi - lo)) - 1u)) << lo) : 0u;
-    if (!__any((vmask & range) != 0u)) return;
-  }
+  // images [bn_lo, bn_hi) of the flattened (sample, camera) index: all of them, or one half when
+  // the caller runs two halves of the lift backward side by side
+  const int n_lo = max(0, bn_lo - b * P.N), n_hi = min(P.N, bn_hi - b * P.N);
+  const unsigned range = n_hi > n_lo ? (((1u << (n_hi - n_lo)) - 1u) << n_lo) : 0u;
+  const unsigned vmask = live ? (amask[(long) b * V + vox] & range) : 0u;
 
-  constexpr int NB = 8;                          // cameras per batch: their atomics are in flight together
   // grad_out / (hit count + 1e-6), the camera-mean factor of bv2:512-514: the same for every
-  // camera of the voxel -- one channel-last row of the table per voxel (lanes = consecutive voxels
-  // = consecutive rows)
-  if (FILL && live) {
+  // camera of the voxel -- one channel-last row of the table per voxel
+#ifndef ABL_FILL_NOTABLE
+  if (live) {
     const int nchunk = P.C / CH;
     float4* row = table + ((long) b * V + vox) * (P.C / 4);
     for (int chunk = 0; chunk < nchunk; ++chunk) {
@@ -104,15 +98,17 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
       for (int c4 = 0; c4 < CH; c4 += 4) row[(chunk * CH + c4) / 4] = make_float4(v[c4], v[c4 + 1], v[c4 + 2], v[c4 + 3]);
     }
   }
+#endif
+#ifdef ABL_FILL_NOPAIRS
+  return;
+#endif
+  if (!__any(vmask != 0u)) return;
 
-  // images [bn_lo, bn_hi) of the flattened (sample, camera) index: all of them, or one half when
-  // the caller runs two halves of the lift backward side by side (an image's records only meet
-  // that image's pixels)
-  const int n_lo = max(0, bn_lo - b * P.N), n_hi = min(P.N, bn_hi - b * P.N);
+  constexpr int NB = 8;                          // cameras per batch: their atomics are in flight together
   for (int n0 = n_lo; n0 < n_hi; n0 += NB) {
     int base[NB], start[NB];
     long cellk[NB];
-    float4 tapk[NB];                             // the pair's fractional tap coordinates and depth plane
+    float4 tapk[NB];
     unsigned actm = 0;
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
@@ -122,23 +118,20 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
       cellk[k] = 0;
       tapk[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (n >= n_hi) continue;                   // uniform
-      if (FILL && !__any((vmask >> (n & 31)) & 1u)) continue;   // uniform: nobody in this wave sees camera n
+      const bool act = (vmask >> n) & 1u;
+      if (!__any(act)) continue;                 // uniform: nobody in this wave has a pair with camera n
       const long bn = (long) b * P.N + n;
-      const LiftTap t = lift_project<true>(P, mats + bn * 48, vx, vy, vz);
-      // at least one of the four pixel taps must exist
-      const bool act = live && t.valid && t.ix0 >= -1 && t.ix0 < P.fW && t.iy0 >= -1 && t.iy0 < P.fH;
-      if (act) wmask |= 1u << (n & 31);
-      const long cell = (bn * ch + (t.iy0 + 1)) * cw + (t.ix0 + 1);
-      cellk[k] = cell;
-      tapk[k] = make_float4(t.wx1, t.wy1, t.wz1, __int_as_float(t.iz0));
-      const LaneRun r = lane_run(act, cell, lane);
-      if (r.head) {
-        if (FILL) base[k] = atomicAdd(cnt + cell, r.len);
-        else atomicAdd(cnt + cell, r.len);
+      long cell = 0;
+      if (act) {
+        tapk[k] = ptaps[bn * V + vox];
+        const int pc = pcell[bn * V + vox];
+        cell = (bn * ch + (pc >> 16)) * cw + (pc & 0xffff);
       }
+      cellk[k] = cell;
+      const LaneRun r = lane_run(act, cell, lane);
+      if (r.head) base[k] = atomicAdd(cnt + cell, r.len);
       if (act) { actm |= 1u << k; start[k] = r.start; }
     }
-    if (!FILL) continue;
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
       const int n = n0 + k;
@@ -151,233 +144,447 @@ lift_bwd_cell_kernel(LiftParams P, int cw, int ch, const float* __restrict__ mat
       recs[slot] = tapk[k];
     }
   }
-  if (!FILL && amask && live) amask[(long) b * V + vox] = wmask;
 }
 
 // ---------------------------------------------------------------------------
-// gather: one wave per feature-map pixel (or wpp = 4 / 16 waves for dense configurations, chosen
-// on the host from the expected pairs per pixel), lane = PAIR: every lane takes one pair (voxel
-// index + fractional taps), loads the voxel's row of the table (64 bytes at C = 16), keeps 16
-// grad_feat partial sums in registers and
-// adds its two depth-plane terms to the pixel's LDS column.  The depth values a pair needs -- the
-// two planes around its projected depth at THIS pixel -- come from the pixel's own depth column,
-// staged in LDS once.  The 16 x 64 partial sums are folded with a recursive-halving reduction at
-// the end.  C > 16 runs in chunks of 16 channels.
-// max(kMinWaves, wpp) waves per workgroup: small workgroups, because a workgroup lives as long
-// as its slowest pixel.
+// gather: one workgroup per strip of kS pixels of one feature-map row
 // ---------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(1024)
-lift_bwd_cell_gather_kernel(LiftParams P, int cw, int ch, int wpp, int xgroup,
-                            const float* __restrict__ mats, const float* __restrict__ xs,
-                            const float* __restrict__ ys, const float* __restrict__ zs,
-                            const T* __restrict__ depth, const T* __restrict__ feat,
-                            const int* __restrict__ off, const int* __restrict__ boff,
-                            const int* __restrict__ ids, const float4* __restrict__ recs,
-                            const float4* __restrict__ table,
-                            float* __restrict__ gdepth, float* __restrict__ gfeat, long pix_lo, long pix_hi,
-                            int softmax_bwd) {
-  extern __shared__ float smem[];                // [ppb][Dp] grad columns, [ppb][Dp] depth columns, [waves][16]
+constexpr int kS = 16;               // pixels per strip: depth planes move as 64-byte runs
+constexpr int kW = 4;                // waves per workgroup
+constexpr int kSlots = 4 * kW;       // lanes a pixel's pairs are dealt to (4 per wave)
+constexpr int kRow = 24;             // floats per staged pair: 16 channels + 2 x {w dep, w wz0, w wz1, iz0}
+constexpr int kFix = 44;             // fixed-point depth sums: |term| < 2^41, 2^10 .. 2^20 terms fit
+
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0.f, v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// exponent e with |v| < 2^e (v = 0 -> a very small exponent)
+__device__ __forceinline__ int exp_above(float v) {
+  int e;
+  frexpf(fmaxf(fabsf(v), 1e-30f), &e);
+  return e;
+}
+// round(w * 2^sc) as a 64-bit integer, |result| < 2^51: the integer sits in the mantissa of
+// w * 2^sc + 1.5 * 2^52 (five instructions; a float -> int64 cast is a dozen)
+__device__ __forceinline__ unsigned long long fixed_of(float w, int sc) {
+  const double x = ldexp((double) w, sc) + 6755399441055744.0;
+  return (unsigned long long) (__double_as_longlong(x) - 0x4338000000000000LL);
+}
+
+#ifdef ABL_STAMPS
+__device__ long long g_stamps[16384 * 8];
+#define STAMP() __builtin_amdgcn_s_memtime()
+#endif
+
+static size_t strip_lds_floats(int D, int cap) {
+  // dtile + 64-bit gtile + stage + cell starts + per-pixel scale exponents + softmax partials + chunk maxima
+  return (size_t) D * kS * 3 + (size_t) std::max(cap * kRow, kW * kS * 16) + 2 * (kS + 2) + kS + 17 * kS + 8;
+}
+
+// The depth gradient of the strip is summed in 64-bit fixed point in LDS (ds_add_u64 is served at
+// 11-19 cycles per wave instruction on gfx950, ds_add_f32 at 100-190, and a read-add-write per pair
+// costs two LDS round trips in a loop that is nothing but latency): a term w * dot is bounded by
+// max|g| * sum_c |feat_c| of its pixel, so with the power-of-two scale 2^(kFix - e_g - e_f[pixel]) every
+// term is below 2^41 and keeps >= 20 bits under a typical term; integer adds are associative, so
+// the sums have the same bits every run.  e_g follows the largest table row staged so far (+3 bits
+// of headroom); when a later chunk exceeds it the tile is shifted down once.
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(kW * 64, 4)
+lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_lo, int cap,
+                      const T* __restrict__ depth, const T* __restrict__ feat,
+                      const int* __restrict__ off, const int* __restrict__ boff,
+                      const int* __restrict__ ids, const float4* __restrict__ recs,
+                      const float4* __restrict__ table, const int* __restrict__ rowq,
+                      float* __restrict__ gdepth, float* __restrict__ gfeat, int softmax_bwd) {
+  extern __shared__ float smem[];
+  constexpr int NT = kW * 64;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int C = P.C, D = P.use_depth ? P.D : 0;
-  const int Dp = D | 1;
-  const int nw = blockDim.x >> 6;
-  const int ppb = nw / wpp;                      // pixels per workgroup
-  const int pw = wv / wpp, ws = wv % wpp;        // pixel of this wave, wave index inside the pixel
-  float* gd = smem;
-  float* dcolumns = smem + ppb * Dp;
-  float* accbuf = smem + 2 * ppb * Dp;
+  const int DS = D * kS;
+  float* dtile = smem;                                              // [D][kS] the strip's depth columns
+  long long* gtile = reinterpret_cast<long long*>(smem + DS);       // [D][kS] their gradients, fixed point
+  float* stage = smem + 3 * DS;                                     // [cap][kRow] staged pairs
+  int* offs = reinterpret_cast<int*>(stage + max(cap * kRow, kW * kS * 16));   // [2][kS + 2] cell starts
+  int* efp = offs + 2 * (kS + 2);                                   // [kS] exponent of sum_c |feat_c|
+  float* red = reinterpret_cast<float*>(efp + kS);                  // [16 + 1][kS]
+  float* cmax = red + 17 * kS;                                      // [kW] chunk maxima
+
+  // the strips of one image row run on one XCD: vertical and horizontal neighbours share cells
+  const unsigned lin = xcd_grouped(blockIdx.x, gridDim.x, xgroup);
+  const int sx = lin % spr;
+  const int row = rowq[(long) bn_lo * P.fH + lin / spr];            // heavy rows first (fill kernel)
+  const int iy = row % P.fH;
+  const long bn = row / P.fH;
+  const int b = (int) (bn / P.N);
+  const int x0 = sx * kS;
+  const int np = min(kS, P.fW - x0);                 // pixels of a ragged last strip
   const long HW = (long) P.fH * P.fW;
   const long V = (long) P.Z * P.Y * P.X;
-  const long npix = pix_hi;                      // this launch owns pixels [pix_lo, pix_hi)
-  // the workgroups of one image row run on one XCD: their 16-byte pieces of a depth plane's row
-  // merge into whole lines in that L2
-  const long pid0 = pix_lo + (long) xcd_grouped(blockIdx.x, gridDim.x, xgroup) * ppb;
-  const long pid = min(pid0 + pw, npix - 1);
-  const bool pix_ok = pid0 + pw < npix;
-  const long bn = __builtin_amdgcn_readfirstlane((int) (pid / HW));      // wave-uniform: the pixel
-  const int pix = __builtin_amdgcn_readfirstlane((int) (pid % HW));
-  const int b = (int) (bn / P.N);
-  const int iy = pix / P.fW, ix = pix % P.fW;
-  const float* m = mats + bn * 48;
+  const long pix0 = (long) iy * P.fW + x0;
+  const int p = lane >> 2, sl = wv * 4 + (lane & 3); // consume phase: lane = (pixel, slot)
 
-  float* gcol = gd + pw * Dp;
-  float* dcol = dcolumns + pw * Dp;
-  for (int dz = ws * 64 + lane; dz < D; dz += wpp * 64) {
-    gcol[dz] = 0.f;
-    dcol[dz] = ldf(depth, (bn * P.D + dz) * HW + pix);
+#ifdef ABL_STAMPS
+  long long st0 = STAMP(), st_stage = 0, st_cons = 0, st2 = 0;
+  const long long rt0 = wall_clock64();
+#endif
+  // start offsets of the cells (row iy + h, column x0 + j), j = 0 .. kS + 1.  A pair of cell (row,
+  // column) has iy0 = row - 1, ix0 = column - 1; the cells are linear in (row, column), so the end of a
+  // row is the start of the next.
+  if (tid < 2 * (kS + 2)) {
+    const int h = tid / (kS + 2), j = tid % (kS + 2);
+    const long c = (bn * ch + iy + h) * cw + min(x0 + j, cw);
+    offs[tid] = off[c] + boff[c / kScanTile];
   }
-  __syncthreads();
-
-  // index ranges of cell rows iy and iy + 1, columns ix .. ix + 1 (mid = where column ix + 1
-  // starts).  The cell tells which tap of the pair this pixel is: a pair of cell (row, column)
-  // has iy0 = row - 1, ix0 = column - 1.
-  int beg0, mid0, n0, beg1, mid1, tot;
-  {
-    const int l6 = min(lane, 5);
-    const long c = (bn * ch + iy + l6 / 3) * cw + ix + l6 % 3;
-    const int sv = off[c] + boff[c / kScanTile];
-    beg0 = __shfl(sv, 0, 64);
-    mid0 = __shfl(sv, 1, 64);
-    n0 = __shfl(sv, 2, 64) - beg0;
-    beg1 = __shfl(sv, 3, 64);
-    mid1 = __shfl(sv, 4, 64);
-    tot = n0 + __shfl(sv, 5, 64) - beg1;
-  }
-  if (!pix_ok) tot = 0;
-
-  for (int c0 = 0; c0 < C; c0 += 16) {           // channel chunk
-    const int nq = min(4, (C - c0) / 4);         // float4 pieces of this chunk
-    // the pixel's features of this chunk, wave-uniform: one load, then scalar broadcasts
-    const float ftv = (lane < 16 && c0 + lane < C) ? ldf(feat, (bn * C + c0 + lane) * HW + pix) : 0.f;
-    float ft[16];
+  // the depth columns: 16-byte pieces of the planes' 64-byte runs (fW % 4 == 0), else single values
+  if (VEC) {
+    for (int e0 = 0; e0 < DS / 4; e0 += 2 * NT) {
+      float4 v[2];
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
-      ft[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ftv), c));
-    float acc[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
-
-    for (int k0 = ws * 64; k0 < tot; k0 += wpp * 64) {
-      const int k = k0 + lane;
-      const bool in = k < tot;
-      const int kc = min(k, tot - 1);
-      const bool row0 = kc < n0;
-      const long pos = row0 ? (long) beg0 + kc : (long) beg1 + (kc - n0);
-      const int vox = ids[pos];
-      // the voxel's row of grad_out / (hits + 1e-6)
-      const float4* e = table + ((long) b * V + vox) * (C / 4) + c0 / 4;
-      float gs[16];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < nq) g4 = e[q];                    // uniform branch
-        gs[4 * q] = g4.x; gs[4 * q + 1] = g4.y; gs[4 * q + 2] = g4.z; gs[4 * q + 3] = g4.w;
+      for (int k = 0; k < 2; ++k) {
+        const int e = min(e0 + k * NT + tid, DS / 4 - 1);
+        const int dz = e / (kS / 4), p4 = min((e % (kS / 4)) * 4, np - 4);
+        v[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(depth) + (bn * P.D + dz) * HW + pix0 + p4);
       }
-      // the pair's taps: fractional coordinates (w1 of each axis) and the lower depth plane; the weights
-      // of the lower taps are taken as 1 - w1 (the forward's (floor + 1) - f up to an ulp: gradients are
-      // held to 1e-4)
-      const float4 rc = recs[pos];
-      const int iz0 = __float_as_int(rc.w);
-      const float wz1v = rc.z, wz0v = 1.0f - rc.z;
-      // which of the pair's taps this pixel is: (iy - iy0) * 2 + (ix - ix0)
-      const int j = (row0 ? 2 : 0) + ((pos >= (row0 ? mid0 : mid1)) ? 0 : 1);
-      const float wj = in ? (((j & 2) ? rc.y : 1.0f - rc.y) * ((j & 1) ? rc.x : 1.0f - rc.x)) : 0.f;
-      // depth interpolated at this pixel: the two planes around the projected depth (zero padding)
-      const bool z0in = iz0 >= 0 && iz0 < D, z1in = iz0 + 1 >= 0 && iz0 + 1 < D;
-      float dep;
-      if (D > 0) dep = (z0in ? wz0v * dcol[min(max(iz0, 0), D - 1)] : 0.f) + (z1in ? wz1v * dcol[min(max(iz0 + 1, 0), D - 1)] : 0.f);
-      else dep = (iz0 == 0 ? wz0v : 0.f) + (iz0 == -1 ? wz1v : 0.f);      // D == 1: the single plane
-      const float pwj = wj * dep;
-      float dot = 0.f;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        acc[c] = __builtin_fmaf(pwj, gs[c], acc[c]);
-        dot = __builtin_fmaf(ft[c], gs[c], dot);
-      }
-      if (D > 0 && in) {
-        const float wd = wj * dot;
-        // (ds_add_f32 is slow on gfx950 -- ~190 cycles per wave instruction against ~11 for
-        // ds_add_u32, tools/microbench/lds_atomic.hip -- but a fixed-point column with a per-pixel
-        // scale measured slower here, 80 vs 69 us: finding the scale costs a wave reduction per batch)
-        if (wd != 0.f) {
-          if (z0in) atomicAdd(gcol + iz0, wz0v * wd);
-          if (z1in) atomicAdd(gcol + iz0 + 1, wz1v * wd);
-        }
+      for (int k = 0; k < 2; ++k) {
+        const int e = e0 + k * NT + tid;
+        if (e < DS / 4) reinterpret_cast<float4*>(dtile)[e] = v[k];
       }
     }
-    // fold the 64 lanes' partial sums: afterwards lane l holds channel c0 + (l >> 2)
-    int cb = 0;
-    reduce_halving<16, 32, 64, 16>(acc, lane, cb);
-    static_assert(reduce_left<16, 32>() == 1 && reduce_dups<16, 32>() == 3, "16 values over 64 lanes");
-    if (wpp == 1) {
-      if (pix_ok && (lane & 3) == 0 && c0 + cb < C) gfeat[(bn * C + c0 + cb) * HW + pix] = acc[0];
-    } else {
-      if ((lane & 3) == 0) accbuf[wv * 16 + cb] = acc[0];
-      __syncthreads();
-      if (ws == 0 && lane < 16 && pix_ok && c0 + lane < C) {
-        float v = 0.f;
-        for (int s2 = 0; s2 < wpp; ++s2) v += accbuf[(wv + s2) * 16 + lane];
-        gfeat[(bn * C + c0 + lane) * HW + pix] = v;
+  } else {
+    for (int e0 = 0; e0 < DS; e0 += 6 * NT) {
+      float v[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int ec = min(e0 + k * NT + tid, DS - 1);
+        v[k] = ldf(depth, (bn * P.D + ec / kS) * HW + pix0 + min(ec % kS, np - 1));
       }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int e = e0 + k * NT + tid;
+        if (e < DS) dtile[e] = v[k];
+      }
+    }
+  }
+  for (int e = tid; e < DS / 2; e += NT) reinterpret_cast<float4*>(gtile)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    // sum_c |feat_c| of every pixel over ALL channels: the bound of the depth terms
+    const int pp = tid % kS;
+    float sa = 0.f;
+    for (int c = tid / kS; c < C; c += NT / kS) sa += fabsf(pp < np ? ldf(feat, (bn * C + c) * HW + pix0 + pp) : 0.f);
+    red[tid] = sa;
+  }
+  __syncthreads();
+  if (tid < kS) {
+    float t = 0.f;
+    for (int k = 0; k < NT / kS; ++k) t += red[k * kS + tid];
+    efp[tid] = exp_above(t);
+  }
+  __syncthreads();
+#ifdef ABL_STAMPS
+  long long st1 = STAMP();
+#endif
+
+  const int n0 = offs[np + 1] - offs[0];             // pairs of cell row iy
+  const int NP = n0 + offs[kS + 2 + np + 1] - offs[kS + 2];   // pairs of both cell rows
+  const int efl = efp[p];
+  int eg = -1000;                                    // uniform: current exponent of the table rows
+
+  for (int c0 = 0; c0 < C; c0 += 16) {               // channel chunk
+    const int nq = min(4, (C - c0) / 4);             // float4 pieces of this chunk
+    // the pixel's 16 features of this chunk, through LDS ([pixel][channel]: one load per thread)
+    __syncthreads();
+    {
+      const int cc = tid / kS, pp = tid % kS;
+      stage[pp * 16 + cc] = (c0 + cc < C && pp < np) ? ldf(feat, (bn * C + c0 + cc) * HW + pix0 + pp) : 0.f;
+    }
+    __syncthreads();
+    float ft[16], acc[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4 f = reinterpret_cast<const float4*>(stage + p * 16)[k];
+      ft[4 * k] = f.x; ft[4 * k + 1] = f.y; ft[4 * k + 2] = f.z; ft[4 * k + 3] = f.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    // this pixel's pairs in the concatenation [cell row iy | cell row iy + 1]: cells (x0 + p) [the
+    // pixel is their x1 tap, role A] and (x0 + p + 1) [x0 tap, role B] of either row
+    int lo_h[2], mid_h[2], hi_h[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int* oh = offs + h * (kS + 2);
+      const int base = h ? n0 - oh[0] : -oh[0];
+      lo_h[h] = oh[p] + base;
+      mid_h[h] = oh[p + 1] + base;
+      hi_h[h] = p < np ? oh[p + 2] + base : lo_h[h];
+    }
+    // The loads of the stage phase run two chunks ahead: at chunk c the table rows of chunk c + 1 are
+    // requested (their voxel indices arrived during chunk c - 1) and the indices / taps of chunk c + 2,
+    // so the chunk loop never waits for a round trip it has just started.
+    // stage phase A: lanes 0..31 of a wave = pair 32 wv + lane of the chunk (voxel index and taps
+    // arrive coalesced; the lane works out the pair's terms for its two pixels); phase B: four lanes
+    // per pair, each one 16-byte piece of the voxel's table row (one line pulled per pair, not four)
+    const int jA = 32 * wv + lane;
+    const bool laneA = lane < 32 && jA < cap;
+    auto load_ids = [&](int tc, int& vox, float4& rc) {
+      vox = 0;
+      rc = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int t = tc + jA;
+      if (laneA && t < NP) {
+        const long pos = (long) (t >= n0 ? offs[kS + 2] + (t - n0) : offs[0] + t);
+#ifdef ABL_NOIDS
+        vox = (int) (pos % V); rc = make_float4(0.3f, 0.4f, 0.5f, __int_as_float(8 | ((x0 + 3) << 16)));
+#else
+        vox = ids[pos];
+        rc = recs[pos];
+#endif
+      }
+    };
+    auto load_rows = [&](int tc, int vox, float4 (&g)[2]) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int jj = 16 * s2 + (lane >> 2), k = lane & 3;
+        const int vj = __shfl(vox, jj, 64);
+        g[s2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // the voxel's row of grad_out / (hits + 1e-6)
+        if (32 * wv + jj < cap && tc + 32 * wv + jj < NP && k < nq) g[s2] = table[((long) b * V + vj) * (C / 4) + c0 / 4 + k];
+      }
+    };
+    int voxB;
+    float4 rcA, rcB, gA[2];
+    {
+      int voxA;
+      load_ids(0, voxA, rcA);
+      load_rows(0, voxA, gA);
+      load_ids(cap, voxB, rcB);
+    }
+    for (int t0 = 0; t0 < NP; t0 += cap) {
+      const int nst = min(cap, NP - t0);
+      __syncthreads();                               // the previous chunk (or the feature tile) is consumed
+#ifdef ABL_STAMPS
+      long long sa = STAMP();
+#endif
+      // ---- stage chunk [t0, t0 + nst) from the registers
+      float gm = 0.f;
+      if (laneA && jA < nst) {
+        const int h = t0 + jA >= n0;
+        const float4 rc = rcA;
+        // the pair's taps: fractional coordinates (w1 of each axis), the lower depth plane and the
+        // cell column; the weights of the lower taps are taken as 1 - w1 (the forward's
+        // (floor + 1) - f up to an ulp: gradients are held to 1e-4)
+        const int pk = __float_as_int(rc.w);
+        const int iz0 = (pk & 0xffff) - 1, col = pk >> 16;
+        const float wz1v = rc.z, wz0v = 1.0f - rc.z;
+        const float wy = h ? 1.0f - rc.y : rc.y;
+        const bool z0in = iz0 >= 0 && iz0 < D, z1in = iz0 + 1 >= 0 && iz0 + 1 < D;
+        const float* d0 = dtile + min(max(iz0, 0), D - 1) * kS;
+        const float* d1 = dtile + min(max(iz0 + 1, 0), D - 1) * kS;
+        float* st = stage + jA * kRow;
+#pragma unroll
+        for (int role = 0; role < 2; ++role) {       // role A: the pixel is the x1 tap, role B: the x0 tap
+          const int pr = col - role - x0;
+          const bool pin = pr >= 0 && pr < np;
+          const int prc = min(max(pr, 0), kS - 1);
+          const float wj = wy * (role ? 1.0f - rc.x : rc.x);
+          // depth interpolated at that pixel: the two planes around the projected depth (zero padding)
+          float dep;
+          if (D > 0) dep = (z0in ? wz0v * d0[prc] : 0.f) + (z1in ? wz1v * d1[prc] : 0.f);
+          else dep = (iz0 == 0 ? wz0v : 0.f) + (iz0 == -1 ? wz1v : 0.f);      // D == 1: the single plane
+          reinterpret_cast<float4*>(st)[4 + role] =
+              make_float4(pin ? wj * dep : 0.f, (pin && z0in) ? wj * wz0v : 0.f, (pin && z1in) ? wj * wz1v : 0.f,
+                          __int_as_float(iz0));
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int j = 32 * wv + 16 * s2 + (lane >> 2);
+        const float4 g4 = gA[s2];
+        gm = fmaxf(gm, fmaxf(fmaxf(fabsf(g4.x), fabsf(g4.y)), fmaxf(fabsf(g4.z), fabsf(g4.w))));
+        if (j < nst) reinterpret_cast<float4*>(stage + j * kRow)[lane & 3] = g4;
+      }
+      // ---- next chunk's rows, the chunk after's indices
+      load_rows(t0 + cap, voxB, gA);
+      rcA = rcB;
+      load_ids(t0 + 2 * cap, voxB, rcB);
+      gm = wave_max(gm);
+      if (lane == 0) cmax[wv] = gm;
       __syncthreads();
+      if (D > 0) {
+        const int ec = exp_above(fmaxf(fmaxf(cmax[0], cmax[1]), fmaxf(cmax[2], cmax[3])));
+        if (ec > eg) {                               // uniform; the first chunk, rarely a later one
+          const int en = ec + 3;
+          if (eg > -1000) {
+            const int sh = min(en - eg, 63);
+            for (int e = tid; e < DS; e += NT) gtile[e] >>= sh;
+            __syncthreads();
+          }
+          eg = en;
+        }
+      }
+#ifdef ABL_STAMPS
+      long long sb = STAMP(); st_stage += sb - sa;
+#endif
+      // ---- consume: lane = (pixel, slot), the pair's 16 channels in the lane
+      const int sce = kFix - eg - efl;
+#ifdef ABL_NOCONSUME
+      if (t0 == 12345)
+#endif
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int lo = max(lo_h[h], t0), hi = min(hi_h[h], t0 + nst), mid = mid_h[h];
+        for (int r = lo + sl; __any(r < hi); r += kSlots) {
+          const bool in = r < hi;
+          const float4* sr = reinterpret_cast<const float4*>(stage + (in ? r - t0 : 0) * kRow);
+          const float4 ax = sr[r < mid ? 4 : 5];
+          const float pwj = in ? ax.x : 0.f;
+          float dot = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float4 g = sr[k];
+            acc[4 * k] = __builtin_fmaf(pwj, g.x, acc[4 * k]);
+            acc[4 * k + 1] = __builtin_fmaf(pwj, g.y, acc[4 * k + 1]);
+            acc[4 * k + 2] = __builtin_fmaf(pwj, g.z, acc[4 * k + 2]);
+            acc[4 * k + 3] = __builtin_fmaf(pwj, g.w, acc[4 * k + 3]);
+            dot = __builtin_fmaf(ft[4 * k], g.x, dot);
+            dot = __builtin_fmaf(ft[4 * k + 1], g.y, dot);
+            dot = __builtin_fmaf(ft[4 * k + 2], g.z, dot);
+            dot = __builtin_fmaf(ft[4 * k + 3], g.w, dot);
+          }
+          if (D > 0) {
+            const float w0 = in ? ax.y * dot : 0.f, w1 = in ? ax.z * dot : 0.f;
+            unsigned long long* gp = reinterpret_cast<unsigned long long*>(gtile + __float_as_int(ax.w) * kS + p);
+            if (w0 != 0.f) atomicAdd(gp, fixed_of(w0, sce));
+            if (w1 != 0.f) atomicAdd(gp + kS, fixed_of(w1, sce));
+          }
+        }
+      }
+#ifdef ABL_STAMPS
+      __syncthreads();
+      st_cons += STAMP() - sb;
+#endif
+    }
+    // grad_feat: the four slots of a wave by DPP, the four waves through LDS
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = quad_sum(acc[c]);
+    __syncthreads();
+    if ((lane & 3) == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        reinterpret_cast<float4*>(stage + (wv * kS + p) * 16)[k] = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
+    }
+    __syncthreads();
+#ifdef ABL_STAMPS
+    st2 = STAMP();
+#endif
+    {
+      const int cc = tid / kS, pp = tid % kS;        // consecutive threads = consecutive pixels of one channel
+      float v = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < kW; ++w2) v += stage[(w2 * kS + pp) * 16 + cc];
+      if (pp < np && c0 + cc < C) gfeat[(bn * C + c0 + cc) * HW + pix0 + pp] = v;
     }
   }
   if (D > 0 && gdepth) {
     __syncthreads();
-    if (softmax_bwd) {
-      // VAMP_LIFTBWD_LOGITS: the depth column is softmax(logits) (base_vampire2.py:550) and the caller
-      // wants the gradient of the logits, p * (g - sum_d p g): both columns sit in LDS, so the
-      // softmax backward costs one wave reduction per pixel and no pass over HBM
-      if (ws == 0) {
-        float dot = 0.f;
-        for (int dz = lane; dz < D; dz += 64) dot = __builtin_fmaf(dcol[dz], gcol[dz], dot);
+    // fixed point -> float, in place (the floats of a pass land below everything still unread)
+    float* gf = reinterpret_cast<float*>(gtile);
+    for (int e0 = 0; e0 < DS; e0 += 6 * NT) {
+      float v[6];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
-        if (lane == 0) accbuf[pw] = dot;
+      for (int k = 0; k < 6; ++k) {
+        const int e = e0 + k * NT + tid;
+        v[k] = e < DS ? (float) ldexp((double) gtile[e], -(kFix - eg - efp[e % kS])) : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int e = e0 + k * NT + tid;
+        if (e < DS) gf[e] = v[k];
       }
       __syncthreads();
     }
-    // consecutive threads = consecutive pixels of one depth plane
-    for (int e = tid; e < D * ppb; e += nw * 64) {
-      const int dz = e / ppb, p = e % ppb;
-      const long pp = pid0 + p;
-      if (pp >= npix) continue;
-      float v = gd[p * Dp + dz];
-      if (softmax_bwd) v = dcolumns[p * Dp + dz] * (v - accbuf[p]);
-      gdepth[((pp / HW) * P.D + dz) * HW + pp % HW] = v;
+    if (softmax_bwd) {
+      // VAMP_LIFTBWD_LOGITS: the depth column is softmax(logits) (base_vampire2.py:550) and the caller
+      // wants the gradient of the logits, p * (g - sum_d p g): both tiles sit in LDS, so the softmax
+      // backward costs one small reduction per strip and no pass over HBM
+      const int pp = tid % kS, gq = tid / kS;        // 16 partial sums per pixel
+      float s = 0.f;
+      for (int dz = gq; dz < D; dz += NT / kS) s = __builtin_fmaf(dtile[dz * kS + pp], gf[dz * kS + pp], s);
+      red[gq * kS + pp] = s;
+      __syncthreads();
+      if (tid < kS) {
+        float t = 0.f;
+        for (int k = 0; k < NT / kS; ++k) t += red[k * kS + tid];
+        red[16 * kS + tid] = t;
+      }
+      __syncthreads();
+    }
+    if (VEC) {
+      for (int e = tid; e < DS / 4; e += NT) {
+        const int dz = e / (kS / 4), p4 = (e % (kS / 4)) * 4;
+        if (p4 >= np) continue;
+        float4 v = reinterpret_cast<const float4*>(gf)[e];
+        if (softmax_bwd) {
+          const float4 d = reinterpret_cast<const float4*>(dtile)[e];
+          const float4 sd = *reinterpret_cast<const float4*>(red + 16 * kS + p4);
+          v = make_float4(d.x * (v.x - sd.x), d.y * (v.y - sd.y), d.z * (v.z - sd.z), d.w * (v.w - sd.w));
+        }
+        *reinterpret_cast<float4*>(gdepth + (bn * P.D + dz) * HW + pix0 + p4) = v;
+      }
+    } else {
+      // consecutive threads = consecutive pixels of one depth plane
+      for (int e = tid; e < DS; e += NT) {
+        const int dz = e / kS, pp = e % kS;
+        if (pp >= np) continue;
+        float v = gf[e];
+        if (softmax_bwd) v = dtile[e] * (v - red[16 * kS + pp]);
+        gdepth[(bn * P.D + dz) * HW + pix0 + pp] = v;
+      }
     }
   }
+#ifdef ABL_STAMPS
+  __syncthreads();
+  if (tid == 0 && blockIdx.x < 16384) {
+    long long* o = g_stamps + (long) blockIdx.x * 8;
+    o[0] = st0; o[1] = st1; o[2] = st_stage; o[3] = st_cons; o[4] = st2; o[5] = STAMP(); o[6] = rt0; o[7] = wall_clock64();
+  }
+#endif
 }
+
+#ifdef ABL_STAMPS
+}  // namespace vamp
+extern "C" int vamp_debug_read_stamps(long long* host, int n) {
+  return (int) hipMemcpyFromSymbol(host, HIP_SYMBOL(vamp::g_stamps), (size_t) n * 8 * sizeof(long long));
+}
+namespace vamp {
+#endif
 
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-struct LiftCellWs {
-  int *cnt, *off, *bsum, *boff, *aux;
-  unsigned* amask;                   // [B * V] cameras each voxel is valid for (N <= 32)
-  int* ids;                          // [cap] voxel index (within its sample) of every pair, in cell order
-  float4* recs;                      // [cap] {wx1, wy1, wz1, iz0} of every pair
-  float4* table;                     // [B * V, C] grad_out / (hits + 1e-6), channel-last
-  size_t bytes;
-};
-
-static LiftCellWs lift_cell_ws(const VampLiftDesc* d, void* scratch) {
-  const LiftCells g = lift_cells(d);
-  const long ntile = g.ncell / kScanTile;
-  // every (voxel, camera) pair can be valid
-  const size_t cap = (size_t) d->B * d->N * d->Z * d->Y * d->X;
-  char* p = static_cast<char*>(scratch);
-  LiftCellWs w;
-  w.cnt = reinterpret_cast<int*>(p); p += align_up((size_t) (g.ncell + kScanPad) * sizeof(int), 256);   // + the scan's ticket word
-  w.off = reinterpret_cast<int*>(p); p += align_up((size_t) g.ncell * sizeof(int), 256);
-  w.bsum = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
-  w.boff = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
-  w.aux = reinterpret_cast<int*>(p); p += align_up((size_t) (ntile + 4) * sizeof(int), 256);
-  w.amask = reinterpret_cast<unsigned*>(p); p += align_up((size_t) d->B * d->Z * d->Y * d->X * sizeof(unsigned), 256);
-  w.ids = reinterpret_cast<int*>(p); p += align_up(cap * sizeof(int), 256);
-  w.recs = reinterpret_cast<float4*>(p); p += align_up(cap * sizeof(float4), 256);
-  w.table = reinterpret_cast<float4*>(p); p += align_up((size_t) d->B * d->Z * d->Y * d->X * d->C * sizeof(float), 256);
-  w.bytes = (size_t) (p - static_cast<char*>(scratch));
-  return w;
-}
-
 size_t lift_bwd_cell_ws_bytes(const VampLiftDesc* d) { return lift_cell_ws(d, nullptr).bytes; }
 
-// count + scan: geometry only, so the host may run it beside the forward (vamp_lift_prepare)
-int launch_lift_cell_prepare(const VampLiftDesc* d, const float* mats, const float* xs,
-                             const float* ys, const float* zs, void* scratch, hipStream_t s) {
-  const LiftParams P = to_params(d);
+// zero the counters in front of a kernel that emits pairs / scan them behind it
+int launch_lift_cells_begin(const VampLiftDesc* d, void* scratch, hipStream_t s) {
   const LiftCells g = lift_cells(d);
   const LiftCellWs w = lift_cell_ws(d, scratch);
   const size_t cap = (size_t) d->B * d->N * d->Z * d->Y * d->X;
   VAMP_REQUIRE(cap < 0x7fffffffu && g.ncell < 0x7fffffffL, "pair / cell count exceeds 2^31");
   VAMP_REQUIRE(d->C % 4 == 0, "C must be a multiple of 4");
-  if (int ze = launch_zero(w.cnt, (size_t) (g.ncell + kScanPad) * sizeof(int), s)) return ze;
-  dim3 grid((d->X + 63) / 64, (d->Y + 3) / 4, d->Z * d->B);
-  VAMP_TIMED(kProfLiftBwdCount, s, (lift_bwd_cell_kernel<float, 16, false><<<grid, 256, 0, s>>>(
-      P, g.cw, g.ch, mats, xs, ys, zs, nullptr, nullptr, nullptr, w.cnt, w.off, w.boff, w.ids, w.recs, w.table, d->N <= 32 ? w.amask : nullptr, 0, d->B * d->N)));
-  if (int e = check_launch("lift_bwd_cell_kernel<count>")) return e;
+  VAMP_REQUIRE(d->fW < 32767 && d->fH < 32767 && d->D < 65535, "feature map too large for the packed cell coordinates");
+  return launch_zero(w.cnt, (size_t) (g.ncell + kScanPad) * sizeof(int), s);
+}
+
+int launch_lift_cells_end(const VampLiftDesc* d, void* scratch, hipStream_t s) {
+  const LiftCells g = lift_cells(d);
+  const LiftCellWs w = lift_cell_ws(d, scratch);
   return launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, g.ncell, s);
 }
 
@@ -385,64 +592,58 @@ template <typename T>
 static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float* mats,
                          const float* xs, const float* ys, const float* zs, const void* depth,
                          const void* feat, const float* gout, const uint64_t* hits, float* gdepth,
-                         float* gfeat, void* scratch, bool cells_valid, int wpp_force, int half, bool softmax_bwd,
+                         float* gfeat, void* scratch, bool cells_valid, int variant, int half, bool softmax_bwd,
                          hipStream_t s) {
   const LiftCells g = lift_cells(d);
   const LiftCellWs w = lift_cell_ws(d, scratch);
-  const size_t cap = (size_t) d->B * d->N * d->Z * d->Y * d->X;
   if (!cells_valid)
     if (int e = launch_lift_cell_prepare(d, mats, xs, ys, zs, scratch, s)) return e;
   // (the counters are the fill cursors: the scan left them at zero)
   // half 0: all images; 1 / 2: the lower / upper half of the flattened (sample, camera) index
   const int BN = d->B * d->N;
   const int bn_lo = half == 2 ? BN / 2 : 0, bn_hi = half == 1 ? BN / 2 : BN;
+  if (bn_hi <= bn_lo) return VAMP_OK;
   dim3 grid((d->X + 63) / 64, (d->Y + 3) / 4, d->Z * d->B);
-  const T* dp = static_cast<const T*>(depth);
 #define VAMP_CELL(CH)                                                                            \
-  VAMP_TIMED(kProfLiftBwdFill, s, (lift_bwd_cell_kernel<T, CH, true><<<grid, 256, 0, s>>>(       \
-      P, g.cw, g.ch, mats, xs, ys, zs, dp, gout, hits, w.cnt, w.off, w.boff, w.ids, w.recs, w.table,     \
-      d->N <= 32 ? w.amask : nullptr, bn_lo, bn_hi)))
+  VAMP_TIMED(kProfLiftBwdFill, s, (lift_bwd_fill_kernel<CH><<<grid, 256, 0, s>>>(                \
+      P, g.cw, g.ch, gout, hits, w.amask, w.ptaps, w.pcell, w.cnt, w.off, w.boff, w.ids, w.recs, w.table, w.rowq, bn_lo, bn_hi)))
   if (P.C == 4) VAMP_CELL(4); else if (P.C == 8) VAMP_CELL(8); else VAMP_CELL(16);
 #undef VAMP_CELL
-  if (int e = check_launch("lift_bwd_cell_kernel<fill>")) return e;
+  if (int e = check_launch("lift_bwd_fill_kernel")) return e;
 
-  // waves per pixel from the expected records per pixel (4 taps x voxels per camera pixel)
-  const long npix_all = (long) d->B * d->N * d->fH * d->fW;
-  const long pix_lo = (long) bn_lo * d->fH * d->fW, pix_hi = (long) bn_hi * d->fH * d->fW;
-  const long npix = pix_hi - pix_lo;
-  if (npix <= 0) return VAMP_OK;
-  const double per_pix = 4.0 * (double) d->B * d->Z * d->Y * d->X / (double) npix_all;
-  int wpp = per_pix <= 96.0 ? 1 : (per_pix <= 768.0 ? 4 : 16);
-  if (wpp_force == 1 || wpp_force == 4 || wpp_force == 16) wpp = wpp_force;
-  const int nw = std::max(kMinWaves, wpp);
-  const int ppb = nw / wpp;
+  // pairs staged per chunk: 128 by default; the variants exist so that the tests cross chunk
+  // boundaries at every size
+  const int cap = variant == 4 ? 64 : (variant == 16 ? 32 : 128);
   const int Dd = d->use_depth ? d->D : 0;
-  const size_t lds = ((size_t) 2 * ppb * (Dd | 1) + (size_t) nw * 16) * sizeof(float);
-  if (lds > 150 * 1024) return fail(VAMP_EINVAL, "%s: D too large for the LDS depth columns", __func__);
-  const unsigned ggrid = (unsigned) ((npix + ppb - 1) / ppb);
+  const size_t lds = strip_lds_floats(Dd, cap) * sizeof(float);
+  if (lds > 150 * 1024) return fail(VAMP_EINVAL, "%s: D too large for the LDS depth tiles", __func__);
+  const int spr = (d->fW + kS - 1) / kS;
+  const unsigned ggrid = (unsigned) (bn_hi - bn_lo) * d->fH * spr;
   {
-    auto k = lift_bwd_cell_gather_kernel<T>;
+    // 16-byte tile I/O needs fp32 depth planes whose strips start on 16-byte boundaries
+    const bool vec = std::is_same<T, float>::value && d->fW % 4 == 0;
+    auto k = vec ? lift_bwd_strip_kernel<T, true> : lift_bwd_strip_kernel<T, false>;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess)
       return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);
-    VAMP_TIMED(kProfLiftBwd, s, (k<<<ggrid, nw * 64, lds, s>>>(
-        P, g.cw, g.ch, wpp, (d->fW % ppb == 0) ? d->fW / ppb : 0, mats, xs, ys, zs, dp, static_cast<const T*>(feat),
-        w.off, w.boff, w.ids, w.recs, w.table, gdepth, gfeat, pix_lo, pix_hi, softmax_bwd ? 1 : 0)));
+    VAMP_TIMED(kProfLiftBwd, s, (k<<<ggrid, kW * 64, lds, s>>>(
+        P, g.cw, g.ch, spr, spr, bn_lo, cap, static_cast<const T*>(depth), static_cast<const T*>(feat),
+        w.off, w.boff, w.ids, w.recs, w.table, w.rowq, gdepth, gfeat, softmax_bwd ? 1 : 0)));
   }
-  return check_launch("lift_bwd_cell_gather_kernel");
+  return check_launch("lift_bwd_strip_kernel");
 }
 
 int launch_lift_bwd_cell(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                          const float* zs, const void* depth, const void* feat, const float* gout,
                          const uint64_t* hits, float* gdepth, float* gfeat, void* scratch,
-                         bool cells_valid, int wpp_force, int half, bool softmax_bwd, hipStream_t s) {
+                         bool cells_valid, int variant, int half, bool softmax_bwd, hipStream_t s) {
   const LiftParams P = to_params(d);
   if (d->in_dtype == VAMP_F32)
     return launch_cell_t<float>(d, P, mats, xs, ys, zs, depth, feat, gout, hits, gdepth, gfeat, scratch,
-                                cells_valid, wpp_force, half, softmax_bwd, s);
+                                cells_valid, variant, half, softmax_bwd, s);
   return launch_cell_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, feat, gout, hits, gdepth, gfeat,
-                                       scratch, cells_valid, wpp_force, half, softmax_bwd, s);
+                                       scratch, cells_valid, variant, half, softmax_bwd, s);
 }
 
 }  // namespace vamp

@@ -1,6 +1,7 @@
 // Shared by the lift kernels: parameters and the bit-exact voxel -> pixel projection.
 #pragma once
 #include "common.hpp"
+#include "cell_list.hpp"
 
 namespace vamp {
 
@@ -85,13 +86,110 @@ __device__ __forceinline__ LiftTap lift_project(const LiftParams& P, const float
 }
 
 
+// ---------------------------------------------------------------------------
+// Cell lists of the lift backward (lift_bwd_cell.hip).  Cell = (image, floor tap row + 1, floor tap
+// column + 1): (fH + 1) x (fW + 1) cells per camera image.  The FORWARD kernel (grad mode) or the
+// stand-alone prepare kernel counts the valid (voxel, camera) pairs per cell and leaves every
+// pair's taps in `ptaps` / `pcell`, indexed by (image, voxel); the backward's fill pass only
+// re-lays them in cell order -- nothing on the backward projects a voxel again.
+// ---------------------------------------------------------------------------
+struct LiftCells {
+  int cw, ch;                        // cells per row / column of one camera
+  long ncell;                        // padded to the scan tile, + 2 for the range ends
+};
+
+inline LiftCells lift_cells(const VampLiftDesc* d) {
+  LiftCells g;
+  g.cw = d->fW + 1;
+  g.ch = d->fH + 1;
+  const long nc = (long) d->B * d->N * g.cw * g.ch + 2;
+  g.ncell = (nc + kScanTile - 1) / kScanTile * kScanTile;
+  return g;
+}
+
+struct LiftCellWs {
+  int *cnt, *off, *bsum, *boff, *aux;
+  unsigned* amask;                   // [B * V] cameras each voxel has a pair with (N <= 32)
+  float4* ptaps;                     // [B * N * V] {wx1, wy1, wz1, (iz0 + 1) | (ix0 + 1) << 16} of the pair, voxel order (sparse)
+  int* pcell;                        // [B * N * V] (floor row + 1) << 16 | (floor column + 1)
+  int* ids;                          // [cap] voxel index (within its sample) of every pair, in cell order
+  float4* recs;                      // [cap] the same four words of every pair, in cell order
+  float4* table;                     // [B * V, C] grad_out / (hits + 1e-6), channel-last
+  int* rowq;                         // [B * N * fH] image rows, those with the most pairs first
+  size_t bytes;
+};
+
+inline LiftCellWs lift_cell_ws(const VampLiftDesc* d, void* scratch) {
+  const LiftCells g = lift_cells(d);
+  const long ntile = g.ncell / kScanTile;
+  // every (voxel, camera) pair can be valid
+  const size_t V = (size_t) d->Z * d->Y * d->X;
+  const size_t cap = (size_t) d->B * d->N * V;
+  char* p = static_cast<char*>(scratch);
+  LiftCellWs w;
+  w.cnt = reinterpret_cast<int*>(p); p += align_up((size_t) (g.ncell + kScanPad) * sizeof(int), 256);   // + the scan's ticket word
+  w.off = reinterpret_cast<int*>(p); p += align_up((size_t) g.ncell * sizeof(int), 256);
+  w.bsum = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
+  w.boff = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
+  w.aux = reinterpret_cast<int*>(p); p += align_up((size_t) (ntile + 4) * sizeof(int), 256);
+  w.amask = reinterpret_cast<unsigned*>(p); p += align_up((size_t) d->B * V * sizeof(unsigned), 256);
+  w.ptaps = reinterpret_cast<float4*>(p); p += align_up(cap * sizeof(float4), 256);
+  w.pcell = reinterpret_cast<int*>(p); p += align_up(cap * sizeof(int), 256);
+  w.ids = reinterpret_cast<int*>(p); p += align_up(cap * sizeof(int), 256);
+  w.recs = reinterpret_cast<float4*>(p); p += align_up(cap * sizeof(float4), 256);
+  w.table = reinterpret_cast<float4*>(p); p += align_up((size_t) d->B * V * d->C * sizeof(float), 256);
+  w.rowq = reinterpret_cast<int*>(p); p += align_up((size_t) d->B * d->N * d->fH * sizeof(int), 256);
+  w.bytes = (size_t) (p - static_cast<char*>(scratch));
+  return w;
+}
+
+// What the projecting kernels hand to lift_emit_pair.
+struct LiftEmit {
+  int* cnt;
+  unsigned* amask;
+  float4* ptaps;
+  int* pcell;
+  int cw, ch;
+};
+
+inline LiftEmit lift_emit_of(const VampLiftDesc* d, void* cells) {
+  const LiftCells g = lift_cells(d);
+  const LiftCellWs w = lift_cell_ws(d, cells);
+  LiftEmit e;
+  e.cnt = w.cnt; e.amask = w.amask; e.ptaps = w.ptaps; e.pcell = w.pcell;
+  e.cw = g.cw; e.ch = g.ch;
+  return e;
+}
+
+// One camera of one voxel, called in WAVE-UNIFORM control flow (exited lanes are fine): counts the
+// pair in its cell -- one atomic per run of lanes with equal cells, x-neighbouring voxels share a
+// cell in the far field -- and stores its taps at (image, voxel).  Returns whether the voxel has
+// a pair with this camera (at least one of the four pixel taps exists).
+__device__ __forceinline__ bool lift_emit_pair(const LiftParams& P, const LiftEmit& E, const LiftTap& t,
+                                               bool live, long bn, long V, long vox, int lane) {
+  const bool act = live && t.valid && t.ix0 >= -1 && t.ix0 < P.fW && t.iy0 >= -1 && t.iy0 < P.fH;
+  if (!__any(act)) return false;
+  const long cell = (bn * E.ch + (t.iy0 + 1)) * E.cw + (t.ix0 + 1);
+  const LaneRun r = lane_run(act, cell, lane);
+  if (r.head) atomicAdd(E.cnt + cell, r.len);
+  if (act) {
+    // (iz0 >= -1 for a valid pair; the cell column rides in the upper half of the same word)
+    E.ptaps[bn * V + vox] = make_float4(t.wx1, t.wy1, t.wz1, __int_as_float((t.iz0 + 1) | ((t.ix0 + 1) << 16)));
+    E.pcell[bn * V + vox] = ((t.iy0 + 1) << 16) | (t.ix0 + 1);
+  }
+  return act;
+}
+
 // lift_bwd_cell.hip
 size_t lift_bwd_cell_ws_bytes(const VampLiftDesc* d);
 int launch_lift_bwd_cell(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                          const float* zs, const void* depth, const void* feat, const float* gout,
                          const uint64_t* hits, float* gdepth, float* gfeat, void* scratch,
-                         bool cells_valid, int wpp_force, int half, bool softmax_bwd, hipStream_t s);
+                         bool cells_valid, int variant, int half, bool softmax_bwd, hipStream_t s);
 int launch_lift_cell_prepare(const VampLiftDesc* d, const float* mats, const float* xs,
                              const float* ys, const float* zs, void* scratch, hipStream_t s);
+// zero the cell counters (before a kernel that emits pairs) / scan them (after it)
+int launch_lift_cells_begin(const VampLiftDesc* d, void* scratch, hipStream_t s);
+int launch_lift_cells_end(const VampLiftDesc* d, void* scratch, hipStream_t s);
 
 }  // namespace vamp

@@ -373,29 +373,25 @@ class _LiftFn(torch.autograd.Function):
         nbytes = hp.lib.vamp_lift_workspace_bytes(C.byref(d))
         ws = hp._workspace("lift", nbytes)
         cur = torch.cuda.current_stream()
-        side = hp._side_stream() if (need_grad and hp.impl["prepare"] and hp.impl["lift_bwd"] == "cell") else None
         hp._lift_gen = getattr(hp, "_lift_gen", 0) + 1
         ctx.cells_key = None
-        if side is not None:
-            # the counting half of the backward's pixel sort depends on the geometry only: it runs
-            # on the side stream beside the forward kernel
-            side.wait_stream(cur)
-            _capi.check(hp.lib.vamp_lift_prepare(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys),
-                                                 _ptr(hp.zs), _ptr(ws), ws.numel(), _stream(side)),
-                        "vamp_lift_prepare")
+        flags = 0
+        if need_grad and hp.impl["prepare"] and hp.impl["lift_bwd"] == "cell":
+            # the forward kernel projects every voxel into every camera anyway: in grad mode it also
+            # counts the backward's (voxel, camera) pairs per pixel cell and leaves their taps in the
+            # workspace, so the backward never projects (VAMP_PREPARE=0: the backward does it itself)
+            flags = _capi.VAMP_LIFTFWD_EMIT_PAIRS
             ctx.cells_key = (hp._lift_gen, ws.data_ptr())
         if logits:
-            _capi.check(hp.lib.vamp_lift_forward_logits(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys), _ptr(hp.zs),
-                                                        _ptr(lg), _dtype_code(lg), _ptr(feat), _ptr(depth), _ptr(out),
-                                                        _ptr(hits), _ptr(ws), ws.numel(), _stream(cur)),
-                        "vamp_lift_forward_logits")
+            _capi.check(hp.lib.vamp_lift_forward_logits_ex(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys), _ptr(hp.zs),
+                                                           _ptr(lg), _dtype_code(lg), _ptr(feat), _ptr(depth), _ptr(out),
+                                                           _ptr(hits), _ptr(ws), ws.numel(), flags, _stream(cur)),
+                        "vamp_lift_forward_logits_ex")
         else:
-            _capi.check(hp.lib.vamp_lift_forward(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys), _ptr(hp.zs),
-                                                 _ptr(depth if use_depth else None), _ptr(feat), _ptr(out),
-                                                 _ptr(hits), _ptr(ws), ws.numel(), _stream(cur)),
-                        "vamp_lift_forward")
-        if side is not None:
-            cur.wait_stream(side)
+            _capi.check(hp.lib.vamp_lift_forward_ex(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys), _ptr(hp.zs),
+                                                    _ptr(depth if use_depth else None), _ptr(feat), _ptr(out),
+                                                    _ptr(hits), _ptr(ws), ws.numel(), flags, _stream(cur)),
+                        "vamp_lift_forward_ex")
         if need_grad:
             ctx.hp, ctx.desc, ctx.use_depth = hp, d, use_depth
             ctx.save_for_backward(depth if use_depth else feat, feat, mats, hits)
