@@ -22,6 +22,7 @@
 // Autograd of render_utils.py:140-141 (grid_sample backward w.r.t. the volume).
 #include "render_common.hpp"
 #include "cell_list.hpp"
+#include "ray_plan.hpp"
 
 #include <algorithm>
 
@@ -37,68 +38,62 @@ __device__ __forceinline__ long sample_cell(const RenderParams& P, int key, unsi
 }
 
 // ---------------------------------------------------------------------------
-// prepare (geometry only, so the host may run it beside the forward): thread per sample in
-// depth-major order -- the 64 lanes of a wave are 64 neighbouring pixels of one image row at one
-// depth and fall into a few cells, in runs.  Each sample's frustum point and floor taps are
-// evaluated exactly as the per-ray pass will (same inline chain, same bits); inside samples are
-// counted into their cell and take their rank there.  Device-scope atomics are served at the
-// memory side on this part (~1 us, and they are the bottleneck of this pass), so each run of
-// equal cells issues ONE atomic: the run head adds the run length and the lanes of the run take
-// base + position.
+// prepare (geometry + the termination table; the host runs it beside the forward): one workgroup per
+// 8 x 8 ray tile, the mapping of the per-ray pass -- the 64 lanes of a wave are the tile's rays at ONE
+// depth index and fall into a few cells, in runs.  The depth indices at which no ray of the tile can
+// be inside the volume (ray_plan.hpp: 64 % of all tile-steps at cfg-B) and those behind the tile's
+// last kept sample (early ray termination) are never visited: the pass costs what the kept samples
+// cost, not what the frustum holds (round 3 ran a thread per (ray, depth index): 5.7 M of them for
+// 0.33 M kept samples).  Each sample's frustum point and floor taps are evaluated exactly as the
+// per-ray pass will (same inline chain, same bits); inside samples are counted into their cell and
+// take their rank there.  Device-scope atomics are served at the memory side on this part (~1 us),
+// so each run of equal cells issues ONE atomic: the run head adds the run length and the lanes of
+// the run take base + position.  The per-ray pass turns (cell, rank) into the record slot itself.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 cam_cells_rank_kernel(RenderParams P, const float* __restrict__ mats, const float* __restrict__ us,
                       const float* __restrict__ vs, const float* __restrict__ ds,
-                      int* __restrict__ cnt, int* __restrict__ KEY, int* __restrict__ RANK,
-                      unsigned samples, long ncell_b, const int* __restrict__ term) {
-  const unsigned sidx = blockIdx.x * 256u + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  const unsigned HW = (unsigned) (P.fH * P.fW), S = (unsigned) (P.D - 1);
-  const unsigned sc = min(sidx, samples - 1);
-  const unsigned bn = sc / (S * HW);
-  const unsigned rem = sc % (S * HW);
-  const unsigned i = rem / HW, pix = rem % HW;
-  const unsigned h = pix / (unsigned) P.fW, w = pix % (unsigned) P.fW;
-  // early ray termination (render_common.hpp): samples from index term[ray] on carry no record;
-  // a wave (64 neighbouring pixels at one depth index) with none left skips the chain
-  const bool kept = sidx < samples && (!term || (int) i < term[bn * HW + pix]);
-  bool inside = false;
-  VolTap tp;
-  tp.ix0 = tp.iy0 = tp.iz0 = 0;
-  if (__ballot(kept) != 0ull) {
+                      int* __restrict__ cnt, int* __restrict__ RANK, long ncell_b,
+                      const int* __restrict__ term) {
+  __shared__ int4 plan[kPlanMax];
+  const RayId id = decode_ray_wps(P);
+  const int lane = threadIdx.x & 63, sub = id.sub;
+  const int S = P.D - 1;
+  const long bn = id.bn;
+  const float* m = mats + bn * 48;
+  const float u = us[id.w], v = vs[id.h];
+  const int keep = term ? term[(bn * P.fH + id.h) * P.fW + id.w] : S;
+  int Se = id.live ? keep : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) Se = max(Se, __shfl_xor(Se, o, 64));
+  Se = __builtin_amdgcn_readfirstlane(Se);
+  const bool planned = S <= kPlanMax;                              // uniform
+  PlanMask mk{~0ull, ~0ull};
+  if (planned) {
+    plan_tile(P, m, us, vs, ds, __builtin_amdgcn_readlane(id.w, 0), __builtin_amdgcn_readlane(id.w, 63),
+              __builtin_amdgcn_readlane(id.h, 0), __builtin_amdgcn_readlane(id.h, 63), sub, plan);
+    __syncthreads();
+    mk = plan_mask(plan);
+    mask_truncate(mk, Se);
+  }
+  // the active depth indices below Se, dealt to the four waves in turn
+  int k = 0;
+  for (int i = planned ? mask_next(mk, 0) : 0; i < (planned ? kPlanMax : Se); i = planned ? mask_next(mk, i + 1) : i + 1, ++k) {
+    if ((k & 3) != sub) continue;                                  // uniform
+    const bool kept = id.live && i < keep;
+    if (__ballot(kept) == 0ull) continue;
     float x, y, z;
-    frustum_point(mats + (long) bn * 48, us[w], vs[h], ds[i], x, y, z);
-    tp = volume_tap(P, nan_to_num_geom(x), nan_to_num_geom(y), nan_to_num_geom(z));
-    inside = tp.inside;
+    frustum_point(m, u, v, ds[i], x, y, z);
+    const VolTap tp = volume_tap(P, nan_to_num_geom(x), nan_to_num_geom(y), nan_to_num_geom(z));
+    const bool valid = kept && tp.inside;
+    const int key = valid ? pack_cell_key(tp.ix0, tp.iy0, tp.iz0) : 0;
+    const long cell = sample_cell(P, key, (unsigned) id.b, ncell_b);
+    const LaneRun r = lane_run(valid, cell, lane);
+    int base = 0;
+    if (r.head) base = atomicAdd(cnt + cell, r.len);
+    base = __shfl(base, valid ? r.start : lane, 64);
+    if (valid) RANK[(id.tile * S + i) * 64 + lane] = base + (lane - r.start);
   }
-  const bool valid = kept && inside;
-  const int key = valid ? pack_cell_key(tp.ix0, tp.iy0, tp.iz0) : 0;
-  const long cell = sample_cell(P, key, bn / (unsigned) P.N, ncell_b);
-  const LaneRun r = lane_run(valid, cell, lane);
-  int base = 0;
-  if (r.head) base = atomicAdd(cnt + cell, r.len);
-  base = __shfl(base, valid ? r.start : lane, 64);
-  if (sidx < samples) {
-    KEY[sidx] = key;
-    RANK[sidx] = base + (lane - r.start);
-  }
-}
-
-// after the scan: slot of every inside sample in the cell-ordered record array (-1: masked)
-__global__ void __launch_bounds__(256)
-cam_cells_slot_kernel(RenderParams P, const int* __restrict__ KEY, int* __restrict__ SLOT,
-                      const int* __restrict__ off, const int* __restrict__ boff, unsigned samples,
-                      long ncell_b) {
-  const unsigned sidx = blockIdx.x * 256u + threadIdx.x;
-  if (sidx >= samples) return;
-  const int key = KEY[sidx];
-  int slot = -1;
-  if (key != 0) {
-    const unsigned HW = (unsigned) (P.fH * P.fW), S = (unsigned) (P.D - 1);
-    const long cell = sample_cell(P, key, sidx / (S * HW) / (unsigned) P.N, ncell_b);
-    slot = boff[cell / kScanTile] + off[cell] + SLOT[sidx];          // SLOT holds the rank on entry
-  }
-  SLOT[sidx] = slot;
 }
 
 // U entries per lane per round (k, k + stride, ...): the record loads of a round go out
@@ -279,8 +274,8 @@ struct CellWs {
   int* boff;       // [ntile] exclusive scan of the tile totals
   int* aux;        // [ntile] scratch of the level-2 scan, then [ntile] = total, [ntile+1] = heavy count
   int* heavy;      // [voxels] queue
-  int* key;        // [samples] packed floor taps of the sample (0 = masked); scratch of prepare
-  int* slot;       // [samples] rank inside the cell, then slot in R (-1 = masked)
+  int* rank;       // [tiles][S][64] rank of the sample inside its cell (written for kept inside samples only)
+  int* slot;       // [tiles][S][64] slot in R (-1 = masked): the per-ray pass's note between its two loops
   float4* R;       // [samples][2] records in cell order
   size_t bytes;
 };
@@ -289,6 +284,8 @@ static CellWs cell_ws(const VampRenderDesc* d, void* scratch) {
   const long ncell = cell_count_padded(d->B, d->Z, d->Y, d->X);
   const long ntile = ncell / kScanTile;
   const size_t samples = (size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW;
+  // per-sample tables are indexed by 8 x 8 ray tile (ragged tiles padded)
+  const size_t tsamples = (size_t) d->B * d->N * ((d->fH + 7) / 8) * ((d->fW + 7) / 8) * 64 * (d->D - 1);
   const size_t voxels = (size_t) d->B * d->Z * d->Y * d->X;
   char* p = static_cast<char*>(scratch);
   CellWs w;
@@ -298,8 +295,8 @@ static CellWs cell_ws(const VampRenderDesc* d, void* scratch) {
   w.boff = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
   w.aux = reinterpret_cast<int*>(p); p += align_up((size_t) (ntile + 4) * sizeof(int), 256);
   w.heavy = reinterpret_cast<int*>(p); p += align_up(voxels * sizeof(int), 256);
-  w.key = reinterpret_cast<int*>(p); p += align_up(samples * sizeof(int), 256);
-  w.slot = reinterpret_cast<int*>(p); p += align_up(samples * sizeof(int), 256);
+  w.rank = reinterpret_cast<int*>(p); p += align_up(tsamples * sizeof(int), 256);
+  w.slot = reinterpret_cast<int*>(p); p += align_up(tsamples * sizeof(int), 256);
   w.R = reinterpret_cast<float4*>(p); p += align_up(samples * 2 * sizeof(float4), 256);
   w.bytes = (size_t) (p - static_cast<char*>(scratch));
   return w;
@@ -308,14 +305,19 @@ static CellWs cell_ws(const VampRenderDesc* d, void* scratch) {
 size_t cam_bwd_cell_bytes(const VampRenderDesc* d) { return cell_ws(d, nullptr).bytes; }
 
 // pointers the per-ray pass needs
-const int* cam_cell_slots(const VampRenderDesc* d, void* scratch) { return cell_ws(d, scratch).slot; }
-float4* cam_cell_records(const VampRenderDesc* d, void* scratch) { return cell_ws(d, scratch).R; }
+CamCellRefs cam_cell_refs(const VampRenderDesc* d, void* scratch) {
+  const CellWs w = cell_ws(d, scratch);
+  CamCellRefs r;
+  r.rank = w.rank; r.slot = w.slot; r.off = w.off; r.boff = w.boff; r.R = w.R;
+  r.ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
+  return r;
+}
 
 // rank -> scan -> slot.  Depends on (d, mats, us, vs, ds) only.
 static int launch_cam_heavy_list(const VampRenderDesc* d, const RenderParams& P, const CellWs& w, hipStream_t s);
 
 // phase 0: everything; 1: rank + scan (what needs the geometry and the termination table);
-// 2: slots + heavy list (needs the scan only) -- a caller may leave phase 2 to the backward
+// 2: heavy list (needs the scan only) -- a caller may leave phase 2 to the backward
 int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                              const float* us, const float* vs, const float* ds, void* scratch,
                              const int* term, int phase, hipStream_t s) {
@@ -326,18 +328,14 @@ int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, con
   VAMP_REQUIRE(samples > 0 && samples < 0x7fffffffu && voxels < 0x7fffffffu && ncell < 0x7fffffffL,
                "sample / voxel / cell count exceeds 2^31");
   const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
-  const unsigned sgrid = (unsigned) ((samples + 255) / 256);
   if (phase != 2) {
     if (int ze = launch_zero(w.cnt, (size_t) (ncell + kScanPad) * sizeof(int), s)) return ze;
-    VAMP_TIMED(kProfCamBwdCount, s, (cam_cells_rank_kernel<<<sgrid, 256, 0, s>>>(
-        P, mats, us, vs, ds, w.cnt, w.key, w.slot, (unsigned) samples, ncell_b, term)));
+    VAMP_TIMED(kProfCamBwdCount, s, (cam_cells_rank_kernel<<<ray_grid<4>(P), 256, 0, s>>>(
+        P, mats, us, vs, ds, w.cnt, w.rank, ncell_b, term)));
     if (int e = check_launch("cam_cells_rank_kernel")) return e;
     if (int e = launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, ncell, s)) return e;
   }
   if (phase == 1) return VAMP_OK;
-  VAMP_TIMED(kProfCamBwdFill, s, (cam_cells_slot_kernel<<<sgrid, 256, 0, s>>>(
-      P, w.key, w.slot, w.off, w.boff, (unsigned) samples, ncell_b)));
-  if (int e = check_launch("cam_cells_slot_kernel")) return e;
   return launch_cam_heavy_list(d, P, w, s);
 }
 

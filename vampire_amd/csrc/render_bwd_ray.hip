@@ -12,6 +12,7 @@
 //                gradient row (Gcl).
 //  The records are then gathered per voxel: render_bwd_cell.hip.
 #include "render_common.hpp"
+#include "cell_list.hpp"
 #include "pair_gather.hpp"
 
 namespace vamp {
@@ -29,7 +30,7 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
                    const T* __restrict__ dens, const T* __restrict__ sem, const T* __restrict__ rgbv,
                    const float* __restrict__ g_rgb,
                    const float* __restrict__ g_seg, const float* __restrict__ g_depth,
-                   const int* __restrict__ SLOT, float4* __restrict__ REC,
+                   CamCellRefs cells,
                    float* __restrict__ Gcl, float* __restrict__ beta_part,
                    const float* __restrict__ samples, const int* __restrict__ term, int L) {
   constexpr int CP = CP4 * 4;
@@ -45,6 +46,7 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
   __shared__ float xm[2 * 4 * 64];
   const RayId id = decode_ray_wps(P);
   const bool live = id.live;
+  float4* __restrict__ REC = cells.R;
   const int w = id.w, h = id.h, sub = id.sub, b = id.b;
   const long bn = id.bn;
   const long ray = (bn * P.fH + h) * P.fW + w;
@@ -97,12 +99,17 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
   if (i0 < i1) point(i0, px, py, pz);
   float cum = 0.f, A = 0.f, E1 = 1.f;
   for (int i = i0; i < i1; ++i) {
-    // the sample's slot in the cell-ordered record array (render_bwd_cell.hip: prepare), loaded
-    // ahead of the gather so that its latency hides behind it
-    const int slot = SLOT[((bn * S + i) * P.fH + h) * P.fW + w];
     point(i + 1, qx, qy, qz);
     VolTap tp = volume_tap(P, px, py, pz);
     tp.inside = tp.inside && i < keep;
+    // the sample's slot in the cell-ordered record array: start of its cell + the rank it drew in the
+    // prepare pass (render_bwd_cell.hip); requested ahead of the gather so that the latency hides behind it
+    const long sidx = (id.tile * S + i) * 64 + (tid & 63);
+    int slot = -1;
+    if (live && tp.inside) {
+      const long cell = key_to_cell(pack_cell_key(tp.ix0, tp.iy0, tp.iz0), P.Y, P.X, (unsigned) b, cells.ncell_b);
+      slot = cells.off[cell] + cells.boff[cell / kScanTile] + cells.rank[sidx];
+    }
     float s[CP];
 #pragma unroll
     for (int c = 0; c < CP; ++c) s[c] = 0.f;
@@ -170,9 +177,10 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
     // a sample passes gradient to s[0] only if it is inside and finite: flag in the sign
     l_dl[j * 256 + tid] = (tp.inside && fin) ? delta : -delta;
     l_q[j * 256 + tid] = qv;
-    if (live && tp.inside) {
+    if (live) {
       // the continuous tap coordinates go to the record now, the weights follow in the second loop
-      REC[2 * (long) slot] = make_float4(tp.fx, tp.fy, tp.fz, 0.f);
+      if (tp.inside) REC[2 * (long) slot] = make_float4(tp.fx, tp.fy, tp.fz, 0.f);
+      cells.slot[sidx] = slot;
     }
     px = qx; py = qy; pz = qz;
   }
@@ -199,7 +207,7 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
   float E2 = 1.f, prefix = 0.f, dbeta = 0.f;
   for (int i = i0; i < i1; ++i) {
     const int j = i - i0;
-    const int slot = SLOT[((bn * S + i) * P.fH + h) * P.fW + w];
+    const int slot = live ? cells.slot[(id.tile * S + i) * 64 + (tid & 63)] : -1;   // this thread's own note
     const float s0 = l_s0[j * 256 + tid];
     const float dl = l_dl[j * 256 + tid];
     const float qv = l_q[j * 256 + tid];
@@ -238,8 +246,7 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
 // ---------------------------------------------------------------------------
 // render_bwd_cell.hip
 size_t cam_bwd_cell_bytes(const VampRenderDesc* d);
-const int* cam_cell_slots(const VampRenderDesc* d, void* scratch);
-float4* cam_cell_records(const VampRenderDesc* d, void* scratch);
+CamCellRefs cam_cell_refs(const VampRenderDesc* d, void* scratch);
 int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                              const float* us, const float* vs, const float* ds, void* scratch,
                              const int* term, int phase, hipStream_t s);
@@ -285,8 +292,7 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
   // (cells_valid 1), or its rank + scan half (2: the slots and the heavy list follow here)
   if (cells_valid != 1)
     if (int e = launch_cam_cells_prepare(d, P, mats, us, vs, ds, cell_scratch, term, cells_valid == 2 ? 2 : 0, s)) return e;
-  const int* SLOT = cam_cell_slots(d, cell_scratch);
-  float4* R = cam_cell_records(d, cell_scratch);
+  const CamCellRefs cells = cam_cell_refs(d, cell_scratch);
   float* beta_part = reinterpret_cast<float*>(static_cast<char*>(cell_scratch) + cam_bwd_cell_bytes(d));
 
   constexpr int LPR = 4;
@@ -304,7 +310,7 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
       return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);                           \
     VAMP_TIMED(kProfCamBwd, s, (kr<<<grid, 256, lds, s>>>(P, mats, us, vs, ds, mids, beta,         \
         static_cast<const T*>(dens), static_cast<const T*>(sem), static_cast<const T*>(rgbv),     \
-        g_rgb, g_seg, g_depth, SLOT, R, Gcl, beta_part, samples, term, L)));                      \
+        g_rgb, g_seg, g_depth, cells, Gcl, beta_part, samples, term, L)));                      \
   } while (0)
 #define VAMP_RAY(CP4, KT)                                                                         \
   do {                                                                                            \

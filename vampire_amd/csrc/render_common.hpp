@@ -55,6 +55,7 @@ struct RayId {
   int w, h, sub;
   long bn;
   int b;
+  long tile;     // 8 x 8 ray tile of the ray (decode_ray_wps only): per-sample tables are [tile][depth index][64]
 };
 
 template <int LPR>
@@ -105,6 +106,7 @@ __device__ __forceinline__ RayId decode_ray_wps(const RenderParams& P) {
   RayId id;
   id.sub = threadIdx.x >> 6;
   const long tc = t < tiles ? t : tiles - 1;
+  id.tile = tc;
   id.bn = tc / (tiles_h * tiles_w);
   const int tt = (int) (tc % (tiles_h * tiles_w));
   id.h = (tt / tiles_w) * 8 + r / 8;
@@ -275,6 +277,16 @@ __device__ __forceinline__ void gather_taps(const RenderParams& P, const float* 
     }
   }
 }
+
+// what the per-ray pass of the camera backward needs of the cell lists (render_bwd_cell.hip)
+struct CamCellRefs {
+  const int* rank;      // [tiles][S][64] rank of a kept inside sample in its cell
+  int* slot;            // [tiles][S][64] scratch of the per-ray pass
+  const int* off;       // cell start = off[c] + boff[c / kScanTile]
+  const int* boff;
+  float4* R;            // [samples][2] records in cell order
+  long ncell_b;         // cells per sample of the batch
+};
 
 // parts of the camera backward a caller may issue separately (VAMP_CAMBWD_PART_*): the per-ray pass
 // (with the cell lists if they are not prepared), the per-voxel gather, the heavy-voxel kernel
