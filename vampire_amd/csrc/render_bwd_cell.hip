@@ -32,6 +32,8 @@ namespace vamp {
 #define VAMP_HEAVY 256
 #endif
 constexpr int kHeavy = VAMP_HEAVY;       // records per voxel beyond which the whole-workgroup kernel runs
+constexpr int kGatherLanes = 8;          // lanes per voxel of the gather
+constexpr int kRunVox = 256 / kGatherLanes;   // voxels (an x-run) per gather workgroup
 
 __device__ __forceinline__ long sample_cell(const RenderParams& P, int key, unsigned b, long ncell_b) {
   return key_to_cell(key, P.Y, P.X, b, ncell_b);
@@ -139,7 +141,7 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
                            const float4* __restrict__ R, const float* __restrict__ Gcl,
                            float* __restrict__ gdens, float* __restrict__ gsem,
                            float* __restrict__ grgb, long ncell_b, int runs_x, int heavy_thresh,
-                           int accumulate, BetaTail btail) {
+                           int accumulate, BetaTail btail, const int* __restrict__ runs) {
   constexpr int CP = CP4 * 4;
   constexpr int CVPB = 256 / CGL;
   beta_tail(btail);                     // the ray pass's d beta partials (a launch of its own before round 3)
@@ -149,6 +151,9 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
   const int g = tid / CGL, l = tid % CGL;
   // (giving each XCD a contiguous slab of x-runs instead of the round-robin deal measured 12 %
   // slower: the slabs next to the cameras carry most of the records)
+  // accumulate mode: only the flagged x-runs have anything to add (cam_heavy_list_kernel): one
+  // scalar load decides, instead of 512 offset loads and a barrier
+  if (runs && runs[blockIdx.x] == 0) return;
   const unsigned lin = blockIdx.x;
   const int bx = lin % (unsigned) runs_x;
   const unsigned rest = lin / (unsigned) runs_x;
@@ -274,6 +279,7 @@ struct CellWs {
   int* boff;       // [ntile] exclusive scan of the tile totals
   int* aux;        // [ntile] scratch of the level-2 scan, then [ntile] = total, [ntile+1] = heavy count
   int* heavy;      // [voxels] queue
+  int* runs;       // [x-runs] 1 = the gather's workgroup has something to add (accumulate mode)
   int* rank;       // [tiles][S][64] rank of the sample inside its cell (written for kept inside samples only)
   int* slot;       // [tiles][S][64] slot in R (-1 = masked): the per-ray pass's note between its two loops
   float4* R;       // [samples][2] records in cell order
@@ -295,6 +301,7 @@ static CellWs cell_ws(const VampRenderDesc* d, void* scratch) {
   w.boff = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
   w.aux = reinterpret_cast<int*>(p); p += align_up((size_t) (ntile + 4) * sizeof(int), 256);
   w.heavy = reinterpret_cast<int*>(p); p += align_up(voxels * sizeof(int), 256);
+  w.runs = reinterpret_cast<int*>(p); p += align_up((size_t) d->B * d->Z * d->Y * ((d->X + kRunVox - 1) / kRunVox) * sizeof(int), 256);
   w.rank = reinterpret_cast<int*>(p); p += align_up(tsamples * sizeof(int), 256);
   w.slot = reinterpret_cast<int*>(p); p += align_up(tsamples * sizeof(int), 256);
   w.R = reinterpret_cast<float4*>(p); p += align_up(samples * 2 * sizeof(float4), 256);
@@ -341,32 +348,49 @@ int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, con
 
 // Heavy list: the voxels whose eight cells hold more than kHeavy records, known as soon as the
 // cells are scanned -- so the list belongs to the prepare pass, and the kernel that drains it can
-// run beside the gather instead of behind it.
+// run beside the gather instead of behind it.  The same walk flags the gather's x-runs that hold at
+// least one voxel with records of its own: when the gather adds on top of the BEV branch's gradient
+// (the default) the workgroups of the other runs leave at once -- with early ray termination most of
+// the volume lies behind terminated rays.  (A compacted list of the runs instead of flags: 22 400
+// appends to one counter took 125 us when nothing terminates.)  Thread = voxel in the gather's own
+// (run, voxel) order.
 __global__ void __launch_bounds__(256)
 cam_heavy_list_kernel(RenderParams P, const int* __restrict__ off, const int* __restrict__ boff,
-                      int* __restrict__ heavy, int* __restrict__ nheavy, long ncell_b, long voxels,
-                      int thresh) {
-  const long v = (long) blockIdx.x * 256 + threadIdx.x;
-  if (v >= voxels) return;
-  const int ix = (int) (v % P.X), iy = (int) ((v / P.X) % P.Y), iz = (int) ((v / ((long) P.X * P.Y)) % P.Z);
-  const long b = v / ((long) P.X * P.Y * P.Z);
+                      int* __restrict__ heavy, int* __restrict__ nheavy, int* __restrict__ runs,
+                      long ncell_b, long total_runs, int runs_x, int thresh) {
+  const long run = (long) blockIdx.x * (256 / kRunVox) + threadIdx.x / kRunVox;
+  const bool run_ok = run < total_runs;
+  const long rc = run_ok ? run : total_runs - 1;
+  const int bx = (int) (rc % runs_x);
+  const long rest = rc / runs_x;
+  const int ix = bx * kRunVox + threadIdx.x % kRunVox, iy = (int) (rest % P.Y);
+  const long zb = rest / P.Y;
+  const int iz = (int) (zb % P.Z);
+  const long b = zb / P.Z;
   int tot = 0;
+  if (run_ok && ix < P.X) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const long c = b * ncell_b + ((long) (iz + (r >> 1)) * (P.Y + 1) + (iy + (r & 1))) * (P.X + 1) + ix;
-    tot += (off[c + 2] + boff[(c + 2) / kScanTile]) - (off[c] + boff[c / kScanTile]);
+    for (int r = 0; r < 4; ++r) {
+      const long c = b * ncell_b + ((long) (iz + (r >> 1)) * (P.Y + 1) + (iy + (r & 1))) * (P.X + 1) + ix;
+      tot += (off[c + 2] + boff[(c + 2) / kScanTile]) - (off[c] + boff[c / kScanTile]);
+    }
   }
-  if (tot > thresh) heavy[atomicAdd(nheavy, 1)] = (int) v;
+  if (tot > thresh) heavy[atomicAdd(nheavy, 1)] = (int) ((((long) b * P.Z + iz) * P.Y + iy) * P.X + ix);
+  static_assert(kRunVox == 32, "a run is half a wave");
+  const unsigned long long any = __ballot(tot > 0 && tot <= thresh);
+  const int lane = threadIdx.x & 63;
+  if ((lane & 31) == 0 && run_ok) runs[run] = ((any >> lane) & 0xffffffffull) != 0ull ? 1 : 0;
 }
 
 static int launch_cam_heavy_list(const VampRenderDesc* d, const RenderParams& P, const CellWs& w, hipStream_t s) {
   const long ncell = cell_count_padded(d->B, d->Z, d->Y, d->X);
   const long ntile = ncell / kScanTile;
-  const long voxels = (long) d->B * d->Z * d->Y * d->X;
   const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
+  const int runs_x = (d->X + kRunVox - 1) / kRunVox;
+  const long total_runs = (long) runs_x * d->Y * d->Z * d->B;
   int* nheavy = w.aux + ntile + 1;              // zeroed by the scan that just ran (runtime.hip)
-  VAMP_TIMED(kProfAux, s, (cam_heavy_list_kernel<<<(unsigned) ((voxels + 255) / 256), 256, 0, s>>>(
-      P, w.off, w.boff, w.heavy, nheavy, ncell_b, voxels, kHeavy)));
+  VAMP_TIMED(kProfAux, s, (cam_heavy_list_kernel<<<(unsigned) ((total_runs * kRunVox + 255) / 256), 256, 0, s>>>(
+      P, w.off, w.boff, w.heavy, nheavy, w.runs, ncell_b, total_runs, runs_x, kHeavy)));
   return check_launch("cam_heavy_list_kernel");
 }
 
@@ -380,11 +404,12 @@ int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const fl
   const size_t voxels = (size_t) d->B * d->Z * d->Y * d->X;
   const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
   const int* nheavy = w.aux + ntile + 1;
+  const int* runs = accumulate ? w.runs : nullptr;   // (overwrite mode: every run is stored)
 
   // measured at cfg-B (gather + heavy, us): 8 lanes 145 + 56, 16 lanes 173 + 56, 32 lanes 249 + 56;
   // threshold 128 / 256 / 512 with 8 lanes: 131 + 107, 145 + 56, 159 + 40 (round 1); after early ray
   // termination 68 + 37, 68 + 34, 91 + 33
-  constexpr int gl = 8;
+  constexpr int gl = kGatherLanes;
   const int heavy_thresh = kHeavy;
   const int vpb = 256 / gl;
   // the gradient buffers are first touched here: whoever else accumulates into them (the BEV
@@ -402,7 +427,7 @@ int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const fl
   do {                                                                                              \
     if (parts & kCamPartGather)                                                                     \
       VAMP_TIMED(kProfCamBwdBrick, s, (cam_bwd_cell_gather_kernel<CP4, gl><<<grid, 256, 0, s>>>(    \
-          P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, ncell_b, runs_x, heavy_thresh, accumulate, btail))); \
+          P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, ncell_b, runs_x, heavy_thresh, accumulate, btail, runs))); \
     if (parts & kCamPartHeavy)                                                                      \
       VAMP_TIMED(kProfCamBwdOwn, s, (cam_bwd_cell_heavy_kernel<CP4><<<hgrid, 256, 0, s>>>(          \
           P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, w.heavy, nheavy, ncell_b, accumulate)));   \

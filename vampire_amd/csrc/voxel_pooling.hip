@@ -149,7 +149,7 @@ PoolWs pool_ws(const VampPoolDesc* d, void* ws) {
   w.off = reinterpret_cast<int*>(take(w.ncell * sizeof(int)));
   w.bsum = reinterpret_cast<int*>(take(ntile * sizeof(int)));
   w.boff = reinterpret_cast<int*>(take(ntile * sizeof(int)));
-  w.aux = reinterpret_cast<int*>(take((ntile + 2) * sizeof(int)));
+  w.aux = reinterpret_cast<int*>(take((ntile + 4) * sizeof(int)));
   w.rank = reinterpret_cast<int*>(take((size_t) d->B * d->P * sizeof(int)));
   w.ids = reinterpret_cast<int*>(take((size_t) d->B * d->P * sizeof(int)));
   w.bytes = (size_t) (p - static_cast<char*>(ws));
