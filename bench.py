@@ -50,8 +50,8 @@ def kernel_algorithmic_bytes(cfg, B):
     zf = min(1.0, (oZ + 1) / cfg.vZ)                 # fraction of volume planes the det grid touches
     return {
         "lift_fwd": B * (4 * P * (D + C) + 4 * C * V),
-        "lift_bwd_fill": B * (4 * C * V + 8 * V + 4 * P * D),     # grad_out, hit words, depth in
-        "lift_bwd_gather": B * (4 * P * C + 4 * P * (D + C)),     # feat in, grad_depth / grad_feat out
+        "lift_bwd_fill": B * (4 * C * V + 8 * V),                 # grad_out, hit words in (round 4: no projection, no depth taps)
+        "lift_bwd_gather": B * (2 * 4 * P * (D + C)),             # depth, feat in; grad_depth / grad_feat out
         "pack_volume": B * (4 * cam * V),                         # the three volumes in
         "render_cam_fwd": B * (4 * cam * V + 4 * P * (K + 4)),
         "render_cam_term": B * (4 * V + 4 * P),                   # density volume in, one int per ray out
@@ -71,6 +71,7 @@ def kernel_algorithmic_bytes(cfg, B):
 STAGES = {   # SURVEY.md section 8(d) stage names -> kernels of this build
     "lift_fwd": ["feat_to_channel_last", "lift_fwd"],
     "render_fwd": ["pack_volume", "render_cam_term", "render_cam_fwd", "render_bev_fwd", "render_bev_fwd_channels"],
+    # (round 4: the count pass lives in lift_fwd; "lift_bwd_count" only appears when a backward runs without it)
     "lift_bwd": ["lift_bwd_count", "lift_bwd_fill", "lift_bwd_gather", "lift_bwd_v1", "feat_to_channel_first"],
     "render_bwd": ["render_cam_bwd_ray", "render_cam_bwd_rank", "render_cam_bwd_fill", "render_cam_bwd_gather",
                    "render_cam_bwd_heavy", "render_cam_bwd_v1", "render_bev_bwd_q", "render_bev_bwd_scan",
@@ -81,12 +82,19 @@ STAGES = {   # SURVEY.md section 8(d) stage names -> kernels of this build
 def measured_traffic(cfg_name, kernel, batch, run_kernels):
     """HBM bytes per launch from a committed rocprofv3 PMC run (profiles/traffic_*.json, made on
     the GPU box by tools/collect_profiles.sh + tools/summarize_profiles.py), or None when no run matches.
-    Only the NEWEST file is considered, and only if its kernel list is this run's (the profiler slots of
-    the eager one-stream step): a profile made before a kernel was added, removed or renamed is stale
-    and is refused rather than quoted."""
+    The files are tried newest first by the round tag in their NAME (file times are checkout times after a
+    clone), and one is used only if its kernel list is this run's (the profiler slots of the eager
+    one-stream step): a profile made before a kernel was added, removed or renamed is stale and is
+    refused rather than quoted."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")), key=os.path.getmtime, reverse=True)
-    for f in files[:1]:
+    import re
+
+    def tag(path):           # traffic_r03.json, traffic_r02d.json, traffic_r04_noert.json -> (round, suffix): newest first
+        m = re.search(r"traffic_r(\d+)([a-z]*)", os.path.basename(path))
+        return (int(m.group(1)), m.group(2)) if m else (-1, "")
+    files = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")) if "noert" not in f),
+                   key=tag, reverse=True)
+    for f in files:
         try:
             with open(f) as fh:
                 t = json.load(fh)
@@ -373,6 +381,71 @@ def capture_step(model, batch, train_step):
     return g
 
 
+class OverlappedBetaSync:
+    """The DDP all-reduce of the path's one parameter gradient around a REPLAYED step.  The captured step
+    holds no collective; after replay k the gradient is copied to a side buffer (4 bytes) and its
+    all-reduce is launched asynchronously on RCCL's stream, where it runs under replay k + 1 (whose
+    backward rewrites beta.grad); it is joined -- a stream wait, the host does not block -- before the
+    next copy, and once more at the end of the timed region.  The headline therefore times replays with
+    an overlapped collective, not replay + a serialized 4-byte RCCL latency."""
+
+    def __init__(self, model, world):
+        self.model, self.world, self.work, self.buf = model, world, None, None
+
+    def after_replay(self):
+        if self.world <= 1 or self.model.beta.grad is None:
+            return
+        if self.work is not None:
+            self.work.wait()
+        if self.buf is None:
+            self.buf = torch.empty_like(self.model.beta.grad)
+        self.buf.copy_(self.model.beta.grad)
+        self.work = dist.all_reduce(self.buf, async_op=True)      # sum (gloo has no AVG); the mean at the join
+
+    def join(self):
+        if self.work is not None:
+            self.work.wait()
+            self.model.beta.grad.copy_(self.buf / self.world)
+            self.work = None
+
+
+def replay_rate(model, batch, train_step, steps, world, dev, vdist):
+    """`steps` steps of `batch` under the headline's protocol -- the step replayed from a HIP graph (all ranks,
+    or none), overlapped beta all-reduce, barrier + synchronize on both sides, max over ranks -- for a
+    secondary batch size.  Returns (seconds, launch mode)."""
+    graph = None
+    if os.environ.get("VAMP_BENCH_GRAPH", "1") == "1":
+        try:
+            graph = capture_step(model, batch, train_step)
+        except Exception as e:                          # noqa: BLE001
+            print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); timing eager steps", file=sys.stderr)
+    if world > 1:
+        ok = torch.tensor([1.0 if graph is not None else 0.0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) == 0.0:
+            graph = None
+    sync = OverlappedBetaSync(model, world)
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            model.zero_grad(set_to_none=True)
+            train_step(model, batch)
+        sync.after_replay()
+
+    for _ in range(3):
+        step()
+    sync.join()
+    vdist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync.join()
+    vdist.barrier(); torch.cuda.synchronize()
+    return vdist.max_over_ranks(time.perf_counter() - t0, dev), ("hip_graph" if graph is not None else "eager")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -385,10 +458,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary configurations (extra_configs)")
     ap.add_argument("--no-matrix", action="store_true",
                     help="skip the {eager, graph} x {early termination on, off} step matrix (profile runs: only default-path kernels)")
-    ap.add_argument("--multitask", action="store_true",
-                    help="also time the full multi-task step of BASELINE configs[4] (R50 encoder, BEV head, 9 losses; bf16 autocast)")
-    ap.add_argument("--layers", action="store_true",
-                    help="also time the step wrapped with the backbone's own layers (always done when --gpus > 1)")
+    ap.add_argument("--multitask", action="store_true", help="(accepted for compatibility: the multi-task step is always timed unless --no-extra)")
+    ap.add_argument("--layers", action="store_true", help="(accepted for compatibility: the layered step is always timed unless --no-extra)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -485,21 +556,23 @@ def main():
         if float(ok.item()) == 0.0:
             graph, launch_mode = None, "eager"
 
+    beta_sync = OverlappedBetaSync(model, world)
+
     def graph_step():
         graph.replay()
-        if world > 1:
-            dist.all_reduce(model.beta.grad)        # sum (gloo has no AVG), then the mean
-            model.beta.grad.div_(world)
+        beta_sync.after_replay()                    # asynchronous: runs under the next replay
 
     timed_step = graph_step if graph is not None else one_step
     for _ in range(3):
         timed_step()
+    beta_sync.join()
     fence()
     if graph is None:
         _capi.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         timed_step()
+    beta_sync.join()
     fence()
     elapsed = time.perf_counter() - t0
     _capi.profile_enable(False)
@@ -518,6 +591,15 @@ def main():
     _capi.profile_select(None)
     fwd_med, fwd_p10, fwd_p90 = forward_pair_us(model, batch) if rank == 0 else (0.0, 0.0, 0.0)
     fwd_graph = forward_pair_graph_us(model, batch) if (rank == 0 and os.environ.get("VAMP_BENCH_GRAPH", "1") == "1") else None
+    # the same pair with early ray termination OFF: the data-independent forward (every inside sample marched)
+    fwd_off, fwd_off_graph = None, None
+    if rank == 0 and not a.no_matrix:
+        ert_default = model.hp.impl["ert"]
+        model.hp.impl["ert"] = False
+        fwd_off = forward_pair_us(model, batch, iters=50, warm=10)
+        if os.environ.get("VAMP_BENCH_GRAPH", "1") == "1":
+            fwd_off_graph = forward_pair_graph_us(model, batch, iters=50, warm=10)
+        model.hp.impl["ert"] = ert_default
 
     # {HIP graph, eager launches} x {early ray termination on, off}: the headline is the best case on
     # both axes (the termination gain is data-dependent), so the line carries all four (N = 1 only:
@@ -555,9 +637,21 @@ def main():
         ert_stats = {"inside_samples": inside, "kept_samples": kept,
                      "terminated_fraction": round(1.0 - kept / max(1, inside), 4)}
 
-    # with more than one rank (or --layers) also the step with a real gradient bucket
-    layered = layered_measure(cfg, dev, a.batch, rank, world) if (world > 1 or a.layers) else None
-    multitask = multitask_measure(dev, a.batch, rank, world) if a.multitask else None
+    # the same workload at 8 samples per GPU per step under the headline's protocol, so that the
+    # driver's N = 1, 2, 4, 8 runs also carry a weak-scaling curve that is not bounded by the latency of a
+    # collective against a half-millisecond step (configs[2] itself is bs = 1 per GPU: the headline)
+    bs8 = None
+    if not a.no_extra and a.batch != 8:
+        batch8 = SyntheticBatch(cfg, 8, dev, seed=vdist.shard_seed(1, rank), dtype=dtype)
+        el8, mode8 = replay_rate(model, batch8, train_step, a.steps, world, dev, vdist)
+        bs8 = {"value": 8 * world * a.steps / el8, "unit": "samples/s", "ms_per_step": el8 / a.steps * 1e3,
+               "per_gpu_batch": 8, "global_batch": 8 * world, "n_gpus": world, "steps": a.steps, "launch": mode8,
+               "scaling": "weak"}
+        del batch8
+    # SURVEY 8(e) / BASELINE configs[4]: the step with a real gradient bucket and the full multi-task step,
+    # always in the line (a few seconds; --no-extra skips them for profile runs)
+    layered = layered_measure(cfg, dev, a.batch, rank, world) if not a.no_extra else None
+    multitask = multitask_measure(dev, a.batch, rank, world) if not a.no_extra else None
 
     prof = dict(warm)
     # the dominant kernel: measured over the timed region
@@ -632,8 +726,19 @@ def main():
                              "eager_one_stream_us": fwd_med, "eager_p10_us": fwd_p10, "eager_p90_us": fwd_p90,
                              "eager_frac": fwd_bytes / (fwd_med * 1e-6) / 1e9 / HBM_PEAK_GBS,
                              "kernel_sum_us": fwd_kernel_sum_us, "algorithmic_bytes": fwd_bytes},
+            "fwd_roofline_ert_off": (None if fwd_off is None else {
+                "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes": fwd_bytes,
+                "fused_fwd_us": (fwd_off_graph or fwd_off)[0],
+                "achieved": fwd_bytes / ((fwd_off_graph or fwd_off)[0] * 1e-6) / 1e9,
+                "frac": fwd_bytes / ((fwd_off_graph or fwd_off)[0] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "eager_one_stream_us": fwd_off[0], "eager_frac": fwd_bytes / (fwd_off[0] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "iters": 50, "warmup": 10,
+                "what": "the same forward pair with early ray termination OFF: every inside sample is marched (data-independent)"}),
             "stages": stages,
             "step_matrix": step_matrix,
+            "step_matrix_note": "graph_* = device-bound (replayed launches); eager_* depend on the HOST's launch rate "
+                                "(~35 launches and two stream joins per step) and vary between boxes",
+            "weak_scaling_bs8": bs8,
             "layered_step": layered,
             "multitask_step": multitask,
             "early_ray_termination": ert_stats,

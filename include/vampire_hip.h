@@ -382,6 +382,7 @@ int vamp_render_bev_forward(const VampRenderDesc* d, const float* oxs, const flo
  * same workspace with VAMP_BEVBWD_SAVED_VALID reads them back instead of sampling again.
  */
 #define VAMP_BEVFWD_SAVE 1
+#define VAMP_BEVFWD_HEIGHTS_LATTICE 4  /* the caller asserts that ozs is an ascending lattice with spacing det_step[2] (what the reference's create_voxel_coords makes, bv2:273-293): only then does the one-kernel forward run -- it sizes its per-wave plane slab from that spacing; any other array takes the two-kernel path */
 #define VAMP_BEVFWD_TWO_KERNELS 2   /* the first implementation (density pass + channel-pair pass) instead of the one-kernel forward of render_bev_fused.hip: kept as the cross-check of the tests */
 int vamp_render_bev_forward_ex(const VampRenderDesc* d, const float* oxs, const float* oys,
                             const float* ozs, const float* bev_mids, const float* beta,
@@ -441,6 +442,18 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
 int vamp_render_indices(const VampRenderDesc* d, const float* geom, const float* mats,
                         const float* us, const float* vs, const float* ds, uint8_t* inside,
                         int16_t* ix0, int16_t* iy0, int16_t* iz0, void* stream);
+
+/*
+ * The same diagnostic for the one-kernel camera forward (render_cam_direct.hip): inside mask and floor
+ * taps of every sample [B, N, D-1, fH, fW] as THAT kernel evaluates them (its sample coordinates come
+ * from an fp64 line per ray with a wave-level fallback to the fp32 chain of bv2:328-349 next to the
+ * faces of the volume); fxyz (may be NULL) [B, N, D-1, fH, fW, 3] receives the continuous tap
+ * coordinates.  The mask is the reference's bit for bit; a floor tap can differ from the reference's
+ * where a coordinate lies within ~1e-5 of an integer (the trilinear sample is continuous there).
+ */
+int vamp_render_camera_direct_taps(const VampRenderDesc* d, const float* mats, const float* us,
+                                   const float* vs, const float* ds, uint8_t* inside, int16_t* ix0,
+                                   int16_t* iy0, int16_t* iz0, float* fxyz, void* stream);
 
 /* get_geometry (bv2:314-349) + nan_to_num(-1e3) (bv2:612): geom [B,N,D,fH,fW,3]. */
 int vamp_frustum_geometry(const VampRenderDesc* d, const float* mats, const float* us,

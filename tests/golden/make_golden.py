@@ -453,6 +453,114 @@ def make_regimes(BaseVAMPIRE2):
         json.dump(res, f)
 
 
+def strided_sample(t, n=10000):
+    """`n` elements of the flattened tensor at a fixed stride (tests rebuild the same index set)."""
+    f = t.detach().float().flatten()
+    stride = max(1, f.numel() // n)
+    return f[::stride][:n].clone(), stride
+
+
+def make_full_samples(BaseVAMPIRE2):
+    """Elementwise pins at full size (VERDICT r03 #5b): 10 000 strided ELEMENTS of each of the eight render
+    outputs, the four volume gradients, the lift output and its two gradients -- cfg-A and cfg-B, sdf
+    density, same inputs / seeds as make_full_grads -- and of the render outputs under
+    density_mode="naive" at cfg-B.  Block sums localise an error; these bound it per element."""
+    from vampire_amd.config import CFG_A, CFG_B
+    from vampire_amd import synthetic
+    out = {}
+    with open(os.path.join(HERE, "full_grad_checksums.json")) as f:
+        grads_ref = json.load(f)
+    for name, cfg, mode in (("A", CFG_A, "sdf"), ("B", CFG_B, "sdf"), ("Bnaive", CFG_B, "naive")):
+        m = ref_module(BaseVAMPIRE2, cfg, mode, False)
+        s2e, K, ida = synthetic.camera_rig(cfg, 1)
+        bda = synthetic.bda_matrix(1)
+        mats = dict(sensor2ego_mats=s2e[:, None], intrin_mats=K[:, None], ida_mats=ida[:, None], bda_mat=bda)
+        if mode == "sdf":
+            depth, feat = synthetic.lift_inputs(cfg, 1, seed=0)
+            d_ = depth.clone().requires_grad_(True)
+            f_ = feat.clone().requires_grad_(True)
+            vox = m.get_voxel_feats(d_.unsqueeze(2) * f_.unsqueeze(3), 0, mats)       # bv2:553, 563
+            (g_vox,) = upstream_grads([vox.shape], grads_ref[name]["seed_lift"])
+            g_vox.view(-1)[grads_ref[name]["lift_upstream_zero_idx"]] = 0.0
+            vox.backward(g_vox)
+            for key, t in (("lift", vox), ("grad_depth", d_.grad), ("grad_feat", f_.grad)):
+                out[f"{name}_{key}"], out[f"{name}_{key}_stride"] = strided_sample(t)
+            del vox, d_, f_, g_vox
+        vols = synthetic.render_inputs(cfg, 1, seed=0)
+        with torch.no_grad():
+            geom = torch.nan_to_num(m.get_geometry(s2e, K, ida, bda), -1e3)        # bv2:612
+        v_ = [t.clone().requires_grad_(True) for t in vols]
+        r = m.volume_rendering_from_multiple_views(geom, *v_)
+        g_r = upstream_grads([t.shape for t in r], 4343 if mode == "sdf" else 4545)
+        torch.autograd.backward(r, g_r)
+        for n_, t in zip(RENDER_NAMES, r):
+            out[f"{name}_{n_}"], out[f"{name}_{n_}_stride"] = strided_sample(t)
+        for n_, t in zip(["density_feature", "semantic_logits", "base", "rgb"], v_):
+            out[f"{name}_grad_{n_}"], out[f"{name}_grad_{n_}_stride"] = strided_sample(t.grad)
+        print("samples", name, "done", flush=True)
+        del r, v_, g_r, geom
+    path = os.path.join(HERE, "full_samples.npz")
+    np.savez_compressed(path, **{k: (v.numpy() if torch.is_tensor(v) else np.int64(v)) for k, v in out.items()})
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def make_smooth(BaseVAMPIRE2):
+    """Two more tiny render fixtures (VERDICT r03 #5c, #5d), sdf density, no cat_seg, on tiny_common's rig:
+      tiny_render_smooth.npz     SMOOTH volumes (low-frequency sinusoids instead of white noise): what real
+                                 feature volumes look like, and the case in which a deviation of the sample
+                                 coordinates shows up as a bias instead of averaging out;
+      tiny_render_nonaffine.npz  white-noise volumes with an `ida` whose first two rows depend on the depth
+                                 (ida[0][2], ida[1][2] != 0): get_geometry is then not affine in the depth --
+                                 no augmentation of the reference produces it, the API accepts it."""
+    from vampire_amd.config import CFG_TINY as cfg
+    from vampire_amd import synthetic
+    from vampire_amd.geometry import render_matrices
+    B = 2
+    s2e, K, ida = tiny_rig(cfg, B)
+    bda = torch.cat([synthetic.bda_matrix(1), synthetic.bda_matrix(1, rot_deg=10.0, scale=1.05, flip_dx=True)], 0)
+    dens, sem, base, rgb = synthetic.render_inputs(cfg, B, seed=11)
+    zz, yy, xx = torch.meshgrid(torch.linspace(0, 1, cfg.vZ), torch.linspace(0, 1, cfg.vY),
+                                torch.linspace(0, 1, cfg.vX), indexing="ij")
+
+    def smooth(like, seed):
+        gg = torch.Generator().manual_seed(seed)
+        ch = like.shape[1]
+        ph = torch.rand(B, ch, 3, generator=gg) * 6.2832
+        fr = 1.0 + 2.0 * torch.rand(B, ch, 3, generator=gg)
+        v = (torch.sin(fr[..., 0, None, None, None] * 3.1416 * xx + ph[..., 0, None, None, None])
+             * torch.cos(fr[..., 1, None, None, None] * 3.1416 * yy + ph[..., 1, None, None, None])
+             + 0.5 * torch.sin(fr[..., 2, None, None, None] * 3.1416 * zz + ph[..., 2, None, None, None]))
+        return v.float().contiguous()
+
+    g = torch.Generator().manual_seed(9)
+    for tag in ("smooth", "nonaffine"):
+        m = ref_module(BaseVAMPIRE2, cfg, "sdf", False)
+        ida_t = ida.clone()
+        if tag == "smooth":
+            vols0 = [0.8 * smooth(dens, 1) - 1.0, smooth(sem, 2), 0.5 * smooth(base, 3), 0.5 + 0.4 * smooth(rgb, 4) / 1.5]
+        else:
+            vols0 = [dens, sem, base, rgb]
+            ida_t[:, :, 0, 2] = 0.35
+            ida_t[:, :, 1, 2] = -0.2
+        with torch.no_grad():
+            geom = torch.nan_to_num(m.get_geometry(s2e, K, ida_t, bda), -1e3)
+        vols = [t.clone().requires_grad_(True) for t in vols0]
+        r = m.volume_rendering_from_multiple_views(geom, *vols)
+        g_r = [torch.randn(t.shape, generator=g) for t in r]
+        torch.autograd.backward(r, g_r)
+        out = dict(render_mats=render_matrices(s2e, K, ida_t, bda), geom=geom,
+                   density_feature=vols0[0], semantic_logits=vols0[1], base=vols0[2], rgb=vols0[3],
+                   beta=m.density.beta.detach().reshape(1), grad_beta=m.density.beta.grad.reshape(1))
+        for n_, t, gt in zip(RENDER_NAMES, r, g_r):
+            out[n_] = t
+            out["g_" + n_] = gt
+        for n_, t in zip(["density_feature", "semantic_logits", "base", "rgb"], vols):
+            out["grad_" + n_] = t.grad
+        path = os.path.join(HERE, f"tiny_render_{tag}.npz")
+        np.savez_compressed(path, **{k: v.detach().cpu().numpy() for k, v in out.items()})
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB", flush=True)
+
+
 def make_points(BaseVAMPIRE2):
     """SURVEY 8f N1.  bv2:576-609 is inline in _forward_single_sweep; the statements are replayed
     on the reference module's own state (occ_coords, density, bounds)."""
@@ -592,12 +700,20 @@ if __name__ == "__main__":
     if "--regimes-only" in sys.argv:
         make_regimes(V2)
         sys.exit(0)
+    if "--samples-only" in sys.argv:
+        make_full_samples(V2)
+        sys.exit(0)
+    if "--smooth-only" in sys.argv:
+        make_smooth(V2)
+        sys.exit(0)
     make_tiny(V2, BL)
     make_glue(V2)
     make_hourglass(V2)
     make_points(V2)
+    make_smooth(V2)
     if "--tiny-only" not in sys.argv:
         make_full(V2)
         make_full_grads(V2)
         make_cfg_d(V2)
         make_regimes(V2)
+        make_full_samples(V2)

@@ -195,3 +195,46 @@ def test_layered_step_parameter_count():
     from vampire_amd.step import LayeredStep
     m = LayeredStep(CFG_A, "cpu", hot_path=object())
     assert sum(p.numel() for p in m.parameters()) == 777111
+
+
+def _partial_bucket_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.nn as nn
+    from vampire_amd import dist as vdist
+    vdist.init("gloo")
+
+    class Two(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.used = nn.Parameter(torch.ones(3))
+            self.unused = nn.Parameter(torch.ones(3))
+
+        def forward(self, x):
+            return (self.used * x).sum()
+
+    sync = vdist.GradSync(Two())                      # both parameters share one bucket
+    assert len(sync._buckets) == 1
+    try:
+        sync(torch.arange(3.0) + rank).backward()
+        out[rank] = "no error"
+    except RuntimeError as e:
+        out[rank] = str(e)
+    # the wrapper is clean again afterwards
+    assert not sync._pending and not sync._joining and not any(sync._ready)
+    vdist.shutdown()
+
+
+def test_gradsync_raises_on_partially_reduced_bucket():
+    """a bucket in which only some parameters received a gradient must not be skipped
+    silently (the others would stay rank-local): GradSync raises, naming the parameter."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = mp.Manager().dict()
+    mp.spawn(_partial_bucket_worker, args=(2, port, out), nprocs=2, join=True)
+    for r in (0, 1):
+        assert "unused" in out[r] and "no gradient" in out[r], out[r]

@@ -1649,3 +1649,117 @@ def test_round3_entry_points_reject_bad_arguments(dev):
     # the library is still usable afterwards
     out = voxel_pooling(torch.zeros(1, 1, 1, 2, 2, 3, dtype=torch.int32, device=dev), torch.ones(1, 1, 1, 2, 2, 4, device=dev), (4, 4, 1))
     assert float(out[0, :, 0, 0].sum()) == 16.0
+
+
+# --------------------------------------------------------------------------- round 4: the one-kernel camera forward, pinned directly
+@pytest.mark.parametrize("name,cfg,golden", [("A", CFG_A, "full_checksums.json"), ("B", CFG_B, "full_checksums.json"),
+                                             ("D", None, "cfgd_checksums.json")])
+def test_direct_kernel_taps_full_size(dev, name, cfg, golden):
+    """The taps of cam_fwd_direct_kernel ITSELF (vamp_render_camera_direct_taps runs the kernel's own
+    direct_tap in the kernel's own wave composition), not of its sibling vamp_render_indices: the inside
+    mask is the reference's bit for bit (sha256 of all 5.7 M / 23 M samples); the floor taps of the inside
+    samples equal the reference's except where the fp64 ray line and the reference's fp32 chain fall on
+    two sides of an integer -- there the coordinate is within 1e-4 of that integer (the trilinear sample is
+    continuous across it) and such samples are fewer than 1 in 10 000."""
+    if cfg is None:
+        from vampire_amd.config import CFG_D as cfg
+    with open(os.path.join(GOLDEN, golden)) as f:
+        ref = json.load(f)[name]
+    hp = hot(cfg, dev)
+    rm = torch.tensor(ref["render_mats"], dtype=torch.float32, device=dev)
+    inside_d, dx, dy, dz, fxyz = hp.render_direct_taps(rm, coords=True)
+    assert int(inside_d.sum()) == ref["render_inside_count"] and _sha(inside_d) == ref["render_inside_sha256"]
+    inside, rx, ry, rz = hp.render_indices(render_mats=rm)        # hash-equal to the reference (test_full_size_checksums)
+    for nm, t in (("ix0", rx), ("iy0", ry), ("iz0", rz)):
+        assert _sha(t) == ref[f"render_{nm}_sha256"], nm
+    m = inside.bool()
+    n_in = int(m.sum())
+    for axis, (a, b) in enumerate(((dx, rx), (dy, ry), (dz, rz))):
+        bad = m & (a != b)
+        nbad = int(bad.sum())
+        assert nbad <= 1e-4 * n_in, (axis, nbad, n_in)
+        if nbad:
+            f = fxyz[..., axis][bad]
+            assert float((f - f.round()).abs().max()) <= 1e-4, axis
+            assert int((a[bad].int() - b[bad].int()).abs().max()) == 1, axis
+
+
+def _sample_check(t, ref, key, what, rtol=1e-4, atol=0.0):
+    """10 000 strided ELEMENTS of a full-size tensor against the reference's (make_golden.strided_sample):
+    every element within rtol of the sample's largest magnitude (+ atol)."""
+    want = ref[key].float()
+    stride = int(ref[key + "_stride"])
+    got = t.detach().float().flatten()[::stride][:want.numel()].cpu()
+    assert got.numel() == want.numel(), what
+    err = (got - want).abs()
+    lim = atol + rtol * float(want.abs().max())
+    assert float(err.max()) <= lim, f"{what}: max element error {float(err.max()):.3e} > {lim:.3e}"
+    return float(err.max()) / max(float(want.abs().max()), 1e-30)
+
+
+@pytest.mark.parametrize("name,cfg,mode", [("A", CFG_A, "sdf"), ("B", CFG_B, "sdf"), ("Bnaive", CFG_B, "naive")])
+def test_full_size_elementwise_samples(dev, name, cfg, mode):
+    """The DEFAULT path (one-kernel camera forward, fused BEV forward, cell-list backward) at cfg-A / cfg-B,
+    element by element: 10 000 strided elements of each of the eight render outputs, the four volume
+    gradients, the lift output and its two gradients against the reference run here on CPU
+    (tests/golden/full_samples.npz, make_golden.py --samples-only) -- every element within 1e-4 of the
+    tensor's scale (north_star's bar), where the block-sum tests only bound averages."""
+    ref = load_golden("full_samples.npz")
+    with open(os.path.join(GOLDEN, "full_checksums.json")) as f:
+        mats = json.load(f)[name[0]]
+    with open(os.path.join(GOLDEN, "full_grad_checksums.json")) as f:
+        gref = json.load(f)[name[0]]
+    cfg = dataclasses.replace(cfg, density_mode=mode)
+    hp = hot(cfg, dev)
+    assert hp.impl["cam_direct"] and hp.impl["bev_fused"] and hp.impl["ert"]
+    lm = torch.tensor(mats["lift_mats"], dtype=torch.float32, device=dev)
+    rm = torch.tensor(mats["render_mats"], dtype=torch.float32, device=dev)
+    worst = {}
+    if mode == "sdf":
+        depth, feat = synthetic.lift_inputs(cfg, 1, seed=0, device=dev)
+        depth.requires_grad_(True); feat.requires_grad_(True)
+        vox = hp.lift(depth, feat, lm)
+        g_vox = _upstream([vox.shape], gref["seed_lift"], dev)[0]
+        g_vox.view(-1)[gref["lift_upstream_zero_idx"]] = 0.0
+        vox.backward(g_vox)
+        worst["lift"] = _sample_check(vox, ref, f"{name}_lift", "lift", rtol=1e-5)
+        worst["grad_depth"] = _sample_check(depth.grad, ref, f"{name}_grad_depth", "grad_depth")
+        worst["grad_feat"] = _sample_check(feat.grad, ref, f"{name}_grad_feat", "grad_feat")
+    vols = [v.requires_grad_(True) for v in synthetic.render_inputs(cfg, 1, seed=0, device=dev)]
+    beta = torch.tensor(gref["beta"], device=dev, requires_grad=True) if mode == "sdf" else None
+    outs = hp.render(*vols, beta, render_mats=rm)
+    torch.autograd.backward(outs, _upstream([o.shape for o in outs], 4343 if mode == "sdf" else 4545, dev))
+    for n_, o in zip(NAMES, outs):
+        worst[n_] = _sample_check(o, ref, f"{name}_{n_}", n_)
+    for k, v in zip(("density_feature", "semantic_logits", "base", "rgb"), vols):
+        worst["grad_" + k] = _sample_check(v.grad, ref, f"{name}_grad_{k}", "grad_" + k)
+    print(f"cfg-{name} worst element error / scale:", {k: f"{v:.1e}" for k, v in worst.items()})
+
+
+@pytest.mark.parametrize("tag", ["smooth", "nonaffine"])
+@pytest.mark.parametrize("direct", [True, False], ids=["direct", "planned"])
+def test_render_smooth_and_nonaffine_fixtures(dev, tag, direct):
+    """Two more reference fixtures for the camera forward (tests/golden/make_golden.py: make_smooth):
+    SMOOTH volumes, where a deviation of the sample coordinates is a bias and does not average out as on
+    white noise (the one-kernel forward must stay an order under the 1e-4 bar there), and an `ida` that
+    makes get_geometry non-affine in the depth (bv2:334-338) -- the one-kernel forward then marches
+    every bin with its own length (render_cam_direct.hip: delta_at)."""
+    r = load_golden(f"tiny_render_{tag}.npz")
+    cfg = dataclasses.replace(CFG_TINY, density_mode="sdf", cat_seg=False)
+    hp = hot(cfg, dev)
+    hp.impl["cam_direct"] = direct
+    rm = r["render_mats"].to(dev)
+    vols = [r[k].to(dev).requires_grad_(True) for k in ("density_feature", "semantic_logits", "base", "rgb")]
+    beta = r["beta"].reshape(()).to(dev).requires_grad_(True)
+    outs = hp.render(*vols, beta, render_mats=rm)
+    tol = 2e-5 if tag == "smooth" else 1e-4
+    for n_, o in zip(NAMES, outs):
+        close(o, r[n_], atol=tol, rtol=tol, scale="max", what=f"{tag} {n_}")
+    torch.autograd.backward(outs, [r["g_" + n].to(dev) for n in NAMES])
+    for k, v in zip(("density_feature", "semantic_logits", "base", "rgb"), vols):
+        close(v.grad, r["grad_" + k], atol=1e-5, rtol=1e-4, scale="max", what=f"{tag} grad_{k}")
+    close(beta.grad.reshape(1), r["grad_beta"], atol=1e-3, rtol=1e-3, what=f"{tag} grad_beta")
+    with torch.no_grad():                                  # forward-only call: same values
+        outs2 = hp.render(*[v.detach() for v in vols], beta.detach(), render_mats=rm)
+    for a, b in zip(outs, outs2):
+        close(a, b, atol=1e-6, rtol=1e-6, scale="max", what=f"{tag} no-grad forward")

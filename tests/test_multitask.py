@@ -258,17 +258,18 @@ def test_multitask_step_end_to_end_cpu():
 
 
 # ----------------------------------------------------------------------------- data parallel (gloo, world size 2)
-def _mt_worker(rank, world, port, out):
+def _mt_worker(rank, world, port, out, mode):
     import dataclasses as dc
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port), VAMP_GRAD_SYNC="ddp")
+                      MASTER_PORT=str(port), VAMP_GRAD_SYNC=mode)
     torch.set_num_threads(2)
     from vampire_amd import dist as vdist
     cfg = dc.replace(CFG_TINY, density_mode="sdf", final_dim=(192, 224), num_classes=6)
     vdist.init("gloo")
     model = _tiny_model(cfg)                                   # same seed -> same weights on both ranks
     ddp = vdist.wrap_ddp(model)
+    assert isinstance(ddp, vdist.GradSync) == (mode == "hook")
     batch = M.synthetic_batch(cfg, 1, seed=vdist.shard_seed(0, rank), num_points=40, num_boxes=6)
     loss_fn = M.MultiTaskLoss(ddp, sdf_bias=cfg.sdf_bias)
     loss = M.multitask_step(ddp, loss_fn, batch, amp_dtype=None)
@@ -277,9 +278,11 @@ def _mt_worker(rank, world, port, out):
     vdist.shutdown()
 
 
-def test_two_rank_multitask_step_gloo():
-    """configs[4] data-parallel on two gloo ranks (different shards): the ranks end the step with the same
-    all-reduced gradients; the detection loss normalises by the cross-rank mean of positives
+@pytest.mark.parametrize("mode", ["hook", "ddp"])
+def test_two_rank_multitask_step_gloo(mode):
+    """configs[4] data-parallel on two gloo ranks (different shards), under the bucketed GradSync (the
+    default) and under DistributedDataParallel: the ranks end the step with the same all-reduced
+    gradients; the detection loss normalises by the cross-rank mean of positives
     (bev_depth_head.py:334-336 `reduce_mean`)."""
     import socket
     import torch.multiprocessing as mp
@@ -287,7 +290,7 @@ def test_two_rank_multitask_step_gloo():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = mp.Manager().dict()
-    mp.spawn(_mt_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_mt_worker, args=(2, port, out, mode), nprocs=2, join=True)
     (l0, g0, d0), (l1, g1, d1) = out[0], out[1]
     assert np.isfinite(l0) and np.isfinite(l1) and l0 != l1          # different shards, different losses
     assert np.isfinite(g0).all() and float(np.abs(g0).max()) > 0

@@ -106,6 +106,29 @@ def test_render_forward_backward(tiny_common, mode, cat_seg):
         torch.testing.assert_close(beta.grad.reshape(1), r["grad_beta"], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("tag", ["smooth", "nonaffine"])
+def test_render_smooth_and_nonaffine_fixtures(tag):
+    """The oracle against the round-4 reference fixtures (smooth volumes; an `ida` that makes the frustum
+    chain non-affine in the depth): forward bit for bit, gradients to 1e-6; the non-affine geometry also
+    through the oracle's own frustum_to_ego on the prepared matrices."""
+    r = load_golden(f"tiny_render_{tag}.npz")
+    c = dataclasses.replace(CFG_TINY, density_mode="sdf", cat_seg=False)
+    vols = [r[k].clone().requires_grad_(True) for k in ("density_feature", "semantic_logits", "base", "rgb")]
+    beta = r["beta"].clone().reshape(()).requires_grad_(True)
+    geom = torch.nan_to_num(O.frustum_to_ego(GEO.frustum, None, None, None, None, prepared=r["render_mats"]), -1e3)
+    assert torch.equal(geom, r["geom"])
+    outs = O.render(geom, *vols, seg_bounds=SEG_BOUNDS, output_coords=GEO.output_coords,
+                    camera_mids=GEO.camera_mids, bev_mids=GEO.bev_mids, d_far=c.d_bound[1],
+                    z_step_det=c.z_bound_det[2], num_classes=c.num_classes, density_mode="sdf",
+                    beta_param=beta, sdf_bias=c.sdf_bias, cat_seg=False)
+    for name, o in zip(NAMES, outs):
+        assert torch.equal(o, r[name]), name
+    torch.autograd.backward(outs, [r["g_" + n] for n in NAMES])
+    for k, v in zip(("density_feature", "semantic_logits", "base", "rgb"), vols):
+        torch.testing.assert_close(v.grad, r["grad_" + k], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(beta.grad.reshape(1), r["grad_beta"], rtol=1e-5, atol=1e-6)
+
+
 def test_render_indices(tiny_common):
     g = tiny_common
     c = CFG_TINY

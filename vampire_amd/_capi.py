@@ -70,7 +70,7 @@ VAMP_CAMFWD_SAVE_SAMPLES, VAMP_CAMFWD_NO_ERT, VAMP_CAMFWD_TERM_VALID = 1, 2, 4
 VAMP_CAMPREP_TERM_VALID, VAMP_CAMPREP_RANK_ONLY = 1, 2
 VAMP_CAMBWD_SLOTS_PENDING = 1024
 VAMP_BEVBWD_OVERWRITE_BASE, VAMP_BEVBWD_OVERWRITE_CAM, VAMP_BEVBWD_SAVED_VALID = 1, 2, 4
-VAMP_BEVFWD_SAVE, VAMP_BEVFWD_TWO_KERNELS = 1, 2
+VAMP_BEVFWD_SAVE, VAMP_BEVFWD_TWO_KERNELS, VAMP_BEVFWD_HEIGHTS_LATTICE = 1, 2, 4
 VAMP_CAMFWD_PACK_ONLY, VAMP_CAMFWD_PACKED_VALID, VAMP_CAMFWD_DIRECT = 8, 16, 32
 VAMP_BEVBWD_ONLY_BASE, VAMP_BEVBWD_SKIP_BASE, VAMP_BEVBWD_TABLE_VALID = 8, 16, 32
 
@@ -116,6 +116,7 @@ SIGNATURES = {
     "vamp_render_bev_backward": (C.c_int, [_RD] + [_P] * 19 + [C.POINTER(C.c_float), _P, C.c_size_t, _P]),
     "vamp_render_bev_backward_ex": (C.c_int, [_RD] + [_P] * 19 + [C.POINTER(C.c_float), _P, C.c_size_t, C.c_int, _P]),
     "vamp_render_indices": (C.c_int, [_RD] + [_P] * 9 + [_P]),
+    "vamp_render_camera_direct_taps": (C.c_int, [_RD] + [_P] * 9 + [_P]),
     "vamp_frustum_geometry": (C.c_int, [_RD] + [_P] * 5 + [_P]),
     "vamp_sample_points_forward": (C.c_int, [_SD, _P, _P, _P, C.c_int64, _P, _P]),
     "vamp_sample_points_workspace_bytes": (C.c_size_t, [_SD, C.c_int64]),

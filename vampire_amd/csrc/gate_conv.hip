@@ -397,6 +397,15 @@ static GcShape gc_shape(int Cin, int Cout, int oZ) {
   s.mb = Cout <= 16 ? 1 : (Cout <= 80 ? 5 : 0);
   s.nb = Cin <= 64 ? 4 : (Cin <= 160 ? 10 : 0);
   if (!s.mb || !s.nb) s.mb = s.nb = 0;
+  // the backward's LDS image must fit the CU (160 KB): otherwise the forward would succeed and the
+  // backward fail in the middle of training -- such shapes take the caller's unfused path
+  constexpr size_t kLdsLimit = 160 * 1024;
+  size_t lds = 0;
+  if (s.mb == 1 && s.nb == 4) lds = GcBwdLds<1, 4>::floats(oZ);
+  else if (s.mb == 1 && s.nb == 10) lds = GcBwdLds<1, 10>::floats(oZ);
+  else if (s.mb == 5 && s.nb == 4) lds = GcBwdLds<5, 4>::floats(oZ);
+  else if (s.mb == 5 && s.nb == 10) lds = GcBwdLds<5, 10>::floats(oZ);
+  if (lds * sizeof(float) > kLdsLimit) s.mb = s.nb = 0;
   return s;
 }
 

@@ -894,7 +894,7 @@ int vamp_render_bev_forward_ex(const VampRenderDesc* d, const float* oxs, const 
   VAMP_REQUIRE(beta || d->density_mode == VAMP_DENSITY_SIGMOID, "beta is NULL");
   const RenderParams P = to_params(d);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (!(flags & VAMP_BEVFWD_TWO_KERNELS) && bev_fwd_fused_supported(d))
+  if (!(flags & VAMP_BEVFWD_TWO_KERNELS) && (flags & VAMP_BEVFWD_HEIGHTS_LATTICE) && bev_fwd_fused_supported(d))
     return launch_bev_fwd_fused(d, P, oxs, oys, ozs, bev_mids, beta, density_feature, semantic, rgb, base, bev_rgb,
                                 bev_seg, bev_height, voxel_density, voxel_output, s0_save, ss_save, s);
   dim3 g1((d->oX + 63) / 64, (d->oY + 3) / 4, d->B);

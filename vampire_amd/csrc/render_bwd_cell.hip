@@ -250,7 +250,10 @@ cam_bwd_cell_heavy_kernel(RenderParams P, const int* __restrict__ off, const int
 #pragma unroll
     for (int c = 0; c < CP; ++c) acc[c] = 0.f;
     const float fix = (float) ix, fiy = (float) iy, fiz = (float) iz;
-    constexpr int U = 1;
+#ifndef VAMP_HEAVY_U
+#define VAMP_HEAVY_U 1
+#endif
+    constexpr int U = VAMP_HEAVY_U;
     for (int k = tid; k < cr.tot; k += U * 256)
       cell_accumulate<CP4, U>(cr, k, 256, R, Gcl, fix, fiy, fiz, acc);
     {

@@ -177,6 +177,25 @@ __device__ __forceinline__ VolTap line_tap(const RenderParams& P, const RayLine&
   return t;
 }
 
+// Tap of the sample at depth d as the kernel uses it: the line, or -- whenever a lane of the wave is
+// within 1e-3 voxel of a face of the volume, or the chain is not affine -- the reference's fp32 chain
+// (wave-uniform decision; `m` is read again here instead of living in 36 scalar registers, which the
+// allocator does not have: they came back through v_readlane).  Shared by the forward kernel and the
+// diagnostic export below, so that the export shows exactly the taps the forward sampled.
+__device__ __forceinline__ VolTap direct_tap(const RenderParams& P, const float* __restrict__ m, const RayLine& L,
+                                             bool affine, float u, float v, float d) {
+  bool near_face;
+  VolTap tp = line_tap(P, L, d, near_face);
+  if (!affine || __any(near_face)) {
+    const float* mm = m;
+    asm volatile("" : "+s"(mm));
+    float x, y, z;
+    frustum_point(mm, u, v, d, x, y, z);
+    tp = volume_tap(P, nan_to_num_geom(x), nan_to_num_geom(y), nan_to_num_geom(z));
+  }
+  return tp;
+}
+
 // tile -> ray with 32-bit arithmetic (decode_ray_wps of render_common.hpp divides 64-bit values)
 __device__ __forceinline__ RayId decode_tile(const RenderParams& P) {
   const int tiles_w = (P.fW + 7) >> 3, tiles_h = (P.fH + 7) >> 3;
@@ -238,19 +257,19 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
   const bool affine = m[2] == 0.0f && m[6] == 0.0f;               // uniform
   const RayLine L = ray_line(m, P, u, v, ds[0], ds[S]);
   // tap of depth index i: the line, or the reference's fp32 chain where the inside mask is decided
-  auto tap_at = [&](int i) -> VolTap {
-    bool near_face;
-    VolTap tp = line_tap(P, L, ds[i], near_face);
-    if (!affine || __any(near_face)) {
-      // (rare: the matrices are read again here instead of living in 36 scalar registers -- which the
-      // allocator does not have: they came back through v_readlane -- across the whole kernel)
-      const float* mm = m;
-      asm volatile("" : "+s"(mm));
-      float x, y, z;
-      frustum_point(mm, u, v, ds[i], x, y, z);
-      tp = volume_tap(P, nan_to_num_geom(x), nan_to_num_geom(y), nan_to_num_geom(z));
-    }
-    return tp;
+  auto tap_at = [&](int i) -> VolTap { return direct_tap(P, m, L, affine, u, v, ds[i]); };
+  // length of bin i (bv2:426: norm of consecutive frustum points): along an affine chain the points of a
+  // ray lie on a line, L.len per unit of depth; otherwise the two points themselves
+  auto delta_at = [&](int i) -> float {
+    if (affine) return L.len * (ds[i + 1] - ds[i]);
+    const float* mm = m;
+    asm volatile("" : "+s"(mm));
+    float x0, y0, z0, x1, y1, z1;
+    frustum_point(mm, u, v, ds[i], x0, y0, z0);
+    frustum_point(mm, u, v, ds[i + 1], x1, y1, z1);
+    const float dx = nan_to_num_geom(x1) - nan_to_num_geom(x0), dy = nan_to_num_geom(y1) - nan_to_num_geom(y0),
+                dz = nan_to_num_geom(z1) - nan_to_num_geom(z0);
+    return sqrtf(dx * dx + dy * dy + dz * dz);
   };
 
   // ---- plan: depth indices of the tile that can hold inside samples (waves 0..3 plan 32 each)
@@ -258,7 +277,14 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
     plan_tile(P, m, us, vs, ds, __builtin_amdgcn_readlane(w, 0), __builtin_amdgcn_readlane(w, 63),
               __builtin_amdgcn_readlane(h, 0), __builtin_amdgcn_readlane(h, 63), sub, plan);
   __syncthreads();
-  const PlanMask mk_all = plan_mask(plan);
+  PlanMask mk_all = plan_mask(plan);
+  if (!affine) {
+    // (never with the reference's image augmentations: inv(ida) then mixes the depth into u, v.)  The
+    // skipped bins' optical depth is priced per unit of depth along a LINE -- without one, every depth
+    // index is marched and carries its own length
+    mk_all.lo = S >= 64 ? ~0ull : ((1ull << S) - 1ull);
+    mk_all.hi = S > 64 ? (S >= 128 ? ~0ull : ((1ull << (S - 64)) - 1ull)) : 0ull;
+  }
   const int A = __builtin_popcountll(mk_all.lo) + __builtin_popcountll(mk_all.hi);
   // the active indices as a list (rank -> depth index) and as flags, so that the loops below index
   // LDS instead of walking the bit masks (75 scalar instructions per index)
@@ -302,7 +328,7 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
         in[g] = false; delta[g] = 0.f;
         if (idx[g] < S) {
           const VolTap tp = tap_at(idx[g]);
-          delta[g] = L.len * (ds[idx[g] + 1] - ds[idx[g]]);                            // bv2:426
+          delta[g] = delta_at(idx[g]);                                                 // bv2:426
           in[g] = tp.inside;
           if (tp.inside) {
             pt[g] = pair_tap<T>(P, tp);
@@ -502,6 +528,39 @@ extern "C" int vamp_debug_direct_stamps(long long* host, size_t n) {
 }
 #endif
 
+// Diagnostic export (tests): inside mask, floor taps and continuous tap coordinates of EVERY sample
+// exactly as cam_fwd_direct_kernel evaluates them -- same tile decomposition, same wave composition (the
+// fallback to the fp32 chain is a wave-level decision), same code (direct_tap).
+__global__ void __launch_bounds__(256)
+cam_direct_taps_kernel(RenderParams P, const float* __restrict__ mats, const float* __restrict__ us,
+                       const float* __restrict__ vs, const float* __restrict__ ds,
+                       uint8_t* __restrict__ inside, int16_t* __restrict__ ix0, int16_t* __restrict__ iy0,
+                       int16_t* __restrict__ iz0, float* __restrict__ fxyz) {
+  const RayId id = decode_tile(P);
+  const int bn = __builtin_amdgcn_readfirstlane((int) id.bn);
+  const int S = P.D - 1;
+  const float* m = mats + (long) bn * 48;
+  const float u = us[id.w], v = vs[id.h];
+  const bool affine = m[2] == 0.0f && m[6] == 0.0f;
+  const RayLine L = ray_line(m, P, u, v, ds[0], ds[S]);
+  for (int i = id.sub; i < S; i += 4) {
+    const VolTap tp = direct_tap(P, m, L, affine, u, v, ds[i]);
+    if (!id.live) continue;
+    const long idx = (((long) bn * S + i) * P.fH + id.h) * P.fW + id.w;
+    inside[idx] = tp.inside ? 1 : 0;
+    ix0[idx] = (int16_t) tp.ix0; iy0[idx] = (int16_t) tp.iy0; iz0[idx] = (int16_t) tp.iz0;
+    if (fxyz) { fxyz[3 * idx] = tp.fx; fxyz[3 * idx + 1] = tp.fy; fxyz[3 * idx + 2] = tp.fz; }
+  }
+}
+
+int launch_cam_direct_taps(const RenderParams& P, const float* mats, const float* us, const float* vs,
+                           const float* ds, uint8_t* inside, int16_t* ix0, int16_t* iy0, int16_t* iz0,
+                           float* fxyz, hipStream_t s) {
+  const long tiles = (long) P.B * P.N * ((P.fH + 7) / 8) * ((P.fW + 7) / 8);
+  cam_direct_taps_kernel<<<(unsigned) ((tiles + 7) / 8 * 8), 256, 0, s>>>(P, mats, us, vs, ds, inside, ix0, iy0, iz0, fxyz);
+  return check_launch("cam_direct_taps_kernel");
+}
+
 #ifndef VAMP_DIRECT_NW
 #define VAMP_DIRECT_NW 4
 #endif
@@ -542,3 +601,12 @@ int launch_cam_fwd_direct(const VampRenderDesc* d, const RenderParams& P, const 
 }
 
 }  // namespace vamp
+
+extern "C" int vamp_render_camera_direct_taps(const VampRenderDesc* d, const float* mats, const float* us,
+                                              const float* vs, const float* ds, uint8_t* inside, int16_t* ix0,
+                                              int16_t* iy0, int16_t* iz0, float* fxyz, void* stream) {
+  if (int e = vamp::validate(d)) return e;
+  VAMP_REQUIRE(mats && us && vs && ds && inside && ix0 && iy0 && iz0, "null pointer");
+  return vamp::launch_cam_direct_taps(vamp::to_params(d), mats, us, vs, ds, inside, ix0, iy0, iz0, fxyz,
+                                      static_cast<hipStream_t>(stream));
+}

@@ -298,6 +298,10 @@ render_cam_fwd_plan_kernel(RenderParams P, const float* __restrict__ mats, const
             __builtin_amdgcn_readlane(h, 0), __builtin_amdgcn_readlane(h, 63), sub, plan);
   __syncthreads();
   PlanMask mk = plan_mask(plan);
+  // (the skipped indices below are priced per unit of depth along a LINE; when inv(ida) mixes the depth
+  // into u, v -- never with the reference's augmentations -- the chain is not affine in the depth and
+  // every index is marched with its own bin length)
+  if (!(m[2] == 0.0f && m[6] == 0.0f)) mk.lo = mk.hi = ~0ull;
   // early ray termination: this ray's samples from index `keep` on are dropped, and the tile is
   // done at the largest `keep` of its 64 rays
   const int keep = term ? term[(bn * P.fH + h) * P.fW + w] : S;

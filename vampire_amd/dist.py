@@ -113,9 +113,23 @@ class GradSync(torch.nn.Module):
     def finish(self):
         """Order the caller's stream after the collectives launched during backward and scatter the
         averaged buckets back into the gradients."""
-        for i, n in enumerate(self._ready):          # (a bucket a hook never completed: reduce what is there)
-            if n and self.enabled and all(q.grad is not None for q in self._buckets[i]):
-                self._reduce(i)
+        for i, n in enumerate(self._ready):
+            if not (n and self.enabled):
+                continue
+            # a bucket some of whose parameters got a gradient in this pass and some did not: reducing
+            # nothing would leave the ones that did rank-local and the ranks would drift apart silently
+            # (DistributedDataParallel raises here too, find_unused_parameters=False)
+            missing = [k for k, q in enumerate(self._buckets[i]) if q.grad is None]
+            if missing:
+                names = {id(q): nm for nm, q in self.module.named_parameters()}
+                self._pending.clear()
+                self._joining = False
+                self._ready = [0] * len(self._buckets)
+                raise RuntimeError(
+                    "GradSync: parameter(s) %s of gradient bucket %d received no gradient in this backward pass while "
+                    "others of the bucket did; every rank must produce a gradient for every parameter in every step"
+                    % (", ".join(names.get(id(self._buckets[i][k]), "?") for k in missing), i))
+            self._reduce(i)          # complete gradients whose hook count was short (accumulated .grad kept from before)
         for work, flat, bucket in self._pending:
             work.wait()
             if not self._avg:

@@ -242,6 +242,23 @@ class HotPath:
                                                  _ptr(iy0), _ptr(iz0), _stream()), "vamp_render_indices")
         return inside, ix0, iy0, iz0
 
+    def render_direct_taps(self, render_mats, coords=False):
+        """Diagnostics: (inside, ix0, iy0, iz0[, fxyz]) of every ray sample as the one-kernel camera forward
+        evaluates them (vamp_render_camera_direct_taps)."""
+        c = self.cfg
+        B, N = render_mats.shape[:2]
+        d = self.render_desc(B, N, _capi.VAMP_F32)
+        shp = (B, N, c.D - 1, c.fH, c.fW)
+        inside = torch.empty(shp, dtype=torch.uint8, device=self.device)
+        ix0, iy0, iz0 = (torch.empty(shp, dtype=torch.int16, device=self.device) for _ in range(3))
+        fxyz = torch.empty(shp + (3,), dtype=torch.float32, device=self.device) if coords else None
+        m = _chk(render_mats.float(), (B, N, 3, 4, 4), "render_mats")
+        _capi.check(self.lib.vamp_render_camera_direct_taps(C.byref(d), _ptr(m), _ptr(self.us), _ptr(self.vs),
+                                                            _ptr(self.ds), _ptr(inside), _ptr(ix0), _ptr(iy0),
+                                                            _ptr(iz0), _ptr(fxyz), _stream()),
+                    "vamp_render_camera_direct_taps")
+        return (inside, ix0, iy0, iz0) + ((fxyz,) if coords else ())
+
     def render(self, density_feature, semantic_logits, base, rgb, beta=None, *, geom=None,
                render_mats=None):
         """The reference's 8-tuple (bv2:462-467).  Give either ``geom`` [B,N,D,fH,fW,3]
@@ -527,7 +544,9 @@ class _RenderFn(torch.autograd.Function):
         ctx.cells = False
         ert = geom is None and hp.impl["ert"]
         direct = geom is None and hp.impl["cam_direct"] and not save and (c.D - 1) <= 128
-        bev_flags = 0 if hp.impl["bev_fused"] else _capi.VAMP_BEVFWD_TWO_KERNELS
+        # (hp.ozs is the reference's lattice of det-grid heights: the one-kernel BEV forward may size its
+        # plane slabs from the spacing)
+        bev_flags = _capi.VAMP_BEVFWD_HEIGHTS_LATTICE if hp.impl["bev_fused"] else _capi.VAMP_BEVFWD_TWO_KERNELS
         fwd_flags = 0 if ert else _capi.VAMP_CAMFWD_NO_ERT
         split = (train and side is not None and (ert or direct) and hp.impl["sched"] == "split" and geom is None
                  and hp.impl["prepare"] and hp.impl["cam_bwd"] != "v1")
