@@ -26,6 +26,12 @@ import os
 import sys
 import time
 
+# The layered and multi-task legs run MIOpen convolutions (image encoder, 3-D UNet, BEV head -- none of it
+# the hot path).  MIOpen's exhaustive find tunes ~150 of them for 6 minutes on a fresh box; its FAST mode
+# (find-db / heuristics) gives the same step times here (layered 11.9 vs 11.9 ms, multi-task 64.6 vs 66.5 ms)
+# in 50 s.  Set before torch loads MIOpen; an explicit MIOPEN_FIND_MODE in the environment wins.
+os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+
 import torch
 import torch.distributed as dist
 
@@ -446,6 +452,14 @@ def replay_rate(model, batch, train_step, steps, world, dev, vdist):
     return vdist.max_over_ranks(time.perf_counter() - t0, dev), ("hip_graph" if graph is not None else "eager")
 
 
+_T0 = time.perf_counter()
+
+
+def _mark(what):
+    """progress on stderr: where the wall time of a bench run goes"""
+    print(f"[bench] +{time.perf_counter() - _T0:6.1f} s  {what}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -556,6 +570,7 @@ def main():
         if float(ok.item()) == 0.0:
             graph, launch_mode = None, "eager"
 
+    _mark("warm-up + capture done")
     beta_sync = OverlappedBetaSync(model, world)
 
     def graph_step():
@@ -589,6 +604,7 @@ def main():
         _capi.profile_enable(False)
         model.hp.impl["overlap"] = overlap
     _capi.profile_select(None)
+    _mark("timed region + kernel profile done")
     fwd_med, fwd_p10, fwd_p90 = forward_pair_us(model, batch) if rank == 0 else (0.0, 0.0, 0.0)
     fwd_graph = forward_pair_graph_us(model, batch) if (rank == 0 and os.environ.get("VAMP_BENCH_GRAPH", "1") == "1") else None
     # the same pair with early ray termination OFF: the data-independent forward (every inside sample marched)
@@ -604,6 +620,7 @@ def main():
     # {HIP graph, eager launches} x {early ray termination on, off}: the headline is the best case on
     # both axes (the termination gain is data-dependent), so the line carries all four (N = 1 only:
     # no collective inside)
+    _mark("forward pairs done")
     step_matrix, ert_stats = None, None
     if world == 1 and not a.no_matrix:
         def time_loop(fn, n):
@@ -640,6 +657,7 @@ def main():
     # the same workload at 8 samples per GPU per step under the headline's protocol, so that the
     # driver's N = 1, 2, 4, 8 runs also carry a weak-scaling curve that is not bounded by the latency of a
     # collective against a half-millisecond step (configs[2] itself is bs = 1 per GPU: the headline)
+    _mark("step matrix done")
     bs8 = None
     if not a.no_extra and a.batch != 8:
         batch8 = SyntheticBatch(cfg, 8, dev, seed=vdist.shard_seed(1, rank), dtype=dtype)
@@ -650,8 +668,11 @@ def main():
         del batch8
     # SURVEY 8(e) / BASELINE configs[4]: the step with a real gradient bucket and the full multi-task step,
     # always in the line (a few seconds; --no-extra skips them for profile runs)
+    _mark("bs8 done")
     layered = layered_measure(cfg, dev, a.batch, rank, world) if not a.no_extra else None
+    _mark("layered step done")
     multitask = multitask_measure(dev, a.batch, rank, world) if not a.no_extra else None
+    _mark("multi-task step done")
 
     prof = dict(warm)
     # the dominant kernel: measured over the timed region
@@ -739,6 +760,7 @@ def main():
             "step_matrix_note": "graph_* = device-bound (replayed launches); eager_* depend on the HOST's launch rate "
                                 "(~35 launches and two stream joins per step) and vary between boxes",
             "weak_scaling_bs8": bs8,
+            "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE"),
             "layered_step": layered,
             "multitask_step": multitask,
             "early_ray_termination": ert_stats,
@@ -751,8 +773,10 @@ def main():
                                      extra_config("D", 1, torch.bfloat16),
                                      extra_config(a.cfg, a.batch, dtype, ert=False),
                                      extra_config(a.cfg, a.batch, dtype, density_mode="naive")]
+        _mark("extra configs done")
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, a.cfg)
+            _mark("cpu baseline done")
         print(json.dumps(line), flush=True)
     vdist.shutdown()
 
