@@ -757,17 +757,24 @@ def test_camera_backward_cell_matches_atomic_splat_full_size(dev, monkeypatch, c
         torch.autograd.backward(outs, gs)
         return [v.grad.clone() for v in vols], beta.grad.clone()
 
-    g3, b3 = run("cell")        # default: BEV branch on the side stream, camera gather accumulates
+    g4, b4 = run("cell")        # the default: the per-ray pass reads the samples the forward kept (save_rows)
+    hp.impl["save_rows"] = False
+    g3, b3 = run("cell")        # the per-ray pass gathers again: BEV branch on the side stream, camera gather accumulates
     hp.impl["overlap"] = False
     g2, b2 = run("cell")        # same kernels on one stream, camera gather overwrites
     hp.impl["overlap"] = True
+    hp.impl["save_rows"] = True
     g1, b1 = run("v1")          # float-atomic splat
-    for name, a3, a2, b in zip(("density_feature", "semantic_logits", "base", "rgb"), g3, g2, g1):
+    for name, a4, a3, a2, b in zip(("density_feature", "semantic_logits", "base", "rgb"), g4, g3, g2, g1):
         close(a3, b, atol=1e-5, rtol=2e-5, scale="max", what="cell (2 streams) vs v1 grad_" + name)
         close(a2, b, atol=1e-5, rtol=2e-5, scale="max", what="cell (1 stream) vs v1 grad_" + name)
+        # the kept samples were taken at the one-kernel forward's coordinates (an fp64 line per ray, within
+        # 1e-5 voxel of the fp32 chain v1 evaluates): <= 3e-5 of the sample values on white noise, which the
+        # density gradient sees through q = G . s; both are pinned to the reference at 1e-4 elsewhere
+        close(a4, b, atol=1e-5, rtol=6e-5, scale="max", what="cell (kept samples) vs v1 grad_" + name)
         assert float(b.abs().max()) > 0 or name == "base"
-    close(b3.reshape(1), b1.reshape(1), atol=1e-3, rtol=1e-3, what="grad_beta")
-    close(b2.reshape(1), b1.reshape(1), atol=1e-3, rtol=1e-3, what="grad_beta")
+    for bb in (b4, b3, b2):
+        close(bb.reshape(1), b1.reshape(1), atol=1e-3, rtol=1e-3, what="grad_beta")
 
 
 @pytest.mark.parametrize("mode,cat_seg,batch", [("naive", True, 2), ("sdf", True, 1), ("naive", False, 1)],

@@ -115,14 +115,11 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
     for (int c = 0; c < CP; ++c) s[c] = 0.f;
     if (tp.inside) {
       if (samples) {
-        // the row the forward gathered for this sample (render_cam_fwd_plan_kernel<SAVE>): 96
-        // contiguous bytes per lane, neighbouring lanes = neighbouring pixels
-        const float4* row = reinterpret_cast<const float4*>(samples + ((((long) bn * S + i) * P.fH + h) * P.fW + w) * CP);
+        // the values the forward sampled (render_cam_direct.hip / render_cam_fwd_plan_kernel<SAVE>): one
+        // coalesced 256-byte run per channel for the tile's 64 rays
+        const float* rr = samples + ((id.tile * S + i) * CP) * 64 + (tid & 63);
 #pragma unroll
-        for (int q = 0; q < CP4; ++q) {
-          const float4 f = row[q];
-          s[q * 4] = f.x; s[q * 4 + 1] = f.y; s[q * 4 + 2] = f.z; s[q * 4 + 3] = f.w;
-        }
+        for (int c = 0; c < CP; ++c) s[c] = (c < nch) ? rr[c * 64] : 0.f;
       } else {
         // channel 0 = density feature, 1..K semantic, K+1..K+3 rgb; four x-pair loads per channel, in
         // batches of four channels (their 16 loads are issued back to back)

@@ -206,6 +206,7 @@ __device__ __forceinline__ RayId decode_tile(const RenderParams& P) {
   RayId id;
   id.sub = threadIdx.x >> 6;
   const int tc = t < tiles ? t : tiles - 1;
+  id.tile = tc;
   const int bn = tc / per_cam, tt = tc - bn * per_cam;
   const int ty = tt / tiles_w, tx = tt - ty * tiles_w;
   id.bn = bn;
@@ -221,6 +222,11 @@ __device__ __forceinline__ RayId decode_tile(const RenderParams& P) {
 // NCH = composited channels (K + 3), rounded up by the launcher; channels >= K + 3 are skipped.
 // NW = waves per 8 x 8 ray tile.  LDS: plan (2 KB) + round sums + dyn = max(S, NW * NCH) * 64 floats
 // (tau / weights, then the merge buffer).
+// rows != nullptr (a backward will follow): every inside sample's raw trilinear values -- the density
+// feature from the density phase, the K + 3 composited channels from the gather phase -- are kept at
+// rows[((tile * S + i) * P.CP + c) * 64 + ray]: 256 contiguous bytes per (tile, depth index, channel), so
+// the backward's per-ray pass (same tiles, same lanes) reads them back coalesced instead of repeating
+// the 8-tap gathers, which are all that pass was bound by.
 template <typename T, int NCH, bool ERT, int NW>
 __global__ void __launch_bounds__(NW * 64)
 cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const float* __restrict__ us,
@@ -228,7 +234,7 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
                       const float* __restrict__ mids, const float* __restrict__ beta_raw,
                       const T* __restrict__ dens, const T* __restrict__ sem, const T* __restrict__ rgb,
                       float* __restrict__ rgb_out, float* __restrict__ seg_out,
-                      float* __restrict__ depth_out, int* __restrict__ term_out) {
+                      float* __restrict__ depth_out, int* __restrict__ term_out, float* __restrict__ rows) {
   extern __shared__ __align__(16) float dyn[];
   __shared__ int4 plan[kPlanMax];
   __shared__ int keep_s[64];
@@ -344,7 +350,11 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
       for (int g = 0; g < G; ++g) {
         if (idx[g] < S) {
           float sv = 0.f;
-          if (in[g]) sv = nan_to_num(pair_combine<T>(pt[g], raw[g]));
+          if (in[g]) {
+            const float raw0 = pair_combine<T>(pt[g], raw[g]);
+            if (rows) rows[(((long) id.tile * S + idx[g]) * P.CP) * 64 + lane] = raw0;
+            sv = nan_to_num(raw0);
+          }
           const float tau = density_fast(dp, sv) * delta[g];
           wbuf[idx[g] * 64 + lane] = tau;
           psum += tau;
@@ -477,6 +487,12 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
           for (int uu = 0; uu < kDirectCB; ++uu)
             if (c0 + uu < NCH) s[c0 + uu] = pair_combine<T>(pt, raw[uu]);
         }
+        if (rows) {
+          float* rr = rows + (((long) id.tile * S + i) * P.CP + 1) * 64 + lane;
+#pragma unroll
+          for (int c = 0; c < NCH; ++c)
+            if (c < nch) rr[c * 64] = s[c];
+        }
         // nan_to_num of the sampled features (bv2:421) only where something is not finite:
         // sum_c 0 * s_c is nan exactly then
         float chk = 0.f;
@@ -568,7 +584,7 @@ int launch_cam_direct_taps(const RenderParams& P, const float* mats, const float
 int launch_cam_fwd_direct(const VampRenderDesc* d, const RenderParams& P, const float* mats, const float* us,
                           const float* vs, const float* ds, const float* mids, const float* beta,
                           const void* dens, const void* sem, const void* rgb, float* rgb_out,
-                          float* seg_out, float* depth_out, int* term_out, bool ert, hipStream_t s) {
+                          float* seg_out, float* depth_out, int* term_out, bool ert, float* rows, hipStream_t s) {
   const int S = P.D - 1, nch = P.K + 3;
   const long tiles = (long) P.B * P.N * ((P.fH + 7) / 8) * ((P.fW + 7) / 8);
   const unsigned grid = (unsigned) ((tiles + 7) / 8 * 8);
@@ -579,11 +595,11 @@ int launch_cam_fwd_direct(const VampRenderDesc* d, const RenderParams& P, const 
     if (ert)                                                                                            \
       VAMP_TIMED(kProfCamFwd, s, (cam_fwd_direct_kernel<T, NCH, true, NW><<<grid, NW * 64, dyn, s>>>(   \
           P, mats, us, vs, ds, mids, beta, static_cast<const T*>(dens), static_cast<const T*>(sem),     \
-          static_cast<const T*>(rgb), rgb_out, seg_out, depth_out, term_out)));                         \
+          static_cast<const T*>(rgb), rgb_out, seg_out, depth_out, term_out, rows)));                   \
     else                                                                                                \
       VAMP_TIMED(kProfCamFwd, s, (cam_fwd_direct_kernel<T, NCH, false, NW><<<grid, NW * 64, dyn, s>>>(  \
           P, mats, us, vs, ds, mids, beta, static_cast<const T*>(dens), static_cast<const T*>(sem),     \
-          static_cast<const T*>(rgb), rgb_out, seg_out, depth_out, term_out)));                         \
+          static_cast<const T*>(rgb), rgb_out, seg_out, depth_out, term_out, rows)));                   \
   } while (0)
 #define VAMP_CAMD_T(T)                                                                                  \
   do {                                                                                                  \

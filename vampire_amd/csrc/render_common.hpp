@@ -237,7 +237,7 @@ int launch_cam_term(const VampRenderDesc* d, const RenderParams& P, const float*
 int launch_cam_fwd_direct(const VampRenderDesc* d, const RenderParams& P, const float* mats, const float* us,
                           const float* vs, const float* ds, const float* mids, const float* beta,
                           const void* dens, const void* sem, const void* rgb, float* rgb_out,
-                          float* seg_out, float* depth_out, int* term_out, bool ert, hipStream_t s);
+                          float* seg_out, float* depth_out, int* term_out, bool ert, float* rows, hipStream_t s);
 
 // render_bev_fused.hip: the BEV forward (density, weights, all channels) as one kernel
 bool bev_fwd_fused_supported(const VampRenderDesc* d);

@@ -265,7 +265,8 @@ int launch_cam_term(const VampRenderDesc* d, const RenderParams& P, const float*
 // ---------------------------------------------------------------------------
 // camera branch forward with a per-tile plan (geometry evaluated from the matrices)
 // ---------------------------------------------------------------------------
-// SAVE: also store the gathered row of every inside sample at samples[((bn * S + i) * fH + h) * fW + w]
+// SAVE: also store the gathered values of every inside sample at samples[((tile * S + i) * CP + c) * 64 + ray]
+// (the layout of render_cam_direct.hip: 256 contiguous bytes per tile, depth index and channel)
 // (CP floats, before the nan_to_num of bv2:421) for the backward's per-ray pass.
 template <int CP4, bool SAVE>
 __global__ void __launch_bounds__(256, 3)
@@ -358,10 +359,10 @@ render_cam_fwd_plan_kernel(RenderParams P, const float* __restrict__ mats, const
       for (int c = 0; c < CP; ++c) s[c] = 0.f;
       if (tp.inside) {
         gather_taps<CP4>(P, vol, tp, s);
-        if (SAVE && live) {
-          float4* row = reinterpret_cast<float4*>(samples + ((((long) bn * S + i) * P.fH + h) * P.fW + w) * CP);
+        if (SAVE) {
+          float* rr = samples + (((long) id.tile * S + i) * CP) * 64 + (threadIdx.x & 63);
 #pragma unroll
-          for (int q = 0; q < CP4; ++q) row[q] = make_float4(s[q * 4], s[q * 4 + 1], s[q * 4 + 2], s[q * 4 + 3]);
+          for (int c = 0; c < CP; ++c) rr[c * 64] = s[c];
         }
         // nan_to_num of the sampled features (bv2:421) only where something is not finite:
         // sum_c 0 * s_c is nan exactly then (two chains, so that they pack)
@@ -534,7 +535,9 @@ size_t vamp_render_term_offset(const VampRenderDesc* d) { return d ? render_base
 size_t vamp_render_samples_bytes(const VampRenderDesc* d) {
   if (!d) return 0;
   const RenderParams P = to_params(d);
-  return align_up((size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW * P.CP * sizeof(float), 256);
+  // [8 x 8 ray tile][depth index][channel][ray of the tile] (ragged tiles padded)
+  const size_t tiles = (size_t) d->B * d->N * ((d->fH + 7) / 8) * ((d->fW + 7) / 8);
+  return align_up(tiles * 64 * (d->D - 1) * P.CP * sizeof(float), 256);
 }
 
 int vamp_render_camera_forward(const VampRenderDesc* d, const float* geom, const float* mats,
@@ -559,13 +562,21 @@ int vamp_render_camera_forward_ex(const VampRenderDesc* d, const float* geom, co
                "null pointer");
   VAMP_REQUIRE(beta || d->density_mode == VAMP_DENSITY_SIGMOID, "beta is NULL");
   const bool planned = !geom && d->D - 1 <= kPlanMax;
-  if ((flags & VAMP_CAMFWD_DIRECT) && planned && !(flags & VAMP_CAMFWD_SAVE_SAMPLES)) {
+  if ((flags & VAMP_CAMFWD_DIRECT) && planned) {
     // one kernel on the channel-first volumes (render_cam_direct.hip): no packed copy, the
-    // termination table is a by-product (written when the workspace can hold it)
+    // termination table is a by-product (written when the workspace can hold it); with SAVE_SAMPLES the
+    // samples' values stay behind the base region for the backward's per-ray pass
     const bool ert = !(flags & VAMP_CAMFWD_NO_ERT);
     int* term = (workspace && workspace_bytes >= vamp_render_workspace_bytes(d)) ? cam_term_ptr(d, workspace) : nullptr;
+    float* rows = nullptr;
+    if (flags & VAMP_CAMFWD_SAVE_SAMPLES) {
+      const size_t need = vamp_render_workspace_bytes(d) + vamp_render_samples_bytes(d);
+      if (!workspace || workspace_bytes < need)
+        return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) need);
+      rows = reinterpret_cast<float*>(static_cast<char*>(workspace) + vamp_render_workspace_bytes(d));
+    }
     return launch_cam_fwd_direct(d, to_params(d), mats, us, vs, ds, mids, beta, density_feature, semantic, rgb,
-                                 rgb_out, seg_out, depth_out, term, ert, static_cast<hipStream_t>(stream));
+                                 rgb_out, seg_out, depth_out, term, ert, rows, static_cast<hipStream_t>(stream));
   }
   const bool save = (flags & VAMP_CAMFWD_SAVE_SAMPLES) && planned;
   const bool ert = planned && !(flags & VAMP_CAMFWD_NO_ERT);

@@ -123,6 +123,9 @@ class HotPath:
                      # eager launches (the fork / join costs more than it hides); a caller that captures the
                      # forward into a HIP graph switches it on (bench.py)
                      "fwd_overlap": os.environ.get("VAMP_FWD_OVERLAP", "0") == "1",
+                     # training: the camera forward keeps every inside sample's values for the backward's
+                     # per-ray pass (+0.5 GB of workspace per sample at cfg-B, touched only where samples are kept)
+                     "save_rows": os.environ.get("VAMP_SAVE_ROWS", "1") != "0",
                      "prepare": os.environ.get("VAMP_PREPARE", "1") != "0"}
 
     # ---------------------------------------------------------------- descs
@@ -525,7 +528,10 @@ class _RenderFn(torch.autograd.Function):
         nbytes = hp.lib.vamp_render_workspace_bytes(C.byref(d))
         # training: the march also stores every inside sample's gathered row behind the base region,
         # and the backward's per-ray pass reads it back instead of repeating the 8-tap gather
-        save = False      # (saving the forward's sample rows for the backward measured neutral in round 2: switched off for good)
+        # (round 4: tile-major rows, 256 contiguous bytes per tile, depth index and channel, written by the
+        # one-kernel forward -- the per-ray pass was bound by repeating the forward's gathers; round 2's
+        # per-sample 96-byte rows had measured neutral)
+        save = bool(train and geom is None and hp.impl["save_rows"] and hp.impl["cam_bwd"] != "v1" and (c.D - 1) <= 128)
         if save:
             nbytes += hp.lib.vamp_render_samples_bytes(C.byref(d))
         ws = hp._workspace("render", nbytes)
@@ -543,7 +549,7 @@ class _RenderFn(torch.autograd.Function):
         side = hp._side_stream() if (train or hp.impl["fwd_overlap"]) else None
         ctx.cells = False
         ert = geom is None and hp.impl["ert"]
-        direct = geom is None and hp.impl["cam_direct"] and not save and (c.D - 1) <= 128
+        direct = geom is None and hp.impl["cam_direct"] and (c.D - 1) <= 128
         # (hp.ozs is the reference's lattice of det-grid heights: the one-kernel BEV forward may size its
         # plane slabs from the spacing)
         bev_flags = _capi.VAMP_BEVFWD_HEIGHTS_LATTICE if hp.impl["bev_fused"] else _capi.VAMP_BEVFWD_TWO_KERNELS
@@ -561,7 +567,8 @@ class _RenderFn(torch.autograd.Function):
                 C.byref(d), None, _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
                 _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
                 _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(),
-                fwd_flags | _capi.VAMP_CAMFWD_DIRECT, _stream(cur)), "vamp_render_camera_forward_ex")
+                fwd_flags | _capi.VAMP_CAMFWD_DIRECT | (_capi.VAMP_CAMFWD_SAVE_SAMPLES if save else 0), _stream(cur)),
+                "vamp_render_camera_forward_ex")
             term_done = torch.cuda.Event()
             term_done.record(cur)
             side.wait_event(term_done)
