@@ -399,6 +399,104 @@ bev_q_saved_kernel(RenderParams P, const float* __restrict__ ss, const float* __
   Q[((long) b * P.oZ + j) * OYX + col] = (q0 + q1) + q2;
 }
 
+// bev_q_saved + bev_scan as ONE kernel (round 4; the forward kept its samples): lanes = (column, height).
+// A workgroup is 64 columns of one row times all heights (wave w takes heights w, w + NWJ, ...): every
+// (column, height) takes its own q = G . s (21 streaming loads) and tau; the per-column scan is then a
+// loop over the heights' taus in LDS that every lane runs for itself in the column kernel's order (same
+// bits), and each lane finishes its own height.  10x the threads of the thread-per-column scan (which
+// was pure latency: 625 waves on 1 024 SIMDs), no Q round trip, one launch less.
+constexpr int kQsMaxWaves = 8;
+__global__ void __launch_bounds__(kQsMaxWaves * 64)
+bev_qscan_saved_kernel(RenderParams P, const float* __restrict__ bev_mids, const float* __restrict__ beta_raw,
+                       const float* __restrict__ s0_saved, const float* __restrict__ ss,
+                       const float* __restrict__ g_brgb, const float* __restrict__ g_bseg,
+                       const float* __restrict__ g_bh, const float* __restrict__ g_vd,
+                       float* __restrict__ Wb, float* __restrict__ DS0, float* __restrict__ beta_part) {
+  extern __shared__ float qs[];                 // [oZ][64] tau, qv, then the scan's three arrays
+  __shared__ float red[kQsMaxWaves];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  const int x = blockIdx.x * 64 + lane, y = blockIdx.y, b = blockIdx.z;
+  const bool live = x < P.oX;
+  const long OYX = (long) P.oY * P.oX, col = (long) y * P.oX + min(x, P.oX - 1);
+  const DensityParams dp = load_density(P.density_mode, beta_raw, P.beta_min, P.sdf_bias);
+  const int nch = P.K + 3;
+  const float Gh = g_bh ? g_bh[(long) b * OYX + col] : 0.f;
+  const float dz = 1.0f * P.z_step;
+  float* l_tau = qs;
+  float* l_q = qs + P.oZ * 64;
+  for (int j = wv; j < P.oZ; j += nwv) {
+    float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+    constexpr int U = 7;                          // channels in flight (K + 3 = 21 = 3 x 7)
+    for (int c0 = 0; c0 < nch; c0 += U) {
+      float g[U], v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int ch = min(c0 + u, nch - 1);
+        const bool is_sem = ch < P.K;
+        const float* gp = is_sem ? g_bseg : g_brgb;
+        g[u] = (gp && c0 + u < nch) ? gp[is_sem ? ((long) b * P.K + ch) * OYX + col : ((long) b * 3 + (ch - P.K)) * OYX + col] : 0.f;
+        v[u] = ss[(((long) b * nch + ch) * P.oZ + j) * OYX + col];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (u % 3 == 0) q0 = __builtin_fmaf(g[u], v[u], q0);
+        else if (u % 3 == 1) q1 = __builtin_fmaf(g[u], v[u], q1);
+        else q2 = __builtin_fmaf(g[u], v[u], q2);
+      }
+    }
+    const float s0 = s0_saved[((long) b * P.oZ + j) * OYX + col];
+    l_tau[j * 64 + lane] = density_fwd(dp, s0) * dz;
+    l_q[j * 64 + lane] = ((q0 + q1) + q2) + Gh * bev_mids[j];
+  }
+  __syncthreads();
+  // the column's scan in height order, as bev_scan_kernel runs it: wave 0, one lane per column, leaves
+  // every height's weight, the transmittance behind it and total - prefix in LDS
+  float* l_w = qs + 2 * P.oZ * 64;              // [oZ][64] w_j, [oZ][64] T_{j+1}, [oZ][64] total - prefix_j
+  float* l_T = l_w + P.oZ * 64;
+  float* l_R = l_T + P.oZ * 64;
+  if (wv == 0) {
+    float total = 0.f, cum = 0.f;
+    for (int k = 0; k < P.oZ; ++k) {
+      const float tau = l_tau[k * 64 + lane];
+      const float wk = (1.0f - expf(-tau)) * expf(-cum);
+      total = __builtin_fmaf(wk, l_q[k * 64 + lane], total);
+      cum += tau;
+      l_w[k * 64 + lane] = wk;
+      l_T[k * 64 + lane] = expf(-cum);
+      l_R[k * 64 + lane] = total;                // prefix_k for now
+    }
+    for (int k = 0; k < P.oZ; ++k) l_R[k * 64 + lane] = total - l_R[k * 64 + lane];
+  }
+  __syncthreads();
+  float dbeta = 0.f;
+  for (int j = wv; j < P.oZ; j += nwv) {
+    const float dtau = l_q[j * 64 + lane] * l_T[j * 64 + lane] - l_R[j * 64 + lane];
+    const float s0 = s0_saved[((long) b * P.oZ + j) * OYX + col];
+    float dsig_ds, dsig_db;
+    density_bwd(dp, s0, dsig_ds, dsig_db);
+    const float gvd = g_vd ? g_vd[((long) b * P.oZ + j) * OYX + col] : 0.f;
+    const float dsigma = dtau * dz + gvd;          // sigma feeds tau and voxel_density
+    dbeta = __builtin_fmaf(dsigma, dsig_db, dbeta);
+    if (live) {
+      Wb[((long) b * P.oZ + j) * OYX + col] = l_w[j * 64 + lane];
+      DS0[((long) b * P.oZ + j) * OYX + col] = dsigma * dsig_ds;
+    }
+  }
+  if (P.density_mode == VAMP_DENSITY_SDF_LAPLACE) {
+    float v = live ? dbeta : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) red[wv] = v;
+    __syncthreads();
+    // one partial per workgroup, summed in a fixed order
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int k = 0; k < nwv; ++k) t += red[k];
+      beta_part[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)] = t;
+    }
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 bev_scan_kernel(RenderParams P, const float* __restrict__ oxs, const float* __restrict__ oys,
@@ -847,8 +945,10 @@ bev_gather_col_kernel(RenderParams P, const int4* __restrict__ tab, const float*
   for (int z = max(cur + 2, za); z < zb; ++z) store_plane(z, zero, 0.f, false);
 }
 
-static size_t bev_scan_blocks(const VampRenderDesc* d) {
-  return (size_t) ((d->oX + 63) / 64) * ((d->oY + 3) / 4) * d->B;
+// d beta partial sums the scan leaves in the workspace: one per workgroup of bev_scan_kernel, or -- when the
+// forward kept its samples -- of bev_qscan_saved_kernel (the workspace holds the larger count)
+static size_t bev_scan_blocks(const VampRenderDesc* d, bool saved = true) {
+  return (size_t) ((d->oX + 63) / 64) * (saved ? d->oY : (d->oY + 3) / 4) * d->B;
 }
 
 // workspace: Q, Wb, DS0 [B, oZ, oY, oX] | axis tables | beta partials | what the forward keeps for
@@ -1005,8 +1105,11 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
 #define VAMP_BEVB(T)                                                                              \
   do {                                                                                            \
     if (saved) {                                                                                  \
-      VAMP_TIMED(kProfBevBwdQ, s, (bev_q_saved_kernel<<<gqs, 256, 0, s>>>(P, ss_saved, g_bev_rgb, g_bev_seg, Q))); \
-      if (int e = check_launch("bev_q_saved_kernel")) return e;                                   \
+      const int nwj = (d->oZ + 1) / 2 < kQsMaxWaves ? (d->oZ + 1) / 2 : kQsMaxWaves;   /* two heights per wave: 3 workgroups per CU */ \
+      VAMP_TIMED(kProfBevBwd, s, (bev_qscan_saved_kernel<<<gq, nwj * 64, (size_t) 5 * d->oZ * 64 * sizeof(float), s>>>( \
+          P, bev_mids, beta, s0_saved, ss_saved, g_bev_rgb, g_bev_seg, g_bev_height, g_voxel_density, Wb, DS0, beta_part))); \
+      if (int e = check_launch("bev_qscan_saved_kernel")) return e;                               \
+      break;                                                                                      \
     } else {                                                                                      \
     if (q_lds > 60 * 1024 &&                                                                      \
         hipFuncSetAttribute(reinterpret_cast<const void*>(&bev_q_kernel<T>),                     \
@@ -1031,7 +1134,7 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
   // such launch follows, by a launch of its own
   BetaTail btail{nullptr, 0, nullptr, nullptr};
   if (!skip_base && d->density_mode == VAMP_DENSITY_SDF_LAPLACE)
-    btail = BetaTail{beta_part, (int) bev_scan_blocks(d), beta, grad_beta};
+    btail = BetaTail{beta_part, (int) bev_scan_blocks(d, saved), beta, grad_beta};
   const BetaTail no_tail{nullptr, 0, nullptr, nullptr};
   auto take_tail = [&]() { const BetaTail t = btail; btail = no_tail; return t; };
   // lattice points within one voxel's trilinear support, per axis
