@@ -15,3 +15,15 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- 
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/tools/time_bwd.py $CFG $BATCH > /dev/null 2> $OUT/pmc_write.log
 cd $ROOT
 python3 tools/summarize_profiles.py $OUT $TAG $CFG $BATCH
+# the same three passes with early ray termination OFF (the data-independent path): VAMP_ERT=0 is read by
+# vampire_amd.ops at import; exported here so that rocprofv3 launches python itself (no env wrapper)
+export VAMP_ERT=0
+OUT2=$ROOT/gpurun_out/profiles_${TAG}_noert
+mkdir -p $OUT2
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT2/stats -- python3 $ROOT/bench.py --cfg $CFG --batch $BATCH --steps 20 --warmup 5 --no-cpu-baseline --no-extra --no-matrix > $OUT2/bench_under_rocprof.json 2> $OUT2/stats.log
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT2/pmc_fetch -- python3 $ROOT/tools/time_bwd.py $CFG $BATCH > /dev/null 2> $OUT2/pmc_fetch.log
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT2/pmc_write -- python3 $ROOT/tools/time_bwd.py $CFG $BATCH > /dev/null 2> $OUT2/pmc_write.log
+cd $ROOT
+python3 tools/summarize_profiles.py $OUT2 ${TAG}_noert $CFG $BATCH > /dev/null
+unset VAMP_ERT
