@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Dev aid (GPU box, library built with -DABL_STAMPS): phase timeline of the lift backward strip gather."""
+"""Dev aid (GPU box, library built with -DVAMP_LIFT_STAMPS (tools/ablate.sh lift_bwd_cell.hip stamps=-DVAMP_LIFT_STAMPS)): phase timeline of the lift backward strip gather."""
 import os, sys, ctypes as C
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

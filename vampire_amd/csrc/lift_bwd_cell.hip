@@ -83,7 +83,6 @@ lift_bwd_fill_kernel(LiftParams P, int cw, int ch, const float* __restrict__ gou
 
   // grad_out / (hit count + 1e-6), the camera-mean factor of bv2:512-514: the same for every
   // camera of the voxel -- one channel-last row of the table per voxel
-#ifndef ABL_FILL_NOTABLE
   if (live) {
     const int nchunk = P.C / CH;
     float4* row = table + ((long) b * V + vox) * (P.C / 4);
@@ -98,10 +97,6 @@ lift_bwd_fill_kernel(LiftParams P, int cw, int ch, const float* __restrict__ gou
       for (int c4 = 0; c4 < CH; c4 += 4) row[(chunk * CH + c4) / 4] = make_float4(v[c4], v[c4 + 1], v[c4 + 2], v[c4 + 3]);
     }
   }
-#endif
-#ifdef ABL_FILL_NOPAIRS
-  return;
-#endif
   if (!__any(vmask != 0u)) return;
 
   constexpr int NB = 8;                          // cameras per batch: their atomics are in flight together
@@ -178,7 +173,8 @@ __device__ __forceinline__ unsigned long long fixed_of(float w, int sc) {
   return (unsigned long long) (__double_as_longlong(x) - 0x4338000000000000LL);
 }
 
-#ifdef ABL_STAMPS
+#ifdef VAMP_LIFT_STAMPS
+// diagnostic build only (tools/debug/lift_stamps.py; -DVAMP_LIFT_STAMPS): per-workgroup phase stamps of the strip gather
 __device__ long long g_stamps[16384 * 8];
 #define STAMP() __builtin_amdgcn_s_memtime()
 #endif
@@ -230,7 +226,7 @@ lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_
   const long pix0 = (long) iy * P.fW + x0;
   const int p = lane >> 2, sl = wv * 4 + (lane & 3); // consume phase: lane = (pixel, slot)
 
-#ifdef ABL_STAMPS
+#ifdef VAMP_LIFT_STAMPS
   long long st0 = STAMP(), st_stage = 0, st_cons = 0, st2 = 0;
   const long long rt0 = wall_clock64();
 #endif
@@ -288,7 +284,7 @@ lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_
     efp[tid] = exp_above(t);
   }
   __syncthreads();
-#ifdef ABL_STAMPS
+#ifdef VAMP_LIFT_STAMPS
   long long st1 = STAMP();
 #endif
 
@@ -339,12 +335,8 @@ lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_
       const int t = tc + jA;
       if (laneA && t < NP) {
         const long pos = (long) (t >= n0 ? offs[kS + 2] + (t - n0) : offs[0] + t);
-#ifdef ABL_NOIDS
-        vox = (int) (pos % V); rc = make_float4(0.3f, 0.4f, 0.5f, __int_as_float(8 | ((x0 + 3) << 16)));
-#else
         vox = ids[pos];
         rc = recs[pos];
-#endif
       }
     };
     auto load_rows = [&](int tc, int vox, float4 (&g)[2]) {
@@ -368,7 +360,7 @@ lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_
     for (int t0 = 0; t0 < NP; t0 += cap) {
       const int nst = min(cap, NP - t0);
       __syncthreads();                               // the previous chunk (or the feature tile) is consumed
-#ifdef ABL_STAMPS
+#ifdef VAMP_LIFT_STAMPS
       long long sa = STAMP();
 #endif
       // ---- stage chunk [t0, t0 + nst) from the registers
@@ -428,14 +420,11 @@ lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_
           eg = en;
         }
       }
-#ifdef ABL_STAMPS
+#ifdef VAMP_LIFT_STAMPS
       long long sb = STAMP(); st_stage += sb - sa;
 #endif
       // ---- consume: lane = (pixel, slot), the pair's 16 channels in the lane
       const int sce = kFix - eg - efl;
-#ifdef ABL_NOCONSUME
-      if (t0 == 12345)
-#endif
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int lo = max(lo_h[h], t0), hi = min(hi_h[h], t0 + nst), mid = mid_h[h];
@@ -465,7 +454,7 @@ lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_
           }
         }
       }
-#ifdef ABL_STAMPS
+#ifdef VAMP_LIFT_STAMPS
       __syncthreads();
       st_cons += STAMP() - sb;
 #endif
@@ -480,7 +469,7 @@ lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_
         reinterpret_cast<float4*>(stage + (wv * kS + p) * 16)[k] = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
     }
     __syncthreads();
-#ifdef ABL_STAMPS
+#ifdef VAMP_LIFT_STAMPS
     st2 = STAMP();
 #endif
     {
@@ -549,7 +538,7 @@ lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_
       }
     }
   }
-#ifdef ABL_STAMPS
+#ifdef VAMP_LIFT_STAMPS
   __syncthreads();
   if (tid == 0 && blockIdx.x < 16384) {
     long long* o = g_stamps + (long) blockIdx.x * 8;
@@ -558,7 +547,7 @@ lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_
 #endif
 }
 
-#ifdef ABL_STAMPS
+#ifdef VAMP_LIFT_STAMPS
 }  // namespace vamp
 extern "C" int vamp_debug_read_stamps(long long* host, int n) {
   return (int) hipMemcpyFromSymbol(host, HIP_SYMBOL(vamp::g_stamps), (size_t) n * 8 * sizeof(long long));
