@@ -141,10 +141,21 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
                            const float4* __restrict__ R, const float* __restrict__ Gcl,
                            float* __restrict__ gdens, float* __restrict__ gsem,
                            float* __restrict__ grgb, long ncell_b, int runs_x, int heavy_thresh,
-                           int accumulate, BetaTail btail, const int* __restrict__ runs) {
+                           int accumulate, BetaTail btail, const int* __restrict__ runs,
+                           const int* __restrict__ heavy, const int* __restrict__ nheavy, unsigned heavy_blocks) {
   constexpr int CP = CP4 * 4;
   constexpr int CVPB = 256 / CGL;
   beta_tail(btail);                     // the ray pass's d beta partials (a launch of its own before round 3)
+  // The first `heavy_blocks` workgroups drain the heavy-voxel list (one voxel per workgroup and turn): the
+  // two jobs own disjoint voxels, so they share a launch -- the long-running voxels start first, the x-run
+  // workgroups fill in behind them, and no second stream or launch is needed to overlap the two.
+  if (blockIdx.x < heavy_blocks) {
+    __shared__ float part[4][CP];
+    cam_heavy_drain<CP4>(P, off, boff, R, Gcl, gdens, gsem, grgb, heavy, nheavy, ncell_b, accumulate,
+                         (int) blockIdx.x, (int) heavy_blocks, part);
+    return;
+  }
+  const unsigned bid = blockIdx.x - heavy_blocks;
   __shared__ float outs[CP][CVPB + 1];
   __shared__ int skip[CVPB];            // the voxel is on the heavy list: its outputs are not ours
   const int tid = threadIdx.x;
@@ -153,8 +164,8 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
   // slower: the slabs next to the cameras carry most of the records)
   // accumulate mode: only the flagged x-runs have anything to add (cam_heavy_list_kernel): one
   // scalar load decides, instead of 512 offset loads and a barrier
-  if (runs && runs[blockIdx.x] == 0) return;
-  const unsigned lin = blockIdx.x;
+  if (runs && runs[bid] == 0) return;
+  const unsigned lin = bid;
   const int bx = lin % (unsigned) runs_x;
   const unsigned rest = lin / (unsigned) runs_x;
   const int ix = bx * CVPB + g, iy = rest % (unsigned) P.Y;
@@ -219,21 +230,22 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
   }
 }
 
-// One workgroup per queued voxel: 256 lanes stream its records, fixed-order reduction.
+// One workgroup per queued voxel: 256 lanes stream its records, fixed-order reduction.  `first` / `stride`:
+// the workgroup's first item and the number of workgroups draining the list.
 template <int CP4>
-__global__ void __launch_bounds__(256)
-cam_bwd_cell_heavy_kernel(RenderParams P, const int* __restrict__ off, const int* __restrict__ boff,
-                          const float4* __restrict__ R, const float* __restrict__ Gcl,
-                          float* __restrict__ gdens, float* __restrict__ gsem,
-                          float* __restrict__ grgb, const int* __restrict__ heavy,
-                          const int* __restrict__ nheavy, long ncell_b, int accumulate) {
+__device__ __forceinline__ void cam_heavy_drain(const RenderParams& P, const int* __restrict__ off,
+                                                const int* __restrict__ boff, const float4* __restrict__ R,
+                                                const float* __restrict__ Gcl, float* __restrict__ gdens,
+                                                float* __restrict__ gsem, float* __restrict__ grgb,
+                                                const int* __restrict__ heavy, const int* __restrict__ nheavy,
+                                                long ncell_b, int accumulate, int first, int stride,
+                                                float (&part)[4][CP4 * 4]) {
   constexpr int CP = CP4 * 4;
-  __shared__ float part[4][CP];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int nch = 1 + P.K + 3;
   const long V = (long) P.Z * P.Y * P.X;
   const int n = *nheavy;
-  for (int item = blockIdx.x; item < n; item += gridDim.x) {
+  for (int item = first; item < n; item += stride) {
     int vid = heavy[item];
     const int ix = vid % P.X; vid /= P.X;
     const int iy = vid % P.Y; vid /= P.Y;
@@ -250,10 +262,7 @@ cam_bwd_cell_heavy_kernel(RenderParams P, const int* __restrict__ off, const int
 #pragma unroll
     for (int c = 0; c < CP; ++c) acc[c] = 0.f;
     const float fix = (float) ix, fiy = (float) iy, fiz = (float) iz;
-#ifndef VAMP_HEAVY_U
-#define VAMP_HEAVY_U 1
-#endif
-    constexpr int U = VAMP_HEAVY_U;
+    constexpr int U = 1;
     for (int k = tid; k < cr.tot; k += U * 256)
       cell_accumulate<CP4, U>(cr, k, 256, R, Gcl, fix, fiy, fiz, acc);
     {
@@ -270,6 +279,18 @@ cam_bwd_cell_heavy_kernel(RenderParams P, const int* __restrict__ off, const int
     if (optr) *optr = prev + ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
     __syncthreads();
   }
+}
+
+template <int CP4>
+__global__ void __launch_bounds__(256)
+cam_bwd_cell_heavy_kernel(RenderParams P, const int* __restrict__ off, const int* __restrict__ boff,
+                          const float4* __restrict__ R, const float* __restrict__ Gcl,
+                          float* __restrict__ gdens, float* __restrict__ gsem,
+                          float* __restrict__ grgb, const int* __restrict__ heavy,
+                          const int* __restrict__ nheavy, long ncell_b, int accumulate) {
+  __shared__ float part[4][CP4 * 4];
+  cam_heavy_drain<CP4>(P, off, boff, R, Gcl, gdens, gsem, grgb, heavy, nheavy, ncell_b, accumulate,
+                       (int) blockIdx.x, (int) gridDim.x, part);
 }
 
 // ---------------------------------------------------------------------------
@@ -424,14 +445,18 @@ int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const fl
   VAMP_REQUIRE(nblk < 0x7fffffffL, "too many x-runs");
   const unsigned grid = (unsigned) nblk;
   const unsigned hgrid = (unsigned) std::min<size_t>(voxels, 8192);
+  // gather and heavy drain in ONE launch when the caller asks for both in one call (the default)
+  const bool merged = (parts & kCamPartGather) && (parts & kCamPartHeavy);
+  const unsigned hgrid_m = (unsigned) std::min<size_t>(voxels, 2048);
   // the two kernels own disjoint voxels (the heavy list was built with the cell lists), so the
   // caller may run them on two streams: parts selects
 #define VAMP_CELL(CP4)                                                                              \
   do {                                                                                              \
     if (parts & kCamPartGather)                                                                     \
-      VAMP_TIMED(kProfCamBwdBrick, s, (cam_bwd_cell_gather_kernel<CP4, gl><<<grid, 256, 0, s>>>(    \
-          P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, ncell_b, runs_x, heavy_thresh, accumulate, btail, runs))); \
-    if (parts & kCamPartHeavy)                                                                      \
+      VAMP_TIMED(kProfCamBwdBrick, s, (cam_bwd_cell_gather_kernel<CP4, gl><<<grid + (merged ? hgrid_m : 0u), 256, 0, s>>>( \
+          P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, ncell_b, runs_x, heavy_thresh, accumulate, btail, runs, \
+          w.heavy, nheavy, merged ? hgrid_m : 0u)));                                                \
+    if ((parts & kCamPartHeavy) && !merged)                                                         \
       VAMP_TIMED(kProfCamBwdOwn, s, (cam_bwd_cell_heavy_kernel<CP4><<<hgrid, 256, 0, s>>>(          \
           P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, w.heavy, nheavy, ncell_b, accumulate)));   \
   } while (0)

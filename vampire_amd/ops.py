@@ -100,7 +100,9 @@ class HotPath:
                      # and prepare pass on the side stream; "split" = table, copy and prepare pass on the
                      # side stream, BEV branch and march on the caller's
                      "sched": os.environ.get("VAMP_SCHED", "split"),
-                     # the heavy-voxel kernel of the camera backward on the side stream beside the gather
+                     # two-stream steps: the heavy-voxel drain of the camera backward as a kernel of its own on the side stream
+                     # beside the gather (replayed step 0.504 vs 0.512 ms); one-stream calls drain the list inside the
+                     # gather launch (its first workgroups: 66 us against 37 + 38)
                      "heavy_side": os.environ.get("VAMP_HEAVY_SIDE", "1") == "1",
                      # the slot table and heavy list of the camera backward in front of its ray pass
                      # instead of at the end of the forward's prepare pass: measured slower (graph step
