@@ -101,6 +101,11 @@ int vamp_lift_forward(const VampLiftDesc* d, const float* mats, const float* xs,
  * vamp_lift_forward.
  */
 #define VAMP_LIFTFWD_EMIT_PAIRS 1
+/* with EMIT_PAIRS: the caller asserts that the cell counters in `workspace` are zero -- as a zero-filled
+   buffer has them, and as every completed vamp_lift_forward_ex(EMIT_PAIRS) / vamp_lift_prepare /
+   vamp_lift_backward on this workspace leaves them (the scan zeroes what it has read, the backward's gather
+   the cursors of the fill) -- so the zero fill in front of the kernel is skipped */
+#define VAMP_LIFTFWD_CELLS_CLEAN 2
 int vamp_lift_forward_ex(const VampLiftDesc* d, const float* mats, const float* xs,
                          const float* ys, const float* zs, const void* depth,
                          const void* feat, float* out, uint64_t* hits,
@@ -323,6 +328,7 @@ int vamp_render_camera_prepare(const VampRenderDesc* d, const float* mats, const
 /* flags: VAMP_CAMPREP_TERM_VALID -- sort only the samples the early-termination table in
    `workspace` keeps (the backward must then be given VAMP_CAMBWD_TERM_VALID too) */
 #define VAMP_CAMPREP_TERM_VALID 1
+#define VAMP_CAMPREP_COUNTERS_CLEAN 4   /* the caller asserts that the cell counters in `workspace` are zero (a zero-filled buffer, or one a completed prepare pass has run on: its scan zeroes what it reads): no zero fill */
 #define VAMP_CAMPREP_RANK_ONLY 2   /* stop after ranking and scanning the cells (what needs the termination table); the backward finishes (VAMP_CAMBWD_SLOTS_PENDING) */
 int vamp_render_camera_prepare_ex(const VampRenderDesc* d, const float* mats, const float* us,
                                   const float* vs, const float* ds, void* workspace,

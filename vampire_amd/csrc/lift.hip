@@ -471,14 +471,15 @@ static LiftWs carve(const VampLiftDesc* d, void* ws) {
 template <typename T>
 static int lift_forward_t(const VampLiftDesc* d, const LiftParams& P, const float* mats,
                           const float* xs, const float* ys, const float* zs, const void* depth,
-                          const float* feat_cl, float* out, uint64_t* hits, void* cells, hipStream_t s) {
+                          const float* feat_cl, float* out, uint64_t* hits, void* cells, bool cells_clean,
+                          hipStream_t s) {
   constexpr int TX = VAMP_LIFT_TX, TY = VAMP_LIFT_TY, TZ = 1;
   dim3 grid((P.X + TX - 1) / TX, (P.Y + TY - 1) / TY, ((P.Z + TZ - 1) / TZ) * P.B);
   const T* dp = static_cast<const T*>(depth);
   LiftEmit E{};
   if (cells) {
     VAMP_REQUIRE(d->N <= 15, "at most 15 cameras");
-    if (int e = launch_lift_cells_begin(d, cells, s)) return e;
+    if (int e = launch_lift_cells_begin(d, cells, s, cells_clean)) return e;
     E = lift_emit_of(d, cells);
   }
 #define VAMP_FWD(CH, EM)                                                                               \
@@ -556,9 +557,10 @@ int vamp_lift_forward_ex(const VampLiftDesc* d, const float* mats, const float* 
   else launch_to_cl<__hip_bfloat16>(feat, w.feat_cl, BN, d->C, HW, s);
   if (int e = check_launch("feat_to_channel_last")) return e;
   void* cells = (flags & VAMP_LIFTFWD_EMIT_PAIRS) ? w.cells : nullptr;
+  const bool clean = (flags & VAMP_LIFTFWD_CELLS_CLEAN) != 0;
   if (d->in_dtype == VAMP_F32)
-    return lift_forward_t<float>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, cells, s);
-  return lift_forward_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, cells, s);
+    return lift_forward_t<float>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, cells, clean, s);
+  return lift_forward_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, cells, clean, s);
 }
 
 int vamp_lift_forward_logits(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
@@ -603,7 +605,8 @@ int vamp_lift_forward_logits_ex(const VampLiftDesc* d, const float* mats, const 
 #undef VAMP_OPERANDS
   if (int e = check_launch("lift_operands_kernel")) return e;
   return lift_forward_t<float>(d, P, mats, xs, ys, zs, depth_out, w.feat_cl, out, hits,
-                               (flags & VAMP_LIFTFWD_EMIT_PAIRS) ? w.cells : nullptr, s);
+                               (flags & VAMP_LIFTFWD_EMIT_PAIRS) ? w.cells : nullptr,
+                               (flags & VAMP_LIFTFWD_CELLS_CLEAN) != 0, s);
 }
 
 int vamp_lift_prepare(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,

@@ -197,7 +197,7 @@ lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_
                       const T* __restrict__ depth, const T* __restrict__ feat,
                       const int* __restrict__ off, const int* __restrict__ boff,
                       const int* __restrict__ ids, const float4* __restrict__ recs,
-                      const float4* __restrict__ table, const int* __restrict__ rowq,
+                      const float4* __restrict__ table, const int* __restrict__ rowq, int* __restrict__ cnt,
                       float* __restrict__ gdepth, float* __restrict__ gfeat, int softmax_bwd) {
   extern __shared__ float smem[];
   constexpr int NT = kW * 64;
@@ -237,6 +237,9 @@ lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_
     const int h = tid / (kS + 2), j = tid % (kS + 2);
     const long c = (bn * ch + iy + h) * cw + min(x0 + j, cw);
     offs[tid] = off[c] + boff[c / kScanTile];
+    // the fill's cursors (= the counters the next forward counts into) go back to zero: this strip owns
+    // the cells of its row and columns, the last strip of a row also column fW, the last row also row fH
+    if ((h == 0 || iy == P.fH - 1) && (j < np || (j == np && x0 + np == P.fW))) cnt[c] = 0;
   }
   // the depth columns: 16-byte pieces of the planes' 64-byte runs (fW % 4 == 0), else single values
   if (VEC) {
@@ -561,13 +564,14 @@ namespace vamp {
 size_t lift_bwd_cell_ws_bytes(const VampLiftDesc* d) { return lift_cell_ws(d, nullptr).bytes; }
 
 // zero the counters in front of a kernel that emits pairs / scan them behind it
-int launch_lift_cells_begin(const VampLiftDesc* d, void* scratch, hipStream_t s) {
+int launch_lift_cells_begin(const VampLiftDesc* d, void* scratch, hipStream_t s, bool clean) {
   const LiftCells g = lift_cells(d);
   const LiftCellWs w = lift_cell_ws(d, scratch);
   const size_t cap = (size_t) d->B * d->N * d->Z * d->Y * d->X;
   VAMP_REQUIRE(cap < 0x7fffffffu && g.ncell < 0x7fffffffL, "pair / cell count exceeds 2^31");
   VAMP_REQUIRE(d->C % 4 == 0, "C must be a multiple of 4");
   VAMP_REQUIRE(d->fW < 32767 && d->fH < 32767 && d->D < 65535, "feature map too large for the packed cell coordinates");
+  if (clean) return VAMP_OK;        // (VAMP_LIFTFWD_CELLS_CLEAN: the caller vouches for zeroed counters)
   return launch_zero(w.cnt, (size_t) (g.ncell + kScanPad) * sizeof(int), s);
 }
 
@@ -618,7 +622,7 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
       return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);
     VAMP_TIMED(kProfLiftBwd, s, (k<<<ggrid, kW * 64, lds, s>>>(
         P, g.cw, g.ch, spr, spr, bn_lo, cap, static_cast<const T*>(depth), static_cast<const T*>(feat),
-        w.off, w.boff, w.ids, w.recs, w.table, w.rowq, gdepth, gfeat, softmax_bwd ? 1 : 0)));
+        w.off, w.boff, w.ids, w.recs, w.table, w.rowq, w.cnt, gdepth, gfeat, softmax_bwd ? 1 : 0)));
   }
   return check_launch("lift_bwd_strip_kernel");
 }

@@ -189,7 +189,7 @@ int launch_lift_bwd_cell(const VampLiftDesc* d, const float* mats, const float* 
 int launch_lift_cell_prepare(const VampLiftDesc* d, const float* mats, const float* xs,
                              const float* ys, const float* zs, void* scratch, hipStream_t s);
 // zero the cell counters (before a kernel that emits pairs) / scan them (after it)
-int launch_lift_cells_begin(const VampLiftDesc* d, void* scratch, hipStream_t s);
+int launch_lift_cells_begin(const VampLiftDesc* d, void* scratch, hipStream_t s, bool clean = false);
 int launch_lift_cells_end(const VampLiftDesc* d, void* scratch, hipStream_t s);
 
 }  // namespace vamp

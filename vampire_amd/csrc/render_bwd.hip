@@ -25,7 +25,7 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
                       int parts, hipStream_t s);
 int launch_cam_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                        const float* us, const float* vs, const float* ds, void* scratch,
-                       const int* term, int phase, hipStream_t s);
+                       const int* term, int phase, hipStream_t s, bool counters_clean = false);
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
   // wave reduce then 4-wave LDS reduce; result valid in thread 0
@@ -361,7 +361,8 @@ int vamp_render_camera_prepare_ex(const VampRenderDesc* d, const float* mats, co
   const RenderParams P = to_params(d);
   return launch_cam_prepare(d, P, mats, us, vs, ds, static_cast<char*>(workspace) + packed_bytes(d),
                             (flags & VAMP_CAMPREP_TERM_VALID) ? cam_term_ptr(d, workspace) : nullptr,
-                            (flags & VAMP_CAMPREP_RANK_ONLY) ? 1 : 0, static_cast<hipStream_t>(stream));
+                            (flags & VAMP_CAMPREP_RANK_ONLY) ? 1 : 0, static_cast<hipStream_t>(stream),
+                            (flags & VAMP_CAMPREP_COUNTERS_CLEAN) != 0);
 }
 
 int vamp_render_camera_backward(const VampRenderDesc* d, const float* geom, const float* mats,

@@ -351,7 +351,7 @@ static int launch_cam_heavy_list(const VampRenderDesc* d, const RenderParams& P,
 // 2: heavy list (needs the scan only) -- a caller may leave phase 2 to the backward
 int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                              const float* us, const float* vs, const float* ds, void* scratch,
-                             const int* term, int phase, hipStream_t s) {
+                             const int* term, int phase, hipStream_t s, bool counters_clean) {
   const CellWs w = cell_ws(d, scratch);
   const long ncell = cell_count_padded(d->B, d->Z, d->Y, d->X);
   const size_t samples = (size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW;
@@ -360,7 +360,8 @@ int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, con
                "sample / voxel / cell count exceeds 2^31");
   const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
   if (phase != 2) {
-    if (int ze = launch_zero(w.cnt, (size_t) (ncell + kScanPad) * sizeof(int), s)) return ze;
+    if (!counters_clean)            // (VAMP_CAMPREP_COUNTERS_CLEAN: the previous scan left them at zero)
+      if (int ze = launch_zero(w.cnt, (size_t) (ncell + kScanPad) * sizeof(int), s)) return ze;
     VAMP_TIMED(kProfCamBwdCount, s, (cam_cells_rank_kernel<<<ray_grid<4>(P), 256, 0, s>>>(
         P, mats, us, vs, ds, w.cnt, w.rank, ncell_b, term)));
     if (int e = check_launch("cam_cells_rank_kernel")) return e;

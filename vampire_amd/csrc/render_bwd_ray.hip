@@ -246,7 +246,7 @@ size_t cam_bwd_cell_bytes(const VampRenderDesc* d);
 CamCellRefs cam_cell_refs(const VampRenderDesc* d, void* scratch);
 int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                              const float* us, const float* vs, const float* ds, void* scratch,
-                             const int* term, int phase, hipStream_t s);
+                             const int* term, int phase, hipStream_t s, bool counters_clean = false);
 int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const float* Gcl,
                         float* gdens, float* gsem, float* grgb, void* scratch, int accumulate,
                         hipEvent_t wait_event, int parts, BetaTail btail, hipStream_t s);
@@ -265,8 +265,9 @@ size_t cam_bwd_v2_bytes(const VampRenderDesc* d) { return gcl_bytes(d) + cam_bwd
 // scratch = workspace region after the packed volume: [Gcl | cell lists | beta partials]
 int launch_cam_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                        const float* us, const float* vs, const float* ds, void* scratch,
-                       const int* term, int phase, hipStream_t s) {
-  return launch_cam_cells_prepare(d, P, mats, us, vs, ds, static_cast<char*>(scratch) + gcl_bytes(d), term, phase, s);
+                       const int* term, int phase, hipStream_t s, bool counters_clean) {
+  return launch_cam_cells_prepare(d, P, mats, us, vs, ds, static_cast<char*>(scratch) + gcl_bytes(d), term, phase, s,
+                                  counters_clean);
 }
 
 int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const float* mats,

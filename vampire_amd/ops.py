@@ -81,6 +81,7 @@ class HotPath:
         ozs_cpu = G.axis_centres(cfg.z_bound_det)
         self.ozs_host = (C.c_float * ozs_cpu.numel())(*ozs_cpu.tolist())
         self._ws = {}
+        self._dirty = set()         # workspaces whose cell counters a call in flight (or one that raised) may have left non-zero
         # Implementation selectors (host-side state of this object; the library itself keeps none):
         # "cell" = the default cell-list gathers, "v1" = the float-atomic splats kept as independent
         # cross-checks for the tests; lift_wpp forces the lift gather's waves per pixel (0 = auto).
@@ -183,11 +184,21 @@ class HotPath:
             self._side = torch.cuda.Stream(device=self.device)
         return self._side
 
+    def _cam_clean_flag(self):
+        """VAMP_CAMPREP_COUNTERS_CLEAN when the render workspace's cell counters are known to be zero (fresh
+        zero-filled buffer, or the last prepare pass on it was issued in full); marks them in flight."""
+        clean = "render" not in self._dirty
+        self._dirty.add("render")
+        return _capi.VAMP_CAMPREP_COUNTERS_CLEAN if clean else 0
+
     def _workspace(self, key, nbytes):
         t = self._ws.get(key)
         if t is None or t.numel() < nbytes:
-            t = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+            # zero-filled once: the cell counters inside start clean, and every completed pass leaves them
+            # clean again (VAMP_LIFTFWD_CELLS_CLEAN / VAMP_CAMPREP_COUNTERS_CLEAN), so no step zeroes them
+            t = torch.zeros(max(nbytes, 256), dtype=torch.uint8, device=self.device)
             self._ws[key] = t
+            self._dirty.discard(key)
         return t
 
     # ----------------------------------------------------------------- lift
@@ -403,6 +414,9 @@ class _LiftFn(torch.autograd.Function):
             # counts the backward's (voxel, camera) pairs per pixel cell and leaves their taps in the
             # workspace, so the backward never projects (VAMP_PREPARE=0: the backward does it itself)
             flags = _capi.VAMP_LIFTFWD_EMIT_PAIRS
+            if "lift" not in hp._dirty:
+                flags |= _capi.VAMP_LIFTFWD_CELLS_CLEAN
+            hp._dirty.add("lift")           # (until this call has been issued in full)
             ctx.cells_key = (hp._lift_gen, ws.data_ptr())
         if logits:
             _capi.check(hp.lib.vamp_lift_forward_logits_ex(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys), _ptr(hp.zs),
@@ -414,6 +428,7 @@ class _LiftFn(torch.autograd.Function):
                                                     _ptr(depth if use_depth else None), _ptr(feat), _ptr(out),
                                                     _ptr(hits), _ptr(ws), ws.numel(), flags, _stream(cur)),
                         "vamp_lift_forward_ex")
+        hp._dirty.discard("lift")           # emit + scan issued: the counters are back at zero
         if need_grad:
             ctx.hp, ctx.desc, ctx.use_depth = hp, d, use_depth
             ctx.save_for_backward(depth if use_depth else feat, feat, mats, hits)
@@ -437,6 +452,8 @@ class _LiftFn(torch.autograd.Function):
             valid |= _capi.VAMP_LIFTBWD_LOGITS
         valid |= {1: _capi.VAMP_LIFTBWD_WPP1, 4: _capi.VAMP_LIFTBWD_WPP4,
                   16: _capi.VAMP_LIFTBWD_WPP16}.get(hp.impl["lift_wpp"], 0)
+        hp._dirty.add("lift")
+
         def call(flags, stream):
             _capi.check(hp.lib.vamp_lift_backward_ex(C.byref(d), _ptr(mats), _ptr(hp.xs), _ptr(hp.ys), _ptr(hp.zs),
                                                      _ptr(depth if use_depth else None), _ptr(feat), _ptr(g),
@@ -454,6 +471,8 @@ class _LiftFn(torch.autograd.Function):
             cur.wait_stream(side)
         else:
             call(valid, None)
+        if hp.impl["lift_bwd"] == "cell":
+            hp._dirty.discard("lift")       # the gather has re-zeroed the fill's cursors
         if ctx.logits and hp.impl["lift_bwd"] == "v1":
             # (the cross-check implementation returns the gradient of the distribution)
             gdepth = depth * (gdepth - (depth * gdepth).sum(2, keepdim=True))
@@ -577,8 +596,9 @@ class _RenderFn(torch.autograd.Function):
             late = hp.impl["slots_late"] and hp.impl["heavy_side"]
             _capi.check(hp.lib.vamp_render_camera_prepare_ex(
                 C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(),
-                _capi.VAMP_CAMPREP_TERM_VALID | (_capi.VAMP_CAMPREP_RANK_ONLY if late else 0), _stream(side)),
-                "vamp_render_camera_prepare_ex")
+                _capi.VAMP_CAMPREP_TERM_VALID | (_capi.VAMP_CAMPREP_RANK_ONLY if late else 0) | hp._cam_clean_flag(),
+                _stream(side)), "vamp_render_camera_prepare_ex")
+            hp._dirty.discard("render")
             ctx.cells = 2 if late else True
             bev_save = train and hp.impl["bev_save"] and hp.impl["bev_bwd"] != "v1"
             ws_bev = (hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d))) if bev_save else None)
@@ -614,8 +634,9 @@ class _RenderFn(torch.autograd.Function):
             late = hp.impl["slots_late"] and hp.impl["heavy_side"]
             _capi.check(hp.lib.vamp_render_camera_prepare_ex(
                 C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(),
-                _capi.VAMP_CAMPREP_TERM_VALID | (_capi.VAMP_CAMPREP_RANK_ONLY if late else 0), _stream(side)),
-                "vamp_render_camera_prepare_ex")
+                _capi.VAMP_CAMPREP_TERM_VALID | (_capi.VAMP_CAMPREP_RANK_ONLY if late else 0) | hp._cam_clean_flag(),
+                _stream(side)), "vamp_render_camera_prepare_ex")
+            hp._dirty.discard("render")
             ctx.cells = 2 if late else True
             bev_save = train and hp.impl["bev_save"] and hp.impl["bev_bwd"] != "v1"
             ws_bev = (hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d))) if bev_save else None)
@@ -671,7 +692,9 @@ class _RenderFn(torch.autograd.Function):
                     # builds its cell lists itself)
                     _capi.check(hp.lib.vamp_render_camera_prepare_ex(
                         C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(),
-                        _capi.VAMP_CAMPREP_TERM_VALID if ert else 0, _stream(side)), "vamp_render_camera_prepare_ex")
+                        (_capi.VAMP_CAMPREP_TERM_VALID if ert else 0) | hp._cam_clean_flag(), _stream(side)),
+                        "vamp_render_camera_prepare_ex")
+                    hp._dirty.discard("render")
                     ctx.cells = True
             # training: the BEV branch keeps its density / semantic / rgb samples for its backward
             bev_save = train and hp.impl["bev_save"] and hp.impl["bev_bwd"] != "v1"
@@ -751,6 +774,10 @@ class _RenderFn(torch.autograd.Function):
                     _ptr(g_seg), _ptr(g_dep))
         cur, side = torch.cuda.current_stream(), hp._side_stream()
         default_impl = hp.impl["cam_bwd"] != "v1"
+        if not default_impl or geom is not None or not ctx.cells:
+            # the v1 splat keeps a packed gradient copy where the cell lists live, and a backward that builds
+            # its own cell lists may stop half way: either way the counters there are no longer known zero
+            hp._dirty.add("render")
         packed_valid = 2 if ctx.pack_key == (getattr(hp, "_pack_gen", 0), ws.data_ptr()) else 0
         if packed_valid and ctx.cells:
             packed_valid |= 4                                    # VAMP_CAMBWD_CELLS_VALID
