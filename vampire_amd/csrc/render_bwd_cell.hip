@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256)
 cam_cells_rank_kernel(RenderParams P, const float* __restrict__ mats, const float* __restrict__ us,
                       const float* __restrict__ vs, const float* __restrict__ ds,
                       int* __restrict__ cnt, int* __restrict__ RANK, long ncell_b,
-                      const int* __restrict__ term) {
+                      const int* __restrict__ term, int* __restrict__ tile_se) {
   __shared__ int4 plan[kPlanMax];
   const RayId id = decode_ray_wps(P);
   const int lane = threadIdx.x & 63, sub = id.sub;
@@ -69,6 +69,8 @@ cam_cells_rank_kernel(RenderParams P, const float* __restrict__ mats, const floa
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) Se = max(Se, __shfl_xor(Se, o, 64));
   Se = __builtin_amdgcn_readfirstlane(Se);
+  // the tile's depth (its longest ray): the per-ray pass takes the deepest tiles first (cam_heavy_list_kernel sorts)
+  if (threadIdx.x == 0 && id.tile_ok) tile_se[id.tile] = Se;
   const bool planned = S <= kPlanMax;                              // uniform
   PlanMask mk{~0ull, ~0ull};
   if (planned) {
@@ -306,6 +308,8 @@ struct CellWs {
   int* runs;       // [x-runs] 1 = the gather's workgroup has something to add (accumulate mode)
   int* rank;       // [tiles][S][64] rank of the sample inside its cell (written for kept inside samples only)
   int* slot;       // [tiles][S][64] slot in R (-1 = masked): the per-ray pass's note between its two loops
+  int* tile_se;    // [tiles] kept samples of the tile's longest ray
+  int* tile_order; // [tiles] tiles sorted by that, longest first
   float4* R;       // [samples][2] records in cell order
   size_t bytes;
 };
@@ -328,6 +332,9 @@ static CellWs cell_ws(const VampRenderDesc* d, void* scratch) {
   w.runs = reinterpret_cast<int*>(p); p += align_up((size_t) d->B * d->Z * d->Y * ((d->X + kRunVox - 1) / kRunVox) * sizeof(int), 256);
   w.rank = reinterpret_cast<int*>(p); p += align_up(tsamples * sizeof(int), 256);
   w.slot = reinterpret_cast<int*>(p); p += align_up(tsamples * sizeof(int), 256);
+  const size_t tiles = tsamples / ((size_t) 64 * (d->D - 1));
+  w.tile_se = reinterpret_cast<int*>(p); p += align_up(tiles * sizeof(int), 256);
+  w.tile_order = reinterpret_cast<int*>(p); p += align_up(tiles * sizeof(int), 256);
   w.R = reinterpret_cast<float4*>(p); p += align_up(samples * 2 * sizeof(float4), 256);
   w.bytes = (size_t) (p - static_cast<char*>(scratch));
   return w;
@@ -340,6 +347,7 @@ CamCellRefs cam_cell_refs(const VampRenderDesc* d, void* scratch) {
   const CellWs w = cell_ws(d, scratch);
   CamCellRefs r;
   r.rank = w.rank; r.slot = w.slot; r.off = w.off; r.boff = w.boff; r.R = w.R;
+  r.tile_order = w.tile_order;
   r.ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
   return r;
 }
@@ -363,7 +371,7 @@ int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, con
     if (!counters_clean)            // (VAMP_CAMPREP_COUNTERS_CLEAN: the previous scan left them at zero)
       if (int ze = launch_zero(w.cnt, (size_t) (ncell + kScanPad) * sizeof(int), s)) return ze;
     VAMP_TIMED(kProfCamBwdCount, s, (cam_cells_rank_kernel<<<ray_grid<4>(P), 256, 0, s>>>(
-        P, mats, us, vs, ds, w.cnt, w.rank, ncell_b, term)));
+        P, mats, us, vs, ds, w.cnt, w.rank, ncell_b, term, w.tile_se)));
     if (int e = check_launch("cam_cells_rank_kernel")) return e;
     if (int e = launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, ncell, s)) return e;
   }
@@ -382,7 +390,25 @@ int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, con
 __global__ void __launch_bounds__(256)
 cam_heavy_list_kernel(RenderParams P, const int* __restrict__ off, const int* __restrict__ boff,
                       int* __restrict__ heavy, int* __restrict__ nheavy, int* __restrict__ runs,
-                      long ncell_b, long total_runs, int runs_x, int thresh) {
+                      long ncell_b, long total_runs, int runs_x, int thresh,
+                      const int* __restrict__ tile_se, int* __restrict__ tile_order, int ntiles) {
+  // A duty of the first workgroup: the order in which the per-ray pass takes the ray tiles -- deepest
+  // first (counting sort by the bit length of the tile's longest ray).  With early ray termination a few
+  // tiles hold a ray that never saturates and march 85 samples where the others march 8: started last
+  // they were the kernel's tail (23 tiles of 1 056, 42 us each, in a kernel of 56 us).
+  if (blockIdx.x == 0) {
+    __shared__ int cls[34];
+    if (threadIdx.x < 34) cls[threadIdx.x] = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < ntiles; t += 256) atomicAdd(cls + (32 - __clz(max(tile_se[t], 0))), 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int acc = 0;
+      for (int k = 32; k >= 0; --k) { const int n = cls[k]; cls[k] = acc; acc += n; }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < ntiles; t += 256) tile_order[atomicAdd(cls + (32 - __clz(max(tile_se[t], 0))), 1)] = t;
+  }
   const long run = (long) blockIdx.x * (256 / kRunVox) + threadIdx.x / kRunVox;
   const bool run_ok = run < total_runs;
   const long rc = run_ok ? run : total_runs - 1;
@@ -415,7 +441,8 @@ static int launch_cam_heavy_list(const VampRenderDesc* d, const RenderParams& P,
   const long total_runs = (long) runs_x * d->Y * d->Z * d->B;
   int* nheavy = w.aux + ntile + 1;              // zeroed by the scan that just ran (runtime.hip)
   VAMP_TIMED(kProfAux, s, (cam_heavy_list_kernel<<<(unsigned) ((total_runs * kRunVox + 255) / 256), 256, 0, s>>>(
-      P, w.off, w.boff, w.heavy, nheavy, w.runs, ncell_b, total_runs, runs_x, kHeavy)));
+      P, w.off, w.boff, w.heavy, nheavy, w.runs, ncell_b, total_runs, runs_x, kHeavy, w.tile_se, w.tile_order,
+      (int) ((long) d->B * d->N * ((d->fH + 7) / 8) * ((d->fW + 7) / 8)))));
   return check_launch("cam_heavy_list_kernel");
 }
 

@@ -44,7 +44,10 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
   // wave-per-depth-chunk mapping (render_common.hpp): lanes = the 64 rays of an 8x8 tile
   static_assert(LPR == 4, "the four waves of the workgroup are the four depth chunks");
   __shared__ float xm[2 * 4 * 64];
-  const RayId id = decode_ray_wps(P);
+  // tiles deepest first (cells.tile_order, from the prepare pass); the grid is padded to a multiple of 8
+  const long ntiles = (long) P.B * P.N * ((P.fH + 7) / 8) * ((P.fW + 7) / 8);
+  const RayId id = cells.tile_order ? decode_ray_tile(P, blockIdx.x < ntiles ? cells.tile_order[blockIdx.x] : -1)
+                                    : decode_ray_wps(P);
   const bool live = id.live;
   float4* __restrict__ REC = cells.R;
   const int w = id.w, h = id.h, sub = id.sub, b = id.b;

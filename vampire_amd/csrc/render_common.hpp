@@ -56,6 +56,7 @@ struct RayId {
   long bn;
   int b;
   long tile;     // 8 x 8 ray tile of the ray (decode_ray_wps only): per-sample tables are [tile][depth index][64]
+  bool tile_ok;  // the workgroup has a tile of its own (the grid is padded to a multiple of 8)
 };
 
 template <int LPR>
@@ -97,25 +98,31 @@ __device__ __forceinline__ RayId decode_ray(const RenderParams& P) {
 // the same depth on neighbouring rays, so lanes that need the same tap are merged by the texture
 // addresser (one fetch), which matters in the near and mid field where many rays cross a voxel.
 // The chunks are merged through LDS instead of shuffles.  Needs 4 waves (LPR = 4).
-__device__ __forceinline__ RayId decode_ray_wps(const RenderParams& P) {
+// tile `t` (-1: none) of the wave-per-depth-chunk mapping
+__device__ __forceinline__ RayId decode_ray_tile(const RenderParams& P, long t) {
   const int tiles_w = (P.fW + 7) / 8, tiles_h = (P.fH + 7) / 8;
   const long tiles = (long) P.B * P.N * tiles_h * tiles_w;
-  const long per_xcd = (tiles + 7) / 8;
-  const long t = (long) (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   const int r = threadIdx.x & 63;
   RayId id;
   id.sub = threadIdx.x >> 6;
-  const long tc = t < tiles ? t : tiles - 1;
+  id.tile_ok = t >= 0 && t < tiles;
+  const long tc = id.tile_ok ? t : tiles - 1;
   id.tile = tc;
   id.bn = tc / (tiles_h * tiles_w);
   const int tt = (int) (tc % (tiles_h * tiles_w));
   id.h = (tt / tiles_w) * 8 + r / 8;
   id.w = (tt % tiles_w) * 8 + r % 8;
-  id.live = t < tiles && id.h < P.fH && id.w < P.fW;
+  id.live = id.tile_ok && id.h < P.fH && id.w < P.fW;
   if (id.h >= P.fH) id.h = P.fH - 1;
   if (id.w >= P.fW) id.w = P.fW - 1;
   id.b = (int) (id.bn / P.N);
   return id;
+}
+__device__ __forceinline__ RayId decode_ray_wps(const RenderParams& P) {
+  const int tiles_w = (P.fW + 7) / 8, tiles_h = (P.fH + 7) / 8;
+  const long tiles = (long) P.B * P.N * tiles_h * tiles_w;
+  const long per_xcd = (tiles + 7) / 8;
+  return decode_ray_tile(P, (long) (blockIdx.x % 8) * per_xcd + blockIdx.x / 8);
 }
 
 // exclusive prefix sum over the LPR lanes of a ray ([sub][ray] lane layout)
@@ -280,6 +287,7 @@ __device__ __forceinline__ void gather_taps(const RenderParams& P, const float* 
 
 // what the per-ray pass of the camera backward needs of the cell lists (render_bwd_cell.hip)
 struct CamCellRefs {
+  const int* tile_order; // [tiles] the order in which the per-ray pass takes the tiles (longest first), or nullptr
   const int* rank;      // [tiles][S][64] rank of a kept inside sample in its cell
   int* slot;            // [tiles][S][64] scratch of the per-ray pass
   const int* off;       // cell start = off[c] + boff[c / kScanTile]
