@@ -27,11 +27,11 @@ import sys
 import time
 
 # The layered and multi-task legs run MIOpen convolutions (image encoder, 3-D UNet, BEV head -- none of it
-# the hot path).  MIOpen's exhaustive find tunes ~150 of them for 6 minutes on a fresh box; its FAST mode
-# (find-db / heuristics) gives the same step times here (layered 11.9 vs 11.9 ms, multi-task 64.6 vs 66.5 ms)
-# in 50 s.  Set before torch loads MIOpen; an explicit MIOPEN_FIND_MODE in the environment wins.
-os.environ.setdefault("MIOPEN_FIND_MODE", "2")
-
+# the hot path).  With torch.backends.cudnn.benchmark MIOpen's find tunes ~150 of them: 6.5 minutes on a
+# fresh box (layered 57 s, multi-task 340 s; MIOPEN_FIND_MODE=FAST changes nothing -- what made one run
+# look fast was a warm kernel cache on a reused box).  The default run therefore uses MIOpen's immediate
+# mode for these two legs (no find; slower convolutions, said so in the line) and `--miopen-find` asks for
+# the tuned numbers.
 import torch
 import torch.distributed as dist
 
@@ -281,7 +281,7 @@ def extra_config(cfg_name, batch, dtype, steps=10, warm=3, ert=True, density_mod
             "fwd_frac_of_hbm_peak": ab["fwd"] * batch / (fwd_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
 
 
-def layered_measure(cfg, dev, batch_per_gpu, rank, world, steps=6, warm=3):
+def layered_measure(cfg, dev, batch_per_gpu, rank, world, steps=6, warm=3, find=False):
     """the operators between the reference backbone's own layers (step.LayeredStep: 777 111
     parameters, a 3.1 MB gradient bucket) under the bucketed GradSync (VAMP_GRAD_SYNC=ddp:
     DistributedDataParallel), so that a multi-GPU run exercises a real all-reduce overlapped with the
@@ -289,7 +289,7 @@ def layered_measure(cfg, dev, batch_per_gpu, rank, world, steps=6, warm=3):
     dominated by the 3-D UNet's convolutions, which are not part of the hot path."""
     from vampire_amd import dist as vdist
     from vampire_amd.step import LayeredStep, LayeredBatch, layered_step
-    torch.backends.cudnn.benchmark = True      # MIOpen find mode for the UNet's remaining layers (immediate mode: 10x slower)
+    torch.backends.cudnn.benchmark = find      # MIOpen find mode for the UNet's remaining layers, or immediate mode
     model = LayeredStep(cfg, dev)
     wrapped = vdist.wrap_ddp(model, dev)
     data = LayeredBatch(cfg, batch_per_gpu, dev, seed=vdist.shard_seed(0, rank))
@@ -316,7 +316,7 @@ def layered_measure(cfg, dev, batch_per_gpu, rank, world, steps=6, warm=3):
                     "voxel_output: forward + backward from synthetic neck features"}
 
 
-def multitask_measure(dev, batch_per_gpu, rank, world, steps=4, warm=2):
+def multitask_measure(dev, batch_per_gpu, rank, world, steps=4, warm=2, find=False):
     """BASELINE.json configs[4]: the full multi-task model -- ResNet-50 + SECOND FPN image encoder, the
     backbone with the HIP lift / render / query / gate operators, the CenterPoint-style BEV head -- on the
     reference's own configuration (cfg-A: 256 x 704 images, 256 x 256 x 20 seg grid, base_exp.py:40-252),
@@ -326,7 +326,7 @@ def multitask_measure(dev, batch_per_gpu, rank, world, steps=4, warm=2):
     from vampire_amd import dist as vdist
     from vampire_amd import multitask as M
     from vampire_amd.config import CFG_A
-    torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.benchmark = find
     torch.manual_seed(0)
     bb, hd = M.reference_confs(CFG_A)
     model = M.VAMPIRE2(bb, hd).to(dev)
@@ -474,6 +474,8 @@ def main():
                     help="skip the {eager, graph} x {early termination on, off} step matrix (profile runs: only default-path kernels)")
     ap.add_argument("--multitask", action="store_true", help="(accepted for compatibility: the multi-task step is always timed unless --no-extra)")
     ap.add_argument("--layers", action="store_true", help="(accepted for compatibility: the layered step is always timed unless --no-extra)")
+    ap.add_argument("--miopen-find", action="store_true",
+                    help="let MIOpen tune the convolutions of the layered / multi-task legs (6.5 minutes on a fresh box)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -669,9 +671,9 @@ def main():
     # SURVEY 8(e) / BASELINE configs[4]: the step with a real gradient bucket and the full multi-task step,
     # always in the line (a few seconds; --no-extra skips them for profile runs)
     _mark("bs8 done")
-    layered = layered_measure(cfg, dev, a.batch, rank, world) if not a.no_extra else None
+    layered = layered_measure(cfg, dev, a.batch, rank, world, find=a.miopen_find) if not a.no_extra else None
     _mark("layered step done")
-    multitask = multitask_measure(dev, a.batch, rank, world) if not a.no_extra else None
+    multitask = multitask_measure(dev, a.batch, rank, world, find=a.miopen_find) if not a.no_extra else None
     _mark("multi-task step done")
 
     prof = dict(warm)
@@ -760,7 +762,8 @@ def main():
             "step_matrix_note": "graph_* = device-bound (replayed launches); eager_* depend on the HOST's launch rate "
                                 "(~35 launches and two stream joins per step) and vary between boxes",
             "weak_scaling_bs8": bs8,
-            "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE"),
+            "miopen": ("find (tuned convolutions)" if a.miopen_find else
+                       "immediate mode (no find) for the layered / multi-task legs: their convolutions are untuned; --miopen-find tunes them"),
             "layered_step": layered,
             "multitask_step": multitask,
             "early_ray_termination": ert_stats,

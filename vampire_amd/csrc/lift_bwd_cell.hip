@@ -82,19 +82,40 @@ lift_bwd_fill_kernel(LiftParams P, int cw, int ch, const float* __restrict__ gou
   const unsigned vmask = live ? (amask[(long) b * V + vox] & range) : 0u;
 
   // grad_out / (hit count + 1e-6), the camera-mean factor of bv2:512-514: the same for every
-  // camera of the voxel -- one channel-last row of the table per voxel
-  if (live) {
+  // camera of the voxel -- one channel-last row of the table per voxel.  The rows of a wave's 64 voxels are
+  // one contiguous run of the table: they pass through LDS so that consecutive lanes store consecutive
+  // 16-byte pieces (lane = voxel stores 16-byte pieces 64 bytes apart: 2.6 M of the kernel's 4.5 M L2
+  // requests at cfg-B)
+  {
+    constexpr int RS = CH + 4;                     // padded row stride (floats): conflict-free b128 writes
+    __shared__ float tbl[4][64 * RS];
+    float* tw = tbl[tid >> 6];
     const int nchunk = P.C / CH;
-    float4* row = table + ((long) b * V + vox) * (P.C / 4);
+    const long vrow0 = (long) b * V + ((long) z * P.Y + yc) * P.X + (long) blockIdx.x * 64;   // the wave's first voxel
     for (int chunk = 0; chunk < nchunk; ++chunk) {
-      const uint64_t hw = hits[((long) b * V + vox) * nchunk + chunk];
-      const float* g = gout + ((long) b * P.C + chunk * CH) * V + vox;
       float v[CH];
+      if (live) {
+        const uint64_t hw = hits[((long) b * V + vox) * nchunk + chunk];
+        const float* g = gout + ((long) b * P.C + chunk * CH) * V + vox;
 #pragma unroll
-      for (int k = 0; k < CH; ++k)
-        v[k] = g[(long) k * V] * __builtin_amdgcn_rcpf((float) ((hw >> (4 * k)) & 15) + 1e-6f);   // 1 ulp: gradients are held to 1e-4
+        for (int k = 0; k < CH; ++k)
+          v[k] = g[(long) k * V] * __builtin_amdgcn_rcpf((float) ((hw >> (4 * k)) & 15) + 1e-6f);   // 1 ulp: gradients are held to 1e-4
+      } else {
 #pragma unroll
-      for (int c4 = 0; c4 < CH; c4 += 4) row[(chunk * CH + c4) / 4] = make_float4(v[c4], v[c4 + 1], v[c4 + 2], v[c4 + 3]);
+        for (int k = 0; k < CH; ++k) v[k] = 0.f;
+      }
+#pragma unroll
+      for (int c4 = 0; c4 < CH; c4 += 4)
+        *reinterpret_cast<float4*>(tw + lane * RS + c4) = make_float4(v[c4], v[c4 + 1], v[c4 + 2], v[c4 + 3]);
+      // (a wave reads back what it alone wrote: no barrier)
+      constexpr int Q = CH / 4;                    // 16-byte pieces per row of this chunk
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        const int c = i * 64 + lane, row = c / Q, quad = c % Q;
+        const float4 piece = *reinterpret_cast<const float4*>(tw + row * RS + quad * 4);
+        if (y < P.Y && blockIdx.x * 64 + row < P.X)
+          table[(vrow0 + row) * (P.C / 4) + chunk * Q + quad] = piece;
+      }
     }
   }
   if (!__any(vmask != 0u)) return;
