@@ -138,7 +138,7 @@ __device__ __forceinline__ void cell_accumulate(const CellRanges& cr, int k0, in
 
 // CGL lanes per voxel, 256 / CGL voxels (an x-run) per workgroup
 template <int CP4, int CGL>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 5)
 cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const int* __restrict__ boff,
                            const float4* __restrict__ R, const float* __restrict__ Gcl,
                            float* __restrict__ gdens, float* __restrict__ gsem,
@@ -284,7 +284,7 @@ __device__ __forceinline__ void cam_heavy_drain(const RenderParams& P, const int
 }
 
 template <int CP4>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 5)
 cam_bwd_cell_heavy_kernel(RenderParams P, const int* __restrict__ off, const int* __restrict__ boff,
                           const float4* __restrict__ R, const float* __restrict__ Gcl,
                           float* __restrict__ gdens, float* __restrict__ gsem,

@@ -228,7 +228,7 @@ __device__ __forceinline__ RayId decode_tile(const RenderParams& P) {
 // the backward's per-ray pass (same tiles, same lanes) reads them back coalesced instead of repeating
 // the 8-tap gathers, which are all that pass was bound by.
 template <typename T, int NCH, bool ERT, int NW>
-__global__ void __launch_bounds__(NW * 64)
+__global__ void __launch_bounds__(NW * 64, 3)      // (3 waves per SIMD: 171 registers would be 2; ERT on 62 -> 57 us, off 225 -> 218)
 cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const float* __restrict__ us,
                       const float* __restrict__ vs, const float* __restrict__ ds,
                       const float* __restrict__ mids, const float* __restrict__ beta_raw,
