@@ -1,0 +1,6 @@
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('%.1f samples/s  %.4f ms' % (d['value'], d['ms_per_step']))
+print({k:v for k,v in d['kernels_us_per_step'].items()})
+print('fwd', d.get('fwd_roofline'))
+print('matrix', d.get('step_matrix'))

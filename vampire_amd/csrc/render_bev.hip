@@ -15,6 +15,7 @@
 //                          planes it feeds kept in registers -- no atomics; overwrites (the
 //                          camera gather then adds) or adds onto what the buffers hold
 #include "render_common.hpp"
+#include "pair_gather.hpp"
 
 namespace vamp {
 
@@ -757,6 +758,14 @@ constexpr int kColG = VAMP_COLG;       // channels per thread, pass-through laun
 #define VAMP_COLGC 4
 #endif
 constexpr int kColGC = VAMP_COLGC;     // channels per thread, composited launch
+#ifndef VAMP_COMPG
+#define VAMP_COMPG 3
+#endif
+#ifndef VAMP_COMPHC
+#define VAMP_COMPHC 10
+#endif
+constexpr int kCompG = VAMP_COMPG;     // channels per thread, composited launch (round 4: 21 = 7 x 3)
+constexpr int kCompHC = VAMP_COMPHC;   // heights whose taps are loaded together
 
 template <int G, bool COL, bool VO, bool OW>
 __global__ void __launch_bounds__(256)
@@ -943,6 +952,254 @@ bev_gather_col_kernel(RenderParams P, const int4* __restrict__ tab, const float*
   store_plane(cur, lo, lod, lo_t);
   store_plane(cur + 1, hi, hid, hi_t);
   for (int z = max(cur + 2, za); z < zb; ++z) store_plane(z, zero, 0.f, false);
+}
+
+// Composited channels (semantic, rgb) and the density of the column gather, round 4.
+//
+// bev_gather_col_kernel<G, true, false, OW> was a thread per (voxel column, 4 channels, z-segment) that issued
+// the 12 tap loads of a height one height ahead of their use: a wave lived for (heights) x (one L2 round trip),
+// 11.8 us where its arithmetic is ~1 us, every one of the 12 (channel group, segment) threads of a column
+// loaded the same Wb taps again -- 1 250 wave-level loads per 64 columns -- and the 56 MB went out at 1.2 TB/s
+// (the stores alone take 12 us: ablation).  What a height gives to a composited channel is
+//      S_j[c] = sum over the (y, x) taps t of  Wb_j[t] * (wyx[t] * gcol_c[t]),
+// and the taps do not depend on the channel.  Here a workgroup is 64 columns x one wave per channel group
+// (G channels; the last wave is the density, whose taps are DS0's and whose per-tap factor is wyx alone -- the
+// same products in the same order as before, bit for bit): the waves fetch the taps of a chunk of kCompHC
+// heights TOGETHER, each its share, all in flight at once, into LDS (two sources x heights x 6 (9) taps x 64
+// columns), and every wave then walks the heights from LDS.  ~220 wave-level loads per 64 columns, one round
+// trip per chunk instead of one per height, 70 registers, and all workgroups of cfg-B resident at once.
+//   grid: x = blocks of 64 columns (XCD-major, like the forward), y = B; block = 64 x min(groups, kCompMaxW)
+#ifdef VAMP_COMP_STAMPS
+// diagnostic build only (tools/debug/bev_gather_stamps.py): phase stamps of wave 0 of every workgroup
+__device__ long long g_comp_stamps[4096 * 8];
+#define VAMP_CSTAMP(k)                                                                                     \
+  do {                                                                                                     \
+    const unsigned wgi_ = blockIdx.y * gridDim.x + blockIdx.x;                                             \
+    if (threadIdx.x == 0 && wgi_ < 4096) g_comp_stamps[wgi_ * 8 + (k)] = (long long) wall_clock64();       \
+  } while (0)
+extern "C" int vamp_debug_comp_stamps(long long* host, size_t n) {
+  return (int) hipMemcpyFromSymbol(host, HIP_SYMBOL(g_comp_stamps), n * sizeof(long long), 0, hipMemcpyDeviceToHost);
+}
+#else
+#define VAMP_CSTAMP(k) do { } while (0)
+#endif
+constexpr int kCompMaxW = 8;           // waves per workgroup (a wave loops over its groups beyond that)
+template <int G, int HC, bool OW>
+__global__ void __launch_bounds__(kCompMaxW * 64, 6)      // (3 workgroups per CU: cfg-B's 625 are one round)
+bev_gather_comp_kernel(RenderParams P, const int4* __restrict__ tab, const float* __restrict__ ozs,
+                       const float* __restrict__ gcol, const float* __restrict__ gcol2,
+                       const float* __restrict__ Wb, const float* __restrict__ DS0, float* __restrict__ gdens,
+                       float* __restrict__ gout, float* __restrict__ gout2, int nchan, int nchan2,
+                       BetaTail btail) {
+  VAMP_CSTAMP(0);
+  beta_tail(btail);                     // the scan's d beta partials
+  __shared__ int tz_i0[kBevMaxOZ];
+  __shared__ float tz_w0[kBevMaxOZ], tz_w1[kBevMaxOZ];
+  __shared__ float taps[2][HC][9][64];  // [Wb | DS0][height of the chunk][(y, x) tap; 6..8: a third y hit][column]
+  if ((int) threadIdx.x < P.oZ) {
+    const AxisTap tz = axis_tap(ozs[threadIdx.x], P.lo[2], P.span[2], P.Z);
+    tz_i0[threadIdx.x] = tz.i0; tz_w0[threadIdx.x] = tz.w0; tz_w1[threadIdx.x] = tz.w1;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  const int nwv = __builtin_amdgcn_readfirstlane((int) (blockDim.x >> 6));
+  const unsigned YX = (unsigned) (P.Y * P.X);
+  const int nwg = (int) ((YX + 63) / 64), per_xcd = (nwg + 7) / 8;
+  const int wg = (int) (blockIdx.x & 7) * per_xcd + (int) (blockIdx.x >> 3);
+  const bool wg_live = wg < nwg && (int) (blockIdx.x >> 3) < per_xcd;          // (uniform: barriers below stay matched)
+  const unsigned col_raw = (unsigned) min(wg, nwg - 1) * 64u + lane;
+  const bool live = wg_live && col_raw < YX;
+  const unsigned col = min(col_raw, YX - 1);
+  const int b = blockIdx.y;
+  const int ngrp = (nchan + nchan2 + G - 1) / G + 1;           // + the density's group
+  const int x = col % (unsigned) P.X, y = col / (unsigned) P.X;
+  const AxisHits hx = load_axis_hits(tab, x), hy = load_axis_hits(tab, P.X + y);
+  const bool y3 = __any(hy.n > 2);
+  const unsigned V = (unsigned) P.Z * YX, OYX = (unsigned) (P.oY * P.oX);
+  VAMP_CSTAMP(1);
+
+  // the (y, x) taps of the column: byte offsets in a lattice plane and weights (absent slots: k = 0, w = 0)
+  unsigned cc[3][3];
+  float wyx[3][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      cc[c][e] = ((unsigned) hy.k[c] * P.oX + hx.k[e]) * 4u;
+      wyx[c][e] = hy.w[c] * hx.w[e];
+    }
+  const __amdgpu_buffer_rsrc_t rs_g1 = make_rsrc(gcol, gcol ? (size_t) P.B * nchan * OYX * 4 : 0);
+  const __amdgpu_buffer_rsrc_t rs_g2 = make_rsrc(gcol2, gcol2 ? (size_t) P.B * nchan2 * OYX * 4 : 0);
+  const __amdgpu_buffer_rsrc_t rs_wb = make_rsrc(Wb, (size_t) P.B * P.oZ * OYX * 4);
+  const __amdgpu_buffer_rsrc_t rs_ds = make_rsrc(DS0, (size_t) P.B * P.oZ * OYX * 4);
+  const __amdgpu_buffer_rsrc_t rs_none = make_rsrc(Wb, 0);
+  const unsigned ocol = live ? col * 4u : 0x7ffffff0u;          // (a lane past the volume: dropped by the hardware)
+  __syncthreads();
+  // the heights whose taps reach the volume's planes (ascending); values read from LDS count as per-lane
+  // for the compiler: as scalar offsets of the buffer accesses they would each get a readfirstlane loop
+  int k_a = P.oZ, k_b = -1;
+  for (int k = 0; k < P.oZ; ++k) {
+    const int i0 = tz_i0[k];
+    if (i0 + 1 >= 0 && i0 < P.Z) { k_a = min(k_a, k); k_b = max(k_b, k); }
+  }
+  k_a = __builtin_amdgcn_readfirstlane(k_a);
+  k_b = __builtin_amdgcn_readfirstlane(k_b);
+
+  // every wave runs the same number of rounds (the barriers below), a wave without a group idles through them
+  for (int g0 = 0; g0 < ngrp; g0 += nwv) {
+    const int cg = g0 + wave;
+    const bool active = cg < ngrp;
+    const bool dgrp = cg == ngrp - 1;
+    // per channel slot: output offset, raw column gradients (their factors once the first taps are issued)
+    bool on[G], second[G], has_g[G];
+    unsigned ob[G], gb[G];
+    float gw[G][2][3], gw3[G][3];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int ch = cg * G + u;
+      on[u] = active && (dgrp ? u == 0 : ch < nchan + nchan2);
+      second[u] = !dgrp && ch >= nchan;
+      const int chc = (on[u] && !dgrp) ? (second[u] ? ch - nchan : ch) : 0;
+      const int nc = second[u] ? nchan2 : nchan;
+      ob[u] = dgrp ? (unsigned) b * V * 4u : ((unsigned) b * nc + chc) * V * 4u;
+      gb[u] = ((unsigned) b * nc + chc) * OYX * 4u;
+      has_g[u] = on[u] && !dgrp && (second[u] ? gcol2 != nullptr : gcol != nullptr);
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+          gw[u][c][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(has_g[u] ? (second[u] ? rs_g2 : rs_g1) : rs_none, cc[c][e], gb[u], 0));
+      // a third y hit somewhere in the workgroup's columns (about 1 row in 100): its column gradients, raw
+#pragma unroll
+      for (int e = 0; e < 3; ++e)
+        gw3[u][e] = y3 ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(has_g[u] ? (second[u] ? rs_g2 : rs_g1) : rs_none, cc[2][e], gb[u], 0)) : 0.f;
+    }
+    const __amdgpu_buffer_rsrc_t rs_o1 = make_rsrc(dgrp ? gdens : gout, (size_t) P.B * (dgrp ? 1 : nchan) * V * 4);
+    const __amdgpu_buffer_rsrc_t rs_o2 = make_rsrc(gout2, gout2 ? (size_t) P.B * nchan2 * V * 4 : 0);
+    auto store_plane = [&](int z, const float (&v)[G], bool touched) __attribute__((always_inline)) {
+      if (z < 0 || z >= P.Z) return;
+      const unsigned zo = (unsigned) z * YX * 4u;
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        if (!on[u]) continue;
+        const __amdgpu_buffer_rsrc_t rs = second[u] ? rs_o2 : rs_o1;
+        if (OW) {
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[u]), rs, ocol, ob[u] + zo, 0);
+        } else if (touched) {
+          const float old = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, ocol, ob[u] + zo, 0));
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(old + v[u]), rs, ocol, ob[u] + zo, 0);
+        }
+      }
+    };
+    float zero[G], lo[G], hi[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) zero[u] = lo[u] = hi[u] = 0.f;
+    if (k_b < k_a) {                               // the lattice misses the volume (uniform)
+      for (int z = 0; z < P.Z; ++z) store_plane(z, zero, false);
+      continue;
+    }
+    int cur = __builtin_amdgcn_readfirstlane(tz_i0[k_a]);       // voxel plane of lo[]
+    bool lo_t = false, hi_t = false;                // does any height touch the plane?
+    bool first = true;
+
+    for (int k0 = k_a; k0 <= k_b; k0 += HC) {
+      const int hcn = min(HC, k_b - k0 + 1);
+      // ---- this wave's share of the chunk's (source, height) items: 6 tap loads each, all in flight
+      constexpr int ITW = (2 * HC + kCompMaxW - 1) / kCompMaxW;      // items per wave and pass (one pass at kCompMaxW waves)
+      if (g0 > 0) __syncthreads();                  // (a second round of groups: the last one's readers are done)
+      // the loads write LDS themselves (buffer_load ... lds: lane i's dword lands at the row's base + 4 i):
+      // no staging registers, which is what lets three of these workgroups share a CU
+      for (int i0 = 0; i0 < 2 * hcn; i0 += ITW * nwv) {
+#pragma unroll
+        for (int u = 0; u < ITW; ++u) {
+          const int it = i0 + wave + u * nwv;
+          if (it < 2 * hcn) {
+            const int src = it >= hcn ? 1 : 0, t = it - src * hcn;
+            const unsigned jo = ((unsigned) b * P.oZ + (unsigned) (P.oZ - 1 - (k0 + t))) * OYX * 4u;   // flip (bv2:443)
+            const __amdgpu_buffer_rsrc_t rs = src ? rs_ds : rs_wb;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              if (c == 2 && !y3) continue;
+#pragma unroll
+              for (int e = 0; e < 3; ++e)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*) &taps[src][t][c * 3 + e][0], 4,
+                                                     cc[c][e], jo, 0, 0);
+            }
+          }
+        }
+      }
+      if (first) {
+        // (the column gradients were issued before the taps: their factors wait for them alone)
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+              gw[u][c][e] = dgrp ? (u == 0 ? wyx[c][e] : 0.f) : (has_g[u] ? wyx[c][e] * gw[u][c][e] : 0.f);
+        VAMP_CSTAMP(2);
+        for (int z = 0; z < min(cur, P.Z); ++z) store_plane(z, zero, false);
+        first = false;
+      }
+      __builtin_amdgcn_s_waitcnt(0x0f70);           // vmcnt(0): this wave's taps are in LDS
+      __syncthreads();
+      // ---- the chunk's heights from LDS
+      if (active) {
+        const int src = dgrp ? 1 : 0;
+        for (int t = 0; t < hcn; ++t) {
+          const int k = k0 + t;
+          float S[G];
+#pragma unroll
+          for (int u = 0; u < G; ++u) S[u] = 0.f;
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+              const float w = taps[src][t][c * 3 + e][lane];
+#pragma unroll
+              for (int u = 0; u < G; ++u) S[u] = __builtin_fmaf(w, gw[u][c][e], S[u]);
+            }
+          if (y3) {                                   // third y hit (same products, same order as the thread-per-column kernel)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+              const float w = wyx[2][e];
+              const float tvv = taps[src][t][6 + e][lane];
+              if (dgrp) {
+                S[0] = __builtin_fmaf(w, tvv, S[0]);
+              } else {
+                const float wbv = w * tvv;
+#pragma unroll
+                for (int u = 0; u < G; ++u)
+                  if (has_g[u]) S[u] = __builtin_fmaf(wbv, gw3[u][e], S[u]);
+              }
+            }
+          }
+          const int i0z = __builtin_amdgcn_readfirstlane(tz_i0[k]);
+          const float w0 = tz_w0[k], w1 = tz_w1[k];
+          // the heights have moved past plane `cur`: store it, shift
+          while (cur < i0z) {
+            store_plane(cur, lo, lo_t);
+#pragma unroll
+            for (int u = 0; u < G; ++u) { lo[u] = hi[u]; hi[u] = 0.f; }
+            lo_t = hi_t; hi_t = false;
+            ++cur;
+          }
+#pragma unroll
+          for (int u = 0; u < G; ++u) {
+            lo[u] = __builtin_fmaf(w0, S[u], lo[u]);
+            hi[u] = __builtin_fmaf(w1, S[u], hi[u]);
+          }
+          lo_t = hi_t = true;
+        }
+      }
+      if (k0 + HC <= k_b) __syncthreads();          // (another chunk: its taps overwrite these)
+    }
+    VAMP_CSTAMP(3);
+    store_plane(cur, lo, lo_t);
+    store_plane(cur + 1, hi, hi_t);
+    for (int z = max(cur + 2, 0); z < P.Z; ++z) store_plane(z, zero, false);
+  }
+  VAMP_CSTAMP(4);
 }
 
 // d beta partial sums the scan leaves in the workspace: one per workgroup of bev_scan_kernel, or -- when the
@@ -1173,7 +1430,16 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
       return dim3((unsigned) (((long) d->Y * d->X + 255) / 256), d->B * nseg * ((nchan + g - 1) / g));
     };
     // semantic + rgb + density in one launch (they share the Wb taps of a height)
+    // (the descriptors of the round-4 kernel address bytes: 2 GB per tensor)
+    const bool comp_ok = (size_t) d->B * d->K * d->Z * d->Y * d->X * 4 < lim && (size_t) d->B * d->oZ * d->oY * d->oX * 4 < lim;
+    const int ngrp_c = (d->K + 3 + kCompG - 1) / kCompG + 1;
+    const int nwv_c = ngrp_c < kCompMaxW ? ngrp_c : kCompMaxW;
+    const dim3 grid_comp((unsigned) ((((long) d->Y * d->X + 63) / 64 + 7) / 8 * 8), d->B);
     if (only_base) {}
+    else if (comp_ok && owc) VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_comp_kernel<kCompG, kCompHC, true><<<grid_comp, nwv_c * 64, 0, s>>>(
+        P, tab, ozs, g_bev_seg, g_bev_rgb, Wb, DS0, grad_density_feature, grad_semantic, grad_rgb, d->K, 3, take_tail())));
+    else if (comp_ok) VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_comp_kernel<kCompG, kCompHC, false><<<grid_comp, nwv_c * 64, 0, s>>>(
+        P, tab, ozs, g_bev_seg, g_bev_rgb, Wb, DS0, grad_density_feature, grad_semantic, grad_rgb, d->K, 3, take_tail())));
     else if (owc) VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_col_kernel<kColGC, true, false, true><<<grid(d->K + 3, kColGC), 256, 0, s>>>(
         P, tab, ozs, g_bev_seg, g_bev_rgb, nullptr, -1, Wb, DS0, grad_density_feature, grad_semantic, grad_rgb,
         d->K, 3, zseg, 1, 0, take_tail())));

@@ -5,14 +5,13 @@
 // voxel_density back and redoes the weights per pair).  Here a workgroup owns 64 consecutive
 // columns of the flattened (y, x) det lattice and NWV waves:
 //
-//   density   the waves split the oZ heights: trilinear density sample, sigma_j -> LDS,
-//             voxel_density (and the raw sample for the backward)
-//   weights   every wave turns the column's sigma_j into compositing weights w_j in LDS
-//             (identical values from every wave: no second barrier) -- wave 0 also the height map
-//   channels  wave g owns channels g, g + NWV, ...: per batch of CB channels and chunk of heights
-//             the x-pair loads of all needed volume planes are issued together through buffer
-//             descriptors (channel and plane offsets are scalars); consecutive heights share a
-//             plane; semantic / rgb are composited, base passes through to voxel_output
+//   density   the waves split the volume planes the heights touch (bilinear (y, x) values -> LDS), then
+//             the oZ heights: trilinear density sample, sigma_j -> LDS, voxel_density (and the raw
+//             sample for the backward), then the compositing weights w_j of the same heights -> LDS
+//   channels  a wave owns every (NWV * groups)-th channel: the x-pair loads of a chunk of volume planes
+//             are issued together through buffer descriptors (channel and plane offsets are scalars)
+//             one chunk ahead of their use; consecutive heights share a plane; semantic / rgb are
+//             composited, base passes through to voxel_output
 //
 // Every global access is coalesced along x (lanes = consecutive columns).  HBM-bound streaming
 // with a short per-column scan: no MFMA.
@@ -82,17 +81,44 @@ constexpr int kFusedPC = VAMP_BEVF_PC; // volume planes fetched together (2 x-pa
 constexpr int kFusedMaxNP = 40;       // distinct volume planes the det heights may touch
 
 #ifndef VAMP_BEVF_NWV
-#define VAMP_BEVF_NWV 8
+#define VAMP_BEVF_NWV 4
+#endif
+#ifndef VAMP_BEVF_PARTS
+#define VAMP_BEVF_PARTS 2            // channel groups per column block (workgroups of NWV waves each)
 #endif
 #ifndef VAMP_BEVF_XCD
 #define VAMP_BEVF_XCD 1
 #endif
 
+#ifdef VAMP_BEVF_STAMPS
+// diagnostic build only (tools/debug/bev_stamps.py): phase stamps of waves 0 and NWV - 1 of every workgroup
+__device__ long long g_bevf_stamps[1024 * 16];
+#define VAMP_BSTAMP(k)                                                                                  \
+  do {                                                                                                  \
+    if (lane == 0 && (wave == 0 || wave == NWV - 1) && blockIdx.x < 1024 && blockIdx.z == 0)                               \
+      g_bevf_stamps[blockIdx.x * 16 + (wave ? 8 : 0) + (k)] = (long long) wall_clock64();               \
+  } while (0)
+#else
+#define VAMP_BSTAMP(k) do { } while (0)
+#endif
 __device__ __forceinline__ void bev_store(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, 0);
 }
 
-// dynamic LDS: sigma [oZ][64] | weights [oZ][64] | per wave: bilinear plane values [NP][64]
+// dynamic LDS: sigma [oZ][64] | weights [oZ][64] | density planes [NPA + 1][64] (shared) | per wave: plane values [NPA][64]
+//
+// Round 4.  Phase stamps (tools/debug/bev_stamps.py) showed where a workgroup's 26 us went: 1 us tables, 2 us
+// density planes, 6-8 us for ten heights' sigma and weights -- every one of the 8 waves evaluated all of them
+// (density_fwd + two expf per height, 6 waves per SIMD doing the same arithmetic) -- and 15 us channels, each
+// wave's 4-5 channels one after the other and two load round trips deep; and 625 workgroups of 8 waves are one
+// uneven round on 256 CUs (2 or 3 per CU: the span was 36 us where the median workgroup took 26).  Now
+//   * the heights are dealt to the waves (sigma, then the weights from a prefix of the others' sigma: two
+//     short barriers instead of 8x the arithmetic),
+//   * the channel loop is software-pipelined over (channel, chunk of planes): the loads of the next chunk are
+//     in flight while the current one is staged, sampled and stored, and the first chunk's loads are issued
+//     before the density phase,
+//   * a workgroup is NWV waves and one of gridDim.z channel groups of a column block (the groups repeat the
+//     density phase, 1.6 MB of L2 hits: blockIdx.z does not enter the XCD of a workgroup).
 template <typename T, int NWV>
 __global__ void __launch_bounds__(NWV * 64)
 bev_fwd_fused_kernel(RenderParams P, int NPA, const float* __restrict__ oxs, const float* __restrict__ oys,
@@ -107,11 +133,14 @@ bev_fwd_fused_kernel(RenderParams P, int NPA, const float* __restrict__ oxs, con
   extern __shared__ __align__(16) float sig[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  VAMP_BSTAMP(0);
   float* wgt = sig + P.oZ * 64;
-  float* bl = wgt + P.oZ * 64 + wave * NPA * 64;                 // this wave's plane values (NPA planes allocated)
+  float* dsl = wgt + P.oZ * 64;                                   // the density planes' bilinear values (all waves)
+  float* bl = dsl + (NPA + 1) * 64 + wave * NPA * 64;                   // this wave's plane values (NPA planes allocated)
   const int b = blockIdx.y;
+  const int part = blockIdx.z, nparts = gridDim.z;                // channel group of this workgroup
   const int OYX = P.oY * P.oX;
-  // XCD k (workgroups with blockIdx % 8 == k) walks a contiguous band of the lattice: y-neighbours,
+  // XCD k (workgroups with blockIdx.x % 8 == k) walks a contiguous band of the lattice: y-neighbours,
   // which read the same volume rows, share that XCD's L2 (the grid is rounded up to a multiple of 8)
   const int nwg = (OYX + 63) / 64, per_xcd = (nwg + 7) / 8;
   const int wg = VAMP_BEVF_XCD ? (int) (blockIdx.x & 7) * per_xcd + (int) (blockIdx.x >> 3) : (int) blockIdx.x;
@@ -133,74 +162,31 @@ bev_fwd_fused_kernel(RenderParams P, int NPA, const float* __restrict__ oxs, con
   // a lane outside the lattice stores beyond every descriptor's range: the hardware drops it
   const unsigned ocol = live ? (unsigned) col * 4u : 0x7ffffff0u;
   __syncthreads();
+  VAMP_BSTAMP(1);
   // the volume planes the heights touch: [pmin, pmin + NP) (uniform; the launcher sized the slabs for a
   // lattice of heights with the descriptor's spacing, NPA planes)
   int pmin = tz_i0[0], pmax = tz_i0[0] + 1;
   for (int j = 1; j < P.oZ; ++j) { pmin = min(pmin, tz_i0[j]); pmax = max(pmax, tz_i0[j] + 1); }
   pmin = __builtin_amdgcn_readfirstlane(pmin);
   const int NP = min(__builtin_amdgcn_readfirstlane(pmax) - pmin + 1, NPA);
-
-  // All NP planes [pmin, pmin + NP) of the channel at scalar byte offset `cso`: bilinear (y, x) samples
-  // into this wave's LDS slab, kFusedPC planes (2 * kFusedPC x-pair loads in flight) at a time.  A plane
-  // outside the volume is zero padding; the last chunk repeats its last plane (branch-free).
-  auto fetch_planes = [&](__amdgpu_buffer_rsrc_t rs, unsigned cso) {
-    for (int p0 = 0; p0 < NP; p0 += kFusedPC) {
-      float a0[kFusedPC], b0[kFusedPC], a1[kFusedPC], b1[kFusedPC];
-      bool zin[kFusedPC];
-#pragma unroll
-      for (int t = 0; t < kFusedPC; ++t) {
-        const int p = pmin + min(p0 + t, NP - 1);
-        const int pc = min(max(p, 0), P.Z - 1);
-        zin[t] = p == pc;
-        const unsigned so = cso + (unsigned) pc * plane_b;
-        bev_ld_pair<T>(rs, ct.o0, so, a0[t], b0[t]);
-        bev_ld_pair<T>(rs, ct.o1, so, a1[t], b1[t]);
-      }
-#pragma unroll
-      for (int t = 0; t < kFusedPC; ++t) {
-        const float r0 = __builtin_fmaf(ct.wb, b0[t], ct.wa * a0[t]), r1 = __builtin_fmaf(ct.wb, b1[t], ct.wa * a1[t]);
-        const float r = __builtin_fmaf(ct.wy1, r1, ct.wy0 * r0);
-        if (p0 + t < NP) bl[(p0 + t) * 64 + lane] = zin[t] ? r : 0.f;
-      }
-    }
+  // bilinear (y, x) value of plane p from its two x-pairs; zero padding for a plane outside the volume.
+  // (The test on p is uniform, and as a uniform branch around the use of the loaded registers it would make
+  // the waits in front of it conditional -- after which the compiler drains ALL loads before it reuses those
+  // registers.  `vz` is a zero the compiler takes for a per-lane value: the padding becomes a select.)
+  int vz = 0;
+  asm volatile("" : "+v"(vz));
+  auto bilin = [&](int p, float a0, float b0, float a1, float b1) -> float {
+    const float r0 = __builtin_fmaf(ct.wb, b0, ct.wa * a0), r1 = __builtin_fmaf(ct.wb, b1, ct.wa * a1);
+    return (unsigned) (p + vz) < (unsigned) P.Z ? __builtin_fmaf(ct.wy1, r1, ct.wy0 * r0) : 0.f;
   };
-  // trilinear sample at height j from the slab (aten: z-interpolation of the two bilinear plane values)
-  auto sample = [&](int j) -> float {
+  // trilinear sample at height j from a slab (aten: z-interpolation of the two bilinear plane values)
+  auto sample = [&](const float* slab, int j) -> float {
     const int k = min(tz_i0[j] - pmin, NP - 2);                    // 0 <= k, k + 1 < NP
-    return __builtin_fmaf(tz_w1[j], bl[(k + 1) * 64 + lane], tz_w0[j] * bl[k * 64 + lane]);
+    return __builtin_fmaf(tz_w1[j], slab[(k + 1) * 64 + lane], tz_w0[j] * slab[k * 64 + lane]);
   };
 
-  // ---- density: wave 0 .. samples every height; sigma_j -> LDS, voxel_density (+ the raw sample)
-  {
-    const __amdgpu_buffer_rsrc_t rs_vd = bev_rsrc(voxel_density + (long) b * P.oZ * OYX, (size_t) ovol_b);
-    const __amdgpu_buffer_rsrc_t rs_s0 = bev_rsrc(s0_save ? s0_save + (long) b * P.oZ * OYX : voxel_density, s0_save ? (size_t) ovol_b : 0);
-    if (wave == 0) {
-      fetch_planes(bev_rsrc(dens + (long) b * V, (size_t) vol_b), 0u);
-      for (int j = 0; j < P.oZ; ++j) {
-        const float s0 = sample(j);
-        const float sigma = density_fwd(dp, s0);
-        sig[j * 64 + lane] = sigma;
-        bev_store(rs_vd, ocol, (unsigned) j * oplane_b, sigma);
-        bev_store(rs_s0, ocol, (unsigned) j * oplane_b, s0);        // for the backward's scan (zero-size descriptor: dropped)
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- weights (every wave writes the same values: a wave reads back only what it wrote itself)
-  {
-    float cum = 0.f, height = 0.f;
-    for (int j = 0; j < P.oZ; ++j) {
-      const float tau = sig[j * 64 + lane] * (1.0f * P.z_step);                   // bv2:451-453
-      const float wj = (1.0f - expf(-tau)) * expf(-cum);
-      cum += tau;
-      height = __builtin_fmaf(wj, bev_mids[j], height);
-      wgt[j * 64 + lane] = wj;
-    }
-    if (wave == 0 && live) bev_height[(long) b * OYX + col] = height;
-  }
-
-  // ---- channels: [0, K) semantic, [K, K + 3) rgb, [K + 3, K + 3 + C) base; wave g owns g, g + NWV, ...
+  // ---- channels: [0, K) semantic, [K, K + 3) rgb, [K + 3, K + 3 + C) base; wave g of channel group `part`
+  // owns channels (g * nparts + part) + NWV * nparts * i
   const int nch = P.K + 3 + P.C;
   const int CO = P.C + (P.cat_seg ? P.K : 0);
   const __amdgpu_buffer_rsrc_t rs_s = bev_rsrc(sem + (long) b * P.K * V, (size_t) P.K * vol_b);
@@ -209,15 +195,106 @@ bev_fwd_fused_kernel(RenderParams P, int NPA, const float* __restrict__ oxs, con
   const __amdgpu_buffer_rsrc_t rs_vo = bev_rsrc(voxel_output + (long) b * CO * P.oZ * OYX, (size_t) CO * ovol_b);
   const __amdgpu_buffer_rsrc_t rs_ss = bev_rsrc(ss_save ? ss_save + (long) b * (P.K + 3) * P.oZ * OYX : voxel_output,
                                                 ss_save ? (size_t) (P.K + 3) * ovol_b : 0);
-  for (int c = wave; c < nch; c += NWV) {
+  constexpr int PC = kFusedPC;
+  struct Chunk {
+    float a0[PC], b0[PC], a1[PC], b1[PC];
+  };
+  const int nck = (NP + PC - 1) / PC;                               // chunks of planes per channel
+  const int cstride = NWV * nparts;
+  // the x-pair loads of chunk k of channel c (2 * PC loads, none waited for here).  Past the last channel
+  // the loads go through a zero-size descriptor (they return at once): the loop below is branch-free around
+  // its loads, so that the wait in front of a chunk's use counts the younger chunk's loads as outstanding.
+  auto issue = [&](Chunk& ch, int c, int k) {
+    const bool is_s = c < P.K, is_r = c < P.K + 3, past = c >= nch;
+    const __amdgpu_buffer_rsrc_t rs = is_s ? rs_s : (is_r ? rs_r : (past ? bev_rsrc(base, 0) : rs_b));
+    const unsigned cso = (unsigned) (is_s ? c : (is_r ? c - P.K : (past ? 0 : c - P.K - 3))) * vol_b;
+#pragma unroll
+    for (int t = 0; t < PC; ++t) {
+      const int p = pmin + min(k * PC + t, NP - 1);
+      const unsigned so = cso + (unsigned) min(max(p, 0), P.Z - 1) * plane_b;
+      bev_ld_pair<T>(rs, ct.o0, so, ch.a0[t], ch.b0[t]);
+      bev_ld_pair<T>(rs, ct.o1, so, ch.a1[t], ch.b1[t]);
+    }
+  };
+  int ci = wave * nparts + part, ki = 0;                            // next chunk to issue
+  int cc = ci, kc = 0;                                              // next chunk to consume
+  auto step = [&](int& c, int& k) {
+    if (++k == nck) { k = 0; c += cstride; }
+  };
+  Chunk A, B;
+  issue(A, ci, ki); step(ci, ki);                                   // (in flight across the density phase)
+
+  // ---- density planes: wave g fetches planes g, g + NWV, ... (all in flight together) into the shared slab
+  {
+    constexpr int DP = (kFusedMaxNP + NWV - 1) / NWV;
+    const T* dbase = dens + (long) b * V;
+    float a0[DP], b0[DP], a1[DP], b1[DP];
+    // (branch-free: a slot past the last plane loads through a zero-size descriptor and lands in the spare
+    // plane [NPA] of the slab)
+#pragma unroll
+    for (int t = 0; t < DP; ++t) {
+      const int q0 = wave + t * NWV;
+      const __amdgpu_buffer_rsrc_t rs_d = bev_rsrc(dbase, q0 < NP ? (size_t) vol_b : 0);
+      const int p = pmin + min(q0, NP - 1);
+      const unsigned so = (unsigned) min(max(p, 0), P.Z - 1) * plane_b;
+      bev_ld_pair<T>(rs_d, ct.o0, so, a0[t], b0[t]);
+      bev_ld_pair<T>(rs_d, ct.o1, so, a1[t], b1[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < DP; ++t) {
+      const int q0 = wave + t * NWV;
+      const int q = q0 < NP ? q0 : NPA;
+      dsl[q * 64 + lane] = bilin(pmin + q0, a0[t], b0[t], a1[t], b1[t]);
+    }
+  }
+  __syncthreads();
+  VAMP_BSTAMP(2);
+
+  // ---- sigma_j: wave g takes heights g, g + NWV, ...; group 0 also stores voxel_density and the raw sample
+  // for the backward's scan (the other groups through zero-size descriptors: dropped)
+  {
+    const __amdgpu_buffer_rsrc_t rs_vd = bev_rsrc(voxel_density + (long) b * P.oZ * OYX, part == 0 ? (size_t) ovol_b : 0);
+    const __amdgpu_buffer_rsrc_t rs_s0 = bev_rsrc(s0_save ? s0_save + (long) b * P.oZ * OYX : voxel_density,
+                                                  s0_save && part == 0 ? (size_t) ovol_b : 0);
+    for (int j = wave; j < P.oZ; j += NWV) {
+      const float s0 = sample(dsl, j);
+      const float sigma = density_fwd(dp, s0);
+      bev_store(rs_vd, ocol, (unsigned) j * oplane_b, sigma);
+      bev_store(rs_s0, ocol, (unsigned) j * oplane_b, s0);
+      sig[j * 64 + lane] = sigma;
+    }
+  }
+  __syncthreads();
+  // ---- compositing weights of the same heights: w_j = (1 - exp(-tau_j)) exp(-sum_{i<j} tau_i), the sum in
+  // the order of the reference's cumsum (bv2:451-453)
+  for (int j = wave; j < P.oZ; j += NWV) {
+    float cum = 0.f;
+    for (int i = 0; i < j; ++i) cum += sig[i * 64 + lane] * (1.0f * P.z_step);
+    const float tau = sig[j * 64 + lane] * (1.0f * P.z_step);
+    wgt[j * 64 + lane] = (1.0f - expf(-tau)) * expf(-cum);
+  }
+  __syncthreads();
+  if (wave == 0 && part == 0) {
+    float height = 0.f;
+    for (int j = 0; j < P.oZ; ++j) height = __builtin_fmaf(wgt[j * 64 + lane], bev_mids[j], height);
+    if (live) bev_height[(long) b * OYX + col] = height;
+  }
+  VAMP_BSTAMP(3);
+
+  // chunk k into this wave's slab; after a channel's last chunk: its heights
+  auto consume = [&](const Chunk& ch, int c, int k) {
+#pragma unroll
+    for (int t = 0; t < PC; ++t) {
+      const int q = min(k * PC + t, NP - 1), p = pmin + q;          // (branch-free, as above)
+      bl[q * 64 + lane] = bilin(p, ch.a0[t], ch.b0[t], ch.a1[t], ch.b1[t]);
+    }
+    if (k != nck - 1) return;
     if (c < P.K + 3) {
       // composited channel (semantic / rgb)
-      if (c < P.K) fetch_planes(rs_s, (unsigned) c * vol_b);
-      else fetch_planes(rs_r, (unsigned) (c - P.K) * vol_b);
       const bool cat = c < P.K && P.cat_seg;
       float acc = 0.f;
       for (int j = 0; j < P.oZ; ++j) {
-        const float sv = sample(j);
+        const float sv = sample(bl, j);
         acc = __builtin_fmaf(wgt[j * 64 + lane], sv, acc);
         // training: the backward's q_j = sum_c G_c s_j[c] reads the samples back (zero-size descriptor otherwise)
         bev_store(rs_ss, ocol, (unsigned) c * ovol_b + (unsigned) j * oplane_b, sv);
@@ -230,12 +307,25 @@ bev_fwd_fused_kernel(RenderParams P, int NPA, const float* __restrict__ oxs, con
     } else {
       // pass-through channel (base -> voxel_output)
       const int cb = c - P.K - 3;
-      fetch_planes(rs_b, (unsigned) cb * vol_b);
       for (int j = 0; j < P.oZ; ++j)
-        bev_store(rs_vo, ocol, (unsigned) cb * ovol_b + (unsigned) j * oplane_b, sample(j));
+        bev_store(rs_vo, ocol, (unsigned) cb * ovol_b + (unsigned) j * oplane_b, sample(bl, j));
     }
+  };
+  while (cc < nch) {
+    issue(B, ci, ki); step(ci, ki);
+    consume(A, cc, kc); step(cc, kc);
+    issue(A, ci, ki); step(ci, ki);
+    if (cc < nch) consume(B, cc, kc);
+    step(cc, kc);
   }
+  VAMP_BSTAMP(4);
 }
+
+#ifdef VAMP_BEVF_STAMPS
+extern "C" int vamp_debug_bevf_stamps(long long* host, size_t n) {
+  return (int) hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bevf_stamps), n * sizeof(long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // Planes a lattice of oZ heights with spacing det_step[2] can touch (+ slack).  Heights that are not
 // such a lattice (the API takes any array) belong to the two-kernel path (VAMP_BEVFWD_TWO_KERNELS).
@@ -262,8 +352,8 @@ int launch_bev_fwd_fused(const VampRenderDesc* d, const RenderParams& P, const f
   constexpr int NWV = VAMP_BEVF_NWV;
   const int np = bev_planes_alloc(d);
   const long cols = (long) P.oY * P.oX;
-  const dim3 grid((unsigned) (((cols + 63) / 64 + 7) / 8 * 8), (unsigned) P.B);
-  const size_t dyn = sizeof(float) * 64 * (2 * (size_t) P.oZ + (size_t) NWV * np);
+  const dim3 grid((unsigned) (((cols + 63) / 64 + 7) / 8 * 8), (unsigned) P.B, (unsigned) VAMP_BEVF_PARTS);
+  const size_t dyn = sizeof(float) * 64 * (2 * (size_t) P.oZ + (size_t) (NWV + 1) * np + 1);
 #define VAMP_BEVFU(T)                                                                                     \
   VAMP_TIMED(kProfBevFwdCh, s, (bev_fwd_fused_kernel<T, NWV><<<grid, NWV * 64, dyn, s>>>(                 \
       P, np, oxs, oys, ozs, bev_mids, beta, static_cast<const T*>(dens), static_cast<const T*>(sem), \
