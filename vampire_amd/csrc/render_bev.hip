@@ -401,81 +401,121 @@ bev_q_saved_kernel(RenderParams P, const float* __restrict__ ss, const float* __
 }
 
 // bev_q_saved + bev_scan as ONE kernel (round 4; the forward kept its samples): lanes = (column, height).
-// A workgroup is 64 columns of one row times all heights (wave w takes heights w, w + NWJ, ...): every
-// (column, height) takes its own q = G . s (21 streaming loads) and tau; the per-column scan is then a
-// loop over the heights' taus in LDS that every lane runs for itself in the column kernel's order (same
-// bits), and each lane finishes its own height.  10x the threads of the thread-per-column scan (which
-// was pure latency: 625 waves on 1 024 SIMDs), no Q round trip, one launch less.
-constexpr int kQsMaxWaves = 8;
+// A workgroup is 64 consecutive columns of the flattened (y, x) lattice times the heights, a wave per height
+// (beyond kQsMaxWaves heights a wave takes several).  Per (column, height): q = G . s and tau with ALL of
+// the height's loads in flight together (the column gradients, the kept samples, the density sample, the
+// voxel_density gradient: one round trip); then the per-column scan WITHOUT a serial pass -- the first cut
+// had wave 0 walk the heights (three expf per height, a dependent chain of ~5 us with every other wave at
+// the barrier): each (column, height) forms its own prefix of the taus in the column kernel's order, its own
+// weight and transmittance, and after one more barrier its own prefix of sum_k w_k q_k (the same fma chain:
+// same bits as the thread-per-column scan); no Q round trip, one launch.
+constexpr int kQsMaxWaves = 16;
+template <int NCH>                               // K + 3 (exact), or 0: any channel count, 7 channels in flight
 __global__ void __launch_bounds__(kQsMaxWaves * 64)
 bev_qscan_saved_kernel(RenderParams P, const float* __restrict__ bev_mids, const float* __restrict__ beta_raw,
                        const float* __restrict__ s0_saved, const float* __restrict__ ss,
                        const float* __restrict__ g_brgb, const float* __restrict__ g_bseg,
                        const float* __restrict__ g_bh, const float* __restrict__ g_vd,
                        float* __restrict__ Wb, float* __restrict__ DS0, float* __restrict__ beta_part) {
-  extern __shared__ float qs[];                 // [oZ][64] tau, qv, then the scan's three arrays
+  extern __shared__ float qs[];                 // [oZ][64] tau | q | w | T
   __shared__ float red[kQsMaxWaves];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-  const int x = blockIdx.x * 64 + lane, y = blockIdx.y, b = blockIdx.z;
-  const bool live = x < P.oX;
-  const long OYX = (long) P.oY * P.oX, col = (long) y * P.oX + min(x, P.oX - 1);
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), nwv = blockDim.x >> 6;
+  const int b = blockIdx.y;
+  const long OYX = (long) P.oY * P.oX;
+  const long col_raw = (long) blockIdx.x * 64 + lane;
+  const bool live = col_raw < OYX;
+  const long col = live ? col_raw : OYX - 1;
   const DensityParams dp = load_density(P.density_mode, beta_raw, P.beta_min, P.sdf_bias);
-  const int nch = P.K + 3;
-  const float Gh = g_bh ? g_bh[(long) b * OYX + col] : 0.f;
+  const int nch = NCH ? NCH : P.K + 3;
   const float dz = 1.0f * P.z_step;
   float* l_tau = qs;
   float* l_q = qs + P.oZ * 64;
+  float* l_w = l_q + P.oZ * 64;
+  float* l_T = l_w + P.oZ * 64;
+  const float* gsem = g_bseg ? g_bseg + (long) b * P.K * OYX + col : nullptr;
+  const float* grgb = g_brgb ? g_brgb + (long) b * 3 * OYX + col : nullptr;
+  // the wave's first height keeps its density sample and voxel_density gradient in registers
+  float s0_first = 0.f, gvd_first = 0.f;
   for (int j = wv; j < P.oZ; j += nwv) {
+    const float* sp = ss + ((long) b * nch * P.oZ + j) * OYX + col;                 // channel stride: oZ * OYX
+    const float Gh = g_bh ? g_bh[(long) b * OYX + col] : 0.f;
+    const float s0 = s0_saved[((long) b * P.oZ + j) * OYX + col];
+    const float gvd = g_vd ? g_vd[((long) b * P.oZ + j) * OYX + col] : 0.f;
     float q0 = 0.f, q1 = 0.f, q2 = 0.f;
-    constexpr int U = 7;                          // channels in flight (K + 3 = 21 = 3 x 7)
-    for (int c0 = 0; c0 < nch; c0 += U) {
-      float g[U], v[U];
+    constexpr int U = 7;                          // (the accumulation pattern of the first cut: K + 3 = 21 = 3 x 7)
+    if (NCH) {
+      // (buffer descriptors: the column is the one per-lane offset, channels and heights are scalar offsets --
+      // 64-bit addresses for 42 loads in flight do not fit the register budget of a 16-wave workgroup.  A
+      // missing gradient tensor is a zero-size descriptor: its loads return 0.)
+      float g[NCH ? NCH : 1], v[NCH ? NCH : 1];
+      const __amdgpu_buffer_rsrc_t rs_gs = make_rsrc(g_bseg, g_bseg ? (size_t) P.B * (NCH - 3) * OYX * 4 : 0);
+      const __amdgpu_buffer_rsrc_t rs_gr = make_rsrc(g_brgb, g_brgb ? (size_t) P.B * 3 * OYX * 4 : 0);
+      const __amdgpu_buffer_rsrc_t rs_ss = make_rsrc(ss, (size_t) P.B * NCH * P.oZ * OYX * 4);
+      const unsigned vo = (unsigned) col * 4u, oyx4 = (unsigned) OYX * 4u;
+      const unsigned sj = ((unsigned) b * NCH * P.oZ + (unsigned) j) * oyx4;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int ch = min(c0 + u, nch - 1);
-        const bool is_sem = ch < P.K;
-        const float* gp = is_sem ? g_bseg : g_brgb;
-        g[u] = (gp && c0 + u < nch) ? gp[is_sem ? ((long) b * P.K + ch) * OYX + col : ((long) b * 3 + (ch - P.K)) * OYX + col] : 0.f;
-        v[u] = ss[(((long) b * nch + ch) * P.oZ + j) * OYX + col];
+      for (int c = 0; c < NCH; ++c) {
+        const bool is_sem = c < NCH - 3;
+        g[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+            is_sem ? rs_gs : rs_gr, vo, ((unsigned) b * (is_sem ? NCH - 3 : 3) + (unsigned) (is_sem ? c : c - (NCH - 3))) * oyx4, 0));
+        v[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_ss, vo, sj + (unsigned) c * P.oZ * oyx4, 0));
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (u % 3 == 0) q0 = __builtin_fmaf(g[u], v[u], q0);
-        else if (u % 3 == 1) q1 = __builtin_fmaf(g[u], v[u], q1);
-        else q2 = __builtin_fmaf(g[u], v[u], q2);
+      for (int c = 0; c < NCH; ++c) {
+        const int u = c % U;
+        if (u % 3 == 0) q0 = __builtin_fmaf(g[c], v[c], q0);
+        else if (u % 3 == 1) q1 = __builtin_fmaf(g[c], v[c], q1);
+        else q2 = __builtin_fmaf(g[c], v[c], q2);
+      }
+    } else {
+      for (int c0 = 0; c0 < nch; c0 += U) {
+        float g[U], v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int ch = min(c0 + u, nch - 1);
+          const bool is_sem = ch < P.K;
+          const float* gp = is_sem ? gsem : grgb;
+          g[u] = (gp && c0 + u < nch) ? gp[(long) (is_sem ? ch : ch - P.K) * OYX] : 0.f;
+          v[u] = sp[(long) ch * P.oZ * OYX];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (u % 3 == 0) q0 = __builtin_fmaf(g[u], v[u], q0);
+          else if (u % 3 == 1) q1 = __builtin_fmaf(g[u], v[u], q1);
+          else q2 = __builtin_fmaf(g[u], v[u], q2);
+        }
       }
     }
-    const float s0 = s0_saved[((long) b * P.oZ + j) * OYX + col];
+    if (j == wv) { s0_first = s0; gvd_first = gvd; }
     l_tau[j * 64 + lane] = density_fwd(dp, s0) * dz;
     l_q[j * 64 + lane] = ((q0 + q1) + q2) + Gh * bev_mids[j];
   }
   __syncthreads();
-  // the column's scan in height order, as bev_scan_kernel runs it: wave 0, one lane per column, leaves
-  // every height's weight, the transmittance behind it and total - prefix in LDS
-  float* l_w = qs + 2 * P.oZ * 64;              // [oZ][64] w_j, [oZ][64] T_{j+1}, [oZ][64] total - prefix_j
-  float* l_T = l_w + P.oZ * 64;
-  float* l_R = l_T + P.oZ * 64;
-  if (wv == 0) {
-    float total = 0.f, cum = 0.f;
-    for (int k = 0; k < P.oZ; ++k) {
-      const float tau = l_tau[k * 64 + lane];
-      const float wk = (1.0f - expf(-tau)) * expf(-cum);
-      total = __builtin_fmaf(wk, l_q[k * 64 + lane], total);
-      cum += tau;
-      l_w[k * 64 + lane] = wk;
-      l_T[k * 64 + lane] = expf(-cum);
-      l_R[k * 64 + lane] = total;                // prefix_k for now
-    }
-    for (int k = 0; k < P.oZ; ++k) l_R[k * 64 + lane] = total - l_R[k * 64 + lane];
+  // weight and transmittance of the own heights: the prefix of the taus in height order (bev_scan_kernel's
+  // cum += tau chain: same bits)
+  for (int j = wv; j < P.oZ; j += nwv) {
+    float cum = 0.f;
+    for (int k = 0; k < j; ++k) cum += l_tau[k * 64 + lane];
+    const float tau = l_tau[j * 64 + lane];
+    l_w[j * 64 + lane] = (1.0f - expf(-tau)) * expf(-cum);
+    cum += tau;
+    l_T[j * 64 + lane] = expf(-cum);
   }
   __syncthreads();
   float dbeta = 0.f;
   for (int j = wv; j < P.oZ; j += nwv) {
-    const float dtau = l_q[j * 64 + lane] * l_T[j * 64 + lane] - l_R[j * 64 + lane];
-    const float s0 = s0_saved[((long) b * P.oZ + j) * OYX + col];
+    // total = sum_k w_k q_k as the column kernel's fma chain, and its prefix up to the own height
+    float total = 0.f, prefix = 0.f;
+    for (int k = 0; k < P.oZ; ++k) {
+      total = __builtin_fmaf(l_w[k * 64 + lane], l_q[k * 64 + lane], total);
+      if (k == j) prefix = total;
+    }
+    const float dtau = l_q[j * 64 + lane] * l_T[j * 64 + lane] - (total - prefix);
+    const float s0 = j == wv ? s0_first : s0_saved[((long) b * P.oZ + j) * OYX + col];
     float dsig_ds, dsig_db;
     density_bwd(dp, s0, dsig_ds, dsig_db);
-    const float gvd = g_vd ? g_vd[((long) b * P.oZ + j) * OYX + col] : 0.f;
+    const float gvd = j == wv ? gvd_first : (g_vd ? g_vd[((long) b * P.oZ + j) * OYX + col] : 0.f);
     const float dsigma = dtau * dz + gvd;          // sigma feeds tau and voxel_density
     dbeta = __builtin_fmaf(dsigma, dsig_db, dbeta);
     if (live) {
@@ -493,7 +533,7 @@ bev_qscan_saved_kernel(RenderParams P, const float* __restrict__ bev_mids, const
     if (threadIdx.x == 0) {
       float t = 0.f;
       for (int k = 0; k < nwv; ++k) t += red[k];
-      beta_part[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)] = t;
+      beta_part[blockIdx.x + gridDim.x * blockIdx.y] = t;
     }
   }
 }
@@ -1205,7 +1245,8 @@ bev_gather_comp_kernel(RenderParams P, const int4* __restrict__ tab, const float
 // d beta partial sums the scan leaves in the workspace: one per workgroup of bev_scan_kernel, or -- when the
 // forward kept its samples -- of bev_qscan_saved_kernel (the workspace holds the larger count)
 static size_t bev_scan_blocks(const VampRenderDesc* d, bool saved = true) {
-  return (size_t) ((d->oX + 63) / 64) * (saved ? d->oY : (d->oY + 3) / 4) * d->B;
+  if (saved) return (size_t) (((long) d->oY * d->oX + 63) / 64) * d->B;
+  return (size_t) ((d->oX + 63) / 64) * ((d->oY + 3) / 4) * d->B;
 }
 
 // workspace: Q, Wb, DS0 [B, oZ, oY, oX] | axis tables | beta partials | what the forward keeps for
@@ -1362,9 +1403,15 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
 #define VAMP_BEVB(T)                                                                              \
   do {                                                                                            \
     if (saved) {                                                                                  \
-      const int nwj = (d->oZ + 1) / 2 < kQsMaxWaves ? (d->oZ + 1) / 2 : kQsMaxWaves;   /* two heights per wave: 3 workgroups per CU */ \
-      VAMP_TIMED(kProfBevBwd, s, (bev_qscan_saved_kernel<<<gq, nwj * 64, (size_t) 5 * d->oZ * 64 * sizeof(float), s>>>( \
-          P, bev_mids, beta, s0_saved, ss_saved, g_bev_rgb, g_bev_seg, g_bev_height, g_voxel_density, Wb, DS0, beta_part))); \
+      const int nwj = d->oZ < kQsMaxWaves ? d->oZ : kQsMaxWaves;   /* a wave per height */             \
+      const dim3 gqf((unsigned) (((long) d->oY * d->oX + 63) / 64), d->B);                           \
+      const size_t qlds = (size_t) 4 * d->oZ * 64 * sizeof(float);                                    \
+      if (d->K + 3 == 21 && (size_t) d->B * 21 * d->oZ * d->oY * d->oX * 4 < 0x7fffffffull)           \
+        VAMP_TIMED(kProfBevBwd, s, (bev_qscan_saved_kernel<21><<<gqf, nwj * 64, qlds, s>>>(            \
+            P, bev_mids, beta, s0_saved, ss_saved, g_bev_rgb, g_bev_seg, g_bev_height, g_voxel_density, Wb, DS0, beta_part))); \
+      else                                                                                            \
+        VAMP_TIMED(kProfBevBwd, s, (bev_qscan_saved_kernel<0><<<gqf, nwj * 64, qlds, s>>>(             \
+            P, bev_mids, beta, s0_saved, ss_saved, g_bev_rgb, g_bev_seg, g_bev_height, g_voxel_density, Wb, DS0, beta_part))); \
       if (int e = check_launch("bev_qscan_saved_kernel")) return e;                               \
       break;                                                                                      \
     } else {                                                                                      \
