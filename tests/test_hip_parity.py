@@ -1352,9 +1352,11 @@ def _regime_inputs(cfg, regime, dev, with_grad=True):
     return cfg, vols
 
 
-def _render_fwd_bwd(cfg, vols, rm, dev, ert, seed, beta_value=0.1):
+def _render_fwd_bwd(cfg, vols, rm, dev, ert, seed, beta_value=0.1, cam_direct=None):
     hp = hot(cfg, dev)
     hp.impl["ert"] = ert
+    if cam_direct is not None:          # (default "auto": one kernel with early termination, copy + march without)
+        hp.impl["cam_direct"] = cam_direct
     for v in vols:
         v.grad = None
     beta = torch.tensor(beta_value, device=dev, requires_grad=(cfg.density_mode == "sdf"))
@@ -1364,9 +1366,11 @@ def _render_fwd_bwd(cfg, vols, rm, dev, ert, seed, beta_value=0.1):
     return [o.detach().clone() for o in outs], grads, (beta.grad.clone() if beta.grad is not None else None)
 
 
+@pytest.mark.parametrize("direct", [True, False], ids=["one-kernel", "copy+march"])
 @pytest.mark.parametrize("regime", ["sdf", "naive", "init", "empty"])
-def test_ert_on_equals_off_full_size(dev, regime):
-    """Early ray termination (render_common.hpp) against the same kernels with it switched off, on
+def test_ert_on_equals_off_full_size(dev, regime, direct):
+    """Early ray termination (render_common.hpp) against the same kernels with it switched off (both camera
+    forwards: by default the one-kernel forward runs with termination, copy + march without), on
     identical cfg-B inputs, in the three density regimes: the synthetic sdf workload (64 % of the
     inside samples dropped), density_mode="naive" (rays saturate behind the volume: the analytic
     exit of cam_term_kernel), the reference's initial regime (sigma = 1 / beta: every ray saturates
@@ -1375,8 +1379,8 @@ def test_ert_on_equals_off_full_size(dev, regime):
     with open(os.path.join(GOLDEN, "full_checksums.json")) as f:
         rm = torch.tensor(json.load(f)["B"]["render_mats"], dtype=torch.float32, device=dev)
     cfg, vols = _regime_inputs(CFG_B, regime, dev)
-    on = _render_fwd_bwd(cfg, vols, rm, dev, True, 4545)
-    off = _render_fwd_bwd(cfg, vols, rm, dev, False, 4545)
+    on = _render_fwd_bwd(cfg, vols, rm, dev, True, 4545, cam_direct=direct)
+    off = _render_fwd_bwd(cfg, vols, rm, dev, False, 4545, cam_direct=direct)
     for nm, a, b in zip(NAMES, on[0], off[0]):
         # (relative to the tensor's largest magnitude: depth_preds = sum w mid + (1 - sum w) * 70.4 carries
         # the fp32 rounding of sum w ~ 1 times d_far, about 1e-5 absolute, whatever the order of summation)

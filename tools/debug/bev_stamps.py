@@ -18,8 +18,9 @@ hp.impl["overlap"] = False
 train = len(sys.argv) > 1 and sys.argv[1] == "train"
 if train:
     vols = [v.clone().requires_grad_(True) for v in batch.vols]
-    for _ in range(5):
-        hp.render(*vols, model.beta, render_mats=batch.render_mats)
+    for _ in range(5):                       # forward + backward, as in a step: the forward finds the caches cold
+        outs = hp.render(*vols, model.beta, render_mats=batch.render_mats)
+        torch.autograd.backward(outs, [torch.ones_like(o) for o in outs])
 else:
     with torch.no_grad():
         for _ in range(5):

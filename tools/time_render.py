@@ -37,11 +37,15 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--only", default="")
+    ap.add_argument("--impl", default="", help="HotPath.impl overrides, e.g. ert=0,cam_direct=0,overlap=1")
     a = ap.parse_args()
     cfg = PRESETS[a.cfg]
     dev = torch.device("cuda:0")
     hp = HotPath(cfg, dev)
     hp.impl["overlap"] = False
+    for kv in filter(None, a.impl.split(",")):
+        k, v = kv.split("=")
+        hp.impl[k] = bool(int(v)) if v in ("0", "1") else (int(v) if v.lstrip("-").isdigit() else v)
     B = a.batch
     s2e, K, ida = synthetic.camera_rig(cfg, B)
     rm = render_matrices(s2e, K, ida, synthetic.bda_matrix(B)).to(dev)

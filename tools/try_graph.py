@@ -50,3 +50,7 @@ got = [batch.depth.grad, batch.feat.grad, *[v.grad for v in batch.vols], model.b
 for a, b in zip(got, ref):
     assert torch.equal(a, b) or float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()), "graph replay differs"
 print("graph  %.4f ms/step (replay == eager gradients)" % timed(g.replay, steps), flush=True)
+if os.environ.get("TRY_EAGER_LAST") == "1":          # (timeline runs: make the trace end with an eager step)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()

@@ -117,8 +117,11 @@ class HotPath:
                      # early ray termination in the camera branch (include/vampire_hip.h)
                      "ert": os.environ.get("VAMP_ERT", "1") != "0",
                      # the camera branch as ONE kernel on the channel-first volumes (no packed copy, no
-                     # separate termination pass; render_cam_direct.hip)
-                     "cam_direct": os.environ.get("VAMP_CAM_DIRECT", "1") != "0",
+                     # separate termination pass; render_cam_direct.hip).  "auto" (default): with early termination;
+                     # without it the channel-last copy + planned march wins (cfg-B forward: 26 + 126 us against 185 --
+                     # 64 far-field rays of a wave touch 64 lines per pair load of a channel-first volume, and
+                     # nothing ends the rays early), True / False force one
+                     "cam_direct": {"1": True, "0": False}.get(os.environ.get("VAMP_CAM_DIRECT", "auto"), "auto"),
                      # the BEV forward as one kernel (render_bev_fused.hip); "0" = the two-kernel first
                      # implementation, the cross-check of the tests
                      "bev_fused": os.environ.get("VAMP_BEV_FUSED", "1") != "0",
@@ -570,7 +573,8 @@ class _RenderFn(torch.autograd.Function):
         side = hp._side_stream() if (train or hp.impl["fwd_overlap"]) else None
         ctx.cells = False
         ert = geom is None and hp.impl["ert"]
-        direct = geom is None and hp.impl["cam_direct"] and (c.D - 1) <= 128
+        want_direct = ert if hp.impl["cam_direct"] == "auto" else bool(hp.impl["cam_direct"])
+        direct = geom is None and want_direct and (c.D - 1) <= 128
         # (hp.ozs is the reference's lattice of det-grid heights: the one-kernel BEV forward may size its
         # plane slabs from the spacing)
         bev_flags = _capi.VAMP_BEVFWD_HEIGHTS_LATTICE if hp.impl["bev_fused"] else _capi.VAMP_BEVFWD_TWO_KERNELS
@@ -699,12 +703,22 @@ class _RenderFn(torch.autograd.Function):
             # training: the BEV branch keeps its density / semantic / rgb samples for its backward
             bev_save = train and hp.impl["bev_save"] and hp.impl["bev_bwd"] != "v1"
             ws_bev = (hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d))) if bev_save else None)
-            _capi.check(hp.lib.vamp_render_bev_forward_ex(
-                C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
-                _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
-                _ptr(vdens), _ptr(vout), _ptr(ws_bev), ws_bev.numel() if bev_save else 0,
-                (_capi.VAMP_BEVFWD_SAVE if bev_save else 0) | bev_flags, _stream(cur if side is None else side)),
-                "vamp_render_bev_forward_ex")
+            # Without early termination the march is the long kernel of the step, and a BEV forward running
+            # beside it costs it more than it hides (kernel timeline of a replayed step at cfg-B: march 207 us
+            # beside the BEV forward, 150 alone): the BEV forward then FOLLOWS the march on this stream, and
+            # only the prepare pass (rank, scan, list: latency, no bandwidth) runs beside it.
+            bev_after = train and side is not None and not ert and ctx.cells and hp.impl["sched"] == "split"
+
+            def bev_forward(stream):
+                _capi.check(hp.lib.vamp_render_bev_forward_ex(
+                    C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
+                    _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
+                    _ptr(vdens), _ptr(vout), _ptr(ws_bev), ws_bev.numel() if bev_save else 0,
+                    (_capi.VAMP_BEVFWD_SAVE if bev_save else 0) | bev_flags, _stream(stream)),
+                    "vamp_render_bev_forward_ex")
+
+            if not bev_after:
+                bev_forward(cur if side is None else side)
             hp._bev_gen = getattr(hp, "_bev_gen", 0) + 1
             ctx.bev_key = (hp._bev_gen, ws_bev.data_ptr()) if bev_save else None
             _capi.check(hp.lib.vamp_render_camera_forward_ex(
@@ -713,6 +727,8 @@ class _RenderFn(torch.autograd.Function):
                 _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(),
                 fwd_flags | (_capi.VAMP_CAMFWD_SAVE_SAMPLES if save else 0) | (_capi.VAMP_CAMFWD_DIRECT if direct else 0),
                 _stream(cur)), "vamp_render_camera_forward_ex")
+            if bev_after:
+                bev_forward(cur)
         ctx.samples = save
         if side is not None:
             cur.wait_stream(side)
