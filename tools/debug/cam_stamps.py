@@ -43,3 +43,16 @@ order = np.argsort(-end)[:12]
 print("last tiles to finish: blk start end | plan dens scan gath merge | A S_eff Se")
 for b in order:
     print("%5d %6.1f %6.1f | %s | %d %d %d" % (b, start[b], end[b], " ".join("%5.1f" % x for x in ph[b]), A[b], Seff[b], Se[b]))
+# per tile row (8 rows of 22 tiles per camera at cfg-B): where the long tiles sit
+blk = np.arange(n)
+per_xcd = (n + 7) // 8
+tile = (blk & 7) * per_xcd + (blk >> 3)
+ty = (tile % 176) // 22
+cam = tile // 176
+print("tile row: mean total us | mean start us | mean Se")
+for r in range(8):
+    m = ty == r
+    print("  row %d: %6.2f | %6.2f | %5.1f" % (r, tot[m].mean(), start[m].mean(), Se[m].mean()))
+print("camera: mean total us")
+for c in range(6):
+    print("  cam %d: %6.2f" % (c, tot[cam == c].mean()))

@@ -117,8 +117,10 @@ __device__ __forceinline__ void bev_store(__amdgpu_buffer_rsrc_t rs, unsigned vo
 //   * the channel loop is software-pipelined over (channel, chunk of planes): the loads of the next chunk are
 //     in flight while the current one is staged, sampled and stored, and the first chunk's loads are issued
 //     before the density phase,
-//   * a workgroup is NWV waves and one of gridDim.z channel groups of a column block (the groups repeat the
-//     density phase, 1.6 MB of L2 hits: blockIdx.z does not enter the XCD of a workgroup).
+//   * a workgroup is NWV waves and one of two channel groups of a column block: the density + the composited
+//     channels, or the pass-through channels -- which need no weights, skip the density phase and stream while
+//     the other group's workgroups on the same CU are in theirs (blockIdx.z does not enter the XCD of a
+//     workgroup).
 template <typename T, int NWV>
 __global__ void __launch_bounds__(NWV * 64)
 bev_fwd_fused_kernel(RenderParams P, int NPA, const float* __restrict__ oxs, const float* __restrict__ oys,
@@ -200,12 +202,20 @@ bev_fwd_fused_kernel(RenderParams P, int NPA, const float* __restrict__ oxs, con
     float a0[PC], b0[PC], a1[PC], b1[PC];
   };
   const int nck = (NP + PC - 1) / PC;                               // chunks of planes per channel
-  const int cstride = NWV * nparts;
+  // Two channel groups: group 0 the density and the composited channels [0, K + 3), group 1 the pass-through
+  // channels [K + 3, nch) -- which need neither sigma nor weights: those workgroups skip the density phase and
+  // stream from their first instruction, while the group-0 workgroups beside them on the CU are in theirs
+  // (one round of workgroups in lockstep: for the first 9 us of the kernel almost nothing moved).
+  const bool split = nparts == 2;
+  const int c_lo = split && part == 1 ? P.K + 3 : 0;
+  const int c_hi = split && part == 0 ? P.K + 3 : nch;
+  const bool with_density = !(split && part == 1);
+  const int cstride = split ? NWV : NWV * nparts;
   // the x-pair loads of chunk k of channel c (2 * PC loads, none waited for here).  Past the last channel
   // the loads go through a zero-size descriptor (they return at once): the loop below is branch-free around
   // its loads, so that the wait in front of a chunk's use counts the younger chunk's loads as outstanding.
   auto issue = [&](Chunk& ch, int c, int k) {
-    const bool is_s = c < P.K, is_r = c < P.K + 3, past = c >= nch;
+    const bool is_s = c < P.K, is_r = c < P.K + 3, past = c >= c_hi;
     const __amdgpu_buffer_rsrc_t rs = is_s ? rs_s : (is_r ? rs_r : (past ? bev_rsrc(base, 0) : rs_b));
     const unsigned cso = (unsigned) (is_s ? c : (is_r ? c - P.K : (past ? 0 : c - P.K - 3))) * vol_b;
 #pragma unroll
@@ -216,7 +226,7 @@ bev_fwd_fused_kernel(RenderParams P, int NPA, const float* __restrict__ oxs, con
       bev_ld_pair<T>(rs, ct.o1, so, ch.a1[t], ch.b1[t]);
     }
   };
-  int ci = wave * nparts + part, ki = 0;                            // next chunk to issue
+  int ci = split ? c_lo + wave : wave * nparts + part, ki = 0;       // next chunk to issue
   int cc = ci, kc = 0;                                              // next chunk to consume
   auto step = [&](int& c, int& k) {
     if (++k == nck) { k = 0; c += cstride; }
@@ -224,60 +234,62 @@ bev_fwd_fused_kernel(RenderParams P, int NPA, const float* __restrict__ oxs, con
   Chunk A, B;
   issue(A, ci, ki); step(ci, ki);                                   // (in flight across the density phase)
 
-  // ---- density planes: wave g fetches planes g, g + NWV, ... (all in flight together) into the shared slab
-  {
-    constexpr int DP = (kFusedMaxNP + NWV - 1) / NWV;
-    const T* dbase = dens + (long) b * V;
-    float a0[DP], b0[DP], a1[DP], b1[DP];
-    // (branch-free: a slot past the last plane loads through a zero-size descriptor and lands in the spare
-    // plane [NPA] of the slab)
-#pragma unroll
-    for (int t = 0; t < DP; ++t) {
-      const int q0 = wave + t * NWV;
-      const __amdgpu_buffer_rsrc_t rs_d = bev_rsrc(dbase, q0 < NP ? (size_t) vol_b : 0);
-      const int p = pmin + min(q0, NP - 1);
-      const unsigned so = (unsigned) min(max(p, 0), P.Z - 1) * plane_b;
-      bev_ld_pair<T>(rs_d, ct.o0, so, a0[t], b0[t]);
-      bev_ld_pair<T>(rs_d, ct.o1, so, a1[t], b1[t]);
+  if (with_density) {
+    // ---- density planes: wave g fetches planes g, g + NWV, ... (all in flight together) into the shared slab
+    {
+      constexpr int DP = (kFusedMaxNP + NWV - 1) / NWV;
+      const T* dbase = dens + (long) b * V;
+      float a0[DP], b0[DP], a1[DP], b1[DP];
+      // (branch-free: a slot past the last plane loads through a zero-size descriptor and lands in the spare
+      // plane [NPA] of the slab)
+  #pragma unroll
+      for (int t = 0; t < DP; ++t) {
+        const int q0 = wave + t * NWV;
+        const __amdgpu_buffer_rsrc_t rs_d = bev_rsrc(dbase, q0 < NP ? (size_t) vol_b : 0);
+        const int p = pmin + min(q0, NP - 1);
+        const unsigned so = (unsigned) min(max(p, 0), P.Z - 1) * plane_b;
+        bev_ld_pair<T>(rs_d, ct.o0, so, a0[t], b0[t]);
+        bev_ld_pair<T>(rs_d, ct.o1, so, a1[t], b1[t]);
+      }
+  #pragma unroll
+      for (int t = 0; t < DP; ++t) {
+        const int q0 = wave + t * NWV;
+        const int q = q0 < NP ? q0 : NPA;
+        dsl[q * 64 + lane] = bilin(pmin + q0, a0[t], b0[t], a1[t], b1[t]);
+      }
     }
-#pragma unroll
-    for (int t = 0; t < DP; ++t) {
-      const int q0 = wave + t * NWV;
-      const int q = q0 < NP ? q0 : NPA;
-      dsl[q * 64 + lane] = bilin(pmin + q0, a0[t], b0[t], a1[t], b1[t]);
-    }
-  }
-  __syncthreads();
-  VAMP_BSTAMP(2);
+    __syncthreads();
+    VAMP_BSTAMP(2);
 
-  // ---- sigma_j: wave g takes heights g, g + NWV, ...; group 0 also stores voxel_density and the raw sample
-  // for the backward's scan (the other groups through zero-size descriptors: dropped)
-  {
-    const __amdgpu_buffer_rsrc_t rs_vd = bev_rsrc(voxel_density + (long) b * P.oZ * OYX, part == 0 ? (size_t) ovol_b : 0);
-    const __amdgpu_buffer_rsrc_t rs_s0 = bev_rsrc(s0_save ? s0_save + (long) b * P.oZ * OYX : voxel_density,
-                                                  s0_save && part == 0 ? (size_t) ovol_b : 0);
-    for (int j = wave; j < P.oZ; j += NWV) {
-      const float s0 = sample(dsl, j);
-      const float sigma = density_fwd(dp, s0);
-      bev_store(rs_vd, ocol, (unsigned) j * oplane_b, sigma);
-      bev_store(rs_s0, ocol, (unsigned) j * oplane_b, s0);
-      sig[j * 64 + lane] = sigma;
+    // ---- sigma_j: wave g takes heights g, g + NWV, ...; group 0 also stores voxel_density and the raw sample
+    // for the backward's scan (the other groups through zero-size descriptors: dropped)
+    {
+      const __amdgpu_buffer_rsrc_t rs_vd = bev_rsrc(voxel_density + (long) b * P.oZ * OYX, part == 0 ? (size_t) ovol_b : 0);
+      const __amdgpu_buffer_rsrc_t rs_s0 = bev_rsrc(s0_save ? s0_save + (long) b * P.oZ * OYX : voxel_density,
+                                                    s0_save && part == 0 ? (size_t) ovol_b : 0);
+      for (int j = wave; j < P.oZ; j += NWV) {
+        const float s0 = sample(dsl, j);
+        const float sigma = density_fwd(dp, s0);
+        bev_store(rs_vd, ocol, (unsigned) j * oplane_b, sigma);
+        bev_store(rs_s0, ocol, (unsigned) j * oplane_b, s0);
+        sig[j * 64 + lane] = sigma;
+      }
     }
-  }
-  __syncthreads();
-  // ---- compositing weights of the same heights: w_j = (1 - exp(-tau_j)) exp(-sum_{i<j} tau_i), the sum in
-  // the order of the reference's cumsum (bv2:451-453)
-  for (int j = wave; j < P.oZ; j += NWV) {
-    float cum = 0.f;
-    for (int i = 0; i < j; ++i) cum += sig[i * 64 + lane] * (1.0f * P.z_step);
-    const float tau = sig[j * 64 + lane] * (1.0f * P.z_step);
-    wgt[j * 64 + lane] = (1.0f - expf(-tau)) * expf(-cum);
-  }
-  __syncthreads();
-  if (wave == 0 && part == 0) {
-    float height = 0.f;
-    for (int j = 0; j < P.oZ; ++j) height = __builtin_fmaf(wgt[j * 64 + lane], bev_mids[j], height);
-    if (live) bev_height[(long) b * OYX + col] = height;
+    __syncthreads();
+    // ---- compositing weights of the same heights: w_j = (1 - exp(-tau_j)) exp(-sum_{i<j} tau_i), the sum in
+    // the order of the reference's cumsum (bv2:451-453)
+    for (int j = wave; j < P.oZ; j += NWV) {
+      float cum = 0.f;
+      for (int i = 0; i < j; ++i) cum += sig[i * 64 + lane] * (1.0f * P.z_step);
+      const float tau = sig[j * 64 + lane] * (1.0f * P.z_step);
+      wgt[j * 64 + lane] = (1.0f - expf(-tau)) * expf(-cum);
+    }
+    __syncthreads();
+    if (wave == 0 && part == 0) {
+      float height = 0.f;
+      for (int j = 0; j < P.oZ; ++j) height = __builtin_fmaf(wgt[j * 64 + lane], bev_mids[j], height);
+      if (live) bev_height[(long) b * OYX + col] = height;
+    }
   }
   VAMP_BSTAMP(3);
 
@@ -311,11 +323,11 @@ bev_fwd_fused_kernel(RenderParams P, int NPA, const float* __restrict__ oxs, con
         bev_store(rs_vo, ocol, (unsigned) cb * ovol_b + (unsigned) j * oplane_b, sample(bl, j));
     }
   };
-  while (cc < nch) {
+  while (cc < c_hi) {
     issue(B, ci, ki); step(ci, ki);
     consume(A, cc, kc); step(cc, kc);
     issue(A, ci, ki); step(ci, ki);
-    if (cc < nch) consume(B, cc, kc);
+    if (cc < c_hi) consume(B, cc, kc);
     step(cc, kc);
   }
   VAMP_BSTAMP(4);
@@ -352,7 +364,7 @@ int launch_bev_fwd_fused(const VampRenderDesc* d, const RenderParams& P, const f
   constexpr int NWV = VAMP_BEVF_NWV;
   const int np = bev_planes_alloc(d);
   const long cols = (long) P.oY * P.oX;
-  const dim3 grid((unsigned) (((cols + 63) / 64 + 7) / 8 * 8), (unsigned) P.B, (unsigned) VAMP_BEVF_PARTS);
+  const dim3 grid((unsigned) (((cols + 63) / 64 + 7) / 8 * 8), (unsigned) P.B, (unsigned) (P.C > 0 ? VAMP_BEVF_PARTS : 1));
   const size_t dyn = sizeof(float) * 64 * (2 * (size_t) P.oZ + (size_t) (NWV + 1) * np + 1);
 #define VAMP_BEVFU(T)                                                                                     \
   VAMP_TIMED(kProfBevFwdCh, s, (bev_fwd_fused_kernel<T, NWV><<<grid, NWV * 64, dyn, s>>>(                 \
