@@ -24,7 +24,7 @@ SLOTS = [("lift_fwd_kernel", "lift_fwd"), ("lift_bwd_strip_kernel", "lift_bwd_ga
          ("bev_q_kernel", "render_bev_bwd_q"), ("bev_q_saved_kernel", "render_bev_bwd_q"), ("bev_scan_kernel", "render_bev_bwd_scan"), ("bev_qscan_saved_kernel", "render_bev_bwd_scan"),
          ("cam_heavy_list_kernel", "cam_heavy_list"), ("bev_axis_table_kernel", "bev_axis_table"),
          ("bev_gather_kernel", "render_bev_bwd_gather"), ("bev_gather_col_kernel", "render_bev_bwd_gather"),
-         ("bev_gather_comp_kernel", "render_bev_bwd_gather"),
+         ("bev_gather_comp_kernel", "render_bev_bwd_gather"), ("bev_gather_pass_kernel", "render_bev_bwd_gather"),
          ("zero_fill_kernel", "memset"), ("cell_scan_kernel", "cell_scan"),
          ("exclusive_scan_kernel", "scan")]
 

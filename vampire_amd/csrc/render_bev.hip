@@ -1242,6 +1242,138 @@ bev_gather_comp_kernel(RenderParams P, const int4* __restrict__ tab, const float
   VAMP_CSTAMP(4);
 }
 
+// Pass-through channels (base; semantic with cat_seg) of the column gather, round 4: dL/ds_j[c] = g_voxel_output[c, j].
+// Here the taps ARE per channel, so there is nothing to share between the threads of a column; what the
+// thread-per-(column, 4 channels, z-segment) kernel lost was the chain of one load round trip per height
+// (wave life 12 us for ~1 us of arithmetic).  A thread owns one (column, channel), loads the 6 taps of a chunk
+// of HC heights together through a buffer descriptor (the tap offsets are per-lane constants, channel and height
+// a scalar offset), forms the heights' plane sums, adds the third-y-hit rows (1 row in 100) from a second
+// batch of loads into the same registers, and then walks the heights.  Same products in the same order as
+// bev_gather_col_kernel<G, false, true, OW>.
+//   grid: x = 256 columns, y = channels * B
+template <int HC, bool OW>
+__global__ void __launch_bounds__(256, 4)
+bev_gather_pass_kernel(RenderParams P, const int4* __restrict__ tab, const float* __restrict__ ozs,
+                       const float* __restrict__ g_vo, int vo_c0, float* __restrict__ gout, int nchan,
+                       BetaTail btail) {
+  beta_tail(btail);
+  __shared__ int tz_i0[kBevMaxOZ];
+  __shared__ float tz_w0[kBevMaxOZ], tz_w1[kBevMaxOZ];
+  if ((int) threadIdx.x < P.oZ) {
+    const AxisTap tz = axis_tap(ozs[threadIdx.x], P.lo[2], P.span[2], P.Z);
+    tz_i0[threadIdx.x] = tz.i0; tz_w0[threadIdx.x] = tz.w0; tz_w1[threadIdx.x] = tz.w1;
+  }
+  __syncthreads();
+  const unsigned YX = (unsigned) (P.Y * P.X);
+  const unsigned col_raw = blockIdx.x * 256 + threadIdx.x;
+  const bool live = col_raw < YX;
+  const unsigned col = live ? col_raw : YX - 1;
+  // (readfirstlane: the divisions run on the vector unit, and what derives from them would count as per-lane)
+  const int ch = __builtin_amdgcn_readfirstlane((int) (blockIdx.y % nchan));
+  const int b = __builtin_amdgcn_readfirstlane((int) (blockIdx.y / nchan));
+  const int x = col % (unsigned) P.X, y = col / (unsigned) P.X;
+  const AxisHits hx = load_axis_hits(tab, x), hy = load_axis_hits(tab, P.X + y);
+  const bool y3 = __any(hy.n > 2);
+  const unsigned V = (unsigned) P.Z * YX, OYX = (unsigned) (P.oY * P.oX);
+  const int CO = P.C + (P.cat_seg ? P.K : 0);
+  unsigned cc[3][3];
+  float wyx[3][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      cc[c][e] = ((unsigned) hy.k[c] * P.oX + hx.k[e]) * 4u;
+      wyx[c][e] = hy.w[c] * hx.w[e];
+    }
+  const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(g_vo, (size_t) P.B * CO * P.oZ * OYX * 4);
+  const __amdgpu_buffer_rsrc_t rs_none = make_rsrc(g_vo, 0);
+  const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(gout, (size_t) P.B * nchan * V * 4);
+  const unsigned vb = ((unsigned) b * CO + (unsigned) (vo_c0 + ch)) * P.oZ * OYX * 4u;
+  const unsigned ob = ((unsigned) b * nchan + (unsigned) ch) * V * 4u;
+  const unsigned ocol = live ? col * 4u : 0x7ffffff0u;
+  int k_a = P.oZ, k_b = -1;
+  for (int k = 0; k < P.oZ; ++k) {
+    const int i0 = tz_i0[k];
+    if (i0 + 1 >= 0 && i0 < P.Z) { k_a = min(k_a, k); k_b = max(k_b, k); }
+  }
+  k_a = __builtin_amdgcn_readfirstlane(k_a);
+  k_b = __builtin_amdgcn_readfirstlane(k_b);
+  auto store_plane = [&](int z, float v, bool touched) __attribute__((always_inline)) {
+    if (z < 0 || z >= P.Z) return;
+    const unsigned zo = (unsigned) z * YX * 4u;
+    if (OW) {
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_o, ocol, ob + zo, 0);
+    } else if (touched) {
+      const float old = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_o, ocol, ob + zo, 0));
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(old + v), rs_o, ocol, ob + zo, 0);
+    }
+  };
+  if (k_b < k_a) {                               // the lattice misses the volume
+    for (int z = 0; z < P.Z; ++z) store_plane(z, 0.f, false);
+    return;
+  }
+  int cur = __builtin_amdgcn_readfirstlane(tz_i0[k_a]);
+  float lo = 0.f, hi = 0.f;
+  bool lo_t = false, hi_t = false;
+  for (int z = 0; z < min(cur, P.Z); ++z) store_plane(z, 0.f, false);
+  for (int k0 = k_a; k0 <= k_b; k0 += HC) {
+    float nv[HC][6], S[HC];
+#pragma unroll
+    for (int t = 0; t < HC; ++t) {
+      const unsigned jo = vb + (unsigned) (P.oZ - 1 - min(k0 + t, k_b)) * OYX * 4u;         // flip (bv2:443)
+      const __amdgpu_buffer_rsrc_t rs = k0 + t <= k_b ? rs_v : rs_none;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+          nv[t][c * 3 + e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, cc[c][e], jo, 0));
+    }
+#pragma unroll
+    for (int t = 0; t < HC; ++t) {
+      float sv = 0.f;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) sv = __builtin_fmaf(wyx[c][e], nv[t][c * 3 + e], sv);
+      S[t] = sv;
+    }
+    if (y3) {                                      // third y hit somewhere in the wave
+#pragma unroll
+      for (int t = 0; t < HC; ++t) {
+        const unsigned jo = vb + (unsigned) (P.oZ - 1 - min(k0 + t, k_b)) * OYX * 4u;
+        const __amdgpu_buffer_rsrc_t rs = k0 + t <= k_b ? rs_v : rs_none;
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+          nv[t][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, cc[2][e], jo, 0));
+      }
+#pragma unroll
+      for (int t = 0; t < HC; ++t)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) S[t] = __builtin_fmaf(wyx[2][e], nv[t][e], S[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < HC; ++t) {
+      const int k = k0 + t;
+      if (k <= k_b) {
+        const int i0 = __builtin_amdgcn_readfirstlane(tz_i0[k]);
+        const float w0 = tz_w0[k], w1 = tz_w1[k];
+        while (cur < i0) {
+          store_plane(cur, lo, lo_t);
+          lo = hi; hi = 0.f;
+          lo_t = hi_t; hi_t = false;
+          ++cur;
+        }
+        lo = __builtin_fmaf(w0, S[t], lo);
+        hi = __builtin_fmaf(w1, S[t], hi);
+        lo_t = hi_t = true;
+      }
+    }
+  }
+  store_plane(cur, lo, lo_t);
+  store_plane(cur + 1, hi, hi_t);
+  for (int z = max(cur + 2, 0); z < P.Z; ++z) store_plane(z, 0.f, false);
+}
+
 // d beta partial sums the scan leaves in the workspace: one per workgroup of bev_scan_kernel, or -- when the
 // forward kept its samples -- of bev_qscan_saved_kernel (the workspace holds the larger count)
 static size_t bev_scan_blocks(const VampRenderDesc* d, bool saved = true) {
@@ -1499,7 +1631,16 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
       VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_col_kernel<kColG, false, true, false><<<grid(d->K), 256, 0, s>>>(
           P, tab, ozs, nullptr, nullptr, g_voxel_output, d->C, Wb, DS0, grad_density_feature, grad_semantic,
           nullptr, d->K, 0, zseg, 0, 0, take_tail())));
+    const bool pass_ok = (size_t) d->B * (d->C + (d->cat_seg ? d->K : 0)) * d->oZ * d->oY * d->oX * 4 < lim &&
+                         (size_t) d->B * d->C * d->Z * d->Y * d->X * 4 < lim;
+    const dim3 grid_pass((unsigned) (((long) d->Y * d->X + 255) / 256), (unsigned) (d->B * d->C));
     if (skip_base) {}
+    else if (d->C > 0 && g_voxel_output && pass_ok && ow)
+      VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_pass_kernel<kCompHC, true><<<grid_pass, 256, 0, s>>>(
+          P, tab, ozs, g_voxel_output, 0, grad_base, d->C, take_tail())));
+    else if (d->C > 0 && g_voxel_output && pass_ok)
+      VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_pass_kernel<kCompHC, false><<<grid_pass, 256, 0, s>>>(
+          P, tab, ozs, g_voxel_output, 0, grad_base, d->C, take_tail())));
     else if (d->C > 0 && g_voxel_output && ow)
       VAMP_TIMED(kProfBevBwdGather, s, (bev_gather_col_kernel<kColG, false, true, true><<<grid(d->C), 256, 0, s>>>(
           P, tab, ozs, nullptr, nullptr, g_voxel_output, 0, Wb, DS0, grad_density_feature, grad_base, nullptr,
