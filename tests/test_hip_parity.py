@@ -844,6 +844,44 @@ def test_bev_backward_gather_matches_atomic_splat_full_size(dev, monkeypatch):
     close(b2.reshape(1), b1.reshape(1), atol=1e-3, rtol=1e-3, what="grad_beta")
 
 
+@pytest.mark.parametrize("accumulate", [False, True], ids=["overwrite", "accumulate"])
+def test_bev_backward_round4_kernels_edge_shapes(dev, accumulate):
+    """The round-4 BEV backward kernels where cfg-A / B / D do not take them: 30 classes (12 channel groups for the
+    8 waves of bev_gather_comp_kernel: a second round of groups; 33 composited channels: the any-channel-count
+    path of bev_qscan_saved_kernel), 13 lattice heights (two chunks of taps; 13 waves in the q + scan), a 40 x 40
+    grid whose last block of 64 columns is ragged -- against the float-atomic splat (v1), with the BEV branch
+    overwriting (default) and adding on top of the camera branch's gradient (VAMP_BEV_FIRST=0, one stream)."""
+    cfg = dataclasses.replace(CFG_B, x_bound_seg=(-8.0, 8.0, 0.4), y_bound_seg=(-8.0, 8.0, 0.4),
+                              x_bound_det=(-8.0, 8.0, 0.4), y_bound_det=(-8.0, 8.0, 0.4),
+                              z_bound_det=(-1.0, 3.0, 0.3), num_classes=30, final_dim=(64, 176))
+    assert cfg.oZ == 13 and cfg.oX == 40
+    hp = hot(cfg, dev)
+    if accumulate:
+        hp.impl["overlap"] = False
+        hp.impl["bev_first"] = False
+    s2e, K, ida = synthetic.camera_rig(cfg, 2, jitter=1.0, seed=5)
+    rm = render_matrices(s2e, K, ida, synthetic.bda_matrix(2)).to(dev)
+    beta = torch.tensor(0.1, device=dev, requires_grad=True)
+    gen = torch.Generator(device=dev)
+
+    def run(impl):
+        hp.impl["bev_bwd"] = impl
+        vols = [v.requires_grad_(True) for v in synthetic.render_inputs(cfg, 2, seed=4, device=dev)]
+        beta.grad = None
+        outs = hp.render(*vols, beta, render_mats=rm)
+        gen.manual_seed(21)
+        gs = [torch.randn(o.shape, device=dev, generator=gen) for o in outs]
+        torch.autograd.backward(outs, gs)
+        return [v.grad.clone() for v in vols], beta.grad.clone()
+
+    g2, b2 = run("cell")
+    g1, b1 = run("v1")
+    for name, a, b in zip(("density_feature", "semantic_logits", "base", "rgb"), g2, g1):
+        assert float(b.abs().max()) > 0
+        close(a, b, atol=1e-5, rtol=3e-5, scale="max", what="bev edge shapes: grad_" + name)
+    close(b2.reshape(1), b1.reshape(1), atol=1e-3, rtol=1e-3, what="grad_beta")
+
+
 @pytest.mark.parametrize("cfg", [CFG_B, CFG_A], ids=["B", "A"])
 def test_lift_backward_cell_matches_atomic_splat_full_size(dev, monkeypatch, cfg):
     """Lift backward: cell list + a wave per pixel (default; also with 4 and 16 waves per pixel,
