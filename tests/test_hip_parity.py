@@ -846,14 +846,14 @@ def test_bev_backward_gather_matches_atomic_splat_full_size(dev, monkeypatch):
 
 @pytest.mark.parametrize("accumulate", [False, True], ids=["overwrite", "accumulate"])
 def test_bev_backward_round4_kernels_edge_shapes(dev, accumulate):
-    """The round-4 BEV backward kernels where cfg-A / B / D do not take them: 30 classes (12 channel groups for the
-    8 waves of bev_gather_comp_kernel: a second round of groups; 33 composited channels: the any-channel-count
+    """The round-4 BEV backward kernels where cfg-A / B / D do not take them: 26 classes (11 channel groups for the
+    8 waves of bev_gather_comp_kernel: a second round of groups; 29 composited channels: the any-channel-count
     path of bev_qscan_saved_kernel), 13 lattice heights (two chunks of taps; 13 waves in the q + scan), a 40 x 40
     grid whose last block of 64 columns is ragged -- against the float-atomic splat (v1), with the BEV branch
     overwriting (default) and adding on top of the camera branch's gradient (VAMP_BEV_FIRST=0, one stream)."""
     cfg = dataclasses.replace(CFG_B, x_bound_seg=(-8.0, 8.0, 0.4), y_bound_seg=(-8.0, 8.0, 0.4),
                               x_bound_det=(-8.0, 8.0, 0.4), y_bound_det=(-8.0, 8.0, 0.4),
-                              z_bound_det=(-1.0, 3.0, 0.3), num_classes=30, final_dim=(64, 176))
+                              z_bound_det=(-1.0, 3.0, 0.3), num_classes=26, final_dim=(64, 176))
     assert cfg.oZ == 13 and cfg.oX == 40
     hp = hot(cfg, dev)
     if accumulate:
