@@ -368,38 +368,6 @@ bev_q_kernel(RenderParams P, const float* __restrict__ oxs, const float* __restr
       Q[((long) b * P.oZ + j) * OYX + col] = (qred[(P.oZ * 3 + j) * 64 + lx] + qred[(j * 3) * 64 + lx]) +
                                              (qred[(j * 3 + 1) * 64 + lx] + qred[(j * 3 + 2) * 64 + lx]);
 }
-
-// the same from the samples the forward kept (VAMP_BEVFWD_SAVE): a streaming dot product
-__global__ void __launch_bounds__(256)
-bev_q_saved_kernel(RenderParams P, const float* __restrict__ ss, const float* __restrict__ g_brgb,
-                   const float* __restrict__ g_bseg, float* __restrict__ Q) {
-  const long OYX = (long) P.oY * P.oX;
-  const long col = (long) blockIdx.x * 256 + threadIdx.x;
-  const int j = blockIdx.y, b = blockIdx.z;
-  if (col >= OYX) return;
-  const int nch = P.K + 3;
-  float q0 = 0.f, q1 = 0.f, q2 = 0.f;
-  constexpr int U = 7;                          // channels in flight (K + 3 = 21 = 3 x 7)
-  for (int c0 = 0; c0 < nch; c0 += U) {
-    float g[U], v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int ch = min(c0 + u, nch - 1);
-      const bool is_sem = ch < P.K;
-      const float* gp = is_sem ? g_bseg : g_brgb;
-      g[u] = (gp && c0 + u < nch) ? gp[is_sem ? ((long) b * P.K + ch) * OYX + col : ((long) b * 3 + (ch - P.K)) * OYX + col] : 0.f;
-      v[u] = ss[(((long) b * nch + ch) * P.oZ + j) * OYX + col];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (u % 3 == 0) q0 = __builtin_fmaf(g[u], v[u], q0);
-      else if (u % 3 == 1) q1 = __builtin_fmaf(g[u], v[u], q1);
-      else q2 = __builtin_fmaf(g[u], v[u], q2);
-    }
-  }
-  Q[((long) b * P.oZ + j) * OYX + col] = (q0 + q1) + q2;
-}
-
 // bev_q_saved + bev_scan as ONE kernel (round 4; the forward kept its samples): lanes = (column, height).
 // A workgroup is 64 consecutive columns of the flattened (y, x) lattice times the heights, a wave per height
 // (beyond kQsMaxWaves heights a wave takes several).  Per (column, height): q = G . s and tau with ALL of
@@ -1531,7 +1499,6 @@ int vamp_render_bev_backward_ex(const VampRenderDesc* d, const float* oxs, const
   const bool saved = (flags & VAMP_BEVBWD_SAVED_VALID) != 0;
   const float* s0_saved = saved ? reinterpret_cast<const float*>(static_cast<char*>(workspace) + bev_saved_offset(d)) : nullptr;
   const float* ss_saved = saved ? reinterpret_cast<const float*>(static_cast<char*>(workspace) + bev_saved_offset(d) + bev_one(d)) : nullptr;
-  dim3 gqs((unsigned) (((long) d->oY * d->oX + 255) / 256), d->oZ, d->B);
 #define VAMP_BEVB(T)                                                                              \
   do {                                                                                            \
     if (saved) {                                                                                  \
