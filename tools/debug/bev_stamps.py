@@ -36,7 +36,7 @@ a = a[a[:, 0, 0] > 0]
 t0 = a[:, :, 0].min()
 names = ["tables", "density planes", "weights", "channels"]
 print("mode", "train" if train else "forward only", "workgroups", len(a))
-for w, nm in ((0, "wave 0"), (1, "last wave")):
+for w, nm in ((0, "group 0 (density + composited channels), wave 0"), (1, "group 1 (pass-through channels), wave 0")):
     t = a[:, w, :5]
     ph = np.diff(t, axis=1) / 100.0
     start, end = (t[:, 0] - t0) / 100.0, (t[:, 4] - t0) / 100.0

@@ -91,12 +91,12 @@ constexpr int kFusedMaxNP = 40;       // distinct volume planes the det heights 
 #endif
 
 #ifdef VAMP_BEVF_STAMPS
-// diagnostic build only (tools/debug/bev_stamps.py): phase stamps of waves 0 and NWV - 1 of every workgroup
+// diagnostic build only (tools/debug/bev_stamps.py): phase stamps of wave 0 of both channel groups of every column block
 __device__ long long g_bevf_stamps[1024 * 16];
 #define VAMP_BSTAMP(k)                                                                                  \
   do {                                                                                                  \
-    if (lane == 0 && (wave == 0 || wave == NWV - 1) && blockIdx.x < 1024 && blockIdx.z == 0)                               \
-      g_bevf_stamps[blockIdx.x * 16 + (wave ? 8 : 0) + (k)] = (long long) wall_clock64();               \
+    if (lane == 0 && wave == 0 && blockIdx.x < 1024 && blockIdx.z < 2)                                  \
+      g_bevf_stamps[blockIdx.x * 16 + (blockIdx.z ? 8 : 0) + (k)] = (long long) wall_clock64();         \
   } while (0)
 #else
 #define VAMP_BSTAMP(k) do { } while (0)
