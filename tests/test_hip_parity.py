@@ -809,7 +809,9 @@ def test_render_variants_full_size_match_atomic_splat(dev, monkeypatch, mode, ca
         assert bool(torch.isfinite(o).all()), name
     for name, a, b in zip(("density_feature", "semantic_logits", "base", "rgb"), g_new, g_old):
         assert float(b.abs().max()) > 0, name
-        close(a, b, atol=1e-5, rtol=3e-5, scale="max", what=f"{mode} cat_seg={cat_seg}: grad_" + name)
+        # (4e-5: with the kept samples the per-ray pass works on the one-kernel forward's line coordinates, the v1
+        # splat on the fp32 chain's -- 3.1e-5 of the largest gradient without early termination, VAMP_ERT=0)
+        close(a, b, atol=1e-5, rtol=4e-5, scale="max", what=f"{mode} cat_seg={cat_seg}: grad_" + name)
     if beta is not None:
         close(b_new.reshape(1), b_old.reshape(1), atol=1e-3, rtol=1e-3, what="grad_beta")
 
