@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VAMP_ABI_VERSION 4   /* bumped whenever entry points or flags are added (round 2: 2, round 3: 3, round 4: 4) */
+#define VAMP_ABI_VERSION 5   /* bumped whenever entry points or flags are added (round 2: 2, round 3: 3, round 4: 4, round 5: 5) */
 
 enum {
   VAMP_OK = 0,
@@ -193,6 +193,18 @@ int vamp_lift_backward_dense(const VampLiftDesc* d, const float* mats, const flo
 int vamp_lift_indices(const VampLiftDesc* d, const float* mats, const float* xs,
                       const float* ys, const float* zs, uint8_t* valid, int16_t* ix0,
                       int16_t* iy0, int16_t* iz0, void* stream);
+
+/*
+ * Diagnostics for the forward's camera cull (lift.hip: lift_cull_eval): before a wave of the forward
+ * kernel projects its patch[0] x patch[1] voxels of one z plane it reads one word, computed from the
+ * matrices alone by the forward's first launch -- bit n set: camera n may hold a voxel of the patch that
+ * passes `valid` (bv2:493-497); bit 15: every camera of the sample shares inv(bda) bit for bit.  A clear
+ * bit is a proof (conservative half-space test of the patch against the six bounds of `valid`), so
+ * skipping the camera changes no bit of the result.  This entry runs the same code into `words`
+ * [B, Z, grid[1], grid[0]] (uint32; pass words == NULL to query patch / grid only).
+ */
+int vamp_lift_cull_words(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
+                         const float* zs, uint32_t* words, int32_t patch[2], int32_t grid[2], void* stream);
 
 /* ------------------------------------------------------------------------- *
  * RENDER: volume_rendering_from_multiple_views (bv2:391-467) with the density

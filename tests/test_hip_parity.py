@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN, RENDER_VARIANTS, load_golden, render_fixture_name
-from vampire_amd.config import CFG_A, CFG_B, CFG_TINY
+from vampire_amd.config import CFG_A, CFG_B, CFG_D, CFG_TINY
 from vampire_amd.geometry import PathGeometry, lift_matrices, render_matrices
 from vampire_amd import synthetic
 
@@ -65,6 +65,60 @@ def test_lift_indices_bitexact_tiny(tiny_common, dev):
     finite = torch.isfinite(g["pix"]).all(dim=-1)
     for got, key in ((ix0, "lift_ix0"), (iy0, "lift_iy0"), (iz0, "lift_iz0")):
         assert torch.equal(got.cpu()[finite], g[key][finite]), key
+
+
+def _cull_covers_valid(hp, lm, valid, use_depth=True):
+    """Every (voxel, camera) pair the chain finds valid has its camera's bit set in the cull word of the
+    voxel's patch; returns the mean number of cameras a patch keeps."""
+    words, (px, py) = hp.lift_cull_words(lm, use_depth=use_depth)
+    B, N, Z, Y, X = valid.shape
+    assert words.shape[1] == Z and words.shape[2] * py >= Y and words.shape[3] * px >= X
+    per_voxel = words.repeat_interleave(py, dim=2).repeat_interleave(px, dim=3)[:, :, :Y, :X]     # [B, Z, Y, X]
+    for n in range(N):
+        missed = valid[:, n].bool() & ((per_voxel >> n) & 1).eq(0)
+        assert not bool(missed.any()), f"camera {n}: {int(missed.sum())} valid voxels in culled patches"
+    # bit 15: one inv(bda) per sample
+    words = words[:, :, :(Y + py - 1) // py, :(X + px - 1) // px]          # (the launch grid's spare patches hold 0)
+    same = (lm[:, :, 0] == lm[:, :1, 0]).flatten(1).all(dim=1)
+    assert torch.equal(((words >> 15) & 1).flatten(1).amin(dim=1).bool(), same)
+    assert torch.equal(((words >> 15) & 1).flatten(1).amax(dim=1).bool(), same)
+    cams = sum(((words >> n) & 1) for n in range(N)).float()
+    return float(cams.mean())
+
+
+def test_lift_cull_words_tiny(tiny_common, dev):
+    """The forward's conservative camera cull never drops a valid pair (the tiny fixture has a rotated,
+    flipped and scaled bda and a camera partly behind the grid; tiny_bilinear is the D == 1 variant)."""
+    g = tiny_common
+    hp = hot(CFG_TINY, dev)
+    lm, _ = tiny_mats(g, dev)
+    _cull_covers_valid(hp, lm, g["lift_valid"].to(dev))
+    gb = load_golden("tiny_bilinear.npz")
+    lmb, _ = tiny_mats(gb, dev)
+    validb = hp.lift_indices(lmb, use_depth=False)[0]
+    _cull_covers_valid(hp, lmb, validb, use_depth=False)
+    # a non-image-plane ida (depth leaks into u) switches the cull off for that camera
+    lm2 = lm.clone()
+    lm2[0, 1, 2, 0, 2] = 0.01
+    w2, _ = hp.lift_cull_words(lm2)
+    assert bool(((w2[0] >> 1) & 1).all())
+    _cull_covers_valid(hp, lm2, hp.lift_indices(lm2)[0])
+
+
+@pytest.mark.parametrize("name,cfg", [("A", CFG_A), ("B", CFG_B), ("D", CFG_D)])
+def test_lift_cull_words_full_size(dev, name, cfg):
+    """cfg-A / B / D with the synthetic rig (jittered, rotated bda, two samples): the cull keeps every valid
+    pair and drops most cameras (about 1.5 of 6 per patch survive)."""
+    hp = hot(cfg, dev)
+    s2e, K, ida = synthetic.camera_rig(cfg, 2, jitter=2.0, seed=5)
+    lm = lift_matrices(s2e, K, ida, synthetic.bda_matrix(2, rot_deg=7.0)).to(dev)
+    valid = hp.lift_indices(lm)[0]
+    kept = _cull_covers_valid(hp, lm, valid)
+    assert kept < 2.2, kept
+    s2e, K, ida = synthetic.camera_rig(cfg, 1)
+    lm = lift_matrices(s2e, K, ida, synthetic.bda_matrix(1)).to(dev)
+    kept = _cull_covers_valid(hp, lm, hp.lift_indices(lm)[0])
+    assert kept < 2.2, kept
 
 
 def test_lift_forward_tiny(tiny_common, dev):

@@ -7,7 +7,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the last replay: walk back from the end until the first lift kernel of that step
 names = [r["Kernel_Name"] for r in rows]
 end = len(rows)
-start = max(i for i, n in enumerate(names) if "feat_to_channel_last" in n)
+start = max(i for i, n in enumerate(names) if any(k in n for k in ("feat_to_channel_last", "lift_prologue_kernel", "lift_operands_kernel")))
 seg = rows[start:end]
 t0 = int(seg[0]["Start_Timestamp"])
 busy_end = t0

@@ -9,7 +9,7 @@ import os
 
 from .build import lib_path
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 VAMP_F32, VAMP_BF16, VAMP_F16 = 0, 1, 2
 VAMP_DENSITY_SIGMOID, VAMP_DENSITY_SDF_LAPLACE = 0, 1
@@ -100,6 +100,7 @@ SIGNATURES = {
     "vamp_lift_forward_dense": (C.c_int, [_LD] + [_P] * 7 + [_P]),
     "vamp_lift_backward_dense": (C.c_int, [_LD] + [_P] * 7 + [_P]),
     "vamp_lift_indices": (C.c_int, [_LD] + [_P] * 8 + [_P]),
+    "vamp_lift_cull_words": (C.c_int, [_LD] + [_P] * 7 + [_P]),
     "vamp_render_workspace_bytes": (C.c_size_t, [_RD]),
     "vamp_render_camera_forward": (C.c_int, [_RD] + [_P] * 13 + [_P, C.c_size_t, _P]),
     "vamp_render_samples_bytes": (C.c_size_t, [_RD]),

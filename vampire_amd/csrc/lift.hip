@@ -14,6 +14,17 @@
 
 namespace vamp {
 
+// tile shape: lanes along x for coalesced stores
+// A wave is a 16 x 4 patch of voxels, not a 64 x 1 row: the exact wave-level camera cull of
+// lift_project<true> skips a camera only when none of the wave's voxels has it in front, and a
+// 6.4 m x 1.6 m patch is on one side of most cameras where a 25.6 m row is not (cfg-B: 47 -> 36 us;
+// 8 x 32 / 16 x 16 / 32 x 8 / 64 x 4 workgroup tiles: 36.5 / 35.7 / 38.2 / 47.1).
+#ifndef VAMP_LIFT_TX
+#define VAMP_LIFT_TX 16
+#define VAMP_LIFT_TY 16
+#endif
+#define VAMP_LIFT_TILE VAMP_LIFT_TX, VAMP_LIFT_TY, 1
+
 // ---------------------------------------------------------------------------
 // feat [BN, C, HW] (f32 or bf16) -> channel-last fp32 [BN, HW, C]
 // ---------------------------------------------------------------------------
@@ -41,28 +52,276 @@ __global__ void __launch_bounds__(256) feat_to_channel_last(const T* __restrict_
 }
 
 // ---------------------------------------------------------------------------
+// Camera cull words of the forward (round 5).  The waves of a lift_fwd_kernel workgroup -- a TX x TY patch
+// of voxel centres in one z plane -- read ONE word before they project anything: bit n set = camera n's
+// frustum may contain a voxel of the patch.  The word comes from the matrices alone.  With ida's rows
+// (a00, a01, 0, a03), (a10, a11, 0, a13), (0, 0, 1, 0) -- image-plane augmentations, the reference's only
+// kind (nusc_det_seg_dataset.py:490-498) -- the point q = (K inv(s2e)) (inv(bda) c) is affine in the voxel
+// centre c and, wherever q.z > 0,
+//     u > -0.5   <=>   a00 q.x + a01 q.y + (a03 q.w + 0.5) q.z > 0            (likewise u_max, v, depth)
+// so each of the six bounds of `valid` (bv2:493-497) is a half-space of c.  If the four corners of the
+// patch's bounding rectangle GROWN BY ONE VOXEL on every side lie outside ONE of them by a further margin of
+// one feature pixel / one depth bin -- both four orders of magnitude above the rounding of the fp32 chain and
+// of the fp32 product (K inv(s2e)) inv(bda) the corners go through -- the whole patch does, and no lane can
+// find the camera valid: skipping it changes no bit of the result.
+// Anything else (another shape of ida, NaN / Inf anywhere) leaves the bit set; the exact chain of
+// lift_project still decides every survivor, and its wave-level test (lift_project_from<true>) still drops a
+// camera the wave's own 16 x 4 voxels are behind.  cfg-B: 1.6 of 6 cameras per patch survive; the forward
+// kernel went from 1 369 to 587 vector instructions per wave.
+// Bit 15: all cameras of the sample share inv(bda) bit for bit (its product is then formed once per voxel).
+// ---------------------------------------------------------------------------
+constexpr unsigned kLiftCullSharedBda = 1u << 15;
+
+struct LiftCull {
+  unsigned* words;      // [B][Z][nyp][nxp]
+  int nxp, nyp;         // patches per row / column of one z plane
+  int px, py;           // patch shape in voxels
+  int group;            // lanes per patch in a cull workgroup: the power of two >= N
+  int bps;              // stand-alone cull: workgroups (256 / group patches each) per sample
+  int ppt;              // forward's first launch: patches per feature tile (N * ptiles tiles per sample)
+};
+
+// What a cull workgroup keeps per camera of its sample (LDS): A = (K inv(s2e)) inv(bda) in fp32 -- its
+// rounding is what the margins are four orders of magnitude above -- and the image-plane rows of ida.
+struct LiftCullCam {
+  float A[16];
+  float a00, a01, a03, a10, a11, a13;
+  int plane;          // ida has the image-plane shape the half-space form needs
+  int same;           // inv(bda) is camera 0's, bit for bit
+};
+constexpr int kLiftCullMaxCams = 15;
+#ifndef VAMP_CULL_WPW
+#define VAMP_CULL_WPW 4      // (1 / 2 / 4: first launch 9.9 / 9.0 / 9.0 us, forward kernel 28.3 / 28.4 / 28.4 at cfg-B)
+#endif
+constexpr int kCullWpw = VAMP_CULL_WPW;     // waves of lift_fwd_kernel (stacked along y) that share a word: 1, 2 or 4
+constexpr int kCullPX = VAMP_LIFT_TX, kCullPY = 64 / VAMP_LIFT_TX * kCullWpw;
+
+// The cull in three pieces, so that a launch can put its loads beside other loads and its arithmetic behind
+// a barrier it has anyway.  (1) per camera of the sample, once per workgroup: the constants above (wave 0);
+// (2) per patch of the workgroup's share, once: its bounding rectangle (wave 1); barrier; (3) a lane per
+// (patch, camera), the cameras of a patch in G consecutive lanes (G = the power of two >= N): the test from
+// LDS, the group's word a ballot.
+struct LiftCullBox { float xlo, xhi, ylo, yhi, zc; int inside; };
+constexpr int kCullBoxes = 64;        // patches per round of a workgroup (256 / G <= 64 for G >= 4; G < 4: rounds of 64)
+
+struct LiftCullLds {
+  LiftCullCam cams[kLiftCullMaxCams];
+  LiftCullBox box[kCullBoxes];
+};
+
+__device__ __forceinline__ int lift_cull_round(const LiftCull& K) { return min(256 / K.group, kCullBoxes); }
+
+// (1): threads [0, N).  16-byte loads: the matrices are 64-byte rows of a 16-byte aligned array.
+__device__ __forceinline__ void lift_cull_constants(const LiftParams& P, const float* __restrict__ mats, int b,
+                                                    LiftCullLds& S) {
+  if ((int) threadIdx.x >= P.N) return;
+  const int cn = threadIdx.x;
+  const float4* m = reinterpret_cast<const float4*>(mats + ((long) b * P.N + cn) * 48);
+  const float4* m0 = reinterpret_cast<const float4*>(mats + (long) b * P.N * 48);
+  float4 r[12], z[4];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) r[i] = m[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) z[i] = m0[i];
+  LiftCullCam c;
+  bool same = true;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    same = same && __float_as_uint(r[i].x) == __float_as_uint(z[i].x) && __float_as_uint(r[i].y) == __float_as_uint(z[i].y) &&
+           __float_as_uint(r[i].z) == __float_as_uint(z[i].z) && __float_as_uint(r[i].w) == __float_as_uint(z[i].w);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {          // A = M2 . M1, row i
+    const float4 k = r[4 + i];
+    c.A[i * 4 + 0] = __builtin_fmaf(k.x, r[0].x, __builtin_fmaf(k.y, r[1].x, __builtin_fmaf(k.z, r[2].x, k.w * r[3].x)));
+    c.A[i * 4 + 1] = __builtin_fmaf(k.x, r[0].y, __builtin_fmaf(k.y, r[1].y, __builtin_fmaf(k.z, r[2].y, k.w * r[3].y)));
+    c.A[i * 4 + 2] = __builtin_fmaf(k.x, r[0].z, __builtin_fmaf(k.y, r[1].z, __builtin_fmaf(k.z, r[2].z, k.w * r[3].z)));
+    c.A[i * 4 + 3] = __builtin_fmaf(k.x, r[0].w, __builtin_fmaf(k.y, r[1].w, __builtin_fmaf(k.z, r[2].w, k.w * r[3].w)));
+  }
+  c.a00 = r[8].x; c.a01 = r[8].y; c.a03 = r[8].w; c.a10 = r[9].x; c.a11 = r[9].y; c.a13 = r[9].w;
+  c.plane = r[8].z == 0.f && r[9].z == 0.f && r[10].x == 0.f && r[10].y == 0.f && r[10].z == 1.f && r[10].w == 0.f;
+  c.same = same;
+  S.cams[cn] = c;
+}
+
+// (2): threads [64, 64 + round): the bounding rectangle of patch `first + slot` of the sample, grown by one
+// voxel on every side (the axes are arrays of the caller: no monotonicity assumed; loads issued together)
+__device__ __forceinline__ void lift_cull_boxes(const LiftParams& P, const float* __restrict__ xs,
+                                                const float* __restrict__ ys, const float* __restrict__ zs,
+                                                const LiftCull& K, long first, long count, LiftCullLds& S) {
+  const int slot = (int) threadIdx.x - 64;
+  if (slot < 0 || slot >= lift_cull_round(K) || slot >= count) return;
+  const long per_sample = (long) P.Z * K.nyp * K.nxp;
+  const long pl = min(first + slot, per_sample - 1);
+  const int xp = (int) (pl % K.nxp);
+  const long r = pl / K.nxp;
+  const int yp = (int) (r % K.nyp);
+  const int x0 = min(xp * K.px, P.X - 1), y0 = min(yp * K.py, P.Y - 1);
+  float xv[kCullPX], yv[kCullPY];
+#pragma unroll
+  for (int i = 0; i < kCullPX; ++i) xv[i] = xs[min(x0 + i, P.X - 1)];
+#pragma unroll
+  for (int i = 0; i < kCullPY; ++i) yv[i] = ys[min(y0 + i, P.Y - 1)];
+  LiftCullBox B;
+  B.zc = zs[(int) (r / K.nyp)];
+  float xlo = xv[0], xhi = xlo, ylo = yv[0], yhi = ylo;
+#pragma unroll
+  for (int i = 1; i < kCullPX; ++i) { xlo = fminf(xlo, xv[i]); xhi = fmaxf(xhi, xv[i]); }
+#pragma unroll
+  for (int i = 1; i < kCullPY; ++i) { ylo = fminf(ylo, yv[i]); yhi = fmaxf(yhi, yv[i]); }
+  const int nx = min(kCullPX, P.X - x0), ny = min(kCullPY, P.Y - y0);
+  const float gx = nx > 1 ? (xhi - xlo) / (float) (nx - 1) : 0.f, gy = ny > 1 ? (yhi - ylo) / (float) (ny - 1) : 0.f;
+  B.xlo = xlo - gx; B.xhi = xhi + gx; B.ylo = ylo - gy; B.yhi = yhi + gy;
+  B.inside = first + slot < per_sample && xp * K.px < P.X && yp * K.py < P.Y;
+  S.box[slot] = B;
+}
+
+// (3): every wave that holds a live lane (wave-uniform: it ballots)
+__device__ __forceinline__ void lift_cull_eval(const LiftParams& P, const LiftCull& K, int b, long first, long count,
+                                               const LiftCullLds& S) {
+  const int G = K.group, round = lift_cull_round(K);
+  const int slot = threadIdx.x / G, n = threadIdx.x & (G - 1);
+  const int wave_slot0 = (threadIdx.x & ~63) / G;                 // first slot of this wave
+  if (wave_slot0 >= round || wave_slot0 >= count) return;
+  const long per_sample = (long) P.Z * K.nyp * K.nxp;
+  const bool live = slot < round && slot < count && first + slot < per_sample && n < P.N;
+  const LiftCullBox B = S.box[min(slot, round - 1)];
+  const LiftCullCam c = S.cams[min(n, P.N - 1)];
+  const float mu = P.u_div / (float) P.fW, mv = P.v_div / (float) P.fH;      // one feature pixel
+  const float mz = P.use_depth ? P.d_span / (float) P.D : 0.f;              // one depth bin
+  const float zlo = P.use_depth ? P.d_lo : 0.f;
+  bool keep = true;
+  if (c.plane) {
+    // corners q = A0 x + A1 y + (A2 z + A3)
+    float base[4], ax[2][4], ay[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      base[i] = __builtin_fmaf(c.A[i * 4 + 2], B.zc, c.A[i * 4 + 3]);
+      ax[0][i] = c.A[i * 4] * B.xlo; ax[1][i] = c.A[i * 4] * B.xhi;
+      ay[0][i] = c.A[i * 4 + 1] * B.ylo; ay[1][i] = c.A[i * 4 + 1] * B.yhi;
+    }
+    // the range of a03 q.w / a13 q.w over the patch (q.w is 1 up to the rounding of inv(s2e))
+    const float wlo = base[3] + fminf(ax[0][3], ax[1][3]) + fminf(ay[0][3], ay[1][3]);
+    const float whi = base[3] + fmaxf(ax[0][3], ax[1][3]) + fmaxf(ay[0][3], ay[1][3]);
+    const float u3lo = fminf(c.a03 * wlo, c.a03 * whi), u3hi = fmaxf(c.a03 * wlo, c.a03 * whi);
+    const float v3lo = fminf(c.a13 * wlo, c.a13 * whi), v3hi = fmaxf(c.a13 * wlo, c.a13 * whi);
+    bool o_near = true, o_far = P.use_depth != 0, o_l = true, o_r = true, o_t = true, o_b = true, front = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float qx = base[0] + ax[k & 1][0] + ay[k >> 1][0], qy = base[1] + ax[k & 1][1] + ay[k >> 1][1];
+      const float qz = base[2] + ax[k & 1][2] + ay[k >> 1][2];
+      o_near = o_near && qz <= zlo - mz;
+      o_far = o_far && qz >= P.d_hi + mz;
+      const float lu = c.a00 * qx + c.a01 * qy, lv = c.a10 * qx + c.a11 * qy;
+      o_l = o_l && lu + (u3hi + 0.5f + mu) * qz <= 0.f;
+      o_r = o_r && lu + (u3lo - P.u_max - mu) * qz >= 0.f;
+      o_t = o_t && lv + (v3hi + 0.5f + mv) * qz <= 0.f;
+      o_b = o_b && lv + (v3lo - P.v_max - mv) * qz >= 0.f;
+      front = front && qz >= 1.0f;
+    }
+    // with the depth bounds a valid voxel has q.z > d_lo; without them (D == 1) or with a near bound
+    // below a metre the side planes are used only for patches wholly a metre in front of the camera
+    // (the chain clamps q.z at 1e-6, and the margins are worth a feature pixel only away from q.z = 0)
+    const bool sides = (P.use_depth && P.d_lo >= 1.0f) || front;
+    if (o_near || o_far || (sides && (o_l || o_r || o_t || o_b))) keep = false;
+  }
+  const int lane = threadIdx.x & 63, g0 = lane & ~(G - 1);
+  const uint64_t gm = ((G == 64) ? ~0ull : ((1ull << G) - 1)) << g0;
+  const uint64_t kept = __ballot(live && keep) & gm, differ = __ballot(live && !c.same) & gm;
+  if (live && n == 0)
+    K.words[(long) b * per_sample + first + slot] =
+        B.inside ? ((unsigned) (kept >> g0) | (differ ? 0u : kLiftCullSharedBda)) : 0u;
+}
+
+// `count` patches of sample b from `first` on, by one workgroup whose caller has run (1) and (2) for the
+// first round and a barrier; further rounds (a share larger than 256 / G patches: huge grids on tiny images)
+__device__ __forceinline__ void lift_cull_share(const LiftParams& P, const float* __restrict__ xs,
+                                                const float* __restrict__ ys, const float* __restrict__ zs,
+                                                const LiftCull& K, int b, long first, long count, LiftCullLds& S) {
+  const int round = lift_cull_round(K);
+  lift_cull_eval(P, K, b, first, count, S);
+  for (long done = round; done < count; done += round) {       // (uniform over the workgroup)
+    __syncthreads();
+    lift_cull_boxes(P, xs, ys, zs, K, first + done, count - done, S);
+    __syncthreads();
+    lift_cull_eval(P, K, b, first + done, count - done, S);
+  }
+}
+
+// stand-alone form (vamp_lift_cull_words): workgroup `blk` = sample * K.bps + chunk of 256 / G patches
+__global__ void __launch_bounds__(256)
+lift_cull_kernel(LiftParams P, const float* __restrict__ mats, const float* __restrict__ xs,
+                 const float* __restrict__ ys, const float* __restrict__ zs, LiftCull K) {
+  __shared__ LiftCullLds S;
+  const int b = blockIdx.x / K.bps, ppr = lift_cull_round(K);
+  const long first = (long) (blockIdx.x % K.bps) * ppr;
+  lift_cull_constants(P, mats, b, S);
+  lift_cull_boxes(P, xs, ys, zs, K, first, ppr, S);
+  __syncthreads();
+  lift_cull_share(P, xs, ys, zs, K, b, first, ppr, S);
+}
+
+// One tile of the forward's first launch: 64 pixels x all channels of feat go channel-last, and -- in the
+// shadow of those loads and behind the same barrier -- the workgroup's share of its sample's cull words.
+// `r` = tile index in [0, B * N * ptiles); the N * ptiles tiles of a sample share its words evenly.
+template <typename T>
+__device__ __forceinline__ void lift_prologue_tile(const LiftParams& P, const T* __restrict__ feat,
+                                                   float* __restrict__ feat_cl, int ptiles, unsigned r,
+                                                   const float* __restrict__ mats, const float* __restrict__ xs,
+                                                   const float* __restrict__ ys, const float* __restrict__ zs,
+                                                   const LiftCull& K, float (&tile)[64][65], LiftCullLds& S) {
+  const int C = P.C, HW = P.fH * P.fW;
+  const long bn = r / ptiles;
+  const int p0 = (r % ptiles) * 64, b = (int) (bn / P.N);
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long first = (long) (r % ((unsigned) P.N * ptiles)) * K.ppt;
+  for (int c = ty; c < C; c += 4) tile[c][tx] = (p0 + tx < HW) ? ldf(feat, (bn * C + c) * HW + p0 + tx) : 0.f;
+  lift_cull_constants(P, mats, b, S);
+  lift_cull_boxes(P, xs, ys, zs, K, first, K.ppt, S);
+  __syncthreads();
+  const int np = min(64, HW - p0);
+  float* o = feat_cl + (bn * HW + p0) * C;
+  if ((C & (C - 1)) == 0) {              // (no integer division on the way out: it costs more than the cull)
+    const int sh = __builtin_ctz(C);
+    for (int i = threadIdx.x; i < np * C; i += 256) o[i] = tile[i & (C - 1)][i >> sh];
+  } else {
+    for (int i = threadIdx.x; i < np * C; i += 256) o[i] = tile[i % C][i / C];
+  }
+  lift_cull_share(P, xs, ys, zs, K, b, first, K.ppt, S);
+}
+
+// The forward's first launch on the plain (depth, feat) entry: channel-last feature copy + cull words.
+template <typename T>
+__global__ void __launch_bounds__(256, 6)
+lift_prologue_kernel(LiftParams P, const T* __restrict__ feat, float* __restrict__ feat_cl, int ptiles,
+                     const float* __restrict__ mats, const float* __restrict__ xs,
+                     const float* __restrict__ ys, const float* __restrict__ zs, LiftCull K) {
+  __shared__ float tile[64][65];
+  __shared__ LiftCullLds S;
+  lift_prologue_tile<T>(P, feat, feat_cl, ptiles, blockIdx.x, mats, xs, ys, zs, K, tile, S);
+}
+
+// ---------------------------------------------------------------------------
 // Both lift operands in one launch (the producer side): workgroups [0, n_sm) turn
 // the raw `mapping_along_depth` logits into the depth distribution (softmax over D,
 // base_vampire2.py:550), the rest make the channel-last copy of the features.  The two jobs are
 // independent, so the 6 600 softmax tiles and the 1 100 transpose tiles of cfg-B share one grid.
 // ---------------------------------------------------------------------------
 template <typename TL, bool REG>
-__global__ void __launch_bounds__(256)
-lift_operands_kernel(const TL* __restrict__ logits, float* __restrict__ depth, int D, long HW, int sm_tiles,
-                     unsigned n_sm, const float* __restrict__ feat, float* __restrict__ feat_cl, int C,
-                     int ptiles, int ctiles) {
+__global__ void __launch_bounds__(256, 6)      // (6 waves per SIMD, what the softmax tiles ran at before they shared the launch with the cull)
+lift_operands_kernel(LiftParams P, const TL* __restrict__ logits, float* __restrict__ depth, int sm_tiles,
+                     unsigned n_sm, const float* __restrict__ feat, float* __restrict__ feat_cl,
+                     int ptiles, const float* __restrict__ mats, const float* __restrict__ xs,
+                     const float* __restrict__ ys, const float* __restrict__ zs, LiftCull K) {
   __shared__ union {
     SoftmaxLds sm;
     float tile[64][65];
   } L;
+  __shared__ LiftCullLds S;
+  const long HW = (long) P.fH * P.fW;
   if (blockIdx.x < n_sm) {
-    depth_softmax_tile<TL, REG>(logits, depth, D, HW, blockIdx.x / sm_tiles, blockIdx.x % sm_tiles, L.sm);
+    depth_softmax_tile<TL, REG>(logits, depth, P.D, HW, blockIdx.x / sm_tiles, blockIdx.x % sm_tiles, L.sm);
   } else {
-    unsigned r = blockIdx.x - n_sm;
-    const int px = r % ptiles;
-    r /= ptiles;
-    const int ct = r % ctiles;
-    feat_to_channel_last_tile<float>(feat, feat_cl, C, (int) HW, (long) (r / ctiles), px * 64, ct * 64, L.tile);
+    lift_prologue_tile<float>(P, feat, feat_cl, ptiles, blockIdx.x - n_sm, mats, xs, ys, zs, K, L.tile, S);
   }
 }
 
@@ -131,13 +390,18 @@ __global__ void __launch_bounds__(TX* TY* TZ, 4)      // (4 waves per SIMD: the 
 lift_fwd_kernel(LiftParams P, const float* __restrict__ mats, const float* __restrict__ xs,
                 const float* __restrict__ ys, const float* __restrict__ zs,
                 const T* __restrict__ depth, const float* __restrict__ feat_cl,
-                float* __restrict__ out, uint64_t* __restrict__ hits, LiftEmit E) {
+                float* __restrict__ out, uint64_t* __restrict__ hits, LiftEmit E,
+                const unsigned* __restrict__ cull) {
+  static_assert(TZ == 1 && TX * TY == 256 && 64 % TX == 0, "a wave is a TX x (64 / TX) patch of one z plane");
   const int tid = threadIdx.x;
   const int x = blockIdx.x * TX + (tid % TX);
   const int y = blockIdx.y * TY + ((tid / TX) % TY);
   const int zblocks = (P.Z + TZ - 1) / TZ;
   const int b = blockIdx.z / zblocks;
   const int z = (blockIdx.z % zblocks) * TZ + tid / (TX * TY);
+  // the wave's cull word (lift_cull_eval): one scalar load
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned cword = cull[((long) blockIdx.z * (gridDim.y * (4 / kCullWpw)) + blockIdx.y * (4 / kCullWpw) + wave / kCullWpw) * gridDim.x + blockIdx.x];
   if (x >= P.X || y >= P.Y || z >= P.Z) return;
 
   const float vx = xs[x], vy = ys[y], vz = zs[z];
@@ -147,15 +411,18 @@ lift_fwd_kernel(LiftParams P, const float* __restrict__ mats, const float* __res
   const int nchunk = P.C / CH;
 
   unsigned wmask = 0;
+  const bool shared_bda = (cword & kLiftCullSharedBda) != 0;                        // uniform
+  const Vec4 p1 = matvec(mats + (long) b * P.N * 48, Vec4{vx, vy, vz, 1.0f});       // inv(bda) . c
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     float sum[CH];
     uint64_t cnt = 0;
 #pragma unroll
     for (int c = 0; c < CH; ++c) sum[c] = 0.f;
 
-    for (int n = 0; n < P.N; ++n) {
+    for (unsigned cams = cword & (kLiftCullSharedBda - 1); cams; cams &= cams - 1) {
+      const int n = __builtin_ctz(cams);
       const long bn = (long) b * P.N + n;
-      const LiftTap t = lift_project<true>(P, mats + bn * 48, vx, vy, vz);
+      const LiftTap t = lift_project_from<true>(P, mats + bn * 48, shared_bda ? p1 : matvec(mats + bn * 48, Vec4{vx, vy, vz, 1.0f}));
       if (EMIT && chunk == 0)        // (wave-uniform here: the lanes part ways at the next line)
         if (lift_emit_pair(P, E, t, true, bn, V, vox, tid & 63)) wmask |= 1u << (n & 31);
       if (!t.valid) continue;
@@ -189,10 +456,23 @@ lift_fwd_kernel(LiftParams P, const float* __restrict__ mats, const float* __res
       }
     }
     float* o = out + ((long) b * P.C + chunk * CH) * V + vox;
+    // the mean over the cameras that hit (bv2:509-514).  Unless a feature channel holds exact zeros the CH
+    // counts of a voxel are one number: one division per lane gives its reciprocal, a product and one
+    // residual step per channel the quotient (within an ulp of sum / denom; the outputs are held to 1e-4)
+    const unsigned k0 = (unsigned) cnt & 15u;
+    if (__all(cnt == (uint64_t) k0 * (0x1111111111111111ull >> (64 - 4 * CH)))) {
+      const float denom = (float) k0 + 1e-6f, r = 1.0f / denom;
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const float denom = (float) ((cnt >> (4 * c)) & 15) + 1e-6f;
-      o[(long) c * V] = sum[c] / denom;
+      for (int c = 0; c < CH; ++c) {
+        const float q = sum[c] * r;
+        o[(long) c * V] = __builtin_fmaf(__builtin_fmaf(-q, denom, sum[c]), r, q);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const float denom = (float) ((cnt >> (4 * c)) & 15) + 1e-6f;
+        o[(long) c * V] = sum[c] / denom;
+      }
     }
     if (hits) hits[((long) b * V + vox) * nchunk + chunk] = cnt;
   }
@@ -436,10 +716,13 @@ static void launch_to_cl(const void* feat, float* out, int BN, int C, int HW, hi
   VAMP_TIMED(kProfFeatCL, s, (feat_to_channel_last<T><<<grid, 256, 0, s>>>(static_cast<const T*>(feat), out, C, HW)));
 }
 
+
 struct LiftWs {
   float* feat_cl;     // [B*N, HW, C]
   float* gfeat_cl;    // [B*N, HW, C] (v1 backward only)
   void* cells;        // cell lists of the backward; vamp_lift_prepare fills their offsets
+  LiftCull cull;      // camera cull words of the forward's waves
+  long ncull;
   size_t bytes;
 };
 
@@ -450,20 +733,24 @@ static LiftWs carve(const VampLiftDesc* d, void* ws) {
   w.gfeat_cl = reinterpret_cast<float*>(static_cast<char*>(ws) + n);
   // the cell lists live behind the copies: the forward must not disturb prepared offsets
   w.cells = static_cast<char*>(ws) + 2 * n;
-  w.bytes = 2 * n + lift_bwd_cell_ws_bytes(d);
+  const size_t ncell_bytes = align_up(lift_bwd_cell_ws_bytes(d), 256);
+  w.cull.words = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + 2 * n + ncell_bytes);
+  w.cull.px = VAMP_LIFT_TX;
+  w.cull.py = kCullPY;
+  w.cull.nxp = (d->X + VAMP_LIFT_TX - 1) / VAMP_LIFT_TX;
+  w.cull.nyp = (d->Y + VAMP_LIFT_TY - 1) / VAMP_LIFT_TY * (4 / kCullWpw);
+  w.ncull = (long) d->B * d->Z * w.cull.nyp * w.cull.nxp;
+  w.cull.group = 1;
+  while (w.cull.group < d->N) w.cull.group *= 2;
+  const int ppb = std::min(256 / w.cull.group, 64);
+  const long per_sample = (long) d->Z * w.cull.nyp * w.cull.nxp;
+  w.cull.bps = (int) ((per_sample + ppb - 1) / ppb);
+  const long tiles = (long) d->N * (((long) d->fH * d->fW + 63) / 64);
+  w.cull.ppt = (int) ((per_sample + tiles - 1) / tiles);
+  w.bytes = 2 * n + ncell_bytes + align_up((size_t) w.ncull * sizeof(unsigned), 256);
   return w;
 }
 
-// tile shape: lanes along x for coalesced stores
-// A wave is a 16 x 4 patch of voxels, not a 64 x 1 row: the exact wave-level camera cull of
-// lift_project<true> skips a camera only when none of the wave's voxels has it in front, and a
-// 6.4 m x 1.6 m patch is on one side of most cameras where a 25.6 m row is not (cfg-B: 47 -> 36 us;
-// 8 x 32 / 16 x 16 / 32 x 8 / 64 x 4 workgroup tiles: 36.5 / 35.7 / 38.2 / 47.1).
-#ifndef VAMP_LIFT_TX
-#define VAMP_LIFT_TX 16
-#define VAMP_LIFT_TY 16
-#endif
-#define VAMP_LIFT_TILE VAMP_LIFT_TX, VAMP_LIFT_TY, 1
 
 // `cells` != nullptr: the kernel emits the backward's pairs into that part of the workspace, between
 // the zero fill of the cell counters and their scan (afterwards the workspace is what
@@ -472,7 +759,7 @@ template <typename T>
 static int lift_forward_t(const VampLiftDesc* d, const LiftParams& P, const float* mats,
                           const float* xs, const float* ys, const float* zs, const void* depth,
                           const float* feat_cl, float* out, uint64_t* hits, void* cells, bool cells_clean,
-                          hipStream_t s) {
+                          const unsigned* cull, hipStream_t s) {
   constexpr int TX = VAMP_LIFT_TX, TY = VAMP_LIFT_TY, TZ = 1;
   dim3 grid((P.X + TX - 1) / TX, (P.Y + TY - 1) / TY, ((P.Z + TZ - 1) / TZ) * P.B);
   const T* dp = static_cast<const T*>(depth);
@@ -483,7 +770,7 @@ static int lift_forward_t(const VampLiftDesc* d, const LiftParams& P, const floa
     E = lift_emit_of(d, cells);
   }
 #define VAMP_FWD(CH, EM)                                                                               \
-  VAMP_TIMED(kProfLiftFwd, s, (lift_fwd_kernel<T, CH, VAMP_LIFT_TILE, EM><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, out, hits, E)))
+  VAMP_TIMED(kProfLiftFwd, s, (lift_fwd_kernel<T, CH, VAMP_LIFT_TILE, EM><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, out, hits, E, cull)))
   if (cells) {
     if (P.C == 4) VAMP_FWD(4, true); else if (P.C == 8) VAMP_FWD(8, true); else VAMP_FWD(16, true);
   } else {
@@ -552,15 +839,22 @@ int vamp_lift_forward_ex(const VampLiftDesc* d, const float* mats, const float* 
     return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) w.bytes);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const LiftParams P = to_params(d);
-  const int BN = d->B * d->N, HW = d->fH * d->fW;
-  if (d->in_dtype == VAMP_F32) launch_to_cl<float>(feat, w.feat_cl, BN, d->C, HW, s);
-  else launch_to_cl<__hip_bfloat16>(feat, w.feat_cl, BN, d->C, HW, s);
-  if (int e = check_launch("feat_to_channel_last")) return e;
+  const long BN = (long) d->B * d->N, HW = (long) d->fH * d->fW;
+  // first launch: channel-last copy of the features + the camera cull words of the forward's waves
+  const int ptiles = (int) ((HW + 63) / 64);
+  const long n_cl = BN * ptiles;
+  VAMP_REQUIRE(n_cl < 0x7fffffffL, "too many tiles");
+  const unsigned grid = (unsigned) n_cl;
+  if (d->in_dtype == VAMP_F32)
+    VAMP_TIMED(kProfFeatCL, s, (lift_prologue_kernel<float><<<grid, 256, 0, s>>>(P, static_cast<const float*>(feat), w.feat_cl, ptiles, mats, xs, ys, zs, w.cull)));
+  else
+    VAMP_TIMED(kProfFeatCL, s, (lift_prologue_kernel<__hip_bfloat16><<<grid, 256, 0, s>>>(P, static_cast<const __hip_bfloat16*>(feat), w.feat_cl, ptiles, mats, xs, ys, zs, w.cull)));
+  if (int e = check_launch("lift_prologue_kernel")) return e;
   void* cells = (flags & VAMP_LIFTFWD_EMIT_PAIRS) ? w.cells : nullptr;
   const bool clean = (flags & VAMP_LIFTFWD_CELLS_CLEAN) != 0;
   if (d->in_dtype == VAMP_F32)
-    return lift_forward_t<float>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, cells, clean, s);
-  return lift_forward_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, cells, clean, s);
+    return lift_forward_t<float>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, cells, clean, w.cull.words, s);
+  return lift_forward_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, cells, clean, w.cull.words, s);
 }
 
 int vamp_lift_forward_logits(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
@@ -588,14 +882,14 @@ int vamp_lift_forward_logits_ex(const VampLiftDesc* d, const float* mats, const 
   const LiftParams P = to_params(d);
   const long BN = (long) d->B * d->N, HW = (long) d->fH * d->fW;
   const long sm_tiles = (HW + kPix - 1) / kPix;
-  const int ptiles = (int) ((HW + 63) / 64), ctiles = (d->C + 63) / 64;
-  const long n_sm = BN * sm_tiles, n_cl = BN * ptiles * ctiles;
+  const int ptiles = (int) ((HW + 63) / 64);
+  const long n_sm = BN * sm_tiles, n_cl = BN * ptiles;
   VAMP_REQUIRE(n_sm + n_cl < 0x7fffffffL, "too many tiles");
   const unsigned grid = (unsigned) (n_sm + n_cl);
 #define VAMP_OPERANDS(TL, REG)                                                                           \
   VAMP_TIMED(kProfFeatCL, s, (lift_operands_kernel<TL, REG><<<grid, 256, 0, s>>>(                        \
-      static_cast<const TL*>(logits), depth_out, d->D, HW, (int) sm_tiles, (unsigned) n_sm, feat,        \
-      w.feat_cl, d->C, ptiles, ctiles)))
+      P, static_cast<const TL*>(logits), depth_out, (int) sm_tiles, (unsigned) n_sm, feat, w.feat_cl,    \
+      ptiles, mats, xs, ys, zs, w.cull)))
   const bool reg = d->D <= kSplit * kRegBins;
   if (logits_dtype == VAMP_F32) {
     if (reg) VAMP_OPERANDS(float, true); else VAMP_OPERANDS(float, false);
@@ -606,7 +900,7 @@ int vamp_lift_forward_logits_ex(const VampLiftDesc* d, const float* mats, const 
   if (int e = check_launch("lift_operands_kernel")) return e;
   return lift_forward_t<float>(d, P, mats, xs, ys, zs, depth_out, w.feat_cl, out, hits,
                                (flags & VAMP_LIFTFWD_EMIT_PAIRS) ? w.cells : nullptr,
-                               (flags & VAMP_LIFTFWD_CELLS_CLEAN) != 0, s);
+                               (flags & VAMP_LIFTFWD_CELLS_CLEAN) != 0, w.cull.words, s);
 }
 
 int vamp_lift_prepare(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
@@ -697,6 +991,21 @@ int vamp_lift_backward_dense(const VampLiftDesc* d, const float* mats, const flo
   VAMP_TIMED(kProfLiftBwdDense, s, (lift_bwd_dense_kernel<<<(unsigned) ((total + 255) / 256), 256, 0, s>>>(
       P, mats, xs, ys, zs, grad_out, hits, grad_frustum_feats)));
   return check_launch("lift_bwd_dense_kernel");
+}
+
+int vamp_lift_cull_words(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
+                         const float* zs, uint32_t* words, int32_t patch[2], int32_t grid[2], void* stream) {
+  if (int e = validate(d)) return e;
+  VAMP_REQUIRE(patch && grid, "null pointer");
+  LiftWs w = carve(d, nullptr);
+  patch[0] = w.cull.px; patch[1] = w.cull.py;
+  grid[0] = w.cull.nxp; grid[1] = w.cull.nyp;
+  if (!words) return VAMP_OK;
+  VAMP_REQUIRE(mats && xs && ys && zs, "null pointer");
+  w.cull.words = words;
+  lift_cull_kernel<<<(unsigned) ((long) d->B * w.cull.bps), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      to_params(d), mats, xs, ys, zs, w.cull);
+  return check_launch("lift_cull_kernel");
 }
 
 int vamp_lift_indices(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,

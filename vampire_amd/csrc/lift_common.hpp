@@ -38,11 +38,11 @@ struct LiftTap {
 // (z > d_lo, resp. z > 0) is invalid for all 64 voxels and the divisions, the third matrix and
 // the normalisation are skipped: the same masks as the full chain, about half of the projections
 // (the cameras facing away) at a third of the instructions.
+// lift_project_from: the chain behind its first product.  `p` = inv(bda) . (x, y, z, 1), which is the same
+// vector for every camera of a sample whose cameras share inv(bda) bit for bit (they do: bda is one matrix
+// per sample, bv2:370-372), so callers that know it (the cull word's kLiftCullSharedBda bit) form it once.
 template <bool WAVE_CULL = false>
-__device__ __forceinline__ LiftTap lift_project(const LiftParams& P, const float* __restrict__ m,
-                                                float x, float y, float z) {
-  Vec4 p{x, y, z, 1.0f};
-  p = matvec(m, p);        // inv(bda)
+__device__ __forceinline__ LiftTap lift_project_from(const LiftParams& P, const float* __restrict__ m, Vec4 p) {
   p = matvec(m + 16, p);   // intrin @ inv(sensor2ego)
   if (WAVE_CULL) {
     const bool e3 = m[40] == 0.0f && m[41] == 0.0f && m[42] == 1.0f && m[43] == 0.0f;   // uniform
@@ -83,6 +83,12 @@ __device__ __forceinline__ LiftTap lift_project(const LiftParams& P, const float
   t.wz1 = fz - flz; t.wz0 = (flz + 1.0f) - fz;
   t.fx = fx; t.fy = fy; t.fz = fz;
   return t;
+}
+
+template <bool WAVE_CULL = false>
+__device__ __forceinline__ LiftTap lift_project(const LiftParams& P, const float* __restrict__ m,
+                                                float x, float y, float z) {
+  return lift_project_from<WAVE_CULL>(P, m, matvec(m, Vec4{x, y, z, 1.0f}));   // inv(bda) first
 }
 
 

@@ -234,6 +234,22 @@ class HotPath:
                                                _ptr(iz0), _stream()), "vamp_lift_indices")
         return valid, ix0, iy0, iz0
 
+    def lift_cull_words(self, lift_mats, use_depth=True):
+        """The forward's camera cull words [B, Z, grid_y, grid_x] (uint32 as int64) and the patch shape
+        (px, py) in voxels: bit n clear = no voxel of the patch can be valid in camera n (diagnostic)."""
+        c = self.cfg
+        B, N = lift_mats.shape[:2]
+        d = self.lift_desc(B, N, 4, _capi.VAMP_F32, use_depth)
+        patch, grid = (C.c_int32 * 2)(), (C.c_int32 * 2)()
+        mats = _chk(lift_mats.float(), (B, N, 3, 4, 4), "lift_mats")
+        _capi.check(self.lib.vamp_lift_cull_words(C.byref(d), None, None, None, None, None, patch, grid, None),
+                    "vamp_lift_cull_words")
+        words = torch.empty(B, c.vZ, grid[1], grid[0], dtype=torch.int32, device=self.device)
+        _capi.check(self.lib.vamp_lift_cull_words(C.byref(d), _ptr(mats), _ptr(self.xs), _ptr(self.ys),
+                                                  _ptr(self.zs), _ptr(words), patch, grid, _stream()),
+                    "vamp_lift_cull_words")
+        return words.long() & 0xffffffff, (patch[0], patch[1])
+
     # --------------------------------------------------------------- render
     def frustum_geometry(self, render_mats):
         c = self.cfg
