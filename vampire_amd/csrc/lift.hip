@@ -357,9 +357,36 @@ __device__ __forceinline__ void depth_taps(const LiftParams& P, const T* __restr
     dep[0] = dep[1] = dep[2] = dep[3] = w;
     return;
   }
-  // branch-free (clamped address, zero weight for taps outside the volume): the eight loads
-  // are independent and issue together
+  // branch-free (clamped address, zero weight for taps outside the volume): the loads are
+  // independent and issue together
   const long plane = (long) P.fH * P.fW;
+  if constexpr (sizeof(T) == 4) {
+    // fp32 planes: the two x taps of a row are neighbours in memory -- ONE 8-byte load (dword aligned, which
+    // is all a multi-dword global load needs) instead of two: four line look-ups per pair instead of eight
+    if (P.fW >= 2) {
+      struct __attribute__((packed, aligned(4))) Pair { float a, b; };
+      const int xb = min(max(t.ix0, 0), P.fW - 2);                 // the pair (xb, xb + 1) holds every in-range tap
+      const bool x0in = t.ix0 >= 0 && t.ix0 < P.fW, x1in = t.ix0 + 1 >= 0 && t.ix0 + 1 < P.fW;
+      const bool x0hi = t.ix0 != xb, x1lo = t.ix0 + 1 == xb;      // which half each tap is
+#pragma unroll
+      for (int kz = 0; kz < 2; ++kz) {
+        const int iz = t.iz0 + kz;
+        const bool zin = iz >= 0 && iz < P.D;
+        const float wz = zin ? (kz ? t.wz1 : t.wz0) : 0.f;
+        const int izc = min(max(iz, 0), P.D - 1);
+#pragma unroll
+        for (int ky = 0; ky < 2; ++ky) {
+          const int iy = t.iy0 + ky;
+          const bool yin = iy >= 0 && iy < P.fH;
+          const Pair pr = *reinterpret_cast<const Pair*>(reinterpret_cast<const float*>(dptr) + izc * plane +
+                                                        (long) min(max(iy, 0), P.fH - 1) * P.fW + xb);
+          dep[ky * 2 + 0] += ((yin && x0in) ? wz : 0.f) * (x0hi ? pr.b : pr.a);
+          dep[ky * 2 + 1] += ((yin && x1in) ? wz : 0.f) * (x1lo ? pr.a : pr.b);
+        }
+      }
+      return;
+    }
+  }
   const bool x0in = t.ix0 >= 0 && t.ix0 < P.fW, x1in = t.ix0 + 1 >= 0 && t.ix0 + 1 < P.fW;
   const int x0c = min(max(t.ix0, 0), P.fW - 1), x1c = min(max(t.ix0 + 1, 0), P.fW - 1);
 #pragma unroll
