@@ -183,11 +183,22 @@ def forward_pair_us(model, batch, iters=100, warm=20):
 
 
 def forward_pair_graph_us(model, batch, iters=100, warm=20):
-    """The same forward pair replayed from a HIP graph: inside the graph the camera and the BEV
-    branch of the renderer -- which share only their inputs -- run side by side on two streams
-    (HotPath.impl["fwd_overlap"]; the lift is NOT overlapped with the renderer: in the model the 3-D
-    UNet sits between them), and the launches cost no host time.  One HIP-event pair around each
-    replay, median.  Returns None when the capture fails or does not reproduce the eager outputs."""
+    """The same forward pair replayed from a HIP graph, where the launches cost no host time (the lift is NOT
+    overlapped with the renderer: in the model the 3-D UNet sits between them).  Two captures -- the renderer's
+    camera and BEV branch, which share only their inputs, on ONE stream and side by side on two
+    (HotPath.impl["fwd_overlap"]) -- and the faster one is reported: since round 5 that is the one-stream graph
+    (a replayed fork costs the camera kernel a 6 - 13 us later start and, beside the BEV kernel, 15 us of its own
+    run time: 136 against 124 us).  One HIP-event pair around each replay, median.
+    Returns (median, p10, p90, "one stream" | "two streams"), or None when no capture reproduces the eager outputs."""
+    best = None
+    for overlap in (False, True):
+        r = _forward_pair_graph_us(model, batch, overlap, iters, warm)
+        if r is not None and (best is None or r[0] < best[0]):
+            best = r + ("two streams" if overlap else "one stream",)
+    return best
+
+
+def _forward_pair_graph_us(model, batch, overlap, iters, warm):
     hp = model.hp
     keep = hp.impl["fwd_overlap"]
     try:
@@ -196,7 +207,7 @@ def forward_pair_graph_us(model, batch, iters=100, warm=20):
                 return model(batch.depth, batch.feat, batch.vols, batch.lift_mats, batch.render_mats)
             vox0, outs0 = fwd()
             ref = [vox0.clone()] + [o.clone() for o in outs0]
-            hp.impl["fwd_overlap"] = True
+            hp.impl["fwd_overlap"] = overlap
             cur = torch.cuda.current_stream()
             side = torch.cuda.Stream()
             side.wait_stream(cur)
@@ -745,8 +756,8 @@ def main():
                              "frac": fwd_gbs / HBM_PEAK_GBS, "fused_fwd_us": fwd_us,
                              "p10_us": fwd_graph[1] if fwd_graph else fwd_p10, "p90_us": fwd_graph[2] if fwd_graph else fwd_p90,
                              "iters": 100, "warmup": 20,
-                             "timing": ("one HIP-event pair around each replay of the captured forward (lift, then camera "
-                                        "and BEV branch of the renderer side by side on two streams), median"
+                             "timing": (f"one HIP-event pair around each replay of the captured forward (lift, then the renderer's "
+                                        f"camera and BEV branch on {fwd_graph[3]}: the faster of the two captures), median"
                                         if fwd_graph else "one HIP-event pair around lift + render per iteration, median"),
                              "eager_one_stream_us": fwd_med, "eager_p10_us": fwd_p10, "eager_p90_us": fwd_p90,
                              "eager_frac": fwd_bytes / (fwd_med * 1e-6) / 1e9 / HBM_PEAK_GBS,

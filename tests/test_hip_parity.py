@@ -767,9 +767,10 @@ def test_edge_cases(tiny_common, dev):
     for v in vols:
         assert float(v.grad.abs().max()) == 0.0
     assert float(beta.grad.abs()) == 0.0
-    # --- forward is deterministic bit for bit (calls of the same kind: a forward-only call runs the
-    # one-kernel camera branch, a call that keeps state for a backward the packed-copy march; the
-    # two agree to rounding)
+    # --- forward is deterministic bit for bit (calls of the same kind, and on the same camera forward: left
+    # at "auto" the choice may move between calls with what the rays did -- the two forwards agree to rounding)
+    hp.impl["cam_direct"] = True
+    outs = hp.render(*vols, beta, render_mats=rm)
     outs2 = hp.render(*[v.detach() for v in vols], beta.detach(), render_mats=rm)
     outs3 = hp.render(*[v.detach() for v in vols], beta.detach(), render_mats=rm)
     for x, y in zip(outs2, outs3):
@@ -906,7 +907,7 @@ def test_bev_backward_round4_kernels_edge_shapes(dev, accumulate):
     8 waves of bev_gather_comp_kernel: a second round of groups; 29 composited channels: the any-channel-count
     path of bev_qscan_saved_kernel), 13 lattice heights (two chunks of taps; 13 waves in the q + scan), a 40 x 40
     grid whose last block of 64 columns is ragged -- against the float-atomic splat (v1), with the BEV branch
-    overwriting (default) and adding on top of the camera branch's gradient (VAMP_BEV_FIRST=0, one stream)."""
+    overwriting (default) and adding on top of the camera branch's gradient (one stream behind the v1 camera splat)."""
     cfg = dataclasses.replace(CFG_B, x_bound_seg=(-8.0, 8.0, 0.4), y_bound_seg=(-8.0, 8.0, 0.4),
                               x_bound_det=(-8.0, 8.0, 0.4), y_bound_det=(-8.0, 8.0, 0.4),
                               z_bound_det=(-1.0, 3.0, 0.3), num_classes=26, final_dim=(64, 176))
@@ -914,7 +915,7 @@ def test_bev_backward_round4_kernels_edge_shapes(dev, accumulate):
     hp = hot(cfg, dev)
     if accumulate:
         hp.impl["overlap"] = False
-        hp.impl["bev_first"] = False
+        hp.impl["cam_bwd"] = "v1"          # the camera splat first, the BEV kernels add on top (their accumulate mode)
     s2e, K, ida = synthetic.camera_rig(cfg, 2, jitter=1.0, seed=5)
     rm = render_matrices(s2e, K, ida, synthetic.bda_matrix(2)).to(dev)
     beta = torch.tensor(0.1, device=dev, requires_grad=True)
@@ -1183,6 +1184,14 @@ def test_bf16_inputs_equal_fp32_path_on_rounded_values(tiny_common, dev, cfg, ba
         q.backward(torch.randn(q.shape, device=dev, generator=gen))
         return (outs, vox, q), [v.grad for v in vols] + [d.grad, f.grad, sem.grad], (b.grad if b is not None else None)
 
+    # (bit-for-bit comparisons of two calls: the camera forward is pinned -- left at "auto" it may move
+    # between the calls with what the rays did; the tiny cases take both forwards in turn)
+    for direct in ((True, False) if cfg.vX == CFG_TINY.vX else (True,)):
+        hp.impl["cam_direct"] = direct
+        _bf16_vs_fp32(run)
+
+
+def _bf16_vs_fp32(run):
     (o16, v16, q16), g16, b16 = run(torch.bfloat16)
     (o32, v32, q32), g32, b32 = run(torch.float32)
     for n, a, b in zip(NAMES, o16, o32):
@@ -1485,6 +1494,45 @@ def test_ert_on_equals_off_full_size(dev, regime, direct):
         close(a, b, atol=1e-12, rtol=1e-5, scale="max", what=f"{regime} ERT on/off grad_{nm}")
     if on[2] is not None:
         assert abs(float(on[2]) - float(off[2])) <= 1e-5 * abs(float(off[2])) + 1e-9, (float(on[2]), float(off[2]))
+
+
+@pytest.mark.parametrize("regime", ["sdf", "naive", "init", "empty"])
+def test_camera_forward_is_chosen_from_the_data(dev, regime):
+    """cam_direct = "auto" (the default): the camera forward of a call follows what the rays of EARLIER calls did
+    (HotPath._camera_forward_choice: the termination table's statistic, read a step late from pinned memory).
+    Where rays saturate (sdf workload, the reference's initial regime) it stays with the one kernel + early
+    termination; where they do not (sigmoid density, empty scene) it goes to copy + planned march within a few
+    calls -- and whichever path a call takes, outputs and gradients are those of the termination-off path
+    (bv2:191-194: density_mode='naive' is a first-class mode of the reference)."""
+    with open(os.path.join(GOLDEN, "full_checksums.json")) as f:
+        rm = torch.tensor(json.load(f)["B"]["render_mats"], dtype=torch.float32, device=dev)
+    cfg, vols = _regime_inputs(CFG_B, regime, dev)
+    # (the two forwards agree to the rounding of their sample coordinates, 3e-5 of a map's scale; a call is held
+    # to the termination-off result of the forward it took, at the tolerance of test_ert_on_equals_off_full_size)
+    refs = {"planned": _render_fwd_bwd(cfg, vols, rm, dev, False, 4545, cam_direct=False),
+            "direct": _render_fwd_bwd(cfg, vols, rm, dev, False, 4545, cam_direct=True)}
+    hp = hot(cfg, dev)
+    assert hp.impl["cam_direct"] == "auto" and hp.impl["ert"]
+    hp._PROBE_EVERY = 1
+    seen = []
+    for it in range(4):
+        for v in vols:
+            v.grad = None
+        beta = torch.tensor(0.1, device=dev, requires_grad=(cfg.density_mode == "sdf"))
+        outs = hp.render(*vols, beta if cfg.density_mode == "sdf" else None, render_mats=rm)
+        torch.autograd.backward(outs, _upstream([o.shape for o in outs], 4545, dev))
+        torch.cuda.synchronize()          # (the test only: makes the probe of this call visible to the next)
+        seen.append(hp._cam_sel["mode"])                    # (the mode this call ran in: it is decided as a call starts)
+        off = refs[seen[-1]]
+        for nm, a, b in zip(NAMES, outs, off[0]):
+            close(a.detach(), b, atol=(3 * 1.2e-7 * cfg.d_bound[1] if nm == "depth_preds" else 1e-7), rtol=1e-6, scale="max",
+                  what=f"{regime} call {it} ({seen}) {nm}")
+        for nm, v, b in zip(("density_feature", "semantic_logits", "base", "rgb"), vols, off[1]):
+            close(v.grad, b, atol=1e-12, rtol=1e-5, scale="max", what=f"{regime} call {it} ({seen}) grad_{nm}")
+    r = float(hp._cam_sel["host"][0])
+    want = "direct" if regime in ("sdf", "init") else "planned"
+    assert seen[0] == "direct" and seen[-1] == want, (regime, seen, r)
+    assert (r < 0.4) if want == "direct" else (r > 0.5), (regime, r)
 
 
 @pytest.mark.parametrize("ert", [True, False], ids=["ert", "no-ert"])

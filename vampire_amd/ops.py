@@ -81,6 +81,10 @@ class HotPath:
         ozs_cpu = G.axis_centres(cfg.z_bound_det)
         self.ozs_host = (C.c_float * ozs_cpu.numel())(*ozs_cpu.tolist())
         self._ws = {}
+        # state of the camera-forward choice ("auto"): mode, call counter, the statistic on the device / in pinned memory
+        self._cam_sel = {"mode": "direct", "calls": 0,
+                         "dev": torch.full((1,), -1.0, dtype=f32, device=dev),
+                         "host": torch.full((1,), -1.0, dtype=f32).pin_memory() if dev.type == "cuda" else torch.full((1,), -1.0)}
         self._dirty = set()         # workspaces whose cell counters a call in flight (or one that raised) may have left non-zero
         # Implementation selectors (host-side state of this object; the library itself keeps none):
         # "cell" = the default cell-list gathers, "v1" = the float-atomic splats kept as independent
@@ -94,33 +98,20 @@ class HotPath:
                      # BEV branch on a second stream in training steps (forward-only calls stay on one
                      # stream): eager step 0.679 vs 0.699 ms, replayed from a HIP graph 0.629 vs 0.695 ms
                      "overlap": os.environ.get("VAMP_OVERLAP", "1") == "1",
-                     # single stream: BEV branch first (overwriting), camera gather adds -- or the
-                     # camera branch first and the BEV gather adds
-                     "bev_first": os.environ.get("VAMP_BEV_FIRST", "1") == "1",
-                     # stream schedule of the render forward in a training step: "default" = BEV branch
-                     # and prepare pass on the side stream; "split" = table, copy and prepare pass on the
-                     # side stream, BEV branch and march on the caller's
-                     "sched": os.environ.get("VAMP_SCHED", "split"),
                      # two-stream steps: the heavy-voxel drain of the camera backward as a kernel of its own on the side stream
                      # beside the gather (replayed step 0.504 vs 0.512 ms); one-stream calls drain the list inside the
                      # gather launch (its first workgroups: 66 us against 37 + 38)
                      "heavy_side": os.environ.get("VAMP_HEAVY_SIDE", "1") == "1",
-                     # the slot table and heavy list of the camera backward in front of its ray pass
-                     # instead of at the end of the forward's prepare pass: measured slower (graph step
-                     # 0.588 vs 0.570 ms: the backward's chain is the tighter one), so off
-                     "slots_late": os.environ.get("VAMP_SLOTS_LATE", "0") == "1",
-                     # the lift backward as two halves of the images on two streams: measured slower
-                     # (graph step 0.613 vs 0.582 ms: each half's fill still walks every voxel), so off
-                     "lift_halves": os.environ.get("VAMP_LIFT_HALVES", "0") == "1",
                      # the BEV forward keeps its samples for the backward (+35 MB per sample at cfg-B)
                      "bev_save": os.environ.get("VAMP_BEV_SAVE", "1") == "1",
                      # early ray termination in the camera branch (include/vampire_hip.h)
                      "ert": os.environ.get("VAMP_ERT", "1") != "0",
                      # the camera branch as ONE kernel on the channel-first volumes (no packed copy, no
-                     # separate termination pass; render_cam_direct.hip).  "auto" (default): with early termination;
-                     # without it the channel-last copy + planned march wins (cfg-B forward: 26 + 126 us against 185 --
-                     # 64 far-field rays of a wave touch 64 lines per pair load of a channel-first volume, and
-                     # nothing ends the rays early), True / False force one
+                     # separate termination pass; render_cam_direct.hip), or the channel-last copy + planned march.
+                     # The one kernel wins where rays saturate early (48 against 19 + 26 + ... us) and loses where they
+                     # do not (cfg-B: 185 - 222 us against 26 + 126: 64 far-field rays of a wave touch 64 lines per pair
+                     # load of a channel-first volume).  "auto" (default): chosen per call from the termination tables
+                     # of the last calls (_camera_forward_choice); True / False force one
                      "cam_direct": {"1": True, "0": False}.get(os.environ.get("VAMP_CAM_DIRECT", "auto"), "auto"),
                      # the BEV forward as one kernel (render_bev_fused.hip); "0" = the two-kernel first
                      # implementation, the cross-check of the tests
@@ -193,6 +184,59 @@ class HotPath:
         clean = "render" not in self._dirty
         self._dirty.add("render")
         return _capi.VAMP_CAMPREP_COUNTERS_CLEAN if clean else 0
+
+    # ------------------------------------------------- which camera forward (bv2:191-194: both density modes are first class)
+    # Two candidates when early termination is allowed: the ONE KERNEL with termination, whose cost follows the
+    # samples the rays keep, and the channel-last COPY + PLANNED MARCH of every inside sample without it (the
+    # termination pre-pass of the planned march never pays: where rays saturate the one kernel is faster, where
+    # they do not the pre-pass marches every sample itself -- cfg-B, sigmoid density: forward 291 us with it, 230
+    # without, 257 for the one kernel; training step 899 / 878 / 979).
+    # The statistic: mean over the 8 x 8 ray tiles of (largest number of leading samples a ray of the tile keeps)
+    # / (samples per ray) -- what the one kernel's cost follows -- from the termination table in the workspace
+    # (0.09 on the synthetic sdf workload, 0.69 under the sigmoid density; the two forwards cost the same near
+    # 0.5 - 0.6).  It is formed on the device on some eager calls, copied to pinned host memory without a sync,
+    # and read by LATER calls: the choice lags the data by a step or two and costs nothing.
+    _PROBE_EVERY = 16            # one-kernel mode: the table is the forward's by-product; the probe is two small reductions
+    _PROBE_EVERY_PLANNED = 64    # planned mode leaves no table: the density-only pre-pass (20 - 60 us) is run for the probe
+    _TO_PLANNED, _TO_DIRECT = 0.5, 0.4                           # hysteresis
+
+    def _camera_forward_choice(self, can_direct, no_geom):
+        """(ert, direct) of this call."""
+        ert_allowed = no_geom and self.impl["ert"]
+        sel = self.impl["cam_direct"]
+        if sel != "auto" or not ert_allowed or not can_direct:
+            want = ert_allowed if sel == "auto" else bool(sel)
+            return ert_allowed, bool(can_direct and want)
+        st = self._cam_sel
+        r = float(st["host"][0])                       # pinned memory: whatever the last finished probe left
+        if r >= 0.0:
+            if st["mode"] == "direct" and r > self._TO_PLANNED:
+                st["mode"] = "planned"
+            elif st["mode"] == "planned" and r < self._TO_DIRECT:
+                st["mode"] = "direct"
+        return (True, True) if st["mode"] == "direct" else (False, False)
+
+    def _camera_forward_probe(self, d, ws, tensors, ert, no_geom, stream):
+        """Some eager calls of the auto mode: the statistic of this call's termination table."""
+        if self.impl["cam_direct"] != "auto" or not (no_geom and self.impl["ert"]):
+            return
+        st = self._cam_sel
+        st["calls"] += 1
+        every = self._PROBE_EVERY if ert else max(self._PROBE_EVERY, self._PROBE_EVERY_PLANNED if self._PROBE_EVERY > 1 else 1)
+        if (st["calls"] - 1) % every or torch.cuda.is_current_stream_capturing():
+            return
+        c = self.cfg
+        if not ert:
+            mats, beta, dens = tensors
+            _capi.check(self.lib.vamp_render_camera_terminate(
+                C.byref(d), _ptr(mats), _ptr(self.us), _ptr(self.vs), _ptr(self.ds), _ptr(beta), _ptr(dens), _ptr(ws),
+                ws.numel(), _stream(stream)), "vamp_render_camera_terminate")
+        off = self.lib.vamp_render_term_offset(C.byref(d))
+        n = d.B * d.N * c.fH * c.fW
+        term = ws[off:off + 4 * n].view(torch.int32).view(d.B * d.N, 1, c.fH, c.fW)
+        tile_max = torch.nn.functional.max_pool2d(term.float(), 8, ceil_mode=True)
+        st["dev"].copy_((tile_max.mean() / float(c.D - 1)).reshape(1))
+        st["host"].copy_(st["dev"], non_blocking=True)
 
     def _workspace(self, key, nbytes):
         t = self._ws.get(key)
@@ -479,17 +523,7 @@ class _LiftFn(torch.autograd.Function):
                                                      _ptr(hits), _ptr(gdepth), _ptr(gfeat), _ptr(ws),
                                                      ws.numel(), flags, _stream(stream)), "vamp_lift_backward_ex")
 
-        side = hp._side_stream()
-        if side is not None and hp.impl["lift_bwd"] == "cell" and (valid & 1) and hp.impl["lift_halves"]:
-            # The two halves of the images (cameras 0-2 / 3-5 at batch 1) touch disjoint records and
-            # outputs: fill + gather of one half on the side stream beside the other half's.
-            cur = torch.cuda.current_stream()
-            side.wait_stream(cur)
-            call(valid | _capi.VAMP_LIFTBWD_HALF_HI, side)
-            call(valid | _capi.VAMP_LIFTBWD_HALF_LO, cur)
-            cur.wait_stream(side)
-        else:
-            call(valid, None)
+        call(valid, None)
         if hp.impl["lift_bwd"] == "cell":
             hp._dirty.discard("lift")       # the gather has re-zeroed the fill's cursors
         if ctx.logits and hp.impl["lift_bwd"] == "v1":
@@ -533,6 +567,52 @@ class _LiftDenseFn(torch.autograd.Function):
         return None, gff, None
 
 
+def render_forward_plan(train, two, prep_ok, direct, ert):
+    """The C calls of one render forward in issue order: [(op, stream, flags, waits, records)].
+
+    op: "term" (termination table), "pack" (channel-last copy of the volumes), "cam" (camera branch: the one
+    kernel when `direct`, else the planned march), "prep" (the backward's geometry-only prepare pass), "bev".
+    stream: "cur" | "side"; flags: beyond the op's base flags; waits / records: names of events.
+    `two`: a side stream is available; `prep_ok`: the cell-list backward will follow on matrices (no explicit
+    geometry, not the v1 splat); `direct` / `ert`: one-kernel camera forward / early ray termination.
+    Every schedule holds exactly one "bev" and one "cam"; the rest is what the measured timelines of
+    DESIGN.md 7g-7h settled on (one table instead of four hand-unrolled branches)."""
+    F = _capi
+    if train and two and prep_ok and direct:
+        # the camera kernel (which leaves the termination table), then the BEV forward; beside them, once the
+        # table is there, the prepare pass
+        return [("cam", "cur", F.VAMP_CAMFWD_DIRECT, (), ("table",)),
+                ("prep", "side", F.VAMP_CAMPREP_TERM_VALID, ("table",), ()),
+                ("bev", "cur", 0, (), ())]
+    if train and two and prep_ok and ert:
+        # planned march: the side stream takes what only the camera branch needs later -- table, copy, prepare
+        # pass -- this stream the BEV forward and, once table and copy are there, the march
+        return [("term", "side", 0, (), ()),
+                ("pack", "side", F.VAMP_CAMFWD_TERM_VALID | F.VAMP_CAMFWD_PACK_ONLY, (), ("packed",)),
+                ("prep", "side", F.VAMP_CAMPREP_TERM_VALID, (), ()),
+                ("bev", "cur", 0, (), ()),
+                ("cam", "cur", F.VAMP_CAMFWD_TERM_VALID | F.VAMP_CAMFWD_PACKED_VALID, ("packed",), ())]
+    if direct and not train:
+        # forward only (BEV issued first: second, it starts behind the camera kernel and finds the CUs taken)
+        return [("bev", "side" if two else "cur", 0, (), ()), ("cam", "cur", F.VAMP_CAMFWD_DIRECT, (), ())]
+    steps, camf = [], (F.VAMP_CAMFWD_DIRECT if direct else 0)
+    if ert and not direct:
+        steps.append(("term", "cur", 0, (), ("table",)))
+        camf |= F.VAMP_CAMFWD_TERM_VALID
+    prep = train and two and prep_ok and not direct
+    if prep:
+        steps.append(("prep", "side", F.VAMP_CAMPREP_TERM_VALID if ert else 0, ("table",) if ert else (), ()))
+    # without early termination the march is the long kernel of the step, and a BEV forward beside it costs it
+    # more than it hides (207 us beside, 150 alone): the BEV forward then FOLLOWS the march
+    bev_after = prep and not ert
+    if not bev_after:
+        steps.append(("bev", "side" if two else "cur", 0, (), ()))
+    steps.append(("cam", "cur", camf, (), ()))
+    if bev_after:
+        steps.append(("bev", "cur", 0, (), ()))
+    return steps
+
+
 class _RenderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, hp: HotPath, dens, sem, base, rgb, beta, geom, mats, grad_mode=True):
@@ -547,8 +627,7 @@ class _RenderFn(torch.autograd.Function):
         dens, sem, base, rgb = (_accept(t) for t in (dens, sem, base, rgb))
         if len({t.dtype for t in (dens, sem, base, rgb)}) > 1:
             dens, sem, base, rgb = (t.float() for t in (dens, sem, base, rgb))
-        code = _dtype_code(dens)
-        d = hp.render_desc(B, N, code, C_)
+        d = hp.render_desc(B, N, _dtype_code(dens), C_)
         vshape = (c.vZ, c.vY, c.vX)
         dens = _chk(dens, (B, 1) + vshape, "density_feature")
         sem = _chk(sem, (B, c.num_classes) + vshape, "semantic_logits")
@@ -562,195 +641,82 @@ class _RenderFn(torch.autograd.Function):
         beta = beta.reshape(1).float().contiguous()
         dev, f32 = dens.device, torch.float32
         K = c.num_classes
+        CO = C_ + (K if c.cat_seg else 0)
         rgb_p = torch.empty(B, N, 3, c.fH, c.fW, dtype=f32, device=dev)
         seg_p = torch.empty(B, N, K, c.fH, c.fW, dtype=f32, device=dev)
         dep_p = torch.empty(B, N, 1, c.fH, c.fW, dtype=f32, device=dev)
-        nbytes = hp.lib.vamp_render_workspace_bytes(C.byref(d))
-        # training: the march also stores every inside sample's gathered row behind the base region,
-        # and the backward's per-ray pass reads it back instead of repeating the 8-tap gather
-        # (round 4: tile-major rows, 256 contiguous bytes per tile, depth index and channel, written by the
-        # one-kernel forward -- the per-ray pass was bound by repeating the forward's gathers; round 2's
-        # per-sample 96-byte rows had measured neutral)
-        save = bool(train and geom is None and hp.impl["save_rows"] and hp.impl["cam_bwd"] != "v1" and (c.D - 1) <= 128)
-        if save:
-            nbytes += hp.lib.vamp_render_samples_bytes(C.byref(d))
-        ws = hp._workspace("render", nbytes)
-        CO = C_ + (K if c.cat_seg else 0)
         bev_rgb = torch.empty(B, 3, c.oY, c.oX, dtype=f32, device=dev)
         bev_seg = torch.empty(B, K, c.oY, c.oX, dtype=f32, device=dev)
         bev_h = torch.empty(B, 1, c.oY, c.oX, dtype=f32, device=dev)
         vdens = torch.empty(B, 1, c.oZ, c.oY, c.oX, dtype=f32, device=dev)
         vout = torch.empty(B, CO, c.oZ, c.oY, c.oX, dtype=f32, device=dev)
-        # the two branches share only their inputs: in a training step the BEV branch (and the
-        # geometry-only prepare pass of the backward) runs on the side stream, the camera branch on
-        # this one.  Forward-only calls stay on one stream: the fork / join costs more than the short
-        # BEV forward hides (296 vs 210 us for the eager forward pair).
+        nbytes = hp.lib.vamp_render_workspace_bytes(C.byref(d))
+        # training: the camera forward also keeps every inside sample's gathered values (tile-major rows, 256
+        # contiguous bytes per tile, depth index and channel), and the backward's per-ray pass reads them back
+        # instead of repeating the 8-tap gathers
+        save = bool(train and geom is None and hp.impl["save_rows"] and hp.impl["cam_bwd"] != "v1" and (c.D - 1) <= 128)
+        if save:
+            nbytes += hp.lib.vamp_render_samples_bytes(C.byref(d))
+        ws = hp._workspace("render", nbytes)
+        # which camera forward: the one kernel with early termination, or copy + planned march (with the
+        # termination pre-pass or without) -- from the switches, or ("auto") from what the rays did lately
+        ert, direct = hp._camera_forward_choice(geom is None and (c.D - 1) <= 128, geom is None)
+        # the two branches share only their inputs: in a training step they (and the prepare pass) use two
+        # streams; forward-only calls stay on one unless the caller captures them into a graph (fwd_overlap)
         cur = torch.cuda.current_stream()
         side = hp._side_stream() if (train or hp.impl["fwd_overlap"]) else None
-        ctx.cells = False
-        ert = geom is None and hp.impl["ert"]
-        want_direct = ert if hp.impl["cam_direct"] == "auto" else bool(hp.impl["cam_direct"])
-        direct = geom is None and want_direct and (c.D - 1) <= 128
+        prep_ok = geom is None and hp.impl["prepare"] and hp.impl["cam_bwd"] != "v1"
+        plan = render_forward_plan(train, side is not None, prep_ok, direct, ert)
         # (hp.ozs is the reference's lattice of det-grid heights: the one-kernel BEV forward may size its
         # plane slabs from the spacing)
         bev_flags = _capi.VAMP_BEVFWD_HEIGHTS_LATTICE if hp.impl["bev_fused"] else _capi.VAMP_BEVFWD_TWO_KERNELS
-        fwd_flags = 0 if ert else _capi.VAMP_CAMFWD_NO_ERT
-        split = (train and side is not None and (ert or direct) and hp.impl["sched"] == "split" and geom is None
-                 and hp.impl["prepare"] and hp.impl["cam_bwd"] != "v1")
-        if split and direct:
-            # Training step, one-kernel camera forward: this stream runs the camera kernel (which leaves
-            # the per-ray termination table in the workspace) and then the BEV forward; the side stream,
-            # once the table is there, the backward's geometry-only prepare pass.  No channel-last copy:
-            # the backward's per-ray pass gathers from the volumes as they are, like the forward.
+        bev_save = train and hp.impl["bev_save"] and hp.impl["bev_bwd"] != "v1"
+        ws_bev = hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d))) if bev_save else None
+        cam_base = 0 if ert else _capi.VAMP_CAMFWD_NO_ERT
+        streams, events = {"cur": cur, "side": side}, {}
+        ctx.cells, ctx.ert, ctx.bev_key = False, ert, None
+        if side is not None:
             side.wait_stream(cur)
-            ctx.ert = ert
-            _capi.check(hp.lib.vamp_render_camera_forward_ex(
-                C.byref(d), None, _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
-                _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
-                _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(),
-                fwd_flags | _capi.VAMP_CAMFWD_DIRECT | (_capi.VAMP_CAMFWD_SAVE_SAMPLES if save else 0), _stream(cur)),
-                "vamp_render_camera_forward_ex")
-            term_done = torch.cuda.Event()
-            term_done.record(cur)
-            side.wait_event(term_done)
-            late = hp.impl["slots_late"] and hp.impl["heavy_side"]
-            _capi.check(hp.lib.vamp_render_camera_prepare_ex(
-                C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(),
-                _capi.VAMP_CAMPREP_TERM_VALID | (_capi.VAMP_CAMPREP_RANK_ONLY if late else 0) | hp._cam_clean_flag(),
-                _stream(side)), "vamp_render_camera_prepare_ex")
-            hp._dirty.discard("render")
-            ctx.cells = 2 if late else True
-            bev_save = train and hp.impl["bev_save"] and hp.impl["bev_bwd"] != "v1"
-            ws_bev = (hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d))) if bev_save else None)
-            _capi.check(hp.lib.vamp_render_bev_forward_ex(
-                C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
-                _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
-                _ptr(vdens), _ptr(vout), _ptr(ws_bev), ws_bev.numel() if bev_save else 0,
-                (_capi.VAMP_BEVFWD_SAVE if bev_save else 0) | bev_flags, _stream(cur)), "vamp_render_bev_forward_ex")
-            hp._bev_gen = getattr(hp, "_bev_gen", 0) + 1
-            ctx.bev_key = (hp._bev_gen, ws_bev.data_ptr()) if bev_save else None
-        elif split and ert:
-            # Schedule "split": the side stream takes what only the camera branch needs later --
-            # termination table, channel-last copy, then the backward's prepare pass -- and this
-            # stream the BEV branch, then the march once table and copy are there.  The critical
-            # chain of the default schedule (table -> prepare -> BEV forward on the side stream,
-            # 158 us) becomes max(BEV + march, table + copy + prepare) = 129 us.
-            side.wait_stream(cur)
-            _capi.check(hp.lib.vamp_render_camera_terminate(
-                C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(beta), _ptr(dens), _ptr(ws),
-                ws.numel(), _stream(side)), "vamp_render_camera_terminate")
-            fwd_flags |= _capi.VAMP_CAMFWD_TERM_VALID
-            ctx.ert = ert
-            _capi.check(hp.lib.vamp_render_camera_forward_ex(
-                C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
-                _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
-                _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(),
-                fwd_flags | _capi.VAMP_CAMFWD_PACK_ONLY, _stream(side)), "vamp_render_camera_forward_ex")
-            packed_done = torch.cuda.Event()
-            packed_done.record(side)
-            # (only the rank + scan half of the prepare pass: the slot table and the heavy list need
-            # nothing but the scan and are built in front of the backward's ray pass, which has the
-            # slack; here they would lengthen the side stream's chain, the longer one of the forward)
-            late = hp.impl["slots_late"] and hp.impl["heavy_side"]
-            _capi.check(hp.lib.vamp_render_camera_prepare_ex(
-                C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(),
-                _capi.VAMP_CAMPREP_TERM_VALID | (_capi.VAMP_CAMPREP_RANK_ONLY if late else 0) | hp._cam_clean_flag(),
-                _stream(side)), "vamp_render_camera_prepare_ex")
-            hp._dirty.discard("render")
-            ctx.cells = 2 if late else True
-            bev_save = train and hp.impl["bev_save"] and hp.impl["bev_bwd"] != "v1"
-            ws_bev = (hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d))) if bev_save else None)
-            _capi.check(hp.lib.vamp_render_bev_forward_ex(
-                C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
-                _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
-                _ptr(vdens), _ptr(vout), _ptr(ws_bev), ws_bev.numel() if bev_save else 0,
-                (_capi.VAMP_BEVFWD_SAVE if bev_save else 0) | bev_flags, _stream(cur)), "vamp_render_bev_forward_ex")
-            hp._bev_gen = getattr(hp, "_bev_gen", 0) + 1
-            ctx.bev_key = (hp._bev_gen, ws_bev.data_ptr()) if bev_save else None
-            cur.wait_event(packed_done)
-            _capi.check(hp.lib.vamp_render_camera_forward_ex(
-                C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
-                _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
-                _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(),
-                fwd_flags | _capi.VAMP_CAMFWD_PACKED_VALID | (_capi.VAMP_CAMFWD_SAVE_SAMPLES if save else 0),
-                _stream(cur)), "vamp_render_camera_forward_ex")
-        elif direct and not train:
-            # forward only: the camera branch is one kernel on the volumes as they are; with
-            # fwd_overlap the BEV branch runs beside it on the side stream
-            ctx.ert = ert
-            bstream = cur
-            if side is not None:
-                side.wait_stream(cur)                 # fork: the BEV branch waits for what precedes the renderer only
-                bstream = side
-            # (BEV first: issued second it starts ~5 us behind the camera kernel, finds the CUs taken and
-            # takes twice as long -- 129 vs 123 us for the replayed pair at cfg-B)
-            _capi.check(hp.lib.vamp_render_bev_forward_ex(
-                C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
-                _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
-                _ptr(vdens), _ptr(vout), None, 0, bev_flags, _stream(bstream)), "vamp_render_bev_forward_ex")
-            ctx.bev_key = None
-            _capi.check(hp.lib.vamp_render_camera_forward_ex(
-                C.byref(d), None, _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
-                _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
-                _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(),
-                fwd_flags | _capi.VAMP_CAMFWD_DIRECT, _stream(cur)), "vamp_render_camera_forward_ex")
-        else:
-            if ert and not direct:
-                # the per-ray termination table first: forward, the backward's sort and its per-ray pass
-                # all read it from the workspace
+        for op, where, flags, waits, records in plan:
+            st = streams[where]
+            for w in waits:
+                st.wait_event(events[w])
+            if op == "term":
                 _capi.check(hp.lib.vamp_render_camera_terminate(
                     C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(beta), _ptr(dens), _ptr(ws),
-                    ws.numel(), _stream(cur)), "vamp_render_camera_terminate")
-                fwd_flags |= _capi.VAMP_CAMFWD_TERM_VALID
-            ctx.ert = ert
-            if side is not None:
-                side.wait_stream(cur)
-                if train and geom is None and hp.impl["prepare"] and hp.impl["cam_bwd"] != "v1" and not direct:
-                    # the sample -> cell-slot table of the backward depends on the geometry (and the
-                    # termination table) only: it is built here, on the side stream, beside the forward
-                    # (with the one-kernel forward the table is that kernel's by-product: the backward
-                    # builds its cell lists itself)
-                    _capi.check(hp.lib.vamp_render_camera_prepare_ex(
-                        C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(),
-                        (_capi.VAMP_CAMPREP_TERM_VALID if ert else 0) | hp._cam_clean_flag(), _stream(side)),
-                        "vamp_render_camera_prepare_ex")
-                    hp._dirty.discard("render")
-                    ctx.cells = True
-            # training: the BEV branch keeps its density / semantic / rgb samples for its backward
-            bev_save = train and hp.impl["bev_save"] and hp.impl["bev_bwd"] != "v1"
-            ws_bev = (hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d))) if bev_save else None)
-            # Without early termination the march is the long kernel of the step, and a BEV forward running
-            # beside it costs it more than it hides (kernel timeline of a replayed step at cfg-B: march 207 us
-            # beside the BEV forward, 150 alone): the BEV forward then FOLLOWS the march on this stream, and
-            # only the prepare pass (rank, scan, list: latency, no bandwidth) runs beside it.
-            bev_after = train and side is not None and not ert and ctx.cells and hp.impl["sched"] == "split"
-
-            def bev_forward(stream):
+                    ws.numel(), _stream(st)), "vamp_render_camera_terminate")
+            elif op in ("cam", "pack"):
+                keep = _capi.VAMP_CAMFWD_SAVE_SAMPLES if (save and op == "cam") else 0
+                _capi.check(hp.lib.vamp_render_camera_forward_ex(
+                    C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
+                    _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
+                    _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(), cam_base | flags | keep, _stream(st)),
+                    "vamp_render_camera_forward_ex")
+            elif op == "prep":
+                _capi.check(hp.lib.vamp_render_camera_prepare_ex(
+                    C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(),
+                    flags | hp._cam_clean_flag(), _stream(st)), "vamp_render_camera_prepare_ex")
+                hp._dirty.discard("render")
+                ctx.cells = True
+            else:
                 _capi.check(hp.lib.vamp_render_bev_forward_ex(
                     C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
                     _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
                     _ptr(vdens), _ptr(vout), _ptr(ws_bev), ws_bev.numel() if bev_save else 0,
-                    (_capi.VAMP_BEVFWD_SAVE if bev_save else 0) | bev_flags, _stream(stream)),
-                    "vamp_render_bev_forward_ex")
-
-            if not bev_after:
-                bev_forward(cur if side is None else side)
-            hp._bev_gen = getattr(hp, "_bev_gen", 0) + 1
-            ctx.bev_key = (hp._bev_gen, ws_bev.data_ptr()) if bev_save else None
-            _capi.check(hp.lib.vamp_render_camera_forward_ex(
-                C.byref(d), _ptr(geom), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds),
-                _ptr(hp.camera_mids), _ptr(beta), _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(rgb_p),
-                _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(),
-                fwd_flags | (_capi.VAMP_CAMFWD_SAVE_SAMPLES if save else 0) | (_capi.VAMP_CAMFWD_DIRECT if direct else 0),
-                _stream(cur)), "vamp_render_camera_forward_ex")
-            if bev_after:
-                bev_forward(cur)
-        ctx.samples = save
+                    (_capi.VAMP_BEVFWD_SAVE if bev_save else 0) | bev_flags, _stream(st)), "vamp_render_bev_forward_ex")
+                hp._bev_gen = getattr(hp, "_bev_gen", 0) + 1
+                ctx.bev_key = (hp._bev_gen, ws_bev.data_ptr()) if bev_save else None
+            for r in records:
+                events[r] = torch.cuda.Event()
+                events[r].record(st)
         if side is not None:
             cur.wait_stream(side)
+        hp._camera_forward_probe(d, ws, (mats, beta, dens), ert, geom is None, cur)
+        ctx.samples = save
         ctx.hp, ctx.desc = hp, d
-        # the workspace now starts with the channel-last copy of (dens, sem, rgb); the backward
-        # reuses it if no other render call has touched the workspace in between
+        # the workspace now holds the termination table, the channel-last copy of (dens, sem, rgb) unless the
+        # one kernel ran, and the cell lists if a prepare pass did; the backward reuses them if no other render
+        # call has touched the workspace in between
         hp._pack_gen = getattr(hp, "_pack_gen", 0) + 1
         ctx.pack_key = None if (direct and not train) else (hp._pack_gen, ws.data_ptr())
         ctx.packed = not direct                 # (the one-kernel forward makes no channel-last copy)
@@ -813,8 +779,6 @@ class _RenderFn(torch.autograd.Function):
         packed_valid = 2 if ctx.pack_key == (getattr(hp, "_pack_gen", 0), ws.data_ptr()) else 0
         if packed_valid and ctx.cells:
             packed_valid |= 4                                    # VAMP_CAMBWD_CELLS_VALID
-            if ctx.cells == 2:
-                packed_valid |= _capi.VAMP_CAMBWD_SLOTS_PENDING
         if packed_valid and ctx.samples and default_impl:
             packed_valid |= _capi.VAMP_CAMBWD_SAMPLES_VALID
         if not ctx.ert:
@@ -822,7 +786,7 @@ class _RenderFn(torch.autograd.Function):
         elif packed_valid:
             packed_valid |= _capi.VAMP_CAMBWD_TERM_VALID           # same validity as the packed copy
         else:
-            packed_valid &= ~(4 | _capi.VAMP_CAMBWD_SLOTS_PENDING)  # no table: the cells are rebuilt with a fresh one
+            packed_valid &= ~4                                   # no table: the cells are rebuilt with a fresh one
         if not ctx.packed:
             packed_valid &= ~2                                   # table / cells are there, a packed copy (v1 splat only) is not
         hp._pack_gen = getattr(hp, "_pack_gen", 0) + 1          # the backward scribbles after the copy only,
@@ -859,7 +823,7 @@ class _RenderFn(torch.autograd.Function):
             else:
                 cam_part(0, cur, C.c_void_p(done.cuda_event))
             cur.wait_stream(side)
-        elif hp.impl["bev_first"] and geom is None and default_impl:
+        elif geom is None and default_impl:
             bev_backward(cur, True)
             _capi.check(hp.lib.vamp_render_camera_backward_acc(
                 *cam_args, _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gbeta), _ptr(ws), ws.numel(), 1 | packed_valid,
