@@ -283,6 +283,14 @@ int vamp_render_camera_forward(const VampRenderDesc* d, const float* geom, const
  * per-ray table is written into `workspace` as a by-product when workspace_bytes >=
  * vamp_render_workspace_bytes(d) (workspace may be NULL otherwise).  Combines with NO_ERT. */
 #define VAMP_CAMFWD_DIRECT 32
+/* with DIRECT: the DENSITY samples' tap coordinates from the reference's own fp32 chain (bv2:328-349, 397-404)
+ * instead of the ray's line in fp64.  The line is the correctly rounded value of the exact map; the reference's
+ * chain deviates from it by its own rounding, a few ulp of the tap coordinate (1e-5 voxel) -- which the Laplace
+ * density's slope (d sigma / d s = 1 / (2 beta^2) = 50) turns into up to 2.1e-4 m of rendered depth and 1e-4 of a
+ * semantic logit at cfg-A (worst of 10 000 elements; 6.5e-5 / 8.2e-5 at cfg-B).  With this flag the weights follow
+ * the reference's coordinates (2.4e-5 m, 7.7e-5; the composited channels, which enter linearly, stay on the line)
+ * and the kernel takes 59 instead of 47 us at cfg-B. */
+#define VAMP_CAMFWD_EXACT_TAPS 64
 int vamp_render_camera_terminate(const VampRenderDesc* d, const float* mats, const float* us,
                                  const float* vs, const float* ds, const float* beta,
                                  const void* density_feature, void* workspace, size_t workspace_bytes,

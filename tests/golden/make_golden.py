@@ -405,6 +405,63 @@ def make_cfg_d(BaseVAMPIRE2):
     print("cfg D done: valid", entry["lift_valid_count"], "inside", entry["render_inside_count"])
 
 
+def make_cfg_d_grads(BaseVAMPIRE2):
+    """BASELINE configs[3] backward: the reference's lift and render at 512x1408 / 400x400x32 on
+    the bf16-rounded inputs WITH autograd (bv2:507-514, 419-440), upstream gradients from `upstream_grads`;
+    10 000 strided elements of each of the six input gradients + grad_beta -> cfgd_grad_samples.npz.
+    (About 25 GB of host memory and ten minutes on 8 cores.)"""
+    import torch.nn.functional as F
+    from vampire_amd.config import CFG_D as cfg
+    from vampire_amd import synthetic
+    from oracle import aten_oracle as O
+    m = ref_module(BaseVAMPIRE2, cfg, "sdf", False)
+    s2e, K, ida = synthetic.camera_rig(cfg, 1)
+    bda = synthetic.bda_matrix(1)
+    rnd = lambda t: t.bfloat16().float()
+    depth, feat = (rnd(t) for t in synthetic.lift_inputs(cfg, 1, seed=0))
+    vols = [rnd(t) for t in synthetic.render_inputs(cfg, 1, seed=0)]
+    mats = dict(sensor2ego_mats=s2e[:, None], intrin_mats=K[:, None], ida_mats=ida[:, None], bda_mat=bda)
+    out = {"seed_lift": 4242, "seed_render": 4343}
+    # the ill-conditioned entries of the per-channel hit count (see make_full_grads): upstream zeroed there
+    with torch.no_grad():
+        pix = m.get_pixel(s2e, K, ida, bda)
+        valid, grid = O.lift_valid_and_grid(pix, cfg.final_dim, cfg.d_bound)
+        fragile = torch.zeros(1, cfg.mid_channels, cfg.vZ, cfg.vY, cfg.vX, dtype=torch.bool)
+        for n in range(cfg.num_cams):          # (camera by camera: the six sampled volumes together are 12 GB)
+            ff = depth[:, n].unsqueeze(1) * feat[:, n].unsqueeze(2)
+            sm = F.grid_sample(ff, grid[:, n], align_corners=False)
+            fragile |= (sm.abs() < 1e-7) & valid[:, n].bool().unsqueeze(1)
+            del ff, sm
+        out["lift_upstream_zero_idx"] = fragile.flatten().nonzero().flatten()
+        del pix, valid, grid, fragile
+    d_ = depth.clone().requires_grad_(True)
+    f_ = feat.clone().requires_grad_(True)
+    vox = m.get_voxel_feats(d_.unsqueeze(2) * f_.unsqueeze(3), 0, mats)
+    (g_vox,) = upstream_grads([vox.shape], out["seed_lift"])
+    g_vox.view(-1)[out["lift_upstream_zero_idx"]] = 0.0
+    vox.backward(g_vox)
+    for key, t in (("grad_depth", d_.grad), ("grad_feat", f_.grad)):
+        out[key], out[key + "_stride"] = strided_sample(t)
+        out[key + "_absmax"] = float(t.abs().max())
+    del vox, d_, f_, g_vox
+    print("cfg D lift gradients done; fragile entries", int(out["lift_upstream_zero_idx"].numel()), flush=True)
+    with torch.no_grad():
+        geom = torch.nan_to_num(m.get_geometry(s2e, K, ida, bda), -1e3)
+    v_ = [t.clone().requires_grad_(True) for t in vols]
+    r = m.volume_rendering_from_multiple_views(geom, *v_)
+    g_r = upstream_grads([t.shape for t in r], out["seed_render"])
+    torch.autograd.backward(r, g_r)
+    for n_, t in zip(["density_feature", "semantic_logits", "base", "rgb"], v_):
+        out["grad_" + n_], out["grad_" + n_ + "_stride"] = strided_sample(t.grad)
+        out["grad_" + n_ + "_absmax"] = float(t.grad.abs().max())
+    out["beta"] = float(m.density.beta.detach())
+    out["grad_beta"] = float(m.density.beta.grad)
+    path = os.path.join(HERE, "cfgd_grad_samples.npz")
+    np.savez_compressed(path, **{k: (v.numpy() if torch.is_tensor(v) else np.float64(v) if isinstance(v, float) else np.int64(v))
+                                 for k, v in out.items()})
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; grad_beta", out["grad_beta"])
+
+
 def make_regimes(BaseVAMPIRE2):
     """cfg-B, B=1, the reference's renderer with autograd in two more density regimes:
       "naive"  density_mode="naive" on the synthetic volumes (bv2:191-194; Q6: masked samples carry
@@ -696,6 +753,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--cfgd-only" in sys.argv:
         make_cfg_d(V2)
+        sys.exit(0)
+    if "--cfgd-grads" in sys.argv:
+        make_cfg_d_grads(V2)
         sys.exit(0)
     if "--regimes-only" in sys.argv:
         make_regimes(V2)

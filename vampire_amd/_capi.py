@@ -71,7 +71,7 @@ VAMP_CAMPREP_TERM_VALID, VAMP_CAMPREP_RANK_ONLY, VAMP_CAMPREP_COUNTERS_CLEAN = 1
 VAMP_CAMBWD_SLOTS_PENDING = 1024
 VAMP_BEVBWD_OVERWRITE_BASE, VAMP_BEVBWD_OVERWRITE_CAM, VAMP_BEVBWD_SAVED_VALID = 1, 2, 4
 VAMP_BEVFWD_SAVE, VAMP_BEVFWD_TWO_KERNELS, VAMP_BEVFWD_HEIGHTS_LATTICE = 1, 2, 4
-VAMP_CAMFWD_PACK_ONLY, VAMP_CAMFWD_PACKED_VALID, VAMP_CAMFWD_DIRECT = 8, 16, 32
+VAMP_CAMFWD_PACK_ONLY, VAMP_CAMFWD_PACKED_VALID, VAMP_CAMFWD_DIRECT, VAMP_CAMFWD_EXACT_TAPS = 8, 16, 32, 64
 VAMP_BEVBWD_ONLY_BASE, VAMP_BEVBWD_SKIP_BASE, VAMP_BEVBWD_TABLE_VALID = 8, 16, 32
 
 _P = C.c_void_p

@@ -76,14 +76,71 @@ __device__ __forceinline__ void frustum_point_rb(const float* __restrict__ m, co
   p = matvec(m + 32, p);
   x = nan_to_num_geom(p.x); y = nan_to_num_geom(p.y); z = nan_to_num_geom(p.z);
 }
+// the same with `bda` known to be the identity (uniform; the reference's default: base_exp.py:113-120 has every
+// bda augmentation off): ((1 x + 0 y) + 0 z) + 0 w is x for finite y, z, w and NaN otherwise -- x + 0 (y + z + w)
+__device__ __forceinline__ void frustum_point_rb_id(const float* __restrict__ m, const RayBase& rb, float dd,
+                                                    float& x, float& y, float& z) {
+  Vec4 p;
+  p.x = (rb.c[0] + m[2] * dd) + m[3] * 1.0f;
+  p.y = (rb.c[1] + m[6] * dd) + m[7] * 1.0f;
+  p.z = (rb.c[2] + m[10] * dd) + m[11] * 1.0f;
+  p.w = (rb.c[3] + m[14] * dd) + m[15] * 1.0f;
+  p.x = p.x * p.z;
+  p.y = p.y * p.z;
+  p = matvec(m + 16, p);
+  const float poison = (((p.x + p.y) + p.z) + p.w) * 0.0f;        // +-0, or NaN when a component is not finite
+  x = nan_to_num_geom(p.x + poison); y = nan_to_num_geom(p.y + poison); z = nan_to_num_geom(p.z + poison);
+}
+
+// volume_tap (render_common.hpp) with each IEEE division by the constant span[k] replaced by the quotient from
+// a refined reciprocal + one residual step: q = x r, q += (x - q span) r.  That is the correctly rounded
+// quotient in all but a vanishing fraction of cases (where it is one ulp off), at 3 instructions instead of
+// ~10.  Used for the DENSITY samples of the one-kernel forward, whose coordinates then carry the reference's own
+// roundings (see chain taps below); never for the inside mask on its own (near a face the wave takes the
+// reference's chain with its IEEE divisions).
+struct SpanRcp { float rx, ry, rz; };
+__device__ __forceinline__ float rcp_refined(float d) {
+  const float y = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(__builtin_fmaf(-d, y, 1.0f), y, y);
+}
+__device__ __forceinline__ float div_by(float x, float d, float r) {
+  const float q = x * r;
+  return __builtin_fmaf(__builtin_fmaf(-q, d, x), r, q);
+}
+__device__ __forceinline__ VolTap volume_tap_rcp(const RenderParams& P, const SpanRcp& R, float x, float y, float z,
+                                                 bool& near_face) {
+  const float gx = div_by(x - P.lo[0], P.span[0], R.rx) * 2.0f - 1.0f;
+  const float gy = div_by(y - P.lo[1], P.span[1], R.ry) * 2.0f - 1.0f;
+  const float gz = div_by(z - P.lo[2], P.span[2], R.rz) * 2.0f - 1.0f;
+  VolTap t;
+  t.inside = (gx >= -1.0f) && (gx <= 1.0f) && (gy >= -1.0f) && (gy <= 1.0f) && (gz >= -1.0f) && (gz <= 1.0f);
+  const float X1 = (float) (P.X - 1), Y1 = (float) (P.Y - 1), Z1 = (float) (P.Z - 1);
+  const float fx = ((gx + 1.0f) * 0.5f) * X1, fy = ((gy + 1.0f) * 0.5f) * Y1, fz = ((gz + 1.0f) * 0.5f) * Z1;
+  const float e = fminf(fminf(fminf(fabsf(fx), fabsf(fx - X1)), fminf(fabsf(fy), fabsf(fy - Y1))),
+                        fminf(fabsf(fz), fabsf(fz - Z1)));
+  near_face = !(e > 1e-3f);                         // (also true for a NaN coordinate)
+  const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+  t.ix0 = (int) flx; t.iy0 = (int) fly; t.iz0 = (int) flz;
+  t.wx1 = fx - flx; t.wx0 = (flx + 1.0f) - fx;
+  t.wy1 = fy - fly; t.wy0 = (fly + 1.0f) - fy;
+  t.wz1 = fz - flz; t.wz0 = (flz + 1.0f) - fz;
+  t.fx = fx; t.fy = fy; t.fz = fz;
+  return t;
+}
 
 // sigma(s) with one v_exp_f32: for t = s - bias > 0 the reference's 0.5 + 0.5 sign(t) expm1(-|t| / beta) is
 // 0.5 e, for t < 0 it is 1 - 0.5 e (e = exp(-|t| / beta)); neither form cancels, so the fast exponential's
 // 1e-6 relative error is all there is (the outputs are held to 1e-4)
 __device__ __forceinline__ float density_fast(const DensityParams& dp, float s) {
+#ifdef VAMP_DENSITY_FAST_EXPF
   if (dp.mode == VAMP_DENSITY_SIGMOID) return __builtin_amdgcn_rcpf(1.f + __expf(-s));
   const float t = s - dp.bias;
   const float e = 0.5f * __expf(-fabsf(t) * dp.ib);
+#else
+  if (dp.mode == VAMP_DENSITY_SIGMOID) return 1.0f / (1.f + exp_acc(-s));
+  const float t = s - dp.bias;
+  const float e = 0.5f * exp_acc(-fabsf(t) * dp.ib);
+#endif
   return dp.ib * (t > 0.f ? e : (t < 0.f ? 1.0f - e : 0.5f));
 }
 
@@ -227,7 +284,10 @@ __device__ __forceinline__ RayId decode_tile(const RenderParams& P) {
 // rows[((tile * S + i) * P.CP + c) * 64 + ray]: 256 contiguous bytes per (tile, depth index, channel), so
 // the backward's per-ray pass (same tiles, same lanes) reads them back coalesced instead of repeating
 // the 8-tap gathers, which are all that pass was bound by.
-template <typename T, int NCH, bool ERT, int NW>
+// CHAIN (VAMP_CAMFWD_EXACT_TAPS): the density samples on the reference's own fp32 coordinate chain (tap_density).
+// A template parameter: as a run-time switch the second path cost the default one 3.7 us (47.1 -> 50.8) by its
+// registers alone.
+template <typename T, int NCH, bool ERT, int NW, bool CHAIN>
 __global__ void __launch_bounds__(NW * 64, 3)      // (3 waves per SIMD: 171 registers would be 2; ERT on 62 -> 57 us, off 225 -> 218)
 cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const float* __restrict__ us,
                       const float* __restrict__ vs, const float* __restrict__ ds,
@@ -264,6 +324,29 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
   const RayLine L = ray_line(m, P, u, v, ds[0], ds[S]);
   // tap of depth index i: the line, or the reference's fp32 chain where the inside mask is decided
   auto tap_at = [&](int i) -> VolTap { return direct_tap(P, m, L, affine, u, v, ds[i]); };
+  // Tap of a DENSITY sample: the reference's own fp32 chain (frustum_point_rb: its roundings bit for bit; the
+  // divisions of the normalisation through refined reciprocals).  The line above is the exact map, the
+  // reference's chain deviates from it by a few ulp of a tap coordinate -- 1e-5 voxel, which the Laplace
+  // density's slope (1 / (2 beta^2) = 50 per unit of the feature) turns into 1e-4 of a seg logit and 2e-4 m of
+  // depth at cfg-A (full-size element check, round 5).  The weights are where that sensitivity sits, so the
+  // density samples follow the reference's coordinates (~65 instructions more per sample of the density
+  // phase); the K + 3 composited channels, which enter linearly, stay on the line.
+  const RayBase rb = ray_base(m, u, v);
+  bool bda_identity = true;                                        // uniform
+#pragma unroll
+  for (int k = 0; k < 16; ++k) bda_identity = bda_identity && m[32 + k] == ((k % 5 == 0) ? 1.0f : 0.0f);
+  const SpanRcp span_r{rcp_refined(P.span[0]), rcp_refined(P.span[1]), rcp_refined(P.span[2])};
+  auto tap_density = [&](int i) -> VolTap {
+    const float* mm = m;
+    asm volatile("" : "+s"(mm));                    // (read the matrices again here: 40 scalars do not stay in registers)
+    float x, y, z;
+    if (bda_identity) frustum_point_rb_id(mm, rb, ds[i], x, y, z);
+    else frustum_point_rb(mm, rb, ds[i], x, y, z);
+    bool near_face;
+    VolTap tp = volume_tap_rcp(P, span_r, x, y, z, near_face);
+    if (__any(near_face)) tp = volume_tap(P, x, y, z);             // the inside mask is the reference's bit for bit
+    return tp;
+  };
   // length of bin i (bv2:426: norm of consecutive frustum points): along an affine chain the points of a
   // ray lie on a line, L.len per unit of depth; otherwise the two points themselves
   auto delta_at = [&](int i) -> float {
@@ -333,7 +416,7 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
       for (int g = 0; g < G; ++g) {
         in[g] = false; delta[g] = 0.f;
         if (idx[g] < S) {
-          const VolTap tp = tap_at(idx[g]);
+          const VolTap tp = CHAIN ? tap_density(idx[g]) : tap_at(idx[g]);
           delta[g] = delta_at(idx[g]);                                                 // bv2:426
           in[g] = tp.inside;
           if (tp.inside) {
@@ -415,7 +498,7 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
     float aw = 0.f, ad = 0.f;
     for (int i = a0; i < a1; ++i) {
       const float tau = wbuf[i * 64 + r];
-      const float wgt = (1.0f - __expf(-tau)) * __expf(-cum);      // bv2:430-434
+      const float wgt = composite_weight(tau, cum);                // bv2:430-434
       wbuf[i * 64 + r] = wgt;
       aw += wgt;
       ad = __builtin_fmaf(wgt, mids[i], ad);
@@ -588,18 +671,15 @@ int launch_cam_fwd_direct(const VampRenderDesc* d, const RenderParams& P, const 
   const int S = P.D - 1, nch = P.K + 3;
   const long tiles = (long) P.B * P.N * ((P.fH + 7) / 8) * ((P.fW + 7) / 8);
   const unsigned grid = (unsigned) ((tiles + 7) / 8 * 8);
+#define VAMP_CAMD_L(T, NCH, ERT, CHAIN)                                                                 \
+  VAMP_TIMED(kProfCamFwd, s, (cam_fwd_direct_kernel<T, NCH, ERT, VAMP_DIRECT_NW, CHAIN><<<grid, VAMP_DIRECT_NW * 64, dyn, s>>>( \
+      P, mats, us, vs, ds, mids, beta, static_cast<const T*>(dens), static_cast<const T*>(sem),         \
+      static_cast<const T*>(rgb), rgb_out, seg_out, depth_out, term_out, rows)))
 #define VAMP_CAMD(T, NCH)                                                                               \
   do {                                                                                                  \
-    constexpr int NW = VAMP_DIRECT_NW;                                                                  \
-    const size_t dyn = sizeof(float) * 64 * (size_t) (S > NW * NCH ? S : NW * NCH);                     \
-    if (ert)                                                                                            \
-      VAMP_TIMED(kProfCamFwd, s, (cam_fwd_direct_kernel<T, NCH, true, NW><<<grid, NW * 64, dyn, s>>>(   \
-          P, mats, us, vs, ds, mids, beta, static_cast<const T*>(dens), static_cast<const T*>(sem),     \
-          static_cast<const T*>(rgb), rgb_out, seg_out, depth_out, term_out, rows)));                   \
-    else                                                                                                \
-      VAMP_TIMED(kProfCamFwd, s, (cam_fwd_direct_kernel<T, NCH, false, NW><<<grid, NW * 64, dyn, s>>>(  \
-          P, mats, us, vs, ds, mids, beta, static_cast<const T*>(dens), static_cast<const T*>(sem),     \
-          static_cast<const T*>(rgb), rgb_out, seg_out, depth_out, term_out, rows)));                   \
+    const size_t dyn = sizeof(float) * 64 * (size_t) (S > VAMP_DIRECT_NW * NCH ? S : VAMP_DIRECT_NW * NCH); \
+    if (P.exact_taps) { if (ert) VAMP_CAMD_L(T, NCH, true, true); else VAMP_CAMD_L(T, NCH, false, true); } \
+    else { if (ert) VAMP_CAMD_L(T, NCH, true, false); else VAMP_CAMD_L(T, NCH, false, false); }         \
   } while (0)
 #define VAMP_CAMD_T(T)                                                                                  \
   do {                                                                                                  \
@@ -613,6 +693,7 @@ int launch_cam_fwd_direct(const VampRenderDesc* d, const RenderParams& P, const 
   else VAMP_CAMD_T(__hip_bfloat16);
 #undef VAMP_CAMD_T
 #undef VAMP_CAMD
+#undef VAMP_CAMD_L
   return check_launch("cam_fwd_direct_kernel");
 }
 

@@ -342,7 +342,7 @@ render_cam_fwd_plan_kernel(RenderParams P, const float* __restrict__ mats, const
       if (i != jn) {
         // all 64 samples of this depth index lie outside the volume: s = 0
         const float tau = sigma_out * (dl_unit * (ds[i + 1] - ds[i]));
-        const float wgt = (1.0f - __expf(-tau)) * __expf(-cum);
+        const float wgt = composite_weight(tau, cum);
         cum += tau;
         acc[0] += wgt;
         acc_depth = __builtin_fmaf(wgt, mids[i], acc_depth);
@@ -381,7 +381,7 @@ render_cam_fwd_plan_kernel(RenderParams P, const float* __restrict__ mats, const
       const float dx = qx - px, dy = qy - py, dz = qz - pz;
       const float delta = sqrtf(dx * dx + dy * dy + dz * dz);       // bv2:426
       const float tau = sigma * delta;
-      const float wgt = (1.0f - __expf(-tau)) * __expf(-cum);       // bv2:430-434
+      const float wgt = composite_weight(tau, cum);       // bv2:430-434
       cum += tau;
       acc[0] += wgt;
       acc_depth = __builtin_fmaf(wgt, mids[i], acc_depth);
@@ -401,7 +401,7 @@ render_cam_fwd_plan_kernel(RenderParams P, const float* __restrict__ mats, const
 #pragma unroll
   for (int k = 0; k < 4; ++k)
     if (k < sub) excl += xc[k * 64 + lane];
-  const float scale = __expf(-excl);                 // transmittance in front of this range
+  const float scale = exp_acc(-excl);                // transmittance in front of this range
   xa[(sub * (CP + 1) + CP) * 64 + lane] = acc_depth * scale;
 #pragma unroll
   for (int c = 0; c < CP; ++c) xa[(sub * (CP + 1) + c) * 64 + lane] = acc[c] * scale;
@@ -575,7 +575,9 @@ int vamp_render_camera_forward_ex(const VampRenderDesc* d, const float* geom, co
         return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) need);
       rows = reinterpret_cast<float*>(static_cast<char*>(workspace) + vamp_render_workspace_bytes(d));
     }
-    return launch_cam_fwd_direct(d, to_params(d), mats, us, vs, ds, mids, beta, density_feature, semantic, rgb,
+    RenderParams P = to_params(d);
+    P.exact_taps = (flags & VAMP_CAMFWD_EXACT_TAPS) ? 1 : 0;
+    return launch_cam_fwd_direct(d, P, mats, us, vs, ds, mids, beta, density_feature, semantic, rgb,
                                  rgb_out, seg_out, depth_out, term, ert, rows, static_cast<hipStream_t>(stream));
   }
   const bool save = (flags & VAMP_CAMFWD_SAVE_SAMPLES) && planned;

@@ -113,6 +113,10 @@ class HotPath:
                      # load of a channel-first volume).  "auto" (default): chosen per call from the termination tables
                      # of the last calls (_camera_forward_choice); True / False force one
                      "cam_direct": {"1": True, "0": False}.get(os.environ.get("VAMP_CAM_DIRECT", "auto"), "auto"),
+                     # the one-kernel camera forward with its density samples on the reference's own fp32 coordinate
+                     # chain instead of the ray's fp64 line (VAMP_CAMFWD_EXACT_TAPS): rendered depth within 2.4e-5 m of
+                     # the reference instead of 2.1e-4 (cfg-A), kernel 59 instead of 47 us
+                     "cam_exact": os.environ.get("VAMP_CAM_EXACT", "0") == "1",
                      # the BEV forward as one kernel (render_bev_fused.hip); "0" = the two-kernel first
                      # implementation, the cross-check of the tests
                      "bev_fused": os.environ.get("VAMP_BEV_FUSED", "1") != "0",
@@ -672,7 +676,7 @@ class _RenderFn(torch.autograd.Function):
         bev_flags = _capi.VAMP_BEVFWD_HEIGHTS_LATTICE if hp.impl["bev_fused"] else _capi.VAMP_BEVFWD_TWO_KERNELS
         bev_save = train and hp.impl["bev_save"] and hp.impl["bev_bwd"] != "v1"
         ws_bev = hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d))) if bev_save else None
-        cam_base = 0 if ert else _capi.VAMP_CAMFWD_NO_ERT
+        cam_base = (0 if ert else _capi.VAMP_CAMFWD_NO_ERT) | (_capi.VAMP_CAMFWD_EXACT_TAPS if hp.impl["cam_exact"] else 0)
         streams, events = {"cur": cur, "side": side}, {}
         ctx.cells, ctx.ert, ctx.bev_key = False, ert, None
         if side is not None:
