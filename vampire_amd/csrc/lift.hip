@@ -24,6 +24,9 @@ namespace vamp {
 #define VAMP_LIFT_TY 16
 #endif
 #define VAMP_LIFT_TILE VAMP_LIFT_TX, VAMP_LIFT_TY, 1
+#ifndef VAMP_LIFT_COOP
+#define VAMP_LIFT_COOP 1
+#endif
 
 // ---------------------------------------------------------------------------
 // feat [BN, C, HW] (f32 or bf16) -> channel-last fp32 [BN, HW, C]
@@ -506,6 +509,145 @@ lift_fwd_kernel(LiftParams P, const float* __restrict__ mats, const float* __res
   if (EMIT && E.amask) E.amask[(long) b * V + vox] = wmask;
 }
 
+// ---------------------------------------------------------------------------
+// LIFT forward, C = 16, with a COOPERATIVE feature gather (round 5).
+// In lift_fwd_kernel a lane fetches the 64-byte channel row of each of its four pixel taps as four 16-byte
+// loads: 16 load instructions per camera whose 64 lanes touch 64 different lines each -- 1 024 line look-ups
+// per wave and camera for 256 rows, and the ablation that fetched one piece per row (4 x fewer look-ups)
+// was 8.7 us faster.  Here the wave works in two roles per camera: lane = voxel (projection, depth taps,
+// the weights of its four pixel taps -> LDS), then lane = (voxel of a 16-voxel row of the patch, channel
+// quad): the four lanes of a voxel fetch the four pieces of a row in ONE instruction, so a load touches 16
+// lines, not 64 (same bytes, same number of instructions).  A lane then holds 4 channels of 4 voxels; sums,
+// hit counts and the stores follow that layout (a store still writes 64-byte runs of 16 x-neighbours).
+// The arithmetic per (voxel, camera, channel) is the old kernel's, in the same order: same bits.
+// ---------------------------------------------------------------------------
+// (waves per SIMD / rows in flight, cfg-B: 4 / 2: 29.2 us, 4 / 1: 29.3, 3 / 2: 38.3, 3 / 4: 31.7, 5 / 1: 48.0)
+template <typename T>
+__global__ void __launch_bounds__(256, 4)
+lift_fwd_coop_kernel(LiftParams P, const float* __restrict__ mats, const float* __restrict__ xs,
+                     const float* __restrict__ ys, const float* __restrict__ zs,
+                     const T* __restrict__ depth, const float* __restrict__ feat_cl,
+                     float* __restrict__ out, uint64_t* __restrict__ hits, const unsigned* __restrict__ cull) {
+  constexpr int TX = 16, TY = 16;                // a wave is a 16 x 4 patch: row g of it = 16 x-neighbours
+  __shared__ float4 xch[4][64][2];               // per wave and voxel: the four taps' pixel indices | weights
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = blockIdx.x * TX + (tid % TX);
+  const int y = blockIdx.y * TY + (tid / TX);
+  const int b = blockIdx.z / P.Z, z = blockIdx.z % P.Z;
+  const unsigned cword = cull[((long) blockIdx.z * (gridDim.y * (4 / kCullWpw)) + blockIdx.y * (4 / kCullWpw) + wave / kCullWpw) * gridDim.x + blockIdx.x];
+  // (no early exit: a lane whose own voxel is outside the grid still fetches for the others')
+  const bool live = x < P.X && y < P.Y;
+  const float vx = xs[min(x, P.X - 1)], vy = ys[min(y, P.Y - 1)], vz = zs[z];
+  const long V = (long) P.Z * P.Y * P.X;
+  const long HW = (long) P.fH * P.fW;
+  const int q = lane & 3, vq = lane >> 2;        // second role: channel quad, voxel within a row of the patch
+
+  float sum[16];                                 // [row g of the patch][channel 4 q + k]
+  uint64_t cnt = 0;                              // their hit counts, 4 bits each
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sum[i] = 0.f;
+  const bool shared_bda = (cword & kLiftCullSharedBda) != 0;                        // uniform
+  const Vec4 p1 = matvec(mats + (long) b * P.N * 48, Vec4{vx, vy, vz, 1.0f});       // inv(bda) . c
+
+  for (unsigned cams = cword & (kLiftCullSharedBda - 1); cams; cams &= cams - 1) {
+    const int n = __builtin_ctz(cams);
+    const long bn = (long) b * P.N + n;
+    const LiftTap t = lift_project_from<true>(P, mats + bn * 48, shared_bda ? p1 : matvec(mats + bn * 48, Vec4{vx, vy, vz, 1.0f}));
+    const bool valid = live && t.valid;
+    if (!__any(valid)) continue;                 // uniform
+    // ---- lane = voxel: the weights w_hw * (sum_d w_d depth) of the four pixel taps
+    {
+      float dep[4] = {0.f, 0.f, 0.f, 0.f};
+      if (valid) depth_taps<T>(P, depth + bn * P.D * HW, t, dep);
+      const float w[4] = {t.wy0 * t.wx0, t.wy0 * t.wx1, t.wy1 * t.wx0, t.wy1 * t.wx1};
+      int pix[4];
+      float wd[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int iy = t.iy0 + (j >> 1), ix = t.ix0 + (j & 1);
+        const bool in = valid && iy >= 0 && iy < P.fH && ix >= 0 && ix < P.fW;
+        wd[j] = in ? w[j] * dep[j] : 0.f;
+        pix[j] = in ? iy * P.fW + ix : -1;       // -1: nothing to fetch
+      }
+      xch[wave][lane][0] = make_float4(__int_as_float(pix[0]), __int_as_float(pix[1]), __int_as_float(pix[2]), __int_as_float(pix[3]));
+      xch[wave][lane][1] = make_float4(wd[0], wd[1], wd[2], wd[3]);
+    }
+    // (one wave writes and reads its own slab: the LDS queue of a wave is in order, no barrier)
+    // ---- lane = (voxel vq of row g, channel quad q): two rows of the patch at a time
+    const float4* frow = reinterpret_cast<const float4*>(feat_cl) + bn * HW * 4 + q;
+constexpr int R = 2;                          // rows of the patch whose loads are in flight together
+#pragma unroll
+    for (int g0 = 0; g0 < 4; g0 += R) {
+      float4 px[R], wv[R], f[R][4];
+#pragma unroll
+      for (int h = 0; h < R; ++h) {
+        px[h] = xch[wave][(g0 + h) * 16 + vq][0];
+        wv[h] = xch[wave][(g0 + h) * 16 + vq][1];
+      }
+#pragma unroll
+      for (int h = 0; h < R; ++h) {
+        const int pj[4] = {__float_as_int(px[h].x), __float_as_int(px[h].y), __float_as_int(px[h].z), __float_as_int(px[h].w)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f[h][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (pj[j] >= 0) f[h][j] = frow[(long) pj[j] * 4];
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < R; ++h) {
+        const float wj[4] = {wv[h].x, wv[h].y, wv[h].z, wv[h].w};
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[0] = __builtin_fmaf(wj[j], f[h][j].x, acc[0]);
+          acc[1] = __builtin_fmaf(wj[j], f[h][j].y, acc[1]);
+          acc[2] = __builtin_fmaf(wj[j], f[h][j].z, acc[2]);
+          acc[3] = __builtin_fmaf(wj[j], f[h][j].w, acc[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = (g0 + h) * 4 + k;
+          sum[i] += acc[k];
+          cnt += (uint64_t) (fabsf(acc[k]) > 0.f) << (4 * i);   // per-channel hit count (bv2:509)
+        }
+      }
+    }
+  }
+
+  // ---- the mean over the cameras that hit (bv2:509-514) and the stores, row by row of the patch
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int xo = blockIdx.x * TX + vq, yo = blockIdx.y * TY + wave * 4 + g;
+    const bool live_o = xo < P.X && yo < P.Y;
+    const long vo = ((long) z * P.Y + min(yo, P.Y - 1)) * P.X + min(xo, P.X - 1);
+    const unsigned c16 = (unsigned) (cnt >> (16 * g)) & 0xffffu;     // this lane's four counts of the row's voxel
+    const unsigned k0 = c16 & 15u;
+    float* o = out + ((long) b * P.C + q * 4) * V + vo;
+    if (__all(c16 == k0 * 0x1111u)) {
+      // (one count per voxel unless a feature channel holds exact zeros: one division, then a product and a
+      // residual step per channel -- within an ulp of sum / denom; the outputs are held to 1e-4)
+      const float denom = (float) k0 + 1e-6f, r = 1.0f / denom;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float qv = sum[g * 4 + k] * r;
+        if (live_o) o[(long) k * V] = __builtin_fmaf(__builtin_fmaf(-qv, denom, sum[g * 4 + k]), r, qv);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (live_o) o[(long) k * V] = sum[g * 4 + k] / ((float) ((c16 >> (4 * k)) & 15u) + 1e-6f);
+    }
+    if (hits) {
+      // the voxel's word: channel c's count in nibble c = the four lanes' 16-bit pieces side by side
+      unsigned lo = q < 2 ? c16 << (16 * q) : 0u, hi = q >= 2 ? c16 << (16 * (q - 2)) : 0u;
+      lo |= __shfl_xor(lo, 1, 64); hi |= __shfl_xor(hi, 1, 64);
+      lo |= __shfl_xor(lo, 2, 64); hi |= __shfl_xor(hi, 2, 64);
+      if (q == 0 && live_o) hits[(long) b * V + vo] = ((uint64_t) hi << 32) | lo;
+    }
+  }
+}
+
 // The same walk without the samples: counts and emits the pairs for a backward whose forward did
 // not (vamp_lift_prepare; vamp_lift_backward without VAMP_LIFTBWD_CELLS_VALID).
 template <int TX, int TY>
@@ -798,7 +940,13 @@ static int lift_forward_t(const VampLiftDesc* d, const LiftParams& P, const floa
   }
 #define VAMP_FWD(CH, EM)                                                                               \
   VAMP_TIMED(kProfLiftFwd, s, (lift_fwd_kernel<T, CH, VAMP_LIFT_TILE, EM><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, out, hits, E, cull)))
-  if (cells) {
+  // C = 16 (the reference's mid_channels), no backward to follow: the kernel with the cooperative feature gather
+  // (cfg-B: 28.6 against 31.8 us.  With the pair emission of a training forward its registers spill and it
+  // loses, 44.3 against 36.3 -- those calls keep lift_fwd_kernel)
+  const bool coop = P.C == 16 && TX == 16 && TY == 16 && VAMP_LIFT_COOP && !cells;
+  if (coop)
+    VAMP_TIMED(kProfLiftFwd, s, (lift_fwd_coop_kernel<T><<<grid, 256, 0, s>>>(P, mats, xs, ys, zs, dp, feat_cl, out, hits, cull)));
+  else if (cells) {
     if (P.C == 4) VAMP_FWD(4, true); else if (P.C == 8) VAMP_FWD(8, true); else VAMP_FWD(16, true);
   } else {
     if (P.C == 4) VAMP_FWD(4, false); else if (P.C == 8) VAMP_FWD(8, false); else VAMP_FWD(16, false);
