@@ -10,7 +10,8 @@ import collections, csv, glob, json, os, sys
 
 out, tag, cfg, batch = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 
-SLOTS = [("lift_fwd_kernel", "lift_fwd"), ("lift_bwd_strip_kernel", "lift_bwd_gather"),
+SLOTS = [("lift_fwd_kernel", "lift_fwd"), ("lift_fwd_coop_kernel", "lift_fwd"),
+         ("lift_prologue_kernel", "feat_to_channel_last"), ("lift_operands_kernel", "feat_to_channel_last"), ("lift_bwd_strip_kernel", "lift_bwd_gather"),
          ("lift_bwd_fill_kernel", "lift_bwd_fill"), ("lift_pairs_kernel", "lift_bwd_count"),
          ("lift_bwd_cell_gather_kernel", "lift_bwd_gather"),
          ("lift_bwd_cell_kernel", None), ("lift_bwd_kernel", "lift_bwd_v1"),

@@ -446,6 +446,9 @@ static int launch_cam_heavy_list(const VampRenderDesc* d, const RenderParams& P,
   return check_launch("cam_heavy_list_kernel");
 }
 
+#ifndef VAMP_ABL_NOHEAVY
+#define VAMP_ABL_NOHEAVY 0        // (measurement build: the heavy-voxel drain is not launched -- wrong gradients near the cameras)
+#endif
 // per-voxel gather of the records the per-ray pass has written in cell order
 int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const float* Gcl,
                         float* gdens, float* gsem, float* grgb, void* scratch, int accumulate,
@@ -484,7 +487,7 @@ int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const fl
       VAMP_TIMED(kProfCamBwdBrick, s, (cam_bwd_cell_gather_kernel<CP4, gl><<<grid + (merged ? hgrid_m : 0u), 256, 0, s>>>( \
           P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, ncell_b, runs_x, heavy_thresh, accumulate, btail, runs, \
           w.heavy, nheavy, merged ? hgrid_m : 0u)));                                                \
-    if ((parts & kCamPartHeavy) && !merged)                                                         \
+    if ((parts & kCamPartHeavy) && !merged && !VAMP_ABL_NOHEAVY)                                    \
       VAMP_TIMED(kProfCamBwdOwn, s, (cam_bwd_cell_heavy_kernel<CP4><<<hgrid, 256, 0, s>>>(          \
           P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, w.heavy, nheavy, ncell_b, accumulate)));   \
   } while (0)
