@@ -50,6 +50,15 @@ const char* vamp_last_error(void);
  * slot `slot` (0 <= slot < vamp_profile_slots()), its name, number of launches
  * and total milliseconds since the last vamp_profile_enable(1).
  */
+/*
+ * Debugging mode (off by default): while on, the promises a caller makes with flags are verified before the
+ * library relies on them -- VAMP_LIFTFWD_CELLS_CLEAN / VAMP_CAMPREP_COUNTERS_CLEAN (the cell counters in the
+ * workspace are zero), VAMP_CAM{FWD,PREP,BWD}_TERM_VALID (the workspace holds a termination table: every entry a
+ * number of kept samples) -- and a broken one returns VAMP_EINVAL ("promise broken: ...") instead of corrupting a
+ * result silently.  Each check drains the stream it is issued on.
+ */
+int vamp_debug_checks(int on);
+
 int vamp_profile_enable(int on);
 int vamp_profile_slots(void);
 /* time only this kernel slot (-1 = all): one event pair per step instead of ~40 */

@@ -3,6 +3,7 @@ reference itself and against the oracle on identical seeded inputs.
 
 Bars (BASELINE.json north_star): tap indices / masks bit-exact; values within 1e-4 fp32.
 """
+import ctypes as C
 import dataclasses
 import hashlib
 import json
@@ -1586,6 +1587,55 @@ def test_density_regimes_match_reference(dev, regime, ert):
         _block_check(g, ref["grad_" + k], f"{regime} grad_{k}", rtol=5e-5, elem_atol=1e-10)
     if "grad_beta" in ref:
         assert abs(float(gbeta) - ref["grad_beta"]) <= 2e-3 * abs(ref["grad_beta"]) + 1e-4, (float(gbeta), ref["grad_beta"])
+
+
+def test_debug_checks_catch_broken_promises(dev):
+    """vamp_debug_checks(1): the *_CLEAN / *_VALID promises of the host are verified before the library relies on
+    them.  A training step of the default schedule passes every check; a workspace whose counters are not zero, or
+    that holds no termination table, is refused with "promise broken" instead of corrupting the result."""
+    from vampire_amd import _capi
+    from vampire_amd.step import LiftRenderStep, SyntheticBatch, train_step
+    cfg = dataclasses.replace(CFG_TINY, density_mode="sdf")
+    lib = _capi.load()
+    lib.vamp_debug_checks(1)
+    try:
+        model = LiftRenderStep(cfg, dev)
+        data = SyntheticBatch(cfg, 2, dev)
+        for _ in range(3):                     # (CELLS_CLEAN / COUNTERS_CLEAN / TERM_VALID all in use from the second step on)
+            model.zero_grad(set_to_none=True)
+            train_step(model, data)
+        torch.cuda.synchronize()
+        hp = model.hp
+        # counters not zero under VAMP_LIFTFWD_CELLS_CLEAN
+        hp._ws["lift"].fill_(1)
+        with pytest.raises(_capi.VampireHipError, match="promise broken.*CELLS_CLEAN"):
+            train_step(model, data)
+        hp._ws["lift"].zero_(); hp._dirty.discard("lift")
+        # counters not zero under VAMP_CAMPREP_COUNTERS_CLEAN (the forward's prepare pass)
+        hp._ws["render"].fill_(1); hp._dirty.discard("render")
+        with pytest.raises(_capi.VampireHipError, match="promise broken"):
+            train_step(model, data)
+        hp._ws["render"].zero_(); hp._dirty.discard("render")
+        # a termination table that is not one, handed to the planned march with VAMP_CAMFWD_TERM_VALID
+        hp.impl["cam_direct"] = False
+        d = hp.render_desc(2, cfg.num_cams, _capi.VAMP_F32)
+        off = hp.lib.vamp_render_term_offset(C.byref(d))
+        ws = hp._workspace("render", hp.lib.vamp_render_workspace_bytes(C.byref(d)))
+        ws[off:off + 4 * 2 * cfg.num_cams * cfg.fH * cfg.fW].view(torch.int32).fill_(-7)
+        rgb_p = torch.empty(2, cfg.num_cams, 3, cfg.fH, cfg.fW, device=dev)
+        seg_p = torch.empty(2, cfg.num_cams, cfg.num_classes, cfg.fH, cfg.fW, device=dev)
+        dep_p = torch.empty(2, cfg.num_cams, 1, cfg.fH, cfg.fW, device=dev)
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        vols = [v.detach() for v in data.vols]
+        beta = torch.tensor([0.1], device=dev)
+        rc = hp.lib.vamp_render_camera_forward_ex(
+            C.byref(d), None, ptr(data.render_mats), ptr(hp.us), ptr(hp.vs), ptr(hp.ds), ptr(hp.camera_mids), ptr(beta),
+            ptr(vols[0]), ptr(vols[1]), ptr(vols[3]), ptr(rgb_p), ptr(seg_p), ptr(dep_p), ptr(ws), ws.numel(),
+            _capi.VAMP_CAMFWD_TERM_VALID, None)
+        assert rc == -1 and b"promise broken" in hp.lib.vamp_last_error() and b"TERM_VALID" in hp.lib.vamp_last_error()
+    finally:
+        lib.vamp_debug_checks(0)
+        torch.cuda.synchronize()
 
 
 # --------------------------------------------------------------------------- round-3: one-kernel camera forward

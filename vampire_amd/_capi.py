@@ -83,6 +83,7 @@ _CD = C.POINTER(VampConvDesc)
 # name -> (restype, argtypes); must list every symbol declared in include/vampire_hip.h
 SIGNATURES = {
     "vamp_abi_version": (C.c_int, []),
+    "vamp_debug_checks": (C.c_int, [C.c_int]),
     "vamp_last_error": (C.c_char_p, []),
     "vamp_profile_enable": (C.c_int, [C.c_int]),
     "vamp_profile_slots": (C.c_int, []),

@@ -61,6 +61,9 @@ int launch_exclusive_scan(const int* cnt, int* off, int* fill, int n, int* total
 // grad_beta[0] += sign(beta_raw[0]) * sum(part[0..n)), summed in a fixed order by one workgroup
 // zero `bytes` (multiple of 4) at ptr with a kernel (graph-safe, see runtime.hip)
 int launch_zero(void* ptr, size_t bytes, hipStream_t s);
+// vamp_debug_checks(1): verify (synchronously) that p[0 .. n) lies in [lo, hi]; VAMP_OK when the mode is off
+extern bool g_debug_checks;
+int debug_expect_range(const int* p, size_t n, int lo, int hi, hipStream_t s, const char* what);
 int launch_beta_reduce(const float* part, int n, const float* beta_raw, float* grad_beta, hipStream_t s);
 constexpr int kScanTile = 2048;
 // `cnt` holds ncell + kScanPad ints, all zeroed by the caller before the count pass: cnt[ncell] is the

@@ -592,7 +592,8 @@ int launch_lift_cells_begin(const VampLiftDesc* d, void* scratch, hipStream_t s,
   VAMP_REQUIRE(cap < 0x7fffffffu && g.ncell < 0x7fffffffL, "pair / cell count exceeds 2^31");
   VAMP_REQUIRE(d->C % 4 == 0, "C must be a multiple of 4");
   VAMP_REQUIRE(d->fW < 32767 && d->fH < 32767 && d->D < 65535, "feature map too large for the packed cell coordinates");
-  if (clean) return VAMP_OK;        // (VAMP_LIFTFWD_CELLS_CLEAN: the caller vouches for zeroed counters)
+  if (clean)                        // (VAMP_LIFTFWD_CELLS_CLEAN: the caller vouches for zeroed counters)
+    return debug_expect_range(w.cnt, (size_t) (g.ncell + kScanPad), 0, 0, s, "VAMP_LIFTFWD_CELLS_CLEAN: the lift workspace's cell counters are zero");
   return launch_zero(w.cnt, (size_t) (g.ncell + kScanPad) * sizeof(int), s);
 }
 

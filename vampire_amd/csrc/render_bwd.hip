@@ -429,6 +429,9 @@ int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, 
       if (!(flags & VAMP_CAMBWD_TERM_VALID) && part_ray) {
         VAMP_REQUIRE(!(flags & VAMP_CAMBWD_CELLS_VALID), "CELLS_VALID with early termination needs TERM_VALID");
         if (int e = launch_cam_term(d, P, mats, us, vs, ds, beta, density_feature, term, s)) return e;
+      } else if (part_ray) {
+        if (int e = debug_expect_range(term, (size_t) d->B * d->N * d->fH * d->fW, 0, d->D - 1, s,
+                                       "VAMP_CAMBWD_TERM_VALID: the workspace holds a termination table")) return e;
       }
     }
     return launch_cam_bwd_v2(d, P, mats, us, vs, ds, mids, beta, density_feature, semantic, rgb, g_rgb, g_seg, g_depth,

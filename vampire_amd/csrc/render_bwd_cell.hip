@@ -368,8 +368,15 @@ int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, con
                "sample / voxel / cell count exceeds 2^31");
   const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
   if (phase != 2) {
-    if (!counters_clean)            // (VAMP_CAMPREP_COUNTERS_CLEAN: the previous scan left them at zero)
+    if (!counters_clean) {          // (VAMP_CAMPREP_COUNTERS_CLEAN: the previous scan left them at zero)
       if (int ze = launch_zero(w.cnt, (size_t) (ncell + kScanPad) * sizeof(int), s)) return ze;
+    } else if (int e = debug_expect_range(w.cnt, (size_t) (ncell + kScanPad), 0, 0, s,
+                                          "VAMP_CAMPREP_COUNTERS_CLEAN: the render workspace's cell counters are zero")) {
+      return e;
+    }
+    // (a termination table handed over with *_TERM_VALID holds a number of kept samples per ray)
+    if (int e = debug_expect_range(term, (size_t) d->B * d->N * d->fH * d->fW, 0, d->D - 1, s,
+                                   "VAMP_CAMPREP_TERM_VALID: the workspace holds a termination table")) return e;
     VAMP_TIMED(kProfCamBwdCount, s, (cam_cells_rank_kernel<<<ray_grid<4>(P), 256, 0, s>>>(
         P, mats, us, vs, ds, w.cnt, w.rank, ncell_b, term, w.tile_se)));
     if (int e = check_launch("cam_cells_rank_kernel")) return e;

@@ -592,8 +592,12 @@ int vamp_render_camera_forward_ex(const VampRenderDesc* d, const float* geom, co
   float* samples = save ? reinterpret_cast<float*>(static_cast<char*>(workspace) + vamp_render_workspace_bytes(d))
                         : nullptr;
   int* term = ert ? cam_term_ptr(d, workspace) : nullptr;
-  if (ert && !(flags & VAMP_CAMFWD_TERM_VALID))
+  if (ert && !(flags & VAMP_CAMFWD_TERM_VALID)) {
     if (int e = launch_cam_term(d, P, mats, us, vs, ds, beta, density_feature, term, s)) return e;
+  } else if (ert) {
+    if (int e = debug_expect_range(term, (size_t) d->B * d->N * d->fH * d->fW, 0, d->D - 1, s,
+                                   "VAMP_CAMFWD_TERM_VALID: the workspace holds a termination table")) return e;
+  }
   // VAMP_CAMFWD_PACK_ONLY / _PACKED_VALID: the channel-last copy as a call of its own (a caller
   // with two streams packs beside its other work and marches when both are there)
   if (!(flags & VAMP_CAMFWD_PACKED_VALID))

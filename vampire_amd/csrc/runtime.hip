@@ -239,6 +239,35 @@ zero_fill_kernel(uint4* __restrict__ p16, size_t n16, uint32_t* __restrict__ tai
   if (blockIdx.x == 0 && (int) threadIdx.x < ntail) tail[threadIdx.x] = 0u;
 }
 
+// ---------------------------------------------------------------------------
+// vamp_debug_checks(1): the promises a caller makes with the *_CLEAN / *_VALID flags are verified before
+// they are relied on -- synchronously (the stream is drained per check: a debugging mode, never on by default).
+// ---------------------------------------------------------------------------
+bool g_debug_checks = false;
+
+__global__ void __launch_bounds__(256)
+debug_range_kernel(const int* __restrict__ p, size_t n, int lo, int hi, unsigned long long* __restrict__ bad) {
+  size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+  unsigned long long c = 0;
+  for (; i < n; i += (size_t) gridDim.x * 256) c += (p[i] < lo || p[i] > hi) ? 1ull : 0ull;
+  if (c) atomicAdd(bad, c);
+}
+
+int debug_expect_range(const int* p, size_t n, int lo, int hi, hipStream_t s, const char* what) {
+  if (!g_debug_checks || !p || n == 0) return VAMP_OK;
+  unsigned long long* bad = nullptr;
+  if (hipHostMalloc(reinterpret_cast<void**>(&bad), sizeof(*bad), 0) != hipSuccess) return fail(VAMP_EHIP, "debug check: hipHostMalloc failed");
+  *bad = 0;
+  const unsigned grid = (unsigned) std::min<size_t>((n + 255) / 256, 4096);
+  debug_range_kernel<<<grid, 256, 0, s>>>(p, n, lo, hi, bad);
+  const hipError_t e = hipStreamSynchronize(s);
+  const unsigned long long nbad = *bad;
+  (void) hipHostFree(bad);
+  if (e != hipSuccess) return fail(VAMP_EHIP, "debug check of (%s) failed to run", what);
+  if (nbad) return fail(VAMP_EINVAL, "promise broken: %s -- %ld of %ld entries are not", what, (long) nbad, (long) n);
+  return VAMP_OK;
+}
+
 int launch_zero(void* ptr, size_t bytes, hipStream_t s) {
   if (bytes == 0) return VAMP_OK;
   const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
@@ -271,6 +300,11 @@ int launch_exclusive_scan(const int* cnt, int* off, int* fill, int n, int* total
 using namespace vamp;
 
 extern "C" {
+
+int vamp_debug_checks(int on) {
+  vamp::g_debug_checks = on != 0;
+  return VAMP_OK;
+}
 
 int vamp_abi_version(void) { return VAMP_ABI_VERSION; }
 const char* vamp_last_error(void) { return g_err; }
