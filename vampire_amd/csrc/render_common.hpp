@@ -226,7 +226,9 @@ __device__ __forceinline__ float exp_acc(float x) {             // e^x to ~1.5 u
   const float hi = x * L;
   const float lo = __builtin_fmaf(x, L, -hi) + x * Ll;
   const float e = __builtin_amdgcn_exp2f(hi);
-  return __builtin_fmaf(e, lo * 0.6931471805599453f, e);
+  // (x = -+inf: the correction is inf - inf; the plain exponential is already exact there -- a density feature of
+  // -inf, bv2:421's nan_to_num notwithstanding, saturates the ray with tau = inf)
+  return fabsf(hi) <= 3.0e38f ? __builtin_fmaf(e, lo * 0.6931471805599453f, e) : e;
 }
 __device__ __forceinline__ float alpha_acc(float tau) {         // 1 - e^{-tau}, tau >= 0
   // tau (1 - tau/2 (1 - tau/3 (... (1 - tau/8)))): remainder tau^8 / 9! of the leading term, 4e-11 at 1/4
