@@ -167,8 +167,8 @@ int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs
 #define VAMP_LIFTBWD_WPP1 4
 #define VAMP_LIFTBWD_WPP4 8
 #define VAMP_LIFTBWD_WPP16 16
-#define VAMP_LIFTBWD_HALF_LO 64   /* only the lower half of the flattened (sample, camera) images: with CELLS_VALID, ... */
-#define VAMP_LIFTBWD_HALF_HI 128  /* ... the two halves touch disjoint records and outputs and may run on two streams */
+/* (64, 128: VAMP_LIFTBWD_HALF_LO / _HI of rounds 2-4, the backward by halves of the images on two streams: measured
+   slower twice, removed in round 5) */
 /* LOGITS: `depth` is softmax(logits) over D as written by vamp_lift_forward_logits, and grad_depth receives
    the gradient w.r.t. the LOGITS, p * (g - sum_d p g) (autograd of bv2:550): applied to the pixel's column
    while it sits in LDS, no extra pass.  Default (cell-list) backward only. */
@@ -358,7 +358,7 @@ int vamp_render_camera_prepare(const VampRenderDesc* d, const float* mats, const
    `workspace` keeps (the backward must then be given VAMP_CAMBWD_TERM_VALID too) */
 #define VAMP_CAMPREP_TERM_VALID 1
 #define VAMP_CAMPREP_COUNTERS_CLEAN 4   /* the caller asserts that the cell counters in `workspace` are zero (a zero-filled buffer, or one a completed prepare pass has run on: its scan zeroes what it reads): no zero fill */
-#define VAMP_CAMPREP_RANK_ONLY 2   /* stop after ranking and scanning the cells (what needs the termination table); the backward finishes (VAMP_CAMBWD_SLOTS_PENDING) */
+/* (2: VAMP_CAMPREP_RANK_ONLY of rounds 2-4, the prepare pass in two phases: measured slower twice, removed in round 5) */
 int vamp_render_camera_prepare_ex(const VampRenderDesc* d, const float* mats, const float* us,
                                   const float* vs, const float* ds, void* workspace,
                                   size_t workspace_bytes, int flags, void* stream);
@@ -382,7 +382,7 @@ int vamp_render_camera_prepare_ex(const VampRenderDesc* d, const float* mats, co
  *   PART_HEAVY   the kernel that drains the heavy-voxel list; it owns other voxels than the gather,
  *                so the two may run side by side once the ray pass is done
  * Give every part the same VALID / ACCUMULATE flags. */
-#define VAMP_CAMBWD_SLOTS_PENDING 1024  /* with CELLS_VALID: vamp_render_camera_prepare_ex ran with VAMP_CAMPREP_RANK_ONLY; the slot table and the heavy list are built here, in front of the ray pass */
+/* (1024: VAMP_CAMBWD_SLOTS_PENDING, the second phase of VAMP_CAMPREP_RANK_ONLY: removed with it) */
 #define VAMP_CAMBWD_PART_RAY 128
 #define VAMP_CAMBWD_PART_GATHER 256
 #define VAMP_CAMBWD_PART_HEAVY 512

@@ -61,14 +61,12 @@ VAMP_PAD_ZEROS, VAMP_PAD_BORDER = 0, 1
 VAMP_LIFTFWD_EMIT_PAIRS, VAMP_LIFTFWD_CELLS_CLEAN = 1, 2
 VAMP_LIFTBWD_CELLS_VALID, VAMP_LIFTBWD_SPLAT = 1, 2
 VAMP_LIFTBWD_WPP1, VAMP_LIFTBWD_WPP4, VAMP_LIFTBWD_WPP16 = 4, 8, 16
-VAMP_LIFTBWD_HALF_LO, VAMP_LIFTBWD_HALF_HI = 64, 128
 VAMP_LIFTBWD_LOGITS = 256
 VAMP_CAMBWD_ACCUMULATE, VAMP_CAMBWD_PACKED_VALID, VAMP_CAMBWD_CELLS_VALID, VAMP_CAMBWD_SPLAT = 1, 2, 4, 8
 VAMP_CAMBWD_SAMPLES_VALID, VAMP_CAMBWD_TERM_VALID, VAMP_CAMBWD_NO_ERT = 16, 32, 64
 VAMP_CAMBWD_PART_RAY, VAMP_CAMBWD_PART_GATHER, VAMP_CAMBWD_PART_HEAVY = 128, 256, 512
 VAMP_CAMFWD_SAVE_SAMPLES, VAMP_CAMFWD_NO_ERT, VAMP_CAMFWD_TERM_VALID = 1, 2, 4
-VAMP_CAMPREP_TERM_VALID, VAMP_CAMPREP_RANK_ONLY, VAMP_CAMPREP_COUNTERS_CLEAN = 1, 2, 4
-VAMP_CAMBWD_SLOTS_PENDING = 1024
+VAMP_CAMPREP_TERM_VALID, VAMP_CAMPREP_COUNTERS_CLEAN = 1, 4
 VAMP_BEVBWD_OVERWRITE_BASE, VAMP_BEVBWD_OVERWRITE_CAM, VAMP_BEVBWD_SAVED_VALID = 1, 2, 4
 VAMP_BEVFWD_SAVE, VAMP_BEVFWD_TWO_KERNELS, VAMP_BEVFWD_HEIGHTS_LATTICE = 1, 2, 4
 VAMP_CAMFWD_PACK_ONLY, VAMP_CAMFWD_PACKED_VALID, VAMP_CAMFWD_DIRECT, VAMP_CAMFWD_EXACT_TAPS = 8, 16, 32, 64

@@ -1118,12 +1118,8 @@ int vamp_lift_backward_ex(const VampLiftDesc* d, const float* mats, const float*
     // boundaries at every size)
     const int wpp = (flags & VAMP_LIFTBWD_WPP1) ? 1 : (flags & VAMP_LIFTBWD_WPP4) ? 4
                     : (flags & VAMP_LIFTBWD_WPP16) ? 16 : 0;
-    // VAMP_LIFTBWD_HALF_LO / _HI: one half of the images (needs prepared cell lists: both halves
-    // read them, and whoever prepared them inside this call would race with the other half)
-    const int half = (flags & VAMP_LIFTBWD_HALF_LO) ? 1 : ((flags & VAMP_LIFTBWD_HALF_HI) ? 2 : 0);
-    VAMP_REQUIRE(half == 0 || (flags & VAMP_LIFTBWD_CELLS_VALID), "HALF_LO / HALF_HI need CELLS_VALID");
     return launch_lift_bwd_cell(d, mats, xs, ys, zs, depth, feat, grad_out, hits, grad_depth,
-                                grad_feat, w.cells, (flags & VAMP_LIFTBWD_CELLS_VALID) != 0, wpp, half,
+                                grad_feat, w.cells, (flags & VAMP_LIFTBWD_CELLS_VALID) != 0, wpp, /*half=*/0,
                                 (flags & VAMP_LIFTBWD_LOGITS) != 0, s);
   }
   VAMP_REQUIRE(!(flags & VAMP_LIFTBWD_LOGITS), "VAMP_LIFTBWD_LOGITS is a feature of the default (cell-list) backward");

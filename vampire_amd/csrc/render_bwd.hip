@@ -361,7 +361,7 @@ int vamp_render_camera_prepare_ex(const VampRenderDesc* d, const float* mats, co
   const RenderParams P = to_params(d);
   return launch_cam_prepare(d, P, mats, us, vs, ds, static_cast<char*>(workspace) + packed_bytes(d),
                             (flags & VAMP_CAMPREP_TERM_VALID) ? cam_term_ptr(d, workspace) : nullptr,
-                            (flags & VAMP_CAMPREP_RANK_ONLY) ? 1 : 0, static_cast<hipStream_t>(stream),
+                            /*phase=*/0, static_cast<hipStream_t>(stream),
                             (flags & VAMP_CAMPREP_COUNTERS_CLEAN) != 0);
 }
 
@@ -437,7 +437,7 @@ int vamp_render_camera_backward_acc(const VampRenderDesc* d, const float* geom, 
     return launch_cam_bwd_v2(d, P, mats, us, vs, ds, mids, beta, density_feature, semantic, rgb, g_rgb, g_seg, g_depth,
                              grad_density_feature, grad_semantic, grad_rgb, grad_beta, gpacked,
                              accumulate, static_cast<hipEvent_t>(wait_event),
-                             (flags & VAMP_CAMBWD_CELLS_VALID) ? ((flags & VAMP_CAMBWD_SLOTS_PENDING) ? 2 : 1) : 0,
+                             (flags & VAMP_CAMBWD_CELLS_VALID) ? 1 : 0,
                              samples, term, parts, s);
   }
   VAMP_REQUIRE(!accumulate && !wait_event, "accumulate / wait_event need the cell-list path");
