@@ -154,6 +154,45 @@ def test_lift_backward_tiny(tiny_common, dev):
     close(fd.grad, g["grad_feat"], atol=1e-5, rtol=1e-5, scale="max", chan_dim=2, what="dense grad_feat")
 
 
+@pytest.mark.parametrize("C_", [8, 32, 48, 64])
+def test_lift_channel_counts(tiny_common, dev, C_):
+    """The lift at the channel counts the fixtures do not have (they are C = 4; cfg-A / B / D are 16): 8 (one chunk of
+    8), 32 / 48 / 64 (chunks of 16; 48 takes the transpose tile's non-power-of-two path), forward with and without
+    the pair emission and backward, against the oracle with autograd on the tiny geometry."""
+    from oracle import aten_oracle as O
+    g = tiny_common
+    cfg = dataclasses.replace(CFG_TINY, mid_channels=C_)
+    hp = hot(cfg, dev)
+    geo = PathGeometry(cfg)
+    lm, _ = tiny_mats(g, dev)
+    gen = torch.Generator().manual_seed(100 + C_)
+    B, N = g["depth"].shape[:2]
+    feat = torch.randn(B, N, C_, cfg.fH, cfg.fW, generator=gen)
+    feat[:, :, 1, ::3] = 0.0                     # exact zeros in a channel: the per-channel hit count (bv2:509-512)
+    depth = g["depth"]
+    dr, fr = depth.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    ref = O.lift(dr, fr, geo.voxel_coords, None, None, None, None, cfg.final_dim, cfg.d_bound, prepared=g["lift_mats"])
+    gout = torch.randn(ref.shape, generator=gen)
+    # (voxels whose only samples are exact zeros carry a 1e6 factor, bv2:512: keep them out of the upstream gradient)
+    with torch.no_grad():
+        pix = O.ego_to_pixel(geo.voxel_coords, None, None, None, None, g["lift_mats"])
+        valid, grid = O.lift_valid_and_grid(pix, cfg.final_dim, cfg.d_bound)
+        ff = O.outer_depth_feat(depth, feat)
+        sm = torch.nn.functional.grid_sample(ff.flatten(0, 1), grid.flatten(0, 1), align_corners=False).reshape(B, N, C_, *ref.shape[2:])
+        fragile = ((sm.abs() < 1e-7) & valid.bool().unsqueeze(2)).any(dim=1)
+    gout[fragile] = 0.0
+    ref.backward(gout)
+    with torch.no_grad():
+        out0 = hp.lift(depth.to(dev), feat.to(dev), lm)
+    close(out0, ref.detach(), atol=1e-5, what=f"lift C={C_} (no grad)")
+    dd, fd = depth.to(dev).requires_grad_(True), feat.to(dev).requires_grad_(True)
+    out = hp.lift(dd, fd, lm)
+    close(out, ref.detach(), atol=1e-5, what=f"lift C={C_}")
+    out.backward(gout.to(dev))
+    close(dd.grad, dr.grad, atol=1e-5, rtol=1e-5, scale="max", what=f"grad_depth C={C_}")
+    close(fd.grad, fr.grad, atol=1e-5, rtol=1e-5, scale="max", chan_dim=2, what=f"grad_feat C={C_}")
+
+
 def test_lift_bilinear_variant(dev):
     g = load_golden("tiny_bilinear.npz")
     hp = hot(CFG_TINY, dev)
