@@ -298,7 +298,7 @@ int vamp_render_camera_forward(const VampRenderDesc* d, const float* geom, const
  * density's slope (d sigma / d s = 1 / (2 beta^2) = 50) turns into up to 2.1e-4 m of rendered depth and 1e-4 of a
  * semantic logit at cfg-A (worst of 10 000 elements; 6.5e-5 / 8.2e-5 at cfg-B).  With this flag the weights follow
  * the reference's coordinates (2.4e-5 m, 7.7e-5; the composited channels, which enter linearly, stay on the line)
- * and the kernel takes 59 instead of 47 us at cfg-B. */
+ * and the kernel takes ~57 instead of ~49 us at cfg-B. */
 #define VAMP_CAMFWD_EXACT_TAPS 64
 int vamp_render_camera_terminate(const VampRenderDesc* d, const float* mats, const float* us,
                                  const float* vs, const float* ds, const float* beta,

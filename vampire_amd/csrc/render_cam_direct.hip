@@ -336,9 +336,9 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
 #pragma unroll
   for (int k = 0; k < 16; ++k) bda_identity = bda_identity && m[32 + k] == ((k % 5 == 0) ? 1.0f : 0.0f);
   const SpanRcp span_r{rcp_refined(P.span[0]), rcp_refined(P.span[1]), rcp_refined(P.span[2])};
-  auto tap_density = [&](int i) -> VolTap {
-    const float* mm = m;
-    asm volatile("" : "+s"(mm));                    // (read the matrices again here: 40 scalars do not stay in registers)
+  // (`mm`: the matrices read again once per ROUND of the density phase, by the caller -- 40 scalars do not stay in
+  // registers across the kernel, and read again per sample the four samples of a round waited four times)
+  auto tap_density = [&](int i, const float* mm) -> VolTap {
     float x, y, z;
     if (bda_identity) frustum_point_rb_id(mm, rb, ds[i], x, y, z);
     else frustum_point_rb(mm, rb, ds[i], x, y, z);
@@ -412,11 +412,13 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
       bool in[G];
       PairTap pt[G];
       PairRaw raw[G][4];
+      const float* mround = m;
+      if (CHAIN) asm volatile("" : "+s"(mround));
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         in[g] = false; delta[g] = 0.f;
         if (idx[g] < S) {
-          const VolTap tp = CHAIN ? tap_density(idx[g]) : tap_at(idx[g]);
+          const VolTap tp = CHAIN ? tap_density(idx[g], mround) : tap_at(idx[g]);
           delta[g] = delta_at(idx[g]);                                                 // bv2:426
           in[g] = tp.inside;
           if (tp.inside) {

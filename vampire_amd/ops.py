@@ -115,7 +115,7 @@ class HotPath:
                      "cam_direct": {"1": True, "0": False}.get(os.environ.get("VAMP_CAM_DIRECT", "auto"), "auto"),
                      # the one-kernel camera forward with its density samples on the reference's own fp32 coordinate
                      # chain instead of the ray's fp64 line (VAMP_CAMFWD_EXACT_TAPS): rendered depth within 2.4e-5 m of
-                     # the reference instead of 2.1e-4 (cfg-A), kernel 59 instead of 47 us
+                     # the reference instead of 2.1e-4 (cfg-A), kernel ~57 instead of ~49 us
                      "cam_exact": os.environ.get("VAMP_CAM_EXACT", "0") == "1",
                      # the BEV forward as one kernel (render_bev_fused.hip); "0" = the two-kernel first
                      # implementation, the cross-check of the tests
