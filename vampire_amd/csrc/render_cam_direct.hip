@@ -155,6 +155,9 @@ __device__ long long g_direct_stamps[4096 * 8];
 #define VAMP_STAMP(k) do { } while (0)
 #endif
 
+#ifndef VAMP_DIRECT_LINE_PLAN
+#define VAMP_DIRECT_LINE_PLAN 1
+#endif
 constexpr int kDirectG = 4;               // depth indices a wave takes per round of the density phase
 #ifndef VAMP_DIRECT_CB
 #define VAMP_DIRECT_CB 4
@@ -361,10 +364,51 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
     return sqrtf(dx * dx + dy * dy + dz * dz);
   };
 
-  // ---- plan: depth indices of the tile that can hold inside samples (waves 0..3 plan 32 each)
-  if (sub < 4)
+  // ---- plan: depth indices of the tile that can hold inside samples.  The tile's samples at one depth index
+  // are an affine image of the pixel rectangle, so the box of its four corner rays bounds all 64 (ray_plan.hpp).
+  // Along an affine chain the corner rays' sample points are the LINES this kernel has just set up (lanes 0, 7,
+  // 56 and 63 of a wave hold them): a lane per depth index evaluates the four corners with 12 fp64 fma instead
+  // of two full fp32 chains per lane with their matrix, axis and lattice loads (round 5; the plan phase was a
+  // fifth of a tile's time).  The lines are the exact map; the box keeps its 0.05 voxel of slack for the
+  // rounding of the chain that decides the mask.  A non-affine chain takes plan_tile.
+  if (VAMP_DIRECT_LINE_PLAN && affine) {
+    __shared__ double cl[4][6];
+    if (sub == 0 && (lane == 0 || lane == 7 || lane == 56 || lane == 63)) {
+      double* c = cl[(lane == 0) ? 0 : (lane == 7 ? 1 : (lane == 56 ? 2 : 3))];
+      c[0] = L.ax; c[1] = L.bx; c[2] = L.ay; c[3] = L.by; c[4] = L.az; c[5] = L.bz;
+    }
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (i < kPlanMax) {
+      const double d = (double) ds[min(i, P.D - 1)];
+      float mn[3], mx[3];
+      bool fin = true;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const float f = (float) __builtin_fma(d, cl[k][2 * a + 1], cl[k][2 * a]);
+          fin = fin && fabsf(f) <= 1e30f;
+          mn[a] = k ? fminf(mn[a], f) : f;
+          mx[a] = k ? fmaxf(mx[a], f) : f;
+        }
+      }
+      const float slack = 0.05f;
+      const bool hit = mx[0] >= -slack && mn[0] <= (float) (P.X - 1) + slack &&
+                       mx[1] >= -slack && mn[1] <= (float) (P.Y - 1) + slack &&
+                       mx[2] >= -slack && mn[2] <= (float) (P.Z - 1) + slack;
+      int4 ent;
+      int lo, hi;
+      brick_axis(mn[0], mx[0], P.X, lo, hi); ent.x = lo | (hi << 16);
+      brick_axis(mn[1], mx[1], P.Y, lo, hi); ent.y = lo | (hi << 16);
+      brick_axis(mn[2], mx[2], P.Z, lo, hi); ent.z = lo | (hi << 16);
+      ent.w = (i < S && (hit || !fin)) ? 1 : 0;
+      plan[i] = ent;
+    }
+  } else if (sub < 4) {
     plan_tile(P, m, us, vs, ds, __builtin_amdgcn_readlane(w, 0), __builtin_amdgcn_readlane(w, 63),
               __builtin_amdgcn_readlane(h, 0), __builtin_amdgcn_readlane(h, 63), sub, plan);
+  }
   __syncthreads();
   PlanMask mk_all = plan_mask(plan);
   if (!affine) {
