@@ -1969,7 +1969,7 @@ def _sample_check(t, ref, key, what, rtol=1e-4, atol=0.0, abs_tol=None):
     return float(err.max()) / max(float(want.abs().max()), 1e-30), float(err.max())
 
 
-@pytest.mark.parametrize("exact", [False, True], ids=["line", "exact-taps"])
+@pytest.mark.parametrize("exact", [True, False], ids=["default", "line-taps"])
 @pytest.mark.parametrize("name,cfg,mode", [("A", CFG_A, "sdf"), ("B", CFG_B, "sdf"), ("Bnaive", CFG_B, "naive")])
 def test_full_size_elementwise_samples(dev, name, cfg, mode, exact):
     """The DEFAULT path (one-kernel camera forward, fused BEV forward, cell-list backward) at cfg-A / cfg-B,
@@ -2006,15 +2006,15 @@ def test_full_size_elementwise_samples(dev, name, cfg, mode, exact):
     torch.autograd.backward(outs, _upstream([o.shape for o in outs], 4343 if mode == "sdf" else 4545, dev))
     # the eight rendered tensors: 1e-4 ABSOLUTE per element (depth_preds reaches 70.4, seg logits 2.2: under the
     # scale-relative bound alone they would be allowed 5e-4 / 2e-4); the gradients: 1e-4 of the tensor's scale
-    # (depth_preds on the default coordinates -- the ray's exact line instead of the reference's fp32 chain, whose
-    # own rounding is a few ulp of a tap coordinate: 1e-5 voxel, times d sigma / d s = 50 of the Laplace density --
-    # is held to 3e-4 m = 4e-6 of its range (measured 2.1e-4 at cfg-A, 6.5e-5 at cfg-B); with the density samples
-    # on the reference's coordinates (exact-taps, VAMP_CAMFWD_EXACT_TAPS: 2.4e-5) to 1e-4 like the rest)
+    # (the default path -- density samples on the reference's own fp32 coordinate chain, VAMP_CAMFWD_EXACT_TAPS -- holds
+    # all eight to 1e-4 (depth_preds: 4.3e-5 m at cfg-A).  With VAMP_CAM_EXACT=0 the samples sit on the ray's exact
+    # line instead; the reference's chain deviates from it by a few ulp of a tap coordinate, 1e-5 voxel, times
+    # d sigma / d s = 50 of the Laplace density: depth_preds 2.2e-4 m at cfg-A, held to 3e-4 = 4e-6 of its range)
     for n_, o in zip(NAMES, outs):
         worst[n_] = _sample_check(o, ref, f"{name}_{n_}", n_, abs_tol=3e-4 if (n_ == "depth_preds" and not exact) else 1e-4)
     for k, v in zip(("density_feature", "semantic_logits", "base", "rgb"), vols):
         worst["grad_" + k] = _sample_check(v.grad, ref, f"{name}_grad_{k}", "grad_" + k)
-    tag = f"cfg-{name} ({'exact taps' if exact else 'line taps'})"
+    tag = f"cfg-{name} ({'default: exact taps' if exact else 'line taps'})"
     print(f"{tag} worst element error / scale:", {k: f"{v[0]:.1e}" for k, v in worst.items()})
     print(f"{tag} worst ABSOLUTE element error:", {k: f"{v[1]:.1e}" for k, v in worst.items()})
 

@@ -158,7 +158,18 @@ __device__ long long g_direct_stamps[4096 * 8];
 #ifndef VAMP_DIRECT_LINE_PLAN
 #define VAMP_DIRECT_LINE_PLAN 1
 #endif
-constexpr int kDirectG = 4;               // depth indices a wave takes per round of the density phase
+// depth indices a wave takes per round of the density phase.  With early termination ONE (round 5; was 4): the
+// tile stops at the first round after which all 64 rays are saturated, the typical tile keeps 8 leading samples,
+// and rounds of 16 indices marched 16 or 32 of them; with rounds of 4 the phase does a quarter of the work on
+// most tiles and the kernel drops from 166 to 126 registers (4 waves per SIMD) -- forward pair 118.5 -> 112 us.
+// Without early termination every active index is marched anyway and a barrier per 4 indices costs more than
+// the registers gain (one-kernel forward forced, termination off: G = 1 / 2 / 4 -> 254 / 238 / 248 us).
+#ifndef VAMP_DIRECT_G
+#define VAMP_DIRECT_G 1
+#endif
+#ifndef VAMP_DIRECT_G_NOERT
+#define VAMP_DIRECT_G_NOERT 2
+#endif
 #ifndef VAMP_DIRECT_CB
 #define VAMP_DIRECT_CB 4
 #endif
@@ -291,7 +302,7 @@ __device__ __forceinline__ RayId decode_tile(const RenderParams& P) {
 // A template parameter: as a run-time switch the second path cost the default one 3.7 us (47.1 -> 50.8) by its
 // registers alone.
 template <typename T, int NCH, bool ERT, int NW, bool CHAIN>
-__global__ void __launch_bounds__(NW * 64, 3)      // (3 waves per SIMD: 171 registers would be 2; ERT on 62 -> 57 us, off 225 -> 218)
+__global__ void __launch_bounds__(NW * 64, ERT ? 4 : 3)   // (termination off: 171 registers would be 2 waves per SIMD; on: 126 with rounds of one index per wave)
 cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const float* __restrict__ us,
                       const float* __restrict__ vs, const float* __restrict__ ds,
                       const float* __restrict__ mids, const float* __restrict__ beta_raw,
@@ -301,7 +312,7 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
   extern __shared__ __align__(16) float dyn[];
   __shared__ int4 plan[kPlanMax];
   __shared__ int keep_s[64];
-  __shared__ float accw_s[64], accd_s[64], tunit_s[64];
+  __shared__ float accd_s[64], tunit_s[64];
   __shared__ float part_s[2][NW][64];
   __shared__ unsigned char act_s[kPlanMax + 8];                  // the active depth indices, in order (then S)
   __shared__ unsigned char actf_s[kPlanMax];                     // 1 = active depth index
@@ -443,7 +454,7 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
   {
     const float tau_unit = tunit_s[lane];
     const __amdgpu_buffer_rsrc_t rs_d = make_rsrc(dens + (long) b * V, (size_t) V * sizeof(T));
-    constexpr int G = kDirectG, R = NW * G;
+    constexpr int G = ERT ? VAMP_DIRECT_G : VAMP_DIRECT_G_NOERT, R = NW * G;
     float carry = 0.f;                // sum of the active indices' tau so far (per ray)
     float d_inact = 0.f;              // sum of the skipped bins' depth extents so far (uniform)
     int cursor = 0;                   // depth index where the current round starts
@@ -526,31 +537,35 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
     const int L_ = (S_eff + SEG - 1) / SEG;
     const int a0 = min(S_eff, q * L_), a1 = min(S_eff, a0 + L_);
     const float tu = tunit_s[r];
-    float part = 0.f;
+    // (the running sums of the scan in fp64, each used once rounded to fp32: an fp32 running optical depth carries
+    // an ulp of ~10 per step, i.e. 1e-6 relative on every later weight, and sum w mid + (1 - sum w) d_far a few ulp
+    // of 70 m -- together 4e-5 m of depth that depend on how the samples fall into the four segments, i.e. on where
+    // early termination cut the tile.  The reference's fp32 cumsum has noise of the same size around the same value.)
+    double part = 0.0;
     for (int i = a0; i < a1; ++i) {
       const float tau = actf_s[i] ? wbuf[i * 64 + r] : tu * (ds[i + 1] - ds[i]);
       wbuf[i * 64 + r] = tau;
-      part += tau;
+      part += (double) tau;
     }
     // exclusive prefix over the segments of the ray (bv2:431-433: exclusive cumsum)
-    float incl = part;
+    double incl = part;
 #pragma unroll
     for (int o = 1; o < SEG; o <<= 1) {
-      const float up = __shfl_up(incl, o * RPW, 64);
+      const double up = __shfl_up(incl, o * RPW, 64);
       if (q >= o) incl += up;
     }
-    float cum = incl - part;
+    double cum = incl - part;
     int keep = S;
-    float aw = 0.f, ad = 0.f;
+    double aw = 0.0, ad = 0.0;
     for (int i = a0; i < a1; ++i) {
       const float tau = wbuf[i * 64 + r];
-      const float wgt = composite_weight(tau, cum);                // bv2:430-434
+      const float wgt = composite_weight(tau, (float) cum);        // bv2:430-434
       wbuf[i * 64 + r] = wgt;
-      aw += wgt;
-      ad = __builtin_fmaf(wgt, mids[i], ad);
-      cum += tau;
+      aw += (double) wgt;
+      ad = __builtin_fma((double) wgt, (double) mids[i], ad);
+      cum += (double) tau;
       // samples 0 .. i are kept; the optical depth in front of sample i + 1 is `cum`
-      if (ERT && keep == S && !(cum < kTermOpticalDepth)) keep = i + 1;
+      if (ERT && keep == S && !(cum < (double) kTermOpticalDepth)) keep = i + 1;
     }
 #pragma unroll
     for (int o = RPW; o < 64; o <<= 1) {
@@ -558,7 +573,7 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
       ad += __shfl_xor(ad, o, 64);
       keep = min(keep, __shfl_xor(keep, o, 64));
     }
-    if (q == 0) { keep_s[r] = min(keep, S_eff < S ? S_eff : S); accw_s[r] = aw; accd_s[r] = ad; }
+    if (q == 0) { keep_s[r] = min(keep, S_eff < S ? S_eff : S); accd_s[r] = (float) (ad + (1.0 - aw) * (double) P.d_far); }   // bv2:436,440
   }
   __syncthreads();
   VAMP_STAMP(3);
@@ -660,7 +675,7 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
       else rgb_out[((long) bn * 3 + (c - Kc)) * HW + pix] = t;
     }
     if (sub == 0) {
-      depth_out[(long) bn * HW + pix] = accd_s[lane] + (1.0f - accw_s[lane]) * P.d_far;   // bv2:436,440
+      depth_out[(long) bn * HW + pix] = accd_s[lane];
       if (term_out) term_out[(long) bn * HW + pix] = keep;
     }
   }

@@ -114,9 +114,10 @@ class HotPath:
                      # of the last calls (_camera_forward_choice); True / False force one
                      "cam_direct": {"1": True, "0": False}.get(os.environ.get("VAMP_CAM_DIRECT", "auto"), "auto"),
                      # the one-kernel camera forward with its density samples on the reference's own fp32 coordinate
-                     # chain instead of the ray's fp64 line (VAMP_CAMFWD_EXACT_TAPS): rendered depth within 2.4e-5 m of
-                     # the reference instead of 2.1e-4 (cfg-A), kernel ~57 instead of ~49 us
-                     "cam_exact": os.environ.get("VAMP_CAM_EXACT", "0") == "1",
+                     # chain instead of the ray's fp64 line (VAMP_CAMFWD_EXACT_TAPS): rendered depth within 4.3e-5 m of
+                     # the reference instead of 2.2e-4 (cfg-A; the bar is 1e-4), forward pair 115.5 instead of 112.8 us.
+                     # On by default since the kernel runs at 4 waves per SIMD (round 5); "0" = the line
+                     "cam_exact": os.environ.get("VAMP_CAM_EXACT", "1") != "0",
                      # the BEV forward as one kernel (render_bev_fused.hip); "0" = the two-kernel first
                      # implementation, the cross-check of the tests
                      "bev_fused": os.environ.get("VAMP_BEV_FUSED", "1") != "0",
