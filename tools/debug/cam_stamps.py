@@ -26,18 +26,29 @@ lib.vamp_debug_direct_stamps.argtypes = [C.c_void_p, C.c_size_t]
 assert lib.vamp_debug_direct_stamps(buf, n * 8) == 0
 a = np.frombuffer(buf, dtype=np.int64).reshape(n, 8)
 t = a[:, :6].astype(np.float64)
-t0 = t[:, 0].min()
-ph = np.diff(t, axis=1) / 100.0            # s_memtime ticks at 100 MHz -> us
-start = (t[:, 0] - t0) / 100.0
-end = (t[:, 5] - t0) / 100.0
+# s_memtime counts shader-clock cycles (2.4 GHz here), and every XCD has its own counter: tile durations are
+# comparable everywhere, start / end offsets only inside an XCD (workgroup b runs on XCD b % 8)
+TICKS_PER_US = float(os.environ.get("VAMP_STAMP_TICKS_PER_US", "2400"))
+xcd = np.arange(n) & 7
+t0 = np.array([t[xcd == x, 0].min() for x in range(8)])[xcd]
+ph = np.diff(t, axis=1) / TICKS_PER_US
+start = (t[:, 0] - t0) / TICKS_PER_US
+end = (t[:, 5] - t0) / TICKS_PER_US
 A, Seff, Se = a[:, 6] >> 32, (a[:, 6] >> 16) & 0xffff, a[:, 6] & 0xffff
 names = ["plan", "density", "scan", "gather", "merge"]
 print("tiles", n, "kernel span (first start -> last end) %.1f us" % end.max())
 print("start offsets: median %.1f  p90 %.1f  max %.1f us" % (np.median(start), np.percentile(start, 90), start.max()))
 for i, nm in enumerate(names):
     print("%-8s mean %6.2f  median %6.2f  p90 %6.2f  max %6.2f us" % (nm, ph[:, i].mean(), np.median(ph[:, i]), np.percentile(ph[:, i], 90), ph[:, i].max()))
-tot = (t[:, 5] - t[:, 0]) / 100.0
+tot = (t[:, 5] - t[:, 0]) / TICKS_PER_US
 print("tile total: mean %.2f median %.2f p90 %.2f max %.2f" % (tot.mean(), np.median(tot), np.percentile(tot, 90), tot.max()))
+print("end offsets (per XCD): median %.1f  p90 %.1f  p99 %.1f  max %.1f us" % (np.median(end), np.percentile(end, 90), np.percentile(end, 99), end.max()))
+print("tiles that START after 5 us: %d (mean start %.1f us)" % ((start > 5).sum(), start[start > 5].mean() if (start > 5).any() else 0))
+for lo, hi in ((0, 8), (8, 16), (16, 32), (32, 64), (64, 200)):
+    m = (Se >= lo) & (Se < hi)
+    if m.any():
+        print("  Se in [%3d, %3d): %4d tiles, total mean %.1f us (plan %.1f dens %.1f scan %.1f gather %.1f merge %.1f), S_eff mean %.0f" % (
+            lo, hi, m.sum(), tot[m].mean(), *[ph[m, i].mean() for i in range(5)], Seff[m].mean()))
 print("A (active indices): mean %.1f max %d;  S_eff mean %.1f;  Se mean %.1f max %d" % (A.mean(), A.max(), Seff.mean(), Se.mean(), Se.max()))
 order = np.argsort(-end)[:12]
 print("last tiles to finish: blk start end | plan dens scan gath merge | A S_eff Se")
