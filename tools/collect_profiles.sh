@@ -15,6 +15,7 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- 
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/tools/time_bwd.py $CFG $BATCH > /dev/null 2> $OUT/pmc_write.log
 cd $ROOT
 python3 tools/summarize_profiles.py $OUT $TAG $CFG $BATCH
+rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write      # (the raw traces: gpurun merges at most 64 MiB back)
 # the same three passes with early ray termination OFF (the data-independent path): VAMP_ERT=0 is read by
 # vampire_amd.ops at import; exported here so that rocprofv3 launches python itself (no env wrapper)
 export VAMP_ERT=0
@@ -26,4 +27,5 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT2/pmc_fetch --
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT2/pmc_write -- python3 $ROOT/tools/time_bwd.py $CFG $BATCH > /dev/null 2> $OUT2/pmc_write.log
 cd $ROOT
 python3 tools/summarize_profiles.py $OUT2 ${TAG}_noert $CFG $BATCH > /dev/null
+rm -rf $OUT2/stats $OUT2/pmc_fetch $OUT2/pmc_write
 unset VAMP_ERT
