@@ -357,7 +357,7 @@ def layered_measure(cfg, dev, batch_per_gpu, rank, world, steps=6, warm=3, find=
                     "voxel_output: forward + backward from synthetic neck features"}
 
 
-def multitask_measure(dev, batch_per_gpu, rank, world, steps=4, warm=2, find=False):
+def multitask_measure(dev, batch_per_gpu, rank, world, steps=6, warm=3, find=False):
     """BASELINE.json configs[4]: the full multi-task model -- ResNet-50 + SECOND FPN image encoder, the
     backbone with the HIP lift / render / query / gate operators, the CenterPoint-style BEV head -- on the
     reference's own configuration (cfg-A: 256 x 704 images, 256 x 256 x 20 seg grid, base_exp.py:40-252),
