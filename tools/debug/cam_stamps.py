@@ -49,6 +49,16 @@ for lo, hi in ((0, 8), (8, 16), (16, 32), (32, 64), (64, 200)):
     if m.any():
         print("  Se in [%3d, %3d): %4d tiles, total mean %.1f us (plan %.1f dens %.1f scan %.1f gather %.1f merge %.1f), S_eff mean %.0f" % (
             lo, hi, m.sum(), tot[m].mean(), *[ph[m, i].mean() for i in range(5)], Seff[m].mean()))
+wall = a[:, 7].astype(np.uint64)
+w0 = (wall >> np.uint64(32)).astype(np.float64) / 100.0
+w1 = (wall & np.uint64(0xffffffff)).astype(np.float64) / 100.0
+base = w0.min()
+w0 -= base; w1 -= base
+print("WALL CLOCK (100 MHz, device-wide): kernel span %.1f us; tile starts: p50 %.1f p90 %.1f p97 %.1f max %.1f; tile ends: p50 %.1f p90 %.1f p99 %.1f max %.1f" % (
+    w1.max(), np.median(w0), np.percentile(w0, 90), np.percentile(w0, 97), w0.max(), np.median(w1), np.percentile(w1, 90), np.percentile(w1, 99), w1.max()))
+late = np.argsort(-w1)[:10]
+print("last tiles by wall clock: blk start end Se S_eff:", [(int(b), round(float(w0[b]), 1), round(float(w1[b]), 1), int(Se[b]), int(Seff[b])) for b in late])
+print("tiles starting after 5 us: %d" % int((w0 > 5).sum()))
 print("A (active indices): mean %.1f max %d;  S_eff mean %.1f;  Se mean %.1f max %d" % (A.mean(), A.max(), Seff.mean(), Se.mean(), Se.max()))
 order = np.argsort(-end)[:12]
 print("last tiles to finish: blk start end | plan dens scan gath merge | A S_eff Se")
