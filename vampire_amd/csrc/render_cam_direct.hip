@@ -333,6 +333,9 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
   const int Kc = NCH == 21 ? 18 : P.K;
   const int nch = Kc + 3;
   VAMP_STAMP(0);
+#ifdef VAMP_DIRECT_STAMPS
+  const long long wall0 = wall_clock64();                          // 100 MHz, one clock for the whole device
+#endif
   // the ray as a line in tap coordinates; `affine`: the chain is affine in the depth (see RayLine)
   const bool affine = m[2] == 0.0f && m[6] == 0.0f;               // uniform
   const RayLine L = ray_line(m, P, u, v, ds[0], ds[S]);
@@ -680,6 +683,10 @@ cam_fwd_direct_kernel(RenderParams P, const float* __restrict__ mats, const floa
     }
   }
   VAMP_STAMP(5);
+#ifdef VAMP_DIRECT_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 4096)
+    g_direct_stamps[blockIdx.x * 8 + 7] = (long long) (((unsigned long long) (wall0 & 0xffffffffll) << 32) | (unsigned long long) (wall_clock64() & 0xffffffffll));
+#endif
 }
 
 #ifdef VAMP_DIRECT_STAMPS
