@@ -136,6 +136,15 @@ __device__ __forceinline__ void cell_accumulate(const CellRanges& cr, int k0, in
   }
 }
 
+template <int CP4>
+__device__ __forceinline__ void cam_heavy_drain(const RenderParams& P, const int* __restrict__ off,
+                                                const int* __restrict__ boff, const float4* __restrict__ R,
+                                                const float* __restrict__ Gcl, float* __restrict__ gdens,
+                                                float* __restrict__ gsem, float* __restrict__ grgb,
+                                                const int* __restrict__ heavy, const int* __restrict__ nheavy,
+                                                long ncell_b, int accumulate, int first, int stride,
+                                                float (&part)[4][CP4 * 4]);
+
 // CGL lanes per voxel, 256 / CGL voxels (an x-run) per workgroup
 template <int CP4, int CGL>
 __global__ void __launch_bounds__(256, 5)
