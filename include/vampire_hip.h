@@ -296,9 +296,9 @@ int vamp_render_camera_forward(const VampRenderDesc* d, const float* geom, const
  * instead of the ray's line in fp64.  The line is the correctly rounded value of the exact map; the reference's
  * chain deviates from it by its own rounding, a few ulp of the tap coordinate (1e-5 voxel) -- which the Laplace
  * density's slope (d sigma / d s = 1 / (2 beta^2) = 50) turns into up to 2.1e-4 m of rendered depth and 1e-4 of a
- * semantic logit at cfg-A (worst of 10 000 elements; 6.5e-5 / 8.2e-5 at cfg-B).  With this flag the weights follow
- * the reference's coordinates (2.4e-5 m, 7.7e-5; the composited channels, which enter linearly, stay on the line)
- * and the kernel takes ~57 instead of ~49 us at cfg-B. */
+ * semantic logit at cfg-A (worst of 10 000 elements; 7.2e-5 / 8.2e-5 at cfg-B).  With this flag the weights follow
+ * the reference's coordinates (4.3e-5 m, 7.7e-5; the composited channels, which enter linearly, stay on the line)
+ * and the kernel takes ~43 instead of ~40 us at cfg-B.  The Python host sets it by default. */
 #define VAMP_CAMFWD_EXACT_TAPS 64
 int vamp_render_camera_terminate(const VampRenderDesc* d, const float* mats, const float* us,
                                  const float* vs, const float* ds, const float* beta,
