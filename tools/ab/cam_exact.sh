@@ -1,4 +1,5 @@
 #!/bin/bash
+# GPU box: forward pair and replayed step with the density samples on the reference chain (1) / the ray line (0)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 for r in 1 2 3; do
   for x in 0 1; do

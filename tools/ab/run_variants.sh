@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: time the ablation libraries built by tools/ablate.sh (usage: tools/r5_abl.sh <script> <args> -- name...)
+# GPU box: time the ablation libraries built by tools/ablate.sh (usage: tools/ab/run_variants.sh <script> <args> -- name...)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
 CMD=()

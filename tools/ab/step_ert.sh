@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: A/B of library variants (vampire_amd/_lib/abl_<name>.so; "" = the shipped one) on the replayed
-# training step with early ray termination on and off.  usage: tools/r5_ab.sh name...
+# training step with early ray termination on and off.  usage: tools/ab/step_ert.sh name...
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 for r in 1 2; do
   for v in "" "$@"; do

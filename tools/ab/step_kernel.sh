@@ -9,5 +9,5 @@ for r in 1 2; do
 done
 for v in "" "$@"; do
   if [ -n "$v" ]; then export VAMPIRE_HIP_LIB=$ROOT/vampire_amd/_lib/abl_$v.so; else unset VAMPIRE_HIP_LIB; fi
-  echo "== ${v:-default}"; $ROOT/tools/r5_steptl.sh B 2>&1 | grep "${KERNEL:-cam_bwd_ray}\|span"
+  echo "== ${v:-default}"; $ROOT/tools/step_timeline.sh B 2>&1 | grep "${KERNEL:-cam_bwd_ray}\|span"
 done

@@ -1,5 +1,7 @@
+"""Debug aid (GPU box): the data-chosen camera forward in one density regime -- which forward the calls take and what a
+step costs.  usage: tools/debug/selector_regimes.py [naive|sdf]"""
 import os, sys, time, dataclasses, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from vampire_amd.config import PRESETS
 from vampire_amd.step import LiftRenderStep, SyntheticBatch, train_step
 mode = sys.argv[1] if len(sys.argv) > 1 else "naive"
