@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VAMP_ABI_VERSION 5   /* bumped whenever entry points or flags are added (round 2: 2, round 3: 3, round 4: 4, round 5: 5) */
+#define VAMP_ABI_VERSION 6   /* bumped whenever entry points or flags are added (round 2: 2, round 3: 3, round 4: 4, round 5: 5, round 6: 6) */
 
 enum {
   VAMP_OK = 0,
@@ -292,13 +292,12 @@ int vamp_render_camera_forward(const VampRenderDesc* d, const float* geom, const
  * per-ray table is written into `workspace` as a by-product when workspace_bytes >=
  * vamp_render_workspace_bytes(d) (workspace may be NULL otherwise).  Combines with NO_ERT. */
 #define VAMP_CAMFWD_DIRECT 32
-/* with DIRECT: the DENSITY samples' tap coordinates from the reference's own fp32 chain (bv2:328-349, 397-404)
- * instead of the ray's line in fp64.  The line is the correctly rounded value of the exact map; the reference's
- * chain deviates from it by its own rounding, a few ulp of the tap coordinate (1e-5 voxel) -- which the Laplace
- * density's slope (d sigma / d s = 1 / (2 beta^2) = 50) turns into up to 2.1e-4 m of rendered depth and 1e-4 of a
- * semantic logit at cfg-A (worst of 10 000 elements; 7.2e-5 / 8.2e-5 at cfg-B).  With this flag the weights follow
- * the reference's coordinates (4.3e-5 m, 7.7e-5; the composited channels, which enter linearly, stay on the line)
- * and the kernel takes ~43 instead of ~40 us at cfg-B.  The Python host sets it by default. */
+/* With DIRECT the DENSITY samples' tap coordinates come from the reference's own fp32 chain (bv2:328-349, 397-404):
+ * the ray's exact line in fp64 deviates from that chain by the chain's rounding, a few ulp of a tap coordinate, which
+ * the Laplace density's slope (1 / (2 beta^2) = 50) turns into up to 2.2e-4 m of rendered depth at cfg-A -- outside
+ * north_star's 1e-4.  Through ABI 5 the chain was this flag and the line the default of the C entry point; since
+ * ABI 6 the chain is the only behaviour (rendered depth within 4.3e-5 m, semantic logits 7.7e-5 at cfg-A) and the flag
+ * is accepted and ignored. */
 #define VAMP_CAMFWD_EXACT_TAPS 64
 int vamp_render_camera_terminate(const VampRenderDesc* d, const float* mats, const float* us,
                                  const float* vs, const float* ds, const float* beta,
@@ -417,15 +416,45 @@ int vamp_render_bev_forward(const VampRenderDesc* d, const float* oxs, const flo
  * same workspace with VAMP_BEVBWD_SAVED_VALID reads them back instead of sampling again.
  */
 #define VAMP_BEVFWD_SAVE 1
-#define VAMP_BEVFWD_HEIGHTS_LATTICE 4  /* the caller asserts that ozs is an ascending lattice with spacing det_step[2] (what the reference's create_voxel_coords makes, bv2:273-293): only then does the one-kernel forward run -- it sizes its per-wave plane slab from that spacing; any other array takes the two-kernel path */
 #define VAMP_BEVFWD_TWO_KERNELS 2   /* the first implementation (density pass + channel-pair pass) instead of the one-kernel forward of render_bev_fused.hip: kept as the cross-check of the tests */
+/* ozs_host (ABI 6; was the caller-asserted flag VAMP_BEVFWD_HEIGHTS_LATTICE = 4): a HOST copy of ozs, or NULL.  The
+ * one-kernel forward sizes its per-wave plane slabs for a lattice of heights with spacing det_step[2] (what the
+ * reference's create_voxel_coords makes, bv2:273-293) and would clamp -- silently -- a plane outside them, so it runs
+ * only when the library has CHECKED, on ozs_host, that the heights' z taps fit the slabs; NULL, or an array that does
+ * not fit (any jittered / non-uniform ozs), takes the two-kernel path, which handles every height on its own. */
 int vamp_render_bev_forward_ex(const VampRenderDesc* d, const float* oxs, const float* oys,
                             const float* ozs, const float* bev_mids, const float* beta,
                             const void* density_feature, const void* semantic,
                             const void* rgb, const void* base, float* bev_rgb,
                             float* bev_seg, float* bev_height, float* voxel_density,
-                            float* voxel_output, void* workspace,
+                            float* voxel_output, const float* ozs_host, void* workspace,
                             size_t workspace_bytes, int flags, void* stream);
+
+/*
+ * The render forward as ONE launch (ABI 6): volume_rendering_from_multiple_views, bv2:396-467 -- camera branch
+ * (bv2:396-440) and BEV branch (bv2:408-418, 442-461) consume the same four volumes in the reference's one function,
+ * and here in one grid: the camera branch's 8 x 8 ray tiles are the first workgroups, the BEV branch's column blocks
+ * the ones behind them, so the BEV blocks fill the slots the camera tiles' long tail leaves idle (no fork, no event,
+ * no second queue).  Same results as vamp_render_camera_forward_ex(VAMP_CAMFWD_DIRECT) + vamp_render_bev_forward_ex
+ * bit for bit (the same device functions).  Early ray termination is on (the data-independent forward keeps its two
+ * launches).  Arguments as in those two calls; `workspace` (>= vamp_render_workspace_bytes(d), plus
+ * vamp_render_samples_bytes(d) with VAMP_RENDERFWD_SAVE_SAMPLES) receives the termination table and the kept sample
+ * rows, `bev_workspace` (vamp_render_bev_workspace_bytes(d), only with VAMP_RENDERFWD_BEV_SAVE) the BEV samples.
+ * vamp_render_forward_merged_supported: 1 when the shapes qualify (at most 128 samples per ray, the one-kernel BEV
+ * forward's limits) AND ozs_host fits the BEV slabs (see vamp_render_bev_forward_ex); the call itself returns
+ * VAMP_EINVAL otherwise -- the caller then issues the two calls.
+ */
+#define VAMP_RENDERFWD_SAVE_SAMPLES 1   /* = VAMP_CAMFWD_SAVE_SAMPLES */
+#define VAMP_RENDERFWD_BEV_SAVE 2       /* = VAMP_BEVFWD_SAVE */
+int vamp_render_forward_merged_supported(const VampRenderDesc* d, const float* ozs_host);
+int vamp_render_forward_merged(const VampRenderDesc* d, const float* mats, const float* us, const float* vs,
+                               const float* ds, const float* mids, const float* oxs, const float* oys,
+                               const float* ozs, const float* ozs_host, const float* bev_mids, const float* beta,
+                               const void* density_feature, const void* semantic, const void* rgb,
+                               const void* base, float* rgb_out, float* seg_out, float* depth_out,
+                               float* bev_rgb, float* bev_seg, float* bev_height, float* voxel_density,
+                               float* voxel_output, void* workspace, size_t workspace_bytes,
+                               void* bev_workspace, size_t bev_workspace_bytes, int flags, void* stream);
 
 /*
  * BEV branch, backward.  The four volume gradients are ACCUMULATED into (so that

@@ -6,6 +6,18 @@ from vampire_amd import _capi
 from vampire_amd.ops import render_forward_plan
 
 
+def test_merged_schedules():
+    """The one-launch render forward stands for "cam" + "bev": exactly where the one-kernel camera forward with early
+    termination runs forward-only, never otherwise."""
+    for train, two, prep_ok, direct, ert in itertools.product((False, True), repeat=5):
+        plan = render_forward_plan(train, two, prep_ok, direct, ert, merged=True)
+        ops = [p[0] for p in plan]
+        if direct and ert and not train:
+            assert ops == ["render"] and plan[0][1] == "cur", ((train, two, prep_ok, direct, ert), ops)
+        else:
+            assert plan == render_forward_plan(train, two, prep_ok, direct, ert), (train, two, prep_ok, direct, ert)
+
+
 def test_every_schedule_is_well_formed():
     for train, two, prep_ok, direct, ert in itertools.product((False, True), repeat=5):
         plan = render_forward_plan(train, two, prep_ok, direct, ert)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The no-grad forward pair (bench.py's fwd_roofline protocol) captured in a HIP graph and replayed.
-usage: tools/fwd_graph.py [cfg] [batch] [replays] [overlap 0|1]
+usage: tools/fwd_graph.py [cfg] [batch] [replays] [overlap 0|1] [impl overrides: key=0|1 ...]
 Under `rocprofv3 --kernel-trace` + tools/debug/graph_timeline.py it gives the kernel timeline of a replay."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,6 +14,9 @@ dev = torch.device("cuda:0")
 model = LiftRenderStep(cfg, dev)
 batch = SyntheticBatch(cfg, B, dev)
 hp = model.hp
+for kv in sys.argv[5:]:
+    k, v = kv.split("=")
+    hp.impl[k] = {"0": False, "1": True}.get(v, v)
 with torch.no_grad():
     def fwd():
         return model(batch.depth, batch.feat, batch.vols, batch.lift_mats, batch.render_mats)
@@ -40,4 +43,10 @@ with torch.no_grad():
         a.record(); g.replay(); b.record(); b.synchronize()
         ts.append(a.elapsed_time(b) * 1e3)
     ts.sort()
-print(f"forward pair replayed (overlap={overlap}): median {ts[len(ts)//2]:.1f} us, p10 {ts[len(ts)//10]:.1f}, p90 {ts[9*len(ts)//10]:.1f}")
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        g.replay()
+    b.record(); b.synchronize()
+    b2b = a.elapsed_time(b) * 1e3 / n
+print(f"forward pair replayed (overlap={overlap} {' '.join(sys.argv[5:])}): back to back {b2b:.1f} us; median {ts[len(ts)//2]:.1f} us, p10 {ts[len(ts)//10]:.1f}, p90 {ts[9*len(ts)//10]:.1f}")

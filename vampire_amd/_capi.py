@@ -9,7 +9,7 @@ import os
 
 from .build import lib_path
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 VAMP_F32, VAMP_BF16, VAMP_F16 = 0, 1, 2
 VAMP_DENSITY_SIGMOID, VAMP_DENSITY_SDF_LAPLACE = 0, 1
@@ -68,7 +68,8 @@ VAMP_CAMBWD_PART_RAY, VAMP_CAMBWD_PART_GATHER, VAMP_CAMBWD_PART_HEAVY = 128, 256
 VAMP_CAMFWD_SAVE_SAMPLES, VAMP_CAMFWD_NO_ERT, VAMP_CAMFWD_TERM_VALID = 1, 2, 4
 VAMP_CAMPREP_TERM_VALID, VAMP_CAMPREP_COUNTERS_CLEAN = 1, 4
 VAMP_BEVBWD_OVERWRITE_BASE, VAMP_BEVBWD_OVERWRITE_CAM, VAMP_BEVBWD_SAVED_VALID = 1, 2, 4
-VAMP_BEVFWD_SAVE, VAMP_BEVFWD_TWO_KERNELS, VAMP_BEVFWD_HEIGHTS_LATTICE = 1, 2, 4
+VAMP_BEVFWD_SAVE, VAMP_BEVFWD_TWO_KERNELS = 1, 2
+VAMP_RENDERFWD_SAVE_SAMPLES, VAMP_RENDERFWD_BEV_SAVE = 1, 2
 VAMP_CAMFWD_PACK_ONLY, VAMP_CAMFWD_PACKED_VALID, VAMP_CAMFWD_DIRECT, VAMP_CAMFWD_EXACT_TAPS = 8, 16, 32, 64
 VAMP_BEVBWD_ONLY_BASE, VAMP_BEVBWD_SKIP_BASE, VAMP_BEVBWD_TABLE_VALID = 8, 16, 32
 
@@ -111,7 +112,10 @@ SIGNATURES = {
     "vamp_render_camera_prepare": (C.c_int, [_RD] + [_P] * 4 + [_P, C.c_size_t, _P]),
     "vamp_render_camera_backward_acc": (C.c_int, [_RD] + [_P] * 17 + [_P, C.c_size_t, C.c_int, _P, _P]),
     "vamp_render_bev_forward": (C.c_int, [_RD] + [_P] * 14 + [_P]),
-    "vamp_render_bev_forward_ex": (C.c_int, [_RD] + [_P] * 14 + [_P, C.c_size_t, C.c_int, _P]),
+    "vamp_render_bev_forward_ex": (C.c_int, [_RD] + [_P] * 14 + [C.POINTER(C.c_float), _P, C.c_size_t, C.c_int, _P]),
+    "vamp_render_forward_merged_supported": (C.c_int, [_RD, C.POINTER(C.c_float)]),
+    "vamp_render_forward_merged": (C.c_int, [_RD] + [_P] * 8 + [C.POINTER(C.c_float)] + [_P] * 14
+                                   + [_P, C.c_size_t, _P, C.c_size_t, C.c_int, _P]),
     "vamp_render_bev_workspace_bytes": (C.c_size_t, [_RD]),
     "vamp_render_bev_backward": (C.c_int, [_RD] + [_P] * 19 + [C.POINTER(C.c_float), _P, C.c_size_t, _P]),
     "vamp_render_bev_backward_ex": (C.c_int, [_RD] + [_P] * 19 + [C.POINTER(C.c_float), _P, C.c_size_t, C.c_int, _P]),

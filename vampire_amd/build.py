@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "_lib")
 LIBNAME = "libvampire_hip.so"
-SOURCES = ["runtime.hip", "lift.hip", "lift_bwd_cell.hip", "render_fwd.hip", "render_cam_direct.hip", "render_bwd.hip", "render_bwd_ray.hip", "render_bwd_cell.hip", "render_bev.hip", "render_bev_fused.hip", "sample_points.hip", "glue.hip", "gate_conv.hip", "voxel_pooling.hip", "upsample.hip", "conv3d.hip", "conv3d_bf16.hip"]
+SOURCES = ["runtime.hip", "lift.hip", "lift_bwd_cell.hip", "render_fwd.hip", "render_cam_direct.hip", "render_bwd.hip", "render_bwd_ray.hip", "render_bwd_cell.hip", "render_bev.hip", "render_bev_fused.hip", "render_fwd_merged.hip", "sample_points.hip", "glue.hip", "gate_conv.hip", "voxel_pooling.hip", "upsample.hip", "conv3d.hip", "conv3d_bf16.hip"]
 # -ffp-contract=off: the projection chains must round like the reference's fp32 ops
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"] + os.environ.get("VAMP_EXTRA_FLAGS", "").split()

@@ -46,7 +46,7 @@ enum ProfSlot {
   kProfPack, kProfCamFwd, kProfBevFwd, kProfCamBwd, kProfUnpack, kProfBevBwd, kProfMemset,
   kProfAux, kProfCamBwdBrick, kProfBevFwdCh, kProfBevBwdQ, kProfBevBwdGather, kProfLiftBwdV1,
   kProfLiftBwdCount, kProfLiftBwdFill, kProfCamBwdCount, kProfCamBwdFill, kProfCamBwdOwn, kProfCamBwdV1,
-  kProfGlueSoftmax, kProfGlueGate, kProfUpsample, kProfConvFwd, kProfConvDgrad, kProfConvWgrad, kProfCamTerm, kProfSlots
+  kProfGlueSoftmax, kProfGlueGate, kProfUpsample, kProfConvFwd, kProfConvDgrad, kProfConvWgrad, kProfCamTerm, kProfRenderFwdMerged, kProfSlots
 };
 struct ProfScope { int idx; };
 bool prof_enabled();

@@ -1375,8 +1375,8 @@ int vamp_render_bev_forward_ex(const VampRenderDesc* d, const float* oxs, const 
                                const float* ozs, const float* bev_mids, const float* beta,
                                const void* density_feature, const void* semantic, const void* rgb,
                                const void* base, float* bev_rgb, float* bev_seg, float* bev_height,
-                               float* voxel_density, float* voxel_output, void* workspace,
-                               size_t workspace_bytes, int flags, void* stream) {
+                               float* voxel_density, float* voxel_output, const float* ozs_host,
+                               void* workspace, size_t workspace_bytes, int flags, void* stream) {
   if (int e = validate(d)) return e;
   float *s0_save = nullptr, *ss_save = nullptr;
   if (flags & VAMP_BEVFWD_SAVE) {
@@ -1392,7 +1392,8 @@ int vamp_render_bev_forward_ex(const VampRenderDesc* d, const float* oxs, const 
   VAMP_REQUIRE(beta || d->density_mode == VAMP_DENSITY_SIGMOID, "beta is NULL");
   const RenderParams P = to_params(d);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (!(flags & VAMP_BEVFWD_TWO_KERNELS) && (flags & VAMP_BEVFWD_HEIGHTS_LATTICE) && bev_fwd_fused_supported(d))
+  // the one-kernel forward only for heights the library has checked against its plane slabs (bev_fused_heights_fit)
+  if (!(flags & VAMP_BEVFWD_TWO_KERNELS) && bev_fwd_fused_supported(d) && bev_fused_heights_fit(d, ozs_host))
     return launch_bev_fwd_fused(d, P, oxs, oys, ozs, bev_mids, beta, density_feature, semantic, rgb, base, bev_rgb,
                                 bev_seg, bev_height, voxel_density, voxel_output, s0_save, ss_save, s);
   dim3 g1((d->oX + 63) / 64, (d->oY + 3) / 4, d->B);
@@ -1410,6 +1411,48 @@ int vamp_render_bev_forward_ex(const VampRenderDesc* d, const float* oxs, const 
   if (d->in_dtype == VAMP_F32) VAMP_BEVF(float); else VAMP_BEVF(__hip_bfloat16);
 #undef VAMP_BEVF
   return check_launch("bev_channels_kernel");
+}
+
+int vamp_render_forward_merged_supported(const VampRenderDesc* d, const float* ozs_host) {
+  if (!d || validate(d)) return 0;
+  return render_fwd_merged_supported(d) && bev_fused_heights_fit(d, ozs_host) ? 1 : 0;
+}
+
+int vamp_render_forward_merged(const VampRenderDesc* d, const float* mats, const float* us, const float* vs,
+                               const float* ds, const float* mids, const float* oxs, const float* oys,
+                               const float* ozs, const float* ozs_host, const float* bev_mids, const float* beta,
+                               const void* density_feature, const void* semantic, const void* rgb,
+                               const void* base, float* rgb_out, float* seg_out, float* depth_out,
+                               float* bev_rgb, float* bev_seg, float* bev_height, float* voxel_density,
+                               float* voxel_output, void* workspace, size_t workspace_bytes,
+                               void* bev_workspace, size_t bev_workspace_bytes, int flags, void* stream) {
+  if (int e = validate(d)) return e;
+  VAMP_REQUIRE(mats && us && vs && ds && mids && oxs && oys && ozs && bev_mids, "null pointer");
+  VAMP_REQUIRE(density_feature && semantic && rgb && (base || d->C == 0), "null input volume");
+  VAMP_REQUIRE(rgb_out && seg_out && depth_out && bev_rgb && bev_seg && bev_height && voxel_density && voxel_output,
+               "null output");
+  VAMP_REQUIRE(beta || d->density_mode == VAMP_DENSITY_SIGMOID, "beta is NULL");
+  VAMP_REQUIRE(render_fwd_merged_supported(d), "shapes outside the merged launch's limits (vamp_render_forward_merged_supported)");
+  VAMP_REQUIRE(bev_fused_heights_fit(d, ozs_host), "ozs_host is NULL or the heights do not fit the BEV plane slabs (vamp_render_forward_merged_supported)");
+  const size_t base_bytes = vamp_render_workspace_bytes(d);
+  int* term = (workspace && workspace_bytes >= base_bytes) ? cam_term_ptr(d, workspace) : nullptr;
+  float* rows = nullptr;
+  if (flags & VAMP_RENDERFWD_SAVE_SAMPLES) {
+    const size_t need = base_bytes + vamp_render_samples_bytes(d);
+    if (!workspace || workspace_bytes < need)
+      return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) need);
+    rows = reinterpret_cast<float*>(static_cast<char*>(workspace) + base_bytes);
+  }
+  float *s0_save = nullptr, *ss_save = nullptr;
+  if (flags & VAMP_RENDERFWD_BEV_SAVE) {
+    if (!bev_workspace || bev_workspace_bytes < bev_ws_bytes(d))
+      return fail(VAMP_ENOSPC, "%s: bev_workspace %ld < %ld bytes", __func__, (long) bev_workspace_bytes, (long) bev_ws_bytes(d));
+    s0_save = reinterpret_cast<float*>(static_cast<char*>(bev_workspace) + bev_saved_offset(d));
+    ss_save = reinterpret_cast<float*>(static_cast<char*>(bev_workspace) + bev_saved_offset(d) + bev_one(d));
+  }
+  return launch_render_fwd_merged(d, to_params(d), mats, us, vs, ds, mids, oxs, oys, ozs, bev_mids, beta, density_feature,
+                                  semantic, rgb, base, rgb_out, seg_out, depth_out, term, rows, bev_rgb, bev_seg, bev_height,
+                                  voxel_density, voxel_output, s0_save, ss_save, static_cast<hipStream_t>(stream));
 }
 
 static int bev_zero_overwritten(const VampRenderDesc* d, int flags, float* gd, float* gs, float* gr,
@@ -1655,7 +1698,7 @@ int vamp_render_bev_forward(const VampRenderDesc* d, const float* oxs, const flo
                             const void* base, float* bev_rgb, float* bev_seg, float* bev_height,
                             float* voxel_density, float* voxel_output, void* stream) {
   return vamp_render_bev_forward_ex(d, oxs, oys, ozs, bev_mids, beta, density_feature, semantic, rgb, base,
-                                    bev_rgb, bev_seg, bev_height, voxel_density, voxel_output, nullptr, 0, 0,
+                                    bev_rgb, bev_seg, bev_height, voxel_density, voxel_output, nullptr, nullptr, 0, 0,
                                     stream);
 }
 

@@ -12,7 +12,6 @@ struct RenderParams {
   float sdf_bias, beta_min;
   int cat_seg;
   int CP;   // packed channels per voxel for the camera branch: 1 + K + 3 rounded up to 12/24/32
-  int exact_taps;   // one-kernel camera forward: every sample through the reference's fp32 chain (VAMP_CAMFWD_EXACT_TAPS)
 };
 
 inline RenderParams to_params(const VampRenderDesc* d) {
@@ -25,7 +24,6 @@ inline RenderParams to_params(const VampRenderDesc* d) {
   // CP is chosen from {12, 24, 32} so that only three kernel bodies are compiled
   const int need = 1 + d->K + 3;
   p.CP = need <= 12 ? 12 : (need <= 24 ? 24 : 32);
-  p.exact_taps = 0;
   return p;
 }
 
@@ -280,12 +278,56 @@ int launch_cam_fwd_direct(const VampRenderDesc* d, const RenderParams& P, const 
                           float* seg_out, float* depth_out, int* term_out, bool ert, float* rows, hipStream_t s);
 
 // render_bev_fused.hip: the BEV forward (density, weights, all channels) as one kernel
+#ifndef VAMP_BEVF_NWV
+#define VAMP_BEVF_NWV 4              // waves per column block
+#endif
+// Planes a lattice of oZ heights with spacing det_step[2] can touch (+ slack): what a wave's slab is sized for.
+inline int bev_planes_alloc(const VampRenderDesc* d) {
+  const float per = fabsf(d->det_step[2]) * (float) (d->Z - 1) / d->span[2];       // volume planes per height step
+  return (int) ceilf((float) (d->oZ - 1) * per) + 4;
+}
+// dynamic LDS of a column block: sigma [oZ][64] | weights [oZ][64] | density planes [NPA + 1][64] | per wave [NPA][64]
+inline size_t bev_fused_dyn_bytes(int oZ, int npa) {
+  return sizeof(float) * 64 * (2 * (size_t) oZ + (size_t) (VAMP_BEVF_NWV + 1) * npa + 1);
+}
+// Do the heights `ozs_host` (the caller's host copy of the device array) fit the slabs?  The kernel clamps a plane index
+// that falls outside [pmin, pmin + NPA) -- silently wrong values -- so the one-kernel forward runs only for arrays that
+// pass here: the z taps are evaluated with the kernel's own fp32 formula (bev_axis) and must span at most NPA - 1
+// planes (one plane of margin for a floor that rounds differently on the host).  The reference's lattice
+// (create_voxel_coords, bv2:273-293) passes by construction of bev_planes_alloc; any other array takes the two-kernel
+// path, which handles every height on its own.
+inline bool bev_fused_heights_fit(const VampRenderDesc* d, const float* ozs_host) {
+  if (!ozs_host || d->oZ < 1) return false;
+  int pmin = 0, pmax = 0;
+  for (int j = 0; j < d->oZ; ++j) {
+    const float pos = ozs_host[j];
+    if (!(fabsf(pos) <= 3.0e38f)) return false;
+    const float g = ((pos - d->lo[2]) / d->span[2]) * 2.0f - 1.0f;
+    const float f = ((g + 1.0f) / 2.0f) * (float) (d->Z - 1);
+    if (!(fabsf(f) < 1.0e9f)) return false;
+    const int i0 = (int) floorf(f);
+    pmin = j ? (i0 < pmin ? i0 : pmin) : i0;
+    pmax = j ? (i0 + 1 > pmax ? i0 + 1 : pmax) : i0 + 1;
+  }
+  return pmax - pmin + 2 <= bev_planes_alloc(d);
+}
+
 bool bev_fwd_fused_supported(const VampRenderDesc* d);
 int launch_bev_fwd_fused(const VampRenderDesc* d, const RenderParams& P, const float* oxs, const float* oys,
                          const float* ozs, const float* bev_mids, const float* beta, const void* dens,
                          const void* sem, const void* rgb, const void* base, float* bev_rgb, float* bev_seg,
                          float* bev_height, float* voxel_density, float* voxel_output, float* s0_save,
                          float* ss_save, hipStream_t s);
+
+// render_fwd_merged.hip: camera tiles + BEV column blocks in one launch (early ray termination on)
+bool render_fwd_merged_supported(const VampRenderDesc* d);
+int launch_render_fwd_merged(const VampRenderDesc* d, const RenderParams& P, const float* mats, const float* us,
+                             const float* vs, const float* ds, const float* mids, const float* oxs, const float* oys,
+                             const float* ozs, const float* bev_mids, const float* beta, const void* dens,
+                             const void* sem, const void* rgb, const void* base, float* rgb_out, float* seg_out,
+                             float* depth_out, int* term_out, float* rows, float* bev_rgb, float* bev_seg,
+                             float* bev_height, float* voxel_density, float* voxel_output, float* s0_save,
+                             float* ss_save, hipStream_t s);
 
 // 8-tap trilinear gather of CP4*4 packed channels for an INSIDE sample, branch-free: all
 // 8 * CP4 16-byte loads are independent and can be in flight together (a per-tap bounds

@@ -575,8 +575,7 @@ int vamp_render_camera_forward_ex(const VampRenderDesc* d, const float* geom, co
         return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) need);
       rows = reinterpret_cast<float*>(static_cast<char*>(workspace) + vamp_render_workspace_bytes(d));
     }
-    RenderParams P = to_params(d);
-    P.exact_taps = (flags & VAMP_CAMFWD_EXACT_TAPS) ? 1 : 0;
+    const RenderParams P = to_params(d);
     return launch_cam_fwd_direct(d, P, mats, us, vs, ds, mids, beta, density_feature, semantic, rgb,
                                  rgb_out, seg_out, depth_out, term, ert, rows, static_cast<hipStream_t>(stream));
   }

@@ -27,7 +27,7 @@ const char* g_names[kProfSlots] = {
     "render_bev_bwd_q", "render_bev_bwd_gather", "lift_bwd_v1", "lift_bwd_count",
     "lift_bwd_fill", "render_cam_bwd_rank", "render_cam_bwd_fill", "render_cam_bwd_heavy", "render_cam_bwd_v1",
     "depth_softmax", "density_gate", "upsample_trilinear",
-    "conv3d_fwd", "conv3d_dgrad", "conv3d_wgrad", "render_cam_term"};
+    "conv3d_fwd", "conv3d_dgrad", "conv3d_wgrad", "render_cam_term", "render_fwd_merged"};
 }  // namespace
 
 bool prof_enabled() { return g_on; }

@@ -113,11 +113,10 @@ class HotPath:
                      # load of a channel-first volume).  "auto" (default): chosen per call from the termination tables
                      # of the last calls (_camera_forward_choice); True / False force one
                      "cam_direct": {"1": True, "0": False}.get(os.environ.get("VAMP_CAM_DIRECT", "auto"), "auto"),
-                     # the one-kernel camera forward with its density samples on the reference's own fp32 coordinate
-                     # chain instead of the ray's fp64 line (VAMP_CAMFWD_EXACT_TAPS): rendered depth within 4.3e-5 m of
-                     # the reference instead of 2.2e-4 (cfg-A; the bar is 1e-4), forward pair 115.5 instead of 112.8 us.
-                     # On by default since the kernel runs at 4 waves per SIMD (round 5); "0" = the line
-                     "cam_exact": os.environ.get("VAMP_CAM_EXACT", "1") != "0",
+                     # the render forward's two branches as ONE launch (render_fwd_merged.hip: camera tiles first, BEV
+                     # column blocks filling the slots the camera tiles' tail leaves idle) wherever the one-kernel camera
+                     # forward with early termination runs; False = the two launches (the tests' cross-check: same bits)
+                     "fwd_merged": True,
                      # the BEV forward as one kernel (render_bev_fused.hip); "0" = the two-kernel first
                      # implementation, the cross-check of the tests
                      "bev_fused": os.environ.get("VAMP_BEV_FUSED", "1") != "0",
@@ -572,17 +571,25 @@ class _LiftDenseFn(torch.autograd.Function):
         return None, gff, None
 
 
-def render_forward_plan(train, two, prep_ok, direct, ert):
+def render_forward_plan(train, two, prep_ok, direct, ert, merged=False):
     """The C calls of one render forward in issue order: [(op, stream, flags, waits, records)].
 
     op: "term" (termination table), "pack" (channel-last copy of the volumes), "cam" (camera branch: the one
-    kernel when `direct`, else the planned march), "prep" (the backward's geometry-only prepare pass), "bev".
+    kernel when `direct`, else the planned march), "prep" (the backward's geometry-only prepare pass), "bev",
+    "render" (camera tiles + BEV column blocks in ONE launch, vamp_render_forward_merged: stands for "cam" + "bev";
+    only with `merged`, which the caller gives when direct and ert hold and the library supports the shapes).
     stream: "cur" | "side"; flags: beyond the op's base flags; waits / records: names of events.
     `two`: a side stream is available; `prep_ok`: the cell-list backward will follow on matrices (no explicit
     geometry, not the v1 splat); `direct` / `ert`: one-kernel camera forward / early ray termination.
     Every schedule holds exactly one "bev" and one "cam"; the rest is what the measured timelines of
     DESIGN.md 7g-7h settled on (one table instead of four hand-unrolled branches)."""
     F = _capi
+    if not (direct and ert):
+        merged = False
+    if merged and not train:
+        return [("render", "cur", 0, (), ())]
+    if merged == "train" and train and two and prep_ok:
+        return [("render", "cur", 0, (), ("table",)), ("prep", "side", F.VAMP_CAMPREP_TERM_VALID, ("table",), ())]
     if train and two and prep_ok and direct:
         # the camera kernel (which leaves the termination table), then the BEV forward; beside them, once the
         # table is there, the prepare pass
@@ -671,13 +678,17 @@ class _RenderFn(torch.autograd.Function):
         cur = torch.cuda.current_stream()
         side = hp._side_stream() if (train or hp.impl["fwd_overlap"]) else None
         prep_ok = geom is None and hp.impl["prepare"] and hp.impl["cam_bwd"] != "v1"
-        plan = render_forward_plan(train, side is not None, prep_ok, direct, ert)
-        # (hp.ozs is the reference's lattice of det-grid heights: the one-kernel BEV forward may size its
-        # plane slabs from the spacing)
-        bev_flags = _capi.VAMP_BEVFWD_HEIGHTS_LATTICE if hp.impl["bev_fused"] else _capi.VAMP_BEVFWD_TWO_KERNELS
+        # camera tiles + BEV column blocks in one launch where the library takes the shapes (it checks the heights
+        # hp.ozs_host against the BEV kernel's plane slabs itself)
+        merged = bool(direct and ert and hp.impl["fwd_merged"] and hp.impl["bev_fused"] and
+                      hp.lib.vamp_render_forward_merged_supported(C.byref(d), hp.ozs_host))
+        if merged and train and os.environ.get("VAMP_X_TRAIN_MERGED", "0") == "1":       # (experiment, to be decided by measurement)
+            merged = "train"
+        plan = render_forward_plan(train, side is not None, prep_ok, direct, ert, merged)
+        bev_flags = 0 if hp.impl["bev_fused"] else _capi.VAMP_BEVFWD_TWO_KERNELS
         bev_save = train and hp.impl["bev_save"] and hp.impl["bev_bwd"] != "v1"
         ws_bev = hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d))) if bev_save else None
-        cam_base = (0 if ert else _capi.VAMP_CAMFWD_NO_ERT) | (_capi.VAMP_CAMFWD_EXACT_TAPS if hp.impl["cam_exact"] else 0)
+        cam_base = 0 if ert else _capi.VAMP_CAMFWD_NO_ERT
         streams, events = {"cur": cur, "side": side}, {}
         ctx.cells, ctx.ert, ctx.bev_key = False, ert, None
         if side is not None:
@@ -703,12 +714,22 @@ class _RenderFn(torch.autograd.Function):
                     flags | hp._cam_clean_flag(), _stream(st)), "vamp_render_camera_prepare_ex")
                 hp._dirty.discard("render")
                 ctx.cells = True
+            elif op == "render":
+                _capi.check(hp.lib.vamp_render_forward_merged(
+                    C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(hp.camera_mids),
+                    _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), hp.ozs_host, _ptr(hp.bev_mids), _ptr(beta),
+                    _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(rgb_p), _ptr(seg_p), _ptr(dep_p),
+                    _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h), _ptr(vdens), _ptr(vout), _ptr(ws), ws.numel(),
+                    _ptr(ws_bev), ws_bev.numel() if bev_save else 0,
+                    (_capi.VAMP_RENDERFWD_SAVE_SAMPLES if save else 0) | (_capi.VAMP_RENDERFWD_BEV_SAVE if bev_save else 0),
+                    _stream(st)), "vamp_render_forward_merged")
             else:
                 _capi.check(hp.lib.vamp_render_bev_forward_ex(
                     C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
                     _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h),
-                    _ptr(vdens), _ptr(vout), _ptr(ws_bev), ws_bev.numel() if bev_save else 0,
+                    _ptr(vdens), _ptr(vout), hp.ozs_host, _ptr(ws_bev), ws_bev.numel() if bev_save else 0,
                     (_capi.VAMP_BEVFWD_SAVE if bev_save else 0) | bev_flags, _stream(st)), "vamp_render_bev_forward_ex")
+            if op in ("render", "bev"):
                 hp._bev_gen = getattr(hp, "_bev_gen", 0) + 1
                 ctx.bev_key = (hp._bev_gen, ws_bev.data_ptr()) if bev_save else None
             for r in records:
