@@ -90,6 +90,9 @@ def kernel_algorithmic_bytes(cfg, B):
         # (since round 3 one kernel: density, weights and all channels -- the density planes and voxel_density /
         # bev_height are its traffic too)
         "render_bev_fwd_channels": B * (4 * (1 + K + 3 + C) * V * zf + 4 * YX * (K + 3) + 4 * oZ * YX * CO + 4 * YX * (oZ + 1)),
+        # round 6: camera tiles + BEV column blocks in one launch (no-grad forwards with early termination): both bodies' bytes
+        "render_fwd_merged": B * (4 * cam * V + 4 * P * (K + 4)
+                                  + 4 * (1 + K + 3 + C) * V * zf + 4 * YX * (K + 3) + 4 * oZ * YX * CO + 4 * YX * (oZ + 1)),
         "render_cam_bwd_ray": B * (4 * cam * V + 4 * P * (K + 4)),  # volumes + upstream gradients in
         # (render_cam_bwd_gather has no entry: in the default schedule it ADDS the camera branch's contributions onto
         # the gradient volumes the BEV gather has written -- and is credited with -- and touches them only where rays
@@ -104,7 +107,7 @@ def kernel_algorithmic_bytes(cfg, B):
 
 STAGES = {   # SURVEY.md section 8(d) stage names -> kernels of this build
     "lift_fwd": ["feat_to_channel_last", "lift_fwd"],
-    "render_fwd": ["pack_volume", "render_cam_term", "render_cam_fwd", "render_bev_fwd", "render_bev_fwd_channels"],
+    "render_fwd": ["pack_volume", "render_cam_term", "render_cam_fwd", "render_bev_fwd", "render_bev_fwd_channels", "render_fwd_merged"],
     # (round 4: the count pass lives in lift_fwd; "lift_bwd_count" only appears when a backward runs without it)
     "lift_bwd": ["lift_bwd_count", "lift_bwd_fill", "lift_bwd_gather", "lift_bwd_v1", "feat_to_channel_first"],
     "render_bwd": ["render_cam_bwd_ray", "render_cam_bwd_rank", "render_cam_bwd_fill", "render_cam_bwd_gather",

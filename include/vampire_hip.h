@@ -115,6 +115,13 @@ int vamp_lift_forward(const VampLiftDesc* d, const float* mats, const float* xs,
    vamp_lift_backward on this workspace leaves them (the scan zeroes what it has read, the backward's gather
    the cursors of the fill) -- so the zero fill in front of the kernel is skipped */
 #define VAMP_LIFTFWD_CELLS_CLEAN 2
+/* (ABI 6) `feat` is handed over CHANNEL-LAST, [B, N, fH, fW, C] fp32 (in_dtype VAMP_F32; 16-byte aligned) -- the
+   memory of a torch.channels_last [B*N, C, fH, fW] tensor, what the producing convolution (channel_lower,
+   bv2:551-553) emits natively in that memory format.  The lift samples a pixel's C features as one run, so this is
+   the layout it wants: the forward's first launch (the transposing copy into the workspace + the camera cull
+   words) disappears -- every workgroup forms its own patch's cull word at its head -- and the forward is one
+   kernel.  Without the flag feat is [B, N, C, fH, fW] as in the reference and the first launch runs. */
+#define VAMP_LIFTFWD_FEAT_CHANNEL_LAST 4
 int vamp_lift_forward_ex(const VampLiftDesc* d, const float* mats, const float* xs,
                          const float* ys, const float* zs, const void* depth,
                          const void* feat, float* out, uint64_t* hits,
@@ -173,6 +180,8 @@ int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs
    the gradient w.r.t. the LOGITS, p * (g - sum_d p g) (autograd of bv2:550): applied to the pixel's column
    while it sits in LDS, no extra pass.  Default (cell-list) backward only. */
 #define VAMP_LIFTBWD_LOGITS 256
+/* (ABI 6) feat is read, and grad_feat written, channel-last [B, N, fH, fW, C] fp32 (see VAMP_LIFTFWD_FEAT_CHANNEL_LAST) */
+#define VAMP_LIFTBWD_FEAT_CHANNEL_LAST 512
 int vamp_lift_prepare(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                       const float* zs, void* workspace, size_t workspace_bytes, void* stream);
 int vamp_lift_backward_ex(const VampLiftDesc* d, const float* mats, const float* xs,

@@ -217,6 +217,82 @@ def test_lift_bf16_inputs(tiny_common, dev):
     assert torch.equal(a, b)
 
 
+def channel_last(feat):
+    """The same [B, N, C, fH, fW] values in [B, N, fH, fW, C] memory (a torch.channels_last producer's output)."""
+    return feat.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)
+
+
+@pytest.mark.parametrize("C_", [4, 16, 48])
+def test_lift_channel_last_features_tiny(tiny_common, dev, C_):
+    """VAMP_LIFTFWD_FEAT_CHANNEL_LAST (round 6): features handed over in channel-last memory go in zero-copy -- no
+    transposing first launch, the forward's workgroups form their camera cull words themselves -- and every result has
+    the bits of the [B, N, C, fH, fW] call: forward with and without the pair emission, the cell-list backward (the
+    gradient comes back in the features' own layout), the logits entry, the D = 1 variant; the float-atomic splat to
+    rounding."""
+    from vampire_amd.ops import _is_channel_last
+    g = tiny_common
+    cfg = dataclasses.replace(CFG_TINY, mid_channels=C_)
+    hp = hot(cfg, dev)
+    lm, _ = tiny_mats(g, dev)
+    gen = torch.Generator().manual_seed(500 + C_)
+    B, N = g["depth"].shape[:2]
+    feat = (g["feat"] if C_ == 4 else torch.randn(B, N, C_, cfg.fH, cfg.fW, generator=gen)).to(dev)
+    depth = g["depth"].to(dev)
+    fcl = channel_last(feat)
+    assert _is_channel_last(fcl) and not _is_channel_last(feat) and torch.equal(fcl, feat)
+    with torch.no_grad():
+        assert torch.equal(hp.lift(depth, fcl, lm), hp.lift(depth, feat, lm)), "no-grad forward"
+        assert torch.equal(hp.lift(None, fcl, lm, use_depth=False), hp.lift(None, feat, lm, use_depth=False)), "D = 1 forward"
+    gout = torch.randn(B, C_, cfg.vZ, cfg.vY, cfg.vX, generator=gen).to(dev)
+    res = {}
+    for tag, f0 in (("cl", fcl), ("cf", feat)):
+        for impl in ("cell", "v1"):
+            hp.impl["lift_bwd"] = impl
+            d, f = depth.clone().requires_grad_(True), f0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+            out = hp.lift(d, f, lm)
+            out.backward(gout)
+            res[tag, impl] = (out.detach(), d.grad, f.grad)
+        hp.impl["lift_bwd"] = "cell"
+        lg = depth.clamp_min(1e-30).log().requires_grad_(True)
+        f = f0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+        out = hp.lift_logits(lg, f, lm)
+        out.backward(gout)
+        res[tag, "logits"] = (out.detach(), lg.grad, f.grad)
+    assert _is_channel_last(res["cl", "cell"][2]), "grad_feat comes back channel-last"
+    # (forward: same bits; the gradients are fp32 sums over a cell's pairs in the order the fill's atomics handed out
+    # their slots, which differs from run to run in the last bits whatever the layout)
+    for impl in ("cell", "logits"):
+        assert torch.equal(res["cl", impl][0], res["cf", impl][0]), f"{impl}: forward differs between the feature layouts"
+        for nm, a, b_ in zip(("grad_depth", "grad_feat"), res["cl", impl][1:], res["cf", impl][1:]):
+            close(a, b_, atol=1e-7, rtol=2e-6, scale="max", what=f"{impl}: {nm} between the feature layouts")
+    for nm, a, b_ in zip(("out", "grad_depth", "grad_feat"), res["cl", "v1"], res["cf", "cell"]):
+        close(a, b_, atol=1e-6, rtol=1e-5, scale="max", what=f"splat on channel-last features, {nm}")
+
+
+def test_lift_channel_last_features_full_size(dev):
+    """cfg-B, two samples with jittered rigs and a rotated bda: the inline cull words are the first launch's (same
+    outputs bit for bit, i.e. no valid pair lost), forward and backward."""
+    cfg = CFG_B
+    hp = hot(cfg, dev)
+    s2e, K, ida = synthetic.camera_rig(cfg, 2, jitter=2.0, seed=5)
+    lm = lift_matrices(s2e, K, ida, synthetic.bda_matrix(2, rot_deg=4.0, scale=0.98)).to(dev)
+    depth, feat = synthetic.lift_inputs(cfg, 2, seed=9, device=dev)
+    fcl = channel_last(feat)
+    with torch.no_grad():
+        assert torch.equal(hp.lift(depth, fcl, lm), hp.lift(depth, feat, lm)), "no-grad forward (cooperative kernel)"
+    gen = torch.Generator(device=dev).manual_seed(77)
+    gout = torch.randn(2, cfg.mid_channels, cfg.vZ, cfg.vY, cfg.vX, device=dev, generator=gen)
+    got = []
+    for f0 in (fcl, feat):
+        d, f = depth.clone().requires_grad_(True), f0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+        out = hp.lift(d, f, lm)
+        out.backward(gout)
+        got.append((out.detach(), d.grad, f.grad))
+    assert torch.equal(got[0][0], got[1][0]), "training forward differs between the feature layouts"
+    for nm, a, b_ in zip(("grad_depth", "grad_feat"), got[0][1:], got[1][1:]):
+        close(a, b_, atol=1e-7, rtol=2e-6, scale="max", what=f"{nm} between the feature layouts")
+
+
 @pytest.mark.parametrize("ldtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_lift_logits_tiny(tiny_common, dev, ldtype):
     """N2 producer fusion (bv2:550 + 553): the lift fed with depth LOGITS -- softmax inside the operand

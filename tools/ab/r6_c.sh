@@ -1,0 +1,9 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_hip_parity.py -x -q -k "lift or bev" 2>&1 | tail -4
+echo "--- feat_cl=1"; bash tools/kstats_cmd.sh 6 tools/fwd_graph.py B 1 100 0 feat_cl=1
+echo "--- feat_cl=0"; bash tools/kstats_cmd.sh 6 tools/fwd_graph.py B 1 100 0 feat_cl=0
+for r in 1 2; do
+python tools/fwd_graph.py B 1 200 0 feat_cl=0 2>&1 | grep 'forward pair'
+python tools/fwd_graph.py B 1 200 0 feat_cl=1 2>&1 | grep 'forward pair'
+done

@@ -12,10 +12,10 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 overlap = (sys.argv[4] != "0") if len(sys.argv) > 4 else True
 dev = torch.device("cuda:0")
 model = LiftRenderStep(cfg, dev)
-batch = SyntheticBatch(cfg, B, dev)
+over = dict(kv.split("=") for kv in sys.argv[5:])
+batch = SyntheticBatch(cfg, B, dev, feat_channel_last=over.pop("feat_cl", "1") != "0")     # (feat_cl=0: [B,N,C,fH,fW] features)
 hp = model.hp
-for kv in sys.argv[5:]:
-    k, v = kv.split("=")
+for k, v in over.items():
     hp.impl[k] = {"0": False, "1": True}.get(v, v)
 with torch.no_grad():
     def fwd():

@@ -58,10 +58,10 @@ class VampSampleDesc(C.Structure):
 
 VAMP_PAD_ZEROS, VAMP_PAD_BORDER = 0, 1
 # flag bits of vamp_lift_backward_ex / vamp_render_camera_backward_acc (include/vampire_hip.h)
-VAMP_LIFTFWD_EMIT_PAIRS, VAMP_LIFTFWD_CELLS_CLEAN = 1, 2
+VAMP_LIFTFWD_EMIT_PAIRS, VAMP_LIFTFWD_CELLS_CLEAN, VAMP_LIFTFWD_FEAT_CHANNEL_LAST = 1, 2, 4
 VAMP_LIFTBWD_CELLS_VALID, VAMP_LIFTBWD_SPLAT = 1, 2
 VAMP_LIFTBWD_WPP1, VAMP_LIFTBWD_WPP4, VAMP_LIFTBWD_WPP16 = 4, 8, 16
-VAMP_LIFTBWD_LOGITS = 256
+VAMP_LIFTBWD_LOGITS, VAMP_LIFTBWD_FEAT_CHANNEL_LAST = 256, 512
 VAMP_CAMBWD_ACCUMULATE, VAMP_CAMBWD_PACKED_VALID, VAMP_CAMBWD_CELLS_VALID, VAMP_CAMBWD_SPLAT = 1, 2, 4, 8
 VAMP_CAMBWD_SAMPLES_VALID, VAMP_CAMBWD_TERM_VALID, VAMP_CAMBWD_NO_ERT = 16, 32, 64
 VAMP_CAMBWD_PART_RAY, VAMP_CAMBWD_PART_GATHER, VAMP_CAMBWD_PART_HEAVY = 128, 256, 512

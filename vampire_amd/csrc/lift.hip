@@ -114,11 +114,9 @@ struct LiftCullLds {
 
 __device__ __forceinline__ int lift_cull_round(const LiftCull& K) { return min(256 / K.group, kCullBoxes); }
 
-// (1): threads [0, N).  16-byte loads: the matrices are 64-byte rows of a 16-byte aligned array.
-__device__ __forceinline__ void lift_cull_constants(const LiftParams& P, const float* __restrict__ mats, int b,
-                                                    LiftCullLds& S) {
-  if ((int) threadIdx.x >= P.N) return;
-  const int cn = threadIdx.x;
+// (1): per camera `cn` of sample b.  16-byte loads: the matrices are 64-byte rows of a 16-byte aligned array
+// (checked at the entry points).
+__device__ __forceinline__ LiftCullCam lift_cull_cam(const LiftParams& P, const float* __restrict__ mats, int b, int cn) {
   const float4* m = reinterpret_cast<const float4*>(mats + ((long) b * P.N + cn) * 48);
   const float4* m0 = reinterpret_cast<const float4*>(mats + (long) b * P.N * 48);
   float4 r[12], z[4];
@@ -143,7 +141,37 @@ __device__ __forceinline__ void lift_cull_constants(const LiftParams& P, const f
   c.a00 = r[8].x; c.a01 = r[8].y; c.a03 = r[8].w; c.a10 = r[9].x; c.a11 = r[9].y; c.a13 = r[9].w;
   c.plane = r[8].z == 0.f && r[9].z == 0.f && r[10].x == 0.f && r[10].y == 0.f && r[10].z == 1.f && r[10].w == 0.f;
   c.same = same;
-  S.cams[cn] = c;
+  return c;
+}
+// threads [0, N) of a workgroup: into LDS
+__device__ __forceinline__ void lift_cull_constants(const LiftParams& P, const float* __restrict__ mats, int b,
+                                                    LiftCullLds& S) {
+  if ((int) threadIdx.x >= P.N) return;
+  S.cams[threadIdx.x] = lift_cull_cam(P, mats, b, threadIdx.x);
+}
+
+// The bounding rectangle of the patch of kCullPX x kCullPY voxel centres whose first voxel is (x0, y0) in plane z,
+// grown by one voxel on every side (the axes are arrays of the caller: no monotonicity assumed; loads issued together)
+__device__ __forceinline__ LiftCullBox lift_cull_box_of(const LiftParams& P, const float* __restrict__ xs,
+                                                        const float* __restrict__ ys, const float* __restrict__ zs,
+                                                        int x0, int y0, int z) {
+  float xv[kCullPX], yv[kCullPY];
+#pragma unroll
+  for (int i = 0; i < kCullPX; ++i) xv[i] = xs[min(x0 + i, P.X - 1)];
+#pragma unroll
+  for (int i = 0; i < kCullPY; ++i) yv[i] = ys[min(y0 + i, P.Y - 1)];
+  LiftCullBox B;
+  B.zc = zs[z];
+  float xlo = xv[0], xhi = xlo, ylo = yv[0], yhi = ylo;
+#pragma unroll
+  for (int i = 1; i < kCullPX; ++i) { xlo = fminf(xlo, xv[i]); xhi = fmaxf(xhi, xv[i]); }
+#pragma unroll
+  for (int i = 1; i < kCullPY; ++i) { ylo = fminf(ylo, yv[i]); yhi = fmaxf(yhi, yv[i]); }
+  const int nx = min(kCullPX, P.X - x0), ny = min(kCullPY, P.Y - y0);
+  const float gx = nx > 1 ? (xhi - xlo) / (float) (nx - 1) : 0.f, gy = ny > 1 ? (yhi - ylo) / (float) (ny - 1) : 0.f;
+  B.xlo = xlo - gx; B.xhi = xhi + gx; B.ylo = ylo - gy; B.yhi = yhi + gy;
+  B.inside = 1;
+  return B;
 }
 
 // (2): threads [64, 64 + round): the bounding rectangle of patch `first + slot` of the sample, grown by one
@@ -159,38 +187,17 @@ __device__ __forceinline__ void lift_cull_boxes(const LiftParams& P, const float
   const long r = pl / K.nxp;
   const int yp = (int) (r % K.nyp);
   const int x0 = min(xp * K.px, P.X - 1), y0 = min(yp * K.py, P.Y - 1);
-  float xv[kCullPX], yv[kCullPY];
-#pragma unroll
-  for (int i = 0; i < kCullPX; ++i) xv[i] = xs[min(x0 + i, P.X - 1)];
-#pragma unroll
-  for (int i = 0; i < kCullPY; ++i) yv[i] = ys[min(y0 + i, P.Y - 1)];
-  LiftCullBox B;
-  B.zc = zs[(int) (r / K.nyp)];
-  float xlo = xv[0], xhi = xlo, ylo = yv[0], yhi = ylo;
-#pragma unroll
-  for (int i = 1; i < kCullPX; ++i) { xlo = fminf(xlo, xv[i]); xhi = fmaxf(xhi, xv[i]); }
-#pragma unroll
-  for (int i = 1; i < kCullPY; ++i) { ylo = fminf(ylo, yv[i]); yhi = fmaxf(yhi, yv[i]); }
-  const int nx = min(kCullPX, P.X - x0), ny = min(kCullPY, P.Y - y0);
-  const float gx = nx > 1 ? (xhi - xlo) / (float) (nx - 1) : 0.f, gy = ny > 1 ? (yhi - ylo) / (float) (ny - 1) : 0.f;
-  B.xlo = xlo - gx; B.xhi = xhi + gx; B.ylo = ylo - gy; B.yhi = yhi + gy;
+  LiftCullBox B = lift_cull_box_of(P, xs, ys, zs, x0, y0, (int) (r / K.nyp));
   B.inside = first + slot < per_sample && xp * K.px < P.X && yp * K.py < P.Y;
   S.box[slot] = B;
 }
 
-// (3): every wave that holds a live lane (wave-uniform: it ballots)
-__device__ __forceinline__ void lift_cull_eval(const LiftParams& P, const LiftCull& K, int b, long first, long count,
-                                               const LiftCullLds& S) {
-  const int G = K.group, round = lift_cull_round(K);
-  const int slot = threadIdx.x / G, n = threadIdx.x & (G - 1);
-  const int wave_slot0 = (threadIdx.x & ~63) / G;                 // first slot of this wave
-  if (wave_slot0 >= round || wave_slot0 >= count) return;
-  const long per_sample = (long) P.Z * K.nyp * K.nxp;
-  const bool live = slot < round && slot < count && first + slot < per_sample && n < P.N;
-  const LiftCullBox B = S.box[min(slot, round - 1)];
-  const LiftCullCam c = S.cams[min(n, P.N - 1)];
+// the test itself: may a voxel of the patch `B` be valid in camera `c`?  (false = provably none)
+__device__ __forceinline__ bool lift_cull_test(const LiftParams& P, const LiftCullCam& c, const LiftCullBox& B) {
   const float mu = P.u_div / (float) P.fW, mv = P.v_div / (float) P.fH;      // one feature pixel
-  const float mz = P.use_depth ? P.d_span / (float) P.D : 0.f;              // one depth bin
+  // one depth bin; without depth bounds (D == 1: valid needs z > 0) a centimetre -- three orders above the rounding
+  // of the fused product A = M2 M1 the corners go through
+  const float mz = P.use_depth ? P.d_span / (float) P.D : 0.01f;
   const float zlo = P.use_depth ? P.d_lo : 0.f;
   bool keep = true;
   if (c.plane) {
@@ -227,6 +234,21 @@ __device__ __forceinline__ void lift_cull_eval(const LiftParams& P, const LiftCu
     const bool sides = (P.use_depth && P.d_lo >= 1.0f) || front;
     if (o_near || o_far || (sides && (o_l || o_r || o_t || o_b))) keep = false;
   }
+  return keep;
+}
+
+// (3): every wave that holds a live lane (wave-uniform: it ballots)
+__device__ __forceinline__ void lift_cull_eval(const LiftParams& P, const LiftCull& K, int b, long first, long count,
+                                               const LiftCullLds& S) {
+  const int G = K.group, round = lift_cull_round(K);
+  const int slot = threadIdx.x / G, n = threadIdx.x & (G - 1);
+  const int wave_slot0 = (threadIdx.x & ~63) / G;                 // first slot of this wave
+  if (wave_slot0 >= round || wave_slot0 >= count) return;
+  const long per_sample = (long) P.Z * K.nyp * K.nxp;
+  const bool live = slot < round && slot < count && first + slot < per_sample && n < P.N;
+  const LiftCullBox B = S.box[min(slot, round - 1)];
+  const LiftCullCam c = S.cams[min(n, P.N - 1)];
+  const bool keep = lift_cull_test(P, c, B);
   const int lane = threadIdx.x & 63, g0 = lane & ~(G - 1);
   const uint64_t gm = ((G == 64) ? ~0ull : ((1ull << G) - 1)) << g0;
   const uint64_t kept = __ballot(live && keep) & gm, differ = __ballot(live && !c.same) & gm;
@@ -248,6 +270,31 @@ __device__ __forceinline__ void lift_cull_share(const LiftParams& P, const float
     __syncthreads();
     lift_cull_eval(P, K, b, first + done, count - done, S);
   }
+}
+
+// The word of ONE workgroup's own patch, formed at its head by the first N lanes (one ballot): what the forward
+// kernels do when no first launch has left the words in the workspace -- a caller that hands the features over
+// channel-last needs no transpose, and with it the whole first launch goes (VAMP_LIFTFWD_FEAT_CHANNEL_LAST).
+// Same constants, same rectangle, same test as the stand-alone kernel: same words.  All threads call it.
+__device__ __forceinline__ unsigned lift_cull_inline(const LiftParams& P, const float* __restrict__ mats,
+                                                     const float* __restrict__ xs, const float* __restrict__ ys,
+                                                     const float* __restrict__ zs, int b, int x0, int y0, int z) {
+  static_assert(kCullWpw == 4, "one word per workgroup");
+  __shared__ unsigned word_s;
+  if (threadIdx.x < 64) {                                         // wave 0
+    const int n = threadIdx.x;
+    bool keep = false, differ = false;
+    if (n < P.N) {
+      const LiftCullCam c = lift_cull_cam(P, mats, b, n);
+      const LiftCullBox B = lift_cull_box_of(P, xs, ys, zs, min(x0, P.X - 1), min(y0, P.Y - 1), z);
+      keep = lift_cull_test(P, c, B);
+      differ = !c.same;
+    }
+    const uint64_t kept = __ballot(keep), df = __ballot(differ);
+    if (n == 0) word_s = (unsigned) kept | (df ? 0u : kLiftCullSharedBda);
+  }
+  __syncthreads();
+  return (unsigned) __builtin_amdgcn_readfirstlane((int) word_s);
 }
 
 // stand-alone form (vamp_lift_cull_words): workgroup `blk` = sample * K.bps + chunk of 256 / G patches
@@ -431,10 +478,14 @@ lift_fwd_kernel(LiftParams P, const float* __restrict__ mats, const float* __res
   const int z = (blockIdx.z % zblocks) * TZ + tid / (TX * TY);
   // the wave's cull word (lift_cull_eval): one scalar load
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned cword = cull[((long) blockIdx.z * (gridDim.y * (4 / kCullWpw)) + blockIdx.y * (4 / kCullWpw) + wave / kCullWpw) * gridDim.x + blockIdx.x];
+  // (the voxel's centre and its first product in front of the word: with the inline cull their loads are in flight
+  // while the first lanes form it)
+  const float vx = xs[min(x, P.X - 1)], vy = ys[min(y, P.Y - 1)], vz = zs[min(z, P.Z - 1)];
+  const Vec4 p1 = matvec(mats + (long) b * P.N * 48, Vec4{vx, vy, vz, 1.0f});       // inv(bda) . c
+  const unsigned cword = cull ? cull[((long) blockIdx.z * (gridDim.y * (4 / kCullWpw)) + blockIdx.y * (4 / kCullWpw) + wave / kCullWpw) * gridDim.x + blockIdx.x]
+                              : lift_cull_inline(P, mats, xs, ys, zs, b, blockIdx.x * TX, blockIdx.y * TY, min(z, P.Z - 1));
   if (x >= P.X || y >= P.Y || z >= P.Z) return;
 
-  const float vx = xs[x], vy = ys[y], vz = zs[z];
   const long V = (long) P.Z * P.Y * P.X;
   const long vox = ((long) z * P.Y + y) * P.X + x;
   const long HW = (long) P.fH * P.fW;
@@ -442,7 +493,6 @@ lift_fwd_kernel(LiftParams P, const float* __restrict__ mats, const float* __res
 
   unsigned wmask = 0;
   const bool shared_bda = (cword & kLiftCullSharedBda) != 0;                        // uniform
-  const Vec4 p1 = matvec(mats + (long) b * P.N * 48, Vec4{vx, vy, vz, 1.0f});       // inv(bda) . c
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     float sum[CH];
     uint64_t cnt = 0;
@@ -535,10 +585,14 @@ lift_fwd_coop_kernel(LiftParams P, const float* __restrict__ mats, const float* 
   const int x = blockIdx.x * TX + (tid % TX);
   const int y = blockIdx.y * TY + (tid / TX);
   const int b = blockIdx.z / P.Z, z = blockIdx.z % P.Z;
-  const unsigned cword = cull[((long) blockIdx.z * (gridDim.y * (4 / kCullWpw)) + blockIdx.y * (4 / kCullWpw) + wave / kCullWpw) * gridDim.x + blockIdx.x];
+  // (the voxel's centre and its first product in front of the word: with the inline cull their loads are in flight
+  // while the first lanes form it)
+  const float vx = xs[min(x, P.X - 1)], vy = ys[min(y, P.Y - 1)], vz = zs[z];
+  const Vec4 p1 = matvec(mats + (long) b * P.N * 48, Vec4{vx, vy, vz, 1.0f});       // inv(bda) . c
+  const unsigned cword = cull ? cull[((long) blockIdx.z * (gridDim.y * (4 / kCullWpw)) + blockIdx.y * (4 / kCullWpw) + wave / kCullWpw) * gridDim.x + blockIdx.x]
+                              : lift_cull_inline(P, mats, xs, ys, zs, b, blockIdx.x * TX, blockIdx.y * TY, z);
   // (no early exit: a lane whose own voxel is outside the grid still fetches for the others')
   const bool live = x < P.X && y < P.Y;
-  const float vx = xs[min(x, P.X - 1)], vy = ys[min(y, P.Y - 1)], vz = zs[z];
   const long V = (long) P.Z * P.Y * P.X;
   const long HW = (long) P.fH * P.fW;
   const int q = lane & 3, vq = lane >> 2;        // second role: channel quad, voxel within a row of the patch
@@ -548,7 +602,6 @@ lift_fwd_coop_kernel(LiftParams P, const float* __restrict__ mats, const float* 
 #pragma unroll
   for (int i = 0; i < 16; ++i) sum[i] = 0.f;
   const bool shared_bda = (cword & kLiftCullSharedBda) != 0;                        // uniform
-  const Vec4 p1 = matvec(mats + (long) b * P.N * 48, Vec4{vx, vy, vz, 1.0f});       // inv(bda) . c
 
   for (unsigned cams = cword & (kLiftCullSharedBda - 1); cams; cams &= cams - 1) {
     const int n = __builtin_ctz(cams);
@@ -1007,6 +1060,7 @@ int vamp_lift_forward_ex(const VampLiftDesc* d, const float* mats, const float* 
                          uint64_t* hits, void* workspace, size_t workspace_bytes, int flags, void* stream) {
   if (int e = validate(d)) return e;
   VAMP_REQUIRE(mats && xs && ys && zs && feat && out, "null pointer");
+  VAMP_REQUIRE(((uintptr_t) mats & 15) == 0, "mats must be 16-byte aligned (the cull reads whole matrix rows)");
   VAMP_REQUIRE(depth || !d->use_depth, "depth is NULL");
   VAMP_REQUIRE(fused_channels_ok(d->C), "C must be 4, 8 or a multiple of 16 (<= 64)");
   const LiftWs w = carve(d, workspace);
@@ -1015,6 +1069,16 @@ int vamp_lift_forward_ex(const VampLiftDesc* d, const float* mats, const float* 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const LiftParams P = to_params(d);
   const long BN = (long) d->B * d->N, HW = (long) d->fH * d->fW;
+  void* cells = (flags & VAMP_LIFTFWD_EMIT_PAIRS) ? w.cells : nullptr;
+  const bool clean = (flags & VAMP_LIFTFWD_CELLS_CLEAN) != 0;
+  if (flags & VAMP_LIFTFWD_FEAT_CHANNEL_LAST) {
+    // the features are already [B, N, fH, fW, C] fp32: no copy, and every workgroup of the forward kernel forms
+    // its own patch's cull word at its head -- the forward is ONE launch
+    VAMP_REQUIRE(d->in_dtype == VAMP_F32, "VAMP_LIFTFWD_FEAT_CHANNEL_LAST takes fp32 features (and depth)");
+    VAMP_REQUIRE(((uintptr_t) feat & 15) == 0, "channel-last feat must be 16-byte aligned");
+    return lift_forward_t<float>(d, P, mats, xs, ys, zs, depth, static_cast<const float*>(feat), out, hits, cells, clean,
+                                 nullptr, s);
+  }
   // first launch: channel-last copy of the features + the camera cull words of the forward's waves
   const int ptiles = (int) ((HW + 63) / 64);
   const long n_cl = BN * ptiles;
@@ -1025,8 +1089,6 @@ int vamp_lift_forward_ex(const VampLiftDesc* d, const float* mats, const float* 
   else
     VAMP_TIMED(kProfFeatCL, s, (lift_prologue_kernel<__hip_bfloat16><<<grid, 256, 0, s>>>(P, static_cast<const __hip_bfloat16*>(feat), w.feat_cl, ptiles, mats, xs, ys, zs, w.cull)));
   if (int e = check_launch("lift_prologue_kernel")) return e;
-  void* cells = (flags & VAMP_LIFTFWD_EMIT_PAIRS) ? w.cells : nullptr;
-  const bool clean = (flags & VAMP_LIFTFWD_CELLS_CLEAN) != 0;
   if (d->in_dtype == VAMP_F32)
     return lift_forward_t<float>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, cells, clean, w.cull.words, s);
   return lift_forward_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, cells, clean, w.cull.words, s);
@@ -1046,6 +1108,7 @@ int vamp_lift_forward_logits_ex(const VampLiftDesc* d, const float* mats, const 
                                 size_t workspace_bytes, int flags, void* stream) {
   if (int e = validate(d)) return e;
   VAMP_REQUIRE(mats && xs && ys && zs && logits && feat && depth_out && out, "null pointer");
+  VAMP_REQUIRE(((uintptr_t) mats & 15) == 0, "mats must be 16-byte aligned (the cull reads whole matrix rows)");
   VAMP_REQUIRE(d->use_depth == 1, "the logits entry is the depth-distribution lift");
   VAMP_REQUIRE(d->in_dtype == VAMP_F32, "feat (and the depth distribution written here) are fp32");
   VAMP_REQUIRE(logits_dtype == VAMP_F32 || logits_dtype == VAMP_BF16, "logits_dtype");
@@ -1058,7 +1121,11 @@ int vamp_lift_forward_logits_ex(const VampLiftDesc* d, const float* mats, const 
   const long BN = (long) d->B * d->N, HW = (long) d->fH * d->fW;
   const long sm_tiles = (HW + kPix - 1) / kPix;
   const int ptiles = (int) ((HW + 63) / 64);
-  const long n_sm = BN * sm_tiles, n_cl = BN * ptiles;
+  // VAMP_LIFTFWD_FEAT_CHANNEL_LAST: only the softmax tiles; the forward kernel reads the caller's features and forms
+  // its cull words itself
+  const bool fcl = (flags & VAMP_LIFTFWD_FEAT_CHANNEL_LAST) != 0;
+  VAMP_REQUIRE(!fcl || ((uintptr_t) feat & 15) == 0, "channel-last feat must be 16-byte aligned");
+  const long n_sm = BN * sm_tiles, n_cl = fcl ? 0 : BN * ptiles;
   VAMP_REQUIRE(n_sm + n_cl < 0x7fffffffL, "too many tiles");
   const unsigned grid = (unsigned) (n_sm + n_cl);
 #define VAMP_OPERANDS(TL, REG)                                                                           \
@@ -1073,9 +1140,9 @@ int vamp_lift_forward_logits_ex(const VampLiftDesc* d, const float* mats, const 
   }
 #undef VAMP_OPERANDS
   if (int e = check_launch("lift_operands_kernel")) return e;
-  return lift_forward_t<float>(d, P, mats, xs, ys, zs, depth_out, w.feat_cl, out, hits,
+  return lift_forward_t<float>(d, P, mats, xs, ys, zs, depth_out, fcl ? feat : w.feat_cl, out, hits,
                                (flags & VAMP_LIFTFWD_EMIT_PAIRS) ? w.cells : nullptr,
-                               (flags & VAMP_LIFTFWD_CELLS_CLEAN) != 0, w.cull.words, s);
+                               (flags & VAMP_LIFTFWD_CELLS_CLEAN) != 0, fcl ? nullptr : w.cull.words, s);
 }
 
 int vamp_lift_prepare(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
@@ -1111,6 +1178,9 @@ int vamp_lift_backward_ex(const VampLiftDesc* d, const float* mats, const float*
   hipStream_t s = static_cast<hipStream_t>(stream);
   const LiftParams P = to_params(d);
   const int BN = d->B * d->N, HW = d->fH * d->fW;
+  // VAMP_LIFTBWD_FEAT_CHANNEL_LAST: feat is read, and grad_feat written, as [B, N, fH, fW, C] fp32
+  const bool fcl = (flags & VAMP_LIFTBWD_FEAT_CHANNEL_LAST) != 0;
+  VAMP_REQUIRE(!fcl || d->in_dtype == VAMP_F32, "VAMP_LIFTBWD_FEAT_CHANNEL_LAST takes fp32 features (and depth)");
   // default: cell list + one wave per pixel (lift_bwd_cell.hip), no float atomics.
   // VAMP_LIFTBWD_SPLAT selects the per-voxel atomic splat below, kept as an independent cross-check.
   if (!(flags & VAMP_LIFTBWD_SPLAT)) {
@@ -1120,19 +1190,24 @@ int vamp_lift_backward_ex(const VampLiftDesc* d, const float* mats, const float*
                     : (flags & VAMP_LIFTBWD_WPP16) ? 16 : 0;
     return launch_lift_bwd_cell(d, mats, xs, ys, zs, depth, feat, grad_out, hits, grad_depth,
                                 grad_feat, w.cells, (flags & VAMP_LIFTBWD_CELLS_VALID) != 0, wpp, /*half=*/0,
-                                (flags & VAMP_LIFTBWD_LOGITS) != 0, s);
+                                (flags & VAMP_LIFTBWD_LOGITS) != 0, fcl, s);
   }
   VAMP_REQUIRE(!(flags & VAMP_LIFTBWD_LOGITS), "VAMP_LIFTBWD_LOGITS is a feature of the default (cell-list) backward");
-  if (d->in_dtype == VAMP_F32) launch_to_cl<float>(feat, w.feat_cl, BN, d->C, HW, s);
-  else launch_to_cl<__hip_bfloat16>(feat, w.feat_cl, BN, d->C, HW, s);
-  if (int e = check_launch("feat_to_channel_last")) return e;
-  if (int ze = launch_zero(w.gfeat_cl, (size_t) BN * HW * d->C * sizeof(float), s)) return ze;
+  // (channel-last features: they are what the splat reads, and the gradient it accumulates is what the caller wants)
+  const float* fsrc = fcl ? static_cast<const float*>(feat) : w.feat_cl;
+  float* gdst = fcl ? grad_feat : w.gfeat_cl;
+  if (!fcl) {
+    if (d->in_dtype == VAMP_F32) launch_to_cl<float>(feat, w.feat_cl, BN, d->C, HW, s);
+    else launch_to_cl<__hip_bfloat16>(feat, w.feat_cl, BN, d->C, HW, s);
+    if (int e = check_launch("feat_to_channel_last")) return e;
+  }
+  if (int ze = launch_zero(gdst, (size_t) BN * HW * d->C * sizeof(float), s)) return ze;
   if (d->use_depth)
     if (int ze = launch_zero(grad_depth, (size_t) BN * d->D * HW * sizeof(float), s)) return ze;
   int e = (d->in_dtype == VAMP_F32)
-              ? lift_backward_t<float>(d, P, mats, xs, ys, zs, depth, w.feat_cl, grad_out, hits, grad_depth, w.gfeat_cl, s)
-              : lift_backward_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, w.feat_cl, grad_out, hits, grad_depth, w.gfeat_cl, s);
-  if (e) return e;
+              ? lift_backward_t<float>(d, P, mats, xs, ys, zs, depth, fsrc, grad_out, hits, grad_depth, gdst, s)
+              : lift_backward_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, fsrc, grad_out, hits, grad_depth, gdst, s);
+  if (e || fcl) return e;
   dim3 grid((HW + 63) / 64, (d->C + 63) / 64, BN);
   VAMP_TIMED(kProfFeatCF, s, (feat_to_channel_first<<<grid, 256, 0, s>>>(w.gfeat_cl, grad_feat, d->C, HW)));
   return check_launch("feat_to_channel_first");
@@ -1173,6 +1248,7 @@ int vamp_lift_cull_words(const VampLiftDesc* d, const float* mats, const float* 
   grid[0] = w.cull.nxp; grid[1] = w.cull.nyp;
   if (!words) return VAMP_OK;
   VAMP_REQUIRE(mats && xs && ys && zs, "null pointer");
+  VAMP_REQUIRE(((uintptr_t) mats & 15) == 0, "mats must be 16-byte aligned (the cull reads whole matrix rows)");
   w.cull.words = words;
   lift_cull_kernel<<<(unsigned) ((long) d->B * w.cull.bps), 256, 0, static_cast<hipStream_t>(stream)>>>(
       to_params(d), mats, xs, ys, zs, w.cull);

@@ -219,7 +219,7 @@ lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_
                       const int* __restrict__ off, const int* __restrict__ boff,
                       const int* __restrict__ ids, const float4* __restrict__ recs,
                       const float4* __restrict__ table, const int* __restrict__ rowq, int* __restrict__ cnt,
-                      float* __restrict__ gdepth, float* __restrict__ gfeat, int softmax_bwd) {
+                      float* __restrict__ gdepth, float* __restrict__ gfeat, int softmax_bwd, int fcl) {
   extern __shared__ float smem[];
   constexpr int NT = kW * 64;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -294,11 +294,16 @@ lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_
     }
   }
   for (int e = tid; e < DS / 2; e += NT) reinterpret_cast<float4*>(gtile)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // one feature of the strip: channel-first planes [C][HW], or (fcl: VAMP_LIFTBWD_FEAT_CHANNEL_LAST, uniform) the
+  // caller's channel-last rows [HW][C] -- a strip's 16 channels x kS pixels are then one contiguous run
+  auto feat_at = [&](int c, int pp) -> float {
+    return fcl ? ldf(feat, (bn * HW + pix0 + pp) * C + c) : ldf(feat, (bn * C + c) * HW + pix0 + pp);
+  };
   {
     // sum_c |feat_c| of every pixel over ALL channels: the bound of the depth terms
     const int pp = tid % kS;
     float sa = 0.f;
-    for (int c = tid / kS; c < C; c += NT / kS) sa += fabsf(pp < np ? ldf(feat, (bn * C + c) * HW + pix0 + pp) : 0.f);
+    for (int c = tid / kS; c < C; c += NT / kS) sa += fabsf(pp < np ? feat_at(c, pp) : 0.f);
     red[tid] = sa;
   }
   __syncthreads();
@@ -322,8 +327,9 @@ lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_
     // the pixel's 16 features of this chunk, through LDS ([pixel][channel]: one load per thread)
     __syncthreads();
     {
-      const int cc = tid / kS, pp = tid % kS;
-      stage[pp * 16 + cc] = (c0 + cc < C && pp < np) ? ldf(feat, (bn * C + c0 + cc) * HW + pix0 + pp) : 0.f;
+      // (consecutive threads = consecutive pixels of a channel plane, or consecutive channels of a channel-last row)
+      const int cc = fcl ? tid % 16 : tid / kS, pp = fcl ? tid / 16 : tid % kS;
+      stage[pp * 16 + cc] = (c0 + cc < C && pp < np) ? feat_at(c0 + cc, pp) : 0.f;
     }
     __syncthreads();
     float ft[16], acc[16];
@@ -497,11 +503,12 @@ lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_
     st2 = STAMP();
 #endif
     {
-      const int cc = tid / kS, pp = tid % kS;        // consecutive threads = consecutive pixels of one channel
+      // consecutive threads = consecutive pixels of one channel (or, channel-last, consecutive channels of a pixel)
+      const int cc = fcl ? tid % 16 : tid / kS, pp = fcl ? tid / 16 : tid % kS;
       float v = 0.f;
 #pragma unroll
       for (int w2 = 0; w2 < kW; ++w2) v += stage[(w2 * kS + pp) * 16 + cc];
-      if (pp < np && c0 + cc < C) gfeat[(bn * C + c0 + cc) * HW + pix0 + pp] = v;
+      if (pp < np && c0 + cc < C) gfeat[fcl ? (bn * HW + pix0 + pp) * C + c0 + cc : (bn * C + c0 + cc) * HW + pix0 + pp] = v;
     }
   }
   if (D > 0 && gdepth) {
@@ -608,7 +615,7 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
                          const float* xs, const float* ys, const float* zs, const void* depth,
                          const void* feat, const float* gout, const uint64_t* hits, float* gdepth,
                          float* gfeat, void* scratch, bool cells_valid, int variant, int half, bool softmax_bwd,
-                         hipStream_t s) {
+                         bool fcl, hipStream_t s) {
   const LiftCells g = lift_cells(d);
   const LiftCellWs w = lift_cell_ws(d, scratch);
   if (!cells_valid)
@@ -644,7 +651,7 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
       return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);
     VAMP_TIMED(kProfLiftBwd, s, (k<<<ggrid, kW * 64, lds, s>>>(
         P, g.cw, g.ch, spr, spr, bn_lo, cap, static_cast<const T*>(depth), static_cast<const T*>(feat),
-        w.off, w.boff, w.ids, w.recs, w.table, w.rowq, w.cnt, gdepth, gfeat, softmax_bwd ? 1 : 0)));
+        w.off, w.boff, w.ids, w.recs, w.table, w.rowq, w.cnt, gdepth, gfeat, softmax_bwd ? 1 : 0, fcl ? 1 : 0)));
   }
   return check_launch("lift_bwd_strip_kernel");
 }
@@ -652,13 +659,13 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
 int launch_lift_bwd_cell(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                          const float* zs, const void* depth, const void* feat, const float* gout,
                          const uint64_t* hits, float* gdepth, float* gfeat, void* scratch,
-                         bool cells_valid, int variant, int half, bool softmax_bwd, hipStream_t s) {
+                         bool cells_valid, int variant, int half, bool softmax_bwd, bool fcl, hipStream_t s) {
   const LiftParams P = to_params(d);
   if (d->in_dtype == VAMP_F32)
     return launch_cell_t<float>(d, P, mats, xs, ys, zs, depth, feat, gout, hits, gdepth, gfeat, scratch,
-                                cells_valid, variant, half, softmax_bwd, s);
+                                cells_valid, variant, half, softmax_bwd, fcl, s);
   return launch_cell_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, feat, gout, hits, gdepth, gfeat,
-                                       scratch, cells_valid, variant, half, softmax_bwd, s);
+                                       scratch, cells_valid, variant, half, softmax_bwd, fcl, s);
 }
 
 }  // namespace vamp

@@ -191,7 +191,7 @@ size_t lift_bwd_cell_ws_bytes(const VampLiftDesc* d);
 int launch_lift_bwd_cell(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                          const float* zs, const void* depth, const void* feat, const float* gout,
                          const uint64_t* hits, float* gdepth, float* gfeat, void* scratch,
-                         bool cells_valid, int variant, int half, bool softmax_bwd, hipStream_t s);
+                         bool cells_valid, int variant, int half, bool softmax_bwd, bool feat_cl, hipStream_t s);
 int launch_lift_cell_prepare(const VampLiftDesc* d, const float* mats, const float* xs,
                              const float* ys, const float* zs, void* scratch, hipStream_t s);
 // zero the cell counters (before a kernel that emits pairs) / scan them (after it)

@@ -186,14 +186,17 @@ bev_fwd_fused_block(const unsigned bx, const int b, const int part, const int np
     float a0[PC], b0[PC], a1[PC], b1[PC];
   };
   const int nck = (NP + PC - 1) / PC;                               // chunks of planes per channel
-  // Two channel groups: group 0 the density and the composited channels [0, K + 3), group 1 the pass-through
-  // channels [K + 3, nch) -- which need neither sigma nor weights: those workgroups skip the density phase and
-  // stream from their first instruction, while the group-0 workgroups beside them on the CU are in theirs
-  // (one round of workgroups in lockstep: for the first 9 us of the kernel almost nothing moved).
-  const bool split = nparts == 2;
-  const int c_lo = split && part == 1 ? P.K + 3 : 0;
-  const int c_hi = split && part == 0 ? P.K + 3 : nch;
-  const bool with_density = !(split && part == 1);
+  // Channel groups (nparts >= 2): group 0 the density and the composited channels [0, K + 3), groups 1 .. nparts - 1
+  // equal slices of the pass-through channels [K + 3, nch) -- which need neither sigma nor weights: those workgroups
+  // skip the density phase and stream from their first instruction, while the group-0 workgroups beside them on the
+  // CU are in theirs (one round of workgroups in lockstep: for the first 9 us of the kernel almost nothing moved).
+  // More than one pass-through group makes their workgroups SHORT: behind the camera tiles of the merged launch
+  // (render_fwd_merged.hip) they are what fills the last microseconds.
+  const bool split = nparts >= 2;
+  const int per = split ? (P.C + nparts - 2) / (nparts - 1) : 0;    // pass-through channels per group
+  const int c_lo = split && part >= 1 ? P.K + 3 + (part - 1) * per : 0;
+  const int c_hi = split ? (part == 0 ? P.K + 3 : min(nch, c_lo + per)) : nch;
+  const bool with_density = !(split && part >= 1);
   const int cstride = split ? NWV : NWV * nparts;
   // the x-pair loads of chunk k of channel c (2 * PC loads, none waited for here).  Past the last channel
   // the loads go through a zero-size descriptor (they return at once): the loop below is branch-free around

@@ -18,9 +18,15 @@
 #include "render_cam_direct_dev.hpp"
 #include "render_bev_fused_dev.hpp"
 
+#include <algorithm>
+
 namespace vamp {
 
 static_assert(VAMP_DIRECT_NW == 4 && VAMP_BEVF_NWV == 4, "both bodies are four-wave workgroups");
+// channel groups of a BEV column block in this launch: the composited group + this many minus one pass-through groups
+#ifndef VAMP_MERGED_BEV_PARTS
+#define VAMP_MERGED_BEV_PARTS 3              // (2 / 3 / 5 at cfg-B: forward pair 107.0 / 105.7 / 107.8 us)
+#endif
 
 struct MergedCam {
   const float *mats, *us, *vs, *ds, *mids;
@@ -77,19 +83,23 @@ render_fwd_merged_kernel(MergedArgs<T> args_in_kernarg_segment) {
 #endif
   typedef const MergedArgs<T> __attribute__((address_space(4))) * KP;
   KP ap = (KP) __builtin_amdgcn_kernarg_segment_ptr();
+  // (Camera tiles FIRST is the order that wins: with BEV groups dealt in between -- one per 2 / 3 / 5 / 8 camera groups,
+  // so that the streaming blocks would overlap the tiles' latency-bound phases from the first microsecond -- the pair
+  // takes 113.7 / 114.1 / 110.2 / 108.6 us against 106.1: a camera tile that starts late ends late.)
   const unsigned ncam = ap->ncam;
-  if (blockIdx.x < ncam) {
+  const bool is_cam = blockIdx.x < ncam;
+  const unsigned bid = is_cam ? blockIdx.x : blockIdx.x - ncam;
+  if (is_cam) {
     asm volatile("" : "+s"(ap));
     const RenderParams P = kernarg_copy<RenderParams>(&ap->P);
     const MergedCam c = kernarg_copy<MergedCam>(&ap->c);
-    cam_fwd_direct_tile<T, NCH, true, 4>(blockIdx.x, P, c.mats, c.us, c.vs, c.ds, c.mids, ap->beta_raw, ap->dens, ap->sem,
+    cam_fwd_direct_tile<T, NCH, true, 4>(bid, P, c.mats, c.us, c.vs, c.ds, c.mids, ap->beta_raw, ap->dens, ap->sem,
                                          ap->rgb, c.rgb_out, c.seg_out, c.depth_out, c.term_out, c.rows);
   } else {
     asm volatile("" : "+s"(ap));
     const RenderParams P = kernarg_copy<RenderParams>(&ap->P);
     const MergedBev v = kernarg_copy<MergedBev>(&ap->v);
-    const unsigned r = blockIdx.x - ncam;
-    const unsigned q = r / v.gx, bx = r - q * v.gx;
+    const unsigned q = bid / v.gx, bx = bid - q * v.gx;
     const int part = (int) (q / (unsigned) P.B), b = (int) (q - (unsigned) part * (unsigned) P.B);
     bev_fwd_fused_block<T, 4>(bx, b, part, v.parts, P, v.NPA, v.oxs, v.oys, v.ozs, v.bev_mids, ap->beta_raw, ap->dens,
                               ap->sem, ap->rgb, ap->base, v.bev_rgb, v.bev_seg, v.bev_height, v.voxel_density,
@@ -121,7 +131,7 @@ int launch_render_fwd_merged(const VampRenderDesc* d, const RenderParams& P, con
   v.NPA = bev_planes_alloc(d);
   const long cols = (long) P.oY * P.oX;
   v.gx = (unsigned) (((cols + 63) / 64 + 7) / 8 * 8);
-  v.parts = P.C > 0 ? VAMP_BEVF_PARTS : 1;
+  v.parts = P.C > 0 ? std::min(VAMP_MERGED_BEV_PARTS, P.C + 1) : 1;
   const long nbev = (long) v.gx * P.B * v.parts;
   VAMP_REQUIRE(ncam + nbev < 0x7fffffffL, "too many workgroups");
   const size_t dyn_cam = cam_direct_dyn_bytes(S, nch), dyn_bev = bev_fused_dyn_bytes(P.oZ, v.NPA);

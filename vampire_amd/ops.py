@@ -48,6 +48,13 @@ def _accept(t):
     return t.float()
 
 
+def _is_channel_last(feat: torch.Tensor) -> bool:
+    """feat [B, N, C, fH, fW] whose memory is [B, N, fH, fW, C] (a torch.channels_last producer's output, reshaped):
+    what the lift wants -- it samples a pixel's C features as one run -- and takes zero-copy."""
+    return (feat.dim() == 5 and feat.dtype == torch.float32 and feat.shape[2] > 1
+            and feat.permute(0, 1, 3, 4, 2).is_contiguous() and feat.data_ptr() % 16 == 0)
+
+
 def _chk(t: torch.Tensor, shape, name):
     if not t.is_cuda:
         raise _capi.VampireHipError(f"{name} must be a device tensor (no CPU fallback)")
@@ -456,11 +463,17 @@ class _LiftFn(torch.autograd.Function):
         code = _dtype_code(feat)
         fhw = tuple(feat.shape[-2:])
         d = hp.lift_desc(B, N, C_, code, use_depth, fhw=fhw)
-        feat = _chk(feat, (B, N, C_) + fhw, "feat")
-        if use_depth:
-            depth = _chk(depth, (B, N, c.D) + fhw, "depth")
-            if depth.dtype != feat.dtype:
-                raise TypeError("depth and feat must share a dtype")
+        # channel-last fp32 features (the memory of a torch.channels_last producer) go in as they are
+        # (VAMP_LIFTFWD_FEAT_CHANNEL_LAST: no transposing first launch); anything else is made [B,N,C,fH,fW]-contiguous
+        fcl = _is_channel_last(feat) and (not use_depth or logits or depth.dtype == torch.float32)
+        ctx.feat_cl = fcl
+        if fcl:
+            if not feat.is_cuda:
+                raise _capi.VampireHipError("feat must be a device tensor (no CPU fallback)")
+            if tuple(feat.shape) != (B, N, C_) + fhw:
+                raise ValueError(f"feat: expected shape {(B, N, C_) + fhw}, got {tuple(feat.shape)}")
+        else:
+            feat = _chk(feat, (B, N, C_) + fhw, "feat")
         mats = _chk(mats.float(), (B, N, 3, 4, 4), "lift_mats")
         out = torch.empty(B, C_, c.vZ, c.vY, c.vX, dtype=torch.float32, device=feat.device)
         # (the caller's grad mode comes in as an argument: inside forward it is always off and
@@ -475,12 +488,12 @@ class _LiftFn(torch.autograd.Function):
         cur = torch.cuda.current_stream()
         hp._lift_gen = getattr(hp, "_lift_gen", 0) + 1
         ctx.cells_key = None
-        flags = 0
+        flags = _capi.VAMP_LIFTFWD_FEAT_CHANNEL_LAST if fcl else 0
         if need_grad and hp.impl["prepare"] and hp.impl["lift_bwd"] == "cell":
             # the forward kernel projects every voxel into every camera anyway: in grad mode it also
             # counts the backward's (voxel, camera) pairs per pixel cell and leaves their taps in the
             # workspace, so the backward never projects (VAMP_PREPARE=0: the backward does it itself)
-            flags = _capi.VAMP_LIFTFWD_EMIT_PAIRS
+            flags |= _capi.VAMP_LIFTFWD_EMIT_PAIRS
             if "lift" not in hp._dirty:
                 flags |= _capi.VAMP_LIFTFWD_CELLS_CLEAN
             hp._dirty.add("lift")           # (until this call has been issued in full)
@@ -506,7 +519,11 @@ class _LiftFn(torch.autograd.Function):
         hp, d, use_depth = ctx.hp, ctx.desc, ctx.use_depth
         depth, feat, mats, hits = ctx.saved_tensors
         g = g.contiguous().float()
-        gfeat = torch.empty(feat.shape, dtype=torch.float32, device=feat.device)
+        if ctx.feat_cl:      # the gradient in the features' own (channel-last) memory layout
+            B_, N_, C_, fH_, fW_ = feat.shape
+            gfeat = torch.empty(B_, N_, fH_, fW_, C_, dtype=torch.float32, device=feat.device).permute(0, 1, 4, 2, 3)
+        else:
+            gfeat = torch.empty(feat.shape, dtype=torch.float32, device=feat.device)
         gdepth = (torch.empty(depth.shape, dtype=torch.float32, device=feat.device)
                   if use_depth else None)
         nbytes = hp.lib.vamp_lift_workspace_bytes(C.byref(d))
@@ -517,6 +534,8 @@ class _LiftFn(torch.autograd.Function):
             valid = _capi.VAMP_LIFTBWD_SPLAT
         elif ctx.logits:
             valid |= _capi.VAMP_LIFTBWD_LOGITS
+        if ctx.feat_cl:
+            valid |= _capi.VAMP_LIFTBWD_FEAT_CHANNEL_LAST
         valid |= {1: _capi.VAMP_LIFTBWD_WPP1, 4: _capi.VAMP_LIFTBWD_WPP4,
                   16: _capi.VAMP_LIFTBWD_WPP16}.get(hp.impl["lift_wpp"], 0)
         hp._dirty.add("lift")

@@ -34,13 +34,17 @@ class LiftRenderStep(nn.Module):
 class SyntheticBatch:
     """Seeded device-resident inputs + fixed upstream gradients for one rank."""
 
-    def __init__(self, cfg: PathConfig, batch: int, device, seed: int = 0, dtype=torch.float32):
+    def __init__(self, cfg: PathConfig, batch: int, device, seed: int = 0, dtype=torch.float32, feat_channel_last=True):
         s2e, K, ida = synthetic.camera_rig(cfg, batch, jitter=1.0 if batch > 1 else 0.0, seed=seed)
         bda = synthetic.bda_matrix(batch)
         self.mats_host = (s2e, K, ida, bda)
         self.lift_mats = lift_matrices(s2e, K, ida, bda).to(device)
         self.render_mats = render_matrices(s2e, K, ida, bda).to(device)
         self.depth, self.feat = synthetic.lift_inputs(cfg, batch, seed=seed, device=device, dtype=dtype)
+        if feat_channel_last and dtype == torch.float32:
+            # the same [B, N, C, fH, fW] values in the memory layout a torch.channels_last `channel_lower` convolution
+            # (bv2:551-553) emits, [B, N, fH, fW, C]: what the lift takes zero-copy (no transposing first launch)
+            self.feat = self.feat.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)
         self.vols = list(synthetic.render_inputs(cfg, batch, seed=seed, device=device, dtype=dtype))
         self.depth.requires_grad_(True)
         self.feat.requires_grad_(True)
