@@ -41,21 +41,58 @@ def _use_shipped_miopen_db():
     layered and the multi-task leg, made on an MI355X of this image by tools/miopen_tune.py (6.5 minutes of find).
     Pointing MIOpen at a private copy (it writes there) gives a default run the TUNED convolutions -- layered step 12
     instead of 130 ms -- without the find.  Must happen before MIOpen loads, i.e. before torch is imported; an
-    environment that already names a db wins.  Returns the directory used, or None."""
+    environment that already names a db wins.  The copy lives in a directory named after a hash of the shipped files
+    (a stale copy of another checkout is never reused), created privately (mode 0700, owned by this user: MIOpen loads
+    compiled code objects from it).  Returns the directory used, or None."""
     src = os.path.join(ROOT, "profiles", "miopen_db")
     if "MIOPEN_USER_DB_PATH" in os.environ or "MIOPEN_CUSTOM_CACHE_DIR" in os.environ or not os.path.isdir(src):
         return None
+    import hashlib
     import shutil
     import tempfile
-    dst = os.path.join(tempfile.gettempdir(), f"vampire_miopen_db_{os.getuid()}_{os.environ.get('LOCAL_RANK', '0')}")
+    h = hashlib.sha256()
+    for root, _dirs, files in sorted(os.walk(src)):
+        for f in sorted(files):
+            path = os.path.join(root, f)
+            h.update(os.path.relpath(path, src).encode())
+            h.update(str(os.path.getsize(path)).encode())
+            with open(path, "rb") as fh:
+                h.update(fh.read(1 << 16))
+    dst = os.path.join(tempfile.gettempdir(),
+                       f"vampire_miopen_db_{os.getuid()}_{os.environ.get('LOCAL_RANK', '0')}_{h.hexdigest()[:16]}")
     try:
-        if not os.path.isdir(dst):
-            shutil.copytree(src, dst)
+        if os.path.isdir(dst):
+            st = os.stat(dst)
+            if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+                return None                      # somebody else's directory under our name: do not load code from it
+        else:
+            tmp = tempfile.mkdtemp(prefix="vampire_miopen_db_")          # 0700, ours
+            shutil.copytree(src, tmp, dirs_exist_ok=True)
+            try:
+                os.rename(tmp, dst)
+            except OSError:                      # another rank of this user won the race: use theirs
+                shutil.rmtree(tmp, ignore_errors=True)
     except OSError:
         return None
     os.environ["MIOPEN_USER_DB_PATH"] = dst
     os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = dst
     return dst
+
+
+def _miopen_db_matches():
+    """Do the shipped db files belong to THIS MIOpen build and device?  Their names carry both
+    (gfx950100.HIP.<version>.ufdb.txt): on another build the find-db is not consulted and `find` would be a real,
+    6.5-minute find -- the caller then stays in immediate mode and says so."""
+    if MIOPEN_DB is None:
+        return False
+    try:
+        ver = torch.backends.cudnn.version()                 # MIOpen's version as major * 1e6 + minor * 1e3 + patch
+        want = f"{ver // 1000000}_{(ver // 1000) % 1000}_{ver % 1000}"
+        names = [f for f in os.listdir(MIOPEN_DB) if f.endswith(".ufdb.txt")]
+        arch = torch.cuda.get_device_properties(0).gcnArchName.split(":")[0]
+        return any(f.startswith(arch) and f".HIP.{want}" in f for f in names)
+    except Exception:                                        # noqa: BLE001
+        return False
 
 
 MIOPEN_DB = _use_shipped_miopen_db()
@@ -351,9 +388,11 @@ def layered_measure(cfg, dev, batch_per_gpu, rank, world, steps=6, warm=3, find=
         model.zero_grad(set_to_none=True)
         layered_step(wrapped, data)
 
+    tw = time.perf_counter()
     for _ in range(warm):
         step()
     vdist.barrier(); torch.cuda.synchronize()
+    warm_s = time.perf_counter() - tw            # (a real MIOpen find shows here: minutes instead of a second)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -365,6 +404,7 @@ def layered_measure(cfg, dev, batch_per_gpu, rank, world, steps=6, warm=3, find=
              if isinstance(wrapped, vdist.GradSync) else "DistributedDataParallel"))
     return {"ms_per_step": el / steps * 1e3, "samples_per_s": batch_per_gpu * world * steps / el,
             "parameters": nparam, "gradient_bytes": 4 * nparam, "grad_sync": sync, "steps": steps,
+            "warmup_s": round(warm_s, 2),
             "what": "mapping_along_depth, channel_lower, depth softmax, lift, Unet3D, heads, render, occupancy queries, "
                     "voxel_output: forward + backward from synthetic neck features"}
 
@@ -725,7 +765,8 @@ def main():
     # always in the line (a few seconds; --no-extra skips them for profile runs)
     _mark("bs8 done")
     # (with the shipped find-db the "find" of these two legs is a look-up: tuned convolutions at no cost)
-    tuned = a.miopen_find or MIOPEN_DB is not None
+    db_ok = _miopen_db_matches()
+    tuned = a.miopen_find or db_ok
     layered = layered_measure(cfg, dev, a.batch, rank, world, find=tuned) if not a.no_extra else None
     _mark("layered step done")
     multitask = multitask_measure(dev, a.batch, rank, world, find=tuned) if not a.no_extra else None
@@ -821,9 +862,12 @@ def main():
                                 "(~35 launches and two stream joins per step) and vary between boxes",
             "weak_scaling_bs8": bs8,
             "miopen": ("find (tuned convolutions)" if a.miopen_find else
-                       "find served from the shipped user find-db + kernel cache (profiles/miopen_db, made by tools/miopen_tune.py): "
-                       "tuned convolutions for the layered / multi-task legs without the 6.5 minutes of find" if MIOPEN_DB is not None else
-                       "immediate mode (no find) for the layered / multi-task legs: their convolutions are untuned; --miopen-find tunes them"),
+                       "find served from the shipped user find-db + kernel cache (profiles/miopen_db, made by tools/miopen_tune.py; "
+                       "its file names match this MIOpen build and device): tuned convolutions for the layered / multi-task legs "
+                       "without the 6.5 minutes of find" if db_ok else
+                       "immediate mode (no find) for the layered / multi-task legs: their convolutions are untuned "
+                       + ("(the shipped find-db is for another MIOpen build / device); " if MIOPEN_DB is not None else "; ")
+                       + "--miopen-find tunes them"),
             "layered_step": layered,
             "multitask_step": multitask,
             "early_ray_termination": ert_stats,

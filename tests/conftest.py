@@ -19,15 +19,26 @@ def pytest_configure(config):
 def pytest_unconfigure(config):
     """Composable-kernel instances inside MIOpen / hipBLASLt print a "GridwiseOp: Problemsize ..." line per call
     into the C stdio buffer, which is flushed when the process exits -- AFTER pytest's summary, so that the tail
-    of a run's output (what the driver records) is nothing but that chatter.  Once pytest has printed its summary,
-    fd 1 goes to /dev/null and the buffer is flushed there."""
+    of a run's output (what the driver records) is nothing but that chatter.  Only when a GPU was used (on CPU runs
+    nothing prints there), and as late as possible -- an atexit hook registered here, i.e. behind pytest's own
+    reporting, plugins' unconfigure hooks and in-process callers that print after pytest.main() -- the buffer is
+    flushed into /dev/null; the temporary descriptor is closed again."""
+    if not (torch.cuda.is_available() and torch.cuda.is_initialized()):
+        return
+    import atexit
     import ctypes
-    try:
-        sys.stdout.flush()
-        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
-        ctypes.CDLL(None).fflush(None)
-    except Exception:           # noqa: BLE001 -- never fail a run over its log
-        pass
+
+    def _drop_c_stdio():
+        try:
+            sys.stdout.flush()
+            fd = os.open(os.devnull, os.O_WRONLY)
+            os.dup2(fd, 1)
+            os.close(fd)
+            ctypes.CDLL(None).fflush(None)
+        except Exception:           # noqa: BLE001 -- never fail a run over its log
+            pass
+
+    atexit.register(_drop_c_stdio)
 
 
 def load_golden(name):

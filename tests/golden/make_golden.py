@@ -462,6 +462,38 @@ def make_cfg_d_grads(BaseVAMPIRE2):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB; grad_beta", out["grad_beta"])
 
 
+def make_cfg_d_samples(BaseVAMPIRE2):
+    """BASELINE configs[3] forward, element by element (VERDICT r05 #5a): the reference's lift output and its eight
+    rendered tensors at 512x1408 / 400x400x32 on the bf16-rounded inputs, 10 000 strided elements each ->
+    cfgd_samples.npz.  (make_cfg_d pins the same run by block sums and 64 probes only.)"""
+    from vampire_amd.config import CFG_D as cfg
+    from vampire_amd import synthetic
+    m = ref_module(BaseVAMPIRE2, cfg, "sdf", False)
+    s2e, K, ida = synthetic.camera_rig(cfg, 1)
+    bda = synthetic.bda_matrix(1)
+    rnd = lambda t: t.bfloat16().float()
+    depth, feat = (rnd(t) for t in synthetic.lift_inputs(cfg, 1, seed=0))
+    vols = [rnd(t) for t in synthetic.render_inputs(cfg, 1, seed=0)]
+    mats = dict(sensor2ego_mats=s2e[:, None], intrin_mats=K[:, None], ida_mats=ida[:, None], bda_mat=bda)
+    out = {}
+    with torch.no_grad():
+        vox = m.get_voxel_feats(depth.unsqueeze(2) * feat.unsqueeze(3), 0, mats)
+        out["lift"], out["lift_stride"] = strided_sample(vox)
+        out["lift_absmax"] = float(vox.abs().max())
+        del vox
+        print("cfg D lift done", flush=True)
+        geom = torch.nan_to_num(m.get_geometry(s2e, K, ida, bda), -1e3)
+        r = m.volume_rendering_from_multiple_views(geom, *vols)
+        for n_, t in zip(RENDER_NAMES, r):
+            out[n_], out[n_ + "_stride"] = strided_sample(t)
+            out[n_ + "_absmax"] = float(t.abs().max())
+    out["beta"] = float(m.density.beta.detach())
+    path = os.path.join(HERE, "cfgd_samples.npz")
+    np.savez_compressed(path, **{k: (v.numpy() if torch.is_tensor(v) else np.float64(v) if isinstance(v, float) else np.int64(v))
+                                 for k, v in out.items()})
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def make_regimes(BaseVAMPIRE2):
     """cfg-B, B=1, the reference's renderer with autograd in two more density regimes:
       "naive"  density_mode="naive" on the synthetic volumes (bv2:191-194; Q6: masked samples carry
@@ -756,6 +788,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--cfgd-grads" in sys.argv:
         make_cfg_d_grads(V2)
+        sys.exit(0)
+    if "--cfgd-samples" in sys.argv:
+        make_cfg_d_samples(V2)
         sys.exit(0)
     if "--regimes-only" in sys.argv:
         make_regimes(V2)

@@ -626,7 +626,12 @@ lift_fwd_coop_kernel(LiftParams P, const float* __restrict__ mats, const float* 
       xch[wave][lane][0] = make_float4(__int_as_float(pix[0]), __int_as_float(pix[1]), __int_as_float(pix[2]), __int_as_float(pix[3]));
       xch[wave][lane][1] = make_float4(wd[0], wd[1], wd[2], wd[3]);
     }
-    // (one wave writes and reads its own slab: the LDS queue of a wave is in order, no barrier)
+    // (one wave writes and reads its own slab.  The writes and the reads below touch the same words from different
+    // lanes: a wave-level fence + barrier between them -- no instruction on gfx9, but it forbids the compiler to
+    // reorder them should it ever prove the two index expressions distinct)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- lane = (voxel vq of row g, channel quad q): two rows of the patch at a time
     const float4* frow = reinterpret_cast<const float4*>(feat_cl) + bn * HW * 4 + q;
 constexpr int R = 2;                          // rows of the patch whose loads are in flight together
@@ -666,6 +671,9 @@ constexpr int R = 2;                          // rows of the patch whose loads a
         }
       }
     }
+    // (the next camera overwrites the slab: its writes stay behind these reads)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 
   // ---- the mean over the cameras that hit (bv2:509-514) and the stores, row by row of the patch

@@ -49,7 +49,7 @@ extern "C" int vamp_debug_direct_stamps(long long* host, size_t n) {
 
 // Diagnostic export (tests): inside mask, floor taps and continuous tap coordinates of EVERY sample
 // exactly as cam_fwd_direct_kernel evaluates them -- same tile decomposition, same wave composition (the
-// fallback to the fp32 chain is a wave-level decision), same code (direct_tap).
+// IEEE-division fallback near a face is a wave-level decision), same code (chain_tap).
 __global__ void __launch_bounds__(256)
 cam_direct_taps_kernel(RenderParams P, const float* __restrict__ mats, const float* __restrict__ us,
                        const float* __restrict__ vs, const float* __restrict__ ds,
@@ -60,10 +60,9 @@ cam_direct_taps_kernel(RenderParams P, const float* __restrict__ mats, const flo
   const int S = P.D - 1;
   const float* m = mats + (long) bn * 48;
   const float u = us[id.w], v = vs[id.h];
-  const bool affine = m[2] == 0.0f && m[6] == 0.0f;
-  const RayLine L = ray_line(m, P, u, v, ds[0], ds[S]);
+  const ChainCtx cc = chain_ctx(P, m, u, v);
   for (int i = id.sub; i < S; i += 4) {
-    const VolTap tp = direct_tap(P, m, L, affine, u, v, ds[i]);
+    const VolTap tp = chain_tap(P, m, cc, ds[i]);
     if (!id.live) continue;
     const long idx = (((long) bn * S + i) * P.fH + id.h) * P.fW + id.w;
     inside[idx] = tp.inside ? 1 : 0;

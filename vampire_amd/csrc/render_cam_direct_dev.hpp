@@ -161,94 +161,49 @@ inline size_t cam_direct_dyn_bytes(int S, int NCH) {
 }
 
 // ---------------------------------------------------------------------------
-// The sample points of one ray as a line in tap coordinates.
+// The sample points of a ray: EVERY tap -- density samples and composited channels alike -- is evaluated with the
+// reference's own fp32 coordinate chain, get_geometry bv2:328-349 + the normalisation of bv2:397-404, its roundings
+// bit for bit (frustum_point_rb; the three divisions by the spans through refined reciprocals, and with the IEEE
+// divisions of volume_tap whenever a lane of the wave is within 1e-3 voxel of a face of the volume, so that the
+// inclusive inside mask, bv2:405-407, is the reference's).
 //
-// get_geometry (bv2:328-349) maps (u, v, d, 1) through inv(ida), multiplies x and y by z, then
-// through two more matrices.  When inv(ida)'s x and y rows do not depend on the depth (entries
-// [0][2] and [1][2] are zero: image-plane augmentations never touch depth) the result is AFFINE in
-// d, and so are the continuous tap coordinates f = (p - lo) / span * (size - 1) of bv2:397-404 /
-// aten's align_corners=True rule.  The line f(d) = A + d B is set up once per ray in fp64 (the exact
-// chain at the first and the last depth plane) and evaluated per sample with three fp64 fma: ~25
-// vector instructions instead of the ~160 of the fp32 chain with its three IEEE divisions, which is
-// what this kernel was bound by.  f(d) is the correctly rounded value of the exact map; the
-// reference's own fp32 chain deviates from that by its accumulated rounding (a few ulp of f, 1e-5
-// voxel), which moves a trilinear sample by < 3e-5 on white-noise volumes (bar: 1e-4).  The one thing
-// that is NOT continuous in f is the inclusive inside mask (bv2:405-407): whenever a lane of the wave
-// is within 1e-3 voxel of a face of the volume, the wave evaluates the reference's fp32 chain for that
-// depth index, so the mask is the reference's bit for bit.
+// Rounds 4 - 5 set every ray up as a LINE in tap coordinates in fp64 (exact map, three fp64 fma per sample) and took
+// the composited channels' taps from it.  The line is the correctly rounded value of the exact map -- and that is the
+// problem: the reference's fp32 chain deviates from the exact map by a few ulp of a tap coordinate, 1e-5 voxel at
+// x = 255 and 1e-4 at x = 400, which on white-noise volumes moves a semantic logit by 7.7e-5 at cfg-A and by 1.06e-4 at
+// cfg-D -- over north_star's 1e-4 (round 6's element check at cfg-D found it; the planned march, which has always
+// used the chain, is within 9e-7 there).  With the chain everywhere the one-kernel forward is as close; it costs ~85
+// vector instructions more per gathered sample and saves the ~500 issue slots of the fp64 set-up per wave.
 // ---------------------------------------------------------------------------
-struct RayLine {
-  double ax, bx, ay, by, az, bz;      // tap coordinates: f = a + d * b
-  float len;                          // ego-space length of the ray per unit of depth (bv2:426)
+struct ChainCtx {
+  RayBase rb;            // inv(ida) (u, v, ., 1) without the depth term
+  SpanRcp span_r;        // refined reciprocals of the volume's spans
+  bool bda_identity;     // uniform
 };
-
-__device__ __forceinline__ void chain_f64(const float* __restrict__ m, const RenderParams& P, double u, double v,
-                                          double d, double& ex, double& ey, double& ez) {
-  double p[4], q[4];
+__device__ __forceinline__ ChainCtx chain_ctx(const RenderParams& P, const float* __restrict__ m, float u, float v) {
+  ChainCtx c;
+  c.rb = ray_base(m, u, v);
+  c.bda_identity = true;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) p[r] = (double) m[4 * r] * u + (double) m[4 * r + 1] * v + (double) m[4 * r + 2] * d + (double) m[4 * r + 3];
-  p[0] *= p[2]; p[1] *= p[2];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) q[r] = (double) m[16 + 4 * r] * p[0] + (double) m[17 + 4 * r] * p[1] + (double) m[18 + 4 * r] * p[2] + (double) m[19 + 4 * r] * p[3];
-  ex = (double) m[32] * q[0] + (double) m[33] * q[1] + (double) m[34] * q[2] + (double) m[35] * q[3];
-  ey = (double) m[36] * q[0] + (double) m[37] * q[1] + (double) m[38] * q[2] + (double) m[39] * q[3];
-  ez = (double) m[40] * q[0] + (double) m[41] * q[1] + (double) m[42] * q[2] + (double) m[43] * q[3];
+  for (int k = 0; k < 16; ++k) c.bda_identity = c.bda_identity && m[32 + k] == ((k % 5 == 0) ? 1.0f : 0.0f);
+  c.span_r = SpanRcp{rcp_refined(P.span[0]), rcp_refined(P.span[1]), rcp_refined(P.span[2])};
+  return c;
 }
-
-__device__ __forceinline__ RayLine ray_line(const float* __restrict__ m, const RenderParams& P, float u, float v,
-                                            float d0, float d1) {
-  double x0, y0, z0, x1, y1, z1;
-  chain_f64(m, P, u, v, d0, x0, y0, z0);
-  chain_f64(m, P, u, v, d1, x1, y1, z1);
-  const double inv = 1.0 / ((double) d1 - (double) d0);
-  const double sx = (double) (P.X - 1) / (double) P.span[0], sy = (double) (P.Y - 1) / (double) P.span[1],
-               sz = (double) (P.Z - 1) / (double) P.span[2];
-  RayLine L;
-  const double dx = (x1 - x0) * inv, dy = (y1 - y0) * inv, dz = (z1 - z0) * inv;
-  L.bx = dx * sx; L.by = dy * sy; L.bz = dz * sz;
-  L.ax = (x0 - (double) P.lo[0]) * sx - (double) d0 * L.bx;
-  L.ay = (y0 - (double) P.lo[1]) * sy - (double) d0 * L.by;
-  L.az = (z0 - (double) P.lo[2]) * sz - (double) d0 * L.bz;
-  L.len = (float) sqrt(dx * dx + dy * dy + dz * dz);
-  return L;
+// the frustum point at depth d in the ego frame (nan_to_num'ed, bv2:612).  `mm`: the matrices, which callers read
+// again per use (asm barrier) instead of keeping 40 scalars alive across the kernel
+__device__ __forceinline__ void chain_point(const float* __restrict__ mm, const ChainCtx& c, float d, float& x, float& y,
+                                            float& z) {
+  if (c.bda_identity) frustum_point_rb_id(mm, c.rb, d, x, y, z);
+  else frustum_point_rb(mm, c.rb, d, x, y, z);
 }
-
-// tap of the sample at depth d: from the line, or -- `exact`, wave-uniform -- from the fp32 chain
-__device__ __forceinline__ VolTap line_tap(const RenderParams& P, const RayLine& L, float d, bool& near_face) {
-  const float fx = (float) __builtin_fma((double) d, L.bx, L.ax);
-  const float fy = (float) __builtin_fma((double) d, L.by, L.ay);
-  const float fz = (float) __builtin_fma((double) d, L.bz, L.az);
-  const float X1 = (float) (P.X - 1), Y1 = (float) (P.Y - 1), Z1 = (float) (P.Z - 1);
-  VolTap t;
-  t.inside = fx >= 0.f && fx <= X1 && fy >= 0.f && fy <= Y1 && fz >= 0.f && fz <= Z1;
-  const float e = fminf(fminf(fminf(fabsf(fx), fabsf(fx - X1)), fminf(fabsf(fy), fabsf(fy - Y1))),
-                        fminf(fabsf(fz), fabsf(fz - Z1)));
-  near_face = !(e > 1e-3f);                         // (also true for a NaN coordinate)
-  const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
-  t.ix0 = (int) flx; t.iy0 = (int) fly; t.iz0 = (int) flz;
-  t.wx1 = fx - flx; t.wx0 = (flx + 1.0f) - fx;
-  t.wy1 = fy - fly; t.wy0 = (fly + 1.0f) - fy;
-  t.wz1 = fz - flz; t.wz0 = (flz + 1.0f) - fz;
-  t.fx = fx; t.fy = fy; t.fz = fz;
-  return t;
-}
-
-// Tap of the sample at depth d as the kernel uses it: the line, or -- whenever a lane of the wave is
-// within 1e-3 voxel of a face of the volume, or the chain is not affine -- the reference's fp32 chain
-// (wave-uniform decision; `m` is read again here instead of living in 36 scalar registers, which the
-// allocator does not have: they came back through v_readlane).  Shared by the forward kernel and the
-// diagnostic export below, so that the export shows exactly the taps the forward sampled.
-__device__ __forceinline__ VolTap direct_tap(const RenderParams& P, const float* __restrict__ m, const RayLine& L,
-                                             bool affine, float u, float v, float d) {
+// Tap of the sample at depth d as the kernel uses it.  Shared by the forward kernel and the diagnostic export, so
+// that the export shows exactly the taps the forward sampled (the face fallback is a wave-level decision).
+__device__ __forceinline__ VolTap chain_tap(const RenderParams& P, const float* __restrict__ mm, const ChainCtx& c, float d) {
+  float x, y, z;
+  chain_point(mm, c, d, x, y, z);
   bool near_face;
-  VolTap tp = line_tap(P, L, d, near_face);
-  if (!affine || __any(near_face)) {
-    const float* mm = m;
-    asm volatile("" : "+s"(mm));
-    float x, y, z;
-    frustum_point(mm, u, v, d, x, y, z);
-    tp = volume_tap(P, nan_to_num_geom(x), nan_to_num_geom(y), nan_to_num_geom(z));
-  }
+  VolTap tp = volume_tap_rcp(P, c.span_r, x, y, z, near_face);
+  if (__any(near_face)) tp = volume_tap(P, x, y, z);             // the inside mask is the reference's bit for bit
   return tp;
 }
 
@@ -283,9 +238,7 @@ __device__ __forceinline__ RayId decode_tile(const RenderParams& P, unsigned bid
 // rows[((tile * S + i) * P.CP + c) * 64 + ray]: 256 contiguous bytes per (tile, depth index, channel), so
 // the backward's per-ray pass (same tiles, same lanes) reads them back coalesced instead of repeating
 // the 8-tap gathers, which are all that pass was bound by.
-// The density samples sit on the reference's own fp32 coordinate chain (tap_density).  (Round 5 had the ray's fp64
-// line as a second mode, 2.7 us faster and 2.2e-4 m off in depth_preds at cfg-A -- outside north_star's 1e-4, so it
-// is not a mode of this library any more.)
+// All samples sit on the reference's own fp32 coordinate chain (chain_tap above).
 // `bid`: the workgroup's index among the camera tiles' workgroups (blockIdx.x of cam_fwd_direct_kernel; the merged
 // render forward of render_fwd_merged.hip passes its own).
 template <typename T, int NCH, bool ERT, int NW>
@@ -323,72 +276,62 @@ cam_fwd_direct_tile(const unsigned bid, const RenderParams& P, const float* __re
 #ifdef VAMP_DIRECT_STAMPS
   const long long wall0 = wall_clock64();                          // 100 MHz, one clock for the whole device
 #endif
-  // the ray as a line in tap coordinates; `affine`: the chain is affine in the depth (see RayLine)
+  // `affine`: the chain is affine in the depth -- inv(ida)'s x and y rows do not depend on it (image-plane
+  // augmentations never touch depth) -- so a ray's sample points lie on a line at constant speed
   const bool affine = m[2] == 0.0f && m[6] == 0.0f;               // uniform
-  const RayLine L = ray_line(m, P, u, v, ds[0], ds[S]);
-  // tap of depth index i: the line, or the reference's fp32 chain where the inside mask is decided
-  auto tap_at = [&](int i) -> VolTap { return direct_tap(P, m, L, affine, u, v, ds[i]); };
-  // Tap of a DENSITY sample: the reference's own fp32 chain (frustum_point_rb: its roundings bit for bit; the
-  // divisions of the normalisation through refined reciprocals).  The line above is the exact map, the
-  // reference's chain deviates from it by a few ulp of a tap coordinate -- 1e-5 voxel, which the Laplace
-  // density's slope (1 / (2 beta^2) = 50 per unit of the feature) turns into 1e-4 of a seg logit and 2e-4 m of
-  // depth at cfg-A (full-size element check, round 5).  The weights are where that sensitivity sits, so the
-  // density samples follow the reference's coordinates (~65 instructions more per sample of the density
-  // phase); the K + 3 composited channels, which enter linearly, stay on the line.
-  const RayBase rb = ray_base(m, u, v);
-  bool bda_identity = true;                                        // uniform
-#pragma unroll
-  for (int k = 0; k < 16; ++k) bda_identity = bda_identity && m[32 + k] == ((k % 5 == 0) ? 1.0f : 0.0f);
-  const SpanRcp span_r{rcp_refined(P.span[0]), rcp_refined(P.span[1]), rcp_refined(P.span[2])};
-  // (`mm`: the matrices read again once per ROUND of the density phase, by the caller -- 40 scalars do not stay in
-  // registers across the kernel, and read again per sample the four samples of a round waited four times)
-  auto tap_density = [&](int i, const float* mm) -> VolTap {
-    float x, y, z;
-    if (bda_identity) frustum_point_rb_id(mm, rb, ds[i], x, y, z);
-    else frustum_point_rb(mm, rb, ds[i], x, y, z);
-    bool near_face;
-    VolTap tp = volume_tap_rcp(P, span_r, x, y, z, near_face);
-    if (__any(near_face)) tp = volume_tap(P, x, y, z);             // the inside mask is the reference's bit for bit
-    return tp;
-  };
-  // length of bin i (bv2:426: norm of consecutive frustum points): along an affine chain the points of a
-  // ray lie on a line, L.len per unit of depth; otherwise the two points themselves
+  const ChainCtx cc = chain_ctx(P, m, u, v);
+  // the ray's first and last frustum point: its ego-space length per unit of depth (bv2:426 along a line) and, for
+  // the tile's corner rays, the plan's lines
+  float ex0, ey0, ez0, ex1, ey1, ez1;
+  chain_point(m, cc, ds[0], ex0, ey0, ez0);
+  chain_point(m, cc, ds[S], ex1, ey1, ez1);
+  const float inv_dd = 1.0f / (ds[S] - ds[0]);
+  const float ray_len = sqrtf((ex1 - ex0) * (ex1 - ex0) + (ey1 - ey0) * (ey1 - ey0) + (ez1 - ez0) * (ez1 - ez0)) * inv_dd;
+  // length of bin i (bv2:426: norm of consecutive frustum points): along an affine chain ray_len per unit of depth;
+  // otherwise the two points themselves
   auto delta_at = [&](int i) -> float {
-    if (affine) return L.len * (ds[i + 1] - ds[i]);
+    if (affine) return ray_len * (ds[i + 1] - ds[i]);
     const float* mm = m;
     asm volatile("" : "+s"(mm));
     float x0, y0, z0, x1, y1, z1;
-    frustum_point(mm, u, v, ds[i], x0, y0, z0);
-    frustum_point(mm, u, v, ds[i + 1], x1, y1, z1);
-    const float dx = nan_to_num_geom(x1) - nan_to_num_geom(x0), dy = nan_to_num_geom(y1) - nan_to_num_geom(y0),
-                dz = nan_to_num_geom(z1) - nan_to_num_geom(z0);
+    chain_point(mm, cc, ds[i], x0, y0, z0);
+    chain_point(mm, cc, ds[i + 1], x1, y1, z1);
+    const float dx = x1 - x0, dy = y1 - y0, dz = z1 - z0;
     return sqrtf(dx * dx + dy * dy + dz * dz);
   };
 
   // ---- plan: depth indices of the tile that can hold inside samples.  The tile's samples at one depth index
   // are an affine image of the pixel rectangle, so the box of its four corner rays bounds all 64 (ray_plan.hpp).
-  // Along an affine chain the corner rays' sample points are the LINES this kernel has just set up (lanes 0, 7,
-  // 56 and 63 of a wave hold them): a lane per depth index evaluates the four corners with 12 fp64 fma instead
-  // of two full fp32 chains per lane with their matrix, axis and lattice loads (round 5; the plan phase was a
-  // fifth of a tile's time).  The lines are the exact map; the box keeps its 0.05 voxel of slack for the
-  // rounding of the chain that decides the mask.  A non-affine chain takes plan_tile.
+  // Along an affine chain a corner ray's tap coordinates are a line through its first and last point (lanes 0, 7, 56
+  // and 63 of a wave hold them): a lane per depth index evaluates the four corners with 12 fma instead of two full
+  // chains per lane with their matrix, axis and lattice loads (round 5; the plan phase was a fifth of a tile's time).
+  // fp32 lines: their error, a few 1e-4 voxel at x = 400, is far inside the box's 0.05 voxel of slack, which also
+  // covers the rounding of the chain that decides the mask.  A non-affine chain takes plan_tile.
   if (VAMP_DIRECT_LINE_PLAN && affine) {
-    __shared__ double cl[4][6];
+    __shared__ float cl[4][6];
     if (sub == 0 && (lane == 0 || lane == 7 || lane == 56 || lane == 63)) {
-      double* c = cl[(lane == 0) ? 0 : (lane == 7 ? 1 : (lane == 56 ? 2 : 3))];
-      c[0] = L.ax; c[1] = L.bx; c[2] = L.ay; c[3] = L.by; c[4] = L.az; c[5] = L.bz;
+      float* c = cl[(lane == 0) ? 0 : (lane == 7 ? 1 : (lane == 56 ? 2 : 3))];
+      const float e0[3] = {ex0, ey0, ez0}, e1[3] = {ex1, ey1, ez1};
+      const float n1[3] = {(float) (P.X - 1), (float) (P.Y - 1), (float) (P.Z - 1)};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float sc = n1[a] / P.span[a];
+        const float f0 = (e0[a] - P.lo[a]) * sc, f1 = (e1[a] - P.lo[a]) * sc;
+        const float bb = (f1 - f0) * inv_dd;
+        c[2 * a] = f0 - ds[0] * bb; c[2 * a + 1] = bb;
+      }
     }
     __syncthreads();
     const int i = threadIdx.x;
     if (i < kPlanMax) {
-      const double d = (double) ds[min(i, P.D - 1)];
+      const float d = ds[min(i, P.D - 1)];
       float mn[3], mx[3];
       bool fin = true;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          const float f = (float) __builtin_fma(d, cl[k][2 * a + 1], cl[k][2 * a]);
+          const float f = __builtin_fmaf(d, cl[k][2 * a + 1], cl[k][2 * a]);
           fin = fin && fabsf(f) <= 1e30f;
           mn[a] = k ? fminf(mn[a], f) : f;
           mx[a] = k ? fmaxf(mx[a], f) : f;
@@ -432,7 +375,7 @@ cam_fwd_direct_tile(const unsigned bid, const RenderParams& P, const float* __re
     actf_s[lane] = a_lo ? 1 : 0;
     actf_s[64 + lane] = a_hi ? 1 : 0;
     // masked samples carry density(0) (Q6): optical depth per unit of depth of the skipped bins
-    tunit_s[lane] = density_fast(dp, 0.f) * L.len;
+    tunit_s[lane] = density_fast(dp, 0.f) * ray_len;
   }
   __syncthreads();
   VAMP_STAMP(1);
@@ -463,7 +406,7 @@ cam_fwd_direct_tile(const unsigned bid, const RenderParams& P, const float* __re
       for (int g = 0; g < G; ++g) {
         in[g] = false; delta[g] = 0.f;
         if (idx[g] < S) {
-          const VolTap tp = tap_density(idx[g], mround);
+          const VolTap tp = chain_tap(P, mround, cc, ds[idx[g]]);
           delta[g] = delta_at(idx[g]);                                                 // bv2:426
           in[g] = tp.inside;
           if (tp.inside) {
@@ -591,7 +534,9 @@ cam_fwd_direct_tile(const unsigned bid, const RenderParams& P, const float* __re
     const unsigned vbytes = V * (unsigned) sizeof(T);               // one channel, bytes (launcher: K * V * es < 2 GB)
     for (int k = k0; k < k1; ++k) {
       const int i = __builtin_amdgcn_readfirstlane((int) act_s[k]);
-      const VolTap tp = tap_at(i);
+      const float* mg = m;
+      asm volatile("" : "+s"(mg));
+      const VolTap tp = chain_tap(P, mg, cc, ds[i]);
       if (tp.inside && i < keep) {
         const PairTap pt = pair_tap<T>(P, tp);
         const float wgt = wbuf[i * 64 + lane];

@@ -205,11 +205,22 @@ class HotPath:
     # The statistic: mean over the 8 x 8 ray tiles of (largest number of leading samples a ray of the tile keeps)
     # / (samples per ray) -- what the one kernel's cost follows -- from the termination table in the workspace
     # (0.09 on the synthetic sdf workload, 0.69 under the sigmoid density; the two forwards cost the same near
-    # 0.5 - 0.6).  It is formed on the device on some eager calls, copied to pinned host memory without a sync,
-    # and read by LATER calls: the choice lags the data by a step or two and costs nothing.
+    # 0.5 - 0.6).
+    # DETERMINISTIC (round 6): the statistic is formed on the device at fixed call indices (every _PROBE_EVERY-th
+    # eager call), copied to pinned host memory behind an event, and APPLIED at a fixed later call index
+    # (_PROBE_LAG calls on), where the host waits for that event -- long done by then, so the wait costs nothing.
+    # Which call switches is therefore a function of the call index and the data alone: two runs of one seed (and
+    # the ranks of a data-parallel job on equal data) take the same kernels in every call.  (Round 5 read the
+    # pinned word whenever it happened to have landed: the switch depended on host timing.)
     _PROBE_EVERY = 16            # one-kernel mode: the table is the forward's by-product; the probe is two small reductions
     _PROBE_EVERY_PLANNED = 64    # planned mode leaves no table: the density-only pre-pass (20 - 60 us) is run for the probe
+    _PROBE_LAG = 8               # calls between a probe and the call that applies it
     _TO_PLANNED, _TO_DIRECT = 0.5, 0.4                           # hysteresis
+
+    def camera_forward_mode(self):
+        """The camera forward the next "auto" call takes ("direct" = one kernel + early termination, "planned" = copy +
+        planned march), for logs: bench.py reports it beside the captured step."""
+        return self._cam_sel["mode"]
 
     def _camera_forward_choice(self, can_direct, no_geom):
         """(ert, direct) of this call."""
@@ -219,8 +230,14 @@ class HotPath:
             want = ert_allowed if sel == "auto" else bool(sel)
             return ert_allowed, bool(can_direct and want)
         st = self._cam_sel
-        r = float(st["host"][0])                       # pinned memory: whatever the last finished probe left
-        if r >= 0.0:
+        pend = st.get("pending")
+        # a probe is applied at ITS call index + lag, never earlier or later (calls under graph capture do not count:
+        # a captured graph keeps the variant of its capture)
+        if pend is not None and st["calls"] + 1 >= pend[0] and not torch.cuda.is_current_stream_capturing():
+            pend[1].synchronize()
+            r = float(st["host"][0])
+            st["last"] = r
+            st["pending"] = None
             if st["mode"] == "direct" and r > self._TO_PLANNED:
                 st["mode"] = "planned"
             elif st["mode"] == "planned" and r < self._TO_DIRECT:
@@ -228,13 +245,15 @@ class HotPath:
         return (True, True) if st["mode"] == "direct" else (False, False)
 
     def _camera_forward_probe(self, d, ws, tensors, ert, no_geom, stream):
-        """Some eager calls of the auto mode: the statistic of this call's termination table."""
+        """The eager calls of the auto mode at the probe indices: the statistic of this call's termination table."""
         if self.impl["cam_direct"] != "auto" or not (no_geom and self.impl["ert"]):
+            return
+        if torch.cuda.is_current_stream_capturing():
             return
         st = self._cam_sel
         st["calls"] += 1
         every = self._PROBE_EVERY if ert else max(self._PROBE_EVERY, self._PROBE_EVERY_PLANNED if self._PROBE_EVERY > 1 else 1)
-        if (st["calls"] - 1) % every or torch.cuda.is_current_stream_capturing():
+        if (st["calls"] - 1) % every or st.get("pending") is not None:
             return
         c = self.cfg
         if not ert:
@@ -248,6 +267,9 @@ class HotPath:
         tile_max = torch.nn.functional.max_pool2d(term.float(), 8, ceil_mode=True)
         st["dev"].copy_((tile_max.mean() / float(c.D - 1)).reshape(1))
         st["host"].copy_(st["dev"], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        st["pending"] = [st["calls"] + min(self._PROBE_LAG, every - 1 if every > 1 else 1), ev]
 
     def _workspace(self, key, nbytes):
         t = self._ws.get(key)
