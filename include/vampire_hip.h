@@ -182,8 +182,9 @@ int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs
 #define VAMP_LIFTBWD_LOGITS 256
 /* (ABI 6) feat is read, and grad_feat written, channel-last [B, N, fH, fW, C] fp32 (see VAMP_LIFTFWD_FEAT_CHANNEL_LAST) */
 #define VAMP_LIFTBWD_FEAT_CHANNEL_LAST 512
+/* (ABI 6: takes `depth` -- a pair now carries its four depth samples, so that the backward reads no depth plane) */
 int vamp_lift_prepare(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
-                      const float* zs, void* workspace, size_t workspace_bytes, void* stream);
+                      const float* zs, const void* depth, void* workspace, size_t workspace_bytes, void* stream);
 int vamp_lift_backward_ex(const VampLiftDesc* d, const float* mats, const float* xs,
                           const float* ys, const float* zs, const void* depth,
                           const void* feat, const float* grad_out, const uint64_t* hits,

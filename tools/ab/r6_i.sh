@@ -1,0 +1,5 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests/test_hip_parity.py -x -q -k "lift or full_size_gradients" 2>&1 | grep -v GridwiseOp | tail -3
+for r in 1 2; do python tools/try_graph.py B 1 300 2>&1 | grep -i "graph"; done
+bash tools/kstats.sh B 1 9

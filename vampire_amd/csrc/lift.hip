@@ -503,8 +503,11 @@ lift_fwd_kernel(LiftParams P, const float* __restrict__ mats, const float* __res
       const int n = __builtin_ctz(cams);
       const long bn = (long) b * P.N + n;
       const LiftTap t = lift_project_from<true>(P, mats + bn * 48, shared_bda ? p1 : matvec(mats + bn * 48, Vec4{vx, vy, vz, 1.0f}));
-      if (EMIT && chunk == 0)        // (wave-uniform here: the lanes part ways at the next line)
-        if (lift_emit_pair(P, E, t, true, bn, V, vox, tid & 63)) wmask |= 1u << (n & 31);
+      bool pair = false;
+      if (EMIT && chunk == 0) {      // (wave-uniform here: the lanes part ways at the next line)
+        pair = lift_emit_pair(P, E, t, true, bn, V, vox, tid & 63);
+        if (pair) wmask |= 1u << (n & 31);
+      }
       if (!t.valid) continue;
       float dep[4];
       depth_taps<T>(P, depth + bn * P.D * HW, t, dep);
@@ -534,6 +537,7 @@ lift_fwd_kernel(LiftParams P, const float* __restrict__ mats, const float* __res
         sum[c] += acc[c];
         cnt += (uint64_t) (fabsf(acc[c]) > 0.f) << (4 * c);   // per-channel hit count (bv2:509)
       }
+      if (EMIT && chunk == 0) lift_emit_dep(E, pair, bn, V, vox, dep);     // (behind the feature gather's loads)
     }
     float* o = out + ((long) b * P.C + chunk * CH) * V + vox;
     // the mean over the cameras that hit (bv2:509-514).  Unless a feature channel holds exact zeros the CH
@@ -711,10 +715,10 @@ constexpr int R = 2;                          // rows of the patch whose loads a
 
 // The same walk without the samples: counts and emits the pairs for a backward whose forward did
 // not (vamp_lift_prepare; vamp_lift_backward without VAMP_LIFTBWD_CELLS_VALID).
-template <int TX, int TY>
+template <typename T, int TX, int TY>
 __global__ void __launch_bounds__(TX* TY)
 lift_pairs_kernel(LiftParams P, const float* __restrict__ mats, const float* __restrict__ xs,
-                  const float* __restrict__ ys, const float* __restrict__ zs, LiftEmit E) {
+                  const float* __restrict__ ys, const float* __restrict__ zs, const T* __restrict__ depth, LiftEmit E) {
   const int tid = threadIdx.x;
   const int x = blockIdx.x * TX + (tid % TX);
   const int y = blockIdx.y * TY + (tid / TX);
@@ -722,12 +726,17 @@ lift_pairs_kernel(LiftParams P, const float* __restrict__ mats, const float* __r
   if (x >= P.X || y >= P.Y) return;
   const float vx = xs[x], vy = ys[y], vz = zs[z];
   const long V = (long) P.Z * P.Y * P.X;
+  const long HW = (long) P.fH * P.fW;
   const long vox = ((long) z * P.Y + y) * P.X + x;
   unsigned wmask = 0;
   for (int n = 0; n < P.N; ++n) {
     const long bn = (long) b * P.N + n;
     const LiftTap t = lift_project<true>(P, mats + bn * 48, vx, vy, vz);
-    if (lift_emit_pair(P, E, t, true, bn, V, vox, tid & 63)) wmask |= 1u << (n & 31);
+    float dep[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t.valid) depth_taps<T>(P, depth + bn * P.D * HW, t, dep);
+    const bool pair = lift_emit_pair(P, E, t, true, bn, V, vox, tid & 63);
+    if (pair) wmask |= 1u << (n & 31);
+    lift_emit_dep(E, pair, bn, V, vox, dep);
   }
   if (E.amask) E.amask[(long) b * V + vox] = wmask;
 }
@@ -1018,13 +1027,16 @@ static int lift_forward_t(const VampLiftDesc* d, const LiftParams& P, const floa
 }
 
 int launch_lift_cell_prepare(const VampLiftDesc* d, const float* mats, const float* xs,
-                             const float* ys, const float* zs, void* scratch, hipStream_t s) {
+                             const float* ys, const float* zs, const void* depth, void* scratch, hipStream_t s) {
   const LiftParams P = to_params(d);
   if (int e = launch_lift_cells_begin(d, scratch, s)) return e;
   const LiftEmit E = lift_emit_of(d, scratch);
   constexpr int TX = VAMP_LIFT_TX, TY = VAMP_LIFT_TY;
   dim3 grid((P.X + TX - 1) / TX, (P.Y + TY - 1) / TY, P.Z * P.B);
-  VAMP_TIMED(kProfLiftBwdCount, s, (lift_pairs_kernel<TX, TY><<<grid, TX * TY, 0, s>>>(P, mats, xs, ys, zs, E)));
+  if (d->in_dtype == VAMP_F32)
+    VAMP_TIMED(kProfLiftBwdCount, s, (lift_pairs_kernel<float, TX, TY><<<grid, TX * TY, 0, s>>>(P, mats, xs, ys, zs, static_cast<const float*>(depth), E)));
+  else
+    VAMP_TIMED(kProfLiftBwdCount, s, (lift_pairs_kernel<__hip_bfloat16, TX, TY><<<grid, TX * TY, 0, s>>>(P, mats, xs, ys, zs, static_cast<const __hip_bfloat16*>(depth), E)));
   if (int e = check_launch("lift_pairs_kernel")) return e;
   return launch_lift_cells_end(d, scratch, s);
 }
@@ -1154,13 +1166,14 @@ int vamp_lift_forward_logits_ex(const VampLiftDesc* d, const float* mats, const 
 }
 
 int vamp_lift_prepare(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
-                      const float* zs, void* workspace, size_t workspace_bytes, void* stream) {
+                      const float* zs, const void* depth, void* workspace, size_t workspace_bytes, void* stream) {
   if (int e = validate(d)) return e;
   VAMP_REQUIRE(mats && xs && ys && zs, "null pointer");
+  VAMP_REQUIRE(depth || !d->use_depth, "depth is NULL");
   const LiftWs w = carve(d, workspace);
   if (!workspace || workspace_bytes < w.bytes)
     return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) w.bytes);
-  return launch_lift_cell_prepare(d, mats, xs, ys, zs, w.cells, static_cast<hipStream_t>(stream));
+  return launch_lift_cell_prepare(d, mats, xs, ys, zs, depth, w.cells, static_cast<hipStream_t>(stream));
 }
 
 int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,

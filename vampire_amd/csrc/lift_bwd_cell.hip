@@ -6,19 +6,28 @@
 //           its cell = (camera, floor tap row + 1, floor tap column + 1), (fH + 1) x (fW + 1) cells per
 //           camera, and leaves its taps {wx1, wy1, wz1, iz0} at (image, voxel)
 //   scan    exclusive prefix sum of the counters -> cell start offsets (runtime.hip)
-//   fill    thread per voxel, NO projection: the voxel's row grad_out / (hits + 1e-6) goes into a
-//           channel-last table [B V, C] (consecutive lanes = consecutive 64-byte rows), and every pair of
-//           the voxel (camera mask + taps from the forward) moves its voxel index and taps -- 20 bytes --
-//           to the next slot of its cell (slots handed out by atomics on the cell cursor)
+//   fill    thread per voxel, NO projection: every pair of the voxel (camera mask + taps + depth samples from the
+//           forward) goes to the next slot of its cell (slots handed out by atomics on the cell cursor) as ONE
+//           record [taps | depth samples | the voxel's row grad_out / (hits + 1e-6)], 32 + 4 C bytes: everything
+//           the gather needs of a pair, contiguous, in the order it will read it
 //   gather  one workgroup per STRIP of 16 consecutive pixels of a feature-map row.  The pairs that touch
 //           the strip are those of the cell rows iy, iy + 1, columns x0 .. x0 + 16: two contiguous ranges
-//           of the cell-ordered list.  The workgroup stages them in LDS lane = pair (ids -> table row:
-//           every load of a chunk is in flight at once), then consumes them lane = (pixel, channel
+//           of the cell-ordered records.  The workgroup stages them in LDS (lane = pair for the taps, four lanes
+//           per pair for the gradient row: plain streaming reads, every load of a chunk in flight at once and
+//           none of them dependent on another), then consumes them lane = (pixel, channel
 //           quad): a pixel's pairs are one contiguous sub-range (its two cells are adjacent), the four
 //           waves take every fourth pair of it, the channel dot product is a 4-lane DPP sum, the depth
-//           terms go to the wave's own LDS tile with plain read-add-write (a pixel's column belongs to
-//           one lane pair).  No atomics of any kind, no cross-lane folds; depth planes enter and leave
-//           as 64-byte runs.
+//           terms go to the strip's LDS tile of 64-bit fixed-point sums.  No float atomics, no cross-lane folds;
+//           depth-gradient planes leave as 64-byte runs.
+//
+// Round 6 changed what a pair carries (review item 2: "change the tile, not the order").  Through round 5 the fill
+// wrote a 41 MB channel-last TABLE of normalised gradient rows, one per voxel, and 20-byte pair records beside it;
+// the gather loaded a pair's voxel index, then -- a second, dependent round trip, a random 64-byte line per pair --
+// its table row, and interpolated the pair's depth sample from a [D][16] tile of depth columns it had loaded at the
+// head of every strip.  Now the forward keeps the four depth samples it computes anyway (16 bytes per pair), the
+// fill writes the row INTO the record, and the gather's staging is one round trip of sequential reads: no table,
+// no voxel indices, no depth tile (the depth columns are only loaded, late, by the fused softmax backward of the
+// logits entry).
 //
 // (Round 3 ran one WAVE per pixel with lane = pair: 67 584 waves at cfg-B of which half held fewer
 // than ten pairs, each paying the column staging, the range loads, a 64-lane fold of 16 channels and
@@ -37,13 +46,12 @@ namespace vamp {
 // fill: thread per voxel, the 64 lanes of a wave are 64 x-consecutive voxels
 // ---------------------------------------------------------------------------
 template <int CH>
-__global__ void __launch_bounds__(256, 4)      // (4 waves per SIMD: 134 registers would be 3; 45 -> 42 us)
+__global__ void __launch_bounds__(256, 4)
 lift_bwd_fill_kernel(LiftParams P, int cw, int ch, const float* __restrict__ gout,
                      const uint64_t* __restrict__ hits, const unsigned* __restrict__ amask,
                      const float4* __restrict__ ptaps, const int* __restrict__ pcell,
                      int* __restrict__ cnt, const int* __restrict__ off, const int* __restrict__ boff,
-                     int* __restrict__ ids, float4* __restrict__ recs, float4* __restrict__ table,
-                     int* __restrict__ rowq, int bn_lo, int bn_hi) {
+                     float4* __restrict__ recs, int* __restrict__ rowq, int bn_lo, int bn_hi) {
   const int tid = threadIdx.x, lane = tid & 63;
   // A duty of the first workgroup, beside its voxels: the order in which the gather takes the image
   // rows -- those with the most pairs first (counting sort by the bit length of a row's pair count), so
@@ -75,56 +83,44 @@ lift_bwd_fill_kernel(LiftParams P, int cw, int ch, const float* __restrict__ gou
   const long V = (long) P.Z * P.Y * P.X;
   const long vox = ((long) z * P.Y + yc) * P.X + xc;
 
-  // images [bn_lo, bn_hi) of the flattened (sample, camera) index: all of them, or one half when
-  // the caller runs two halves of the lift backward side by side
+  // images [bn_lo, bn_hi) of the flattened (sample, camera) index
   const int n_lo = max(0, bn_lo - b * P.N), n_hi = min(P.N, bn_hi - b * P.N);
   const unsigned range = n_hi > n_lo ? (((1u << (n_hi - n_lo)) - 1u) << n_lo) : 0u;
   const unsigned vmask = live ? (amask[(long) b * V + vox] & range) : 0u;
+  if (!__any(vmask != 0u)) return;                   // (9 % of the voxels are seen by no camera: whole waves of them leave here)
 
-  // grad_out / (hit count + 1e-6), the camera-mean factor of bv2:512-514: the same for every
-  // camera of the voxel -- one channel-last row of the table per voxel.  The rows of a wave's 64 voxels are
-  // one contiguous run of the table: they pass through LDS so that consecutive lanes store consecutive
-  // 16-byte pieces (lane = voxel stores 16-byte pieces 64 bytes apart: 2.6 M of the kernel's 4.5 M L2
-  // requests at cfg-B)
-  {
-    constexpr int RS = CH + 4;                     // padded row stride (floats): conflict-free b128 writes
-    __shared__ float tbl[4][64 * RS];
-    float* tw = tbl[tid >> 6];
-    const int nchunk = P.C / CH;
-    const long vrow0 = (long) b * V + ((long) z * P.Y + yc) * P.X + (long) blockIdx.x * 64;   // the wave's first voxel
+  const int nchunk = P.C / CH;
+  const int RS = 2 + P.C / 4;                        // float4 pieces per record
+  // The records of a wave's pairs leave through LDS: a lane's 32 + 4 C bytes are one record, but stored by the lane
+  // itself they are RS separate 16-byte pieces 16 RS bytes apart (the first build of this kernel: 62 us).  Staged
+  // [lane][piece] and written piece by piece with consecutive lanes on consecutive pieces, a record is one run, and
+  // the records of a run of lanes that share a cell -- consecutive slots -- are one longer run.
+  extern __shared__ float4 fstage[];                 // [4 waves][64 lanes][RS]
+  __shared__ int fslot[4][64];
+  float4* my = fstage + (size_t) (tid >> 6) * 64 * RS;
+  int* myslot = fslot[tid >> 6];
+
+  // the voxel's row grad_out / (hit count + 1e-6), the camera-mean factor of bv2:512-514 -- the same for every
+  // camera of the voxel -- into the lane's LDS row behind the two tap pieces; its loads are in flight under the atomics
+  if (vmask != 0u) {
     for (int chunk = 0; chunk < nchunk; ++chunk) {
+      const uint64_t hw = hits[((long) b * V + vox) * nchunk + chunk];
+      const float* g = gout + ((long) b * P.C + chunk * CH) * V + vox;
       float v[CH];
-      if (live) {
-        const uint64_t hw = hits[((long) b * V + vox) * nchunk + chunk];
-        const float* g = gout + ((long) b * P.C + chunk * CH) * V + vox;
 #pragma unroll
-        for (int k = 0; k < CH; ++k)
-          v[k] = g[(long) k * V] * __builtin_amdgcn_rcpf((float) ((hw >> (4 * k)) & 15) + 1e-6f);   // 1 ulp: gradients are held to 1e-4
-      } else {
-#pragma unroll
-        for (int k = 0; k < CH; ++k) v[k] = 0.f;
-      }
+      for (int k = 0; k < CH; ++k)
+        v[k] = g[(long) k * V] * __builtin_amdgcn_rcpf((float) ((hw >> (4 * k)) & 15) + 1e-6f);   // 1 ulp: gradients are held to 1e-4
 #pragma unroll
       for (int c4 = 0; c4 < CH; c4 += 4)
-        *reinterpret_cast<float4*>(tw + lane * RS + c4) = make_float4(v[c4], v[c4 + 1], v[c4 + 2], v[c4 + 3]);
-      // (a wave reads back what it alone wrote: no barrier)
-      constexpr int Q = CH / 4;                    // 16-byte pieces per row of this chunk
-#pragma unroll
-      for (int i = 0; i < Q; ++i) {
-        const int c = i * 64 + lane, row = c / Q, quad = c % Q;
-        const float4 piece = *reinterpret_cast<const float4*>(tw + row * RS + quad * 4);
-        if (y < P.Y && blockIdx.x * 64 + row < P.X)
-          table[(vrow0 + row) * (P.C / 4) + chunk * Q + quad] = piece;
-      }
+        my[lane * RS + 2 + (chunk * CH + c4) / 4] = make_float4(v[c4], v[c4 + 1], v[c4 + 2], v[c4 + 3]);
     }
   }
-  if (!__any(vmask != 0u)) return;
 
-  constexpr int NB = 8;                          // cameras per batch: their atomics are in flight together
+  constexpr int NB = 8;                              // cameras per batch: their atomics are in flight together
   for (int n0 = n_lo; n0 < n_hi; n0 += NB) {
     int base[NB], start[NB];
     long cellk[NB];
-    float4 tapk[NB];
+    float4 tapk[NB], depk[NB];
     unsigned actm = 0;
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
@@ -133,13 +129,15 @@ lift_bwd_fill_kernel(LiftParams P, int cw, int ch, const float* __restrict__ gou
       start[k] = lane;
       cellk[k] = 0;
       tapk[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      depk[k] = tapk[k];
       if (n >= n_hi) continue;                   // uniform
       const bool act = (vmask >> n) & 1u;
       if (!__any(act)) continue;                 // uniform: nobody in this wave has a pair with camera n
       const long bn = (long) b * P.N + n;
       long cell = 0;
       if (act) {
-        tapk[k] = ptaps[bn * V + vox];
+        tapk[k] = ptaps[(bn * V + vox) * 2];
+        depk[k] = ptaps[(bn * V + vox) * 2 + 1];
         const int pc = pcell[bn * V + vox];
         cell = (bn * ch + (pc >> 16)) * cw + (pc & 0xffff);
       }
@@ -154,10 +152,22 @@ lift_bwd_fill_kernel(LiftParams P, int cw, int ch, const float* __restrict__ gou
       if (n >= n_hi) continue;                   // uniform
       if (!__any((actm >> k) & 1u)) continue;    // uniform
       const int rb = __shfl(base[k], start[k], 64);
-      if (!((actm >> k) & 1u)) continue;
-      const long slot = (long) off[cellk[k]] + boff[cellk[k] / kScanTile] + rb + (lane - start[k]);
-      ids[slot] = (int) vox;
-      recs[slot] = tapk[k];
+      const bool act = (actm >> k) & 1u;
+      const long slot = act ? (long) off[cellk[k]] + boff[cellk[k] / kScanTile] + rb + (lane - start[k]) : -1;
+      // (a wave writes and reads its own slab: fence + wave barrier, no instruction on gfx9)
+      my[lane * RS] = tapk[k];
+      my[lane * RS + 1] = depk[k];
+      myslot[lane] = (int) slot;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int i = lane; i < 64 * RS; i += 64) {
+        const int r = i / RS, q = i - r * RS;
+        const int sl = myslot[r];
+        if (sl >= 0) recs[(long) sl * RS + q] = my[i];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
@@ -201,8 +211,9 @@ __device__ long long g_stamps[16384 * 8];
 #endif
 
 static size_t strip_lds_floats(int D, int cap) {
-  // dtile + 64-bit gtile + stage + cell starts + per-pixel scale exponents + softmax partials + chunk maxima
-  return (size_t) D * kS * 3 + (size_t) std::max(cap * kRow, kW * kS * 16) + 2 * (kS + 2) + kS + 17 * kS + 8;
+  // 64-bit gtile + stage (staged pairs | feature tile | lane-reduction buffer | the softmax backward's depth columns)
+  // + cell starts + per-pixel scale exponents + softmax partials + chunk maxima
+  return (size_t) D * kS * 2 + (size_t) std::max(std::max(cap * kRow, kW * kS * 16), D * kS) + 2 * (kS + 2) + kS + 17 * kS + 8;
 }
 
 // The depth gradient of the strip is summed in 64-bit fixed point in LDS (ds_add_u64 is served at
@@ -217,18 +228,17 @@ __global__ void __launch_bounds__(kW * 64, 4)
 lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_lo, int cap,
                       const T* __restrict__ depth, const T* __restrict__ feat,
                       const int* __restrict__ off, const int* __restrict__ boff,
-                      const int* __restrict__ ids, const float4* __restrict__ recs,
-                      const float4* __restrict__ table, const int* __restrict__ rowq, int* __restrict__ cnt,
+                      const float4* __restrict__ recs, const int* __restrict__ rowq, int* __restrict__ cnt,
                       float* __restrict__ gdepth, float* __restrict__ gfeat, int softmax_bwd, int fcl) {
   extern __shared__ float smem[];
   constexpr int NT = kW * 64;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int C = P.C, D = P.use_depth ? P.D : 0;
   const int DS = D * kS;
-  float* dtile = smem;                                              // [D][kS] the strip's depth columns
-  long long* gtile = reinterpret_cast<long long*>(smem + DS);       // [D][kS] their gradients, fixed point
-  float* stage = smem + 3 * DS;                                     // [cap][kRow] staged pairs
-  int* offs = reinterpret_cast<int*>(stage + max(cap * kRow, kW * kS * 16));   // [2][kS + 2] cell starts
+  long long* gtile = reinterpret_cast<long long*>(smem);            // [D][kS] the depth columns' gradients, fixed point
+  float* stage = smem + 2 * DS;                                     // [cap][kRow] staged pairs
+  float* dtile = stage;                                             // [D][kS] the depth columns (softmax backward only, at the end)
+  int* offs = reinterpret_cast<int*>(stage + max(max(cap * kRow, kW * kS * 16), DS));   // [2][kS + 2] cell starts
   int* efp = offs + 2 * (kS + 2);                                   // [kS] exponent of sum_c |feat_c|
   float* red = reinterpret_cast<float*>(efp + kS);                  // [16 + 1][kS]
   float* cmax = red + 17 * kS;                                      // [kW] chunk maxima
@@ -261,37 +271,6 @@ lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_
     // the fill's cursors (= the counters the next forward counts into) go back to zero: this strip owns
     // the cells of its row and columns, the last strip of a row also column fW, the last row also row fH
     if ((h == 0 || iy == P.fH - 1) && (j < np || (j == np && x0 + np == P.fW))) cnt[c] = 0;
-  }
-  // the depth columns: 16-byte pieces of the planes' 64-byte runs (fW % 4 == 0), else single values
-  if (VEC) {
-    for (int e0 = 0; e0 < DS / 4; e0 += 2 * NT) {
-      float4 v[2];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int e = min(e0 + k * NT + tid, DS / 4 - 1);
-        const int dz = e / (kS / 4), p4 = min((e % (kS / 4)) * 4, np - 4);
-        v[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(depth) + (bn * P.D + dz) * HW + pix0 + p4);
-      }
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int e = e0 + k * NT + tid;
-        if (e < DS / 4) reinterpret_cast<float4*>(dtile)[e] = v[k];
-      }
-    }
-  } else {
-    for (int e0 = 0; e0 < DS; e0 += 6 * NT) {
-      float v[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const int ec = min(e0 + k * NT + tid, DS - 1);
-        v[k] = ldf(depth, (bn * P.D + ec / kS) * HW + pix0 + min(ec % kS, np - 1));
-      }
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const int e = e0 + k * NT + tid;
-        if (e < DS) dtile[e] = v[k];
-      }
-    }
   }
   for (int e = tid; e < DS / 2; e += NT) reinterpret_cast<float4*>(gtile)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
   // one feature of the strip: channel-first planes [C][HW], or (fcl: VAMP_LIFTBWD_FEAT_CHANNEL_LAST, uniform) the
@@ -351,42 +330,37 @@ lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_
       mid_h[h] = oh[p + 1] + base;
       hi_h[h] = p < np ? oh[p + 2] + base : lo_h[h];
     }
-    // The loads of the stage phase run two chunks ahead: at chunk c the table rows of chunk c + 1 are
-    // requested (their voxel indices arrived during chunk c - 1) and the indices / taps of chunk c + 2,
-    // so the chunk loop never waits for a round trip it has just started.
-    // stage phase A: lanes 0..31 of a wave = pair 32 wv + lane of the chunk (voxel index and taps
-    // arrive coalesced; the lane works out the pair's terms for its two pixels); phase B: four lanes
-    // per pair, each one 16-byte piece of the voxel's table row (one line pulled per pair, not four)
+    // The loads of the stage phase run one chunk ahead, and none depends on another: a pair's record sits at its
+    // POSITION in the cell-ordered list (round 6: the gradient row travels in the record; through round 5 a pair's
+    // voxel index had to arrive before its table row could be asked for).
+    // stage phase A: lanes 0..31 of a wave = pair 32 wv + lane of the chunk (taps and depth samples; the lane works
+    // out the pair's terms for its two pixels); phase B: four lanes per pair, each one 16-byte piece of the row
     const int jA = 32 * wv + lane;
     const bool laneA = lane < 32 && jA < cap;
-    auto load_ids = [&](int tc, int& vox, float4& rc) {
-      vox = 0;
+    const int RS = 2 + C / 4;                        // float4 pieces per record
+    auto rec_at = [&](int t) -> long { return (long) (t >= n0 ? offs[kS + 2] + (t - n0) : offs[0] + t) * RS; };
+    auto load_taps = [&](int tc, float4& rc, float4& dp) {
       rc = make_float4(0.f, 0.f, 0.f, 0.f);
+      dp = rc;
       const int t = tc + jA;
       if (laneA && t < NP) {
-        const long pos = (long) (t >= n0 ? offs[kS + 2] + (t - n0) : offs[0] + t);
-        vox = ids[pos];
+        const long pos = rec_at(t);
         rc = recs[pos];
+        dp = recs[pos + 1];
       }
     };
-    auto load_rows = [&](int tc, int vox, float4 (&g)[2]) {
+    auto load_rows = [&](int tc, float4 (&g)[2]) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const int jj = 16 * s2 + (lane >> 2), k = lane & 3;
-        const int vj = __shfl(vox, jj, 64);
+        const int jj = 32 * wv + 16 * s2 + (lane >> 2), k = lane & 3;
         g[s2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        // the voxel's row of grad_out / (hits + 1e-6)
-        if (32 * wv + jj < cap && tc + 32 * wv + jj < NP && k < nq) g[s2] = table[((long) b * V + vj) * (C / 4) + c0 / 4 + k];
+        // the voxel's row of grad_out / (hits + 1e-6), this chunk of channels
+        if (jj < cap && tc + jj < NP && k < nq) g[s2] = recs[rec_at(tc + jj) + 2 + c0 / 4 + k];
       }
     };
-    int voxB;
-    float4 rcA, rcB, gA[2];
-    {
-      int voxA;
-      load_ids(0, voxA, rcA);
-      load_rows(0, voxA, gA);
-      load_ids(cap, voxB, rcB);
-    }
+    float4 rcA, dpA, gA[2];
+    load_taps(0, rcA, dpA);
+    load_rows(0, gA);
     for (int t0 = 0; t0 < NP; t0 += cap) {
       const int nst = min(cap, NP - t0);
       __syncthreads();                               // the previous chunk (or the feature tile) is consumed
@@ -406,19 +380,16 @@ lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_
         const float wz1v = rc.z, wz0v = 1.0f - rc.z;
         const float wy = h ? 1.0f - rc.y : rc.y;
         const bool z0in = iz0 >= 0 && iz0 < D, z1in = iz0 + 1 >= 0 && iz0 + 1 < D;
-        const float* d0 = dtile + min(max(iz0, 0), D - 1) * kS;
-        const float* d1 = dtile + min(max(iz0 + 1, 0), D - 1) * kS;
+        // the forward's depth samples at the pair's four pixel taps, [y tap][x tap]: this strip's row is the pair's
+        // y1 tap when the pair comes from cell row iy (h = 0), its y0 tap from cell row iy + 1
+        const float dpy[2] = {h ? dpA.x : dpA.z, h ? dpA.y : dpA.w};     // [x tap] of this row
         float* st = stage + jA * kRow;
 #pragma unroll
         for (int role = 0; role < 2; ++role) {       // role A: the pixel is the x1 tap, role B: the x0 tap
           const int pr = col - role - x0;
           const bool pin = pr >= 0 && pr < np;
-          const int prc = min(max(pr, 0), kS - 1);
           const float wj = wy * (role ? 1.0f - rc.x : rc.x);
-          // depth interpolated at that pixel: the two planes around the projected depth (zero padding)
-          float dep;
-          if (D > 0) dep = (z0in ? wz0v * d0[prc] : 0.f) + (z1in ? wz1v * d1[prc] : 0.f);
-          else dep = (iz0 == 0 ? wz0v : 0.f) + (iz0 == -1 ? wz1v : 0.f);      // D == 1: the single plane
+          const float dep = dpy[1 - role];
           reinterpret_cast<float4*>(st)[4 + role] =
               make_float4(pin ? wj * dep : 0.f, (pin && z0in) ? wj * wz0v : 0.f, (pin && z1in) ? wj * wz1v : 0.f,
                           __int_as_float(iz0));
@@ -431,10 +402,9 @@ lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_
         gm = fmaxf(gm, fmaxf(fmaxf(fabsf(g4.x), fabsf(g4.y)), fmaxf(fabsf(g4.z), fabsf(g4.w))));
         if (j < nst) reinterpret_cast<float4*>(stage + j * kRow)[lane & 3] = g4;
       }
-      // ---- next chunk's rows, the chunk after's indices
-      load_rows(t0 + cap, voxB, gA);
-      rcA = rcB;
-      load_ids(t0 + 2 * cap, voxB, rcB);
+      // ---- the next chunk's loads
+      load_taps(t0 + cap, rcA, dpA);
+      load_rows(t0 + cap, gA);
       gm = wave_max(gm);
       if (lane == 0) cmax[wv] = gm;
       __syncthreads();
@@ -532,8 +502,41 @@ lift_bwd_strip_kernel(LiftParams P, int cw, int ch, int spr, int xgroup, int bn_
     }
     if (softmax_bwd) {
       // VAMP_LIFTBWD_LOGITS: the depth column is softmax(logits) (base_vampire2.py:550) and the caller
-      // wants the gradient of the logits, p * (g - sum_d p g): both tiles sit in LDS, so the softmax
-      // backward costs one small reduction per strip and no pass over HBM
+      // wants the gradient of the logits, p * (g - sum_d p g): the gradient tile sits in LDS and the strip's
+      // depth columns join it here (the stage region is free by now), so the softmax backward costs one
+      // small reduction per strip and no pass of its own over HBM
+      // the depth columns: 16-byte pieces of the planes' 64-byte runs (fW % 4 == 0), else single values
+      if (VEC) {
+        for (int e0 = 0; e0 < DS / 4; e0 += 2 * NT) {
+          float4 v[2];
+    #pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int e = min(e0 + k * NT + tid, DS / 4 - 1);
+            const int dz = e / (kS / 4), p4 = min((e % (kS / 4)) * 4, np - 4);
+            v[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(depth) + (bn * P.D + dz) * HW + pix0 + p4);
+          }
+    #pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int e = e0 + k * NT + tid;
+            if (e < DS / 4) reinterpret_cast<float4*>(dtile)[e] = v[k];
+          }
+        }
+      } else {
+        for (int e0 = 0; e0 < DS; e0 += 6 * NT) {
+          float v[6];
+    #pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            const int ec = min(e0 + k * NT + tid, DS - 1);
+            v[k] = ldf(depth, (bn * P.D + ec / kS) * HW + pix0 + min(ec % kS, np - 1));
+          }
+    #pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            const int e = e0 + k * NT + tid;
+            if (e < DS) dtile[e] = v[k];
+          }
+        }
+      }
+      __syncthreads();
       const int pp = tid % kS, gq = tid / kS;        // 16 partial sums per pixel
       float s = 0.f;
       for (int dz = gq; dz < D; dz += NT / kS) s = __builtin_fmaf(dtile[dz * kS + pp], gf[dz * kS + pp], s);
@@ -619,16 +622,17 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
   const LiftCells g = lift_cells(d);
   const LiftCellWs w = lift_cell_ws(d, scratch);
   if (!cells_valid)
-    if (int e = launch_lift_cell_prepare(d, mats, xs, ys, zs, scratch, s)) return e;
+    if (int e = launch_lift_cell_prepare(d, mats, xs, ys, zs, depth, scratch, s)) return e;
   // (the counters are the fill cursors: the scan left them at zero)
   // half 0: all images; 1 / 2: the lower / upper half of the flattened (sample, camera) index
   const int BN = d->B * d->N;
   const int bn_lo = half == 2 ? BN / 2 : 0, bn_hi = half == 1 ? BN / 2 : BN;
   if (bn_hi <= bn_lo) return VAMP_OK;
   dim3 grid((d->X + 63) / 64, (d->Y + 3) / 4, d->Z * d->B);
+  const size_t fill_lds = (size_t) 4 * 64 * (2 + d->C / 4) * sizeof(float4);      // [wave][lane][record piece]
 #define VAMP_CELL(CH)                                                                            \
-  VAMP_TIMED(kProfLiftBwdFill, s, (lift_bwd_fill_kernel<CH><<<grid, 256, 0, s>>>(                \
-      P, g.cw, g.ch, gout, hits, w.amask, w.ptaps, w.pcell, w.cnt, w.off, w.boff, w.ids, w.recs, w.table, w.rowq, bn_lo, bn_hi)))
+  VAMP_TIMED(kProfLiftBwdFill, s, (lift_bwd_fill_kernel<CH><<<grid, 256, fill_lds, s>>>(         \
+      P, g.cw, g.ch, gout, hits, w.amask, w.ptaps, w.pcell, w.cnt, w.off, w.boff, w.recs, w.rowq, bn_lo, bn_hi)))
   if (P.C == 4) VAMP_CELL(4); else if (P.C == 8) VAMP_CELL(8); else VAMP_CELL(16);
 #undef VAMP_CELL
   if (int e = check_launch("lift_bwd_fill_kernel")) return e;
@@ -651,7 +655,7 @@ static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float
       return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);
     VAMP_TIMED(kProfLiftBwd, s, (k<<<ggrid, kW * 64, lds, s>>>(
         P, g.cw, g.ch, spr, spr, bn_lo, cap, static_cast<const T*>(depth), static_cast<const T*>(feat),
-        w.off, w.boff, w.ids, w.recs, w.table, w.rowq, w.cnt, gdepth, gfeat, softmax_bwd ? 1 : 0, fcl ? 1 : 0)));
+        w.off, w.boff, w.recs, w.rowq, w.cnt, gdepth, gfeat, softmax_bwd ? 1 : 0, fcl ? 1 : 0)));
   }
   return check_launch("lift_bwd_strip_kernel");
 }

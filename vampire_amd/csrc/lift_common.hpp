@@ -96,8 +96,9 @@ __device__ __forceinline__ LiftTap lift_project(const LiftParams& P, const float
 // Cell lists of the lift backward (lift_bwd_cell.hip).  Cell = (image, floor tap row + 1, floor tap
 // column + 1): (fH + 1) x (fW + 1) cells per camera image.  The FORWARD kernel (grad mode) or the
 // stand-alone prepare kernel counts the valid (voxel, camera) pairs per cell and leaves every
-// pair's taps in `ptaps` / `pcell`, indexed by (image, voxel); the backward's fill pass only
-// re-lays them in cell order -- nothing on the backward projects a voxel again.
+// pair's taps and its four depth samples in `ptaps` (and `pcell`), indexed by (image, voxel); the
+// backward's fill pass only re-lays them in cell order, each with its voxel's gradient row -- nothing on
+// the backward projects a voxel or reads a depth plane again.
 // ---------------------------------------------------------------------------
 struct LiftCells {
   int cw, ch;                        // cells per row / column of one camera
@@ -116,11 +117,12 @@ inline LiftCells lift_cells(const VampLiftDesc* d) {
 struct LiftCellWs {
   int *cnt, *off, *bsum, *boff, *aux;
   unsigned* amask;                   // [B * V] cameras each voxel has a pair with (N <= 32)
-  float4* ptaps;                     // [B * N * V] {wx1, wy1, wz1, (iz0 + 1) | (ix0 + 1) << 16} of the pair, voxel order (sparse)
+  float4* ptaps;                     // [B * N * V][2] of the pair, voxel order (sparse): {wx1, wy1, wz1, (iz0 + 1) | (ix0 + 1) << 16} |
+                                     // its depth samples sum_d w_d depth[d, pixel] at its four pixel taps (32 bytes side by side:
+                                     // as two arrays the second store cost the training forward 8 us)
   int* pcell;                        // [B * N * V] (floor row + 1) << 16 | (floor column + 1)
-  int* ids;                          // [cap] voxel index (within its sample) of every pair, in cell order
-  float4* recs;                      // [cap] the same four words of every pair, in cell order
-  float4* table;                     // [B * V, C] grad_out / (hits + 1e-6), channel-last
+  float4* recs;                      // [cap][2 + C / 4] every pair in cell order: its taps | its depth samples | its voxel's
+                                     // row grad_out / (hits + 1e-6) -- everything the gather needs of a pair, one run
   int* rowq;                         // [B * N * fH] image rows, those with the most pairs first
   size_t bytes;
 };
@@ -139,11 +141,9 @@ inline LiftCellWs lift_cell_ws(const VampLiftDesc* d, void* scratch) {
   w.boff = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
   w.aux = reinterpret_cast<int*>(p); p += align_up((size_t) (ntile + 4) * sizeof(int), 256);
   w.amask = reinterpret_cast<unsigned*>(p); p += align_up((size_t) d->B * V * sizeof(unsigned), 256);
-  w.ptaps = reinterpret_cast<float4*>(p); p += align_up(cap * sizeof(float4), 256);
+  w.ptaps = reinterpret_cast<float4*>(p); p += align_up(cap * 2 * sizeof(float4), 256);
   w.pcell = reinterpret_cast<int*>(p); p += align_up(cap * sizeof(int), 256);
-  w.ids = reinterpret_cast<int*>(p); p += align_up(cap * sizeof(int), 256);
-  w.recs = reinterpret_cast<float4*>(p); p += align_up(cap * sizeof(float4), 256);
-  w.table = reinterpret_cast<float4*>(p); p += align_up((size_t) d->B * V * d->C * sizeof(float), 256);
+  w.recs = reinterpret_cast<float4*>(p); p += align_up(cap * (size_t) (2 + (d->C + 3) / 4) * sizeof(float4), 256);
   w.rowq = reinterpret_cast<int*>(p); p += align_up((size_t) d->B * d->N * d->fH * sizeof(int), 256);
   w.bytes = (size_t) (p - static_cast<char*>(scratch));
   return w;
@@ -153,7 +153,7 @@ inline LiftCellWs lift_cell_ws(const VampLiftDesc* d, void* scratch) {
 struct LiftEmit {
   int* cnt;
   unsigned* amask;
-  float4* ptaps;
+  float4* ptaps;                     // [.][2]: taps | depth samples
   int* pcell;
   int cw, ch;
 };
@@ -169,8 +169,12 @@ inline LiftEmit lift_emit_of(const VampLiftDesc* d, void* cells) {
 
 // One camera of one voxel, called in WAVE-UNIFORM control flow (exited lanes are fine): counts the
 // pair in its cell -- one atomic per run of lanes with equal cells, x-neighbouring voxels share a
-// cell in the far field -- and stores its taps at (image, voxel).  Returns whether the voxel has
-// a pair with this camera (at least one of the four pixel taps exists).
+// cell in the far field -- and stores its taps and its depth samples `dep` (depth_taps: the planes around
+// the projected depth interpolated at the four pixel taps, zero padding) at (image, voxel).  Returns whether
+// the voxel has a pair with this camera (at least one of the four pixel taps exists).
+// (The depth samples are stored by lift_emit_dep, which callers place BEHIND their other loads: the store has to
+// wait for the depth planes, and issued here -- in front of the feature gather -- it held that gather's loads
+// back by a round trip per camera: 37 -> 45 us for the training forward.)
 __device__ __forceinline__ bool lift_emit_pair(const LiftParams& P, const LiftEmit& E, const LiftTap& t,
                                                bool live, long bn, long V, long vox, int lane) {
   const bool act = live && t.valid && t.ix0 >= -1 && t.ix0 < P.fW && t.iy0 >= -1 && t.iy0 < P.fH;
@@ -180,10 +184,13 @@ __device__ __forceinline__ bool lift_emit_pair(const LiftParams& P, const LiftEm
   if (r.head) atomicAdd(E.cnt + cell, r.len);
   if (act) {
     // (iz0 >= -1 for a valid pair; the cell column rides in the upper half of the same word)
-    E.ptaps[bn * V + vox] = make_float4(t.wx1, t.wy1, t.wz1, __int_as_float((t.iz0 + 1) | ((t.ix0 + 1) << 16)));
+    E.ptaps[(bn * V + vox) * 2] = make_float4(t.wx1, t.wy1, t.wz1, __int_as_float((t.iz0 + 1) | ((t.ix0 + 1) << 16)));
     E.pcell[bn * V + vox] = ((t.iy0 + 1) << 16) | (t.ix0 + 1);
   }
   return act;
+}
+__device__ __forceinline__ void lift_emit_dep(const LiftEmit& E, bool act, long bn, long V, long vox, const float (&dep)[4]) {
+  if (act) E.ptaps[(bn * V + vox) * 2 + 1] = make_float4(dep[0], dep[1], dep[2], dep[3]);
 }
 
 // lift_bwd_cell.hip
@@ -193,7 +200,7 @@ int launch_lift_bwd_cell(const VampLiftDesc* d, const float* mats, const float* 
                          const uint64_t* hits, float* gdepth, float* gfeat, void* scratch,
                          bool cells_valid, int variant, int half, bool softmax_bwd, bool feat_cl, hipStream_t s);
 int launch_lift_cell_prepare(const VampLiftDesc* d, const float* mats, const float* xs,
-                             const float* ys, const float* zs, void* scratch, hipStream_t s);
+                             const float* ys, const float* zs, const void* depth, void* scratch, hipStream_t s);
 // zero the cell counters (before a kernel that emits pairs) / scan them (after it)
 int launch_lift_cells_begin(const VampLiftDesc* d, void* scratch, hipStream_t s, bool clean = false);
 int launch_lift_cells_end(const VampLiftDesc* d, void* scratch, hipStream_t s);
