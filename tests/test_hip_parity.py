@@ -194,6 +194,26 @@ def test_lift_channel_counts(tiny_common, dev, C_):
     close(fd.grad, fr.grad, atol=1e-5, rtol=1e-5, scale="max", chan_dim=2, what=f"grad_feat C={C_}")
 
 
+def test_lift_backward_rebuilds_overwritten_lists(tiny_common, dev):
+    """Two forwards on one workspace, then the backward of the FIRST: the pairs the second forward left are not the
+    first one's, so that backward builds its own cell lists (lift_pairs_kernel: projection + depth samples) -- same
+    gradients as an undisturbed forward + backward."""
+    g = tiny_common
+    hp = hot(CFG_TINY, dev)
+    lm, _ = tiny_mats(g, dev)
+    d1, f1 = g["depth"].to(dev).requires_grad_(True), g["feat"].to(dev).requires_grad_(True)
+    out1 = hp.lift(d1, f1, lm)
+    gen = torch.Generator(device=dev).manual_seed(9)
+    d2 = torch.rand(d1.shape, device=dev, generator=gen).requires_grad_(True)
+    f2 = torch.randn(f1.shape, device=dev, generator=gen).requires_grad_(True)
+    out2 = hp.lift(d2, f2, lm.flip(1))                     # other values, other camera order: other pairs
+    out1.backward(g["g_lift"].to(dev))
+    close(d1.grad, g["grad_depth"], atol=1e-5, rtol=1e-5, scale="max", what="grad_depth behind a second forward")
+    close(f1.grad, g["grad_feat"], atol=1e-5, rtol=1e-5, scale="max", chan_dim=2, what="grad_feat behind a second forward")
+    out2.sum().backward()                                  # (its lists are gone too by now)
+    assert bool(torch.isfinite(d2.grad).all()) and bool(torch.isfinite(f2.grad).all())
+
+
 def test_lift_bilinear_variant(dev):
     g = load_golden("tiny_bilinear.npz")
     hp = hot(CFG_TINY, dev)

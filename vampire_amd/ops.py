@@ -105,12 +105,6 @@ class HotPath:
                      # BEV branch on a second stream in training steps (forward-only calls stay on one
                      # stream): eager step 0.679 vs 0.699 ms, replayed from a HIP graph 0.629 vs 0.695 ms
                      "overlap": os.environ.get("VAMP_OVERLAP", "1") == "1",
-                     # two-stream steps: the heavy-voxel drain of the camera backward as a kernel of its own on the side stream
-                     # beside the gather (replayed step 0.504 vs 0.512 ms); one-stream calls drain the list inside the
-                     # gather launch (its first workgroups: 66 us against 37 + 38)
-                     "heavy_side": os.environ.get("VAMP_HEAVY_SIDE", "1") == "1",
-                     # the BEV forward keeps its samples for the backward (+35 MB per sample at cfg-B)
-                     "bev_save": os.environ.get("VAMP_BEV_SAVE", "1") == "1",
                      # early ray termination in the camera branch (include/vampire_hip.h)
                      "ert": os.environ.get("VAMP_ERT", "1") != "0",
                      # the camera branch as ONE kernel on the channel-first volumes (no packed copy, no
@@ -124,17 +118,17 @@ class HotPath:
                      # column blocks filling the slots the camera tiles' tail leaves idle) wherever the one-kernel camera
                      # forward with early termination runs; False = the two launches (the tests' cross-check: same bits)
                      "fwd_merged": True,
-                     # the BEV forward as one kernel (render_bev_fused.hip); "0" = the two-kernel first
+                     # the BEV forward as one kernel (render_bev_fused.hip); False = the two-kernel first
                      # implementation, the cross-check of the tests
-                     "bev_fused": os.environ.get("VAMP_BEV_FUSED", "1") != "0",
+                     "bev_fused": True,
                      # forward-only calls: BEV branch on the side stream beside the camera branch.  Off for
                      # eager launches (the fork / join costs more than it hides); a caller that captures the
                      # forward into a HIP graph switches it on (bench.py)
-                     "fwd_overlap": os.environ.get("VAMP_FWD_OVERLAP", "0") == "1",
-                     # training: the camera forward keeps every inside sample's values for the backward's
-                     # per-ray pass (+0.5 GB of workspace per sample at cfg-B, touched only where samples are kept)
-                     "save_rows": os.environ.get("VAMP_SAVE_ROWS", "1") != "0",
-                     "prepare": os.environ.get("VAMP_PREPARE", "1") != "0"}
+                     "fwd_overlap": False,
+                     # training: the camera forward keeps every inside sample's values for the backward's per-ray pass
+                     # (+0.5 GB of workspace per sample at cfg-B, touched only where samples are kept); False = that pass
+                     # gathers again (the tests' cross-check of the re-sampling path; no environment switch)
+                     "save_rows": True}
 
     # ---------------------------------------------------------------- descs
     def lift_desc(self, B, N, C_, dtype_code, use_depth=True, fhw=None) -> _capi.VampLiftDesc:
@@ -511,10 +505,11 @@ class _LiftFn(torch.autograd.Function):
         hp._lift_gen = getattr(hp, "_lift_gen", 0) + 1
         ctx.cells_key = None
         flags = _capi.VAMP_LIFTFWD_FEAT_CHANNEL_LAST if fcl else 0
-        if need_grad and hp.impl["prepare"] and hp.impl["lift_bwd"] == "cell":
+        if need_grad and hp.impl["lift_bwd"] == "cell":
             # the forward kernel projects every voxel into every camera anyway: in grad mode it also
-            # counts the backward's (voxel, camera) pairs per pixel cell and leaves their taps in the
-            # workspace, so the backward never projects (VAMP_PREPARE=0: the backward does it itself)
+            # counts the backward's (voxel, camera) pairs per pixel cell and leaves their taps and depth samples in
+            # the workspace, so the backward never projects (a backward whose lists another call has overwritten
+            # since -- cells_key below -- builds them itself)
             flags |= _capi.VAMP_LIFTFWD_EMIT_PAIRS
             if "lift" not in hp._dirty:
                 flags |= _capi.VAMP_LIFTFWD_CELLS_CLEAN
@@ -629,8 +624,6 @@ def render_forward_plan(train, two, prep_ok, direct, ert, merged=False):
         merged = False
     if merged and not train:
         return [("render", "cur", 0, (), ())]
-    if merged == "train" and train and two and prep_ok:
-        return [("render", "cur", 0, (), ("table",)), ("prep", "side", F.VAMP_CAMPREP_TERM_VALID, ("table",), ())]
     if train and two and prep_ok and direct:
         # the camera kernel (which leaves the termination table), then the BEV forward; beside them, once the
         # table is there, the prepare pass
@@ -718,16 +711,14 @@ class _RenderFn(torch.autograd.Function):
         # streams; forward-only calls stay on one unless the caller captures them into a graph (fwd_overlap)
         cur = torch.cuda.current_stream()
         side = hp._side_stream() if (train or hp.impl["fwd_overlap"]) else None
-        prep_ok = geom is None and hp.impl["prepare"] and hp.impl["cam_bwd"] != "v1"
+        prep_ok = geom is None and hp.impl["cam_bwd"] != "v1"
         # camera tiles + BEV column blocks in one launch where the library takes the shapes (it checks the heights
         # hp.ozs_host against the BEV kernel's plane slabs itself)
         merged = bool(direct and ert and hp.impl["fwd_merged"] and hp.impl["bev_fused"] and
                       hp.lib.vamp_render_forward_merged_supported(C.byref(d), hp.ozs_host))
-        if merged and train and os.environ.get("VAMP_X_TRAIN_MERGED", "0") == "1":       # (experiment, to be decided by measurement)
-            merged = "train"
         plan = render_forward_plan(train, side is not None, prep_ok, direct, ert, merged)
         bev_flags = 0 if hp.impl["bev_fused"] else _capi.VAMP_BEVFWD_TWO_KERNELS
-        bev_save = train and hp.impl["bev_save"] and hp.impl["bev_bwd"] != "v1"
+        bev_save = train and hp.impl["bev_bwd"] != "v1"
         ws_bev = hp._workspace("bev", hp.lib.vamp_render_bev_workspace_bytes(C.byref(d))) if bev_save else None
         cam_base = 0 if ert else _capi.VAMP_CAMFWD_NO_ERT
         streams, events = {"cur": cur, "side": side}, {}
@@ -880,15 +871,12 @@ class _RenderFn(torch.autograd.Function):
                     *cam_args, _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gbeta), _ptr(ws), ws.numel(), cam_flags | part,
                     event, _stream(stream)), "vamp_render_camera_backward_acc")
 
-            if hp.impl["heavy_side"]:
-                cam_part(_capi.VAMP_CAMBWD_PART_RAY, cur)
-                ray_done = torch.cuda.Event()
-                ray_done.record(cur)
-                side.wait_event(ray_done)
-                cam_part(_capi.VAMP_CAMBWD_PART_HEAVY, side)
-                cam_part(_capi.VAMP_CAMBWD_PART_GATHER, cur, C.c_void_p(done.cuda_event))
-            else:
-                cam_part(0, cur, C.c_void_p(done.cuda_event))
+            cam_part(_capi.VAMP_CAMBWD_PART_RAY, cur)
+            ray_done = torch.cuda.Event()
+            ray_done.record(cur)
+            side.wait_event(ray_done)
+            cam_part(_capi.VAMP_CAMBWD_PART_HEAVY, side)
+            cam_part(_capi.VAMP_CAMBWD_PART_GATHER, cur, C.c_void_p(done.cuda_event))
             cur.wait_stream(side)
         elif geom is None and default_impl:
             bev_backward(cur, True)
