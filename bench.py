@@ -63,16 +63,26 @@ def _use_shipped_miopen_db():
     try:
         if os.path.isdir(dst):
             st = os.stat(dst)
-            if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            if st.st_uid != os.getuid():
+                print(f"[bench] {dst} belongs to another user: MIOpen db not used", file=sys.stderr)
                 return None                      # somebody else's directory under our name: do not load code from it
+            if st.st_mode & 0o077:
+                os.chmod(dst, 0o700)             # (ours, made by an older checkout with the source's mode bits)
         else:
             tmp = tempfile.mkdtemp(prefix="vampire_miopen_db_")          # 0700, ours
-            shutil.copytree(src, tmp, dirs_exist_ok=True)
+            for root, _dirs, files in os.walk(src):                       # (contents only: no permission bits, no times)
+                rel = os.path.relpath(root, src)
+                os.makedirs(os.path.join(tmp, rel), exist_ok=True)
+                for f in files:
+                    shutil.copyfile(os.path.join(root, f), os.path.join(tmp, rel, f))
             try:
                 os.rename(tmp, dst)
             except OSError:                      # another rank of this user won the race: use theirs
                 shutil.rmtree(tmp, ignore_errors=True)
-    except OSError:
+                if not os.path.isdir(dst):
+                    raise
+    except OSError as e:
+        print(f"[bench] shipped MIOpen db not usable ({type(e).__name__}: {e})", file=sys.stderr)
         return None
     os.environ["MIOPEN_USER_DB_PATH"] = dst
     os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = dst

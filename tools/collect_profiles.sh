@@ -1,31 +1,53 @@
 #!/bin/bash
-# Run ON THE GPU BOX (via gpurun): collects the rocprofv3 evidence bench.py's numbers are judged
-# against and writes it under gpurun_out/ (copy the summaries into profiles/ afterwards).
-#   1. --kernel-trace --stats of the default bench command
-#   2. PMC passes (FETCH_SIZE, then WRITE_SIZE; separate passes, no trace domains) of the same step
-# usage: tools/collect_profiles.sh <round-tag> [cfg] [batch]
+# Run ON THE GPU BOX (via gpurun): collects the rocprofv3 evidence bench.py's numbers are judged against and writes
+# it under gpurun_out/profiles_<tag>/ (copy the summaries into profiles/ afterwards).  Since round 6 every file holds
+# ONE kind of call, so that the per-stage tables of README / DESIGN can be reproduced from profiles/ alone:
+#   kernel_stats_<tag>_train_step_one_stream.csv        eager training steps, both render branches on one stream
+#                                                       (undisturbed kernel durations: the per-stage table)
+#   kernel_stats_<tag>_train_step_replayed.csv          the step replayed from a HIP graph on two streams (what the
+#                                                       headline times; kernels side by side stretch each other)
+#   kernel_stats_<tag>_fwd_pair.csv                     the no-grad forward pair replayed (north_star's metric)
+#   kernel_stats_<tag>_train_step_one_stream_noert.csv  the one-stream step with early ray termination off
+#   kernel_stats_<tag>_cfgB_b8_replayed.csv             the replayed step at 8 samples per GPU
+#   traffic_<tag>.json / traffic_<tag>_fwd.json         HBM bytes per launch (separate --pmc FETCH_SIZE / WRITE_SIZE passes)
+#   bench_under_rocprof_<tag>.json                      the bench line printed under the profiler
+# usage: tools/collect_profiles.sh <round-tag> [cfg]
 set -u
-TAG=${1:-r01}; CFG=${2:-B}; BATCH=${3:-1}
+TAG=${1:-r06}; CFG=${2:-B}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --cfg $CFG --batch $BATCH --steps 20 --warmup 5 --no-cpu-baseline --no-extra --no-matrix > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/tools/time_bwd.py $CFG $BATCH > /dev/null 2> $OUT/pmc_fetch.log
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/tools/time_bwd.py $CFG $BATCH > /dev/null 2> $OUT/pmc_write.log
-cd $ROOT
-python3 tools/summarize_profiles.py $OUT $TAG $CFG $BATCH
-rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write      # (the raw traces: gpurun merges at most 64 MiB back)
-# the same three passes with early ray termination OFF (the data-independent path): VAMP_ERT=0 is read by
-# vampire_amd.ops at import; exported here so that rocprofv3 launches python itself (no env wrapper)
+stats() {   # <name> <header> <script> [args...]
+  local name=$1 hdr=$2; shift 2
+  rm -rf $OUT/st
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st -- python3 "$@" > $OUT/$name.log 2>&1
+  python3 $ROOT/tools/kernel_stats_csv.py $OUT/st $OUT/kernel_stats_${TAG}_$name.csv "$hdr" > /dev/null
+  rm -rf $OUT/st
+}
+export VAMP_OVERLAP=0
+stats train_step_one_stream "cfg-$CFG, 1 sample: 3 + 5 eager training steps (tools/time_bwd.py), VAMP_OVERLAP=0 (one stream)" $ROOT/tools/time_bwd.py $CFG 1
 export VAMP_ERT=0
-OUT2=$ROOT/gpurun_out/profiles_${TAG}_noert
-mkdir -p $OUT2
-cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT2/stats -- python3 $ROOT/bench.py --cfg $CFG --batch $BATCH --steps 20 --warmup 5 --no-cpu-baseline --no-extra --no-matrix > $OUT2/bench_under_rocprof.json 2> $OUT2/stats.log
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT2/pmc_fetch -- python3 $ROOT/tools/time_bwd.py $CFG $BATCH > /dev/null 2> $OUT2/pmc_fetch.log
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT2/pmc_write -- python3 $ROOT/tools/time_bwd.py $CFG $BATCH > /dev/null 2> $OUT2/pmc_write.log
+stats train_step_one_stream_noert "cfg-$CFG, 1 sample: eager training steps, one stream, early ray termination OFF (VAMP_ERT=0)" $ROOT/tools/time_bwd.py $CFG 1
+unset VAMP_ERT VAMP_OVERLAP
+stats train_step_replayed "cfg-$CFG, 1 sample: 20 + 3 eager steps, then 200 replays of the captured two-stream step (tools/try_graph.py)" $ROOT/tools/try_graph.py $CFG 1 200
+stats fwd_pair "cfg-$CFG, 1 sample: the no-grad forward pair, 4 eager calls then 20 + 300 + 300 replays (tools/fwd_graph.py)" $ROOT/tools/fwd_graph.py $CFG 1 300 0
+stats cfg${CFG}_b8_replayed "cfg-$CFG, 8 samples per GPU: 20 + 3 eager steps, then 60 replays of the captured step (tools/try_graph.py)" $ROOT/tools/try_graph.py $CFG 8 60
+# the bench line under the profiler (default-path kernels only)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --cfg $CFG --steps 20 --warmup 5 --no-cpu-baseline --no-extra --no-matrix > $OUT/bench_under_rocprof_$TAG.json 2> $OUT/bench_under_rocprof.log
+rm -rf $OUT/stats
+# HBM traffic: separate passes, no trace domains
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/tools/time_bwd.py $CFG 1 > /dev/null 2> $OUT/pmc_fetch.log
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/tools/time_bwd.py $CFG 1 > /dev/null 2> $OUT/pmc_write.log
 cd $ROOT
-python3 tools/summarize_profiles.py $OUT2 ${TAG}_noert $CFG $BATCH > /dev/null
-rm -rf $OUT2/stats $OUT2/pmc_fetch $OUT2/pmc_write
-unset VAMP_ERT
+mkdir -p $OUT/stats
+python3 tools/summarize_profiles.py $OUT $TAG $CFG 1 > /dev/null
+rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/stats $OUT/kernel_stats_$TAG.csv
+cd /tmp
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/tools/fwd_graph.py $CFG 1 50 0 > /dev/null 2> $OUT/pmc_fetch_fwd.log
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/tools/fwd_graph.py $CFG 1 50 0 > /dev/null 2> $OUT/pmc_write_fwd.log
+cd $ROOT
+mkdir -p $OUT/stats
+python3 tools/summarize_profiles.py $OUT ${TAG}_fwd $CFG 1 > /dev/null
+rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/stats $OUT/kernel_stats_${TAG}_fwd.csv
+ls -la $OUT

@@ -18,6 +18,7 @@ SLOTS = [("lift_fwd_kernel", "lift_fwd"), ("lift_fwd_coop_kernel", "lift_fwd"),
          ("feat_to_channel_last", "feat_to_channel_last"), ("pack_volume_kernel", "pack_volume"),
          ("render_cam_fwd_kernel", "render_cam_fwd"), ("render_cam_fwd_plan_kernel", "render_cam_fwd"),
          ("cam_fwd_direct_kernel", "render_cam_fwd"), ("bev_fwd_fused_kernel", "render_bev_fwd_channels"),
+         ("render_fwd_merged_kernel", "render_fwd_merged"),
          ("cam_term_kernel", "render_cam_term"), ("bev_density_kernel", "render_bev_fwd"),
          ("bev_channels_kernel", "render_bev_fwd_channels"), ("cam_bwd_ray_kernel", "render_cam_bwd_ray"),
          ("cam_bwd_cell_gather_kernel", "render_cam_bwd_gather"), ("cam_bwd_cell_heavy_kernel", "render_cam_bwd_heavy"),
@@ -65,7 +66,8 @@ fetch, write = read_pmc(os.path.join(out, "pmc_fetch"), "FETCH_SIZE"), read_pmc(
 # How each kernel reads: the guide's x2 correction of FETCH_SIZE on gfx950 is calibrated for wide,
 # coalesced streaming reads.  Kernels whose reads are mostly scattered 4 .. 64-byte gathers are marked
 # "gather": for them the doubled figure is an upper bound and the uncorrected one a lower bound.
-ACCESS = {"lift_fwd": "gather", "lift_bwd_gather": "gather (table rows) + streaming (depth tiles)", "lift_bwd_fill": "streaming",
+ACCESS = {"lift_fwd": "gather", "lift_bwd_gather": "streaming (pair records in cell order)", "lift_bwd_fill": "streaming",
+          "render_fwd_merged": "gather (camera tiles) + streaming (BEV blocks)",
           "feat_to_channel_last": "streaming", "render_cam_fwd": "gather", "render_cam_bwd_ray": "streaming (kept samples) + gather",
           "render_cam_bwd_gather": "gather", "render_cam_bwd_heavy": "gather", "render_cam_bwd_rank": "none (geometry only)",
           "render_bev_fwd_channels": "streaming", "render_bev_bwd_scan": "streaming", "render_bev_bwd_q": "streaming",
