@@ -116,20 +116,27 @@ __device__ __forceinline__ int lift_cull_round(const LiftCull& K) { return min(2
 
 // (1): per camera `cn` of sample b.  16-byte loads: the matrices are 64-byte rows of a 16-byte aligned array
 // (checked at the entry points).
-__device__ __forceinline__ LiftCullCam lift_cull_cam(const LiftParams& P, const float* __restrict__ mats, int b, int cn) {
+struct LiftCullMats { float4 r[12], z[4]; };    // the camera's three matrices | inv(bda) of the sample's first camera
+__device__ __forceinline__ LiftCullMats lift_cull_load(const LiftParams& P, const float* __restrict__ mats, int b, int cn) {
   const float4* m = reinterpret_cast<const float4*>(mats + ((long) b * P.N + cn) * 48);
   const float4* m0 = reinterpret_cast<const float4*>(mats + (long) b * P.N * 48);
-  float4 r[12], z[4];
+  LiftCullMats L;
 #pragma unroll
-  for (int i = 0; i < 12; ++i) r[i] = m[i];
+  for (int i = 0; i < 12; ++i) L.r[i] = m[i];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) z[i] = m0[i];
+  for (int i = 0; i < 4; ++i) L.z[i] = m0[i];
+  return L;
+}
+__device__ __forceinline__ LiftCullCam lift_cull_cam_of(const LiftCullMats& L) {
+  const float4 (&r)[12] = L.r;
+  const float4 (&z)[4] = L.z;
   LiftCullCam c;
-  bool same = true;
+  unsigned diff = 0;                     // (bitwise, no short-circuit: the comparison stays inside the loads' basic block)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    same = same && __float_as_uint(r[i].x) == __float_as_uint(z[i].x) && __float_as_uint(r[i].y) == __float_as_uint(z[i].y) &&
-           __float_as_uint(r[i].z) == __float_as_uint(z[i].z) && __float_as_uint(r[i].w) == __float_as_uint(z[i].w);
+    diff |= (__float_as_uint(r[i].x) ^ __float_as_uint(z[i].x)) | (__float_as_uint(r[i].y) ^ __float_as_uint(z[i].y)) |
+            (__float_as_uint(r[i].z) ^ __float_as_uint(z[i].z)) | (__float_as_uint(r[i].w) ^ __float_as_uint(z[i].w));
+  const bool same = diff == 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {          // A = M2 . M1, row i
     const float4 k = r[4 + i];
@@ -142,6 +149,9 @@ __device__ __forceinline__ LiftCullCam lift_cull_cam(const LiftParams& P, const 
   c.plane = r[8].z == 0.f && r[9].z == 0.f && r[10].x == 0.f && r[10].y == 0.f && r[10].z == 1.f && r[10].w == 0.f;
   c.same = same;
   return c;
+}
+__device__ __forceinline__ LiftCullCam lift_cull_cam(const LiftParams& P, const float* __restrict__ mats, int b, int cn) {
+  return lift_cull_cam_of(lift_cull_load(P, mats, b, cn));
 }
 // threads [0, N) of a workgroup: into LDS
 __device__ __forceinline__ void lift_cull_constants(const LiftParams& P, const float* __restrict__ mats, int b,
@@ -282,14 +292,17 @@ __device__ __forceinline__ unsigned lift_cull_inline(const LiftParams& P, const 
   static_assert(kCullWpw == 4, "one word per workgroup");
   __shared__ unsigned word_s;
   if (threadIdx.x < 64) {                                         // wave 0
+    // (no branch around the loads: lanes >= N repeat camera 0, and the matrix loads go out in front of the axis loads
+    // -- scalar: the patch is the same for every lane -- and of the box's arithmetic.  What the word costs a workgroup,
+    // ~2.5 us, is the chain itself: one load round trip and ~400 dependent vector instructions on one wave; neither the
+    // order of the loads nor which of the four waves runs it moved the kernel, 32.8 us against 25.8 with the words of
+    // a first launch.)
     const int n = threadIdx.x;
-    bool keep = false, differ = false;
-    if (n < P.N) {
-      const LiftCullCam c = lift_cull_cam(P, mats, b, n);
-      const LiftCullBox B = lift_cull_box_of(P, xs, ys, zs, min(x0, P.X - 1), min(y0, P.Y - 1), z);
-      keep = lift_cull_test(P, c, B);
-      differ = !c.same;
-    }
+    const bool act = n < P.N;
+    const LiftCullMats M = lift_cull_load(P, mats, b, act ? n : 0);       // (in flight under the axis loads and the box)
+    const LiftCullBox B = lift_cull_box_of(P, xs, ys, zs, min(x0, P.X - 1), min(y0, P.Y - 1), z);
+    const LiftCullCam c = lift_cull_cam_of(M);
+    const bool keep = act && lift_cull_test(P, c, B), differ = act && !c.same;
     const uint64_t kept = __ballot(keep), df = __ballot(differ);
     if (n == 0) word_s = (unsigned) kept | (df ? 0u : kLiftCullSharedBda);
   }
