@@ -456,6 +456,14 @@ int vamp_render_bev_forward_ex(const VampRenderDesc* d, const float* oxs, const 
  */
 #define VAMP_RENDERFWD_SAVE_SAMPLES 1   /* = VAMP_CAMFWD_SAVE_SAMPLES */
 #define VAMP_RENDERFWD_BEV_SAVE 2       /* = VAMP_BEVFWD_SAVE */
+/* training: the camera tiles also do the RANK PASS of the camera backward's cell sort -- every kept inside sample is
+   counted into its cell and takes its rank there, behind its channel loads -- and the call finishes the prepare step
+   (scan + heavy-voxel list) behind the launch: afterwards `workspace` holds what vamp_render_camera_prepare_ex
+   (VAMP_CAMPREP_TERM_VALID) leaves, and the backward takes VAMP_CAMBWD_CELLS_VALID.  The three launches on two streams
+   of a training forward (camera kernel, BEV forward, prepare pass beside it) become one launch + two small ones.
+   COUNTERS_CLEAN: as VAMP_CAMPREP_COUNTERS_CLEAN (otherwise the counters are zero-filled first). */
+#define VAMP_RENDERFWD_RANK 4
+#define VAMP_RENDERFWD_COUNTERS_CLEAN 8
 int vamp_render_forward_merged_supported(const VampRenderDesc* d, const float* ozs_host);
 int vamp_render_forward_merged(const VampRenderDesc* d, const float* mats, const float* us, const float* vs,
                                const float* ds, const float* mids, const float* oxs, const float* oys,

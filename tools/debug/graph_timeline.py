@@ -7,7 +7,11 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the last replay: walk back from the end until the first lift kernel of that step
 names = [r["Kernel_Name"] for r in rows]
 end = len(rows)
-start = max(i for i, n in enumerate(names) if any(k in n for k in ("feat_to_channel_last", "lift_prologue_kernel", "lift_operands_kernel")))
+# (the step's first kernel: the lift's first launch, or -- channel-last features, round 6 -- the lift forward itself)
+firsts = [i for i, n in enumerate(names) if any(k in n for k in ("feat_to_channel_last", "lift_prologue_kernel", "lift_operands_kernel"))]
+if not firsts:
+    firsts = [i for i, n in enumerate(names) if "lift_fwd_kernel" in n or "lift_fwd_coop_kernel" in n]
+start = max(firsts)
 seg = rows[start:end]
 t0 = int(seg[0]["Start_Timestamp"])
 busy_end = t0

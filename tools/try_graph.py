@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Experiment: one training step of the hot path captured in a HIP graph (torch.cuda.CUDAGraph)
-against the eager step.  usage: tools/try_graph.py [cfg] [batch] [steps]"""
+against the eager step.  usage: tools/try_graph.py [cfg] [batch] [steps] [HotPath.impl overrides: key=0|1 ...]"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vampire_amd.config import PRESETS
@@ -12,6 +12,9 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 dev = torch.device("cuda:0")
 model = LiftRenderStep(cfg, dev)
 batch = SyntheticBatch(cfg, B, dev)
+for kv in sys.argv[4:]:
+    k, v = kv.split("=")
+    model.hp.impl[k] = {"0": False, "1": True}.get(v, v)
 
 
 def step():

@@ -69,7 +69,7 @@ VAMP_CAMFWD_SAVE_SAMPLES, VAMP_CAMFWD_NO_ERT, VAMP_CAMFWD_TERM_VALID = 1, 2, 4
 VAMP_CAMPREP_TERM_VALID, VAMP_CAMPREP_COUNTERS_CLEAN = 1, 4
 VAMP_BEVBWD_OVERWRITE_BASE, VAMP_BEVBWD_OVERWRITE_CAM, VAMP_BEVBWD_SAVED_VALID = 1, 2, 4
 VAMP_BEVFWD_SAVE, VAMP_BEVFWD_TWO_KERNELS = 1, 2
-VAMP_RENDERFWD_SAVE_SAMPLES, VAMP_RENDERFWD_BEV_SAVE = 1, 2
+VAMP_RENDERFWD_SAVE_SAMPLES, VAMP_RENDERFWD_BEV_SAVE, VAMP_RENDERFWD_RANK, VAMP_RENDERFWD_COUNTERS_CLEAN = 1, 2, 4, 8
 VAMP_CAMFWD_PACK_ONLY, VAMP_CAMFWD_PACKED_VALID, VAMP_CAMFWD_DIRECT, VAMP_CAMFWD_EXACT_TAPS = 8, 16, 32, 64
 VAMP_BEVBWD_ONLY_BASE, VAMP_BEVBWD_SKIP_BASE, VAMP_BEVBWD_TABLE_VALID = 8, 16, 32
 

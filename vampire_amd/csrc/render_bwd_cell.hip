@@ -361,11 +361,21 @@ CamCellRefs cam_cell_refs(const VampRenderDesc* d, void* scratch) {
   return r;
 }
 
+CamRankRefs cam_rank_refs_cells(const VampRenderDesc* d, void* scratch) {
+  const CellWs w = cell_ws(d, scratch);
+  return CamRankRefs{w.cnt, w.rank, w.tile_se, (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1)};
+}
+int launch_cam_cells_zero(const VampRenderDesc* d, void* scratch, hipStream_t s) {
+  const CellWs w = cell_ws(d, scratch);
+  return launch_zero(w.cnt, (size_t) (cell_count_padded(d->B, d->Z, d->Y, d->X) + kScanPad) * sizeof(int), s);
+}
+
 // rank -> scan -> slot.  Depends on (d, mats, us, vs, ds) only.
 static int launch_cam_heavy_list(const VampRenderDesc* d, const RenderParams& P, const CellWs& w, hipStream_t s);
 
 // phase 0: everything; 1: rank + scan (what needs the geometry and the termination table);
-// 2: heavy list (needs the scan only) -- a caller may leave phase 2 to the backward
+// 2: heavy list (needs the scan only) -- a caller may leave phase 2 to the backward; 3: scan + heavy list behind a
+// forward that has drawn the ranks itself (mats .. term unused)
 int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                              const float* us, const float* vs, const float* ds, void* scratch,
                              const int* term, int phase, hipStream_t s, bool counters_clean) {
@@ -376,6 +386,10 @@ int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, con
   VAMP_REQUIRE(samples > 0 && samples < 0x7fffffffu && voxels < 0x7fffffffu && ncell < 0x7fffffffL,
                "sample / voxel / cell count exceeds 2^31");
   const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
+  if (phase == 3) {
+    if (int e = launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, ncell, s)) return e;
+    return launch_cam_heavy_list(d, P, w, s);
+  }
   if (phase != 2) {
     if (!counters_clean) {          // (VAMP_CAMPREP_COUNTERS_CLEAN: the previous scan left them at zero)
       if (int ze = launch_zero(w.cnt, (size_t) (ncell + kScanPad) * sizeof(int), s)) return ze;

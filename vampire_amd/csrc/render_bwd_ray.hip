@@ -265,6 +265,21 @@ static size_t beta_part_bytes(const VampRenderDesc* d) {
 
 size_t cam_bwd_v2_bytes(const VampRenderDesc* d) { return gcl_bytes(d) + cam_bwd_cell_bytes(d) + beta_part_bytes(d); }
 
+// the cell lists inside the render workspace: [packed volume | Gcl | cell lists | beta partials]
+CamRankRefs cam_rank_refs_cells(const VampRenderDesc* d, void* scratch);
+int launch_cam_cells_zero(const VampRenderDesc* d, void* scratch, hipStream_t s);
+static void* cell_scratch_of(const VampRenderDesc* d, void* workspace) {
+  return static_cast<char*>(workspace) + packed_bytes(d) + gcl_bytes(d);
+}
+CamRankRefs cam_rank_refs(const VampRenderDesc* d, void* workspace) { return cam_rank_refs_cells(d, cell_scratch_of(d, workspace)); }
+int launch_cam_counters_zero(const VampRenderDesc* d, void* workspace, hipStream_t s) {
+  return launch_cam_cells_zero(d, cell_scratch_of(d, workspace), s);
+}
+int launch_cam_prepare_ranked(const VampRenderDesc* d, void* workspace, hipStream_t s) {
+  return launch_cam_cells_prepare(d, to_params(d), nullptr, nullptr, nullptr, nullptr, cell_scratch_of(d, workspace), nullptr,
+                                  /*phase=*/3, s);
+}
+
 // scratch = workspace region after the packed volume: [Gcl | cell lists | beta partials]
 int launch_cam_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                        const float* us, const float* vs, const float* ds, void* scratch,

@@ -4,6 +4,7 @@
 #include "render_common.hpp"
 #include "ray_plan.hpp"
 #include "pair_gather.hpp"
+#include "cell_list.hpp"
 
 namespace vamp {
 
@@ -207,6 +208,16 @@ __device__ __forceinline__ VolTap chain_tap(const RenderParams& P, const float* 
   return tp;
 }
 
+// The same with the IEEE divisions of volume_tap for every lane: bit for bit what the camera backward's per-ray pass
+// evaluates (frustum_point + volume_tap; frustum_point_rb has frustum_point's roundings).  For the samples whose
+// cell RANK the forward draws (RANK instances): the per-ray pass looks a sample's record slot up as (its cell, the
+// rank drawn here), so the two must agree on the cell of every sample, not in all but one in a million.
+__device__ __forceinline__ VolTap chain_tap_exact(const RenderParams& P, const float* __restrict__ mm, const ChainCtx& c, float d) {
+  float x, y, z;
+  chain_point(mm, c, d, x, y, z);
+  return volume_tap(P, x, y, z);
+}
+
 // tile -> ray with 32-bit arithmetic (decode_ray_wps of render_common.hpp divides 64-bit values)
 __device__ __forceinline__ RayId decode_tile(const RenderParams& P, unsigned bid) {
   const int tiles_w = (P.fW + 7) >> 3, tiles_h = (P.fH + 7) >> 3;
@@ -241,14 +252,21 @@ __device__ __forceinline__ RayId decode_tile(const RenderParams& P, unsigned bid
 // All samples sit on the reference's own fp32 coordinate chain (chain_tap above).
 // `bid`: the workgroup's index among the camera tiles' workgroups (blockIdx.x of cam_fwd_direct_kernel; the merged
 // render forward of render_fwd_merged.hip passes its own).
-template <typename T, int NCH, bool ERT, int NW>
+// RANK (training calls of the merged render forward): the tile also does the camera backward's RANK PASS -- every kept
+// inside sample is counted into its cell (the voxel-grid cube of its floor taps) and takes its rank there, one
+// run-aggregated atomic per run of lanes in a cell, issued in front of the sample's 84 channel loads and collected
+// behind them.  The prepare step's first kernel (cam_cells_rank_kernel: 16 - 18 us of chain evaluations and atomics on
+// the same samples) disappears, and with it the reason to keep camera forward, BEV forward and prepare pass as three
+// launches on two streams: training forwards are one launch + the scan + the heavy list.
+template <typename T, int NCH, bool ERT, int NW, bool RANK = false>
 __device__ __forceinline__ void
 cam_fwd_direct_tile(const unsigned bid, const RenderParams& P, const float* __restrict__ mats, const float* __restrict__ us,
                       const float* __restrict__ vs, const float* __restrict__ ds,
                       const float* __restrict__ mids, const float* __restrict__ beta_raw,
                       const T* __restrict__ dens, const T* __restrict__ sem, const T* __restrict__ rgb,
                       float* __restrict__ rgb_out, float* __restrict__ seg_out,
-                      float* __restrict__ depth_out, int* __restrict__ term_out, float* __restrict__ rows) {
+                      float* __restrict__ depth_out, int* __restrict__ term_out, float* __restrict__ rows,
+                      const CamRankRefs rk = CamRankRefs{nullptr, nullptr, nullptr, 0}) {
   extern __shared__ __align__(16) float dyn[];
   __shared__ int4 plan[kPlanMax];
   __shared__ int keep_s[64];
@@ -536,7 +554,18 @@ cam_fwd_direct_tile(const unsigned bid, const RenderParams& P, const float* __re
       const int i = __builtin_amdgcn_readfirstlane((int) act_s[k]);
       const float* mg = m;
       asm volatile("" : "+s"(mg));
-      const VolTap tp = chain_tap(P, mg, cc, ds[i]);
+      const VolTap tp = RANK ? chain_tap_exact(P, mg, cc, ds[i]) : chain_tap(P, mg, cc, ds[i]);
+      // the sample's rank in its cell (wave-uniform control flow: every lane takes part in the run detection)
+      LaneRun run{false, 0, 0};
+      int rbase = 0;
+      bool ranked = false;
+      if (RANK) {
+        ranked = id.live && tp.inside && i < keep;
+        const int key = ranked ? pack_cell_key(tp.ix0, tp.iy0, tp.iz0) : 0;
+        const long cell = key_to_cell(key, P.Y, P.X, (unsigned) b, rk.ncell_b);
+        run = lane_run(ranked, cell, lane);
+        if (run.head) rbase = atomicAdd(rk.cnt + cell, run.len);       // (returns under the channel loads below)
+      }
       if (tp.inside && i < keep) {
         const PairTap pt = pair_tap<T>(P, tp);
         const float wgt = wbuf[i * 64 + lane];
@@ -585,7 +614,18 @@ cam_fwd_direct_tile(const unsigned bid, const RenderParams& P, const float* __re
 #pragma unroll
         for (int c = 0; c < NCH; ++c) acc[c] = __builtin_fmaf(wgt, s[c], acc[c]);
       }
+      if (RANK) {
+        rbase = __shfl(rbase, ranked ? run.start : lane, 64);
+        if (ranked) rk.rank[((long) id.tile * S + i) * 64 + lane] = rbase + (lane - run.start);
+      }
     }
+  }
+  if (RANK && threadIdx.x < 64) {
+    // the tile's depth (its longest LIVE ray): the per-ray pass takes the deepest tiles first
+    int sl = id.live ? keep : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sl = max(sl, __shfl_xor(sl, o, 64));
+    if (threadIdx.x == 0 && id.live) rk.tile_se[id.tile] = sl;       // (lane 0 is live exactly when the workgroup has a tile of its own)
   }
   __syncthreads();                                                   // all reads of wbuf are done
   VAMP_STAMP(4);

@@ -270,6 +270,22 @@ int launch_cam_term(const VampRenderDesc* d, const RenderParams& P, const float*
                     const float* vs, const float* ds, const float* beta, const void* density_feature,
                     int* term, hipStream_t s);
 
+// What a forward that draws the camera backward's cell ranks itself needs of the cell lists (round 6: the rank pass
+// of the prepare step inside the one-kernel camera forward's gather phase, render_cam_direct_dev.hpp): cell counters
+// (zero on entry), the per-sample rank table, the tiles' depths.
+struct CamRankRefs {
+  int* cnt;             // [cells] nullptr: the forward draws no ranks
+  int* rank;            // [tiles][S][64]
+  int* tile_se;         // [tiles]
+  long ncell_b;         // cells per sample of the batch
+};
+// `workspace`: the render workspace (vamp_render_workspace_bytes).  render_bwd_ray.hip
+CamRankRefs cam_rank_refs(const VampRenderDesc* d, void* workspace);
+// zero the cell counters (a forward that draws ranks on a workspace not known clean) / scan them and build the heavy
+// list behind such a forward (what vamp_render_camera_prepare does behind its own rank pass)
+int launch_cam_counters_zero(const VampRenderDesc* d, void* workspace, hipStream_t s);
+int launch_cam_prepare_ranked(const VampRenderDesc* d, void* workspace, hipStream_t s);
+
 // render_cam_direct.hip: plan + density march + scan + channel gather in one kernel, on the
 // channel-first volumes; term_out (may be NULL) receives the per-ray table
 int launch_cam_fwd_direct(const VampRenderDesc* d, const RenderParams& P, const float* mats, const float* us,
@@ -327,7 +343,7 @@ int launch_render_fwd_merged(const VampRenderDesc* d, const RenderParams& P, con
                              const void* sem, const void* rgb, const void* base, float* rgb_out, float* seg_out,
                              float* depth_out, int* term_out, float* rows, float* bev_rgb, float* bev_seg,
                              float* bev_height, float* voxel_density, float* voxel_output, float* s0_save,
-                             float* ss_save, hipStream_t s);
+                             float* ss_save, const CamRankRefs& rank, hipStream_t s);
 
 // 8-tap trilinear gather of CP4*4 packed channels for an INSIDE sample, branch-free: all
 // 8 * CP4 16-byte loads are independent and can be in flight together (a per-tap bounds

@@ -33,6 +33,7 @@ struct MergedCam {
   float *rgb_out, *seg_out, *depth_out;
   int* term_out;
   float* rows;
+  CamRankRefs rank;       // training: the tiles draw the camera backward's cell ranks (cnt == nullptr: no)
 };
 struct MergedBev {
   const float *oxs, *oys, *ozs, *bev_mids;
@@ -75,7 +76,7 @@ __device__ __forceinline__ S kernarg_copy(KS src) {
 // plain by-value parameters the compiler loads all of them in the entry block and keeps the union of both bodies'
 // 70-odd scalars alive across the branch -- 48 scalar spills and, through the lanes that hold them, 52 bytes of
 // scratch per lane in a camera tile that has none on its own.
-template <typename T, int NCH>
+template <typename T, int NCH, bool RANK>
 __global__ void __launch_bounds__(256, 4)
 render_fwd_merged_kernel(MergedArgs<T> args_in_kernarg_segment) {
 #ifdef VAMP_MERGED_STAMPS
@@ -93,8 +94,8 @@ render_fwd_merged_kernel(MergedArgs<T> args_in_kernarg_segment) {
     asm volatile("" : "+s"(ap));
     const RenderParams P = kernarg_copy<RenderParams>(&ap->P);
     const MergedCam c = kernarg_copy<MergedCam>(&ap->c);
-    cam_fwd_direct_tile<T, NCH, true, 4>(bid, P, c.mats, c.us, c.vs, c.ds, c.mids, ap->beta_raw, ap->dens, ap->sem,
-                                         ap->rgb, c.rgb_out, c.seg_out, c.depth_out, c.term_out, c.rows);
+    cam_fwd_direct_tile<T, NCH, true, 4, RANK>(bid, P, c.mats, c.us, c.vs, c.ds, c.mids, ap->beta_raw, ap->dens, ap->sem,
+                                               ap->rgb, c.rgb_out, c.seg_out, c.depth_out, c.term_out, c.rows, c.rank);
   } else {
     asm volatile("" : "+s"(ap));
     const RenderParams P = kernarg_copy<RenderParams>(&ap->P);
@@ -123,7 +124,7 @@ int launch_render_fwd_merged(const VampRenderDesc* d, const RenderParams& P, con
                              const void* sem, const void* rgb, const void* base, float* rgb_out, float* seg_out,
                              float* depth_out, int* term_out, float* rows, float* bev_rgb, float* bev_seg,
                              float* bev_height, float* voxel_density, float* voxel_output, float* s0_save,
-                             float* ss_save, hipStream_t s) {
+                             float* ss_save, const CamRankRefs& rank, hipStream_t s) {
   const int S = P.D - 1, nch = cam_direct_nch(P.K + 3);
   const long tiles = (long) P.B * P.N * ((P.fH + 7) / 8) * ((P.fW + 7) / 8);
   const long ncam = (tiles + 7) / 8 * 8;
@@ -141,8 +142,11 @@ int launch_render_fwd_merged(const VampRenderDesc* d, const RenderParams& P, con
   do {                                                                                                     \
     const MergedArgs<T> a{(unsigned) ncam, P, beta, static_cast<const T*>(dens), static_cast<const T*>(sem), \
                           static_cast<const T*>(rgb), static_cast<const T*>(base),                         \
-                          MergedCam{mats, us, vs, ds, mids, rgb_out, seg_out, depth_out, term_out, rows}, v}; \
-    VAMP_TIMED(kProfRenderFwdMerged, s, (render_fwd_merged_kernel<T, NCH><<<grid, 256, dyn, s>>>(a)));     \
+                          MergedCam{mats, us, vs, ds, mids, rgb_out, seg_out, depth_out, term_out, rows, rank}, v}; \
+    if (rank.cnt)                                                                                          \
+      VAMP_TIMED(kProfRenderFwdMerged, s, (render_fwd_merged_kernel<T, NCH, true><<<grid, 256, dyn, s>>>(a)));  \
+    else                                                                                                   \
+      VAMP_TIMED(kProfRenderFwdMerged, s, (render_fwd_merged_kernel<T, NCH, false><<<grid, 256, dyn, s>>>(a))); \
   } while (0)
 #define VAMP_MRG_T(T)                                                                                      \
   do {                                                                                                     \

@@ -624,6 +624,11 @@ def render_forward_plan(train, two, prep_ok, direct, ert, merged=False):
         merged = False
     if merged and not train:
         return [("render", "cur", 0, (), ())]
+    if merged and train and prep_ok:
+        # training: the camera tiles also draw the backward's cell ranks, and the call finishes the prepare step (scan +
+        # heavy-voxel list) behind the launch -- one launch + two small ones on ONE stream where rounds 3 - 5 ran the
+        # camera kernel, the BEV forward and the prepare pass as three launches on two (replayed step 0.403 -> ... ms)
+        return [("render", "cur", F.VAMP_RENDERFWD_RANK, (), ())]
     if train and two and prep_ok and direct:
         # the camera kernel (which leaves the termination table), then the BEV forward; beside them, once the
         # table is there, the prepare pass
@@ -716,6 +721,13 @@ class _RenderFn(torch.autograd.Function):
         # hp.ozs_host against the BEV kernel's plane slabs itself)
         merged = bool(direct and ert and hp.impl["fwd_merged"] and hp.impl["bev_fused"] and
                       hp.lib.vamp_render_forward_merged_supported(C.byref(d), hp.ozs_host))
+        # training calls take the one launch (camera tiles + rank pass + BEV blocks) while the camera tiles are at most
+        # four rounds of the chip's workgroup slots: cfg-B, replayed step, merged against the three launches on two
+        # streams -- 1 / 2 / 3 samples per GPU 0.395 / 0.710 / 1.03 against 0.410 / 0.723 / 1.05 ms, 4 samples equal,
+        # 8 samples 2.69 against 2.63 (a full chip hides the prepare pass beside the BEV forward better than it
+        # fills the camera tiles' tail)
+        if merged and train and B * N * ((c.fH + 7) // 8) * ((c.fW + 7) // 8) > 4096:
+            merged = False
         plan = render_forward_plan(train, side is not None, prep_ok, direct, ert, merged)
         bev_flags = 0 if hp.impl["bev_fused"] else _capi.VAMP_BEVFWD_TWO_KERNELS
         bev_save = train and hp.impl["bev_bwd"] != "v1"
@@ -753,8 +765,12 @@ class _RenderFn(torch.autograd.Function):
                     _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(rgb_p), _ptr(seg_p), _ptr(dep_p),
                     _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h), _ptr(vdens), _ptr(vout), _ptr(ws), ws.numel(),
                     _ptr(ws_bev), ws_bev.numel() if bev_save else 0,
-                    (_capi.VAMP_RENDERFWD_SAVE_SAMPLES if save else 0) | (_capi.VAMP_RENDERFWD_BEV_SAVE if bev_save else 0),
+                    (_capi.VAMP_RENDERFWD_SAVE_SAMPLES if save else 0) | (_capi.VAMP_RENDERFWD_BEV_SAVE if bev_save else 0)
+                    | flags | (_capi.VAMP_RENDERFWD_COUNTERS_CLEAN if (flags & _capi.VAMP_RENDERFWD_RANK) and hp._cam_clean_flag() else 0),
                     _stream(st)), "vamp_render_forward_merged")
+                if flags & _capi.VAMP_RENDERFWD_RANK:
+                    hp._dirty.discard("render")         # (ranks drawn, counters scanned back to zero)
+                    ctx.cells = True
             else:
                 _capi.check(hp.lib.vamp_render_bev_forward_ex(
                     C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
