@@ -15,8 +15,9 @@ def test_merged_schedules():
         if direct and ert and not train:
             assert ops == ["render"] and plan[0][1] == "cur" and plan[0][2] == 0, ((train, two, prep_ok, direct, ert), ops)
         elif direct and ert and train and prep_ok:
-            # training: the one launch also draws the backward's cell ranks and finishes the prepare step
-            assert ops == ["render"] and plan[0][1] == "cur" and plan[0][2] == _capi.VAMP_RENDERFWD_RANK
+            # training: the one launch also draws the backward's cell ranks; scan + heavy list behind it
+            assert ops == ["render", "prep"] and plan[0][1] == "cur" and plan[0][2] == _capi.VAMP_RENDERFWD_RANK
+            assert plan[1][2] == _capi.VAMP_CAMPREP_RANKED and plan[1][1] == "cur"
         else:
             assert plan == render_forward_plan(train, two, prep_ok, direct, ert), (train, two, prep_ok, direct, ert)
 

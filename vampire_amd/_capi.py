@@ -66,7 +66,7 @@ VAMP_CAMBWD_ACCUMULATE, VAMP_CAMBWD_PACKED_VALID, VAMP_CAMBWD_CELLS_VALID, VAMP_
 VAMP_CAMBWD_SAMPLES_VALID, VAMP_CAMBWD_TERM_VALID, VAMP_CAMBWD_NO_ERT = 16, 32, 64
 VAMP_CAMBWD_PART_RAY, VAMP_CAMBWD_PART_GATHER, VAMP_CAMBWD_PART_HEAVY = 128, 256, 512
 VAMP_CAMFWD_SAVE_SAMPLES, VAMP_CAMFWD_NO_ERT, VAMP_CAMFWD_TERM_VALID = 1, 2, 4
-VAMP_CAMPREP_TERM_VALID, VAMP_CAMPREP_COUNTERS_CLEAN = 1, 4
+VAMP_CAMPREP_TERM_VALID, VAMP_CAMPREP_COUNTERS_CLEAN, VAMP_CAMPREP_RANKED = 1, 4, 8
 VAMP_BEVBWD_OVERWRITE_BASE, VAMP_BEVBWD_OVERWRITE_CAM, VAMP_BEVBWD_SAVED_VALID = 1, 2, 4
 VAMP_BEVFWD_SAVE, VAMP_BEVFWD_TWO_KERNELS = 1, 2
 VAMP_RENDERFWD_SAVE_SAMPLES, VAMP_RENDERFWD_BEV_SAVE, VAMP_RENDERFWD_RANK, VAMP_RENDERFWD_COUNTERS_CLEAN = 1, 2, 4, 8

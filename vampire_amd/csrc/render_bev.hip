@@ -1450,8 +1450,8 @@ int vamp_render_forward_merged(const VampRenderDesc* d, const float* mats, const
     s0_save = reinterpret_cast<float*>(static_cast<char*>(bev_workspace) + bev_saved_offset(d));
     ss_save = reinterpret_cast<float*>(static_cast<char*>(bev_workspace) + bev_saved_offset(d) + bev_one(d));
   }
-  // VAMP_RENDERFWD_RANK: the camera tiles draw the backward's cell ranks; the scan and the heavy-voxel list follow here
-  // (what vamp_render_camera_prepare does behind its own rank pass), and the workspace is then what that call leaves
+  // VAMP_RENDERFWD_RANK: the camera tiles draw the backward's cell ranks; the caller finishes the prepare step with
+  // vamp_render_camera_prepare_ex(VAMP_CAMPREP_RANKED) -- on this stream or another
   CamRankRefs rank{nullptr, nullptr, nullptr, 0};
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (flags & VAMP_RENDERFWD_RANK) {
@@ -1463,10 +1463,9 @@ int vamp_render_forward_merged(const VampRenderDesc* d, const float* mats, const
       return e;
     }
   }
-  if (int e = launch_render_fwd_merged(d, to_params(d), mats, us, vs, ds, mids, oxs, oys, ozs, bev_mids, beta, density_feature,
-                                       semantic, rgb, base, rgb_out, seg_out, depth_out, term, rows, bev_rgb, bev_seg, bev_height,
-                                       voxel_density, voxel_output, s0_save, ss_save, rank, s)) return e;
-  return (flags & VAMP_RENDERFWD_RANK) ? launch_cam_prepare_ranked(d, workspace, s) : VAMP_OK;
+  return launch_render_fwd_merged(d, to_params(d), mats, us, vs, ds, mids, oxs, oys, ozs, bev_mids, beta, density_feature,
+                                  semantic, rgb, base, rgb_out, seg_out, depth_out, term, rows, bev_rgb, bev_seg, bev_height,
+                                  voxel_density, voxel_output, s0_save, ss_save, rank, s);
 }
 
 static int bev_zero_overwritten(const VampRenderDesc* d, int flags, float* gd, float* gs, float* gr,

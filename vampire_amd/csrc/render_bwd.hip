@@ -354,10 +354,12 @@ int vamp_render_camera_prepare_ex(const VampRenderDesc* d, const float* mats, co
                                   const float* vs, const float* ds, void* workspace,
                                   size_t workspace_bytes, int flags, void* stream) {
   if (int e = validate(d)) return e;
-  VAMP_REQUIRE(mats && us && vs && ds, "null pointer");
   const size_t need = vamp_render_workspace_bytes(d);
   if (!workspace || workspace_bytes < need)
     return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) need);
+  // the ranks are drawn (vamp_render_forward_merged with VAMP_RENDERFWD_RANK): scan + heavy-voxel list only
+  if (flags & VAMP_CAMPREP_RANKED) return launch_cam_prepare_ranked(d, workspace, static_cast<hipStream_t>(stream));
+  VAMP_REQUIRE(mats && us && vs && ds, "null pointer");
   const RenderParams P = to_params(d);
   return launch_cam_prepare(d, P, mats, us, vs, ds, static_cast<char*>(workspace) + packed_bytes(d),
                             (flags & VAMP_CAMPREP_TERM_VALID) ? cam_term_ptr(d, workspace) : nullptr,

@@ -628,7 +628,10 @@ def render_forward_plan(train, two, prep_ok, direct, ert, merged=False):
         # training: the camera tiles also draw the backward's cell ranks, and the call finishes the prepare step (scan +
         # heavy-voxel list) behind the launch -- one launch + two small ones on ONE stream where rounds 3 - 5 ran the
         # camera kernel, the BEV forward and the prepare pass as three launches on two (replayed step 0.403 -> ... ms)
-        return [("render", "cur", F.VAMP_RENDERFWD_RANK, (), ())]
+        # (the scan + heavy list on the side stream, with the backward's camera chain behind them there and its BEV
+        # chain here, so that the BEV chain would start beside them: 0.411 against 0.395 ms -- they stay on this stream)
+        return [("render", "cur", F.VAMP_RENDERFWD_RANK, (), ()),
+                ("prep", "cur", F.VAMP_CAMPREP_RANKED, (), ())]
     if train and two and prep_ok and direct:
         # the camera kernel (which leaves the termination table), then the BEV forward; beside them, once the
         # table is there, the prepare pass
@@ -753,9 +756,10 @@ class _RenderFn(torch.autograd.Function):
                     _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(), cam_base | flags | keep, _stream(st)),
                     "vamp_render_camera_forward_ex")
             elif op == "prep":
+                ranked = bool(flags & _capi.VAMP_CAMPREP_RANKED)       # (the forward drew the ranks: scan + heavy list only)
                 _capi.check(hp.lib.vamp_render_camera_prepare_ex(
                     C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(),
-                    flags | hp._cam_clean_flag(), _stream(st)), "vamp_render_camera_prepare_ex")
+                    flags | (0 if ranked else hp._cam_clean_flag()), _stream(st)), "vamp_render_camera_prepare_ex")
                 hp._dirty.discard("render")
                 ctx.cells = True
             elif op == "render":
@@ -768,9 +772,7 @@ class _RenderFn(torch.autograd.Function):
                     (_capi.VAMP_RENDERFWD_SAVE_SAMPLES if save else 0) | (_capi.VAMP_RENDERFWD_BEV_SAVE if bev_save else 0)
                     | flags | (_capi.VAMP_RENDERFWD_COUNTERS_CLEAN if (flags & _capi.VAMP_RENDERFWD_RANK) and hp._cam_clean_flag() else 0),
                     _stream(st)), "vamp_render_forward_merged")
-                if flags & _capi.VAMP_RENDERFWD_RANK:
-                    hp._dirty.discard("render")         # (ranks drawn, counters scanned back to zero)
-                    ctx.cells = True
+                # (with VAMP_RENDERFWD_RANK the counters stay "in flight" until the "prep" op behind has scanned them)
             else:
                 _capi.check(hp.lib.vamp_render_bev_forward_ex(
                     C.byref(d), _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), _ptr(hp.bev_mids), _ptr(beta),
@@ -871,14 +873,15 @@ class _RenderFn(torch.autograd.Function):
             # waits for the BEV event and adds on top.
             # The pass-through (grad_base) gather of the BEV branch is issued behind the event: nobody
             # waits for grad_base, so it runs beside the camera gather instead of in front of it.
+            s_bev, s_cam = side, cur
             side.wait_stream(cur)
-            bev_backward(side, True, _capi.VAMP_BEVBWD_SKIP_BASE)
+            bev_backward(s_bev, True, _capi.VAMP_BEVBWD_SKIP_BASE)
             done = torch.cuda.Event()
-            done.record(side)
-            bev_backward(side, True, _capi.VAMP_BEVBWD_ONLY_BASE)
+            done.record(s_bev)
+            bev_backward(s_bev, True, _capi.VAMP_BEVBWD_ONLY_BASE)
             hp._bev_tab_key = tab_key
-            # The camera backward in three parts: ray pass here; then the gather here (after the BEV
-            # event) and, beside it on the side stream, the kernel that drains the heavy-voxel list --
+            # The camera backward in three parts: ray pass on one stream; then the gather there (after the BEV
+            # event) and, beside it on the BEV chain's stream, the kernel that drains the heavy-voxel list --
             # the two own different voxels (the list is built with the cell lists).
             cam_flags = 1 | packed_valid
 
@@ -887,12 +890,12 @@ class _RenderFn(torch.autograd.Function):
                     *cam_args, _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gbeta), _ptr(ws), ws.numel(), cam_flags | part,
                     event, _stream(stream)), "vamp_render_camera_backward_acc")
 
-            cam_part(_capi.VAMP_CAMBWD_PART_RAY, cur)
+            cam_part(_capi.VAMP_CAMBWD_PART_RAY, s_cam)
             ray_done = torch.cuda.Event()
-            ray_done.record(cur)
-            side.wait_event(ray_done)
-            cam_part(_capi.VAMP_CAMBWD_PART_HEAVY, side)
-            cam_part(_capi.VAMP_CAMBWD_PART_GATHER, cur, C.c_void_p(done.cuda_event))
+            ray_done.record(s_cam)
+            s_bev.wait_event(ray_done)
+            cam_part(_capi.VAMP_CAMBWD_PART_HEAVY, s_bev)
+            cam_part(_capi.VAMP_CAMBWD_PART_GATHER, s_cam, C.c_void_p(done.cuda_event))
             cur.wait_stream(side)
         elif geom is None and default_impl:
             bev_backward(cur, True)
