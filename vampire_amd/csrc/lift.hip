@@ -282,29 +282,89 @@ __device__ __forceinline__ void lift_cull_share(const LiftParams& P, const float
   }
 }
 
-// The word of ONE workgroup's own patch, formed at its head by the first N lanes (one ballot): what the forward
-// kernels do when no first launch has left the words in the workspace -- a caller that hands the features over
-// channel-last needs no transpose, and with it the whole first launch goes (VAMP_LIFTFWD_FEAT_CHANNEL_LAST).
-// Same constants, same rectangle, same test as the stand-alone kernel: same words.  All threads call it.
+// The word of ONE workgroup's own patch, formed at its head: what the forward kernels do when no first launch has
+// left the words in the workspace -- a caller that hands the features over channel-last needs no transpose, and with
+// it the whole first launch goes (VAMP_LIFTFWD_FEAT_CHANNEL_LAST).  All threads call it.
+//
+// The same test as lift_cull_test -- the patch's bounding rectangle grown by a voxel, its four corners against the six
+// half-spaces of `valid` with the same margins -- laid out over the lanes of wave 0 instead of down one lane: lane =
+// (camera, corner), 4 N <= 60 lanes.  A lane sends ONE corner through inv(bda) and K inv(s2e) (two matrix-vector
+// products, 28 fma, where the lane-per-camera form built the 4 x 4 product and then walked the corners: ~400 dependent
+// vector instructions per workgroup, 2.5 us at the head of each of them and 7 us on the kernel), the range of q.w and
+// the "all four corners outside" conjunctions are two-step exchanges inside the camera's quad of lanes, and the patch's
+// axes arrive as one load (lanes 0 .. 15 x, 16 .. 31 y) + a 16-lane min / max.  The corners go through the two matrices
+// one after the other here and through their fp32 product there: roundings four orders of magnitude inside the margins
+// either way (a feature pixel, a depth bin); both are conservative, so the forward's bits do not depend on which ran.
 __device__ __forceinline__ unsigned lift_cull_inline(const LiftParams& P, const float* __restrict__ mats,
                                                      const float* __restrict__ xs, const float* __restrict__ ys,
                                                      const float* __restrict__ zs, int b, int x0, int y0, int z) {
-  static_assert(kCullWpw == 4, "one word per workgroup");
+  static_assert(kCullWpw == 4 && kCullPX == 16 && kCullPY == 16, "one word per workgroup of 16 x 16 voxels");
   __shared__ unsigned word_s;
   if (threadIdx.x < 64) {                                         // wave 0
-    // (no branch around the loads: lanes >= N repeat camera 0, and the matrix loads go out in front of the axis loads
-    // -- scalar: the patch is the same for every lane -- and of the box's arithmetic.  What the word costs a workgroup,
-    // ~2.5 us, is the chain itself: one load round trip and ~400 dependent vector instructions on one wave; neither the
-    // order of the loads nor which of the four waves runs it moved the kernel, 32.8 us against 25.8 with the words of
-    // a first launch.)
-    const int n = threadIdx.x;
+    const int lane = threadIdx.x, n = lane >> 2, k = lane & 3;
     const bool act = n < P.N;
-    const LiftCullMats M = lift_cull_load(P, mats, b, act ? n : 0);       // (in flight under the axis loads and the box)
-    const LiftCullBox B = lift_cull_box_of(P, xs, ys, zs, min(x0, P.X - 1), min(y0, P.Y - 1), z);
-    const LiftCullCam c = lift_cull_cam_of(M);
-    const bool keep = act && lift_cull_test(P, c, B), differ = act && !c.same;
-    const uint64_t kept = __ballot(keep), df = __ballot(differ);
-    if (n == 0) word_s = (unsigned) kept | (df ? 0u : kLiftCullSharedBda);
+    const float4* m = reinterpret_cast<const float4*>(mats + ((long) b * P.N + (act ? n : 0)) * 48);
+    const float4* m0 = reinterpret_cast<const float4*>(mats + (long) b * P.N * 48);
+    float4 r[11], z4[4];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) r[i] = m[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z4[i] = m0[i];
+    // the patch's axes (arrays of the caller: no monotonicity assumed) and their extremes
+    const int x0c = min(x0, P.X - 1), y0c = min(y0, P.Y - 1);
+    const float av = (lane & 16) ? ys[min(y0c + (lane & 15), P.Y - 1)] : xs[min(x0c + (lane & 15), P.X - 1)];
+    const float zc = zs[z];
+    // (exchanges inside a quad and inside a row of 16 lanes are DPP operands of the min / max itself; through the LDS
+    // crossbar, which is what __shfl compiles to, each of the nine dependent steps of this function was a round trip)
+    float lo = av, hi = av;
+    lo = fminf(lo, __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, false)); hi = fmaxf(hi, __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]
+    lo = fminf(lo, __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xf, 0xf, false)); hi = fmaxf(hi, __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]
+    lo = fminf(lo, __builtin_amdgcn_update_dpp(lo, lo, 0x124, 0xf, 0xf, false)); hi = fmaxf(hi, __builtin_amdgcn_update_dpp(hi, hi, 0x124, 0xf, 0xf, false));   // row_ror:4
+    lo = fminf(lo, __builtin_amdgcn_update_dpp(lo, lo, 0x128, 0xf, 0xf, false)); hi = fmaxf(hi, __builtin_amdgcn_update_dpp(hi, hi, 0x128, 0xf, 0xf, false));   // row_ror:8
+    const float xlo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo), 0)), xhi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi), 0));
+    const float ylo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo), 16)), yhi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi), 16));
+    const int nx = min(kCullPX, P.X - x0c), ny = min(kCullPY, P.Y - y0c);
+    const float gx = nx > 1 ? (xhi - xlo) / (float) (nx - 1) : 0.f, gy = ny > 1 ? (yhi - ylo) / (float) (ny - 1) : 0.f;
+    // this lane's corner of the grown rectangle
+    const float cx = (k & 1) ? xhi + gx : xlo - gx, cy = (k & 2) ? yhi + gy : ylo - gy;
+    float pv[4], q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pv[i] = __builtin_fmaf(r[i].x, cx, __builtin_fmaf(r[i].y, cy, __builtin_fmaf(r[i].z, zc, r[i].w)));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      q[i] = __builtin_fmaf(r[4 + i].x, pv[0], __builtin_fmaf(r[4 + i].y, pv[1], __builtin_fmaf(r[4 + i].z, pv[2], r[4 + i].w * pv[3])));
+    // the range of q.w over the rectangle (affine in the centre: its corners' extremes)
+    float wlo = q[3], whi = q[3];
+    wlo = fminf(wlo, __builtin_amdgcn_update_dpp(wlo, wlo, 0xB1, 0xf, 0xf, false)); whi = fmaxf(whi, __builtin_amdgcn_update_dpp(whi, whi, 0xB1, 0xf, 0xf, false));
+    wlo = fminf(wlo, __builtin_amdgcn_update_dpp(wlo, wlo, 0x4E, 0xf, 0xf, false)); whi = fmaxf(whi, __builtin_amdgcn_update_dpp(whi, whi, 0x4E, 0xf, 0xf, false));
+    const float a00 = r[8].x, a01 = r[8].y, a03 = r[8].w, a10 = r[9].x, a11 = r[9].y, a13 = r[9].w;
+    const bool plane = r[8].z == 0.f && r[9].z == 0.f && r[10].x == 0.f && r[10].y == 0.f && r[10].z == 1.f && r[10].w == 0.f;
+    const float mu = P.u_div / (float) P.fW, mv = P.v_div / (float) P.fH;      // one feature pixel
+    const float mz = P.use_depth ? P.d_span / (float) P.D : 0.01f;            // one depth bin (D == 1: a centimetre)
+    const float zlo = P.use_depth ? P.d_lo : 0.f;
+    const float u3lo = fminf(a03 * wlo, a03 * whi), u3hi = fmaxf(a03 * wlo, a03 * whi);
+    const float v3lo = fminf(a13 * wlo, a13 * whi), v3hi = fmaxf(a13 * wlo, a13 * whi);
+    const float lu = a00 * q[0] + a01 * q[1], lv = a10 * q[0] + a11 * q[1], qz = q[2];
+    // this corner's side of each bound (lift_cull_test's o_near .. front), then the conjunction over the four corners
+    unsigned f = (qz <= zlo - mz ? 1u : 0u) | ((P.use_depth != 0 && qz >= P.d_hi + mz) ? 2u : 0u) |
+                 (lu + (u3hi + 0.5f + mu) * qz <= 0.f ? 4u : 0u) | (lu + (u3lo - P.u_max - mu) * qz >= 0.f ? 8u : 0u) |
+                 (lv + (v3hi + 0.5f + mv) * qz <= 0.f ? 16u : 0u) | (lv + (v3lo - P.v_max - mv) * qz >= 0.f ? 32u : 0u) |
+                 (qz >= 1.0f ? 64u : 0u);
+    f &= (unsigned) __builtin_amdgcn_update_dpp((int) f, (int) f, 0xB1, 0xf, 0xf, false);
+    f &= (unsigned) __builtin_amdgcn_update_dpp((int) f, (int) f, 0x4E, 0xf, 0xf, false);
+    const bool sides = (P.use_depth && P.d_lo >= 1.0f) || (f & 64u);
+    const bool out = plane && ((f & 3u) || (sides && (f & 60u)));
+    unsigned diff = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      diff |= (__float_as_uint(r[i].x) ^ __float_as_uint(z4[i].x)) | (__float_as_uint(r[i].y) ^ __float_as_uint(z4[i].y)) |
+              (__float_as_uint(r[i].z) ^ __float_as_uint(z4[i].z)) | (__float_as_uint(r[i].w) ^ __float_as_uint(z4[i].w));
+    // camera n's verdict sits in lanes 4 n .. 4 n + 3: bit 4 n of a ballot -> bit n of the word (scalar)
+    const uint64_t kb = __ballot(act && !out && k == 0), df = __ballot(act && diff != 0);
+    unsigned kept = 0;
+#pragma unroll
+    for (int c = 0; c < kLiftCullMaxCams; ++c) kept |= (unsigned) ((kb >> (4 * c)) & 1ull) << c;
+    if (lane == 0) word_s = kept | (df ? 0u : kLiftCullSharedBda);
   }
   __syncthreads();
   return (unsigned) __builtin_amdgcn_readfirstlane((int) word_s);
