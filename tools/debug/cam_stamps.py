@@ -15,6 +15,8 @@ model = LiftRenderStep(cfg, dev)
 batch = SyntheticBatch(cfg, 1, dev, seed=0)
 hp = model.hp
 hp.impl["ert"] = not (len(sys.argv) > 1 and sys.argv[1] == "noert")
+hp.impl["fwd_merged"] = False          # (the stamps live in the stand-alone kernel's translation unit)
+hp.impl["cam_direct"] = True
 with torch.no_grad():
     for _ in range(5):
         hp.render(*batch.vols, model.beta, render_mats=batch.render_mats)
