@@ -25,7 +25,7 @@ lib = _capi.load()
 tiles = B * cfg.num_cams * ((cfg.fH + 7) // 8) * ((cfg.fW + 7) // 8)
 ncam = (tiles + 7) // 8 * 8
 gx = ((cfg.oY * cfg.oX + 63) // 64 + 7) // 8 * 8
-nbev = gx * B * 2
+nbev = gx * B * 3                      # VAMP_MERGED_BEV_PARTS channel groups per column block
 n = min(ncam + nbev, 8192)
 buf = (C.c_longlong * (8192 * 2))()
 lib.vamp_debug_merged_stamps.argtypes = [C.c_void_p, C.c_size_t]
