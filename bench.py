@@ -518,29 +518,40 @@ class OverlappedBetaSync:
             self.work = None
 
 
-def replay_rate(model, batch, train_step, steps, world, dev, vdist):
+def replay_rate(model, batch, train_step, steps, world, dev, vdist, sync_wrapper=None):
     """`steps` steps of `batch` under the headline's protocol -- the step replayed from a HIP graph (all ranks,
     or none), overlapped beta all-reduce, barrier + synchronize on both sides, max over ranks -- for a
-    secondary batch size.  Returns (seconds, launch mode)."""
+    secondary batch size.  `sync_wrapper`: the GradSync around `model` on a multi-rank run -- its hook must stay
+    silent while the step is captured (the capture must not hold the collective: found with two ranks in round 6,
+    "capturing stream has unjoined work").  Returns (seconds, launch mode)."""
     graph = None
     if os.environ.get("VAMP_BENCH_GRAPH", "1") == "1":
+        hook = sync_wrapper is not None and hasattr(sync_wrapper, "enabled")
         try:
+            if hook:
+                sync_wrapper.enabled = False
             graph = capture_step(model, batch, train_step)
         except Exception as e:                          # noqa: BLE001
             print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); timing eager steps", file=sys.stderr)
+            model.hp._side = None                       # (a stream a failed capture forked stays in capture mode: a fresh one)
+        finally:
+            if hook:
+                sync_wrapper.enabled = True
     if world > 1:
         ok = torch.tensor([1.0 if graph is not None else 0.0], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if float(ok.item()) == 0.0:
             graph = None
-    sync = OverlappedBetaSync(model, world)
+    # (eager fallback: the wrapper's own hook + join do the all-reduce; replays use the overlapped one)
+    eager_model = sync_wrapper if sync_wrapper is not None else model
+    sync = OverlappedBetaSync(model, world if graph is not None or sync_wrapper is None else 1)
 
     def step():
         if graph is not None:
             graph.replay()
         else:
             model.zero_grad(set_to_none=True)
-            train_step(model, batch)
+            train_step(eager_model, batch)
         sync.after_replay()
 
     for _ in range(3):
@@ -766,7 +777,8 @@ def main():
     bs8 = None
     if not a.no_extra and a.batch != 8:
         batch8 = SyntheticBatch(cfg, 8, dev, seed=vdist.shard_seed(1, rank), dtype=dtype)
-        el8, mode8 = replay_rate(model, batch8, train_step, a.steps, world, dev, vdist)
+        el8, mode8 = replay_rate(model, batch8, train_step, a.steps, world, dev, vdist,
+                                 sync_wrapper=step_model if step_model is not model else None)
         bs8 = {"value": 8 * world * a.steps / el8, "unit": "samples/s", "ms_per_step": el8 / a.steps * 1e3,
                "per_gpu_batch": 8, "global_batch": 8 * world, "n_gpus": world, "steps": a.steps, "launch": mode8,
                "scaling": "weak"}
