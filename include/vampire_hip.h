@@ -385,12 +385,15 @@ int vamp_render_camera_prepare_ex(const VampRenderDesc* d, const float* mats, co
    `workspace`; without it the backward builds the table itself; NO_ERT = every sample */
 #define VAMP_CAMBWD_TERM_VALID 32
 #define VAMP_CAMBWD_NO_ERT 64
-/* Parts of the call, for a caller with two streams (none set = all three, in this order):
+/* Parts of the call, for a caller with two streams (none set = all three: ray, heavy, gather):
  *   PART_RAY     the per-ray pass (and the channel-last copy / termination table / cell lists and
  *                heavy list where the VALID flags do not promise them), d loss / d beta
+ *   PART_HEAVY   the kernel that sums the heavy cells (more than 32 records) once per cell into per-corner
+ *                partial rows in the workspace; it does not touch the gradient buffers.  (Rounds 1 - 5: a
+ *                drain of heavy VOXELS that could run beside the gather; since round 6 the gather reads
+ *                this part's output, so a caller that splits the parts issues it before PART_GATHER on
+ *                the same stream, or behind an event of its own.)
  *   PART_GATHER  the per-voxel gather (waits for wait_event first)
- *   PART_HEAVY   the kernel that drains the heavy-voxel list; it owns other voxels than the gather,
- *                so the two may run side by side once the ray pass is done
  * Give every part the same VALID / ACCUMULATE flags. */
 /* (1024: VAMP_CAMBWD_SLOTS_PENDING, the second phase of VAMP_CAMPREP_RANK_ONLY: removed with it) */
 #define VAMP_CAMBWD_PART_RAY 128

@@ -81,6 +81,45 @@ __device__ __forceinline__ CellRanges cell_ranges(int Y, int X, const int* __res
   return cr;
 }
 
+// The same four ranges WITHOUT the records of "heavy" cells (more than `thresh` records): those cells are summed
+// once per cell by a kernel of their own (render_bwd_cell.hip: cam_cell_splat_kernel) and reach the voxel as eight
+// per-corner partial sums.  W = 8 lanes per voxel; lane l is also the voxel's cell l = (dz, dy, dx) = (l >> 2,
+// (l >> 1) & 1, l & 1), and leaves with that cell's first record and count.
+struct CellRangesLight {
+  CellRanges cr;      // light cells only
+  int all;            // records of all eight cells
+  int own_start, own_n;
+};
+template <int W>
+__device__ __forceinline__ CellRangesLight cell_ranges_light(int Y, int X, const int* __restrict__ off,
+                                                             const int* __restrict__ boff, long ncell_b, int b,
+                                                             int ix, int iy, int iz, int l, int thresh) {
+  static_assert(W == 8, "one lane per cell of the voxel");
+  const int r = (l >> 1) & 3, j = l & 1;
+  const long c0 = (long) b * ncell_b + ((long) (iz + (r >> 1)) * (Y + 1) + (iy + (r & 1))) * (X + 1) + ix;
+  const long c = c0 + 2 * j;
+  const int sv = off[c] + boff[c / kScanTile];                   // start(c0) for j = 0, start(c0 + 2) for j = 1
+  const int mid = off[c0 + 1] + boff[(c0 + 1) / kScanTile];      // start(c0 + 1)
+  CellRangesLight o;
+  o.own_start = j ? mid : sv;
+  o.own_n = j ? sv - mid : mid - sv;
+  const int hv = o.own_n > thresh;
+  int run = 0, all = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int s0 = __shfl(sv, 2 * q, W), s2 = __shfl(sv, 2 * q + 1, W), s1 = __shfl(mid, 2 * q, W);
+    const int ha = __shfl(hv, 2 * q, W), hb = __shfl(hv, 2 * q + 1, W);
+    const int beg = ha ? s1 : s0, end = hb ? s1 : s2;
+    o.cr.beg[q] = beg;
+    o.cr.pre[q] = run;
+    run += end - beg;
+    all += s2 - s0;
+  }
+  o.cr.tot = run;
+  o.all = all;
+  return o;
+}
+
 // record position of the k-th entry of the concatenated ranges (k clamped by the caller)
 __device__ __forceinline__ long cell_pos(const CellRanges& cr, int k) {
   const int q = (k >= cr.pre[1]) + (k >= cr.pre[2]) + (k >= cr.pre[3]);

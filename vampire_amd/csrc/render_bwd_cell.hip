@@ -9,12 +9,13 @@
 //   the per-ray pass (render_bwd_ray.hip) writes each sample's record {fx, fy, fz, - | w,
 //           dL/ds0, ray, -} straight to its slot: records of a cell, and of x-neighbouring cells, are
 //           contiguous
+//   splat   cells with more than kCellHeavy records (the cells next to a camera hold hundreds) are summed ONCE,
+//           into eight per-corner partial rows (cam_cell_splat_kernel)
 //   gather  GL lanes per voxel: the samples whose trilinear support contains voxel (x, y, z)
 //           are exactly those of the 2x2x2 cells (x..x+1, y..y+1, z..z+1), i.e. four contiguous
-//           record ranges; the lanes stream them, accumulate weight * dL/ds[c] in registers
-//           and store every output element once.  Voxels with more than kHeavy records go to
-//           a queue that a second kernel drains with one workgroup per voxel (the voxels next
-//           to a camera collect thousands of samples).
+//           record ranges; the lanes stream the records of the light cells among them, accumulate
+//           weight * dL/ds[c] in registers, add the heavy cells' partial rows and store every output
+//           element once.
 //
 // No search, no failed candidates: the work is the 8 * (inside samples) real contributions.
 // The order of a cell's records follows the order in which the count atomics were served, so
@@ -28,10 +29,10 @@
 
 namespace vamp {
 
-#ifndef VAMP_HEAVY
-#define VAMP_HEAVY 256
+#ifndef VAMP_CELL_HEAVY
+#define VAMP_CELL_HEAVY 32
 #endif
-constexpr int kHeavy = VAMP_HEAVY;       // records per voxel beyond which the whole-workgroup kernel runs
+constexpr int kCellHeavy = VAMP_CELL_HEAVY;   // records per cell beyond which the cell is summed once per corner (cam_cell_splat_kernel)
 constexpr int kGatherLanes = 8;          // lanes per voxel of the gather
 constexpr int kRunVox = 256 / kGatherLanes;   // voxels (an x-run) per gather workgroup
 
@@ -136,14 +137,97 @@ __device__ __forceinline__ void cell_accumulate(const CellRanges& cr, int k0, in
   }
 }
 
+// ---------------------------------------------------------------------------
+// Heavy cells, summed ONCE per cell.  A record reaches the eight voxels at the corners of its cell with eight
+// trilinear weights of the same three fractions; the per-voxel gather would stream the cell's records eight times
+// (once from each corner voxel) -- and next to a camera a cell holds hundreds of records (cfg-B with early ray
+// termination: 0.34 M kept samples in 3 710 cells, 94 % of them in the 2 000 cells with more than 32 records;
+// tools/debug/cell_stats.py).  One workgroup per listed cell: the four waves split the channels (CP / 4 each), a lane
+// takes every 64th record and keeps 8 corners x CP / 4 channel sums; the wave reduces them and writes the cell's
+// 8 x CP partial sums to slot start(cell) / kCellHeavy of the partial table (cells with more than kCellHeavy
+// records cannot share a slot).  The gather adds the up to eight partial rows of a voxel in a fixed order: no float
+// atomics, and the order of the sums inside a cell is the record order (the rank atomics'), as in the gather.
+// ---------------------------------------------------------------------------
 template <int CP4>
-__device__ __forceinline__ void cam_heavy_drain(const RenderParams& P, const int* __restrict__ off,
-                                                const int* __restrict__ boff, const float4* __restrict__ R,
-                                                const float* __restrict__ Gcl, float* __restrict__ gdens,
-                                                float* __restrict__ gsem, float* __restrict__ grgb,
-                                                const int* __restrict__ heavy, const int* __restrict__ nheavy,
-                                                long ncell_b, int accumulate, int first, int stride,
-                                                float (&part)[4][CP4 * 4]);
+__global__ void __launch_bounds__(256)
+cam_cell_splat_kernel(const int* __restrict__ off, const int* __restrict__ boff, const float4* __restrict__ R,
+                      const float* __restrict__ Gcl, const int* __restrict__ hcells,
+                      const int* __restrict__ nhcells, float* __restrict__ part) {
+  constexpr int CP = CP4 * 4, CW = CP4, NA = 8 * CW;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n = *nhcells;
+  for (int item = blockIdx.x; item < n; item += gridDim.x) {
+    const int c = hcells[item];
+    const int s0 = off[c] + boff[c / kScanTile], s1 = off[c + 1] + boff[(c + 1) / kScanTile];
+    float acc[NA];
+#pragma unroll
+    for (int e = 0; e < NA; ++e) acc[e] = 0.f;
+    constexpr int U = 2;
+    for (int k0 = s0 + lane; k0 < s1; k0 += U * 64) {
+      float4 a[U], g[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long pos = min(k0 + u * 64, s1 - 1);
+        a[u] = R[2 * pos];
+        g[u] = R[2 * pos + 1];
+      }
+      float gv[U][CW];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float* row = Gcl + (long) __float_as_uint(g[u].z) * CP + wv * CW;
+        if constexpr (CW % 4 == 0) {
+#pragma unroll
+          for (int q = 0; q < CW / 4; ++q) {
+            const float4 f = reinterpret_cast<const float4*>(row)[q];
+            gv[u][q * 4] = f.x; gv[u][q * 4 + 1] = f.y; gv[u][q * 4 + 2] = f.z; gv[u][q * 4 + 3] = f.w;
+          }
+        } else if constexpr (CW % 2 == 0) {
+#pragma unroll
+          for (int q = 0; q < CW / 2; ++q) {
+            const float2 f = reinterpret_cast<const float2*>(row)[q];
+            gv[u][q * 2] = f.x; gv[u][q * 2 + 1] = f.y;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < CW; ++q) gv[u][q] = row[q];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool in = k0 + u * 64 < s1;
+        // record = {fx, fy, fz, - | w, dL/ds0, ray, -}; the weights as cell_tap_weight forms them
+        const float flx = floorf(a[u].x), fly = floorf(a[u].y), flz = floorf(a[u].z);
+        float wx[2] = {(flx + 1.0f) - a[u].x, a[u].x - flx};
+        const float wy[2] = {(fly + 1.0f) - a[u].y, a[u].y - fly};
+        const float wz[2] = {(flz + 1.0f) - a[u].z, a[u].z - flz};
+        if (!in) wx[0] = wx[1] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float wt = wx[k & 1] * wy[(k >> 1) & 1] * wz[k >> 2];
+          const float Wv = wt * g[u].x;
+#pragma unroll
+          for (int q = 0; q < CW; ++q) {
+            // channel 0 of the row (wave 0, q == 0) is the density: weight * dL/ds0
+            if (q == 0) acc[k * CW] = wv == 0 ? __builtin_fmaf(wt, g[u].y, acc[k * CW]) : __builtin_fmaf(Wv, gv[u][0], acc[k * CW]);
+            else acc[k * CW + q] = __builtin_fmaf(Wv, gv[u][q], acc[k * CW + q]);
+          }
+        }
+      }
+    }
+    int cbase = 0;
+    reduce_halving<NA, 32, 64, NA>(acc, lane, cbase);
+    constexpr int NL = reduce_left<NA, 32>();
+    constexpr int DUP = reduce_dups<NA, 32>();
+    if ((lane & DUP) == 0) {
+      float* o = part + (long) (s0 / kCellHeavy) * 8 * CP + wv * CW;
+#pragma unroll
+      for (int e = 0; e < NL; ++e) {
+        const int idx = cbase + e;
+        o[(idx / CW) * CP + idx % CW] = acc[e];
+      }
+    }
+  }
+}
 
 // CGL lanes per voxel, 256 / CGL voxels (an x-run) per workgroup
 template <int CP4, int CGL>
@@ -151,30 +235,20 @@ __global__ void __launch_bounds__(256, 5)
 cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const int* __restrict__ boff,
                            const float4* __restrict__ R, const float* __restrict__ Gcl,
                            float* __restrict__ gdens, float* __restrict__ gsem,
-                           float* __restrict__ grgb, long ncell_b, int runs_x, int heavy_thresh,
+                           float* __restrict__ grgb, long ncell_b, int runs_x,
                            int accumulate, BetaTail btail, const int* __restrict__ runs,
-                           const int* __restrict__ heavy, const int* __restrict__ nheavy, unsigned heavy_blocks) {
+                           const float* __restrict__ part) {
   constexpr int CP = CP4 * 4;
   constexpr int CVPB = 256 / CGL;
   beta_tail(btail);                     // the ray pass's d beta partials (a launch of its own before round 3)
-  // The first `heavy_blocks` workgroups drain the heavy-voxel list (one voxel per workgroup and turn): the
-  // two jobs own disjoint voxels, so they share a launch -- the long-running voxels start first, the x-run
-  // workgroups fill in behind them, and no second stream or launch is needed to overlap the two.
-  if (blockIdx.x < heavy_blocks) {
-    __shared__ float part[4][CP];
-    cam_heavy_drain<CP4>(P, off, boff, R, Gcl, gdens, gsem, grgb, heavy, nheavy, ncell_b, accumulate,
-                         (int) blockIdx.x, (int) heavy_blocks, part);
-    return;
-  }
-  const unsigned bid = blockIdx.x - heavy_blocks;
+  const unsigned bid = blockIdx.x;
   __shared__ float outs[CP][CVPB + 1];
-  __shared__ int skip[CVPB];            // the voxel is on the heavy list: its outputs are not ours
   const int tid = threadIdx.x;
   const int g = tid / CGL, l = tid % CGL;
   // (giving each XCD a contiguous slab of x-runs instead of the round-robin deal measured 12 %
   // slower: the slabs next to the cameras carry most of the records)
   // accumulate mode: only the flagged x-runs have anything to add (cam_heavy_list_kernel): one
-  // scalar load decides, instead of 512 offset loads and a barrier
+  // scalar load decides, instead of 768 offset loads and a barrier
   if (runs && runs[bid] == 0) return;
   const unsigned lin = bid;
   const int bx = lin % (unsigned) runs_x;
@@ -185,11 +259,12 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
   const bool vox_ok = ix < P.X;
   const int nch = 1 + P.K + 3;
   const int ixc = min(ix, P.X - 1);
-  const CellRanges cr = cell_ranges<CGL>(P.Y, P.X, off, boff, ncell_b, b, ixc, iy, iz, l);
-  // An x-run none of whose voxels has a record for this kernel (nothing sampled there: behind a
-  // terminated ray, outside every frustum -- or all on the heavy list) has nothing to add: when the
-  // buffers already hold the BEV branch's gradient the workgroup is done before it touches them.
-  if (accumulate && !__syncthreads_or(vox_ok && cr.tot > 0 && cr.tot <= heavy_thresh)) return;
+  const CellRangesLight cl = cell_ranges_light<CGL>(P.Y, P.X, off, boff, ncell_b, b, ixc, iy, iz, l, kCellHeavy);
+  const CellRanges& cr = cl.cr;
+  // An x-run none of whose voxels has a record (nothing sampled there: behind a terminated ray, outside every
+  // frustum) has nothing to add: when the buffers already hold the BEV branch's gradient the workgroup is done
+  // before it touches them.
+  if (accumulate && !__syncthreads_or(vox_ok && cl.all > 0)) return;
 
   // output elements this thread stores at the end; with accumulate their current values (the
   // BEV branch's gradient) are fetched now, so that the load overlaps the record streaming
@@ -208,15 +283,23 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
     optr[i] = (e < nch * CVPB && bx * CVPB + gx < P.X) ? o + vox0 + gx : nullptr;
     prevv[i] = (accumulate && optr[i]) ? *optr[i] : 0.f;
   }
-  if (l == 0) skip[g] = vox_ok && cr.tot > heavy_thresh;
 
   float acc[CP];
 #pragma unroll
   for (int c = 0; c < CP; ++c) acc[c] = 0.f;
 
-  // (voxels with more records than the threshold are on the heavy list, built with the cell lists:
-  // cam_heavy_list_kernel; the whole-workgroup kernel owns their outputs and may run beside this one)
-  if (vox_ok && cr.tot <= heavy_thresh) {
+  if (vox_ok) {
+    // lane l's own cell (dz, dy, dx) = (l >> 2, (l >> 1) & 1, l & 1) is heavy: its records were summed per corner
+    // by cam_cell_splat_kernel, and this voxel is the cell's corner (1 - dx, 1 - dy, 1 - dz)
+    if (cl.own_n > kCellHeavy) {
+      const int corner = l ^ 7;
+      const float4* p4 = reinterpret_cast<const float4*>(part + ((long) (cl.own_start / kCellHeavy) * 8 + corner) * CP);
+#pragma unroll
+      for (int c4 = 0; c4 < CP4; ++c4) {
+        const float4 f = p4[c4];
+        acc[c4 * 4] = f.x; acc[c4 * 4 + 1] = f.y; acc[c4 * 4 + 2] = f.z; acc[c4 * 4 + 3] = f.w;
+      }
+    }
     const float fix = (float) ix, fiy = (float) iy, fiz = (float) iz;
     constexpr int U = 1;              // U = 2 costs a wave of occupancy and measured slower
     for (int k = l; k < cr.tot; k += U * CGL)
@@ -237,71 +320,8 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
 #pragma unroll
   for (int i = 0; i < PE; ++i) {
     const int e = tid + i * 256;
-    if (optr[i] && !skip[e % CVPB]) *optr[i] = prevv[i] + outs[e / CVPB][e % CVPB];
+    if (optr[i]) *optr[i] = prevv[i] + outs[e / CVPB][e % CVPB];
   }
-}
-
-// One workgroup per queued voxel: 256 lanes stream its records, fixed-order reduction.  `first` / `stride`:
-// the workgroup's first item and the number of workgroups draining the list.
-template <int CP4>
-__device__ __forceinline__ void cam_heavy_drain(const RenderParams& P, const int* __restrict__ off,
-                                                const int* __restrict__ boff, const float4* __restrict__ R,
-                                                const float* __restrict__ Gcl, float* __restrict__ gdens,
-                                                float* __restrict__ gsem, float* __restrict__ grgb,
-                                                const int* __restrict__ heavy, const int* __restrict__ nheavy,
-                                                long ncell_b, int accumulate, int first, int stride,
-                                                float (&part)[4][CP4 * 4]) {
-  constexpr int CP = CP4 * 4;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int nch = 1 + P.K + 3;
-  const long V = (long) P.Z * P.Y * P.X;
-  const int n = *nheavy;
-  for (int item = first; item < n; item += stride) {
-    int vid = heavy[item];
-    const int ix = vid % P.X; vid /= P.X;
-    const int iy = vid % P.Y; vid /= P.Y;
-    const int iz = vid % P.Z, b = vid / P.Z;
-    const CellRanges cr = cell_ranges<64>(P.Y, P.X, off, boff, ncell_b, b, ix, iy, iz, lane);
-    const long vox = ((long) iz * P.Y + iy) * P.X + ix;
-    float* optr = nullptr;
-    if (tid < nch)
-      optr = (tid == 0) ? gdens + (long) b * V + vox
-             : (tid <= P.K) ? gsem + ((long) b * P.K + (tid - 1)) * V + vox
-                            : grgb + ((long) b * 3 + (tid - 1 - P.K)) * V + vox;
-    const float prev = (accumulate && optr) ? *optr : 0.f;
-    float acc[CP];
-#pragma unroll
-    for (int c = 0; c < CP; ++c) acc[c] = 0.f;
-    const float fix = (float) ix, fiy = (float) iy, fiz = (float) iz;
-    constexpr int U = 1;
-    for (int k = tid; k < cr.tot; k += U * 256)
-      cell_accumulate<CP4, U>(cr, k, 256, R, Gcl, fix, fiy, fiz, acc);
-    {
-      int cbase = 0;
-      reduce_halving<CP, 32, 64, CP>(acc, lane, cbase);
-      constexpr int NL = reduce_left<CP, 32>();
-      constexpr int DUP = reduce_dups<CP, 32>();
-      if ((lane & DUP) == 0) {
-#pragma unroll
-        for (int c = 0; c < NL; ++c) part[wv][cbase + c] = acc[c];
-      }
-    }
-    __syncthreads();
-    if (optr) *optr = prev + ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
-    __syncthreads();
-  }
-}
-
-template <int CP4>
-__global__ void __launch_bounds__(256, 5)
-cam_bwd_cell_heavy_kernel(RenderParams P, const int* __restrict__ off, const int* __restrict__ boff,
-                          const float4* __restrict__ R, const float* __restrict__ Gcl,
-                          float* __restrict__ gdens, float* __restrict__ gsem,
-                          float* __restrict__ grgb, const int* __restrict__ heavy,
-                          const int* __restrict__ nheavy, long ncell_b, int accumulate) {
-  __shared__ float part[4][CP4 * 4];
-  cam_heavy_drain<CP4>(P, off, boff, R, Gcl, gdens, gsem, grgb, heavy, nheavy, ncell_b, accumulate,
-                       (int) blockIdx.x, (int) gridDim.x, part);
 }
 
 // ---------------------------------------------------------------------------
@@ -312,8 +332,9 @@ struct CellWs {
   int* off;        // [ncell] tile-local exclusive offsets
   int* bsum;       // [ntile] tile totals
   int* boff;       // [ntile] exclusive scan of the tile totals
-  int* aux;        // [ntile] scratch of the level-2 scan, then [ntile] = total, [ntile+1] = heavy count
-  int* heavy;      // [voxels] queue
+  int* aux;        // [ntile] scratch of the level-2 scan, then [ntile] = total, [ntile+1] = heavy cells listed
+  int* hcells;     // [ncell] list of the heavy cells
+  float* part;     // [samples / kCellHeavy + 2][8][CP] per-corner partial sums of the heavy cells
   int* runs;       // [x-runs] 1 = the gather's workgroup has something to add (accumulate mode)
   int* rank;       // [tiles][S][64] rank of the sample inside its cell (written for kept inside samples only)
   int* slot;       // [tiles][S][64] slot in R (-1 = masked): the per-ray pass's note between its two loops
@@ -329,7 +350,6 @@ static CellWs cell_ws(const VampRenderDesc* d, void* scratch) {
   const size_t samples = (size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW;
   // per-sample tables are indexed by 8 x 8 ray tile (ragged tiles padded)
   const size_t tsamples = (size_t) d->B * d->N * ((d->fH + 7) / 8) * ((d->fW + 7) / 8) * 64 * (d->D - 1);
-  const size_t voxels = (size_t) d->B * d->Z * d->Y * d->X;
   char* p = static_cast<char*>(scratch);
   CellWs w;
   w.cnt = reinterpret_cast<int*>(p); p += align_up((size_t) (ncell + kScanPad) * sizeof(int), 256);   // + the scan's ticket word
@@ -337,7 +357,8 @@ static CellWs cell_ws(const VampRenderDesc* d, void* scratch) {
   w.bsum = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
   w.boff = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
   w.aux = reinterpret_cast<int*>(p); p += align_up((size_t) (ntile + 4) * sizeof(int), 256);
-  w.heavy = reinterpret_cast<int*>(p); p += align_up(voxels * sizeof(int), 256);
+  w.hcells = reinterpret_cast<int*>(p); p += align_up((size_t) ncell * sizeof(int), 256);
+  w.part = reinterpret_cast<float*>(p); p += align_up((samples / kCellHeavy + 2) * 8 * (size_t) to_params(d).CP * sizeof(float), 256);
   w.runs = reinterpret_cast<int*>(p); p += align_up((size_t) d->B * d->Z * d->Y * ((d->X + kRunVox - 1) / kRunVox) * sizeof(int), 256);
   w.rank = reinterpret_cast<int*>(p); p += align_up(tsamples * sizeof(int), 256);
   w.slot = reinterpret_cast<int*>(p); p += align_up(tsamples * sizeof(int), 256);
@@ -409,18 +430,17 @@ int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, con
   return launch_cam_heavy_list(d, P, w, s);
 }
 
-// Heavy list: the voxels whose eight cells hold more than kHeavy records, known as soon as the
-// cells are scanned -- so the list belongs to the prepare pass, and the kernel that drains it can
-// run beside the gather instead of behind it.  The same walk flags the gather's x-runs that hold at
-// least one voxel with records of its own: when the gather adds on top of the BEV branch's gradient
-// (the default) the workgroups of the other runs leave at once -- with early ray termination most of
-// the volume lies behind terminated rays.  (A compacted list of the runs instead of flags: 22 400
-// appends to one counter took 125 us when nothing terminates.)  Thread = voxel in the gather's own
-// (run, voxel) order.
+// Heavy-cell list: the cells with more than kCellHeavy records, known as soon as the cells are scanned -- so the list
+// belongs to the prepare pass.  One atomic per wave that has a heavy cell (the lanes take base + their position
+// among the wave's heavy lanes).  The same kernel flags the gather's x-runs that hold at least one voxel with
+// records: when the gather adds on top of the BEV branch's gradient (the default) the workgroups of the other
+// runs leave at once -- with early ray termination most of the volume lies behind terminated rays.  (A compacted
+// list of the runs instead of flags: 22 400 appends to one counter took 125 us when nothing terminates.)
+// Thread = voxel in the gather's own (run, voxel) order, then = cell for the list.
 __global__ void __launch_bounds__(256)
 cam_heavy_list_kernel(RenderParams P, const int* __restrict__ off, const int* __restrict__ boff,
-                      int* __restrict__ heavy, int* __restrict__ nheavy, int* __restrict__ runs,
-                      long ncell_b, long total_runs, int runs_x, int thresh,
+                      int* __restrict__ hcells, int* __restrict__ nhcells, int* __restrict__ runs,
+                      long ncell_b, long total_runs, int runs_x, long ncell,
                       const int* __restrict__ tile_se, int* __restrict__ tile_order, int ntiles) {
   // A duty of the first workgroup: the order in which the per-ray pass takes the ray tiles -- deepest
   // first (counting sort by the bit length of the tile's longest ray).  With early ray termination a few
@@ -439,6 +459,20 @@ cam_heavy_list_kernel(RenderParams P, const int* __restrict__ off, const int* __
     __syncthreads();
     for (int t = threadIdx.x; t < ntiles; t += 256) tile_order[atomicAdd(cls + (32 - __clz(max(tile_se[t], 0))), 1)] = t;
   }
+  const int lane = threadIdx.x & 63;
+  // the heavy cells (the last cell with a successor is ncell - 2: cell_count_padded)
+  for (long c0 = ((long) blockIdx.x * 256 + threadIdx.x) - lane; c0 < ncell - 1; c0 += (long) gridDim.x * 256) {
+    const long c = min(c0 + lane, ncell - 2);
+    const int n = (off[c + 1] + boff[(c + 1) / kScanTile]) - (off[c] + boff[c / kScanTile]);
+    const bool hv = c0 + lane < ncell - 1 && n > kCellHeavy;
+    const unsigned long long m = __ballot(hv);
+    if (m == 0ull) continue;
+    const int lead = __ffsll((long long) m) - 1;
+    int base = 0;
+    if (lane == lead) base = atomicAdd(nhcells, __popcll(m));
+    base = __shfl(base, lead, 64);
+    if (hv) hcells[base + __popcll(m & ((1ull << lane) - 1ull))] = (int) c;
+  }
   const long run = (long) blockIdx.x * (256 / kRunVox) + threadIdx.x / kRunVox;
   const bool run_ok = run < total_runs;
   const long rc = run_ok ? run : total_runs - 1;
@@ -456,10 +490,8 @@ cam_heavy_list_kernel(RenderParams P, const int* __restrict__ off, const int* __
       tot += (off[c + 2] + boff[(c + 2) / kScanTile]) - (off[c] + boff[c / kScanTile]);
     }
   }
-  if (tot > thresh) heavy[atomicAdd(nheavy, 1)] = (int) ((((long) b * P.Z + iz) * P.Y + iy) * P.X + ix);
   static_assert(kRunVox == 32, "a run is half a wave");
-  const unsigned long long any = __ballot(tot > 0 && tot <= thresh);
-  const int lane = threadIdx.x & 63;
+  const unsigned long long any = __ballot(tot > 0);
   if ((lane & 31) == 0 && run_ok) runs[run] = ((any >> lane) & 0xffffffffull) != 0ull ? 1 : 0;
 }
 
@@ -469,57 +501,48 @@ static int launch_cam_heavy_list(const VampRenderDesc* d, const RenderParams& P,
   const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
   const int runs_x = (d->X + kRunVox - 1) / kRunVox;
   const long total_runs = (long) runs_x * d->Y * d->Z * d->B;
-  int* nheavy = w.aux + ntile + 1;              // zeroed by the scan that just ran (runtime.hip)
+  int* nhcells = w.aux + ntile + 1;              // zeroed by the scan that just ran (runtime.hip)
   VAMP_TIMED(kProfAux, s, (cam_heavy_list_kernel<<<(unsigned) ((total_runs * kRunVox + 255) / 256), 256, 0, s>>>(
-      P, w.off, w.boff, w.heavy, nheavy, w.runs, ncell_b, total_runs, runs_x, kHeavy, w.tile_se, w.tile_order,
+      P, w.off, w.boff, w.hcells, nhcells, w.runs, ncell_b, total_runs, runs_x, ncell, w.tile_se, w.tile_order,
       (int) ((long) d->B * d->N * ((d->fH + 7) / 8) * ((d->fW + 7) / 8)))));
   return check_launch("cam_heavy_list_kernel");
 }
 
-#ifndef VAMP_ABL_NOHEAVY
-#define VAMP_ABL_NOHEAVY 0        // (measurement build: the heavy-voxel drain is not launched -- wrong gradients near the cameras)
-#endif
-// per-voxel gather of the records the per-ray pass has written in cell order
+// the heavy cells' per-corner sums, then the per-voxel gather of the records the per-ray pass has written in cell order
 int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const float* Gcl,
                         float* gdens, float* gsem, float* grgb, void* scratch, int accumulate,
                         hipEvent_t wait_event, int parts, BetaTail btail, hipStream_t s) {
   const CellWs w = cell_ws(d, scratch);
   const long ncell = cell_count_padded(d->B, d->Z, d->Y, d->X);
   const long ntile = ncell / kScanTile;
-  const size_t voxels = (size_t) d->B * d->Z * d->Y * d->X;
   const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
-  const int* nheavy = w.aux + ntile + 1;
+  const int* nhcells = w.aux + ntile + 1;
   const int* runs = accumulate ? w.runs : nullptr;   // (overwrite mode: every run is stored)
 
-  // measured at cfg-B (gather + heavy, us): 8 lanes 145 + 56, 16 lanes 173 + 56, 32 lanes 249 + 56;
-  // threshold 128 / 256 / 512 with 8 lanes: 131 + 107, 145 + 56, 159 + 40 (round 1); after early ray
-  // termination 68 + 37, 68 + 34, 91 + 33
+  // measured at cfg-B (gather + heavy-VOXEL drain, rounds 1 - 5, us): 8 lanes 145 + 56, 16 lanes 173 + 56, 32 lanes
+  // 249 + 56; after early ray termination 68 + 34
   constexpr int gl = kGatherLanes;
-  const int heavy_thresh = kHeavy;
   const int vpb = 256 / gl;
-  // the gradient buffers are first touched here: whoever else accumulates into them (the BEV
-  // branch on another stream) must be done
-  if (wait_event && hipStreamWaitEvent(s, wait_event, 0) != hipSuccess)
-    return fail(VAMP_EHIP, "%s: hipStreamWaitEvent failed", __func__);
   const int runs_x = (d->X + vpb - 1) / vpb;
   const long nblk = (long) runs_x * d->Y * d->Z * d->B;
   VAMP_REQUIRE(nblk < 0x7fffffffL, "too many x-runs");
   const unsigned grid = (unsigned) nblk;
-  const unsigned hgrid = (unsigned) std::min<size_t>(voxels, 8192);
-  // gather and heavy drain in ONE launch when the caller asks for both in one call (the default)
-  const bool merged = (parts & kCamPartGather) && (parts & kCamPartHeavy);
-  const unsigned hgrid_m = (unsigned) std::min<size_t>(voxels, 2048);
-  // the two kernels own disjoint voxels (the heavy list was built with the cell lists), so the
-  // caller may run them on two streams: parts selects
+  const unsigned sgrid = (unsigned) std::min<long>(ncell, 2048);
+  // PART_HEAVY: the per-cell sums (they touch the partial table only: no need to wait for whoever else writes the
+  // gradient buffers); PART_GATHER reads them, so a caller that splits the parts issues HEAVY first, same stream
 #define VAMP_CELL(CP4)                                                                              \
   do {                                                                                              \
-    if (parts & kCamPartGather)                                                                     \
-      VAMP_TIMED(kProfCamBwdBrick, s, (cam_bwd_cell_gather_kernel<CP4, gl><<<grid + (merged ? hgrid_m : 0u), 256, 0, s>>>( \
-          P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, ncell_b, runs_x, heavy_thresh, accumulate, btail, runs, \
-          w.heavy, nheavy, merged ? hgrid_m : 0u)));                                                \
-    if ((parts & kCamPartHeavy) && !merged && !VAMP_ABL_NOHEAVY)                                    \
-      VAMP_TIMED(kProfCamBwdOwn, s, (cam_bwd_cell_heavy_kernel<CP4><<<hgrid, 256, 0, s>>>(          \
-          P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, w.heavy, nheavy, ncell_b, accumulate)));   \
+    if (parts & kCamPartHeavy)                                                                      \
+      VAMP_TIMED(kProfCamBwdOwn, s, (cam_cell_splat_kernel<CP4><<<sgrid, 256, 0, s>>>(              \
+          w.off, w.boff, w.R, Gcl, w.hcells, nhcells, w.part)));                                    \
+    if (parts & kCamPartGather) {                                                                   \
+      /* the gradient buffers are first touched here: whoever else accumulates into them (the BEV   \
+         branch on another stream) must be done */                                                  \
+      if (wait_event && hipStreamWaitEvent(s, wait_event, 0) != hipSuccess)                         \
+        return fail(VAMP_EHIP, "%s: hipStreamWaitEvent failed", __func__);                          \
+      VAMP_TIMED(kProfCamBwdBrick, s, (cam_bwd_cell_gather_kernel<CP4, gl><<<grid, 256, 0, s>>>(    \
+          P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, ncell_b, runs_x, accumulate, btail, runs, w.part))); \
+    }                                                                                               \
   } while (0)
   if (P.CP == 12) VAMP_CELL(3); else if (P.CP == 24) VAMP_CELL(6); else VAMP_CELL(8);
 #undef VAMP_CELL

@@ -91,9 +91,9 @@ exclusive_scan_kernel(const int* __restrict__ cnt, int* __restrict__ off, int* _
     if (tid == 1023) carry = c0 + wbase + incl;
     __syncthreads();
   }
-  // total[1] is the heavy-list counter of the cell-list users (aux[ntile + 1]): the list is built
-  // right after this scan, so it is zeroed here instead of by a launch of its own
-  if (tid == 0) { total[0] = carry; total[1] = 0; }
+  // total[1], total[2] are list counters of the cell-list users (aux[ntile + 1], aux[ntile + 2]): the lists are built
+  // right after this scan, so they are zeroed here instead of by a launch of their own
+  if (tid == 0) { total[0] = carry; total[1] = 0; total[2] = 0; }
 }
 
 // The cell-list scan in ONE launch.  Level 1: every workgroup scans its kScanTile-cell tile (256
@@ -182,11 +182,12 @@ cell_scan_kernel(int* __restrict__ cnt, int* __restrict__ off, int* __restrict__
     if (tid == 255) carry = c0 + wb + inc2;
     __syncthreads();
   }
-  // total[1] is the heavy-list counter of the cell-list users (aux[ntile + 1]): the list is built
-  // right after this scan, so it is zeroed here instead of by a launch of its own
+  // total[1], total[2] are list counters of the cell-list users (aux[ntile + 1], aux[ntile + 2]): the lists are built
+  // right after this scan, so they are zeroed here instead of by a launch of their own
   if (tid == 0) {
     total[0] = carry;
     total[1] = 0;
+    total[2] = 0;
     *ticket = 0;                                      // ready for the next scan without a zero fill
   }
 }

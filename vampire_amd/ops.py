@@ -880,9 +880,8 @@ class _RenderFn(torch.autograd.Function):
             done.record(s_bev)
             bev_backward(s_bev, True, _capi.VAMP_BEVBWD_ONLY_BASE)
             hp._bev_tab_key = tab_key
-            # The camera backward in three parts: ray pass on one stream; then the gather there (after the BEV
-            # event) and, beside it on the BEV chain's stream, the kernel that drains the heavy-voxel list --
-            # the two own different voxels (the list is built with the cell lists).
+            # The camera backward in two calls on its own stream: the ray pass and the heavy cells' per-corner sums
+            # (neither touches the gradient buffers), then -- behind the BEV event -- the gather, which adds both on top.
             cam_flags = 1 | packed_valid
 
             def cam_part(part, stream, event=None):
@@ -890,11 +889,7 @@ class _RenderFn(torch.autograd.Function):
                     *cam_args, _ptr(gd), _ptr(gs), _ptr(gr), _ptr(gbeta), _ptr(ws), ws.numel(), cam_flags | part,
                     event, _stream(stream)), "vamp_render_camera_backward_acc")
 
-            cam_part(_capi.VAMP_CAMBWD_PART_RAY, s_cam)
-            ray_done = torch.cuda.Event()
-            ray_done.record(s_cam)
-            s_bev.wait_event(ray_done)
-            cam_part(_capi.VAMP_CAMBWD_PART_HEAVY, s_bev)
+            cam_part(_capi.VAMP_CAMBWD_PART_RAY | _capi.VAMP_CAMBWD_PART_HEAVY, s_cam)
             cam_part(_capi.VAMP_CAMBWD_PART_GATHER, s_cam, C.c_void_p(done.cuda_event))
             cur.wait_stream(side)
         elif geom is None and default_impl:
