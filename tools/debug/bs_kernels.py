@@ -29,7 +29,8 @@ def run(B, replicate):
     torch.cuda.synchronize(); _capi.profile_enable(False)
     return {k: ms / 5 * 1e3 / B for k, (n, ms) in _capi.profile_read().items()}
 
-r1 = run(1, False); r8 = run(8, False); r8r = run(8, True)
+quick = len(sys.argv) > 1 and sys.argv[1] == "quick"      # (quick: no replicated batch)
+r1 = run(1, False); r8 = run(8, False); r8r = {} if quick else run(8, True)
 print("%-28s %10s %10s %12s" % ("kernel (us per sample)", "batch 1", "batch 8", "8 x sample 0"))
 for k in sorted(r1, key=lambda k: -r1[k]):
     print("%-28s %10.1f %10.1f %12.1f" % (k, r1[k], r8.get(k, 0), r8r.get(k, 0)))

@@ -33,6 +33,10 @@ namespace vamp {
 #define VAMP_CELL_HEAVY 32
 #endif
 constexpr int kCellHeavy = VAMP_CELL_HEAVY;   // records per cell beyond which the cell is summed once per corner (cam_cell_splat_kernel)
+#ifndef VAMP_GATHER_GRID
+#define VAMP_GATHER_GRID 20480
+#endif
+constexpr int kGatherGrid = VAMP_GATHER_GRID;   // workgroups of the gather at most (a workgroup takes every kGatherGrid-th listed x-run)
 constexpr int kGatherLanes = 8;          // lanes per voxel of the gather
 constexpr int kRunVox = 256 / kGatherLanes;   // voxels (an x-run) per gather workgroup
 
@@ -158,6 +162,8 @@ cam_cell_splat_kernel(const int* __restrict__ off, const int* __restrict__ boff,
   const int n = *nhcells;
   for (int item = blockIdx.x; item < n; item += gridDim.x) {
     const int c = hcells[item];
+    // (sharing the cells with more than 256 records among four workgroups, each with a row set of its own, changed
+    // nothing: 24.2 against 24.2 us, step 0.3945 against 0.3936 ms)
     const int s0 = off[c] + boff[c / kScanTile], s1 = off[c + 1] + boff[(c + 1) / kScanTile];
     float acc[NA];
 #pragma unroll
@@ -231,96 +237,97 @@ cam_cell_splat_kernel(const int* __restrict__ off, const int* __restrict__ boff,
 
 // CGL lanes per voxel, 256 / CGL voxels (an x-run) per workgroup
 template <int CP4, int CGL>
-__global__ void __launch_bounds__(256, 5)
+#ifndef VAMP_GATHER_OCC
+#define VAMP_GATHER_OCC 5
+#endif
+__global__ void __launch_bounds__(256, VAMP_GATHER_OCC)
 cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const int* __restrict__ boff,
                            const float4* __restrict__ R, const float* __restrict__ Gcl,
                            float* __restrict__ gdens, float* __restrict__ gsem,
-                           float* __restrict__ grgb, long ncell_b, int runs_x,
+                           float* __restrict__ grgb, long ncell_b, int runs_x, long total_runs,
                            int accumulate, BetaTail btail, const int* __restrict__ runs,
-                           const float* __restrict__ part) {
+                           const int* __restrict__ nruns, const float* __restrict__ part) {
   constexpr int CP = CP4 * 4;
   constexpr int CVPB = 256 / CGL;
   beta_tail(btail);                     // the ray pass's d beta partials (a launch of its own before round 3)
-  const unsigned bid = blockIdx.x;
   __shared__ float outs[CP][CVPB + 1];
-  const int tid = threadIdx.x;
-  const int g = tid / CGL, l = tid % CGL;
-  // (giving each XCD a contiguous slab of x-runs instead of the round-robin deal measured 12 %
-  // slower: the slabs next to the cameras carry most of the records)
-  // accumulate mode: only the flagged x-runs have anything to add (cam_heavy_list_kernel): one
-  // scalar load decides, instead of 768 offset loads and a barrier
-  if (runs && runs[bid] == 0) return;
-  const unsigned lin = bid;
-  const int bx = lin % (unsigned) runs_x;
-  const unsigned rest = lin / (unsigned) runs_x;
-  const int ix = bx * CVPB + g, iy = rest % (unsigned) P.Y;
-  const int zb = rest / (unsigned) P.Y;
-  const int iz = zb % P.Z, b = zb / P.Z;
-  const bool vox_ok = ix < P.X;
   const int nch = 1 + P.K + 3;
-  const int ixc = min(ix, P.X - 1);
-  const CellRangesLight cl = cell_ranges_light<CGL>(P.Y, P.X, off, boff, ncell_b, b, ixc, iy, iz, l, kCellHeavy);
-  const CellRanges& cr = cl.cr;
-  // An x-run none of whose voxels has a record (nothing sampled there: behind a terminated ray, outside every
-  // frustum) has nothing to add: when the buffers already hold the BEV branch's gradient the workgroup is done
-  // before it touches them.
-  if (accumulate && !__syncthreads_or(vox_ok && cl.all > 0)) return;
-
-  // output elements this thread stores at the end; with accumulate their current values (the
-  // BEV branch's gradient) are fetched now, so that the load overlaps the record streaming
   const long V = (long) P.Z * P.Y * P.X;
-  const long vox0 = ((long) iz * P.Y + iy) * P.X + (long) bx * CVPB;
-  constexpr int PE = (CP * CVPB + 255) / 256;
-  float* optr[PE];
-  float prevv[PE];
-#pragma unroll
-  for (int i = 0; i < PE; ++i) {
-    const int e = tid + i * 256;
-    const int c = e / CVPB, gx = e % CVPB;
-    float* o = (c == 0) ? gdens + (long) b * V
-               : (c <= P.K) ? gsem + ((long) b * P.K + (c - 1)) * V
-                            : grgb + ((long) b * 3 + (c - 1 - P.K)) * V;
-    optr[i] = (e < nch * CVPB && bx * CVPB + gx < P.X) ? o + vox0 + gx : nullptr;
-    prevv[i] = (accumulate && optr[i]) ? *optr[i] : 0.f;
-  }
+  // accumulate mode: only the listed x-runs have anything to add (cam_heavy_list_kernel); the grid is fixed and a
+  // workgroup takes every gridDim.x-th entry (x-neighbouring runs, which share cells, land on different CUs; a
+  // contiguous slab of x-runs per XCD measured 12 % slower: the slabs next to the cameras carry most of the records)
+  const int nitems = runs ? *nruns : (int) total_runs;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    // (the thread's own indices are formed per item: hoisted out of the loop, what derives from them holds 20
+    // registers across it and the kernel loses a wave of occupancy or spills)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int g = tid / CGL, l = tid % CGL;
+    const unsigned lin = runs ? (unsigned) runs[item] : (unsigned) item;
+    const int bx = lin % (unsigned) runs_x;
+    const unsigned rest = lin / (unsigned) runs_x;
+    const int ix = bx * CVPB + g, iy = rest % (unsigned) P.Y;
+    const int zb = rest / (unsigned) P.Y;
+    const int iz = zb % P.Z, b = zb / P.Z;
+    const bool vox_ok = ix < P.X;
+    const int ixc = min(ix, P.X - 1);
+    const CellRangesLight cl = cell_ranges_light<CGL>(P.Y, P.X, off, boff, ncell_b, b, ixc, iy, iz, l, kCellHeavy);
+    const CellRanges& cr = cl.cr;
 
-  float acc[CP];
+    float acc[CP];
 #pragma unroll
-  for (int c = 0; c < CP; ++c) acc[c] = 0.f;
+    for (int c = 0; c < CP; ++c) acc[c] = 0.f;
 
-  if (vox_ok) {
-    // lane l's own cell (dz, dy, dx) = (l >> 2, (l >> 1) & 1, l & 1) is heavy: its records were summed per corner
-    // by cam_cell_splat_kernel, and this voxel is the cell's corner (1 - dx, 1 - dy, 1 - dz)
-    if (cl.own_n > kCellHeavy) {
-      const int corner = l ^ 7;
-      const float4* p4 = reinterpret_cast<const float4*>(part + ((long) (cl.own_start / kCellHeavy) * 8 + corner) * CP);
+    if (vox_ok) {
+      // lane l's own cell (dz, dy, dx) = (l >> 2, (l >> 1) & 1, l & 1) is heavy: its records were summed per corner
+      // by cam_cell_splat_kernel, and this voxel is the cell's corner (1 - dx, 1 - dy, 1 - dz)
+      if (cl.own_n > kCellHeavy) {
+        const int corner = l ^ 7;
+        const float4* p4 = reinterpret_cast<const float4*>(part + ((long) (cl.own_start / kCellHeavy) * 8 + corner) * CP);
 #pragma unroll
-      for (int c4 = 0; c4 < CP4; ++c4) {
-        const float4 f = p4[c4];
-        acc[c4 * 4] = f.x; acc[c4 * 4 + 1] = f.y; acc[c4 * 4 + 2] = f.z; acc[c4 * 4 + 3] = f.w;
+        for (int c4 = 0; c4 < CP4; ++c4) {
+          const float4 f = p4[c4];
+          acc[c4 * 4] = f.x; acc[c4 * 4 + 1] = f.y; acc[c4 * 4 + 2] = f.z; acc[c4 * 4 + 3] = f.w;
+        }
+      }
+      const float fix = (float) ix, fiy = (float) iy, fiz = (float) iz;
+      constexpr int U = 1;              // U = 2 costs a wave of occupancy and measured slower
+      for (int k = l; k < cr.tot; k += U * CGL)
+        cell_accumulate<CP4, U>(cr, k, CGL, R, Gcl, fix, fiy, fiz, acc);
+    }
+    // reduce over the lanes of the voxel, transpose through LDS, store x-runs
+    {
+      int cbase = 0;
+      reduce_halving<CP, CGL / 2, CGL, CP>(acc, l, cbase);
+      constexpr int NL = reduce_left<CP, CGL / 2>();
+      constexpr int DUP = reduce_dups<CP, CGL / 2>();
+      if ((l & DUP) == 0) {
+#pragma unroll
+        for (int c = 0; c < NL; ++c) outs[cbase + c][g] = acc[c];
       }
     }
-    const float fix = (float) ix, fiy = (float) iy, fiz = (float) iz;
-    constexpr int U = 1;              // U = 2 costs a wave of occupancy and measured slower
-    for (int k = l; k < cr.tot; k += U * CGL)
-      cell_accumulate<CP4, U>(cr, k, CGL, R, Gcl, fix, fiy, fiz, acc);
-  }
-  // reduce over the lanes of the voxel, transpose through LDS, store x-runs
-  {
-    int cbase = 0;
-    reduce_halving<CP, CGL / 2, CGL, CP>(acc, l, cbase);
-    constexpr int NL = reduce_left<CP, CGL / 2>();
-    constexpr int DUP = reduce_dups<CP, CGL / 2>();
-    if ((l & DUP) == 0) {
+    __syncthreads();
+    // x-runs of every channel: with accumulate on top of what the buffers hold (the BEV branch's gradient)
+    const long vox0 = ((long) iz * P.Y + iy) * P.X + (long) bx * CVPB;
+    constexpr int PE = (CP * CVPB + 255) / 256;
+    float* optr[PE];
+    float prevv[PE];
 #pragma unroll
-      for (int c = 0; c < NL; ++c) outs[cbase + c][g] = acc[c];
+    for (int i = 0; i < PE; ++i) {
+      const int e = tid + i * 256;
+      const int c = e / CVPB, gx = e % CVPB;
+      float* o = (c == 0) ? gdens + (long) b * V
+                 : (c <= P.K) ? gsem + ((long) b * P.K + (c - 1)) * V
+                              : grgb + ((long) b * 3 + (c - 1 - P.K)) * V;
+      optr[i] = (e < nch * CVPB && bx * CVPB + gx < P.X) ? o + vox0 + gx : nullptr;
+      prevv[i] = (accumulate && optr[i]) ? *optr[i] : 0.f;
     }
-  }
-  __syncthreads();
 #pragma unroll
-  for (int i = 0; i < PE; ++i) {
-    const int e = tid + i * 256;
-    if (optr[i]) *optr[i] = prevv[i] + outs[e / CVPB][e % CVPB];
+    for (int i = 0; i < PE; ++i) {
+      const int e = tid + i * 256;
+      if (optr[i]) *optr[i] = prevv[i] + outs[e / CVPB][e % CVPB];
+    }
+    __syncthreads();                    // outs is the next item's too
   }
 }
 
@@ -335,7 +342,7 @@ struct CellWs {
   int* aux;        // [ntile] scratch of the level-2 scan, then [ntile] = total, [ntile+1] = heavy cells listed
   int* hcells;     // [ncell] list of the heavy cells
   float* part;     // [samples / kCellHeavy + 2][8][CP] per-corner partial sums of the heavy cells
-  int* runs;       // [x-runs] 1 = the gather's workgroup has something to add (accumulate mode)
+  int* runs;       // [x-runs] list of the x-runs with records (accumulate mode); aux[ntile + 2] = their number
   int* rank;       // [tiles][S][64] rank of the sample inside its cell (written for kept inside samples only)
   int* slot;       // [tiles][S][64] slot in R (-1 = masked): the per-ray pass's note between its two loops
   int* tile_se;    // [tiles] kept samples of the tile's longest ray
@@ -430,18 +437,26 @@ int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, con
   return launch_cam_heavy_list(d, P, w, s);
 }
 
-// Heavy-cell list: the cells with more than kCellHeavy records, known as soon as the cells are scanned -- so the list
-// belongs to the prepare pass.  One atomic per wave that has a heavy cell (the lanes take base + their position
-// among the wave's heavy lanes).  The same kernel flags the gather's x-runs that hold at least one voxel with
-// records: when the gather adds on top of the BEV branch's gradient (the default) the workgroups of the other
-// runs leave at once -- with early ray termination most of the volume lies behind terminated rays.  (A compacted
-// list of the runs instead of flags: 22 400 appends to one counter took 125 us when nothing terminates.)
-// Thread = voxel in the gather's own (run, voxel) order, then = cell for the list.
+// The two work lists of the backward, known as soon as the cells are scanned -- so they belong to the prepare pass:
+//   cells  the cells with more than kCellHeavy records (cam_cell_splat_kernel's items).  A workgroup takes a scan
+//          tile of 2 048 cells, eight per thread, compacts its heavy cells and appends them with ONE atomic.
+//   runs   the gather's x-runs (32 voxels) that hold at least one record.  When the gather adds on top of the BEV
+//          branch's gradient (the default) it visits those only -- with early ray termination most of the volume
+//          lies behind terminated rays (cfg-B: 925 of 22 400 runs), and a workgroup per run that leaves at once
+//          still costs its dispatch.  Thread = run: the records in reach of a run's voxels are four ranges of 33
+//          x-neighbouring cells, i.e. eight start offsets; one append per wave.
+// (Rounds 3 - 5 walked the voxels, a thread each, for run FLAGS: 0.7 M threads and 16 offset loads per thread; an
+// append per run took 125 us when nothing terminates.)
+constexpr int kListCells = kScanTile;        // cells per workgroup of the list kernel's cell part
+__device__ __forceinline__ int cell_start(const int* __restrict__ off, const int* __restrict__ boff, long c) {
+  return off[c] + boff[c / kScanTile];
+}
 __global__ void __launch_bounds__(256)
 cam_heavy_list_kernel(RenderParams P, const int* __restrict__ off, const int* __restrict__ boff,
                       int* __restrict__ hcells, int* __restrict__ nhcells, int* __restrict__ runs,
-                      long ncell_b, long total_runs, int runs_x, long ncell,
-                      const int* __restrict__ tile_se, int* __restrict__ tile_order, int ntiles) {
+                      int* __restrict__ nruns, long ncell_b, long total_runs, int runs_x, long ncell,
+                      const int* __restrict__ tile_se, int* __restrict__ tile_order, int ntiles,
+                      unsigned cell_blocks) {
   // A duty of the first workgroup: the order in which the per-ray pass takes the ray tiles -- deepest
   // first (counting sort by the bit length of the tile's longest ray).  With early ray termination a few
   // tiles hold a ray that never saturates and march 85 samples where the others march 8: started last
@@ -459,40 +474,62 @@ cam_heavy_list_kernel(RenderParams P, const int* __restrict__ off, const int* __
     __syncthreads();
     for (int t = threadIdx.x; t < ntiles; t += 256) tile_order[atomicAdd(cls + (32 - __clz(max(tile_se[t], 0))), 1)] = t;
   }
-  const int lane = threadIdx.x & 63;
-  // the heavy cells (the last cell with a successor is ncell - 2: cell_count_padded)
-  for (long c0 = ((long) blockIdx.x * 256 + threadIdx.x) - lane; c0 < ncell - 1; c0 += (long) gridDim.x * 256) {
-    const long c = min(c0 + lane, ncell - 2);
-    const int n = (off[c + 1] + boff[(c + 1) / kScanTile]) - (off[c] + boff[c / kScanTile]);
-    const bool hv = c0 + lane < ncell - 1 && n > kCellHeavy;
-    const unsigned long long m = __ballot(hv);
-    if (m == 0ull) continue;
-    const int lead = __ffsll((long long) m) - 1;
-    int base = 0;
-    if (lane == lead) base = atomicAdd(nhcells, __popcll(m));
-    base = __shfl(base, lead, 64);
-    if (hv) hcells[base + __popcll(m & ((1ull << lane) - 1ull))] = (int) c;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (blockIdx.x < cell_blocks) {
+    // cells c0 .. c0 + 7 of this thread (the last cell with a successor is ncell - 2: cell_count_padded)
+    const long c0 = (long) blockIdx.x * kListCells + 8 * threadIdx.x;
+    int st[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) st[k] = cell_start(off, boff, min(c0 + k, ncell - 1));
+    unsigned hv = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hv |= (c0 + k < ncell - 1 && st[k + 1] - st[k] > kCellHeavy) ? 1u << k : 0u;
+    const int mine = __popc(hv);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    __shared__ int wsum[4], base_s;
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int n = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+      base_s = n ? atomicAdd(nhcells, n) : 0;
+    }
+    __syncthreads();
+    int at = base_s + incl - mine;
+    for (int k = 0; k < wv; ++k) at += wsum[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (hv & (1u << k)) hcells[at++] = (int) (c0 + k);
+    return;
   }
-  const long run = (long) blockIdx.x * (256 / kRunVox) + threadIdx.x / kRunVox;
+  const long run = (long) (blockIdx.x - cell_blocks) * 256 + threadIdx.x;
   const bool run_ok = run < total_runs;
   const long rc = run_ok ? run : total_runs - 1;
   const int bx = (int) (rc % runs_x);
   const long rest = rc / runs_x;
-  const int ix = bx * kRunVox + threadIdx.x % kRunVox, iy = (int) (rest % P.Y);
+  const int iy = (int) (rest % P.Y);
   const long zb = rest / P.Y;
   const int iz = (int) (zb % P.Z);
   const long b = zb / P.Z;
+  const int ix0 = bx * kRunVox, span = min(kRunVox, P.X - ix0) + 1;      // cells ix0 .. ix0 + span - 1
   int tot = 0;
-  if (run_ok && ix < P.X) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long c = b * ncell_b + ((long) (iz + (r >> 1)) * (P.Y + 1) + (iy + (r & 1))) * (P.X + 1) + ix;
-      tot += (off[c + 2] + boff[(c + 2) / kScanTile]) - (off[c] + boff[c / kScanTile]);
-    }
+  for (int r = 0; r < 4; ++r) {
+    const long c = b * ncell_b + ((long) (iz + (r >> 1)) * (P.Y + 1) + (iy + (r & 1))) * (P.X + 1) + ix0;
+    tot += cell_start(off, boff, c + span) - cell_start(off, boff, c);
   }
-  static_assert(kRunVox == 32, "a run is half a wave");
-  const unsigned long long any = __ballot(tot > 0);
-  if ((lane & 31) == 0 && run_ok) runs[run] = ((any >> lane) & 0xffffffffull) != 0ull ? 1 : 0;
+  const bool act = run_ok && tot > 0;
+  const unsigned long long m = __ballot(act);
+  if (m == 0ull) return;
+  const int lead = __ffsll((long long) m) - 1;
+  int base = 0;
+  if (lane == lead) base = atomicAdd(nruns, __popcll(m));
+  base = __shfl(base, lead, 64);
+  if (act) runs[base + __popcll(m & ((1ull << lane) - 1ull))] = (int) run;
 }
 
 static int launch_cam_heavy_list(const VampRenderDesc* d, const RenderParams& P, const CellWs& w, hipStream_t s) {
@@ -501,10 +538,11 @@ static int launch_cam_heavy_list(const VampRenderDesc* d, const RenderParams& P,
   const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
   const int runs_x = (d->X + kRunVox - 1) / kRunVox;
   const long total_runs = (long) runs_x * d->Y * d->Z * d->B;
-  int* nhcells = w.aux + ntile + 1;              // zeroed by the scan that just ran (runtime.hip)
-  VAMP_TIMED(kProfAux, s, (cam_heavy_list_kernel<<<(unsigned) ((total_runs * kRunVox + 255) / 256), 256, 0, s>>>(
-      P, w.off, w.boff, w.hcells, nhcells, w.runs, ncell_b, total_runs, runs_x, ncell, w.tile_se, w.tile_order,
-      (int) ((long) d->B * d->N * ((d->fH + 7) / 8) * ((d->fW + 7) / 8)))));
+  int* nhcells = w.aux + ntile + 1;              // (and the run counter behind it) zeroed by the scan that just ran (runtime.hip)
+  const unsigned cell_blocks = (unsigned) (ncell / kListCells);
+  VAMP_TIMED(kProfAux, s, (cam_heavy_list_kernel<<<cell_blocks + (unsigned) ((total_runs + 255) / 256), 256, 0, s>>>(
+      P, w.off, w.boff, w.hcells, nhcells, w.runs, nhcells + 1, ncell_b, total_runs, runs_x, ncell, w.tile_se, w.tile_order,
+      (int) ((long) d->B * d->N * ((d->fH + 7) / 8) * ((d->fW + 7) / 8)), cell_blocks)));
   return check_launch("cam_heavy_list_kernel");
 }
 
@@ -526,7 +564,7 @@ int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const fl
   const int runs_x = (d->X + vpb - 1) / vpb;
   const long nblk = (long) runs_x * d->Y * d->Z * d->B;
   VAMP_REQUIRE(nblk < 0x7fffffffL, "too many x-runs");
-  const unsigned grid = (unsigned) nblk;
+  const unsigned grid = (unsigned) std::min<long>(nblk, kGatherGrid);
   const unsigned sgrid = (unsigned) std::min<long>(ncell, 2048);
   // PART_HEAVY: the per-cell sums (they touch the partial table only: no need to wait for whoever else writes the
   // gradient buffers); PART_GATHER reads them, so a caller that splits the parts issues HEAVY first, same stream
@@ -541,7 +579,7 @@ int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const fl
       if (wait_event && hipStreamWaitEvent(s, wait_event, 0) != hipSuccess)                         \
         return fail(VAMP_EHIP, "%s: hipStreamWaitEvent failed", __func__);                          \
       VAMP_TIMED(kProfCamBwdBrick, s, (cam_bwd_cell_gather_kernel<CP4, gl><<<grid, 256, 0, s>>>(    \
-          P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, ncell_b, runs_x, accumulate, btail, runs, w.part))); \
+          P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, ncell_b, runs_x, nblk, accumulate, btail, runs, nhcells + 1, w.part))); \
     }                                                                                               \
   } while (0)
   if (P.CP == 12) VAMP_CELL(3); else if (P.CP == 24) VAMP_CELL(6); else VAMP_CELL(8);
