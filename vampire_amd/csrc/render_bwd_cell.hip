@@ -33,6 +33,18 @@ namespace vamp {
 #define VAMP_CELL_HEAVY 32
 #endif
 constexpr int kCellHeavy = VAMP_CELL_HEAVY;   // records per cell beyond which the cell is summed once per corner (cam_cell_splat_kernel)
+#ifndef VAMP_SPLAT_CHUNK
+#define VAMP_SPLAT_CHUNK 256
+#endif
+// A heavy cell of n records is summed in ceil(n / kSplatChunk) chunks of n / chunks records (the last one takes the
+// remainder), each a list entry and a workgroup of the splat with a row set of its own: slot (first record of the
+// chunk) / kCellHeavy -- chunks are at least kSplatChunk / 2 >= kCellHeavy records long, so no two share a slot.
+constexpr int kSplatChunk = VAMP_SPLAT_CHUNK;
+static_assert(kSplatChunk / 2 >= kCellHeavy, "chunks must not share slots");
+__host__ __device__ inline int splat_chunks(int n) { return (n + kSplatChunk - 1) / kSplatChunk; }
+#ifndef VAMP_SPLAT_NW
+#define VAMP_SPLAT_NW 2
+#endif
 #ifndef VAMP_GATHER_GRID
 #define VAMP_GATHER_GRID 20480
 #endif
@@ -146,37 +158,50 @@ __device__ __forceinline__ void cell_accumulate(const CellRanges& cr, int k0, in
 // trilinear weights of the same three fractions; the per-voxel gather would stream the cell's records eight times
 // (once from each corner voxel) -- and next to a camera a cell holds hundreds of records (cfg-B with early ray
 // termination: 0.34 M kept samples in 3 710 cells, 94 % of them in the 2 000 cells with more than 32 records;
-// tools/debug/cell_stats.py).  One workgroup per listed cell: the four waves split the channels (CP / 4 each), a lane
-// takes every 64th record and keeps 8 corners x CP / 4 channel sums; the wave reduces them and writes the cell's
-// 8 x CP partial sums to slot start(cell) / kCellHeavy of the partial table (cells with more than kCellHeavy
-// records cannot share a slot).  The gather adds the up to eight partial rows of a voxel in a fixed order: no float
-// atomics, and the order of the sums inside a cell is the record order (the rank atomics'), as in the gather.
+// tools/debug/cell_stats.py).  One workgroup per listed cell: its NW waves split the channels (CP / NW each); a
+// lane is (record, z half): it takes every 32nd record and keeps the sums of the four corners of its z plane x
+// CP / NW channels; the half-waves reduce them and write the cell's 8 x CP partial sums to slot start(cell) /
+// kCellHeavy of the partial table (cells with more than kCellHeavy records cannot share a slot).  The gather adds
+// the up to eight partial rows of a voxel in a fixed order: no float atomics, and the order of the sums inside a
+// cell is the record order (the rank atomics'), as in the gather.
+// The kernel is a chain of dependent fetches (list entry -> records -> gradient rows), so what counts is that every
+// listed cell is resident at once: 2 000 cells x NW waves over 1 024 SIMDs -- two waves per cell (2 x 12 channels at
+// cfg-B) fit at four waves per SIMD; four waves per cell with a lane per record (116 registers) ran in two batches,
+// 20 us, eight waves of three channels in three, 25 us.
 // ---------------------------------------------------------------------------
-template <int CP4>
-__global__ void __launch_bounds__(256)
-cam_cell_splat_kernel(const int* __restrict__ off, const int* __restrict__ boff, const float4* __restrict__ R,
-                      const float* __restrict__ Gcl, const int* __restrict__ hcells,
+template <int CP4, int NW>
+__global__ void __launch_bounds__(NW * 64)
+cam_cell_splat_kernel(const float4* __restrict__ R, const float* __restrict__ Gcl, const int2* __restrict__ hcells,
                       const int* __restrict__ nhcells, float* __restrict__ part) {
-  constexpr int CP = CP4 * 4, CW = CP4, NA = 8 * CW;
+  constexpr int CP = CP4 * 4, CW = CP / NW, NA = 4 * CW;
+  static_assert(CW * NW == CP && CW % 2 == 0, "the waves split the channels evenly, in pairs at least");
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  // the list entry {first record, records} goes out with the length of the list, not behind it (the list has room
+  // for every cell)
+  int2 ent = hcells[blockIdx.x];
   const int n = *nhcells;
   for (int item = blockIdx.x; item < n; item += gridDim.x) {
-    const int c = hcells[item];
     // (sharing the cells with more than 256 records among four workgroups, each with a row set of its own, changed
     // nothing: 24.2 against 24.2 us, step 0.3945 against 0.3936 ms)
-    const int s0 = off[c] + boff[c / kScanTile], s1 = off[c + 1] + boff[(c + 1) / kScanTile];
+#ifdef VAMP_SPLAT_CAP       // (measurement builds: wrong sums)
+    const int s0 = ent.x, s1 = ent.x + min(ent.y, VAMP_SPLAT_CAP);
+#else
+    const int s0 = ent.x, s1 = ent.x + ent.y;
+#endif
+    constexpr int U = 2;
+    float4 a[U], g[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long pos = min(s0 + r + u * 32, s1 - 1);
+      a[u] = R[2 * pos];
+      g[u] = R[2 * pos + 1];
+    }
+    if (item + (int) gridDim.x < n) ent = hcells[item + gridDim.x];
     float acc[NA];
 #pragma unroll
     for (int e = 0; e < NA; ++e) acc[e] = 0.f;
-    constexpr int U = 2;
-    for (int k0 = s0 + lane; k0 < s1; k0 += U * 64) {
-      float4 a[U], g[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const long pos = min(k0 + u * 64, s1 - 1);
-        a[u] = R[2 * pos];
-        g[u] = R[2 * pos + 1];
-      }
+    for (int k0 = s0 + r; k0 < s1; k0 += U * 32) {
       float gv[U][CW];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -187,45 +212,58 @@ cam_cell_splat_kernel(const int* __restrict__ off, const int* __restrict__ boff,
             const float4 f = reinterpret_cast<const float4*>(row)[q];
             gv[u][q * 4] = f.x; gv[u][q * 4 + 1] = f.y; gv[u][q * 4 + 2] = f.z; gv[u][q * 4 + 3] = f.w;
           }
-        } else if constexpr (CW % 2 == 0) {
+        } else {
 #pragma unroll
           for (int q = 0; q < CW / 2; ++q) {
             const float2 f = reinterpret_cast<const float2*>(row)[q];
             gv[u][q * 2] = f.x; gv[u][q * 2 + 1] = f.y;
           }
-        } else {
+        }
+      }
+      // the records of the next round travel while this one is summed
+      float4 ca[U], cg[U];
 #pragma unroll
-          for (int q = 0; q < CW; ++q) gv[u][q] = row[q];
+      for (int u = 0; u < U; ++u) { ca[u] = a[u]; cg[u] = g[u]; }
+      if (k0 - r + U * 32 < s1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const long pos = min(k0 + (U + u) * 32, s1 - 1);
+          a[u] = R[2 * pos];
+          g[u] = R[2 * pos + 1];
         }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const bool in = k0 + u * 64 < s1;
+        const bool in = k0 + u * 32 < s1;
         // record = {fx, fy, fz, - | w, dL/ds0, ray, -}; the weights as cell_tap_weight forms them
-        const float flx = floorf(a[u].x), fly = floorf(a[u].y), flz = floorf(a[u].z);
-        float wx[2] = {(flx + 1.0f) - a[u].x, a[u].x - flx};
-        const float wy[2] = {(fly + 1.0f) - a[u].y, a[u].y - fly};
-        const float wz[2] = {(flz + 1.0f) - a[u].z, a[u].z - flz};
+        const float flx = floorf(ca[u].x), fly = floorf(ca[u].y), flz = floorf(ca[u].z);
+        float wx[2] = {(flx + 1.0f) - ca[u].x, ca[u].x - flx};
+        const float wy[2] = {(fly + 1.0f) - ca[u].y, ca[u].y - fly};
+        const float wz = h ? ca[u].z - flz : (flz + 1.0f) - ca[u].z;
         if (!in) wx[0] = wx[1] = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float wt = wx[k & 1] * wy[(k >> 1) & 1] * wz[k >> 2];
-          const float Wv = wt * g[u].x;
+        for (int k = 0; k < 4; ++k) {
+          const float wt = wx[k & 1] * wy[k >> 1] * wz;
+          const float Wv = wt * cg[u].x;
 #pragma unroll
           for (int q = 0; q < CW; ++q) {
             // channel 0 of the row (wave 0, q == 0) is the density: weight * dL/ds0
-            if (q == 0) acc[k * CW] = wv == 0 ? __builtin_fmaf(wt, g[u].y, acc[k * CW]) : __builtin_fmaf(Wv, gv[u][0], acc[k * CW]);
+            if (q == 0) acc[k * CW] = wv == 0 ? __builtin_fmaf(wt, cg[u].y, acc[k * CW]) : __builtin_fmaf(Wv, gv[u][0], acc[k * CW]);
             else acc[k * CW + q] = __builtin_fmaf(Wv, gv[u][q], acc[k * CW + q]);
           }
         }
       }
     }
+    // over the 32 lanes of each z half
     int cbase = 0;
-    reduce_halving<NA, 32, 64, NA>(acc, lane, cbase);
-    constexpr int NL = reduce_left<NA, 32>();
-    constexpr int DUP = reduce_dups<NA, 32>();
+#ifdef VAMP_SPLAT_NORED
+    if (acc[0] != 123.f) continue;
+#endif
+    reduce_halving<NA, 16, 32, NA>(acc, lane, cbase);
+    constexpr int NL = reduce_left<NA, 16>();
+    constexpr int DUP = reduce_dups<NA, 16>();
     if ((lane & DUP) == 0) {
-      float* o = part + (long) (s0 / kCellHeavy) * 8 * CP + wv * CW;
+      float* o = part + ((long) (s0 / kCellHeavy) * 8 + 4 * h) * CP + wv * CW;
 #pragma unroll
       for (int e = 0; e < NL; ++e) {
         const int idx = cbase + e;
@@ -256,6 +294,8 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
   // accumulate mode: only the listed x-runs have anything to add (cam_heavy_list_kernel); the grid is fixed and a
   // workgroup takes every gridDim.x-th entry (x-neighbouring runs, which share cells, land on different CUs; a
   // contiguous slab of x-runs per XCD measured 12 % slower: the slabs next to the cameras carry most of the records)
+  // (the first list entry goes out with the length of the list, not behind it: the list has room for every run)
+  int ent = runs ? runs[blockIdx.x] : 0;
   const int nitems = runs ? *nruns : (int) total_runs;
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     // (the thread's own indices are formed per item: hoisted out of the loop, what derives from them holds 20
@@ -263,7 +303,8 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int g = tid / CGL, l = tid % CGL;
-    const unsigned lin = runs ? (unsigned) runs[item] : (unsigned) item;
+    const unsigned lin = runs ? (unsigned) ent : (unsigned) item;
+    if (runs && item + (int) gridDim.x < nitems) ent = runs[item + gridDim.x];
     const int bx = lin % (unsigned) runs_x;
     const unsigned rest = lin / (unsigned) runs_x;
     const int ix = bx * CVPB + g, iy = rest % (unsigned) P.Y;
@@ -283,11 +324,14 @@ cam_bwd_cell_gather_kernel(RenderParams P, const int* __restrict__ off, const in
       // by cam_cell_splat_kernel, and this voxel is the cell's corner (1 - dx, 1 - dy, 1 - dz)
       if (cl.own_n > kCellHeavy) {
         const int corner = l ^ 7;
-        const float4* p4 = reinterpret_cast<const float4*>(part + ((long) (cl.own_start / kCellHeavy) * 8 + corner) * CP);
+        const int nchunk = splat_chunks(cl.own_n), len = cl.own_n / nchunk;
+        for (int j = 0; j < nchunk; ++j) {
+          const float4* p4 = reinterpret_cast<const float4*>(part + ((long) ((cl.own_start + j * len) / kCellHeavy) * 8 + corner) * CP);
 #pragma unroll
-        for (int c4 = 0; c4 < CP4; ++c4) {
-          const float4 f = p4[c4];
-          acc[c4 * 4] = f.x; acc[c4 * 4 + 1] = f.y; acc[c4 * 4 + 2] = f.z; acc[c4 * 4 + 3] = f.w;
+          for (int c4 = 0; c4 < CP4; ++c4) {
+            const float4 f = p4[c4];
+            acc[c4 * 4] += f.x; acc[c4 * 4 + 1] += f.y; acc[c4 * 4 + 2] += f.z; acc[c4 * 4 + 3] += f.w;
+          }
         }
       }
       const float fix = (float) ix, fiy = (float) iy, fiz = (float) iz;
@@ -340,7 +384,7 @@ struct CellWs {
   int* bsum;       // [ntile] tile totals
   int* boff;       // [ntile] exclusive scan of the tile totals
   int* aux;        // [ntile] scratch of the level-2 scan, then [ntile] = total, [ntile+1] = heavy cells listed
-  int* hcells;     // [ncell] list of the heavy cells
+  int2* hcells;    // [max(ncell, samples / 16)] list of the heavy cells' chunks: {first record, records}
   float* part;     // [samples / kCellHeavy + 2][8][CP] per-corner partial sums of the heavy cells
   int* runs;       // [x-runs] list of the x-runs with records (accumulate mode); aux[ntile + 2] = their number
   int* rank;       // [tiles][S][64] rank of the sample inside its cell (written for kept inside samples only)
@@ -364,7 +408,7 @@ static CellWs cell_ws(const VampRenderDesc* d, void* scratch) {
   w.bsum = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
   w.boff = reinterpret_cast<int*>(p); p += align_up((size_t) ntile * sizeof(int), 256);
   w.aux = reinterpret_cast<int*>(p); p += align_up((size_t) (ntile + 4) * sizeof(int), 256);
-  w.hcells = reinterpret_cast<int*>(p); p += align_up((size_t) ncell * sizeof(int), 256);
+  w.hcells = reinterpret_cast<int2*>(p); p += align_up(std::max<size_t>((size_t) ncell, samples / 16 + 4096) * sizeof(int2), 256);
   w.part = reinterpret_cast<float*>(p); p += align_up((samples / kCellHeavy + 2) * 8 * (size_t) to_params(d).CP * sizeof(float), 256);
   w.runs = reinterpret_cast<int*>(p); p += align_up((size_t) d->B * d->Z * d->Y * ((d->X + kRunVox - 1) / kRunVox) * sizeof(int), 256);
   w.rank = reinterpret_cast<int*>(p); p += align_up(tsamples * sizeof(int), 256);
@@ -453,7 +497,7 @@ __device__ __forceinline__ int cell_start(const int* __restrict__ off, const int
 }
 __global__ void __launch_bounds__(256)
 cam_heavy_list_kernel(RenderParams P, const int* __restrict__ off, const int* __restrict__ boff,
-                      int* __restrict__ hcells, int* __restrict__ nhcells, int* __restrict__ runs,
+                      int2* __restrict__ hcells, int* __restrict__ nhcells, int* __restrict__ runs,
                       int* __restrict__ nruns, long ncell_b, long total_runs, int runs_x, long ncell,
                       const int* __restrict__ tile_se, int* __restrict__ tile_order, int ntiles,
                       unsigned cell_blocks) {
@@ -482,9 +526,13 @@ cam_heavy_list_kernel(RenderParams P, const int* __restrict__ off, const int* __
 #pragma unroll
     for (int k = 0; k < 9; ++k) st[k] = cell_start(off, boff, min(c0 + k, ncell - 1));
     unsigned hv = 0;
+    int mine = 0;                       // list entries of this thread: the chunks of its heavy cells
 #pragma unroll
-    for (int k = 0; k < 8; ++k) hv |= (c0 + k < ncell - 1 && st[k + 1] - st[k] > kCellHeavy) ? 1u << k : 0u;
-    const int mine = __popc(hv);
+    for (int k = 0; k < 8; ++k) {
+      const bool heavy = c0 + k < ncell - 1 && st[k + 1] - st[k] > kCellHeavy;
+      hv |= heavy ? 1u << k : 0u;
+      mine += heavy ? splat_chunks(st[k + 1] - st[k]) : 0;
+    }
     int incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -502,8 +550,12 @@ cam_heavy_list_kernel(RenderParams P, const int* __restrict__ off, const int* __
     int at = base_s + incl - mine;
     for (int k = 0; k < wv; ++k) at += wsum[k];
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (hv & (1u << k)) hcells[at++] = (int) (c0 + k);
+    for (int k = 0; k < 8; ++k) {
+      if (!(hv & (1u << k))) continue;
+      const int nrec = st[k + 1] - st[k], nchunk = splat_chunks(nrec), len = nrec / nchunk;
+      for (int j = 0; j < nchunk; ++j)
+        hcells[at++] = make_int2(st[k] + j * len, j == nchunk - 1 ? nrec - j * len : len);
+    }
     return;
   }
   const long run = (long) (blockIdx.x - cell_blocks) * 256 + threadIdx.x;
@@ -565,14 +617,14 @@ int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const fl
   const long nblk = (long) runs_x * d->Y * d->Z * d->B;
   VAMP_REQUIRE(nblk < 0x7fffffffL, "too many x-runs");
   const unsigned grid = (unsigned) std::min<long>(nblk, kGatherGrid);
-  const unsigned sgrid = (unsigned) std::min<long>(ncell, 2048);
+  const unsigned sgrid = (unsigned) std::min<long>(ncell, 4096);
   // PART_HEAVY: the per-cell sums (they touch the partial table only: no need to wait for whoever else writes the
   // gradient buffers); PART_GATHER reads them, so a caller that splits the parts issues HEAVY first, same stream
-#define VAMP_CELL(CP4)                                                                              \
+#define VAMP_CELL(CP4, NW)                                                                            \
   do {                                                                                              \
     if (parts & kCamPartHeavy)                                                                      \
-      VAMP_TIMED(kProfCamBwdOwn, s, (cam_cell_splat_kernel<CP4><<<sgrid, 256, 0, s>>>(              \
-          w.off, w.boff, w.R, Gcl, w.hcells, nhcells, w.part)));                                    \
+      VAMP_TIMED(kProfCamBwdOwn, s, (cam_cell_splat_kernel<CP4, NW><<<sgrid, NW * 64, 0, s>>>(      \
+          w.R, Gcl, w.hcells, nhcells, w.part)));                                                   \
     if (parts & kCamPartGather) {                                                                   \
       /* the gradient buffers are first touched here: whoever else accumulates into them (the BEV   \
          branch on another stream) must be done */                                                  \
@@ -582,7 +634,8 @@ int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const fl
           P, w.off, w.boff, w.R, Gcl, gdens, gsem, grgb, ncell_b, runs_x, nblk, accumulate, btail, runs, nhcells + 1, w.part))); \
     }                                                                                               \
   } while (0)
-  if (P.CP == 12) VAMP_CELL(3); else if (P.CP == 24) VAMP_CELL(6); else VAMP_CELL(8);
+  // (waves of the splat: CP / NW channels each)
+  if (P.CP == 12) VAMP_CELL(3, 2); else if (P.CP == 24) VAMP_CELL(6, VAMP_SPLAT_NW); else VAMP_CELL(8, 4);
 #undef VAMP_CELL
   return check_launch("cam_bwd_cell_gather_kernel");
 }
