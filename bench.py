@@ -185,8 +185,8 @@ def measured_traffic(cfg_name, kernel, batch, run_kernels):
         except (OSError, ValueError):
             continue
         ks = set(t.get("kernels", {}))
-        # (small helper kernels share the "aux" slot of the in-library timer; the heavy-voxel drain is a kernel
-        # of its own only in two-stream steps, which is what the profiled bench command runs)
+        # (small helper kernels share the "aux" slot of the in-library timer; the heavy-cell sums -- before round 6's
+        # cell splat: the heavy-voxel drain -- are not matched, so that earlier rounds' files stay comparable)
         ignore = {"aux", "memset", "scan", "cell_scan", "cam_heavy_list", "bev_axis_table", "render_cam_bwd_heavy"}
         if (t.get("cfg") == cfg_name and t.get("batch") == batch and kernel in ks
                 and (set(run_kernels) - ignore) == (ks - ignore)):

@@ -22,6 +22,7 @@ SLOTS = [("lift_fwd_kernel", "lift_fwd"), ("lift_fwd_coop_kernel", "lift_fwd"),
          ("cam_term_kernel", "render_cam_term"), ("bev_density_kernel", "render_bev_fwd"),
          ("bev_channels_kernel", "render_bev_fwd_channels"), ("cam_bwd_ray_kernel", "render_cam_bwd_ray"),
          ("cam_bwd_cell_gather_kernel", "render_cam_bwd_gather"), ("cam_bwd_cell_heavy_kernel", "render_cam_bwd_heavy"),
+         ("cam_cell_splat_kernel", "render_cam_bwd_heavy"),
          ("cam_cells_rank_kernel", "render_cam_bwd_rank"), ("cam_cells_slot_kernel", "render_cam_bwd_fill"),
          ("bev_q_kernel", "render_bev_bwd_q"), ("bev_scan_kernel", "render_bev_bwd_scan"), ("bev_qscan_saved_kernel", "render_bev_bwd_scan"),
          ("cam_heavy_list_kernel", "cam_heavy_list"), ("bev_axis_table_kernel", "bev_axis_table"),
