@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU box: how the camera backward's records distribute over cells and voxels (cfg-B sample of the bench, early termination on)."""
+"""GPU box: how the camera backward's records distribute over cells and voxels (cfg-B sample of the bench; early termination on, or -- argument `noert` -- off)."""
 import os, sys, ctypes as C, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from vampire_amd.config import PRESETS
@@ -14,12 +14,14 @@ term = hp._ws["render"][off:off + 4 * n].view(torch.int32).reshape(1, cfg.num_ca
 inside, ix0, iy0, iz0 = hp.render_indices(render_mats=batch.render_mats)
 idx = torch.arange(cfg.D - 1, device=dev).reshape(1, 1, -1, 1, 1)
 kept = inside.bool() & (idx < term)
+if "noert" in sys.argv[1:]:                # every inside sample (early termination off)
+    kept = inside.bool()
 print("inside", int(inside.sum()), "kept", int(kept.sum()))
 X, Y, Z = cfg.vX, cfg.vY, cfg.vZ
 cell = ((iz0.long() + 1) * (Y + 1) + (iy0.long() + 1)) * (X + 1) + (ix0.long() + 1)
 cnt = torch.bincount(cell[kept], minlength=(Z + 1) * (Y + 1) * (X + 1)).reshape(Z + 1, Y + 1, X + 1)
 print("cells with records", int((cnt > 0).sum()), "max per cell", int(cnt.max()))
-for T in (32, 64, 128, 256, 512):
+for T in (4, 8, 16, 32, 64, 128, 256, 512):
     m = cnt > T
     print(f"  cells > {T}: {int(m.sum())} holding {int(cnt[m].sum())} records ({100.0 * float(cnt[m].sum()) / float(cnt.sum()):.1f} %)")
 # records per voxel = sum over its 8 cells
