@@ -14,7 +14,7 @@ model = LiftRenderStep(cfg, dev)
 batch = SyntheticBatch(cfg, B, dev)
 for kv in sys.argv[4:]:
     k, v = kv.split("=")
-    model.hp.impl[k] = {"0": False, "1": True}.get(v, v)
+    model.hp.impl[k] = {"0": False, "1": True}.get(v, int(v) if v.isdigit() else v)
 
 
 def step():

@@ -729,7 +729,7 @@ class _RenderFn(torch.autograd.Function):
         # streams -- 1 / 2 / 3 samples per GPU 0.395 / 0.710 / 1.03 against 0.410 / 0.723 / 1.05 ms, 4 samples equal,
         # 8 samples 2.69 against 2.63 (a full chip hides the prepare pass beside the BEV forward better than it
         # fills the camera tiles' tail)
-        if merged and train and B * N * ((c.fH + 7) // 8) * ((c.fW + 7) // 8) > 4096:
+        if merged and train and B * N * ((c.fH + 7) // 8) * ((c.fW + 7) // 8) > int(hp.impl.get("merged_tiles", 4096)):
             merged = False
         plan = render_forward_plan(train, side is not None, prep_ok, direct, ert, merged)
         bev_flags = 0 if hp.impl["bev_fused"] else _capi.VAMP_BEVFWD_TWO_KERNELS
@@ -738,6 +738,9 @@ class _RenderFn(torch.autograd.Function):
         cam_base = 0 if ert else _capi.VAMP_CAMFWD_NO_ERT
         streams, events = {"cur": cur, "side": side}, {}
         ctx.cells, ctx.ert, ctx.bev_key = False, ert, None
+        # the backward's d loss / d beta accumulator is zeroed HERE, in front of the forward's kernels: as the first
+        # node of the backward the one-element fill sat alone on the step's critical path (4 us + a launch gap)
+        ctx.gbeta0 = torch.zeros(1, dtype=f32, device=dev) if train else None
         if side is not None:
             side.wait_stream(cur)
         for op, where, flags, waits, records in plan:
@@ -820,7 +823,9 @@ class _RenderFn(torch.autograd.Function):
         gd = torch.empty(dens.shape, dtype=f32, device=dens.device)
         gs = torch.empty(sem.shape, dtype=f32, device=dens.device)
         gr = torch.empty(rgb.shape, dtype=f32, device=dens.device)
-        gbeta = torch.zeros(1, dtype=f32, device=dens.device)
+        gbeta, ctx.gbeta0 = getattr(ctx, "gbeta0", None), None        # (a second backward of the same graph zeroes its own)
+        if gbeta is None:
+            gbeta = torch.zeros(1, dtype=f32, device=dens.device)
 
         bev_saved = (ctx.bev_key is not None and hp.impl["bev_bwd"] != "v1"
                      and ctx.bev_key == (getattr(hp, "_bev_gen", 0), ws_bev.data_ptr()))
