@@ -122,6 +122,12 @@ int vamp_lift_forward(const VampLiftDesc* d, const float* mats, const float* xs,
    words) disappears -- every workgroup forms its own patch's cull word at its head -- and the forward is one
    kernel.  Without the flag feat is [B, N, C, fH, fW] as in the reference and the first launch runs. */
 #define VAMP_LIFTFWD_FEAT_CHANNEL_LAST 4
+/* (ABI 6) with VAMP_LIFTFWD_EMIT_PAIRS: the forward counts the pairs per cell but leaves the scan of the counters
+ * to a later call on the same stream -- vamp_lift_finish_cells, or vamp_render_camera_prepare_with_lift, which scans
+ * them in the launch that scans the camera backward's cells (a training step has both lists due between the render
+ * forward and the backward).  Until then the workspace is NOT what VAMP_LIFTBWD_CELLS_VALID promises, and its
+ * counters are not clean. */
+#define VAMP_LIFTFWD_DEFER_SCAN 8
 int vamp_lift_forward_ex(const VampLiftDesc* d, const float* mats, const float* xs,
                          const float* ys, const float* zs, const void* depth,
                          const void* feat, float* out, uint64_t* hits,
@@ -185,6 +191,9 @@ int vamp_lift_backward(const VampLiftDesc* d, const float* mats, const float* xs
 /* (ABI 6: takes `depth` -- a pair now carries its four depth samples, so that the backward reads no depth plane) */
 int vamp_lift_prepare(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
                       const float* zs, const void* depth, void* workspace, size_t workspace_bytes, void* stream);
+/* (ABI 6) the scan a forward with VAMP_LIFTFWD_DEFER_SCAN left out (one small kernel); afterwards the workspace
+ * is what VAMP_LIFTBWD_CELLS_VALID promises */
+int vamp_lift_finish_cells(const VampLiftDesc* d, void* workspace, size_t workspace_bytes, void* stream);
 int vamp_lift_backward_ex(const VampLiftDesc* d, const float* mats, const float* xs,
                           const float* ys, const float* zs, const void* depth,
                           const void* feat, const float* grad_out, const uint64_t* hits,
@@ -372,6 +381,12 @@ int vamp_render_camera_prepare(const VampRenderDesc* d, const float* mats, const
 int vamp_render_camera_prepare_ex(const VampRenderDesc* d, const float* mats, const float* us,
                                   const float* vs, const float* ds, void* workspace,
                                   size_t workspace_bytes, int flags, void* stream);
+/* (ABI 6) vamp_render_camera_prepare_ex(.., VAMP_CAMPREP_RANKED, ..) whose scan launch ALSO scans the pair cells
+ * of a lift forward that ran with VAMP_LIFTFWD_DEFER_SCAN on `lift_workspace` (same stream, or ordered before this
+ * call): one launch of two independent scans instead of two launches -- it stands for vamp_lift_finish_cells. */
+int vamp_render_camera_prepare_with_lift(const VampRenderDesc* d, void* workspace, size_t workspace_bytes,
+                                         const VampLiftDesc* lift_desc, void* lift_workspace,
+                                         size_t lift_workspace_bytes, void* stream);
 #define VAMP_CAMBWD_ACCUMULATE 1
 #define VAMP_CAMBWD_PACKED_VALID 2
 #define VAMP_CAMBWD_CELLS_VALID 4
@@ -457,6 +472,9 @@ int vamp_render_bev_forward_ex(const VampRenderDesc* d, const float* oxs, const 
  * vamp_render_forward_merged_supported: 1 when the shapes qualify (at most 128 samples per ray, the one-kernel BEV
  * forward's limits) AND ozs_host fits the BEV slabs (see vamp_render_bev_forward_ex); the call itself returns
  * VAMP_EINVAL otherwise -- the caller then issues the two calls.
+ * grad_beta_zero (may be NULL): one float the launch sets to zero -- the accumulator a training caller will hand to
+ * vamp_render_bev_backward* / vamp_render_camera_backward* as grad_beta, which ADD to it: a one-element fill launch
+ * at the head of the backward costs a replayed step ~10 us.
  */
 #define VAMP_RENDERFWD_SAVE_SAMPLES 1   /* = VAMP_CAMFWD_SAVE_SAMPLES */
 #define VAMP_RENDERFWD_BEV_SAVE 2       /* = VAMP_BEVFWD_SAVE */
@@ -477,7 +495,8 @@ int vamp_render_forward_merged(const VampRenderDesc* d, const float* mats, const
                                const void* base, float* rgb_out, float* seg_out, float* depth_out,
                                float* bev_rgb, float* bev_seg, float* bev_height, float* voxel_density,
                                float* voxel_output, void* workspace, size_t workspace_bytes,
-                               void* bev_workspace, size_t bev_workspace_bytes, int flags, void* stream);
+                               void* bev_workspace, size_t bev_workspace_bytes, float* grad_beta_zero, int flags,
+                               void* stream);
 
 /*
  * BEV branch, backward.  The four volume gradients are ACCUMULATED into (so that

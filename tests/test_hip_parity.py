@@ -613,6 +613,30 @@ def test_step_is_graph_capturable(dev, cfg, batch):
                 name, err, top)
 
 
+@pytest.mark.parametrize("cfg,batch", [(CFG_TINY, 2), (CFG_B, 1)], ids=["tiny", "cfg-B"])
+def test_deferred_lift_scan_matches_the_scan_in_the_forward(dev, cfg, batch):
+    """A training lift forward leaves the scan of its pair cells to the render forward's prepare step, which scans both
+    cell lists in one launch (vamp_render_camera_prepare_with_lift): same step gradients as with the scan inside the
+    lift's own call -- up to the order of a cell's records (1e-6 of the largest gradient)."""
+    from vampire_amd.step import LiftRenderStep, SyntheticBatch, train_step
+
+    def grads_of(defer):
+        model = LiftRenderStep(cfg, dev)
+        model.hp.impl["defer_lift_scan"] = defer
+        data = SyntheticBatch(cfg, batch, dev)
+        for _ in range(2):                                  # (the second step runs on workspaces the first has used)
+            model.zero_grad(set_to_none=True)
+            train_step(model, data)
+        assert model.hp._lift_scan_pending is None          # somebody has run it
+        torch.cuda.synchronize()
+        return [data.depth.grad, data.feat.grad] + [v.grad for v in data.vols] + [model.beta.grad]
+
+    for name, a, b in zip(("depth", "feat", "density_feature", "semantic_logits", "base", "rgb", "beta"),
+                          grads_of(True), grads_of(False)):
+        err, top = float((a - b).abs().max()), float(b.abs().max())
+        assert err <= (1e-5 if name == "beta" else 1e-6) * top, "grad_%s: max |diff| %.3e of %.3e" % (name, err, top)
+
+
 # --------------------------------------------------------------------------- trilinear resize (UNet)
 def test_resize_and_hourglass_tiny(dev):
     """SURVEY 8f N3, resize piece (bv2:66, 72): the HIP resize against the recorded F.interpolate

@@ -58,7 +58,7 @@ class VampSampleDesc(C.Structure):
 
 VAMP_PAD_ZEROS, VAMP_PAD_BORDER = 0, 1
 # flag bits of vamp_lift_backward_ex / vamp_render_camera_backward_acc (include/vampire_hip.h)
-VAMP_LIFTFWD_EMIT_PAIRS, VAMP_LIFTFWD_CELLS_CLEAN, VAMP_LIFTFWD_FEAT_CHANNEL_LAST = 1, 2, 4
+VAMP_LIFTFWD_EMIT_PAIRS, VAMP_LIFTFWD_CELLS_CLEAN, VAMP_LIFTFWD_FEAT_CHANNEL_LAST, VAMP_LIFTFWD_DEFER_SCAN = 1, 2, 4, 8
 VAMP_LIFTBWD_CELLS_VALID, VAMP_LIFTBWD_SPLAT = 1, 2
 VAMP_LIFTBWD_WPP1, VAMP_LIFTBWD_WPP4, VAMP_LIFTBWD_WPP16 = 4, 8, 16
 VAMP_LIFTBWD_LOGITS, VAMP_LIFTBWD_FEAT_CHANNEL_LAST = 256, 512
@@ -97,6 +97,8 @@ SIGNATURES = {
     "vamp_lift_backward": (C.c_int, [_LD] + [_P] * 10 + [_P, C.c_size_t, _P]),
     "vamp_lift_backward_ex": (C.c_int, [_LD] + [_P] * 10 + [_P, C.c_size_t, C.c_int, _P]),
     "vamp_lift_prepare": (C.c_int, [_LD] + [_P] * 5 + [_P, C.c_size_t, _P]),
+    "vamp_lift_finish_cells": (C.c_int, [_LD, _P, C.c_size_t, _P]),
+    "vamp_render_camera_prepare_with_lift": (C.c_int, [_RD, _P, C.c_size_t, _LD, _P, C.c_size_t, _P]),
     "vamp_lift_forward_dense": (C.c_int, [_LD] + [_P] * 7 + [_P]),
     "vamp_lift_backward_dense": (C.c_int, [_LD] + [_P] * 7 + [_P]),
     "vamp_lift_indices": (C.c_int, [_LD] + [_P] * 8 + [_P]),
@@ -115,7 +117,7 @@ SIGNATURES = {
     "vamp_render_bev_forward_ex": (C.c_int, [_RD] + [_P] * 14 + [C.POINTER(C.c_float), _P, C.c_size_t, C.c_int, _P]),
     "vamp_render_forward_merged_supported": (C.c_int, [_RD, C.POINTER(C.c_float)]),
     "vamp_render_forward_merged": (C.c_int, [_RD] + [_P] * 8 + [C.POINTER(C.c_float)] + [_P] * 14
-                                   + [_P, C.c_size_t, _P, C.c_size_t, C.c_int, _P]),
+                                   + [_P, C.c_size_t, _P, C.c_size_t, _P, C.c_int, _P]),
     "vamp_render_bev_workspace_bytes": (C.c_size_t, [_RD]),
     "vamp_render_bev_backward": (C.c_int, [_RD] + [_P] * 19 + [C.POINTER(C.c_float), _P, C.c_size_t, _P]),
     "vamp_render_bev_backward_ex": (C.c_int, [_RD] + [_P] * 19 + [C.POINTER(C.c_float), _P, C.c_size_t, C.c_int, _P]),

@@ -72,6 +72,13 @@ constexpr int kScanTile = 2048;
 constexpr int kScanPad = 64;
 int launch_cell_scan(int* cnt, int* off, int* bsum, int* boff, int* aux, long ncell,
                      hipStream_t s);
+// the same scan as a job description, and two jobs in one launch (runtime.hip: cell_scan_pair_kernel)
+struct ScanJob {
+  int *cnt, *off, *bsum, *boff, *fill, *total, *ticket;
+  int ntile;
+};
+int make_scan_job(int* cnt, int* off, int* bsum, int* boff, int* aux, long ncell, ScanJob* job);
+int launch_cell_scan_pair(const ScanJob& a, const ScanJob& b, hipStream_t s);
 // A duty a consumer kernel takes over from a launch of its own: the first workgroup adds up, in a
 // fixed order, the per-workgroup partial sums of d loss / d beta_eff that an EARLIER kernel of the same
 // stream left in `part` (kernel boundary: visible), and adds sign(beta_raw) * sum to grad_beta with one

@@ -1071,7 +1071,7 @@ template <typename T>
 static int lift_forward_t(const VampLiftDesc* d, const LiftParams& P, const float* mats,
                           const float* xs, const float* ys, const float* zs, const void* depth,
                           const float* feat_cl, float* out, uint64_t* hits, void* cells, bool cells_clean,
-                          const unsigned* cull, hipStream_t s) {
+                          const unsigned* cull, hipStream_t s, bool defer_scan = false) {
   constexpr int TX = VAMP_LIFT_TX, TY = VAMP_LIFT_TY, TZ = 1;
   dim3 grid((P.X + TX - 1) / TX, (P.Y + TY - 1) / TY, ((P.Z + TZ - 1) / TZ) * P.B);
   const T* dp = static_cast<const T*>(depth);
@@ -1096,7 +1096,9 @@ static int lift_forward_t(const VampLiftDesc* d, const LiftParams& P, const floa
   }
 #undef VAMP_FWD
   if (int e = check_launch("lift_fwd_kernel")) return e;
-  return cells ? launch_lift_cells_end(d, cells, s) : VAMP_OK;
+  // (VAMP_LIFTFWD_DEFER_SCAN: the counters stay as counted; vamp_lift_finish_cells or
+  // vamp_render_camera_prepare_with_lift scans them)
+  return (cells && !defer_scan) ? launch_lift_cells_end(d, cells, s) : VAMP_OK;
 }
 
 int launch_lift_cell_prepare(const VampLiftDesc* d, const float* mats, const float* xs,
@@ -1164,13 +1166,14 @@ int vamp_lift_forward_ex(const VampLiftDesc* d, const float* mats, const float* 
   const long BN = (long) d->B * d->N, HW = (long) d->fH * d->fW;
   void* cells = (flags & VAMP_LIFTFWD_EMIT_PAIRS) ? w.cells : nullptr;
   const bool clean = (flags & VAMP_LIFTFWD_CELLS_CLEAN) != 0;
+  const bool defer = (flags & VAMP_LIFTFWD_DEFER_SCAN) != 0;
   if (flags & VAMP_LIFTFWD_FEAT_CHANNEL_LAST) {
     // the features are already [B, N, fH, fW, C] fp32: no copy, and every workgroup of the forward kernel forms
     // its own patch's cull word at its head -- the forward is ONE launch
     VAMP_REQUIRE(d->in_dtype == VAMP_F32, "VAMP_LIFTFWD_FEAT_CHANNEL_LAST takes fp32 features (and depth)");
     VAMP_REQUIRE(((uintptr_t) feat & 15) == 0, "channel-last feat must be 16-byte aligned");
     return lift_forward_t<float>(d, P, mats, xs, ys, zs, depth, static_cast<const float*>(feat), out, hits, cells, clean,
-                                 nullptr, s);
+                                 nullptr, s, defer);
   }
   // first launch: channel-last copy of the features + the camera cull words of the forward's waves
   const int ptiles = (int) ((HW + 63) / 64);
@@ -1183,8 +1186,8 @@ int vamp_lift_forward_ex(const VampLiftDesc* d, const float* mats, const float* 
     VAMP_TIMED(kProfFeatCL, s, (lift_prologue_kernel<__hip_bfloat16><<<grid, 256, 0, s>>>(P, static_cast<const __hip_bfloat16*>(feat), w.feat_cl, ptiles, mats, xs, ys, zs, w.cull)));
   if (int e = check_launch("lift_prologue_kernel")) return e;
   if (d->in_dtype == VAMP_F32)
-    return lift_forward_t<float>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, cells, clean, w.cull.words, s);
-  return lift_forward_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, cells, clean, w.cull.words, s);
+    return lift_forward_t<float>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, cells, clean, w.cull.words, s, defer);
+  return lift_forward_t<__hip_bfloat16>(d, P, mats, xs, ys, zs, depth, w.feat_cl, out, hits, cells, clean, w.cull.words, s, defer);
 }
 
 int vamp_lift_forward_logits(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,
@@ -1235,7 +1238,26 @@ int vamp_lift_forward_logits_ex(const VampLiftDesc* d, const float* mats, const 
   if (int e = check_launch("lift_operands_kernel")) return e;
   return lift_forward_t<float>(d, P, mats, xs, ys, zs, depth_out, fcl ? feat : w.feat_cl, out, hits,
                                (flags & VAMP_LIFTFWD_EMIT_PAIRS) ? w.cells : nullptr,
-                               (flags & VAMP_LIFTFWD_CELLS_CLEAN) != 0, fcl ? nullptr : w.cull.words, s);
+                               (flags & VAMP_LIFTFWD_CELLS_CLEAN) != 0, fcl ? nullptr : w.cull.words, s,
+                               (flags & VAMP_LIFTFWD_DEFER_SCAN) != 0);
+}
+
+// the scan a forward with VAMP_LIFTFWD_DEFER_SCAN left out
+int vamp_lift_finish_cells(const VampLiftDesc* d, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  const LiftWs w = carve(d, workspace);
+  if (!workspace || workspace_bytes < w.bytes)
+    return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) w.bytes);
+  return launch_lift_cells_end(d, w.cells, static_cast<hipStream_t>(stream));
+}
+
+// the same scan as a job for a launch shared with another cell list (render_bwd.hip: vamp_render_camera_prepare_with_lift)
+int lift_scan_job(const VampLiftDesc* d, void* workspace, size_t workspace_bytes, ScanJob* job) {
+  if (int e = validate(d)) return e;
+  const LiftWs w = carve(d, workspace);
+  if (!workspace || workspace_bytes < w.bytes)
+    return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) w.bytes);
+  return lift_cells_scan_job(d, w.cells, job);
 }
 
 int vamp_lift_prepare(const VampLiftDesc* d, const float* mats, const float* xs, const float* ys,

@@ -612,6 +612,11 @@ int launch_lift_cells_end(const VampLiftDesc* d, void* scratch, hipStream_t s) {
   const LiftCellWs w = lift_cell_ws(d, scratch);
   return launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, g.ncell, s);
 }
+int lift_cells_scan_job(const VampLiftDesc* d, void* scratch, ScanJob* job) {
+  const LiftCells g = lift_cells(d);
+  const LiftCellWs w = lift_cell_ws(d, scratch);
+  return make_scan_job(w.cnt, w.off, w.bsum, w.boff, w.aux, g.ncell, job);
+}
 
 template <typename T>
 static int launch_cell_t(const VampLiftDesc* d, const LiftParams& P, const float* mats,

@@ -204,5 +204,6 @@ int launch_lift_cell_prepare(const VampLiftDesc* d, const float* mats, const flo
 // zero the cell counters (before a kernel that emits pairs) / scan them (after it)
 int launch_lift_cells_begin(const VampLiftDesc* d, void* scratch, hipStream_t s, bool clean = false);
 int launch_lift_cells_end(const VampLiftDesc* d, void* scratch, hipStream_t s);
+int lift_cells_scan_job(const VampLiftDesc* d, void* scratch, ScanJob* job);
 
 }  // namespace vamp

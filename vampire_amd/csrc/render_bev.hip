@@ -1425,7 +1425,8 @@ int vamp_render_forward_merged(const VampRenderDesc* d, const float* mats, const
                                const void* base, float* rgb_out, float* seg_out, float* depth_out,
                                float* bev_rgb, float* bev_seg, float* bev_height, float* voxel_density,
                                float* voxel_output, void* workspace, size_t workspace_bytes,
-                               void* bev_workspace, size_t bev_workspace_bytes, int flags, void* stream) {
+                               void* bev_workspace, size_t bev_workspace_bytes, float* grad_beta_zero, int flags,
+                               void* stream) {
   if (int e = validate(d)) return e;
   VAMP_REQUIRE(mats && us && vs && ds && mids && oxs && oys && ozs && bev_mids, "null pointer");
   VAMP_REQUIRE(density_feature && semantic && rgb && (base || d->C == 0), "null input volume");
@@ -1452,7 +1453,7 @@ int vamp_render_forward_merged(const VampRenderDesc* d, const float* mats, const
   }
   // VAMP_RENDERFWD_RANK: the camera tiles draw the backward's cell ranks; the caller finishes the prepare step with
   // vamp_render_camera_prepare_ex(VAMP_CAMPREP_RANKED) -- on this stream or another
-  CamRankRefs rank{nullptr, nullptr, nullptr, 0};
+  CamRankRefs rank{nullptr, nullptr, nullptr, 0, nullptr};
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (flags & VAMP_RENDERFWD_RANK) {
     VAMP_REQUIRE(term != nullptr, "VAMP_RENDERFWD_RANK needs the render workspace");
@@ -1463,6 +1464,7 @@ int vamp_render_forward_merged(const VampRenderDesc* d, const float* mats, const
       return e;
     }
   }
+  rank.zero_word = grad_beta_zero;
   return launch_render_fwd_merged(d, to_params(d), mats, us, vs, ds, mids, oxs, oys, ozs, bev_mids, beta, density_feature,
                                   semantic, rgb, base, rgb_out, seg_out, depth_out, term, rows, bev_rgb, bev_seg, bev_height,
                                   voxel_density, voxel_output, s0_save, ss_save, rank, s);

@@ -367,6 +367,22 @@ int vamp_render_camera_prepare_ex(const VampRenderDesc* d, const float* mats, co
                             (flags & VAMP_CAMPREP_COUNTERS_CLEAN) != 0);
 }
 
+// lift.hip
+int lift_scan_job(const VampLiftDesc* d, void* workspace, size_t workspace_bytes, ScanJob* job);
+
+int vamp_render_camera_prepare_with_lift(const VampRenderDesc* d, void* workspace, size_t workspace_bytes,
+                                         const VampLiftDesc* lift_desc, void* lift_workspace,
+                                         size_t lift_workspace_bytes, void* stream) {
+  if (int e = validate(d)) return e;
+  const size_t need = vamp_render_workspace_bytes(d);
+  if (!workspace || workspace_bytes < need)
+    return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) need);
+  VAMP_REQUIRE(lift_desc && lift_workspace, "null pointer");
+  ScanJob lift;
+  if (int e = lift_scan_job(lift_desc, lift_workspace, lift_workspace_bytes, &lift)) return e;
+  return launch_cam_prepare_ranked(d, workspace, static_cast<hipStream_t>(stream), &lift);
+}
+
 int vamp_render_camera_backward(const VampRenderDesc* d, const float* geom, const float* mats,
                                 const float* us, const float* vs, const float* ds,
                                 const float* mids, const float* beta, const void* density_feature,

@@ -435,7 +435,7 @@ CamCellRefs cam_cell_refs(const VampRenderDesc* d, void* scratch) {
 
 CamRankRefs cam_rank_refs_cells(const VampRenderDesc* d, void* scratch) {
   const CellWs w = cell_ws(d, scratch);
-  return CamRankRefs{w.cnt, w.rank, w.tile_se, (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1)};
+  return CamRankRefs{w.cnt, w.rank, w.tile_se, (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1), nullptr};
 }
 int launch_cam_cells_zero(const VampRenderDesc* d, void* scratch, hipStream_t s) {
   const CellWs w = cell_ws(d, scratch);
@@ -450,7 +450,7 @@ static int launch_cam_heavy_list(const VampRenderDesc* d, const RenderParams& P,
 // forward that has drawn the ranks itself (mats .. term unused)
 int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                              const float* us, const float* vs, const float* ds, void* scratch,
-                             const int* term, int phase, hipStream_t s, bool counters_clean) {
+                             const int* term, int phase, hipStream_t s, bool counters_clean, const ScanJob* also) {
   const CellWs w = cell_ws(d, scratch);
   const long ncell = cell_count_padded(d->B, d->Z, d->Y, d->X);
   const size_t samples = (size_t) d->B * d->N * (d->D - 1) * d->fH * d->fW;
@@ -459,7 +459,13 @@ int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, con
                "sample / voxel / cell count exceeds 2^31");
   const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
   if (phase == 3) {
-    if (int e = launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, ncell, s)) return e;
+    if (also) {                     // one launch for this list's scan and another list's (the lift's pair cells)
+      ScanJob mine;
+      if (int e = make_scan_job(w.cnt, w.off, w.bsum, w.boff, w.aux, ncell, &mine)) return e;
+      if (int e = launch_cell_scan_pair(mine, *also, s)) return e;
+    } else if (int e = launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, ncell, s)) {
+      return e;
+    }
     return launch_cam_heavy_list(d, P, w, s);
   }
   if (phase != 2) {

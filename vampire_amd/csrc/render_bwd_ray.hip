@@ -249,7 +249,8 @@ size_t cam_bwd_cell_bytes(const VampRenderDesc* d);
 CamCellRefs cam_cell_refs(const VampRenderDesc* d, void* scratch);
 int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                              const float* us, const float* vs, const float* ds, void* scratch,
-                             const int* term, int phase, hipStream_t s, bool counters_clean = false);
+                             const int* term, int phase, hipStream_t s, bool counters_clean = false,
+                             const ScanJob* also = nullptr);
 int launch_cam_bwd_cell(const VampRenderDesc* d, const RenderParams& P, const float* Gcl,
                         float* gdens, float* gsem, float* grgb, void* scratch, int accumulate,
                         hipEvent_t wait_event, int parts, BetaTail btail, hipStream_t s);
@@ -275,9 +276,9 @@ CamRankRefs cam_rank_refs(const VampRenderDesc* d, void* workspace) { return cam
 int launch_cam_counters_zero(const VampRenderDesc* d, void* workspace, hipStream_t s) {
   return launch_cam_cells_zero(d, cell_scratch_of(d, workspace), s);
 }
-int launch_cam_prepare_ranked(const VampRenderDesc* d, void* workspace, hipStream_t s) {
+int launch_cam_prepare_ranked(const VampRenderDesc* d, void* workspace, hipStream_t s, const ScanJob* also) {
   return launch_cam_cells_prepare(d, to_params(d), nullptr, nullptr, nullptr, nullptr, cell_scratch_of(d, workspace), nullptr,
-                                  /*phase=*/3, s);
+                                  /*phase=*/3, s, false, also);
 }
 
 // scratch = workspace region after the packed volume: [Gcl | cell lists | beta partials]

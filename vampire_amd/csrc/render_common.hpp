@@ -278,13 +278,15 @@ struct CamRankRefs {
   int* rank;            // [tiles][S][64]
   int* tile_se;         // [tiles]
   long ncell_b;         // cells per sample of the batch
+  float* zero_word;     // not nullptr: the launch also stores 0.f there (the backward's d loss / d beta accumulator)
 };
 // `workspace`: the render workspace (vamp_render_workspace_bytes).  render_bwd_ray.hip
 CamRankRefs cam_rank_refs(const VampRenderDesc* d, void* workspace);
 // zero the cell counters (a forward that draws ranks on a workspace not known clean) / scan them and build the heavy
 // list behind such a forward (what vamp_render_camera_prepare does behind its own rank pass)
 int launch_cam_counters_zero(const VampRenderDesc* d, void* workspace, hipStream_t s);
-int launch_cam_prepare_ranked(const VampRenderDesc* d, void* workspace, hipStream_t s);
+// (`also`: another cell list scanned by the same launch -- the lift's, vamp_render_camera_prepare_with_lift)
+int launch_cam_prepare_ranked(const VampRenderDesc* d, void* workspace, hipStream_t s, const ScanJob* also = nullptr);
 
 // render_cam_direct.hip: plan + density march + scan + channel gather in one kernel, on the
 // channel-first volumes; term_out (may be NULL) receives the per-ray table

@@ -94,6 +94,9 @@ render_fwd_merged_kernel(MergedArgs<T> args_in_kernarg_segment) {
     asm volatile("" : "+s"(ap));
     const RenderParams P = kernarg_copy<RenderParams>(&ap->P);
     const MergedCam c = kernarg_copy<MergedCam>(&ap->c);
+    // a duty of the first workgroup: the word the backward will accumulate d loss / d beta into starts at zero (a
+    // one-element fill launch of its own costs a training step ~10 us: 5 of kernel, 5 of hand-over behind it)
+    if (bid == 0 && threadIdx.x == 0 && c.rank.zero_word) *c.rank.zero_word = 0.f;
     cam_fwd_direct_tile<T, NCH, true, 4, RANK>(bid, P, c.mats, c.us, c.vs, c.ds, c.mids, ap->beta_raw, ap->dens, ap->sem,
                                                ap->rgb, c.rgb_out, c.seg_out, c.depth_out, c.term_out, c.rows, c.rank);
   } else {

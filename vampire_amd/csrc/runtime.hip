@@ -102,14 +102,14 @@ exclusive_scan_kernel(const int* __restrict__ cnt, int* __restrict__ off, int* _
 // boff[c / kScanTile].  The hand-off goes through agent-scope atomics on both sides (see below).
 // (Two launches before round 3: the second one, a single workgroup, cost a dependent kernel boundary
 // four times per step.)
-__global__ void __launch_bounds__(256)
-cell_scan_kernel(int* __restrict__ cnt, int* __restrict__ off, int* __restrict__ bsum, int* __restrict__ boff,
-                 int* __restrict__ fill, int* __restrict__ total, int* __restrict__ ticket, int ntile) {
+__device__ __forceinline__ void cell_scan_tile(int* __restrict__ cnt, int* __restrict__ off, int* __restrict__ bsum,
+                                               int* __restrict__ boff, int* __restrict__ fill, int* __restrict__ total,
+                                               int* __restrict__ ticket, int ntile, unsigned bid) {
   __shared__ int wsum[4];
   __shared__ int is_last;
   __shared__ int carry;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const long base = (long) blockIdx.x * kScanTile + tid * 8;
+  const long base = (long) bid * kScanTile + tid * 8;
   int4* c4 = reinterpret_cast<int4*>(cnt + base);
   const int4 a = c4[0], b = c4[1];
   // the counters are spent: left at zero they are the fill cursors of the list's user (the lift
@@ -148,7 +148,7 @@ cell_scan_kernel(int* __restrict__ cnt, int* __restrict__ off, int* __restrict__
     // the hand-off needs no release / acquire fence (a release fence here writes back the 16 KB of
     // offsets the workgroup has just dirtied: measured slower than the second launch it was to
     // replace).  The exchange has returned before the ticket is taken.
-    const int old = __hip_atomic_exchange(bsum + blockIdx.x, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int old = __hip_atomic_exchange(bsum + bid, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::"v"(old) : "memory");
     const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = (t == ntile - 1) ? 1 : 0;
@@ -192,6 +192,24 @@ cell_scan_kernel(int* __restrict__ cnt, int* __restrict__ off, int* __restrict__
   }
 }
 
+__global__ void __launch_bounds__(256)
+cell_scan_kernel(int* __restrict__ cnt, int* __restrict__ off, int* __restrict__ bsum, int* __restrict__ boff,
+                 int* __restrict__ fill, int* __restrict__ total, int* __restrict__ ticket, int ntile) {
+  cell_scan_tile(cnt, off, bsum, boff, fill, total, ticket, ntile, blockIdx.x);
+}
+
+// Two independent cell lists scanned by ONE launch (workgroups [0, a.ntile) the first, the rest the second; each has
+// its own ticket word and level 2): the lift's pair cells and the camera backward's sample cells of a training
+// forward are both due between the render forward and the backward, and a launch of a few hundred small workgroups
+// costs what its slowest workgroup costs -- 5 + 10 us as two launches, 10 as one.
+__global__ void __launch_bounds__(256)
+cell_scan_pair_kernel(ScanJob a, ScanJob b) {
+  if (blockIdx.x < (unsigned) a.ntile)
+    cell_scan_tile(a.cnt, a.off, a.bsum, a.boff, a.fill, a.total, a.ticket, a.ntile, blockIdx.x);
+  else
+    cell_scan_tile(b.cnt, b.off, b.bsum, b.boff, b.fill, b.total, b.ticket, b.ntile, blockIdx.x - (unsigned) a.ntile);
+}
+
 int launch_cell_scan(int* cnt, int* off, int* bsum, int* boff, int* aux, long ncell,
                      hipStream_t s) {
   const long ntile = ncell / kScanTile;
@@ -200,6 +218,19 @@ int launch_cell_scan(int* cnt, int* off, int* bsum, int* boff, int* aux, long nc
   VAMP_TIMED(kProfAux, s, (cell_scan_kernel<<<(unsigned) ntile, 256, 0, s>>>(
       cnt, off, bsum, boff, aux, aux + ntile, cnt + ncell, (int) ntile)));
   return check_launch("cell_scan_kernel");
+}
+
+int make_scan_job(int* cnt, int* off, int* bsum, int* boff, int* aux, long ncell, ScanJob* job) {
+  const long ntile = ncell / kScanTile;
+  if (ncell % kScanTile != 0 || ntile > 0x3fffffffL)
+    return fail(VAMP_EINVAL, "%s: cell count must be a multiple of the scan tile", __func__);
+  *job = ScanJob{cnt, off, bsum, boff, aux, aux + ntile, cnt + ncell, (int) ntile};
+  return VAMP_OK;
+}
+
+int launch_cell_scan_pair(const ScanJob& a, const ScanJob& b, hipStream_t s) {
+  VAMP_TIMED(kProfAux, s, (cell_scan_pair_kernel<<<(unsigned) (a.ntile + b.ntile), 256, 0, s>>>(a, b)));
+  return check_launch("cell_scan_pair_kernel");
 }
 
 // grad_beta += sign(beta_raw) * sum(part[0..n)): the per-workgroup partial sums of d loss / d beta_eff

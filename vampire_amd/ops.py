@@ -128,7 +128,13 @@ class HotPath:
                      # training: the camera forward keeps every inside sample's values for the backward's per-ray pass
                      # (+0.5 GB of workspace per sample at cfg-B, touched only where samples are kept); False = that pass
                      # gathers again (the tests' cross-check of the re-sampling path; no environment switch)
-                     "save_rows": True}
+                     "save_rows": True,
+                     # a training lift forward leaves the scan of its pair cells to the render forward's prepare step,
+                     # which scans both operators' cell lists in ONE launch (vamp_render_camera_prepare_with_lift); a lift
+                     # backward, or another lift forward, that finds the scan still pending runs it itself
+                     # (vamp_lift_finish_cells).  False = the scan inside the lift forward's call (no environment switch)
+                     "defer_lift_scan": True}
+        self._lift_scan_pending = None      # (desc, workspace, stream) of a lift forward whose cell scan is still due
 
     # ---------------------------------------------------------------- descs
     def lift_desc(self, B, N, C_, dtype_code, use_depth=True, fhw=None) -> _capi.VampLiftDesc:
@@ -182,6 +188,19 @@ class HotPath:
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device)
         return self._side
+
+    def _finish_lift_scan(self):
+        """Run the cell scan a training lift forward deferred (impl["defer_lift_scan"]), if it is still due."""
+        p, self._lift_scan_pending = self._lift_scan_pending, None
+        if p is None:
+            return
+        d, ws, st = p
+        cur = torch.cuda.current_stream()
+        if cur != st:
+            cur.wait_stream(st)
+        _capi.check(self.lib.vamp_lift_finish_cells(C.byref(d), _ptr(ws), ws.numel(), _stream(cur)),
+                    "vamp_lift_finish_cells")
+        self._dirty.discard("lift")         # scanned: the counters are back at zero
 
     def _cam_clean_flag(self):
         """VAMP_CAMPREP_COUNTERS_CLEAN when the render workspace's cell counters are known to be zero (fresh
@@ -511,6 +530,9 @@ class _LiftFn(torch.autograd.Function):
             # the workspace, so the backward never projects (a backward whose lists another call has overwritten
             # since -- cells_key below -- builds them itself)
             flags |= _capi.VAMP_LIFTFWD_EMIT_PAIRS
+            hp._finish_lift_scan()          # (an earlier forward's deferred scan: its counters must be spent first)
+            if hp.impl["defer_lift_scan"]:
+                flags |= _capi.VAMP_LIFTFWD_DEFER_SCAN
             if "lift" not in hp._dirty:
                 flags |= _capi.VAMP_LIFTFWD_CELLS_CLEAN
             hp._dirty.add("lift")           # (until this call has been issued in full)
@@ -525,7 +547,10 @@ class _LiftFn(torch.autograd.Function):
                                                     _ptr(depth if use_depth else None), _ptr(feat), _ptr(out),
                                                     _ptr(hits), _ptr(ws), ws.numel(), flags, _stream(cur)),
                         "vamp_lift_forward_ex")
-        hp._dirty.discard("lift")           # emit + scan issued: the counters are back at zero
+        if flags & _capi.VAMP_LIFTFWD_DEFER_SCAN:
+            hp._lift_scan_pending = (d, ws, cur)      # (the counters stay in flight until the scan)
+        else:
+            hp._dirty.discard("lift")       # emit + scan issued: the counters are back at zero
         if need_grad:
             ctx.hp, ctx.desc, ctx.use_depth = hp, d, use_depth
             ctx.save_for_backward(depth if use_depth else feat, feat, mats, hits)
@@ -545,6 +570,7 @@ class _LiftFn(torch.autograd.Function):
                   if use_depth else None)
         nbytes = hp.lib.vamp_lift_workspace_bytes(C.byref(d))
         ws = hp._workspace("lift", nbytes)
+        hp._finish_lift_scan()              # (nobody has run the forward's deferred scan: a lift without a render forward)
         valid = 1 if ctx.cells_key == (getattr(hp, "_lift_gen", 0), ws.data_ptr()) else 0
         hp._lift_gen = getattr(hp, "_lift_gen", 0) + 1       # the backward consumes the prepared counters
         if hp.impl["lift_bwd"] == "v1":
@@ -738,9 +764,12 @@ class _RenderFn(torch.autograd.Function):
         cam_base = 0 if ert else _capi.VAMP_CAMFWD_NO_ERT
         streams, events = {"cur": cur, "side": side}, {}
         ctx.cells, ctx.ert, ctx.bev_key = False, ert, None
-        # the backward's d loss / d beta accumulator is zeroed HERE, in front of the forward's kernels: as the first
-        # node of the backward the one-element fill sat alone on the step's critical path (4 us + a launch gap)
-        ctx.gbeta0 = torch.zeros(1, dtype=f32, device=dev) if train else None
+        # the backward's d loss / d beta accumulator is zeroed by the FORWARD: as the first node of the backward the
+        # one-element fill sat alone on the step's critical path (5 us + the same again of hand-over behind a kernel
+        # that short).  The merged launch zeroes the word itself; the other schedules with a fill in front of their kernels
+        gbeta_in_launch = train and any(op == "render" for op, *_ in plan)
+        ctx.gbeta0 = (torch.empty(1, dtype=f32, device=dev) if gbeta_in_launch
+                      else torch.zeros(1, dtype=f32, device=dev)) if train else None
         if side is not None:
             side.wait_stream(cur)
         for op, where, flags, waits, records in plan:
@@ -759,10 +788,19 @@ class _RenderFn(torch.autograd.Function):
                     _ptr(seg_p), _ptr(dep_p), _ptr(ws), ws.numel(), cam_base | flags | keep, _stream(st)),
                     "vamp_render_camera_forward_ex")
             elif op == "prep":
-                ranked = bool(flags & _capi.VAMP_CAMPREP_RANKED)       # (the forward drew the ranks: scan + heavy list only)
-                _capi.check(hp.lib.vamp_render_camera_prepare_ex(
-                    C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(),
-                    flags | (0 if ranked else hp._cam_clean_flag()), _stream(st)), "vamp_render_camera_prepare_ex")
+                ranked = bool(flags & _capi.VAMP_CAMPREP_RANKED)       # (the forward drew the ranks: scan + work lists only)
+                pend = hp._lift_scan_pending
+                if ranked and pend is not None and pend[2] == st:
+                    # a lift forward's pair cells are due too: both scans in one launch
+                    hp._lift_scan_pending = None
+                    _capi.check(hp.lib.vamp_render_camera_prepare_with_lift(
+                        C.byref(d), _ptr(ws), ws.numel(), C.byref(pend[0]), _ptr(pend[1]), pend[1].numel(), _stream(st)),
+                        "vamp_render_camera_prepare_with_lift")
+                    hp._dirty.discard("lift")
+                else:
+                    _capi.check(hp.lib.vamp_render_camera_prepare_ex(
+                        C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(),
+                        flags | (0 if ranked else hp._cam_clean_flag()), _stream(st)), "vamp_render_camera_prepare_ex")
                 hp._dirty.discard("render")
                 ctx.cells = True
             elif op == "render":
@@ -771,7 +809,7 @@ class _RenderFn(torch.autograd.Function):
                     _ptr(hp.oxs), _ptr(hp.oys), _ptr(hp.ozs), hp.ozs_host, _ptr(hp.bev_mids), _ptr(beta),
                     _ptr(dens), _ptr(sem), _ptr(rgb), _ptr(base), _ptr(rgb_p), _ptr(seg_p), _ptr(dep_p),
                     _ptr(bev_rgb), _ptr(bev_seg), _ptr(bev_h), _ptr(vdens), _ptr(vout), _ptr(ws), ws.numel(),
-                    _ptr(ws_bev), ws_bev.numel() if bev_save else 0,
+                    _ptr(ws_bev), ws_bev.numel() if bev_save else 0, _ptr(ctx.gbeta0) if train else None,
                     (_capi.VAMP_RENDERFWD_SAVE_SAMPLES if save else 0) | (_capi.VAMP_RENDERFWD_BEV_SAVE if bev_save else 0)
                     | flags | (_capi.VAMP_RENDERFWD_COUNTERS_CLEAN if (flags & _capi.VAMP_RENDERFWD_RANK) and hp._cam_clean_flag() else 0),
                     _stream(st)), "vamp_render_forward_merged")
