@@ -70,15 +70,23 @@ constexpr int kScanTile = 2048;
 // scan's arrival ticket (the workgroup that takes the last ticket scans the tile totals, so the whole
 // scan is one launch)
 constexpr int kScanPad = 64;
+// A duty the scan's first workgroup can take over from a launch of its own: the order in which a later kernel takes
+// its `n` work items -- those with the largest key first (counting sort by the bit length of key[i] >= 0).  The camera
+// backward's per-ray pass takes its ray tiles deepest first that way (render_bwd_cell.hip).
+struct ScanDuty {
+  const int* key;      // [n], nullptr: no duty
+  int* order;          // [n] out
+  int n;
+};
 int launch_cell_scan(int* cnt, int* off, int* bsum, int* boff, int* aux, long ncell,
-                     hipStream_t s);
+                     hipStream_t s, const ScanDuty* duty = nullptr);
 // the same scan as a job description, and two jobs in one launch (runtime.hip: cell_scan_pair_kernel)
 struct ScanJob {
   int *cnt, *off, *bsum, *boff, *fill, *total, *ticket;
   int ntile;
 };
 int make_scan_job(int* cnt, int* off, int* bsum, int* boff, int* aux, long ncell, ScanJob* job);
-int launch_cell_scan_pair(const ScanJob& a, const ScanJob& b, hipStream_t s);
+int launch_cell_scan_pair(const ScanJob& a, const ScanJob& b, hipStream_t s, const ScanDuty* duty = nullptr);
 // A duty a consumer kernel takes over from a launch of its own: the first workgroup adds up, in a
 // fixed order, the per-workgroup partial sums of d loss / d beta_eff that an EARLIER kernel of the same
 // stream left in `part` (kernel boundary: visible), and adds sign(beta_raw) * sum to grad_beta with one

@@ -23,34 +23,15 @@
 // Autograd of render_utils.py:140-141 (grid_sample backward w.r.t. the volume).
 #include "render_common.hpp"
 #include "cell_list.hpp"
+#include "cam_lists.hpp"
 #include "ray_plan.hpp"
 
 #include <algorithm>
 
 namespace vamp {
 
-#ifndef VAMP_CELL_HEAVY
-#define VAMP_CELL_HEAVY 32
-#endif
-constexpr int kCellHeavy = VAMP_CELL_HEAVY;   // records per cell beyond which the cell is summed once per corner (cam_cell_splat_kernel)
-#ifndef VAMP_SPLAT_CHUNK
-#define VAMP_SPLAT_CHUNK 256
-#endif
-// A heavy cell of n records is summed in ceil(n / kSplatChunk) chunks of n / chunks records (the last one takes the
-// remainder), each a list entry and a workgroup of the splat with a row set of its own: slot (first record of the
-// chunk) / kCellHeavy -- chunks are at least kSplatChunk / 2 >= kCellHeavy records long, so no two share a slot.
-constexpr int kSplatChunk = VAMP_SPLAT_CHUNK;
-static_assert(kSplatChunk / 2 >= kCellHeavy, "chunks must not share slots");
-__host__ __device__ inline int splat_chunks(int n) { return (n + kSplatChunk - 1) / kSplatChunk; }
-#ifndef VAMP_SPLAT_NW
-#define VAMP_SPLAT_NW 2
-#endif
-#ifndef VAMP_GATHER_GRID
-#define VAMP_GATHER_GRID 20480
-#endif
-constexpr int kGatherGrid = VAMP_GATHER_GRID;   // workgroups of the gather at most (a workgroup takes every kGatherGrid-th listed x-run)
 constexpr int kGatherLanes = 8;          // lanes per voxel of the gather
-constexpr int kRunVox = 256 / kGatherLanes;   // voxels (an x-run) per gather workgroup
+static_assert(kRunVox == 256 / kGatherLanes, "an x-run is what a gather workgroup owns");
 
 __device__ __forceinline__ long sample_cell(const RenderParams& P, int key, unsigned b, long ncell_b) {
   return key_to_cell(key, P.Y, P.X, b, ncell_b);
@@ -442,12 +423,10 @@ int launch_cam_cells_zero(const VampRenderDesc* d, void* scratch, hipStream_t s)
   return launch_zero(w.cnt, (size_t) (cell_count_padded(d->B, d->Z, d->Y, d->X) + kScanPad) * sizeof(int), s);
 }
 
-// rank -> scan -> slot.  Depends on (d, mats, us, vs, ds) only.
-static int launch_cam_heavy_list(const VampRenderDesc* d, const RenderParams& P, const CellWs& w, hipStream_t s);
-
-// phase 0: everything; 1: rank + scan (what needs the geometry and the termination table);
-// 2: heavy list (needs the scan only) -- a caller may leave phase 2 to the backward; 3: scan + heavy list behind a
-// forward that has drawn the ranks itself (mats .. term unused)
+// phase 0 / 1: rank + scan (what needs the geometry and the termination table); 3: the scan behind a forward that has
+// drawn the ranks itself (mats .. term unused).  (2, the work lists as a launch of their own, is gone: they are built
+// by the tail workgroups of the per-ray pass's launch, cam_lists.hpp.)  The scan's first workgroup sorts the ray tiles
+// deepest first for the per-ray pass.
 int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                              const float* us, const float* vs, const float* ds, void* scratch,
                              const int* term, int phase, hipStream_t s, bool counters_clean, const ScanJob* also) {
@@ -458,150 +437,48 @@ int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, con
   VAMP_REQUIRE(samples > 0 && samples < 0x7fffffffu && voxels < 0x7fffffffu && ncell < 0x7fffffffL,
                "sample / voxel / cell count exceeds 2^31");
   const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
+  const ScanDuty duty{w.tile_se, w.tile_order, (int) ((long) d->B * d->N * ((d->fH + 7) / 8) * ((d->fW + 7) / 8))};
+  if (phase == 2) return VAMP_OK;
   if (phase == 3) {
     if (also) {                     // one launch for this list's scan and another list's (the lift's pair cells)
       ScanJob mine;
       if (int e = make_scan_job(w.cnt, w.off, w.bsum, w.boff, w.aux, ncell, &mine)) return e;
-      if (int e = launch_cell_scan_pair(mine, *also, s)) return e;
-    } else if (int e = launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, ncell, s)) {
-      return e;
+      return launch_cell_scan_pair(mine, *also, s, &duty);
     }
-    return launch_cam_heavy_list(d, P, w, s);
+    return launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, ncell, s, &duty);
   }
-  if (phase != 2) {
-    if (!counters_clean) {          // (VAMP_CAMPREP_COUNTERS_CLEAN: the previous scan left them at zero)
-      if (int ze = launch_zero(w.cnt, (size_t) (ncell + kScanPad) * sizeof(int), s)) return ze;
-    } else if (int e = debug_expect_range(w.cnt, (size_t) (ncell + kScanPad), 0, 0, s,
-                                          "VAMP_CAMPREP_COUNTERS_CLEAN: the render workspace's cell counters are zero")) {
-      return e;
-    }
-    // (a termination table handed over with *_TERM_VALID holds a number of kept samples per ray)
-    if (int e = debug_expect_range(term, (size_t) d->B * d->N * d->fH * d->fW, 0, d->D - 1, s,
-                                   "VAMP_CAMPREP_TERM_VALID: the workspace holds a termination table")) return e;
-    VAMP_TIMED(kProfCamBwdCount, s, (cam_cells_rank_kernel<<<ray_grid<4>(P), 256, 0, s>>>(
-        P, mats, us, vs, ds, w.cnt, w.rank, ncell_b, term, w.tile_se)));
-    if (int e = check_launch("cam_cells_rank_kernel")) return e;
-    if (int e = launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, ncell, s)) return e;
+  if (!counters_clean) {          // (VAMP_CAMPREP_COUNTERS_CLEAN: the previous scan left them at zero)
+    if (int ze = launch_zero(w.cnt, (size_t) (ncell + kScanPad) * sizeof(int), s)) return ze;
+  } else if (int e = debug_expect_range(w.cnt, (size_t) (ncell + kScanPad), 0, 0, s,
+                                        "VAMP_CAMPREP_COUNTERS_CLEAN: the render workspace's cell counters are zero")) {
+    return e;
   }
-  if (phase == 1) return VAMP_OK;
-  return launch_cam_heavy_list(d, P, w, s);
+  // (a termination table handed over with *_TERM_VALID holds a number of kept samples per ray)
+  if (int e = debug_expect_range(term, (size_t) d->B * d->N * d->fH * d->fW, 0, d->D - 1, s,
+                                 "VAMP_CAMPREP_TERM_VALID: the workspace holds a termination table")) return e;
+  VAMP_TIMED(kProfCamBwdCount, s, (cam_cells_rank_kernel<<<ray_grid<4>(P), 256, 0, s>>>(
+      P, mats, us, vs, ds, w.cnt, w.rank, ncell_b, term, w.tile_se)));
+  if (int e = check_launch("cam_cells_rank_kernel")) return e;
+  return launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, ncell, s, &duty);
 }
 
-// The two work lists of the backward, known as soon as the cells are scanned -- so they belong to the prepare pass:
-//   cells  the cells with more than kCellHeavy records (cam_cell_splat_kernel's items).  A workgroup takes a scan
-//          tile of 2 048 cells, eight per thread, compacts its heavy cells and appends them with ONE atomic.
-//   runs   the gather's x-runs (32 voxels) that hold at least one record.  When the gather adds on top of the BEV
-//          branch's gradient (the default) it visits those only -- with early ray termination most of the volume
-//          lies behind terminated rays (cfg-B: 925 of 22 400 runs), and a workgroup per run that leaves at once
-//          still costs its dispatch.  Thread = run: the records in reach of a run's voxels are four ranges of 33
-//          x-neighbouring cells, i.e. eight start offsets; one append per wave.
-// (Rounds 3 - 5 walked the voxels, a thread each, for run FLAGS: 0.7 M threads and 16 offset loads per thread; an
-// append per run took 125 us when nothing terminates.)
-constexpr int kListCells = kScanTile;        // cells per workgroup of the list kernel's cell part
-__device__ __forceinline__ int cell_start(const int* __restrict__ off, const int* __restrict__ boff, long c) {
-  return off[c] + boff[c / kScanTile];
-}
-__global__ void __launch_bounds__(256)
-cam_heavy_list_kernel(RenderParams P, const int* __restrict__ off, const int* __restrict__ boff,
-                      int2* __restrict__ hcells, int* __restrict__ nhcells, int* __restrict__ runs,
-                      int* __restrict__ nruns, long ncell_b, long total_runs, int runs_x, long ncell,
-                      const int* __restrict__ tile_se, int* __restrict__ tile_order, int ntiles,
-                      unsigned cell_blocks) {
-  // A duty of the first workgroup: the order in which the per-ray pass takes the ray tiles -- deepest
-  // first (counting sort by the bit length of the tile's longest ray).  With early ray termination a few
-  // tiles hold a ray that never saturates and march 85 samples where the others march 8: started last
-  // they were the kernel's tail (23 tiles of 1 056, 42 us each, in a kernel of 56 us).
-  if (blockIdx.x == 0) {
-    __shared__ int cls[34];
-    if (threadIdx.x < 34) cls[threadIdx.x] = 0;
-    __syncthreads();
-    for (int t = threadIdx.x; t < ntiles; t += 256) atomicAdd(cls + (32 - __clz(max(tile_se[t], 0))), 1);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int acc = 0;
-      for (int k = 32; k >= 0; --k) { const int n = cls[k]; cls[k] = acc; acc += n; }
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < ntiles; t += 256) tile_order[atomicAdd(cls + (32 - __clz(max(tile_se[t], 0))), 1)] = t;
-  }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (blockIdx.x < cell_blocks) {
-    // cells c0 .. c0 + 7 of this thread (the last cell with a successor is ncell - 2: cell_count_padded)
-    const long c0 = (long) blockIdx.x * kListCells + 8 * threadIdx.x;
-    int st[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) st[k] = cell_start(off, boff, min(c0 + k, ncell - 1));
-    unsigned hv = 0;
-    int mine = 0;                       // list entries of this thread: the chunks of its heavy cells
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const bool heavy = c0 + k < ncell - 1 && st[k + 1] - st[k] > kCellHeavy;
-      hv |= heavy ? 1u << k : 0u;
-      mine += heavy ? splat_chunks(st[k + 1] - st[k]) : 0;
-    }
-    int incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += v;
-    }
-    __shared__ int wsum[4], base_s;
-    if (lane == 63) wsum[wv] = incl;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const int n = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-      base_s = n ? atomicAdd(nhcells, n) : 0;
-    }
-    __syncthreads();
-    int at = base_s + incl - mine;
-    for (int k = 0; k < wv; ++k) at += wsum[k];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (!(hv & (1u << k))) continue;
-      const int nrec = st[k + 1] - st[k], nchunk = splat_chunks(nrec), len = nrec / nchunk;
-      for (int j = 0; j < nchunk; ++j)
-        hcells[at++] = make_int2(st[k] + j * len, j == nchunk - 1 ? nrec - j * len : len);
-    }
-    return;
-  }
-  const long run = (long) (blockIdx.x - cell_blocks) * 256 + threadIdx.x;
-  const bool run_ok = run < total_runs;
-  const long rc = run_ok ? run : total_runs - 1;
-  const int bx = (int) (rc % runs_x);
-  const long rest = rc / runs_x;
-  const int iy = (int) (rest % P.Y);
-  const long zb = rest / P.Y;
-  const int iz = (int) (zb % P.Z);
-  const long b = zb / P.Z;
-  const int ix0 = bx * kRunVox, span = min(kRunVox, P.X - ix0) + 1;      // cells ix0 .. ix0 + span - 1
-  int tot = 0;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const long c = b * ncell_b + ((long) (iz + (r >> 1)) * (P.Y + 1) + (iy + (r & 1))) * (P.X + 1) + ix0;
-    tot += cell_start(off, boff, c + span) - cell_start(off, boff, c);
-  }
-  const bool act = run_ok && tot > 0;
-  const unsigned long long m = __ballot(act);
-  if (m == 0ull) return;
-  const int lead = __ffsll((long long) m) - 1;
-  int base = 0;
-  if (lane == lead) base = atomicAdd(nruns, __popcll(m));
-  base = __shfl(base, lead, 64);
-  if (act) runs[base + __popcll(m & ((1ull << lane) - 1ull))] = (int) run;
-}
-
-static int launch_cam_heavy_list(const VampRenderDesc* d, const RenderParams& P, const CellWs& w, hipStream_t s) {
+// what the list-building workgroups behind the per-ray pass's tiles need (cam_lists.hpp)
+CamListArgs cam_list_args(const VampRenderDesc* d, void* scratch) {
+  const CellWs w = cell_ws(d, scratch);
   const long ncell = cell_count_padded(d->B, d->Z, d->Y, d->X);
   const long ntile = ncell / kScanTile;
-  const long ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
-  const int runs_x = (d->X + kRunVox - 1) / kRunVox;
-  const long total_runs = (long) runs_x * d->Y * d->Z * d->B;
-  int* nhcells = w.aux + ntile + 1;              // (and the run counter behind it) zeroed by the scan that just ran (runtime.hip)
-  const unsigned cell_blocks = (unsigned) (ncell / kListCells);
-  VAMP_TIMED(kProfAux, s, (cam_heavy_list_kernel<<<cell_blocks + (unsigned) ((total_runs + 255) / 256), 256, 0, s>>>(
-      P, w.off, w.boff, w.hcells, nhcells, w.runs, nhcells + 1, ncell_b, total_runs, runs_x, ncell, w.tile_se, w.tile_order,
-      (int) ((long) d->B * d->N * ((d->fH + 7) / 8) * ((d->fW + 7) / 8)), cell_blocks)));
-  return check_launch("cam_heavy_list_kernel");
+  CamListArgs a;
+  a.off = w.off; a.boff = w.boff; a.hcells = w.hcells;
+  a.nhcells = w.aux + ntile + 1;                  // (and the run counter behind it) zeroed by the scan (runtime.hip)
+  a.runs = w.runs; a.nruns = a.nhcells + 1;
+  a.ncell_b = (long) (d->Z + 1) * (d->Y + 1) * (d->X + 1);
+  a.runs_x = (d->X + kRunVox - 1) / kRunVox;
+  a.total_runs = (long) a.runs_x * d->Y * d->Z * d->B;
+  a.ncell = ncell;
+  a.cell_blocks = (unsigned) (ncell / kListCells);
+  a.nblocks = a.cell_blocks + (unsigned) ((a.total_runs + 255) / 256);
+  a.first_block = 0;
+  return a;
 }
 
 // the heavy cells' per-corner sums, then the per-voxel gather of the records the per-ray pass has written in cell order

@@ -13,6 +13,7 @@
 //  The records are then gathered per voxel: render_bwd_cell.hip.
 #include "render_common.hpp"
 #include "cell_list.hpp"
+#include "cam_lists.hpp"
 #include "pair_gather.hpp"
 
 namespace vamp {
@@ -32,8 +33,14 @@ cam_bwd_ray_kernel(RenderParams P, const float* __restrict__ mats, const float* 
                    const float* __restrict__ g_seg, const float* __restrict__ g_depth,
                    CamCellRefs cells,
                    float* __restrict__ Gcl, float* __restrict__ beta_part,
-                   const float* __restrict__ samples, const int* __restrict__ term, int L) {
+                   const float* __restrict__ samples, const int* __restrict__ term, int L, CamListArgs lists) {
   constexpr int CP = CP4 * 4;
+  // the workgroups behind the ray tiles build the work lists of the two kernels that follow (cam_lists.hpp): they
+  // need the scanned cells only, and start as the tiles' tail frees slots
+  if (blockIdx.x >= lists.first_block) {
+    cam_lists_block(P, lists, blockIdx.x - lists.first_block);
+    return;
+  }
   extern __shared__ float lds[];              // [3][L][256]: s0, delta (sign = no-grad flag), q
   __shared__ float red[4];
   const int tid = threadIdx.x;
@@ -318,6 +325,8 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
   const size_t lds = (size_t) 3 * L * 256 * sizeof(float);
   if (lds > 150 * 1024) return fail(VAMP_EINVAL, "%s: too many depth samples for the LDS staging", __func__);
   const unsigned grid = ray_grid<LPR>(P);
+  CamListArgs lists = cam_list_args(d, cell_scratch);
+  lists.first_block = grid;
 #define VAMP_RAY_T(T, CP4, KT)                                                                    \
   do {                                                                                            \
     auto kr = cam_bwd_ray_kernel<T, LPR, CP4, KT>;                                                \
@@ -325,9 +334,9 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
         hipFuncSetAttribute(reinterpret_cast<const void*>(kr),                                    \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) \
       return fail(VAMP_EHIP, "%s: cannot raise dynamic LDS", __func__);                           \
-    VAMP_TIMED(kProfCamBwd, s, (kr<<<grid, 256, lds, s>>>(P, mats, us, vs, ds, mids, beta,         \
+    VAMP_TIMED(kProfCamBwd, s, (kr<<<grid + lists.nblocks, 256, lds, s>>>(P, mats, us, vs, ds, mids, beta, \
         static_cast<const T*>(dens), static_cast<const T*>(sem), static_cast<const T*>(rgbv),     \
-        g_rgb, g_seg, g_depth, cells, Gcl, beta_part, samples, term, L)));                      \
+        g_rgb, g_seg, g_depth, cells, Gcl, beta_part, samples, term, L, lists)));               \
   } while (0)
 #define VAMP_RAY(CP4, KT)                                                                         \
   do {                                                                                            \
