@@ -770,6 +770,11 @@ class _RenderFn(torch.autograd.Function):
         gbeta_in_launch = train and any(op == "render" for op, *_ in plan)
         ctx.gbeta0 = (torch.empty(1, dtype=f32, device=dev) if gbeta_in_launch
                       else torch.zeros(1, dtype=f32, device=dev)) if train else None
+        # (a fork / join with nothing on the other side still costs a replayed graph a barrier: only plans that use the
+        # side stream touch it)
+        if side is not None and not any(where == "side" for _, where, *_ in plan):
+            side = None
+            streams["side"] = None
         if side is not None:
             side.wait_stream(cur)
         for op, where, flags, waits, records in plan:
