@@ -375,7 +375,7 @@ int vamp_render_camera_prepare(const VampRenderDesc* d, const float* mats, const
 /* flags: VAMP_CAMPREP_TERM_VALID -- sort only the samples the early-termination table in
    `workspace` keeps (the backward must then be given VAMP_CAMBWD_TERM_VALID too) */
 #define VAMP_CAMPREP_TERM_VALID 1
-#define VAMP_CAMPREP_RANKED 8   /* (ABI 6) the ranks have been drawn by vamp_render_forward_merged(VAMP_RENDERFWD_RANK): only the scan and the heavy-voxel list run (mats .. ds may be NULL) */
+#define VAMP_CAMPREP_RANKED 8   /* (ABI 6) the ranks have been drawn by vamp_render_forward_merged(VAMP_RENDERFWD_RANK): only the cell scan runs (mats .. ds may be NULL; the backward's work lists are built inside the per-ray pass's launch) */
 #define VAMP_CAMPREP_COUNTERS_CLEAN 4   /* the caller asserts that the cell counters in `workspace` are zero (a zero-filled buffer, or one a completed prepare pass has run on: its scan zeroes what it reads): no zero fill */
 /* (2: VAMP_CAMPREP_RANK_ONLY of rounds 2-4, the prepare pass in two phases: measured slower twice, removed in round 5) */
 int vamp_render_camera_prepare_ex(const VampRenderDesc* d, const float* mats, const float* us,
@@ -402,7 +402,7 @@ int vamp_render_camera_prepare_with_lift(const VampRenderDesc* d, void* workspac
 #define VAMP_CAMBWD_NO_ERT 64
 /* Parts of the call, for a caller with two streams (none set = all three: ray, heavy, gather):
  *   PART_RAY     the per-ray pass (and the channel-last copy / termination table / cell lists and
- *                heavy list where the VALID flags do not promise them), d loss / d beta
+ *                work lists), d loss / d beta
  *   PART_HEAVY   the kernel that sums the heavy cells (more than 32 records) once per cell into per-corner
  *                partial rows in the workspace; it does not touch the gradient buffers.  (Rounds 1 - 5: a
  *                drain of heavy VOXELS that could run beside the gather; since round 6 the gather reads
@@ -480,10 +480,10 @@ int vamp_render_bev_forward_ex(const VampRenderDesc* d, const float* oxs, const 
 #define VAMP_RENDERFWD_BEV_SAVE 2       /* = VAMP_BEVFWD_SAVE */
 /* training: the camera tiles also do the RANK PASS of the camera backward's cell sort -- every kept inside sample is
    counted into its cell and takes its rank there, behind its channel loads.  The caller finishes the prepare step with
-   vamp_render_camera_prepare_ex(.., VAMP_CAMPREP_RANKED, stream) (scan + heavy-voxel list: two small kernels, on any
+   vamp_render_camera_prepare_ex(.., VAMP_CAMPREP_RANKED, stream) (the cell scan: one small kernel, on any
    stream ordered behind this call); afterwards `workspace` holds what vamp_render_camera_prepare_ex
    (VAMP_CAMPREP_TERM_VALID) leaves, and the backward takes VAMP_CAMBWD_CELLS_VALID.  The three launches on two streams
-   of a training forward (camera kernel, BEV forward, prepare pass beside it) become one launch + two small ones.
+   of a training forward (camera kernel, BEV forward, prepare pass beside it) become one launch + one small one.
    COUNTERS_CLEAN: as VAMP_CAMPREP_COUNTERS_CLEAN (otherwise the counters are zero-filled first). */
 #define VAMP_RENDERFWD_RANK 4
 #define VAMP_RENDERFWD_COUNTERS_CLEAN 8

@@ -57,7 +57,7 @@ int launch_exclusive_scan(const int* cnt, int* off, int* fill, int n, int* total
 // Two-level exclusive scan of `ncell` counters (ncell a multiple of kScanTile) for the cell lists:
 // afterwards the start offset of cell c is off[c] + boff[c / kScanTile]; bsum / boff / aux hold
 // ncell / kScanTile ints (aux four more) and aux[ncell / kScanTile] receives the grand total; the word
-// behind it is zeroed (heavy-list counter of the cell-list users).
+// and the two words behind it are zeroed (list counters of the cell-list users).
 // grad_beta[0] += sign(beta_raw[0]) * sum(part[0..n)), summed in a fixed order by one workgroup
 // zero `bytes` (multiple of 4) at ptr with a kernel (graph-safe, see runtime.hip)
 int launch_zero(void* ptr, size_t bytes, hipStream_t s);

@@ -357,7 +357,7 @@ int vamp_render_camera_prepare_ex(const VampRenderDesc* d, const float* mats, co
   const size_t need = vamp_render_workspace_bytes(d);
   if (!workspace || workspace_bytes < need)
     return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) need);
-  // the ranks are drawn (vamp_render_forward_merged with VAMP_RENDERFWD_RANK): scan + heavy-voxel list only
+  // the ranks are drawn (vamp_render_forward_merged with VAMP_RENDERFWD_RANK): the cell scan only
   if (flags & VAMP_CAMPREP_RANKED) return launch_cam_prepare_ranked(d, workspace, static_cast<hipStream_t>(stream));
   VAMP_REQUIRE(mats && us && vs && ds, "null pointer");
   const RenderParams P = to_params(d);

@@ -313,7 +313,7 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
   if (!(parts & kCamPartRay))
     return launch_cam_bwd_cell(d, P, Gcl, gdens, gsem, grgb, cell_scratch, accumulate, wait_event, parts, btail, s);
   // the sample -> slot table depends on the geometry only; the caller may have prepared it
-  // (cells_valid 1), or its rank + scan half (2: the slots and the heavy list follow here)
+  // (cells_valid 1), or its rank + scan half (2, a caller of rounds 2 - 5: nothing left to do here -- the work lists are built by this launch's tail)
   if (cells_valid != 1)
     if (int e = launch_cam_cells_prepare(d, P, mats, us, vs, ds, cell_scratch, term, cells_valid == 2 ? 2 : 0, s)) return e;
   const CamCellRefs cells = cam_cell_refs(d, cell_scratch);

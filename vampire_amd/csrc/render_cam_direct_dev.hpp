@@ -257,7 +257,7 @@ __device__ __forceinline__ RayId decode_tile(const RenderParams& P, unsigned bid
 // run-aggregated atomic per run of lanes in a cell, issued in front of the sample's 84 channel loads and collected
 // behind them.  The prepare step's first kernel (cam_cells_rank_kernel: 16 - 18 us of chain evaluations and atomics on
 // the same samples) disappears, and with it the reason to keep camera forward, BEV forward and prepare pass as three
-// launches on two streams: training forwards are one launch + the scan + the heavy list.
+// launches on two streams: training forwards are one launch + the scan.
 template <typename T, int NCH, bool ERT, int NW, bool RANK = false>
 __device__ __forceinline__ void
 cam_fwd_direct_tile(const unsigned bid, const RenderParams& P, const float* __restrict__ mats, const float* __restrict__ us,

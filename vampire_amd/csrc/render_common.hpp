@@ -390,7 +390,7 @@ struct CamCellRefs {
 };
 
 // parts of the camera backward a caller may issue separately (VAMP_CAMBWD_PART_*): the per-ray pass
-// (with the cell lists if they are not prepared), the per-voxel gather, the heavy-voxel kernel
+// (with the cell lists if they are not prepared), the heavy cells' per-corner sums, the per-voxel gather
 constexpr int kCamPartRay = 1, kCamPartGather = 2, kCamPartHeavy = 4, kCamPartAll = 7;
 
 }  // namespace vamp

@@ -651,11 +651,11 @@ def render_forward_plan(train, two, prep_ok, direct, ert, merged=False):
     if merged and not train:
         return [("render", "cur", 0, (), ())]
     if merged and train and prep_ok:
-        # training: the camera tiles also draw the backward's cell ranks, and the call finishes the prepare step (scan +
-        # heavy-voxel list) behind the launch -- one launch + two small ones on ONE stream where rounds 3 - 5 ran the
-        # camera kernel, the BEV forward and the prepare pass as three launches on two (replayed step 0.403 -> ... ms)
-        # (the scan + heavy list on the side stream, with the backward's camera chain behind them there and its BEV
-        # chain here, so that the BEV chain would start beside them: 0.411 against 0.395 ms -- they stay on this stream)
+        # training: the camera tiles also draw the backward's cell ranks, and the call finishes the prepare step (the cell
+        # scan, together with the lift's deferred one) behind the launch -- one launch + one small one on ONE stream where
+        # rounds 3 - 5 ran the camera kernel, the BEV forward and the prepare pass as three launches on two
+        # (the scan on the side stream, with the backward's camera chain behind it there and its BEV chain here, so that
+        # the BEV chain would start beside it: 0.411 against 0.395 ms -- it stays on this stream)
         return [("render", "cur", F.VAMP_RENDERFWD_RANK, (), ()),
                 ("prep", "cur", F.VAMP_CAMPREP_RANKED, (), ())]
     if train and two and prep_ok and direct:
