@@ -381,11 +381,13 @@ int vamp_render_camera_prepare(const VampRenderDesc* d, const float* mats, const
 int vamp_render_camera_prepare_ex(const VampRenderDesc* d, const float* mats, const float* us,
                                   const float* vs, const float* ds, void* workspace,
                                   size_t workspace_bytes, int flags, void* stream);
-/* (ABI 6) vamp_render_camera_prepare_ex(.., VAMP_CAMPREP_RANKED, ..) whose scan launch ALSO scans the pair cells
- * of a lift forward that ran with VAMP_LIFTFWD_DEFER_SCAN on `lift_workspace` (same stream, or ordered before this
- * call): one launch of two independent scans instead of two launches -- it stands for vamp_lift_finish_cells. */
-int vamp_render_camera_prepare_with_lift(const VampRenderDesc* d, void* workspace, size_t workspace_bytes,
-                                         const VampLiftDesc* lift_desc, void* lift_workspace,
+/* (ABI 6) vamp_render_camera_prepare_ex whose scan launch ALSO scans the pair cells of a lift forward that ran with
+ * VAMP_LIFTFWD_DEFER_SCAN on `lift_workspace` (on this stream, or on one this call is ordered behind): one launch of
+ * two independent scans instead of two launches -- it stands for vamp_lift_finish_cells.  Whoever consumes the lift's
+ * cells (vamp_lift_backward_ex) must be ordered behind this call. */
+int vamp_render_camera_prepare_with_lift(const VampRenderDesc* d, const float* mats, const float* us,
+                                         const float* vs, const float* ds, void* workspace, size_t workspace_bytes,
+                                         int flags, const VampLiftDesc* lift_desc, void* lift_workspace,
                                          size_t lift_workspace_bytes, void* stream);
 #define VAMP_CAMBWD_ACCUMULATE 1
 #define VAMP_CAMBWD_PACKED_VALID 2

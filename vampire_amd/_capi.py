@@ -98,7 +98,7 @@ SIGNATURES = {
     "vamp_lift_backward_ex": (C.c_int, [_LD] + [_P] * 10 + [_P, C.c_size_t, C.c_int, _P]),
     "vamp_lift_prepare": (C.c_int, [_LD] + [_P] * 5 + [_P, C.c_size_t, _P]),
     "vamp_lift_finish_cells": (C.c_int, [_LD, _P, C.c_size_t, _P]),
-    "vamp_render_camera_prepare_with_lift": (C.c_int, [_RD, _P, C.c_size_t, _LD, _P, C.c_size_t, _P]),
+    "vamp_render_camera_prepare_with_lift": (C.c_int, [_RD] + [_P] * 4 + [_P, C.c_size_t, C.c_int, _LD, _P, C.c_size_t, _P]),
     "vamp_lift_forward_dense": (C.c_int, [_LD] + [_P] * 7 + [_P]),
     "vamp_lift_backward_dense": (C.c_int, [_LD] + [_P] * 7 + [_P]),
     "vamp_lift_indices": (C.c_int, [_LD] + [_P] * 8 + [_P]),

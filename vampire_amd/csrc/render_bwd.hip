@@ -25,7 +25,8 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
                       int parts, hipStream_t s);
 int launch_cam_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                        const float* us, const float* vs, const float* ds, void* scratch,
-                       const int* term, int phase, hipStream_t s, bool counters_clean = false);
+                       const int* term, int phase, hipStream_t s, bool counters_clean = false,
+                       const ScanJob* also = nullptr);
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
   // wave reduce then 4-wave LDS reduce; result valid in thread 0
@@ -350,37 +351,40 @@ int vamp_render_camera_prepare(const VampRenderDesc* d, const float* mats, const
   return vamp_render_camera_prepare_ex(d, mats, us, vs, ds, workspace, workspace_bytes, 0, stream);
 }
 
-int vamp_render_camera_prepare_ex(const VampRenderDesc* d, const float* mats, const float* us,
-                                  const float* vs, const float* ds, void* workspace,
-                                  size_t workspace_bytes, int flags, void* stream) {
+static int camera_prepare(const VampRenderDesc* d, const float* mats, const float* us, const float* vs,
+                          const float* ds, void* workspace, size_t workspace_bytes, int flags, const ScanJob* also,
+                          void* stream) {
   if (int e = validate(d)) return e;
   const size_t need = vamp_render_workspace_bytes(d);
   if (!workspace || workspace_bytes < need)
     return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) need);
   // the ranks are drawn (vamp_render_forward_merged with VAMP_RENDERFWD_RANK): the cell scan only
-  if (flags & VAMP_CAMPREP_RANKED) return launch_cam_prepare_ranked(d, workspace, static_cast<hipStream_t>(stream));
+  if (flags & VAMP_CAMPREP_RANKED) return launch_cam_prepare_ranked(d, workspace, static_cast<hipStream_t>(stream), also);
   VAMP_REQUIRE(mats && us && vs && ds, "null pointer");
   const RenderParams P = to_params(d);
   return launch_cam_prepare(d, P, mats, us, vs, ds, static_cast<char*>(workspace) + packed_bytes(d),
                             (flags & VAMP_CAMPREP_TERM_VALID) ? cam_term_ptr(d, workspace) : nullptr,
                             /*phase=*/0, static_cast<hipStream_t>(stream),
-                            (flags & VAMP_CAMPREP_COUNTERS_CLEAN) != 0);
+                            (flags & VAMP_CAMPREP_COUNTERS_CLEAN) != 0, also);
+}
+
+int vamp_render_camera_prepare_ex(const VampRenderDesc* d, const float* mats, const float* us,
+                                  const float* vs, const float* ds, void* workspace,
+                                  size_t workspace_bytes, int flags, void* stream) {
+  return camera_prepare(d, mats, us, vs, ds, workspace, workspace_bytes, flags, nullptr, stream);
 }
 
 // lift.hip
 int lift_scan_job(const VampLiftDesc* d, void* workspace, size_t workspace_bytes, ScanJob* job);
 
-int vamp_render_camera_prepare_with_lift(const VampRenderDesc* d, void* workspace, size_t workspace_bytes,
-                                         const VampLiftDesc* lift_desc, void* lift_workspace,
+int vamp_render_camera_prepare_with_lift(const VampRenderDesc* d, const float* mats, const float* us,
+                                         const float* vs, const float* ds, void* workspace, size_t workspace_bytes,
+                                         int flags, const VampLiftDesc* lift_desc, void* lift_workspace,
                                          size_t lift_workspace_bytes, void* stream) {
-  if (int e = validate(d)) return e;
-  const size_t need = vamp_render_workspace_bytes(d);
-  if (!workspace || workspace_bytes < need)
-    return fail(VAMP_ENOSPC, "%s: workspace %ld < %ld bytes", __func__, (long) workspace_bytes, (long) need);
   VAMP_REQUIRE(lift_desc && lift_workspace, "null pointer");
   ScanJob lift;
   if (int e = lift_scan_job(lift_desc, lift_workspace, lift_workspace_bytes, &lift)) return e;
-  return launch_cam_prepare_ranked(d, workspace, static_cast<hipStream_t>(stream), &lift);
+  return camera_prepare(d, mats, us, vs, ds, workspace, workspace_bytes, flags, &lift, stream);
 }
 
 int vamp_render_camera_backward(const VampRenderDesc* d, const float* geom, const float* mats,

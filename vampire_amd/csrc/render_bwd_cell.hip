@@ -459,6 +459,11 @@ int launch_cam_cells_prepare(const VampRenderDesc* d, const RenderParams& P, con
   VAMP_TIMED(kProfCamBwdCount, s, (cam_cells_rank_kernel<<<ray_grid<4>(P), 256, 0, s>>>(
       P, mats, us, vs, ds, w.cnt, w.rank, ncell_b, term, w.tile_se)));
   if (int e = check_launch("cam_cells_rank_kernel")) return e;
+  if (also) {
+    ScanJob mine;
+    if (int e = make_scan_job(w.cnt, w.off, w.bsum, w.boff, w.aux, ncell, &mine)) return e;
+    return launch_cell_scan_pair(mine, *also, s, &duty);
+  }
   return launch_cell_scan(w.cnt, w.off, w.bsum, w.boff, w.aux, ncell, s, &duty);
 }
 

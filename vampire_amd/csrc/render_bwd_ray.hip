@@ -291,9 +291,9 @@ int launch_cam_prepare_ranked(const VampRenderDesc* d, void* workspace, hipStrea
 // scratch = workspace region after the packed volume: [Gcl | cell lists | beta partials]
 int launch_cam_prepare(const VampRenderDesc* d, const RenderParams& P, const float* mats,
                        const float* us, const float* vs, const float* ds, void* scratch,
-                       const int* term, int phase, hipStream_t s, bool counters_clean) {
+                       const int* term, int phase, hipStream_t s, bool counters_clean, const ScanJob* also) {
   return launch_cam_cells_prepare(d, P, mats, us, vs, ds, static_cast<char*>(scratch) + gcl_bytes(d), term, phase, s,
-                                  counters_clean);
+                                  counters_clean, also);
 }
 
 int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const float* mats,

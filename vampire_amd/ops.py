@@ -766,10 +766,9 @@ class _RenderFn(torch.autograd.Function):
         ctx.cells, ctx.ert, ctx.bev_key = False, ert, None
         # the backward's d loss / d beta accumulator is zeroed by the FORWARD: as the first node of the backward the
         # one-element fill sat alone on the step's critical path (5 us + the same again of hand-over behind a kernel
-        # that short).  The merged launch zeroes the word itself; the other schedules with a fill in front of their kernels
+        # that short).  The merged launch zeroes the word itself; the other schedules with a fill on their side stream
         gbeta_in_launch = train and any(op == "render" for op, *_ in plan)
-        ctx.gbeta0 = (torch.empty(1, dtype=f32, device=dev) if gbeta_in_launch
-                      else torch.zeros(1, dtype=f32, device=dev)) if train else None
+        ctx.gbeta0 = torch.empty(1, dtype=f32, device=dev) if gbeta_in_launch else None
         # (a fork / join with nothing on the other side still costs a replayed graph a barrier: only plans that use the
         # side stream touch it)
         if side is not None and not any(where == "side" for _, where, *_ in plan):
@@ -777,6 +776,13 @@ class _RenderFn(torch.autograd.Function):
             streams["side"] = None
         if side is not None:
             side.wait_stream(cur)
+        if train and not gbeta_in_launch:
+            if side is not None:
+                with torch.cuda.stream(side):
+                    ctx.gbeta0 = torch.zeros(1, dtype=f32, device=dev)
+                ctx.gbeta0.record_stream(cur)
+            else:
+                ctx.gbeta0 = torch.zeros(1, dtype=f32, device=dev)
         for op, where, flags, waits, records in plan:
             st = streams[where]
             for w in waits:
@@ -795,17 +801,21 @@ class _RenderFn(torch.autograd.Function):
             elif op == "prep":
                 ranked = bool(flags & _capi.VAMP_CAMPREP_RANKED)       # (the forward drew the ranks: scan + work lists only)
                 pend = hp._lift_scan_pending
-                if ranked and pend is not None and pend[2] == st:
-                    # a lift forward's pair cells are due too: both scans in one launch
+                pflags = flags | (0 if ranked else hp._cam_clean_flag())
+                if pend is not None and pend[2] == cur:
+                    # a lift forward's pair cells are due too: both scans in one launch.  (The lift ran on `cur`; this
+                    # op's stream is `cur` or the side stream, which has waited for `cur` above and which `cur` waits
+                    # for below: the lift backward is ordered behind the scan either way.)
                     hp._lift_scan_pending = None
                     _capi.check(hp.lib.vamp_render_camera_prepare_with_lift(
-                        C.byref(d), _ptr(ws), ws.numel(), C.byref(pend[0]), _ptr(pend[1]), pend[1].numel(), _stream(st)),
+                        C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(), pflags,
+                        C.byref(pend[0]), _ptr(pend[1]), pend[1].numel(), _stream(st)),
                         "vamp_render_camera_prepare_with_lift")
                     hp._dirty.discard("lift")
                 else:
                     _capi.check(hp.lib.vamp_render_camera_prepare_ex(
                         C.byref(d), _ptr(mats), _ptr(hp.us), _ptr(hp.vs), _ptr(hp.ds), _ptr(ws), ws.numel(),
-                        flags | (0 if ranked else hp._cam_clean_flag()), _stream(st)), "vamp_render_camera_prepare_ex")
+                        pflags, _stream(st)), "vamp_render_camera_prepare_ex")
                 hp._dirty.discard("render")
                 ctx.cells = True
             elif op == "render":
