@@ -680,16 +680,18 @@ def render_forward_plan(train, two, prep_ok, direct, ert, merged=False):
         steps.append(("term", "cur", 0, (), ("table",)))
         camf |= F.VAMP_CAMFWD_TERM_VALID
     prep = train and two and prep_ok and not direct
+    # without early termination the march is the long kernel of the step, and a BEV forward beside it costs it more
+    # than it hides (207 us beside, 150 alone).  The BEV forward therefore OPENS the side stream: it runs beside the
+    # channel-last copy in front of the march (a kernel of 1.5 TB/s: latency, not bytes), with the prepare pass behind
+    # it -- replayed step 0.788 against 0.808 ms with the BEV forward behind the march (rounds 4 - 6)
+    bev_first = prep and not ert
+    if bev_first or not prep:
+        steps.append(("bev", "side" if two else "cur", 0, (), ()))
     if prep:
         steps.append(("prep", "side", F.VAMP_CAMPREP_TERM_VALID if ert else 0, ("table",) if ert else (), ()))
-    # without early termination the march is the long kernel of the step, and a BEV forward beside it costs it
-    # more than it hides (207 us beside, 150 alone): the BEV forward then FOLLOWS the march
-    bev_after = prep and not ert
-    if not bev_after:
-        steps.append(("bev", "side" if two else "cur", 0, (), ()))
+    if prep and not bev_first:
+        steps.append(("bev", "side", 0, (), ()))
     steps.append(("cam", "cur", camf, (), ()))
-    if bev_after:
-        steps.append(("bev", "cur", 0, (), ()))
     return steps
 
 
