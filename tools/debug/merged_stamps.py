@@ -2,7 +2,8 @@
 """Debug aid (GPU box): wall-clock start / end of every workgroup of the merged render forward (camera tiles, then BEV
 column blocks) -- the timeline that shows the BEV blocks running in the camera tiles' tail.
 Build the diagnostic library first:  tools/ablate.sh render_fwd_merged.hip mstamps=-DVAMP_MERGED_STAMPS
-Run:  VAMPIRE_HIP_LIB=vampire_amd/_lib/abl_mstamps.so python tools/debug/merged_stamps.py [cfg] [batch] [out.txt]"""
+Run:  VAMPIRE_HIP_LIB=vampire_amd/_lib/abl_mstamps.so python tools/debug/merged_stamps.py [cfg] [batch] [out.txt] [train]
+(`train`: the training launch -- ranks drawn, sample rows and BEV planes kept -- instead of the no-grad one)"""
 import ctypes as C, os, sys
 import numpy as np
 import torch
@@ -17,10 +18,18 @@ dev = torch.device("cuda:0")
 model = LiftRenderStep(cfg, dev)
 batch = SyntheticBatch(cfg, B, dev, seed=0)
 hp = model.hp
-with torch.no_grad():
+train = len(sys.argv) > 4 and sys.argv[4] == "train"
+if train:
+    from vampire_amd.step import train_step
     for _ in range(5):
-        hp.render(*batch.vols, model.beta, render_mats=batch.render_mats)
+        model.zero_grad(set_to_none=True)
+        train_step(model, batch)
     torch.cuda.synchronize()
+else:
+    with torch.no_grad():
+        for _ in range(5):
+            hp.render(*batch.vols, model.beta, render_mats=batch.render_mats)
+        torch.cuda.synchronize()
 lib = _capi.load()
 tiles = B * cfg.num_cams * ((cfg.fH + 7) // 8) * ((cfg.fW + 7) // 8)
 ncam = (tiles + 7) // 8 * 8
@@ -39,7 +48,7 @@ cam = np.arange(n) < ncam
 lines = []
 def P(x):
     print(x); lines.append(x)
-P(f"merged render forward, cfg-{name} x{B}: {ncam} camera workgroups + {nbev} BEV workgroups; span {e[live].max():.1f} us")
+P(f"merged render forward ({'training' if train else 'no-grad'}), cfg-{name} x{B}: {ncam} camera workgroups + {nbev} BEV workgroups; span {e[live].max():.1f} us")
 for nm, m in (("camera tiles", cam & live), ("BEV blocks", ~cam & live & ((e - s) > 0.5))):
     P(f"{nm:13s} n={int(m.sum()):5d}  start p0/p50/p90/max {s[m].min():5.1f} {np.median(s[m]):5.1f} {np.percentile(s[m], 90):5.1f} {s[m].max():5.1f}   "
       f"end p50/p90/p99/max {np.median(e[m]):5.1f} {np.percentile(e[m], 90):5.1f} {np.percentile(e[m], 99):5.1f} {e[m].max():5.1f}   "

@@ -116,7 +116,10 @@ lift_bwd_fill_kernel(LiftParams P, int cw, int ch, const float* __restrict__ gou
     }
   }
 
-  constexpr int NB = 8;                              // cameras per batch: their atomics are in flight together
+#ifndef VAMP_FILL_NB
+#define VAMP_FILL_NB 4        // (8: 122 registers, fill 43 us; 4: 74 registers, 40.5 us; 3 / 2: the same)
+#endif
+  constexpr int NB = VAMP_FILL_NB;                   // cameras per batch: their atomics are in flight together
   for (int n0 = n_lo; n0 < n_hi; n0 += NB) {
     int base[NB], start[NB];
     long cellk[NB];
@@ -143,7 +146,11 @@ lift_bwd_fill_kernel(LiftParams P, int cw, int ch, const float* __restrict__ gou
       }
       cellk[k] = cell;
       const LaneRun r = lane_run(act, cell, lane);
+#ifdef VAMP_FILL_NOATOMIC          // (measurement build: wrong slots)
+      if (r.head) base[k] = 0;
+#else
       if (r.head) base[k] = atomicAdd(cnt + cell, r.len);
+#endif
       if (act) { actm |= 1u << k; start[k] = r.start; }
     }
 #pragma unroll
@@ -164,7 +171,11 @@ lift_bwd_fill_kernel(LiftParams P, int cw, int ch, const float* __restrict__ gou
       for (int i = lane; i < 64 * RS; i += 64) {
         const int r = i / RS, q = i - r * RS;
         const int sl = myslot[r];
+#ifdef VAMP_FILL_NOSTORE           // (measurement build: no records)
+        if (sl == -12345) recs[(long) sl * RS + q] = my[i];
+#else
         if (sl >= 0) recs[(long) sl * RS + q] = my[i];
+#endif
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
