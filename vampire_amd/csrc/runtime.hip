@@ -195,8 +195,9 @@ __device__ __forceinline__ void cell_scan_tile(int* __restrict__ cnt, int* __res
 // ScanDuty (common.hpp): with early ray termination a few ray tiles hold a ray that never saturates and march 85
 // samples where the others march 8: started last they were the per-ray pass's tail (23 tiles of 1 056, 42 us each,
 // in a kernel of 56 us).
+// The duty has a workgroup of its own, behind the scan's (in front of workgroup 0's tile it made that workgroup the last to
+// publish its total: the scan's second level, and with it the launch, waited for the sort).
 __device__ __forceinline__ void scan_duty(const ScanDuty& d) {
-  if (blockIdx.x != 0 || !d.key) return;                 // uniform per workgroup
   __shared__ int cls[34];
   if (threadIdx.x < 34) cls[threadIdx.x] = 0;
   __syncthreads();
@@ -214,7 +215,7 @@ __device__ __forceinline__ void scan_duty(const ScanDuty& d) {
 __global__ void __launch_bounds__(256)
 cell_scan_kernel(int* __restrict__ cnt, int* __restrict__ off, int* __restrict__ bsum, int* __restrict__ boff,
                  int* __restrict__ fill, int* __restrict__ total, int* __restrict__ ticket, int ntile, ScanDuty duty) {
-  scan_duty(duty);
+  if (blockIdx.x == (unsigned) ntile) { scan_duty(duty); return; }
   cell_scan_tile(cnt, off, bsum, boff, fill, total, ticket, ntile, blockIdx.x);
 }
 
@@ -224,7 +225,7 @@ cell_scan_kernel(int* __restrict__ cnt, int* __restrict__ off, int* __restrict__
 // costs what its slowest workgroup costs -- 5 + 10 us as two launches, 10 as one.
 __global__ void __launch_bounds__(256)
 cell_scan_pair_kernel(ScanJob a, ScanJob b, ScanDuty duty) {
-  scan_duty(duty);
+  if (blockIdx.x == (unsigned) (a.ntile + b.ntile)) { scan_duty(duty); return; }
   if (blockIdx.x < (unsigned) a.ntile)
     cell_scan_tile(a.cnt, a.off, a.bsum, a.boff, a.fill, a.total, a.ticket, a.ntile, blockIdx.x);
   else
@@ -236,7 +237,7 @@ int launch_cell_scan(int* cnt, int* off, int* bsum, int* boff, int* aux, long nc
   const long ntile = ncell / kScanTile;
   if (ncell % kScanTile != 0 || ntile > 0x7fffffffL)
     return fail(VAMP_EINVAL, "%s: cell count must be a multiple of the scan tile", __func__);
-  VAMP_TIMED(kProfAux, s, (cell_scan_kernel<<<(unsigned) ntile, 256, 0, s>>>(
+  VAMP_TIMED(kProfAux, s, (cell_scan_kernel<<<(unsigned) ntile + (duty && duty->key ? 1u : 0u), 256, 0, s>>>(
       cnt, off, bsum, boff, aux, aux + ntile, cnt + ncell, (int) ntile, duty ? *duty : ScanDuty{nullptr, nullptr, 0})));
   return check_launch("cell_scan_kernel");
 }
@@ -250,7 +251,7 @@ int make_scan_job(int* cnt, int* off, int* bsum, int* boff, int* aux, long ncell
 }
 
 int launch_cell_scan_pair(const ScanJob& a, const ScanJob& b, hipStream_t s, const ScanDuty* duty) {
-  VAMP_TIMED(kProfAux, s, (cell_scan_pair_kernel<<<(unsigned) (a.ntile + b.ntile), 256, 0, s>>>(
+  VAMP_TIMED(kProfAux, s, (cell_scan_pair_kernel<<<(unsigned) (a.ntile + b.ntile) + (duty && duty->key ? 1u : 0u), 256, 0, s>>>(
       a, b, duty ? *duty : ScanDuty{nullptr, nullptr, 0})));
   return check_launch("cell_scan_pair_kernel");
 }
