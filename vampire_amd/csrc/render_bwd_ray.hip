@@ -327,6 +327,10 @@ int launch_cam_bwd_v2(const VampRenderDesc* d, const RenderParams& P, const floa
   const unsigned grid = ray_grid<LPR>(P);
   CamListArgs lists = cam_list_args(d, cell_scratch);
   lists.first_block = grid;
+  // (the list counters are zeroed by the cell scan and spent by this launch: VAMP_CAMBWD_CELLS_VALID holds for ONE
+  // backward per prepare pass, as the header says)
+  if (int e = debug_expect_range(lists.nhcells, 2, 0, 0, s,
+                                 "VAMP_CAMBWD_CELLS_VALID: no camera backward has run on this workspace since the prepare pass")) return e;
 #define VAMP_RAY_T(T, CP4, KT)                                                                    \
   do {                                                                                            \
     auto kr = cam_bwd_ray_kernel<T, LPR, CP4, KT>;                                                \
